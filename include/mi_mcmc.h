@@ -1,0 +1,131 @@
+/*
+ * mi_mcmc.h -- C ABI of the MI355X many-chain HMC / MALA / NUTS engine (libmi_mcmc.so).
+ *
+ * This is the drop-in boundary for the one hot path of kthohr/mcmc that BASELINE.json names.
+ * Each entry point replaces, for C independent chains at once, one reference function:
+ *
+ *   mi_mcmc_hmc_*   <->  mcmc::hmc  -> internal::hmc_impl   /root/reference/include/mcmc/hmc.hpp:42-48,65-72,78-85
+ *                                                            /root/reference/src/hmc.cpp:30-227
+ *   mi_mcmc_mala_*  <->  mcmc::mala -> internal::mala_impl  /root/reference/include/mcmc/mala.hpp:43-49,66-73,79-86
+ *                                                            /root/reference/src/mala.cpp:30-208, include/mcmc/mala.ipp:30-70
+ *   mi_mcmc_nuts_*  <->  mcmc::nuts -> internal::nuts_impl  /root/reference/include/mcmc/nuts.hpp:42-48,65-72,78-85
+ *                                                            /root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241
+ *   mi_settings     <->  algo_settings_t + hmc_/mala_/nuts_settings_t
+ *                                                            /root/reference/include/misc/mcmc_structs.hpp:66-101,123-134,151-184
+ *
+ * The reference's std::function callback cannot run on the GPU, so the target density is
+ * selected by a tagged descriptor (mi_target).  Plain C types only: no torch, no Eigen.
+ * All structs start with their own size so the ABI can grow.
+ *
+ * Layouts (fp64 everywhere, fp_t = double: /root/reference/include/misc/mcmc_options.hpp:80-81,99):
+ *   state  theta  [d][C]          structure-of-arrays, chain index contiguous
+ *   draws         [n_keep][d][C]  one kept draw of every chain per slab
+ *   n_accept      [C] uint64      post-burn-in accepts per chain (src/hmc.cpp:196-199)
+ * Chain c of this call is global chain (chain0 + c): the Philox counter uses the global id, so
+ * results do not depend on how chains are sharded over GPUs.
+ */
+#ifndef MI_MCMC_H
+#define MI_MCMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_MCMC_VERSION 0x000100
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_BAD_ARG = 1,       /* NULL where forbidden, unsupported kind / dimension, struct_size mismatch */
+    MI_ERR_HIP = 2,           /* a HIP runtime call failed; see mi_mcmc_last_error() */
+    MI_ERR_UNSUPPORTED = 3,   /* valid request the device path does not implement (never falls back to CPU) */
+    MI_ERR_OOM = 4,
+    MI_ERR_NO_DEVICE = 5
+} mi_status;
+
+typedef enum mi_target_kind {
+    MI_TARGET_GAUSS_ISO = 1,    /* log K = -1/2 |theta|^2 */
+    MI_TARGET_GAUSS_DIAG = 2,   /* log K = -1/2 sum_i prec_i theta_i^2;       prec: d values */
+    MI_TARGET_GAUSS_DENSE = 3,  /* log K = -1/2 theta^T P theta;              prec: d*d, symmetric, row-major */
+    MI_TARGET_LOGISTIC = 4      /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta */
+} mi_target_kind;
+
+typedef enum mi_mem { MI_MEM_HOST = 0, MI_MEM_DEVICE = 1 } mi_mem;
+
+typedef struct mi_target {
+    uint32_t      struct_size;
+    int32_t       kind;        /* mi_target_kind */
+    uint64_t      d;           /* n_vals of one chain (BMO_MATOPS_SIZE(initial_vals), src/hmc.cpp:40) */
+    const double* prec;        /* see mi_target_kind */
+    const double* X;           /* LOGISTIC: n_rows x d row-major */
+    const double* y;           /* LOGISTIC: n_rows */
+    uint64_t      n_rows;
+    int32_t       mem;         /* mi_mem: where prec / X / y live */
+    int32_t       reserved;
+} mi_target;
+
+/* POD mirror of algo_settings_t restricted to what hmc / mala / nuts read.
+ * Field names and defaults follow mcmc_structs.hpp; mi_settings_default() fills them. */
+typedef struct mi_settings {
+    uint32_t struct_size;
+    int32_t  vals_bound;          /* algo_settings_t::vals_bound (mcmc_structs.hpp:159) */
+    uint64_t rng_seed_value;      /* algo_settings_t::rng_seed_value (:155) -> Philox key */
+    const double* lower_bounds;   /* d values or NULL (host memory) */
+    const double* upper_bounds;
+    uint64_t n_burnin_draws;      /* default 1000 (:68) */
+    uint64_t n_keep_draws;        /* default 1000 (:69) */
+    uint64_t n_leap_steps;        /* hmc_settings_t::n_leap_steps, default 1 (:73) */
+    double   step_size;           /* default 1.0 (:74, :94, :130); nuts: epsilon_bar_0 */
+    const double* precond_mat;    /* d*d (host) or NULL = identity (src/hmc.cpp:57) */
+    uint64_t n_adapt_draws;       /* nuts, default 1000 (:89) */
+    double   target_accept_rate;  /* nuts, default 0.55 (:90) */
+    uint64_t max_tree_depth;      /* nuts, default 10 (:92) */
+    double   gamma_val;           /* 0.05 (:95) */
+    double   t0_val;              /* 10 (:96) */
+    double   kappa_val;           /* 0.75 (:97) */
+} mi_settings;
+
+/* One shard of chains. All pointers live in `mem` (host or device). */
+typedef struct mi_chains {
+    uint32_t  struct_size;
+    int32_t   mem;            /* mi_mem of theta / draws / n_accept / step_size / n_leapfrogs */
+    uint64_t  n_chains;       /* C: chains in this call */
+    uint64_t  chain0;         /* global index of local chain 0 */
+    double*   theta;          /* in: initial_vals [d][C]; out: last state of every chain */
+    double*   draws;          /* out [n_keep][d][C], may be NULL (draws discarded) */
+    uint64_t* n_accept;       /* out [C], may be NULL */
+    double*   step_size;      /* nuts out [C]: adapted step size per chain, may be NULL */
+    uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain, may be NULL */
+} mi_chains;
+
+void        mi_settings_default(mi_settings* s);
+const char* mi_mcmc_last_error(void);
+int         mi_mcmc_version(void);
+int         mi_mcmc_device_count(void);
+
+/* Blocking calls. `stream` is a hipStream_t (NULL = default stream); with mem == MI_MEM_DEVICE the
+ * kernels are enqueued on it and the call returns after enqueueing (asynchronous), so inputs can be
+ * resident in HBM and timed with events.  With MI_MEM_HOST buffers are staged and the call blocks. */
+int mi_mcmc_hmc_run (const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
+int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
+int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
+
+/* Layout converters between the engine's [n_keep][d][C] slabs and the reference's per-chain
+ * draws_out (n_keep x d, column-major as Eigen stores it: element (i,j) at i + j*n_keep;
+ * src/hmc.cpp:138,197). Host memory. */
+int mi_mcmc_draws_to_chain_major(const double* draws_kdc, uint64_t n_keep, uint64_t d, uint64_t n_chains,
+                                 double* out_c_colmajor /* [C][d][n_keep] */);
+
+/* Diagnostics used by the GPU tests (host pointers, blocking). */
+int mi_probe_mfma_f64(const double* A16x4, const double* B4x16, const double* C16x16, double* D16x16);
+int mi_probe_math(int fn, const double* x, uint64_t n, double* out, double* out2);
+int mi_probe_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out);
+int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out);
+int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_MCMC_H */

@@ -1,0 +1,211 @@
+"""mcmc_amd -- host-side mirror of the C ABI in include/mi_mcmc.h (libmi_mcmc.so).
+
+The product is the gfx950 shared library; this module only binds it (ctypes) so that tests,
+bench.py and Python callers can reach `mi_mcmc_{hmc,mala,nuts}_run` with numpy / torch buffers.
+Names follow the reference: settings fields are those of mcmc::algo_settings_t
+(/root/reference/include/misc/mcmc_structs.hpp:66-101,123-134,151-184), the entry points those of
+mcmc::hmc / mcmc::mala / mcmc::nuts (/root/reference/include/mcmc/{hmc,mala,nuts}.hpp).
+
+There is no CPU fallback: if the library is missing, or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_mcmc.so")
+
+MI_OK, MI_ERR_BAD_ARG, MI_ERR_HIP, MI_ERR_UNSUPPORTED, MI_ERR_OOM, MI_ERR_NO_DEVICE = range(6)
+TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC = 1, 2, 3, 4
+MEM_HOST, MEM_DEVICE = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class mi_target(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("d", C.c_uint64),
+                ("prec", C.c_void_p), ("X", C.c_void_p), ("y", C.c_void_p),
+                ("n_rows", C.c_uint64), ("mem", C.c_int32), ("reserved", C.c_int32)]
+
+
+class mi_settings(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("vals_bound", C.c_int32),
+                ("rng_seed_value", C.c_uint64), ("lower_bounds", C.c_void_p),
+                ("upper_bounds", C.c_void_p), ("n_burnin_draws", C.c_uint64),
+                ("n_keep_draws", C.c_uint64), ("n_leap_steps", C.c_uint64),
+                ("step_size", C.c_double), ("precond_mat", C.c_void_p),
+                ("n_adapt_draws", C.c_uint64), ("target_accept_rate", C.c_double),
+                ("max_tree_depth", C.c_uint64), ("gamma_val", C.c_double),
+                ("t0_val", C.c_double), ("kappa_val", C.c_double)]
+
+
+class mi_chains(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("mem", C.c_int32), ("n_chains", C.c_uint64),
+                ("chain0", C.c_uint64), ("theta", C.c_void_p), ("draws", C.c_void_p),
+                ("n_accept", C.c_void_p), ("step_size", C.c_void_p), ("n_leapfrogs", C.c_void_p)]
+
+
+class MiMcmcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mi_mcmc status {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+EXPORTS = [
+    "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_draws_to_chain_major",
+    "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak",
+]
+
+
+def lib():
+    """Load libmi_mcmc.so (built in-tree by __graft_entry__.build() / mcmc_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiMcmcError(-1, f"{LIB_PATH} not built: run `make -C mcmc_amd/csrc` (no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.mi_mcmc_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != MI_OK:
+        raise MiMcmcError(rc, lib().mi_mcmc_last_error().decode())
+
+
+def _ptr(a):
+    """Address of a numpy array (host), a torch tensor (host or device), an int, or None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data
+
+
+def default_settings(**kw):
+    """algo_settings_t with the reference defaults, then keyword overrides."""
+    s = mi_settings()
+    lib().mi_settings_default(C.byref(s))
+    keep = []
+    for k, v in kw.items():
+        if k in ("lower_bounds", "upper_bounds", "precond_mat"):
+            if v is not None:
+                v = np.ascontiguousarray(v, dtype=np.float64)
+                keep.append(v)
+                v = v.ctypes.data
+        setattr(s, k, v)
+    s._keep = keep
+    return s
+
+
+def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST):
+    t = mi_target()
+    t.struct_size = C.sizeof(mi_target)
+    t.kind, t.d, t.mem = kind, int(d), mem
+    keep = []
+    if mem == MEM_HOST:
+        prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64)
+        X = None if X is None else np.ascontiguousarray(X, dtype=np.float64)
+        y = None if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    keep += [prec, X, y]
+    t.prec, t.X, t.y = _ptr(prec), _ptr(X), _ptr(y)
+    t.n_rows = 0 if X is None else int(X.shape[0])
+    t._keep = keep
+    return t
+
+
+def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=None, n_leapfrogs=None,
+                mem=MEM_HOST):
+    c = mi_chains()
+    c.struct_size = C.sizeof(mi_chains)
+    c.mem, c.n_chains, c.chain0 = mem, int(n_chains), int(chain0)
+    c.theta, c.draws, c.n_accept = _ptr(theta), _ptr(draws), _ptr(n_accept)
+    c.step_size, c.n_leapfrogs = _ptr(step_size), _ptr(n_leapfrogs)
+    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs]
+    return c
+
+
+_RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run"}
+
+
+def run(algo, target, settings, chains, stream=None):
+    """Raw call: mi_mcmc_<algo>_run(target, settings, chains, stream)."""
+    fn = getattr(lib(), _RUN[algo])
+    _check(fn(C.byref(target), C.byref(settings), C.byref(chains), C.c_void_p(stream or 0)))
+
+
+def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True):
+    """Host-buffer convenience: init is [C, d] (row per chain, like C calls of mcmc::<algo> with
+    initial_vals = init[c]).  Returns draws [n_keep, d, C] and a dict of per-chain outputs."""
+    init = np.ascontiguousarray(init, dtype=np.float64)
+    n_chains, d = init.shape
+    theta = np.ascontiguousarray(init.T)            # [d][C]
+    n_keep = int(settings.n_keep_draws)
+    draws = np.zeros((n_keep, d, n_chains)) if want_draws else None
+    n_accept = np.zeros(n_chains, dtype=np.uint64)
+    n_leap = np.zeros(n_chains, dtype=np.uint64)
+    eps = np.zeros(n_chains)
+    t = make_target(kind, d, prec=prec, X=X, y=y)
+    c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept,
+                    step_size=eps, n_leapfrogs=n_leap)
+    run(algo, t, settings, c)
+    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta)
+
+
+# mcmc::hmc / mcmc::mala / mcmc::nuts, many chains at once
+def hmc(kind, init, settings, **kw):
+    return sample("hmc", kind, init, settings, **kw)
+
+
+def mala(kind, init, settings, **kw):
+    return sample("mala", kind, init, settings, **kw)
+
+
+def nuts(kind, init, settings, **kw):
+    return sample("nuts", kind, init, settings, **kw)
+
+
+# ---------------------------------------------------------------- diagnostics (GPU tests)
+def probe_mfma(A, B, Cin):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    Cin = np.ascontiguousarray(Cin, dtype=np.float64)
+    D = np.zeros((16, 16))
+    _check(lib().mi_probe_mfma_f64(C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data),
+                                   C.c_void_p(Cin.ctypes.data), C.c_void_p(D.ctypes.data)))
+    return D
+
+
+def probe_math(fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    o1, o2 = np.empty_like(x), np.empty_like(x)
+    _check(lib().mi_probe_math(fn, C.c_void_p(x.ctypes.data), C.c_uint64(x.size),
+                               C.c_void_p(o1.ctypes.data), C.c_void_p(o2.ctypes.data)))
+    return o1, o2
+
+
+def probe_normals(seed, chain, draw, stream, d):
+    out = np.zeros(d)
+    _check(lib().mi_probe_normals(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
+                                  C.c_uint32(stream), C.c_uint64(d), C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def probe_uniform(seed, chain, draw, slot):
+    out = np.zeros(1)
+    _check(lib().mi_probe_uniform(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
+                                  C.c_uint32(slot), C.c_void_p(out.ctypes.data)))
+    return float(out[0])
+
+
+def probe_fp64_peak(use_mfma, iters=20000):
+    out = C.c_double(0.0)
+    _check(lib().mi_probe_fp64_peak(int(use_mfma), int(iters), C.byref(out)))
+    return out.value

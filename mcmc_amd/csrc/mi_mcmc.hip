@@ -1,0 +1,406 @@
+// mi_mcmc.hip -- C ABI (include/mi_mcmc.h) of the MI355X many-chain HMC / MALA / NUTS engine.
+// Host side of the boundary: validates the POD mirrors of algo_settings_t, stages targets and
+// chain state in HBM, launches the gfx950 kernels.  No CPU fallback: anything the device path
+// does not implement returns MI_ERR_UNSUPPORTED.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_mcmc.h"
+#include "det_math.hpp"
+#include "hmc_dense.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                        \
+    } while (0)
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
+{
+    if (!t || !s || !c) return fail(MI_ERR_BAD_ARG, "null target / settings / chains");
+    if (t->struct_size != sizeof(mi_target) || s->struct_size != sizeof(mi_settings) ||
+        c->struct_size != sizeof(mi_chains))
+        return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
+    if (t->d == 0 || c->n_chains == 0) return fail(MI_ERR_BAD_ARG, "d and n_chains must be positive");
+    if (!c->theta) return fail(MI_ERR_BAD_ARG, "chains.theta is required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    return MI_OK;
+}
+
+// Dense d x d precision on the device for the Gaussian kinds (ISO / DIAG expand to a diagonal
+// matrix: an fma chain over exact zeros reproduces prec_i * theta_i bit for bit).
+int dense_precision_on_device(const mi_target* t, DevBuf& owned, const double** P_dev, hipStream_t st)
+{
+    const size_t d = t->d;
+    if (t->kind == MI_TARGET_GAUSS_DENSE) {
+        if (!t->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
+        if (t->mem == MI_MEM_DEVICE) { *P_dev = t->prec; return MI_OK; }
+        HIP_TRY(owned.alloc(d * d * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(owned.p, t->prec, d * d * sizeof(double), hipMemcpyHostToDevice, st));
+        *P_dev = owned.as<double>();
+        return MI_OK;
+    }
+    std::vector<double> diag(d, 1.0);
+    if (t->kind == MI_TARGET_GAUSS_DIAG) {
+        if (!t->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DIAG needs prec (d)");
+        if (t->mem == MI_MEM_DEVICE)
+            HIP_TRY(hipMemcpy(diag.data(), t->prec, d * sizeof(double), hipMemcpyDeviceToHost));
+        else
+            std::memcpy(diag.data(), t->prec, d * sizeof(double));
+    } else if (t->kind != MI_TARGET_GAUSS_ISO) {
+        return fail(MI_ERR_UNSUPPORTED, "target kind %d has no dense-precision form", t->kind);
+    }
+    std::vector<double> P(d * d, 0.0);
+    for (size_t i = 0; i < d; ++i) P[i * d + i] = diag[i];
+    HIP_TRY(owned.alloc(d * d * sizeof(double)));
+    HIP_TRY(hipMemcpy(owned.p, P.data(), d * d * sizeof(double), hipMemcpyHostToDevice));
+    *P_dev = owned.as<double>();
+    return MI_OK;
+}
+
+// host <-> device staging of one mi_chains shard
+struct StagedChains {
+    DevBuf theta, draws, n_accept, step, n_leap;
+    mi_chains dev;   // device-pointer view
+};
+
+int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st)
+{
+    sc.dev = *c;
+    if (c->mem == MI_MEM_DEVICE) return MI_OK;
+    const size_t C = c->n_chains;
+    HIP_TRY(sc.theta.alloc(d * C * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(sc.theta.p, c->theta, d * C * sizeof(double), hipMemcpyHostToDevice, st));
+    sc.dev.theta = sc.theta.as<double>();
+    if (c->draws) { HIP_TRY(sc.draws.alloc(n_keep * d * C * sizeof(double))); sc.dev.draws = sc.draws.as<double>(); }
+    if (c->n_accept) { HIP_TRY(sc.n_accept.alloc(C * sizeof(uint64_t))); sc.dev.n_accept = sc.n_accept.as<uint64_t>(); }
+    if (c->step_size) { HIP_TRY(sc.step.alloc(C * sizeof(double))); sc.dev.step_size = sc.step.as<double>(); }
+    if (c->n_leapfrogs) { HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>(); }
+    sc.dev.mem = MI_MEM_DEVICE;
+    return MI_OK;
+}
+
+int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st)
+{
+    if (c->mem == MI_MEM_DEVICE) return MI_OK;
+    const size_t C = c->n_chains;
+    HIP_TRY(hipMemcpyAsync(c->theta, sc.dev.theta, d * C * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (c->draws) HIP_TRY(hipMemcpyAsync(c->draws, sc.dev.draws, n_keep * d * C * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (c->n_accept) HIP_TRY(hipMemcpyAsync(c->n_accept, sc.dev.n_accept, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (c->step_size) HIP_TRY(hipMemcpyAsync(c->step_size, sc.dev.step_size, C * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (c->n_leapfrogs) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs, sc.dev.n_leapfrogs, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+template <int NT>
+int launch_hmc_mfma(const mi::HmcParams& prm, hipStream_t st)
+{
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
+    auto kern = mi::hmc_gauss_mfma_kernel<NT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 63) / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void mi_settings_default(mi_settings* s)
+{
+    if (!s) return;
+    std::memset(s, 0, sizeof(*s));
+    s->struct_size = sizeof(mi_settings);
+    s->rng_seed_value = 0;
+    s->n_burnin_draws = 1000;
+    s->n_keep_draws = 1000;
+    s->n_leap_steps = 1;
+    s->step_size = 1.0;
+    s->n_adapt_draws = 1000;
+    s->target_accept_rate = 0.55;
+    s->max_tree_depth = 10;
+    s->gamma_val = 0.05;
+    s->t0_val = 10.0;
+    s->kappa_val = 0.75;
+}
+
+const char* mi_mcmc_last_error(void) { return g_last_error.c_str(); }
+int mi_mcmc_version(void) { return MI_MCMC_VERSION; }
+int mi_mcmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound is not implemented on the device path yet");
+    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat is not implemented on the device path yet");
+    const uint64_t d = target->d;
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
+        return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
+    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+
+    mi::HmcParams prm{};
+    prm.P = P_dev;
+    prm.d = (uint32_t)d;
+    prm.C = chains->n_chains;
+    prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta;
+    // stream-ordered workspace: P * theta of the last accepted state, [d][C]
+    void* wsave = nullptr;
+    HIP_TRY(hipMallocAsync(&wsave, d * chains->n_chains * sizeof(double), st));
+    prm.wsave = static_cast<double*>(wsave);
+    prm.draws = sc.dev.draws;
+    prm.n_accept = sc.dev.n_accept;
+    prm.n_leap = sc.dev.n_leapfrogs;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws;
+    prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.n_leap_steps = (uint32_t)settings->n_leap_steps;
+    prm.eps = settings->step_size;
+
+    const int nt = (int)((d + 15) / 16);
+    if (nt <= 1) rc = launch_hmc_mfma<1>(prm, st);
+    else if (nt == 2) rc = launch_hmc_mfma<2>(prm, st);
+    else if (nt <= 4) rc = launch_hmc_mfma<4>(prm, st);
+    else rc = launch_hmc_mfma<8>(prm, st);
+    (void)hipFreeAsync(wsave, st);
+    if (rc) return rc;
+
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    // buffers we own (staged target / host-mode chains) must outlive the kernel
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_mcmc_mala_run(const mi_target*, const mi_settings*, mi_chains*, void*)
+{
+    return fail(MI_ERR_UNSUPPORTED, "mala: device path not built yet");
+}
+
+int mi_mcmc_nuts_run(const mi_target*, const mi_settings*, mi_chains*, void*)
+{
+    return fail(MI_ERR_UNSUPPORTED, "nuts: device path not built yet");
+}
+
+int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
+{
+    if (!kdc || !out) return fail(MI_ERR_BAD_ARG, "null buffer");
+    for (uint64_t c = 0; c < C; ++c)
+        for (uint64_t j = 0; j < d; ++j)
+            for (uint64_t i = 0; i < n_keep; ++i)
+                out[(c * d + j) * n_keep + i] = kdc[(i * d + j) * C + c];
+    return MI_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ diagnostics
+namespace {
+
+__global__ void probe_mfma_kernel(const double* A, const double* B, const double* Cin, double* D)
+{
+    const int l = threadIdx.x;
+    const double a = A[(l & 15) * 4 + (l >> 4)];       // A[i][k], 16x4 row-major
+    const double b = B[(l >> 4) * 16 + (l & 15)];      // B[k][j], 4x16 row-major
+    mi::double4_t c;
+    for (int r = 0; r < 4; ++r) c[r] = Cin[((l >> 4) + 4 * r) * 16 + (l & 15)];
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
+}
+
+__global__ void probe_math_kernel(int fn, const double* x, uint64_t n, double* out, double* out2)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0, c = 0.0;
+    switch (fn) {
+    case 0: s = mi::det_exp(x[i]); break;
+    case 1: s = mi::det_log(x[i]); break;
+    case 2: mi::det_sincos2pi(x[i], s, c); break;
+    case 3: s = mi::softplus(x[i]); break;
+    case 4: s = mi::sigmoid(x[i]); break;
+    default: s = __builtin_nan("");
+    }
+    out[i] = s;
+    out2[i] = c;
+}
+
+__global__ void probe_normals_kernel(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out)
+{
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nslots = 4 * ((d + 7) / 8);
+    if (slot >= nslots) return;
+    const uint64_t b = slot / 4, j = slot % 4;
+    const uint64_t i0 = 8 * b + j, i1 = i0 + 4;
+    double z0, z1;
+    mi::rng_normal_pair(seed, chain, draw, (uint32_t)slot, stream, z0, z1);
+    if (i0 < d) out[i0] = z0;
+    if (i1 < d) out[i1] = z1;
+}
+
+__global__ void probe_uniform_kernel(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out)
+{
+    out[0] = mi::rng_uniform(seed, chain, draw, slot);
+}
+
+// fp64 throughput ceilings: 8 independent accumulators per wave, no memory traffic.
+__global__ __launch_bounds__(256) void peak_mfma_kernel(int iters, double* sink)
+{
+    mi::double4_t acc[8];
+    for (int t = 0; t < 8; ++t) acc[t] = mi::double4_t{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+    double s = 0.0;
+    for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+__global__ __launch_bounds__(256) void peak_fma_kernel(int iters, double* sink)
+{
+    double acc[16];
+    for (int t = 0; t < 16; ++t) acc[t] = threadIdx.x * 1e-3 + t;
+    const double a = 1.0000001, b = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = __builtin_fma(acc[t], a, b);
+    }
+    double s = 0.0;
+    for (int t = 0; t < 16; ++t) s += acc[t];
+    if (s == 12345.678) sink[0] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_probe_mfma_f64(const double* A, const double* B, const double* Cin, double* D)
+{
+    if (!A || !B || !Cin || !D) return fail(MI_ERR_BAD_ARG, "null buffer");
+    DevBuf a, b, c, dd;
+    HIP_TRY(a.alloc(64 * 8)); HIP_TRY(b.alloc(64 * 8)); HIP_TRY(c.alloc(256 * 8)); HIP_TRY(dd.alloc(256 * 8));
+    HIP_TRY(hipMemcpy(a.p, A, 64 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b.p, B, 64 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c.p, Cin, 256 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, 0, a.as<double>(), b.as<double>(), c.as<double>(), dd.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(D, dd.p, 256 * 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_probe_math(int fn, const double* x, uint64_t n, double* out, double* out2)
+{
+    if (!x || !out || !out2) return fail(MI_ERR_BAD_ARG, "null buffer");
+    DevBuf dx, d1, d2;
+    HIP_TRY(dx.alloc(n * 8)); HIP_TRY(d1.alloc(n * 8)); HIP_TRY(d2.alloc(n * 8));
+    HIP_TRY(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, dx.as<double>(), n, d1.as<double>(), d2.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d1.p, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out2, d2.p, n * 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_probe_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out)
+{
+    if (!out || d == 0) return fail(MI_ERR_BAD_ARG, "bad args");
+    DevBuf o;
+    HIP_TRY(o.alloc(d * 8));
+    const uint64_t nslots = 4 * ((d + 7) / 8);
+    hipLaunchKernelGGL(probe_normals_kernel, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, 0, seed, chain, draw, stream, d, o.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, o.p, d * 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out)
+{
+    if (!out) return fail(MI_ERR_BAD_ARG, "null buffer");
+    DevBuf o;
+    HIP_TRY(o.alloc(8));
+    hipLaunchKernelGGL(probe_uniform_kernel, dim3(1), dim3(1), 0, 0, seed, chain, draw, slot, o.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, o.p, 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out)
+{
+    if (!tflops_out || iters <= 0) return fail(MI_ERR_BAD_ARG, "bad args");
+    DevBuf sink;
+    HIP_TRY(sink.alloc(8));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int grid = 256 * 8;   // 8 workgroups (32 waves) per CU
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(hipEventRecord(e0, 0));
+        if (use_mfma) hipLaunchKernelGGL(peak_mfma_kernel, dim3(grid), dim3(256), 0, 0, iters, sink.as<double>());
+        else hipLaunchKernelGGL(peak_fma_kernel, dim3(grid), dim3(256), 0, 0, iters, sink.as<double>());
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double waves = (double)grid * 4;
+    const double flop = use_mfma ? waves * iters * 8.0 * (16.0 * 16 * 4 * 2) : waves * iters * 16.0 * 64 * 2;
+    *tflops_out = flop / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+/*
+ * oracle/mcmc_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C11) of the hot path of kthohr/mcmc (MCMCLib 2.1.0):
+ *   mcmc::internal::hmc_impl   /root/reference/src/hmc.cpp:30-227
+ *   mcmc::internal::mala_impl  /root/reference/src/mala.cpp:30-208
+ *       + mala_prop_adjustment /root/reference/include/mcmc/mala.ipp:30-70
+ *       + stats_mcmc::dmvnorm  /root/reference/include/stats/dmvnorm.hpp:28-54
+ *   mcmc::internal::nuts_impl  /root/reference/src/nuts.cpp:30-332
+ *       + nuts_find_initial_step_size / nuts_build_tree
+ *                              /root/reference/include/mcmc/nuts.ipp:30-241
+ *   box-constraint helpers     /root/reference/include/misc/{determine_bounds_type,
+ *                              transform_vals,log_jacobian,inv_jacobian_adjust}.hpp
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or known-answer
+ * fixtures for this path, and it cannot be built in this image: its linear
+ * algebra and RNG live in Eigen and in the un-vendored kthohr/BaseMatrixOps
+ * submodule (include/BaseMatrixOps/ is empty; .gitmodules:1-3, pinned commit
+ * unknown), neither of which is installed.  This restatement therefore pins the
+ * reference's control flow, formulas, call order and RNG consumption order by
+ * line-by-line reading only; the reduction orders and the random-number
+ * generator are stated here (see orc_math.h, orc_dot) because the originals are
+ * not recoverable.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything in this directory.
+ */
+#ifndef MCMC_ORACLE_H
+#define MCMC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* user callback contract of the reference (hmc.hpp:42-48): returns the log
+ * kernel; fills grad_out (length d) when it is not NULL. */
+typedef double (*orc_kernel_fn)(const double* vals, double* grad_out, void* data);
+
+/* built-in targets (ours; the reference has none).  data points to orc_target. */
+enum { ORC_TARGET_GAUSS_ISO = 1, ORC_TARGET_GAUSS_DIAG = 2, ORC_TARGET_GAUSS_DENSE = 3,
+       ORC_TARGET_LOGISTIC = 4 };
+
+typedef struct orc_target {
+    int           kind;
+    size_t        d;
+    const double* prec;      /* DENSE: d*d row-major precision; DIAG: d precisions; ISO: NULL */
+    const double* X;         /* LOGISTIC: n_rows*d row-major design matrix */
+    const double* y;         /* LOGISTIC: n_rows labels in {0,1} */
+    size_t        n_rows;
+    int           reduce_width;  /* W of orc_dot used inside the target (see below) */
+    uint64_t      n_grad_calls;  /* instrumentation */
+    uint64_t      n_value_calls;
+} orc_target;
+
+double orc_target_kernel(const double* vals, double* grad_out, void* data);
+
+/* POD mirror of algo_settings_t (mcmc_structs.hpp:151-184) restricted to the
+ * fields hmc/mala/nuts read. */
+typedef struct orc_settings {
+    uint64_t rng_seed_value;
+    int      vals_bound;
+    const double* lower_bounds;   /* d, may be NULL if !vals_bound */
+    const double* upper_bounds;
+    size_t   n_burnin_draws;
+    size_t   n_keep_draws;
+    size_t   n_leap_steps;        /* hmc */
+    double   step_size;           /* hmc, mala; nuts: epsilon_bar_0 */
+    const double* precond_mat;    /* d*d column- or row-major (symmetric), NULL -> identity */
+    /* nuts (mcmc_structs.hpp:82-101) */
+    size_t   n_adapt_draws;
+    double   target_accept_rate;
+    size_t   max_tree_depth;
+    double   gamma_val, t0_val, kappa_val;
+    /* oracle-only knobs */
+    int      reduce_width;        /* W: number of strided partial sums in dot products (1,4,64,...) */
+    int      hoist_factorizations;/* mala: 0 = factorise eps^2 M inside every dmvnorm call as the
+                                     reference does (mala.ipp:63-64); 1 = once (same bits) */
+    uint64_t chain_id;            /* Philox counter word: global chain index */
+} orc_settings;
+
+typedef struct orc_stats {
+    size_t   n_accept_draws;      /* post-burn-in accepts (hmc.cpp:198) */
+    uint64_t n_leapfrogs;         /* executed leapfrog steps */
+    double   final_step_size;     /* nuts */
+    /* optional per-draw traces (n_burnin+n_keep entries) if non-NULL */
+    uint8_t* accept_trace;
+    uint32_t* depth_trace;        /* nuts: tree_depth reached */
+    uint32_t* leap_trace;         /* nuts: leapfrogs executed in the draw */
+    double*  eps_trace;           /* nuts: step size used by the draw */
+} orc_stats;
+
+/* draws_out: n_keep x d, element (i,j) at draws_out[i*d + j] (row per draw). */
+int orc_hmc (const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st);
+int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st);
+int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st);
+
+/* many independent chains of a built-in target, OpenMP over chains (the CPU
+ * baseline of BASELINE.md section 3).  init: n_chains x d (row per chain).
+ * draws_out: [n_keep][d][n_chains] (the engine's device layout) or NULL.
+ * algo: 0 hmc, 1 mala, 2 nuts.  Chain c uses chain_id = chain0 + c. */
+int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t n_chains,
+                 uint64_t chain0, const double* init, double* draws_out,
+                 uint64_t* n_accept_out, uint64_t* n_leap_out, double* eps_out, int n_threads);
+
+/* exported pieces for unit tests */
+double orc_dot(const double* x, const double* y, size_t d, int W);
+void   orc_gemv(const double* A /*row-major d x d*/, const double* x, size_t d, double* y);
+int    orc_inv(const double* A, size_t d, double* Ainv);
+int    orc_chol_lower(const double* A, size_t d, double* L);
+double orc_dmvnorm_log(const double* x, const double* mu, const double* Sigma, size_t d, int W);
+void   orc_math_eval(int fn, const double* x, size_t n, double* out, double* out2);
+void   orc_philox_eval(const uint32_t* ctr, const uint32_t* key, uint32_t* out);
+void   orc_normal_vec(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, size_t d, double* out);
+double orc_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot);
+void   orc_transform(const double* vals, const int* btype, const double* lb, const double* ub, size_t d, double* out);
+void   orc_inv_transform(const double* vals, const int* btype, const double* lb, const double* ub, size_t d, double* out);
+double orc_log_jacobian(const double* vals, const int* btype, const double* lb, const double* ub, size_t d);
+void   orc_determine_bounds_type(int vals_bound, size_t d, const double* lb, const double* ub, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,156 @@
+"""GPU: HIP path vs the CPU oracle through the C ABI -- bit-exact (fp64, identical Philox streams)."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _fma(a, b, c):
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def test_native_library_is_loaded_and_sees_a_gpu():
+    assert mcmc_amd.lib().mi_mcmc_device_count() >= 1
+
+
+def test_mfma_f64_accumulates_k_in_order_as_an_fma_chain():
+    """The oracle's mat-vec order (sequential fma chain, k ascending) is what the matrix core does."""
+    rng = np.random.default_rng(0)
+    for _ in range(4):
+        A = rng.standard_normal((16, 4)) * 10.0 ** rng.integers(-3, 4, (16, 4))
+        B = rng.standard_normal((4, 16)) * 10.0 ** rng.integers(-3, 4, (4, 16))
+        C0 = rng.standard_normal((16, 16))
+        D = mcmc_amd.probe_mfma(A, B, C0)
+        ref = np.empty((16, 16))
+        for i in range(16):
+            for j in range(16):
+                acc = C0[i, j]
+                for k in range(4):
+                    acc = _fma(A[i, k], B[k, j], acc)
+                ref[i, j] = acc
+        assert np.array_equal(D, ref)
+
+
+def test_device_math_matches_oracle_bitwise():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-1, 1, 20000), [0.0, 0.01, -0.0, 710, -800]])
+    assert np.array_equal(mcmc_amd.probe_math(0, x)[0], orc.math_eval(0, x)[0])
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 20000)), rng.uniform(0, 2, 20000), [1.0, 5e-324, 2.0 ** -53]])
+    assert np.array_equal(mcmc_amd.probe_math(1, x)[0], orc.math_eval(1, x)[0])
+    u = np.concatenate([rng.random(40000), [0.0, 0.125, 0.25, 0.5, 0.999999999]])
+    gs, gc = mcmc_amd.probe_math(2, u)
+    os_, oc = orc.math_eval(2, u)
+    assert np.array_equal(gs, os_) and np.array_equal(gc, oc)
+    x = rng.uniform(-40, 40, 20000)
+    assert np.array_equal(mcmc_amd.probe_math(3, x)[0], orc.math_eval(3, x)[0])
+    assert np.array_equal(mcmc_amd.probe_math(4, x)[0], orc.math_eval(4, x)[0])
+
+
+def test_device_rng_matches_oracle_bitwise():
+    for seed, chain, draw, stream, d in [(1, 0, 0, 0, 128), (2 ** 40 + 7, 2 ** 33 + 5, 17, 0, 37),
+                                         (99, 65535, 199, 2, 1024), (5, 3, 2, 0, 3)]:
+        assert np.array_equal(mcmc_amd.probe_normals(seed, chain, draw, stream, d),
+                              orc.normal_vec(seed, chain, draw, stream, d))
+    for args in [(1, 0, 0, 0), (7, 123456, 42, 3), (2 ** 63 + 1, 2 ** 35, 2 ** 31, 9)]:
+        assert mcmc_amd.probe_uniform(*args) == orc.uniform(*args)
+
+
+def _oracle_many(kind_orc, d, init, st, prec=None, chain0=0):
+    t = orc.TargetSpec(kind_orc, d, prec=prec, W=4)
+    s = orc.make_settings(seed=int(st.rng_seed_value), n_burnin=int(st.n_burnin_draws),
+                          n_keep=int(st.n_keep_draws), n_leap=int(st.n_leap_steps),
+                          step=float(st.step_size), W=4)
+    return orc.run_many(orc.ALGO_HMC, t, init, s, chain0=chain0)
+
+
+CASES = [
+    # kind,            d,   C,   L,  eps,  burn, keep
+    ("dense", 128, 64, 16, 0.05, 5, 12),     # BASELINE config 2 shape, one workgroup
+    ("dense", 128, 37, 4, 0.10, 3, 6),       # ragged chain count (partial wave, dead lanes)
+    ("dense", 8, 16, 5, 0.20, 5, 20),        # SURVEY 8(c) golden shape "dense Gaussian d=8"
+    ("dense", 100, 130, 3, 0.05, 2, 5),      # d not a multiple of 16, C not a multiple of 64
+    ("dense", 33, 17, 2, 0.10, 0, 4),        # odd d, no burn-in
+    ("iso", 3, 5, 10, 0.20, 10, 30),         # BASELINE config 1 shape (3-D isotropic Gaussian)
+    ("diag", 50, 48, 8, 0.02, 4, 8),
+    ("dense", 64, 256, 1, 0.9, 2, 10),       # large step: many rejections exercise the reload path
+]
+
+
+@pytest.mark.parametrize("kind,d,C,L,eps,burn,keep", CASES)
+def test_hmc_draws_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep):
+    init = synth.initial_states(C, d, seed=11)
+    prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+    if kind == "dense":
+        prec, k_gpu, k_orc = synth.dense_gaussian_precision(d, seed=5), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+    elif kind == "diag":
+        prec, k_gpu, k_orc = synth.ill_conditioned_diag(d, 100.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+    st = mcmc_amd.default_settings(rng_seed_value=1234, n_burnin_draws=burn, n_keep_draws=keep,
+                                   n_leap_steps=L, step_size=eps)
+    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=1000)
+    o_draws, o = _oracle_many(k_orc, d, init, st, prec=prec, chain0=1000)
+    assert np.array_equal(g["n_accept"], o["n_accept"])          # bit-exact accept decisions
+    assert np.array_equal(g_draws, o_draws)                      # bit-exact draws
+    rel = np.linalg.norm(g_draws - o_draws) / np.linalg.norm(o_draws)
+    assert rel <= 1e-9                                           # BASELINE.json tolerance (trivially)
+    assert np.array_equal(g["n_leap"], np.full(C, (burn + keep) * L, dtype=np.uint64))
+    assert np.array_equal(g["theta"].T, o_draws[-1].T)           # state out = last kept draw
+
+
+def test_rejections_happen_and_match():
+    d, C = 64, 256
+    init = synth.initial_states(C, d, seed=11)
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=0, n_keep_draws=20, n_leap_steps=1, step_size=0.9)
+    _, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    assert 0 < g["n_accept"].sum() < 20 * C
+
+
+def test_results_do_not_depend_on_sharding():
+    """Chains are keyed by global id: [0,C) in one call == two half shards with chain0 offsets."""
+    d, C = 128, 192
+    init = synth.initial_states(C, d, seed=3)
+    prec = synth.dense_gaussian_precision(d)
+    st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=8, step_size=0.05)
+    full, gf = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=0)
+    a, ga = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init[:80], st, prec=prec, chain0=0)
+    b, gb = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init[80:], st, prec=prec, chain0=80)
+    assert np.array_equal(full, np.concatenate([a, b], axis=2))
+    assert np.array_equal(gf["n_accept"], np.concatenate([ga["n_accept"], gb["n_accept"]]))
+
+
+def test_full_size_config2_subset_parity_and_statistics():
+    """BASELINE config 2: d=128 dense Gaussian, 65536 chains, L=16, eps=0.05.
+    The oracle re-runs a sample of the chains (global ids) bit-exactly; the whole population is
+    checked through statistics the domain offers."""
+    d, C = 128, 65536
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=3)
+    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=20, n_keep_draws=10,
+                                   n_leap_steps=16, step_size=0.05)
+    draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    assert draws.shape == (10, d, C) and np.isfinite(draws).all()
+    pick = np.array([0, 1, 15, 16, 63, 64, 4095, 4096, 32767, 40000, 65534, 65535])
+    for c in pick:
+        o_draws, o = _oracle_many(orc.TARGET_DENSE, d, init[c:c + 1], st, prec=prec, chain0=int(c))
+        assert np.array_equal(draws[:, :, c], o_draws[:, :, 0])
+        assert g["n_accept"][c] == o["n_accept"][0]
+    acc = g["n_accept"].mean() / 10
+    assert 0.9 < acc <= 1.0
+    # population covariance of the last draw approaches P^-1 (30 draws x 16 steps from N(0,I) starts):
+    last = draws[-1]                                   # [d, C]
+    cov = last @ last.T / C
+    want = np.linalg.inv(prec)
+    assert np.abs(cov - want).max() < 0.1
+    assert abs(np.trace(cov) / np.trace(want) - 1) < 0.05
+
+
+def test_unsupported_requests_fail_loudly():
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:
+        mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, np.zeros((4, 300)), st, prec=np.eye(300))
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
