@@ -32,12 +32,24 @@ WORKLOAD = dict(d=128, chains_per_gpu=65536, n_leap_steps=16, step_size=0.05,
                 n_burnin_draws=100, n_keep_draws=100, seed=2024)
 
 
+def usable_cores():
+    """Threads the host really grants: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, prec):
     """Oracle (port of src/hmc.cpp, reference-faithful work profile) on the host cores."""
     import orc   # tests/orc.py: ctypes binding of oracle/liboracle.so
     from mcmc_amd import synth
-    cores = os.cpu_count() or 1
-    n_chains = 4 * cores
+    cores = usable_cores()
+    n_chains = 8 * cores
     d = cfg["d"]
     init = synth.initial_states(n_chains, d, seed=3)
     tgt = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
