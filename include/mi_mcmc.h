@@ -98,6 +98,7 @@ typedef struct mi_chains {
     uint64_t* n_accept;       /* out [C], may be NULL */
     double*   step_size;      /* nuts out [C]: adapted step size per chain, may be NULL */
     uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain, may be NULL */
+    uint32_t* nuts_depth;     /* nuts out [n_burnin+n_keep][C]: tree depth reached per draw, may be NULL */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);

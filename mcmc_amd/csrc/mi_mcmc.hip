@@ -13,6 +13,7 @@
 #include "../../include/mi_mcmc.h"
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
+#include "nuts_dense.hpp"
 
 namespace {
 
@@ -92,11 +93,11 @@ int dense_precision_on_device(const mi_target* t, DevBuf& owned, const double** 
 
 // host <-> device staging of one mi_chains shard
 struct StagedChains {
-    DevBuf theta, draws, n_accept, step, n_leap;
+    DevBuf theta, draws, n_accept, step, n_leap, depth;
     mi_chains dev;   // device-pointer view
 };
 
-int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st)
+int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st, uint64_t n_total = 0)
 {
     sc.dev = *c;
     if (c->mem == MI_MEM_DEVICE) return MI_OK;
@@ -108,11 +109,12 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
     if (c->n_accept) { HIP_TRY(sc.n_accept.alloc(C * sizeof(uint64_t))); sc.dev.n_accept = sc.n_accept.as<uint64_t>(); }
     if (c->step_size) { HIP_TRY(sc.step.alloc(C * sizeof(double))); sc.dev.step_size = sc.step.as<double>(); }
     if (c->n_leapfrogs) { HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>(); }
+    if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
     sc.dev.mem = MI_MEM_DEVICE;
     return MI_OK;
 }
 
-int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st)
+int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st, uint64_t n_total = 0)
 {
     if (c->mem == MI_MEM_DEVICE) return MI_OK;
     const size_t C = c->n_chains;
@@ -121,7 +123,20 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     if (c->n_accept) HIP_TRY(hipMemcpyAsync(c->n_accept, sc.dev.n_accept, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (c->step_size) HIP_TRY(hipMemcpyAsync(c->step_size, sc.dev.step_size, C * sizeof(double), hipMemcpyDeviceToHost, st));
     if (c->n_leapfrogs) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs, sc.dev.n_leapfrogs, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (c->nuts_depth) HIP_TRY(hipMemcpyAsync(c->nuts_depth, sc.dev.nuts_depth, n_total * C * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+template <int NT>
+int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
+{
+    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double);
+    auto kern = mi::nuts_gauss_mfma_kernel<NT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 63) / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
@@ -228,9 +243,67 @@ int mi_mcmc_mala_run(const mi_target*, const mi_settings*, mi_chains*, void*)
     return fail(MI_ERR_UNSUPPORTED, "mala: device path not built yet");
 }
 
-int mi_mcmc_nuts_run(const mi_target*, const mi_settings*, mi_chains*, void*)
+int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
-    return fail(MI_ERR_UNSUPPORTED, "nuts: device path not built yet");
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "nuts: vals_bound is not implemented on the device path yet");
+    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "nuts: precond_mat is not implemented on the device path yet");
+    const uint64_t d = target->d;
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
+        return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
+    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "nuts: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
+    if (settings->max_tree_depth > (uint64_t)mi::NUTS_MAX_DEPTH)
+        return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented", (int)mi::NUTS_MAX_DEPTH);
+    const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+
+    mi::NutsParams prm{};
+    prm.P = P_dev;
+    prm.d = (uint32_t)d;
+    prm.C = chains->n_chains;
+    prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta;
+    void* ws = nullptr;
+    HIP_TRY(hipMallocAsync(&ws, (size_t)mi::NUTS_NVEC * d * chains->n_chains * sizeof(double), st));
+    prm.ws = static_cast<double*>(ws);
+    prm.draws = sc.dev.draws;
+    prm.n_accept = sc.dev.n_accept;
+    prm.n_leap = sc.dev.n_leapfrogs;
+    prm.step_out = sc.dev.step_size;
+    prm.depth_trace = sc.dev.nuts_depth;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws;
+    prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+    prm.max_depth = (uint32_t)settings->max_tree_depth;
+    prm.delta = settings->target_accept_rate;
+    prm.eps_bar0 = settings->step_size;
+    prm.gamma = settings->gamma_val;
+    prm.t0 = settings->t0_val;
+    prm.kappa = settings->kappa_val;
+
+    const int nt = (int)((d + 15) / 16);
+    if (nt <= 1) rc = launch_nuts_mfma<1>(prm, st);
+    else if (nt == 2) rc = launch_nuts_mfma<2>(prm, st);
+    else if (nt <= 4) rc = launch_nuts_mfma<4>(prm, st);
+    else rc = launch_nuts_mfma<8>(prm, st);
+    (void)hipFreeAsync(ws, st);
+    if (rc) return rc;
+
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
 }
 
 int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
