@@ -1,0 +1,80 @@
+"""GPU: NUTS (iterative wavefront tree) vs the recursive CPU oracle -- bit-exact through the C ABI."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(kind_orc, d, init, st, prec=None, chain0=0):
+    C = init.shape[0]
+    n_tot = int(st.n_burnin_draws + st.n_keep_draws)
+    draws = np.zeros((int(st.n_keep_draws), d, C))
+    out = dict(n_accept=np.zeros(C, dtype=np.uint64), n_leap=np.zeros(C, dtype=np.uint64),
+               eps=np.zeros(C), depth=np.zeros((n_tot, C), dtype=np.uint32))
+    for c in range(C):
+        t = orc.TargetSpec(kind_orc, d, prec=prec, W=4)
+        s = orc.make_settings(seed=int(st.rng_seed_value), n_burnin=int(st.n_burnin_draws),
+                              n_keep=int(st.n_keep_draws), step=float(st.step_size),
+                              n_adapt=int(st.n_adapt_draws), delta=float(st.target_accept_rate),
+                              max_depth=int(st.max_tree_depth), gamma=float(st.gamma_val),
+                              t0=float(st.t0_val), kappa=float(st.kappa_val), W=4, chain_id=chain0 + c)
+        dr, info = orc.run_chain(orc.ALGO_NUTS, t, init[c], s, traces=True)
+        draws[:, :, c] = dr
+        out["n_accept"][c] = info["n_accept"]
+        out["n_leap"][c] = info["n_leap"]
+        out["eps"][c] = info["eps"]
+        out["depth"][:, c] = info["depth"]
+    return draws, out
+
+
+CASES = [
+    # kind,   d,   C,  burn, keep, adapt, max_depth, eps_bar0
+    ("dense", 8, 16, 5, 20, 15, 10, 1.0),        # SURVEY 8(c) golden shape, adaptation on
+    ("iso", 3, 20, 30, 30, 30, 10, 1.0),         # 3-D isotropic Gaussian
+    ("dense", 128, 16, 6, 6, 8, 10, 1.0),        # BASELINE config 4 shape (one wave)
+    ("dense", 128, 70, 3, 4, 4, 10, 1.0),        # ragged: partial waves, dead lanes
+    ("dense", 33, 40, 4, 8, 6, 4, 1.0),          # odd d, shallow trees (max_tree_depth cap hit)
+    ("diag", 20, 32, 0, 12, 0, 6, 0.05),         # no adaptation: fixed small step -> deep trees
+    ("dense", 16, 64, 2, 10, 12, 1, 1.0),        # max_tree_depth = 1
+]
+
+
+@pytest.mark.parametrize("kind,d,C,burn,keep,adapt,max_depth,eps0", CASES)
+def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0):
+    init = synth.initial_states(C, d, seed=21)
+    prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+    if kind == "dense":
+        prec, k_gpu, k_orc = synth.dense_gaussian_precision(d, seed=6), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+    elif kind == "diag":
+        prec, k_gpu, k_orc = synth.ill_conditioned_diag(d, 50.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
+                                   n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
+    g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500)
+    o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
+    assert np.array_equal(g["depth"], o["depth"])            # same trees
+    assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"])                # same dual-averaging trajectory
+    assert np.array_equal(g_draws, o_draws)
+    assert np.linalg.norm(g_draws - o_draws) <= 1e-9 * np.linalg.norm(o_draws)
+
+
+def test_nuts_sharding_independence_and_statistics():
+    d, C = 32, 512
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=2)
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=60, n_keep_draws=40, n_adapt_draws=60)
+    full, gf = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    a, _ = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init[:200], st, prec=prec, chain0=0)
+    b, _ = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init[200:], st, prec=prec, chain0=200)
+    assert np.array_equal(full, np.concatenate([a, b], axis=2))
+    last = full[-1]
+    cov = last @ last.T / C
+    want = np.linalg.inv(prec)
+    assert abs(np.trace(cov) / np.trace(want) - 1) < 0.15
+    assert (gf["depth"] <= 10).all() and gf["depth"].max() >= 2
+    assert 0.3 < gf["n_accept"].mean() / 40 <= 1.0
