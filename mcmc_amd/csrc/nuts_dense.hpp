@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     const uint32_t n_adapt = prm.n_adapt <= n_total ? prm.n_adapt : n_total;    // :54
     const uint32_t max_depth = prm.max_depth;
+    bool wprev_dirty = false;                            // V_WPREV is stale w.r.t. V_PREV for this chain
 
     // ---------------------------------------------------------------- draws (nuts.cpp:199-310)
 #pragma unroll 1
@@ -208,11 +209,11 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
         copy_vec(V_PREV, V_TNEG_T, true);
 
         uint32_t depth = 0;                              // wave-uniform for alive chains
+        uint32_t my_depth = 0;                           // tree_depth of this chain when its loop ended
         double n_val = 1.0;
         bool alive = max_depth > 0;                      // s_val == 1 && tree_depth < max_tree_depth (:227)
         double alpha_val = 0.0, n_alpha_val = 0.0;       // :221-222
         int good_round = 0;
-        bool wprev_dirty = false;
 
 #pragma unroll 1
         while (__ballot(alive) != 0ull) {
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
             const double e_signed = (double)vdir * eps;
             const double H0 = prev_U + prev_K;
 
-            if (__ballot(alive && wprev_dirty) != 0ull) {                        // refresh P*prev_draw
+            if (__ballot(wprev_dirty) != 0ull) {                                 // refresh P*prev_draw
                 load_vec(V_PREV, th);
                 matvec_mfma<NT>(afrag, th, w);
-                store_vec(V_WPREV, w, alive && wprev_dirty);
+                store_vec(V_WPREV, w, wprev_dirty);
                 wprev_dirty = false;
             }
 
@@ -365,11 +366,12 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
                 s_ok = res_s && (q1 >= 0.0) && (q2 >= 0.0);                      // :289
             }
             depth += 1;                                                          // :284
+            if (alive) my_depth = depth;
             alive = alive && s_ok && (depth < max_depth);
         }
 
         // ---- dual averaging (src/nuts.cpp:294-302)
-        if (prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = depth;
+        if (prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
         if (draw < n_adapt) {
             const double it = (double)(draw + 1);
             h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
