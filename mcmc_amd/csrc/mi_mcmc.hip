@@ -14,6 +14,7 @@
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
+#include "mala_dense.hpp"
 
 namespace {
 
@@ -129,6 +130,18 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
 }
 
 template <int NT>
+int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
+{
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
+    auto kern = mi::mala_gauss_mfma_kernel<NT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 63) / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+template <int NT>
 int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 {
     const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double);
@@ -238,9 +251,62 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     return MI_OK;
 }
 
-int mi_mcmc_mala_run(const mi_target*, const mi_settings*, mi_chains*, void*)
+int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
-    return fail(MI_ERR_UNSUPPORTED, "mala: device path not built yet");
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound is not implemented on the device path yet");
+    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "mala: precond_mat is not implemented on the device path yet");
+    const uint64_t d = target->d;
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
+        return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
+    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "mala: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+
+    mi::MalaParams prm{};
+    prm.P = P_dev;
+    prm.d = (uint32_t)d;
+    prm.C = chains->n_chains;
+    prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta;
+    prm.draws = sc.dev.draws;
+    prm.n_accept = sc.dev.n_accept;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws;
+    prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.eps = settings->step_size;
+    // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
+    // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
+    prm.s2 = settings->step_size * settings->step_size;
+    prm.rs = 1.0 / prm.s2;
+    prm.cons_term = -0.5 * (double)d * 1.83787706640934548356;   // MCMC_LOG_2PI, stats/mcmc_stats.hpp:28-30
+    {
+        const double lii = __builtin_sqrt(prm.s2);
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(lii);
+        prm.log_det = ld;
+    }
+
+    const int nt = (int)((d + 15) / 16);
+    if (nt <= 1) rc = launch_mala_mfma<1>(prm, st);
+    else if (nt == 2) rc = launch_mala_mfma<2>(prm, st);
+    else if (nt <= 4) rc = launch_mala_mfma<4>(prm, st);
+    else rc = launch_mala_mfma<8>(prm, st);
+    if (rc) return rc;
+
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
 }
 
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
