@@ -113,6 +113,17 @@ int mi_mcmc_hmc_run (const mi_target* target, const mi_settings* settings, mi_ch
 int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 
+/* Host-callback form of mcmc::hmc for ONE chain: the reference's own target contract
+ * (std::function<fp_t(const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>, hmc.hpp:42-48)
+ * flattened to a C function pointer. The callback runs on the host, called exactly where the
+ * reference calls it (2 gradient calls per leapfrog step, 1 value call per draw, 1 at setup);
+ * everything else of the draw loop runs on the GPU. draws_out: n_keep x d column-major
+ * (element (i,j) at i + j*n_keep, as Eigen's Mat_t stores draws_out). Identity precond, unbounded. */
+typedef double (*mi_log_kernel_cb)(const double* vals_inp, double* grad_out /* NULL = value only */, void* target_data);
+int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
+                             void* target_data, const mi_settings* settings, double* draws_out,
+                             uint64_t* n_accept_draws);
+
 /* Layout converters between the engine's [n_keep][d][C] slabs and the reference's per-chain
  * draws_out (n_keep x d, column-major as Eigen stores it: element (i,j) at i + j*n_keep;
  * src/hmc.cpp:138,197). Host memory. */

@@ -58,7 +58,8 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_draws_to_chain_major",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_hmc_run_callback",
+    "mi_mcmc_draws_to_chain_major",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak",
 ]
 
@@ -173,6 +174,35 @@ def mala(kind, init, settings, **kw):
 
 def nuts(kind, init, settings, **kw):
     return sample("nuts", kind, init, settings, **kw)
+
+
+LOG_KERNEL_CB = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+
+def hmc_callback(initial_vals, callback, settings, target_data=None):
+    """mcmc::hmc with a host callback for one chain (mi_mcmc_hmc_run_callback).
+
+    callback: either a ctypes function pointer with the mi_log_kernel_cb signature or a Python
+    callable f(vals: np.ndarray, want_grad: bool) -> (value, grad or None)."""
+    x0 = np.ascontiguousarray(initial_vals, dtype=np.float64)
+    d = x0.size
+    n_keep = int(settings.n_keep_draws)
+    draws = np.zeros((n_keep, d), order="F")
+    n_acc = C.c_uint64(0)
+    if callable(callback) and not isinstance(callback, C._CFuncPtr):
+        def _tramp(vals, grad, _user):
+            v = np.ctypeslib.as_array(vals, shape=(d,))
+            val, g = callback(v.copy(), bool(grad))
+            if grad:
+                np.ctypeslib.as_array(grad, shape=(d,))[:] = g
+            return float(val)
+        cb = LOG_KERNEL_CB(_tramp)
+    else:
+        cb = callback
+    fn = lib().mi_mcmc_hmc_run_callback
+    _check(fn(C.c_void_p(x0.ctypes.data), C.c_uint64(d), C.cast(cb, C.c_void_p), C.c_void_p(target_data or 0),
+              C.byref(settings), C.c_void_p(draws.ctypes.data), C.byref(n_acc)))
+    return draws, int(n_acc.value)
 
 
 # ---------------------------------------------------------------- diagnostics (GPU tests)

@@ -15,6 +15,7 @@
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
 #include "mala_dense.hpp"
+#include "callback_mode.hpp"
 
 namespace {
 
@@ -369,6 +370,67 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
+                             const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws)
+{
+    if (!initial_vals || !cb || !settings || d == 0) return fail(MI_ERR_BAD_ARG, "null / empty argument");
+    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
+    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): vals_bound not implemented on the device path yet");
+    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): precond_mat not implemented on the device path yet");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    const uint32_t dd = (uint32_t)d;
+    const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
+    if (n_keep && !draws_out) return fail(MI_ERR_BAD_ARG, "draws_out is required");
+    const double eps = settings->step_size;
+    const uint64_t seed = settings->rng_seed_value;
+
+    DevBuf prev, cur, mntm, grad, scal, draws, nacc;
+    HIP_TRY(prev.alloc(d * 8)); HIP_TRY(cur.alloc(d * 8)); HIP_TRY(mntm.alloc(d * 8)); HIP_TRY(grad.alloc(d * 8));
+    HIP_TRY(scal.alloc(4 * 8)); HIP_TRY(draws.alloc(n_keep * d * 8)); HIP_TRY(nacc.alloc(8));
+    HIP_TRY(hipMemset(nacc.p, 0, 8));
+    HIP_TRY(hipMemcpy(prev.p, initial_vals, d * 8, hipMemcpyHostToDevice));
+    std::vector<double> h_pos(d), h_grad(d);
+    double h_scal[4] = {0, 0, 0, 0};
+
+    // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
+    h_scal[1] = -cb(initial_vals, nullptr, target_data);
+    HIP_TRY(hipMemcpy(scal.p, h_scal, sizeof(h_scal), hipMemcpyHostToDevice));
+
+    auto grad_at_cur = [&]() -> int {   // mntm_update_fn's callback (hmc.cpp:124): gradient at new_draw
+        HIP_TRY(hipMemcpy(h_pos.data(), cur.p, d * 8, hipMemcpyDeviceToHost));
+        (void)cb(h_pos.data(), h_grad.data(), target_data);
+        HIP_TRY(hipMemcpy(grad.p, h_grad.data(), d * 8, hipMemcpyHostToDevice));
+        return MI_OK;
+    };
+
+    for (uint64_t draw = 0; draw < n_total; ++draw) {
+        hipLaunchKernelGGL(mi::cb_begin_draw, dim3(1), dim3(64), 0, 0, seed, 0ull, (uint32_t)draw, dd,
+                           prev.as<double>(), cur.as<double>(), mntm.as<double>(), scal.as<double>());
+        for (uint64_t k = 0; k < settings->n_leap_steps; ++k) {          // hmc.cpp:164-176
+            int rc = grad_at_cur(); if (rc) return rc;
+            hipLaunchKernelGGL(mi::cb_half_kick, dim3(1), dim3(64), 0, 0, dd, eps, grad.as<double>(), mntm.as<double>());
+            hipLaunchKernelGGL(mi::cb_drift, dim3(1), dim3(64), 0, 0, dd, eps, mntm.as<double>(), cur.as<double>());
+            rc = grad_at_cur(); if (rc) return rc;
+            hipLaunchKernelGGL(mi::cb_half_kick, dim3(1), dim3(64), 0, 0, dd, eps, grad.as<double>(), mntm.as<double>());
+        }
+        // prop_U = -box_log_kernel(new_draw)  (hmc.cpp:178): value-only callback
+        HIP_TRY(hipMemcpy(h_pos.data(), cur.p, d * 8, hipMemcpyDeviceToHost));
+        const double prop_U = -cb(h_pos.data(), nullptr, target_data);
+        HIP_TRY(hipMemcpy(scal.as<double>() + 2, &prop_U, 8, hipMemcpyHostToDevice));
+        double* row = (draw >= n_burnin) ? draws.as<double>() + (draw - n_burnin) : nullptr;   // column-major n_keep x d
+        hipLaunchKernelGGL(mi::cb_accept, dim3(1), dim3(64), 0, 0, seed, 0ull, (uint32_t)draw, dd, (uint32_t)n_burnin,
+                           cur.as<double>(), mntm.as<double>(), prev.as<double>(), scal.as<double>(), row, n_keep,
+                           nacc.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_keep) HIP_TRY(hipMemcpy(draws_out, draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
+    if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

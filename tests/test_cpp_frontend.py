@@ -1,0 +1,98 @@
+"""C++ drop-in header include/mcmc.hpp: builds on CPU; runs (and is checked) on the GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "hmc_plumbing")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{ROOT}/include", f"{ROOT}/examples/hmc_plumbing.cpp",
+           f"-L{ROOT}/mcmc_amd", "-lmi_mcmc", f"-Wl,-rpath,{ROOT}/mcmc_amd", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_reference_style_program_compiles_against_the_header(tmp_path):
+    if not os.path.exists(mcmc_amd.LIB_PATH):
+        pytest.skip("libmi_mcmc.so not built")
+    exe = _build(tmp_path)
+    if mcmc_amd.lib().mi_mcmc_device_count() == 0:
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert "callback ok=0" in out.stdout          # no GPU: fails loudly, never samples on the CPU
+        assert out.returncode != 0
+
+
+def test_settings_structs_keep_reference_names_and_defaults():
+    """Field names / defaults of mcmc_structs.hpp:66-101,123-134,151-184 are present in our header."""
+    src = open(os.path.join(ROOT, "include", "mcmc.hpp")).read()
+    for frag in ["size_t n_burnin_draws = 1E03;", "size_t n_keep_draws = 1E03;", "size_t n_leap_steps = 1;",
+                 "fp_t step_size = 1.0;", "Mat_t precond_mat;", "size_t n_accept_draws;",
+                 "size_t n_adapt_draws = 1E03;", "fp_t target_accept_rate = 0.55;",
+                 "size_t max_tree_depth = size_t(10);", "fp_t gamma_val = 0.05;", "fp_t t0_val = 10;",
+                 "fp_t kappa_val = 0.75;", "size_t rng_seed_value = std::random_device{}();",
+                 "bool vals_bound = false;", "ColVec_t lower_bounds;", "ColVec_t upper_bounds;",
+                 "hmc_settings_t hmc_settings;", "nuts_settings_t nuts_settings;", "mala_settings_t mala_settings;"]:
+        assert frag in src, frag
+    for sig in ["hmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t& draws_out, void* target_data,",
+                "mala(const ColVec_t& initial_vals", "nuts(const ColVec_t& initial_vals", "algo_settings_t& settings)"]:
+        assert sig in src, sig
+
+
+@pytest.mark.gpu
+def test_example_runs_on_the_gpu(tmp_path):
+    exe = _build(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"callback ok=1 rows=1000 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+)", out.stdout)
+    assert m, out.stdout
+    mean = np.array([float(m.group(i)) for i in (1, 2, 3)])
+    assert np.abs(mean).max() < 0.15 and 0.9 < float(m.group(4)) <= 1.0     # examples/eigen/hmc_normal.cpp flow
+    # the reference's callback pattern: 2 gradient calls per leapfrog, 1 value call per draw + 1 at setup
+    assert int(m.group(5)) == 2 * 10 * 2000 and int(m.group(6)) == 2000 + 1
+    for algo in ("hmc", "mala", "nuts"):
+        mm = re.search(rf"device {algo} ok=1 rows=50 cols=1024 acc0=(\S+)", out.stdout)
+        assert mm, out.stdout
+        assert 0.2 < float(mm.group(1)) <= 1.0
+    assert "refused=1" in out.stdout
+
+
+@pytest.mark.gpu
+def test_host_callback_route_matches_oracle_and_fused_kernel_bitwise():
+    """mcmc::hmc with a host callback (GPU drives everything but the callback) == oracle == fused kernel."""
+    d = 3
+    st = mcmc_amd.default_settings(rng_seed_value=1234, n_burnin_draws=50, n_keep_draws=100, n_leap_steps=10,
+                                   step_size=0.2)
+    tgt = orc.TargetSpec(orc.TARGET_ISO, d, W=4)
+    cb = C.cast(orc.lib().orc_target_kernel, C.c_void_p)
+    draws_cb, nacc_cb = mcmc_amd.hmc_callback(np.ones(d), cb, st, target_data=C.addressof(tgt.c))
+    so = orc.make_settings(seed=1234, n_burnin=50, n_keep=100, n_leap=10, step=0.2, W=4, chain_id=0)
+    t2 = orc.TargetSpec(orc.TARGET_ISO, d, W=4)
+    o_draws, o = orc.run_chain(orc.ALGO_HMC, t2, np.ones(d), so)
+    assert np.array_equal(np.asarray(draws_cb), o_draws) and nacc_cb == o["n_accept"]
+    assert tgt.c.n_grad_calls == t2.c.n_grad_calls == 2 * 10 * 150
+    assert tgt.c.n_value_calls == t2.c.n_value_calls == 151
+    f_draws, f = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.ones((1, d)), st)
+    assert np.array_equal(f_draws[:, :, 0], o_draws)
+
+
+@pytest.mark.gpu
+def test_python_callable_as_target():
+    d = 4
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=200, n_keep_draws=400, n_leap_steps=5, step_size=0.3)
+    prec = np.array([1.0, 2.0, 4.0, 8.0])
+
+    def logk(v, want_grad):
+        return -0.5 * float(np.sum(prec * v * v)), (-prec * v if want_grad else None)
+
+    draws, nacc = mcmc_amd.hmc_callback(np.zeros(d) + 0.5, logk, st)
+    assert draws.shape == (400, d) and 0.6 < nacc / 400 <= 1.0
+    assert np.abs(draws.var(0) * prec - 1).max() < 0.5
