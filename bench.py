@@ -153,7 +153,7 @@ def main():
     collate_ms = None
     if args.collate and dist is not None:
         last = draws[-1].contiguous()
-        gathered = torch.empty((world,) + tuple(last.shape), dtype=last.dtype, device=dev)
+        gathered = torch.empty((world * last.shape[0],) + tuple(last.shape[1:]), dtype=last.dtype, device=dev)
         barrier()
         tc = time.perf_counter()
         dist.all_gather_into_tensor(gathered, last)

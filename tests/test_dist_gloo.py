@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: chain sharding + draws collation of mcmc_amd.dist (the N>1 path).
+
+The engine itself needs a GPU, so the per-shard runner here is the CPU oracle (tests may use it):
+what is under test is the shard arithmetic, the global chain ids handed to the runner and the
+all-gather layout."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import orc
+from mcmc_amd import dist as mdist, synth
+dist.init_process_group(backend="gloo")
+d, C_total = 6, 13                      # 13 chains over 2 ranks: ragged shards 7 + 6
+P = synth.dense_gaussian_precision(d, seed=4)
+
+def runner(algo, kind, init, settings, chain0=0, **kw):
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=P, W=4)
+    return orc.run_many(orc.ALGO_HMC, t, init, settings, chain0=chain0)
+
+st = orc.make_settings(seed=11, n_burnin=3, n_keep=5, n_leap=4, step=0.1, W=4)
+init_fn = lambda chain0, c: synth.initial_states(c, d, seed=3, chain0=chain0)
+draws, nacc = mdist.run_sharded("hmc", None, init_fn, C_total, st, runner=runner)
+if dist.get_rank() == 0:
+    np.savez(sys.argv[2], draws=draws, nacc=nacc)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds_cover_all_chains_once():
+    from mcmc_amd.dist import shard_bounds
+    for total, world in [(65536, 8), (13, 2), (5, 8), (1 << 20, 8), (7, 3)]:
+        got = []
+        for r in range(world):
+            c0, c = shard_bounds(total, world, r)
+            got += list(range(c0, c0 + c))
+        assert got == list(range(total))
+    assert shard_bounds(65536, 8, 3) == (3 * 8192, 8192)
+
+
+def test_two_rank_gloo_collation_equals_single_process(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from mcmc_amd import synth
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "out.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script), ROOT, str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
+    got = np.load(out)
+    d, C = 6, 13
+    P = synth.dense_gaussian_precision(d, seed=4)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=P, W=4)
+    st = orc.make_settings(seed=11, n_burnin=3, n_keep=5, n_leap=4, step=0.1, W=4)
+    want, info = orc.run_many(orc.ALGO_HMC, t, synth.initial_states(C, d, seed=3), st, chain0=0)
+    assert got["draws"].shape == (5, d, C)
+    assert np.array_equal(got["draws"], want)
+    assert np.array_equal(got["nacc"], info["n_accept"].astype(np.int64))
