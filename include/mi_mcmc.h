@@ -136,6 +136,7 @@ int mi_probe_math(int fn, const double* x, uint64_t n, double* out, double* out2
 int mi_probe_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out);
 int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out);
 int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out);
+int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cycles_per_mfma, double* tflops_out);
 
 #ifdef __cplusplus
 }

@@ -60,7 +60,7 @@ EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_hmc_run_callback",
     "mi_mcmc_draws_to_chain_major",
-    "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak",
+    "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
 
 
@@ -242,3 +242,9 @@ def probe_fp64_peak(use_mfma, iters=20000):
     out = C.c_double(0.0)
     _check(lib().mi_probe_fp64_peak(int(use_mfma), int(iters), C.byref(out)))
     return out.value
+
+
+def probe_mfma_cycles(waves_per_simd, use_lds, iters=20000):
+    cyc, tf = C.c_double(0.0), C.c_double(0.0)
+    _check(lib().mi_probe_mfma_cycles(int(waves_per_simd), int(use_lds), int(iters), C.byref(cyc), C.byref(tf)))
+    return cyc.value, tf.value

@@ -36,13 +36,15 @@ struct HmcParams {
     uint64_t C;             // chains in this launch
     uint64_t chain0;        // global id of local chain 0
     double* theta;          // [d][C] in/out: always the last accepted state
-    double* wsave;          // [d][C] workspace: P * theta of the last accepted state
+    double* wsave;          // [2][16*NT][C] workspace: last accepted theta and P*theta, rows padded
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_leap_steps;
     double eps;
+    uint32_t ablate;        // profiling only: 1 = skip kick/drift, 2 = skip mat-vec (results meaningless)
+    uint32_t stagger;       // start delay of the second wave of each SIMD, in s_sleep(127) units
 };
 
 template <int NS>
@@ -108,8 +110,10 @@ __device__ __forceinline__ void stage_precision(const double* __restrict__ P, ui
     __syncthreads();
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams prm)
+// WPB = waves per workgroup: 4 (one wave per SIMD, 512-register budget) or 8 (two waves per SIMD,
+// 256 registers each: one wave's VALU phases -- kick/drift, RNG, accept -- hide under the other's MFMAs).
+template <int NT, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
-    const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
     const bool live = cl < prm.C;
     const uint64_t cld = live ? cl : prm.C - 1;       // clamped index for loads
     const uint64_t chain = prm.chain0 + cl;           // global chain id (Philox counter)
@@ -132,25 +136,29 @@ __global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams 
     double th[NS], pm[NS], w[NS];
     // addresses = wave-uniform row base (SGPR) + one per-lane element offset (VGPR)
     const size_t lane_off = (size_t)j * C + cld;
-    auto th_mem = [&](int s) -> double* { return prm.theta + (size_t)(4 * s) * C + lane_off; };
-    auto w_mem = [&](int s) -> double* { return prm.wsave + (size_t)(4 * s) * C + lane_off; };
+    auto th_mem = [&](int s) -> double* { return prm.wsave + (size_t)(4 * s) * C + lane_off; };
+    auto w_mem = [&](int s) -> double* { return prm.wsave + (size_t)(16 * NT + 4 * s) * C + lane_off; };
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t dim = 4 * s + j;
-        th[s] = (dim < d) ? *th_mem(s) : 0.0;
+        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];   // clamped row: unconditional load
+        th[s] = (dim < d) ? v : 0.0;
     }
     matvec_mfma<NT>(afrag, th, w);
     if (live) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint32_t dim = 4 * s + j;
-            if (dim < d) *w_mem(s) = w[s];
-        }
+        for (int s = 0; s < NS; ++s) { *th_mem(s) = th[s]; *w_mem(s) = w[s]; }
     }
     double prev_U = 0.5 * dot4<NS>(th, w);              // -box_log_kernel(first_draw), hmc.cpp:140
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
+
+    // Two waves share each SIMD's matrix pipe.  Started together they stay in lock-step and their
+    // VALU phases (RNG, accept, kick/drift) coincide; a one-off start offset is self-preserving under
+    // round-robin MFMA issue, so one wave's VALU work then always sits under the other's MFMAs.
+    if (WPB > 4 && wave >= 4)
+        for (uint32_t k = 0; k < prm.stagger; ++k) __builtin_amdgcn_s_sleep(127);
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
@@ -167,14 +175,18 @@ __global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams 
 
 #pragma unroll 1
         for (uint32_t k = 0; k < prm.n_leap_steps; ++k) {   // hmc.cpp:164-176, grad = -w
+            if (prm.ablate != 1) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 pm[s] = pm[s] - (eps * w[s]) / 2.0;     // first half-step (:167,126)
                 th[s] = th[s] + eps * pm[s];            // (:171)
             }
-            matvec_mfma<NT>(afrag, th, w);
+            }
+            if (prm.ablate != 2) matvec_mfma<NT>(afrag, th, w);
+            if (prm.ablate != 1) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * w[s]) / 2.0;   // second half-step (:175)
+            }
         }
 
         double prop_U = 0.5 * dot4<NS>(th, w);          // -box_log_kernel(new_draw), hmc.cpp:178
@@ -188,18 +200,11 @@ __global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams 
             prev_U = prop_U;
             if (live) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const uint32_t dim = 4 * s + j;
-                    if (dim < d) { *th_mem(s) = th[s]; *w_mem(s) = w[s]; }
-                }
+                for (int s = 0; s < NS; ++s) { *th_mem(s) = th[s]; *w_mem(s) = w[s]; }
             }
-        } else {                                        // keep prev_draw: reload it
+        } else {                                        // keep prev_draw: reload it (padded rows: no predicates)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const uint32_t dim = 4 * s + j;
-                th[s] = (dim < d) ? *th_mem(s) : 0.0;
-                w[s] = (dim < d) ? *w_mem(s) : 0.0;
-            }
+            for (int s = 0; s < NS; ++s) { th[s] = *th_mem(s); w[s] = *w_mem(s); }
         }
         if (draw >= prm.n_burnin) {                     // :196-204
             n_acc += accept ? 1u : 0u;
@@ -214,6 +219,13 @@ __global__ __launch_bounds__(256, 1) void hmc_gauss_mfma_kernel(const HmcParams 
         }
     }
 
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t dim = 4 * s + j;
+            if (dim < d) prm.theta[(size_t)dim * C + cl] = th[s];
+        }
+    }
     if (live && j == 0) {
         if (prm.n_accept) prm.n_accept[cl] = n_acc;                            // hmc.cpp:220-222
         if (prm.n_leap) prm.n_leap[cl] = (uint64_t)n_total * prm.n_leap_steps;

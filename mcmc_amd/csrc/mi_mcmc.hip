@@ -6,11 +6,15 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/mi_mcmc.h"
+#ifndef MI_HMC_WPB
+#define MI_HMC_WPB 8
+#endif
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
@@ -157,11 +161,12 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 template <int NT>
 int launch_hmc_mfma(const mi::HmcParams& prm, hipStream_t st)
 {
+    constexpr int WPB = MI_HMC_WPB;
     const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
-    auto kern = mi::hmc_gauss_mfma_kernel<NT>;
+    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -226,7 +231,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     prm.theta = sc.dev.theta;
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
     void* wsave = nullptr;
-    HIP_TRY(hipMallocAsync(&wsave, d * chains->n_chains * sizeof(double), st));
+    const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
+    HIP_TRY(hipMallocAsync(&wsave, 2 * d_pad_h * chains->n_chains * sizeof(double), st));
     prm.wsave = static_cast<double*>(wsave);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
@@ -236,6 +242,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     prm.n_keep = (uint32_t)settings->n_keep_draws;
     prm.n_leap_steps = (uint32_t)settings->n_leap_steps;
     prm.eps = settings->step_size;
+    prm.stagger = 40;
+    if (const char* e = getenv("MI_HMC_STAGGER")) prm.stagger = (uint32_t)atoi(e);
+    if (const char* e = getenv("MI_HMC_ABLATE")) prm.ablate = (uint32_t)atoi(e);
 
     const int nt = (int)((d + 15) / 16);
     if (nt <= 1) rc = launch_hmc_mfma<1>(prm, st);
@@ -341,7 +350,9 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;
     void* ws = nullptr;
-    HIP_TRY(hipMallocAsync(&ws, (size_t)mi::NUTS_NVEC * d * chains->n_chains * sizeof(double), st));
+    const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
+    HIP_TRY(hipMallocAsync(&ws, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), st));
     prm.ws = static_cast<double*>(ws);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
@@ -510,6 +521,32 @@ __global__ __launch_bounds__(256) void peak_mfma_kernel(int iters, double* sink)
     if (s == 12345.678) sink[0] = s;
 }
 
+// cycles-per-MFMA probe: NACC independent accumulators per wave, optional LDS operand fetch
+template <int NACC, bool USE_LDS>
+__global__ __launch_bounds__(256) void mfma_cycles_kernel(int iters, unsigned long long* cyc, double* sink)
+{
+    __shared__ double lds[64 * 64];
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) lds[i] = 1.0 + i * 1e-9;
+    __syncthreads();
+    mi::double4_t acc[NACC];
+    for (int t = 0; t < NACC; ++t) acc[t] = mi::double4_t{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+            if (USE_LDS) a = lds[((it + t) & 63) * 64 + lane];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = clock64();
+    double s = 0.0;
+    for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    if (s == 12345.678) sink[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 __global__ __launch_bounds__(256) void peak_fma_kernel(int iters, double* sink)
 {
     double acc[16];
@@ -575,6 +612,32 @@ int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot
     hipLaunchKernelGGL(probe_uniform_kernel, dim3(1), dim3(1), 0, 0, seed, chain, draw, slot, o.as<double>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, o.p, 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+// mode: waves per SIMD (1,2,4,8) ; returns shader cycles per MFMA per wave and wall TFLOP/s
+int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cycles_per_mfma, double* tflops_out)
+{
+    if (!cycles_per_mfma || !tflops_out || iters <= 0) return fail(MI_ERR_BAD_ARG, "bad args");
+    DevBuf sink, cyc;
+    HIP_TRY(sink.alloc(8)); HIP_TRY(cyc.alloc(8));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    const int grid = 256 * waves_per_simd;      // 256-thread blocks: 1 wave per SIMD each
+    for (int rep = 0; rep < 2; ++rep) {
+        HIP_TRY(hipEventRecord(e0, 0));
+        if (use_lds) hipLaunchKernelGGL((mfma_cycles_kernel<8, true>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        else hipLaunchKernelGGL((mfma_cycles_kernel<8, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpy(&c, cyc.p, 8, hipMemcpyDeviceToHost));
+    *cycles_per_mfma = (double)c / ((double)iters * 8.0);
+    *tflops_out = (double)grid * 4 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MI_OK;
 }
 

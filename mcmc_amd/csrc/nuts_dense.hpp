@@ -39,7 +39,7 @@ struct NutsParams {
     uint32_t d;
     uint64_t C, chain0;
     double* theta;          // [d][C] in: initial_vals, out: last state
-    double* ws;             // [NUTS_NVEC][d][C] workspace
+    double* ws;             // [NUTS_NVEC][16*NT][C] workspace (rows padded: no per-element predicates)
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
-    const size_t vstride = (size_t)d * C;
+    const size_t vstride = (size_t)(16 * NT) * C;       // padded rows hold zeros (theta, p, P*theta pads are 0)
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
     // element (4s + j4) of workspace vector v of this lane's chain
@@ -88,25 +88,29 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
 
     double th[NS], pm[NS], w[NS];
 
-    auto load_vec = [&](int v, double (&x)[NS]) {
+    // workspace vectors: unconditional, fully pipelined loads (rows are padded, dead lanes read a clamped chain)
+    auto load_vec = [&](int v, double (&x)[NS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) x[s] = dim_ok(s) ? *wsp(v, s) : 0.0;
+        for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
     };
-    auto store_vec = [&](int v, const double (&x)[NS], bool pred) {
+    auto store_vec = [&](int v, const double (&x)[NS], bool pred) __attribute__((always_inline)) {
         if (pred && live) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) if (dim_ok(s)) *wsp(v, s) = x[s];
+            for (int s = 0; s < NS; ++s) *wsp(v, s) = x[s];
         }
     };
     // per-lane source/destination vector ids
-    auto copy_vec = [&](int vsrc, int vdst, bool pred) {
+    auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
+        double tmp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(vsrc, s);
         if (pred && live) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) if (dim_ok(s)) *wsp(vdst, s) = *wsp(vsrc, s);
+            for (int s = 0; s < NS; ++s) *wsp(vdst, s) = tmp[s];
         }
     };
     // one leapfrog step of signed size e (nuts.cpp:139-154), grad = -w
-    auto leapfrog = [&](double e) {
+    auto leapfrog = [&](double e) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             pm[s] = pm[s] - (e * w[s]) / 2.0;
@@ -116,13 +120,13 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
 #pragma unroll
         for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
     };
-    auto potential = [&]() -> double {                   // -box_log_kernel_fn(theta), non-finite -> +inf
+    auto potential = [&]() __attribute__((always_inline)) -> double {                   // -box_log_kernel_fn(theta), non-finite -> +inf
         double u = 0.5 * dot4<NS>(th, w);
         if (!is_finite(u)) u = INF;
         return u;
     };
-    auto kinetic = [&]() -> double { return dot4<NS>(pm, pm) / 2.0; };
-    auto draw_momentum = [&](uint32_t draw, uint32_t stream) {
+    auto kinetic = [&]() __attribute__((always_inline)) -> double { return dot4<NS>(pm, pm) / 2.0; };
+    auto draw_momentum = [&](uint32_t draw, uint32_t stream) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
@@ -133,15 +137,14 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
         }
     };
     // [ (pos - neg) . p_a >= 0 ] * [ (pos - neg) . p_b >= 0 ] with pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1
-    auto uturn_ok = [&](int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) -> bool {
+    auto uturn_ok = [&](int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
         double q1 = 0.0, q2 = 0.0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const bool ok = dim_ok(s);
-            const double t1 = ok ? *wsp(vt1, s) : 0.0;
-            const double p1 = ok ? *wsp(vp1, s) : 0.0;
-            const double t2 = n2_in_regs ? th[s] : (ok ? *wsp(vt2, s) : 0.0);
-            const double p2 = n2_in_regs ? pm[s] : (ok ? *wsp(vp2, s) : 0.0);
+            const double t1 = *wsp(vt1, s);
+            const double p1 = *wsp(vp1, s);
+            const double t2 = n2_in_regs ? th[s] : *wsp(vt2, s);
+            const double p2 = n2_in_regs ? pm[s] : *wsp(vp2, s);
             const double dd = (vdir > 0) ? (t2 - t1) : (t1 - t2);
             q1 = dfma(dd, p1, q1);
             q2 = dfma(dd, p2, q2);
@@ -153,7 +156,11 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
 
     // ---------------------------------------------------------------- setup (nuts.cpp:156-195)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) th[s] = dim_ok(s) ? prm.theta[(size_t)(4 * s) * C + lane_off] : 0.0;
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dimc = dim_ok(s) ? (uint32_t)(4 * s + j4) : 0u;        // clamped row: unconditional load
+        const double v = prm.theta[(size_t)dimc * C + cld];
+        th[s] = dim_ok(s) ? v : 0.0;
+    }
     matvec_mfma<NT>(afrag, th, w);
     store_vec(V_PREV, th, true);
     store_vec(V_WPREV, w, true);
@@ -314,12 +321,13 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
                     const bool do_store = tact && !failed && live;
                     if (__ballot(do_store) != 0ull) {
                         const int vdst = V_PP0 + (int)pend_level;
+                        const int csrc = (cref < 0) ? V_PREV : cref;    // any valid vector when the leaf itself is kept
+                        double tmp[NS];
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            if (do_store && dim_ok(s)) {
-                                const double val = (cref < 0) ? th[s] : *wsp(cref, s);
-                                *wsp(vdst, s) = val;
-                            }
+                        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(csrc, s);
+                        if (do_store) {
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) *wsp(vdst, s) = (cref < 0) ? th[s] : tmp[s];
                         }
                     }
                 }
@@ -354,9 +362,8 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
                 double q1 = 0.0, q2 = 0.0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const bool ok = dim_ok(s);
-                    const double tp = ok ? *wsp(V_TPOS_T, s) : 0.0, tn = ok ? *wsp(V_TNEG_T, s) : 0.0;
-                    const double pp = ok ? *wsp(V_TPOS_P, s) : 0.0, pn = ok ? *wsp(V_TNEG_P, s) : 0.0;
+                    const double tp = *wsp(V_TPOS_T, s), tn = *wsp(V_TNEG_T, s);
+                    const double pp = *wsp(V_TPOS_P, s), pn = *wsp(V_TNEG_P, s);
                     const double dd = tp - tn;
                     q1 = dfma(dd, pn, q1);                                       // :286
                     q2 = dfma(dd, pp, q2);                                       // :287
@@ -384,17 +391,23 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
             n_acc += (uint64_t)good_round;
             if (prm.draws != nullptr && live) {
                 double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+                double tmp[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    if (dim_ok(s)) (out + (size_t)(4 * s) * C)[lane_off] = *wsp(V_PREV, s);
+                    if (dim_ok(s)) (out + (size_t)(4 * s) * C)[lane_off] = tmp[s];
             }
         }
     }
 
     if (live) {
+        double tmp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            if (dim_ok(s)) prm.theta[(size_t)(4 * s) * C + lane_off] = *wsp(V_PREV, s);
+            if (dim_ok(s)) prm.theta[(size_t)(4 * s) * C + lane_off] = tmp[s];
         if (j4 == 0) {
             if (prm.n_accept) prm.n_accept[cl] = n_acc;
             if (prm.n_leap) prm.n_leap[cl] = n_leap;

@@ -13,6 +13,7 @@ ap.add_argument("--d", type=int, default=128)
 ap.add_argument("--burn", type=int, default=100)
 ap.add_argument("--keep", type=int, default=100)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--leap", type=int, default=16)
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 d, C = args.d, args.chains
@@ -27,7 +28,7 @@ target = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcm
 if args.algo == "nuts":
     st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=args.burn, n_keep_draws=args.keep, n_adapt_draws=args.burn)
 else:
-    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=args.burn, n_keep_draws=args.keep, n_leap_steps=16, step_size=0.05)
+    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=args.burn, n_keep_draws=args.keep, n_leap_steps=args.leap, step_size=0.05)
 ch = mcmc_amd.make_chains(theta, C, draws=draws, n_accept=n_accept, n_leapfrogs=n_leap, step_size=eps, mem=mcmc_amd.MEM_DEVICE)
 stream = torch.cuda.current_stream().cuda_stream
 for rep in range(args.reps):
