@@ -1,0 +1,130 @@
+// hmc_diag.hpp -- many-chain HMC for separable Gaussian targets (iso / diagonal precision), any d.
+//
+// Replaces the draw loop of mcmc::internal::hmc_impl (/root/reference/src/hmc.cpp:155-205) for
+// targets without a contraction (BASELINE config 5: d = 1024 ill-conditioned diagonal Gaussian).
+// With a diagonal precision and the identity preconditioner every dimension's (theta_i, p_i)
+// trajectory is independent of the others through all L leapfrog steps; only the energies couple
+// them.  So: one lane per chain, the lane walks its d dimensions in blocks of 8 (= 4 Philox slots),
+// keeps 8 trajectories in flight for ILP, runs all L steps of each in registers and touches HBM once
+// per dimension per draw: read theta_i, write the proposal.  State is [d][C] (chain contiguous ->
+// coalesced), the proposal is written straight into the slab it will live in if accepted
+// (the kept-draw slab, or a ping-pong scratch slab during burn-in); a rejection copies instead.
+// Bound: fp64 VALU (5 ops per chain.dim.step, ~2 B of HBM per unit at L = 32), not HBM.
+//
+// Arithmetic identical to the oracle / the MFMA kernel: w_i = prec_i * theta_i, kicks p - (eps*w)/2,
+// drift theta + eps*p, dot products as 4 strided fma chains (dimension i -> chain i mod 4, ascending)
+// combined (q0+q2)+(q1+q3) -- all inside one lane, no cross-lane traffic.
+#pragma once
+
+#include "det_math.hpp"
+
+namespace mi {
+
+struct HmcDiagParams {
+    const double* prec;     // device, d precisions; nullptr = isotropic (all ones)
+    uint32_t d;
+    uint64_t C, chain0;
+    double* theta;          // [d][C] in/out
+    double* scratch;        // [2][d][C] ping-pong slabs
+    double* draws;          // [n_keep][d][C] or nullptr
+    uint64_t* n_accept;
+    uint64_t* n_leap;
+    uint64_t seed;
+    uint32_t n_burnin, n_keep, n_leap_steps;
+    double eps;
+};
+
+__global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= prm.C) return;
+    const uint64_t chain = prm.chain0 + c;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps;
+    const double* prec = prm.prec;
+    const uint32_t L = prm.n_leap_steps;
+    const size_t slab = (size_t)d * C;
+
+    const double* cur = prm.theta + c;                  // this chain's column of the slab holding prev_draw
+    // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
+    double prev_U;
+    {
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        for (uint32_t i = 0; i < d; ++i) {
+            const double t = cur[(size_t)i * C];
+            const double w = (prec ? prec[i] : 1.0) * t;
+            q[i & 3] = dfma(t, w, q[i & 3]);
+        }
+        prev_U = 0.5 * ((q[0] + q[2]) + (q[1] + q[3]));
+    }
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    uint32_t pp = 0;                                    // ping-pong index of the next free scratch slab
+
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        const bool kept = draw >= prm.n_burnin;
+        double* dst = (kept && prm.draws) ? prm.draws + (size_t)(draw - prm.n_burnin) * slab + c
+                                          : prm.scratch + (size_t)pp * slab + c;
+        if (dst == cur) { pp ^= 1u; dst = prm.scratch + (size_t)pp * slab + c; }   // never overwrite prev_draw
+        double qk0[4] = {0, 0, 0, 0}, qu1[4] = {0, 0, 0, 0}, qk1[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; b * 8 < d; ++b) {
+            double z[8], th[8], pm[8], lam[8], w[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rng_normal_pair(prm.seed, chain, draw, 4 * b + j, STREAM_NORMAL, z[j], z[4 + j]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t i = 8 * b + r;
+                const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
+                th[r] = cur[(size_t)ic * C];
+                lam[r] = prec ? prec[ic] : 1.0;
+                pm[r] = z[r];                                             // p = L z, L = I (hmc.cpp:158)
+                w[r] = lam[r] * th[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (8 * b + r < d) qk0[r & 3] = dfma(pm[r], pm[r], qk0[r & 3]);
+            for (uint32_t k = 0; k < L; ++k) {                            // hmc.cpp:164-176
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                    th[r] = th[r] + eps * pm[r];
+                    w[r] = lam[r] * th[r];
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t i = 8 * b + r;
+                if (i < d) {
+                    qu1[r & 3] = dfma(th[r], w[r], qu1[r & 3]);
+                    qk1[r & 3] = dfma(pm[r], pm[r], qk1[r & 3]);
+                    dst[(size_t)i * C] = th[r];
+                }
+            }
+        }
+        const double prev_K = ((qk0[0] + qk0[2]) + (qk0[1] + qk0[3])) / 2.0;   // hmc.cpp:160
+        double prop_U = 0.5 * ((qu1[0] + qu1[2]) + (qu1[1] + qu1[3]));         // :178
+        if (!is_finite(prop_U)) prop_U = INF;
+        const double prop_K = ((qk1[0] + qk1[2]) + (qk1[1] + qk1[3])) / 2.0;   // :184
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;
+        const double zu = rng_uniform(prm.seed, chain, draw, 0u);
+        const bool accept = zu < det_exp(comp_val);
+        if (accept) {
+            cur = dst;
+            prev_U = prop_U;
+            if (!(kept && prm.draws)) pp ^= 1u;
+        } else if (kept && prm.draws) {
+            for (uint32_t i = 0; i < d; ++i) dst[(size_t)i * C] = cur[(size_t)i * C];   // row = prev_draw (:202)
+            cur = dst;
+        }
+        if (kept) n_acc += accept ? 1u : 0u;
+    }
+    double* out = prm.theta + c;
+    if (cur != out)
+        for (uint32_t i = 0; i < d; ++i) out[(size_t)i * C] = cur[(size_t)i * C];
+    if (prm.n_accept) prm.n_accept[c] = n_acc;
+    if (prm.n_leap) prm.n_leap[c] = (uint64_t)n_total * L;
+}
+
+}  // namespace mi

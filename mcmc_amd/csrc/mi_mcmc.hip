@@ -20,6 +20,7 @@
 #include "nuts_dense.hpp"
 #include "mala_dense.hpp"
 #include "callback_mode.hpp"
+#include "hmc_diag.hpp"
 
 namespace {
 
@@ -212,8 +213,44 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     const uint64_t d = target->d;
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
-    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    const bool separable = target->kind != MI_TARGET_GAUSS_DENSE;
+    const bool force_diag = getenv("MI_HMC_FORCE_DIAG") != nullptr;          // tests: same bits from both kernels
+    if (d > 128 && !separable)
+        return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
+    if (separable && (d > 128 || force_diag)) {
+        // no contraction: the elementwise (lane-per-chain) kernel
+        DevBuf prec_owned;
+        const double* prec_dev = nullptr;
+        if (target->kind == MI_TARGET_GAUSS_DIAG) {
+            if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DIAG needs prec (d)");
+            if (target->mem == MI_MEM_DEVICE) prec_dev = target->prec;
+            else {
+                HIP_TRY(prec_owned.alloc(d * sizeof(double)));
+                HIP_TRY(hipMemcpy(prec_owned.p, target->prec, d * sizeof(double), hipMemcpyHostToDevice));
+                prec_dev = prec_owned.as<double>();
+            }
+        }
+        StagedChains sc;
+        rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        mi::HmcDiagParams q{};
+        q.prec = prec_dev; q.d = (uint32_t)d; q.C = chains->n_chains; q.chain0 = chains->chain0;
+        q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept; q.n_leap = sc.dev.n_leapfrogs;
+        q.seed = settings->rng_seed_value;
+        q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+        q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
+        void* scratch = nullptr;
+        HIP_TRY(hipMallocAsync(&scratch, 2 * d * chains->n_chains * sizeof(double), st));
+        q.scratch = static_cast<double*>(scratch);
+        hipLaunchKernelGGL(mi::hmc_diag_kernel, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+        HIP_TRY(hipGetLastError());
+        (void)hipFreeAsync(scratch, st);
+        rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        if (prec_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+        return MI_OK;
+    }
 
     DevBuf P_owned;
     const double* P_dev = nullptr;

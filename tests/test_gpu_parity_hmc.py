@@ -154,3 +154,45 @@ def test_unsupported_requests_fail_loudly():
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
         mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, np.zeros((4, 300)), st, prec=np.eye(300))
     assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- elementwise kernel (separable targets, any d)
+DIAG_CASES = [
+    # kind, d,    C,   L,  eps,    burn, keep
+    ("diag", 300, 100, 6, 0.01, 3, 5),        # d > 128 -> lane-per-chain kernel
+    ("iso", 1024, 33, 4, 0.05, 2, 3),         # BASELINE config 5 dimension
+    ("diag", 1024, 300, 32, 0.005, 1, 2),     # config 5 settings (eps 0.005, L 32, cond 1e4)
+    ("diag", 7, 10, 5, 0.10, 4, 9),           # ragged: d not a multiple of 8 (forced onto the diag kernel)
+]
+
+
+@pytest.mark.parametrize("kind,d,C,L,eps,burn,keep", DIAG_CASES)
+def test_hmc_elementwise_kernel_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep, monkeypatch):
+    monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
+    init = synth.initial_states(C, d, seed=12)
+    prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+    if kind == "diag":
+        prec, k_gpu, k_orc = synth.ill_conditioned_diag(d, 1.0e4), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+    st = mcmc_amd.default_settings(rng_seed_value=55, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps)
+    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=9)
+    o_draws, o = _oracle_many(k_orc, d, init, st, prec=prec, chain0=9)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert np.array_equal(g["theta"], o_draws[-1])
+    # draws discarded: same final state
+    t = mcmc_amd.make_target(k_gpu, d, prec=prec)
+    theta = np.ascontiguousarray(init.T)
+    c = mcmc_amd.make_chains(theta, C, chain0=9)
+    mcmc_amd.run("hmc", t, st, c)
+    assert np.array_equal(theta, o_draws[-1])
+
+
+def test_both_hmc_kernels_agree_bitwise_on_a_diagonal_target(monkeypatch):
+    d, C = 96, 80
+    init = synth.initial_states(C, d, seed=12)
+    prec = synth.ill_conditioned_diag(d, 100.0)
+    st = mcmc_amd.default_settings(rng_seed_value=8, n_burnin_draws=3, n_keep_draws=6, n_leap_steps=7, step_size=0.05)
+    a, ga = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec)          # MFMA kernel
+    monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
+    b, gb = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec)          # elementwise kernel
+    assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
