@@ -21,6 +21,7 @@
 #include "mala_dense.hpp"
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
+#include "mala_logistic.hpp"
 
 namespace {
 
@@ -132,6 +133,26 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     if (c->n_leapfrogs) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs, sc.dev.n_leapfrogs, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (c->nuts_depth) HIP_TRY(hipMemcpyAsync(c->nuts_depth, sc.dev.nuts_depth, n_total * C * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+template <int NTQ>
+int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+{
+    constexpr int NSQ = 4 * NTQ;
+    const size_t NB = prm.NB;
+    void *xe = nullptr, *xg = nullptr, *yp = nullptr;
+    HIP_TRY(hipMallocAsync(&xe, NB * 4 * NSQ * 64 * sizeof(double), st));
+    HIP_TRY(hipMallocAsync(&xg, NB * 4 * NTQ * 4 * 64 * sizeof(double), st));
+    HIP_TRY(hipMallocAsync(&yp, NB * 16 * sizeof(double), st));
+    hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
+                       prm.NB, static_cast<double*>(xe), static_cast<double*>(xg), static_cast<double*>(yp));
+    prm.XE = static_cast<const double*>(xe);
+    prm.XG = static_cast<const double*>(xg);
+    prm.ypad = static_cast<const double*>(yp);
+    hipLaunchKernelGGL(mi::mala_logistic_kernel<NTQ>, dim3((unsigned)((prm.C + 15) / 16)), dim3(256), 0, st, prm);
+    HIP_TRY(hipGetLastError());
+    (void)hipFreeAsync(xe, st); (void)hipFreeAsync(xg, st); (void)hipFreeAsync(yp, st);
     return MI_OK;
 }
 
@@ -306,10 +327,52 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound is not implemented on the device path yet");
     if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "mala: precond_mat is not implemented on the device path yet");
     const uint64_t d = target->d;
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
+    // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
+    const double s2_ = settings->step_size * settings->step_size;
+    double log_det_ = 0.0;
+    {
+        const double lii = __builtin_sqrt(s2_);
+        for (uint64_t i = 0; i < d; ++i) log_det_ = log_det_ + 2.0 * mi::det_log(lii);
+    }
+    if (target->kind == MI_TARGET_LOGISTIC) {
+        if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+        if (d > 512) return fail(MI_ERR_UNSUPPORTED, "mala: logistic target with d = %llu > 512 not implemented", (unsigned long long)d);
+        const uint64_t n = target->n_rows;
+        DevBuf Xo, yo;
+        const double *X_dev = target->X, *y_dev = target->y;
+        if (target->mem == MI_MEM_HOST) {
+            HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
+            HIP_TRY(hipMemcpyAsync(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice, st));
+            X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+        }
+        StagedChains sc;
+        rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        mi::MalaLogitParams q{};
+        q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
+        q.C = chains->n_chains; q.chain0 = chains->chain0;
+        q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
+        q.seed = settings->rng_seed_value;
+        q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+        q.eps = settings->step_size; q.s2 = s2_; q.rs = 1.0 / s2_;
+        q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
+        q.log_det = log_det_;
+        if (d <= 64) rc = launch_mala_logistic<1>(q, X_dev, y_dev, st);
+        else if (d <= 128) rc = launch_mala_logistic<2>(q, X_dev, y_dev, st);
+        else if (d <= 256) rc = launch_mala_logistic<4>(q, X_dev, y_dev, st);
+        else rc = launch_mala_logistic<8>(q, X_dev, y_dev, st);
+        if (rc) return rc;
+        rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+        return MI_OK;
+    }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "mala: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
-    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
 
     DevBuf P_owned;
     const double* P_dev = nullptr;

@@ -42,6 +42,20 @@ double orc_dot(const double* x, const double* y, size_t d, int W)
     return q[0];
 }
 
+/* dimension-blocked dot: ((B0 + B1) + B2) + ... with B_k = orc_dot over block k */
+double orc_dot_b(const double* x, const double* y, size_t d, int W, int nblk, size_t bs)
+{
+    if (nblk <= 1 || bs == 0) return orc_dot(x, y, d, W);
+    double r = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        const size_t lo = (size_t)k * bs;
+        const size_t len = (lo < d) ? ((d - lo < bs) ? d - lo : bs) : 0;
+        const double bk = orc_dot(x + (len ? lo : 0), y + (len ? lo : 0), len, W);
+        r = (k == 0) ? bk : r + bk;
+    }
+    return r;
+}
+
 static double orc_sum(const double* x, size_t n, int W)
 {
     if (W <= 1) {
@@ -142,6 +156,18 @@ static double orc_log_det_from_chol(const double* L, size_t d)
 
 /* stats_mcmc::dmvnorm(X, mu, Sigma, true)  (ref: include/stats/dmvnorm.hpp:28-54)
  * QUAD_FORM_INV(x,S) restated as dot(x, INV(S) x). */
+static int g_dummy_unused;
+static double orc_dmvnorm_core_b(const double* x, const double* mu, size_t d, const double* Sinv,
+                                 double log_det, int W, int nblk, size_t bs, double* xc, double* t)
+{
+    const double cons_term = -0.5 * (double)d * ORC_LOG_2PI;             /* dmvnorm.hpp:36 */
+    for (size_t i = 0; i < d; ++i) xc[i] = x[i] - mu[i];                 /* :37 */
+    orc_gemv(Sinv, xc, d, t);
+    const double quad_term = orc_dot_b(xc, t, d, W, nblk, bs);           /* :39 */
+    (void)g_dummy_unused;
+    return cons_term - 0.5 * (log_det + quad_term);                      /* :41 */
+}
+
 static double orc_dmvnorm_core(const double* x, const double* mu, size_t d, const double* Sinv,
                                double log_det, int W, double* xc, double* t)
 {
@@ -281,17 +307,19 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
     orc_target* t = (orc_target*)data;
     const size_t d = t->d;
     const int W = t->reduce_width;
+    const int nblk = t->reduce_blocks;
+    const size_t bs = t->reduce_block_size;
     if (grad_out) t->n_grad_calls++; else t->n_value_calls++;
     switch (t->kind) {
     case ORC_TARGET_GAUSS_ISO: {
         if (grad_out) for (size_t i = 0; i < d; ++i) grad_out[i] = -th[i];
-        return -0.5 * orc_dot(th, th, d, W);
+        return -0.5 * orc_dot_b(th, th, d, W, nblk, bs);
     }
     case ORC_TARGET_GAUSS_DIAG: {
         double* w = (double*)malloc(d * sizeof(double));
         for (size_t i = 0; i < d; ++i) w[i] = t->prec[i] * th[i];
         if (grad_out) for (size_t i = 0; i < d; ++i) grad_out[i] = -w[i];
-        const double r = -0.5 * orc_dot(th, w, d, W);
+        const double r = -0.5 * orc_dot_b(th, w, d, W, nblk, bs);
         free(w);
         return r;
     }
@@ -299,7 +327,7 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
         double* w = (double*)malloc(d * sizeof(double));
         orc_gemv(t->prec, th, d, w);
         if (grad_out) for (size_t i = 0; i < d; ++i) grad_out[i] = -w[i];
-        const double r = -0.5 * orc_dot(th, w, d, W);
+        const double r = -0.5 * orc_dot_b(th, w, d, W, nblk, bs);
         free(w);
         return r;
     }
@@ -312,12 +340,20 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
         for (size_t r = 0; r < n; ++r) {
             double acc = 0.0;
             const double* x = t->X + r * d;
-            for (size_t j = 0; j < d; ++j) acc = fma(x[j], th[j], acc);
+            if (nblk <= 1 || bs == 0) {
+                for (size_t j = 0; j < d; ++j) acc = fma(x[j], th[j], acc);
+            } else {                     /* ((e0 + e1) + e2) + ...: one fma chain per dimension block */
+                for (int k = 0; k < nblk; ++k) {
+                    double e = 0.0;
+                    for (size_t j = (size_t)k * bs; j < d && j < (size_t)(k + 1) * bs; ++j) e = fma(x[j], th[j], e);
+                    acc = (k == 0) ? e : acc + e;
+                }
+            }
             eta[r] = acc;
             term[r] = t->y[r] * acc - orc_softplus(acc);
         }
         const double ll = orc_sum(term, n, W);
-        const double ret = ll - 0.5 * orc_dot(th, th, d, W);
+        const double ret = ll - 0.5 * orc_dot_b(th, th, d, W, nblk, bs);
         if (grad_out) {
             for (size_t r = 0; r < n; ++r) term[r] = t->y[r] - orc_sigmoid(eta[r]);
             for (size_t j = 0; j < d; ++j) {
@@ -347,6 +383,8 @@ typedef struct orc_ctx {
     double* inv_precond;
     double* sqrt_precond;
     int W;
+    int nblk;
+    size_t bs;
     uint64_t seed, chain;
     uint64_t n_leap;
 } orc_ctx;
@@ -359,6 +397,7 @@ static void ctx_init(orc_ctx* c, size_t d, orc_kernel_fn kernel, void* data, con
     c->d = d; c->kernel = kernel; c->data = data;
     c->vals_bound = s->vals_bound; c->lb = s->lower_bounds; c->ub = s->upper_bounds;
     c->W = s->reduce_width > 0 ? s->reduce_width : 1;
+    c->nblk = s->reduce_blocks; c->bs = s->reduce_block_size;
     c->seed = s->rng_seed_value; c->chain = s->chain_id;
     /* ref: src/hmc.cpp:57-59 -- user matrix if it has d*d elements, else identity; dense either way */
     c->precond = dvec(d * d);
@@ -433,7 +472,7 @@ static double kinetic(orc_ctx* c, const double* mntm)
 {
     double* mp = dvec(c->d);
     orc_gemv(c->inv_precond, mntm, c->d, mp);
-    const double k = orc_dot(mntm, mp, c->d, c->W) / 2.0;
+    const double k = orc_dot_b(mntm, mp, c->d, c->W, c->nblk, c->bs) / 2.0;
     free(mp);
     return k;
 }
@@ -576,22 +615,22 @@ static double mala_prop_adjustment(orc_ctx* c, const double* prop_vals, const do
         for (size_t i = 0; i < d * d; ++i) Sigma[i] = s2 * Sigma[i];
         /* the reference factorises inside each dmvnorm call; bits are the same */
         mala_fact f; mala_factorise(Sigma, d, &f);
-        ret = orc_dmvnorm_core(prev_vals, prop_mean, d, f.Sinv, f.log_det, c->W, scratch, scratch + d)
-            - orc_dmvnorm_core(prop_vals, prev_mean, d, f.Sinv, f.log_det, c->W, scratch, scratch + d);
+        ret = orc_dmvnorm_core_b(prev_vals, prop_mean, d, f.Sinv, f.log_det, c->W, c->nblk, c->bs, scratch, scratch + d)
+            - orc_dmvnorm_core_b(prop_vals, prev_mean, d, f.Sinv, f.log_det, c->W, c->nblk, c->bs, scratch, scratch + d);
         free(f.Sinv); free(Jprop); free(Jprev);
     } else {
         mala_mean(c, prop_vals, step, NULL, prop_mean);                 /* :60 */
         mala_mean(c, prev_vals, step, NULL, prev_mean);                 /* :61 */
         if (hoisted) {
-            ret = orc_dmvnorm_core(prev_vals, prop_mean, d, hoisted->Sinv, hoisted->log_det, c->W, scratch, scratch + d)
-                - orc_dmvnorm_core(prop_vals, prev_mean, d, hoisted->Sinv, hoisted->log_det, c->W, scratch, scratch + d);
+            ret = orc_dmvnorm_core_b(prev_vals, prop_mean, d, hoisted->Sinv, hoisted->log_det, c->W, c->nblk, c->bs, scratch, scratch + d)
+                - orc_dmvnorm_core_b(prop_vals, prev_mean, d, hoisted->Sinv, hoisted->log_det, c->W, c->nblk, c->bs, scratch, scratch + d);
         } else {
             for (size_t i = 0; i < d * d; ++i) Sigma[i] = s2 * c->precond[i];
             mala_fact f1; mala_factorise(Sigma, d, &f1);                /* :63 (inside dmvnorm) */
-            const double a = orc_dmvnorm_core(prev_vals, prop_mean, d, f1.Sinv, f1.log_det, c->W, scratch, scratch + d);
+            const double a = orc_dmvnorm_core_b(prev_vals, prop_mean, d, f1.Sinv, f1.log_det, c->W, c->nblk, c->bs, scratch, scratch + d);
             free(f1.Sinv);
             mala_fact f2; mala_factorise(Sigma, d, &f2);                /* :64 (inside dmvnorm) */
-            const double b = orc_dmvnorm_core(prop_vals, prev_mean, d, f2.Sinv, f2.log_det, c->W, scratch, scratch + d);
+            const double b = orc_dmvnorm_core_b(prop_vals, prev_mean, d, f2.Sinv, f2.log_det, c->W, c->nblk, c->bs, scratch, scratch + d);
             free(f2.Sinv);
             ret = a - b;
         }
@@ -781,8 +820,8 @@ static void nuts_build_tree(orc_ctx* c, int direction_val, double step_size, dou
             n_alpha_p_val += n_alpha_pp_val;
             double* diff = dvec(d);
             for (size_t i = 0; i < d; ++i) diff[i] = new_draw_pos[i] - new_draw_neg[i];
-            const int check_val_1 = orc_dot(diff, new_mntm_neg, d, c->W) >= 0.0;            /* :226 */
-            const int check_val_2 = orc_dot(diff, new_mntm_pos, d, c->W) >= 0.0;            /* :227 */
+            const int check_val_1 = orc_dot_b(diff, new_mntm_neg, d, c->W, c->nblk, c->bs) >= 0.0;            /* :226 */
+            const int check_val_2 = orc_dot_b(diff, new_mntm_pos, d, c->W, c->nblk, c->bs) >= 0.0;            /* :227 */
             s_p_val = s_pp_val * (size_t)check_val_1 * (size_t)check_val_2;                 /* :229 */
             free(diff); free(new_draw_pp); free(dummy_draw); free(dummy_mntm); free(edge_draw); free(edge_mntm);
         }
@@ -887,8 +926,8 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
             n_val += n_p_val;                                           /* :283 */
             tree_depth += 1;
             for (size_t i = 0; i < d; ++i) diff[i] = draw_pos[i] - draw_neg[i];
-            const int check_val_1 = orc_dot(diff, mntm_neg, d, c.W) >= 0.0;             /* :286 */
-            const int check_val_2 = orc_dot(diff, mntm_pos, d, c.W) >= 0.0;             /* :287 */
+            const int check_val_1 = orc_dot_b(diff, mntm_neg, d, c.W, c.nblk, c.bs) >= 0.0;             /* :286 */
+            const int check_val_2 = orc_dot_b(diff, mntm_pos, d, c.W, c.nblk, c.bs) >= 0.0;             /* :287 */
             s_val = s_p_val * (size_t)check_val_1 * (size_t)check_val_2;                /* :289 */
         }
 

@@ -51,6 +51,8 @@ typedef struct orc_target {
     const double* y;         /* LOGISTIC: n_rows labels in {0,1} */
     size_t        n_rows;
     int           reduce_width;  /* W of orc_dot used inside the target (see below) */
+    int           reduce_blocks; /* >1: dimension-blocked reductions (see orc_dot_b), block size reduce_block_size */
+    size_t        reduce_block_size;
     uint64_t      n_grad_calls;  /* instrumentation */
     uint64_t      n_value_calls;
 } orc_target;
@@ -76,6 +78,10 @@ typedef struct orc_settings {
     double   gamma_val, t0_val, kappa_val;
     /* oracle-only knobs */
     int      reduce_width;        /* W: number of strided partial sums in dot products (1,4,64,...) */
+    int      reduce_blocks;       /* >1: dot products are ((B0+B1)+B2)+... over contiguous dimension blocks of
+                                     reduce_block_size, each block an orc_dot of width W (the order of a kernel that
+                                     splits the dimensions of a chain over several wavefronts) */
+    size_t   reduce_block_size;
     int      hoist_factorizations;/* mala: 0 = factorise eps^2 M inside every dmvnorm call as the
                                      reference does (mala.ipp:63-64); 1 = once (same bits) */
     uint64_t chain_id;            /* Philox counter word: global chain index */
@@ -110,6 +116,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
 
 /* exported pieces for unit tests */
 double orc_dot(const double* x, const double* y, size_t d, int W);
+double orc_dot_b(const double* x, const double* y, size_t d, int W, int nblk, size_t bs);
 void   orc_gemv(const double* A /*row-major d x d*/, const double* x, size_t d, double* y);
 int    orc_inv(const double* A, size_t d, double* Ainv);
 int    orc_chol_lower(const double* A, size_t d, double* L);

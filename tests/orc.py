@@ -15,7 +15,8 @@ _dp = C.POINTER(C.c_double)
 
 class Target(C.Structure):
     _fields_ = [("kind", C.c_int), ("d", C.c_size_t), ("prec", _dp), ("X", _dp), ("y", _dp),
-                ("n_rows", C.c_size_t), ("reduce_width", C.c_int),
+                ("n_rows", C.c_size_t), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
+                ("reduce_block_size", C.c_size_t),
                 ("n_grad_calls", C.c_uint64), ("n_value_calls", C.c_uint64)]
 
 
@@ -26,7 +27,8 @@ class Settings(C.Structure):
                 ("n_leap_steps", C.c_size_t), ("step_size", C.c_double), ("precond_mat", _dp),
                 ("n_adapt_draws", C.c_size_t), ("target_accept_rate", C.c_double),
                 ("max_tree_depth", C.c_size_t), ("gamma_val", C.c_double), ("t0_val", C.c_double),
-                ("kappa_val", C.c_double), ("reduce_width", C.c_int),
+                ("kappa_val", C.c_double), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
+                ("reduce_block_size", C.c_size_t),
                 ("hoist_factorizations", C.c_int), ("chain_id", C.c_uint64)]
 
 
@@ -63,11 +65,11 @@ def _f64(a):
 class TargetSpec:
     """Holds the numpy buffers alive next to the C struct."""
 
-    def __init__(self, kind, d, prec=None, X=None, y=None, W=4):
+    def __init__(self, kind, d, prec=None, X=None, y=None, W=4, blocks=0, block_size=0):
         self.kind, self.d, self.W = kind, int(d), W
         self.prec, self.X, self.y = _f64(prec), _f64(X), _f64(y)
         self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y),
-                        0 if self.X is None else self.X.shape[0], W, 0, 0)
+                        0 if self.X is None else self.X.shape[0], W, blocks, block_size, 0, 0)
 
     def kernel(self, theta, want_grad=True):
         theta = _f64(theta)
@@ -78,11 +80,11 @@ class TargetSpec:
 
 def make_settings(seed=1, n_burnin=0, n_keep=10, n_leap=1, step=1.0, precond=None, n_adapt=1000,
                   delta=0.55, max_depth=10, gamma=0.05, t0=10.0, kappa=0.75, W=4, hoist=1, chain_id=0,
-                  lower=None, upper=None):
+                  lower=None, upper=None, blocks=0, block_size=0):
     keep = dict(precond=_f64(precond), lower=_f64(lower), upper=_f64(upper))
     s = Settings(seed, 0 if lower is None else 1, _p(keep["lower"]), _p(keep["upper"]),
                  n_burnin, n_keep, n_leap, step, _p(keep["precond"]), n_adapt, delta, max_depth,
-                 gamma, t0, kappa, W, hoist, chain_id)
+                 gamma, t0, kappa, W, blocks, block_size, hoist, chain_id)
     s._keep = keep
     return s
 

@@ -49,3 +49,48 @@ def test_mala_rejects_and_samples_the_target():
     last = draws[-1]
     cov = last @ last.T / C
     assert abs(np.trace(cov) / np.trace(np.linalg.inv(prec)) - 1) < 0.1
+
+
+# ---------------------------------------------------------------- logistic-regression target (BASELINE config 3)
+LOGIT_CASES = [
+    # d,   N,    C,  eps,   burn, keep
+    (5, 40, 16, 0.10, 5, 20),        # SURVEY 8(c) golden shape "logistic d=5"
+    (64, 100, 20, 0.05, 3, 8),       # one tile per wave, ragged N and C
+    (100, 333, 40, 0.03, 2, 6),      # d_pad 128, ragged everything
+    (512, 1024, 32, 0.02, 2, 4),     # config 3 dimensions
+    (300, 64, 17, 0.20, 0, 10),      # big step: rejections
+]
+
+
+def _blocks(d):
+    dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    return 4, dq
+
+
+@pytest.mark.parametrize("d,N,C,eps,burn,keep", LOGIT_CASES)
+def test_mala_logistic_bit_exact_vs_oracle(d, N, C, eps, burn, keep):
+    X, y = synth.logistic_problem(d, N, seed=4)
+    init = synth.initial_states(C, d, seed=41) * 0.1
+    st = mcmc_amd.default_settings(rng_seed_value=123, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=3)
+    nb, bs = _blocks(d)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=nb, block_size=bs)
+    s = orc.make_settings(seed=123, n_burnin=burn, n_keep=keep, step=eps, W=4, hoist=1, blocks=nb, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s, chain0=3)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert np.linalg.norm(g_draws - o_draws) <= 1e-9 * np.linalg.norm(o_draws)
+
+
+def test_mala_logistic_posterior_is_sane():
+    d, N, C = 8, 400, 2048
+    X, y = synth.logistic_problem(d, N, seed=9)
+    init = np.zeros((C, d))
+    st = mcmc_amd.default_settings(rng_seed_value=2, n_burnin_draws=300, n_keep_draws=20, step_size=0.25)
+    draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    assert 0.3 < g["n_accept"].mean() / 20 < 0.999
+    post_mean = draws[-1].mean(axis=1)
+    # the posterior mean is close to the mode: gradient of log K at it is near zero relative to the prior scale
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y)
+    _, grad = t.kernel(post_mean)
+    assert np.abs(grad).max() < 2.0
