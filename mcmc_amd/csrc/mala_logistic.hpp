@@ -27,6 +27,13 @@
 
 #include "hmc_dense.hpp"
 
+#ifndef MI_LOGIT_EXTRA_NOPS
+#define MI_LOGIT_EXTRA_NOPS 0
+#endif
+#ifndef MI_LOGIT_PREFETCH
+#define MI_LOGIT_PREFETCH 1
+#endif
+
 namespace mi {
 
 struct MalaLogitParams {
@@ -121,10 +128,14 @@ __global__ __launch_bounds__(256, 1) void mala_logistic_kernel(const MalaLogitPa
 #pragma unroll 1
         for (uint32_t b = 0; b < NB; ++b) {
             const int buf = (int)(b & 1u);
+            if (!MI_LOGIT_PREFETCH && b > 0) { load_xe(b); load_xg(b); }
             double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < NSQ; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[s], x[s], acc, 0, 0, 0);
-            if (b + 1 < NB) load_xe(b + 1);
+            if (MI_LOGIT_PREFETCH && b + 1 < NB) load_xe(b + 1);
+#if MI_LOGIT_EXTRA_NOPS
+            asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
             lds_part[buf][q][0][lane] = acc[0]; lds_part[buf][q][1][lane] = acc[1];
             lds_part[buf][q][2][lane] = acc[2]; lds_part[buf][q][3][lane] = acc[3];
             __syncthreads();
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void mala_logistic_kernel(const MalaLogitPa
                 for (int sp = 0; sp < 4; ++sp)
                     gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[t * 4 + sp], res[sp], gacc[t], 0, 0, 0);
             }
-            if (b + 1 < NB) load_xg(b + 1);
+            if (MI_LOGIT_PREFETCH && b + 1 < NB) load_xg(b + 1);
         }
         llq = llq + __shfl_xor(llq, 32);
         llq = llq + __shfl_xor(llq, 16);

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,6 +55,29 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
+
+// Per-(device, stream) grow-only workspace.  Kernels of one stream are ordered, so the same buffer can
+// serve consecutive calls; it is reallocated (after a stream sync) only when a call needs more.
+// (hipMallocAsync / hipFreeAsync pool memory was observed to hand the pack -> sample kernel pair of the
+// logistic path buffers whose first blocks read back as zeros; a plain cached hipMalloc does not.)
+struct WsEntry { void* p = nullptr; size_t cap = 0; };
+std::mutex g_ws_mu;
+std::map<std::pair<int, hipStream_t>, WsEntry> g_ws;
+
+int ws_get(hipStream_t st, size_t bytes, void** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    WsEntry& w = g_ws[std::make_pair(dev, st)];
+    if (w.cap < bytes) {
+        if (w.p) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(w.p)); w.p = nullptr; w.cap = 0; }
+        HIP_TRY(hipMalloc(&w.p, bytes));
+        w.cap = bytes;
+    }
+    *out = w.p;
+    return MI_OK;
+}
 
 int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
 {
@@ -141,18 +166,21 @@ int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const do
 {
     constexpr int NSQ = 4 * NTQ;
     const size_t NB = prm.NB;
-    void *xe = nullptr, *xg = nullptr, *yp = nullptr;
-    HIP_TRY(hipMallocAsync(&xe, NB * 4 * NSQ * 64 * sizeof(double), st));
-    HIP_TRY(hipMallocAsync(&xg, NB * 4 * NTQ * 4 * 64 * sizeof(double), st));
-    HIP_TRY(hipMallocAsync(&yp, NB * 16 * sizeof(double), st));
+    const size_t n_xe = NB * 4 * NSQ * 64, n_xg = NB * 4 * NTQ * 4 * 64, n_yp = NB * 16;
+    void* base = nullptr;
+    int rcw = ws_get(st, (n_xe + n_xg + n_yp) * sizeof(double), &base);
+    if (rcw) return rcw;
+    void* xe = base;
+    void* xg = static_cast<double*>(base) + n_xe;
+    void* yp = static_cast<double*>(base) + n_xe + n_xg;
     hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
                        prm.NB, static_cast<double*>(xe), static_cast<double*>(xg), static_cast<double*>(yp));
     prm.XE = static_cast<const double*>(xe);
     prm.XG = static_cast<const double*>(xg);
     prm.ypad = static_cast<const double*>(yp);
+
     hipLaunchKernelGGL(mi::mala_logistic_kernel<NTQ>, dim3((unsigned)((prm.C + 15) / 16)), dim3(256), 0, st, prm);
     HIP_TRY(hipGetLastError());
-    (void)hipFreeAsync(xe, st); (void)hipFreeAsync(xg, st); (void)hipFreeAsync(yp, st);
     return MI_OK;
 }
 
@@ -262,11 +290,11 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
         q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
         void* scratch = nullptr;
-        HIP_TRY(hipMallocAsync(&scratch, 2 * d * chains->n_chains * sizeof(double), st));
+        rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), &scratch);
+        if (rc) return rc;
         q.scratch = static_cast<double*>(scratch);
         hipLaunchKernelGGL(mi::hmc_diag_kernel, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
-        (void)hipFreeAsync(scratch, st);
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
         if (prec_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -290,7 +318,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
     void* wsave = nullptr;
     const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    HIP_TRY(hipMallocAsync(&wsave, 2 * d_pad_h * chains->n_chains * sizeof(double), st));
+    rc = ws_get(st, 2 * d_pad_h * chains->n_chains * sizeof(double), &wsave);
+    if (rc) return rc;
     prm.wsave = static_cast<double*>(wsave);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
@@ -309,7 +338,6 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     else if (nt == 2) rc = launch_hmc_mfma<2>(prm, st);
     else if (nt <= 4) rc = launch_hmc_mfma<4>(prm, st);
     else rc = launch_hmc_mfma<8>(prm, st);
-    (void)hipFreeAsync(wsave, st);
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -344,8 +372,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         const double *X_dev = target->X, *y_dev = target->y;
         if (target->mem == MI_MEM_HOST) {
             HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
-            HIP_TRY(hipMemcpyAsync(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
             X_dev = Xo.as<double>(); y_dev = yo.as<double>();
         }
         StagedChains sc;
@@ -451,8 +479,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.theta = sc.dev.theta;
     void* ws = nullptr;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    HIP_TRY(hipMallocAsync(&ws, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), st));
-    HIP_TRY(hipMemsetAsync(ws, 0, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), st));
+    rc = ws_get(st, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), &ws);
+    if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = static_cast<double*>(ws);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
@@ -475,7 +503,6 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     else if (nt == 2) rc = launch_nuts_mfma<2>(prm, st);
     else if (nt <= 4) rc = launch_nuts_mfma<4>(prm, st);
     else rc = launch_nuts_mfma<8>(prm, st);
-    (void)hipFreeAsync(ws, st);
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
