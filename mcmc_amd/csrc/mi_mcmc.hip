@@ -20,6 +20,7 @@
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
+#include "nuts_async.hpp"
 #include "mala_dense.hpp"
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
@@ -200,10 +201,19 @@ template <int NT>
 int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 {
     const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double);
-    auto kern = mi::nuts_gauss_mfma_kernel<NT>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    if (getenv("MI_NUTS_LOCKSTEP")) {           // first-generation kernel: chains of a wave in lock-step per draw
+        auto kern = mi::nuts_gauss_mfma_kernel<NT>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    } else {
+        uint32_t batch = 2;
+        if (const char* e = getenv("MI_NUTS_BATCH")) batch = (uint32_t)atoi(e);
+        if (batch < 1) batch = 1;
+        auto kern = mi::nuts_gauss_async_kernel<NT>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm, batch);
+    }
     HIP_TRY(hipGetLastError());
     return MI_OK;
 }
@@ -479,7 +489,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.theta = sc.dev.theta;
     void* ws = nullptr;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, (size_t)mi::NUTS_NVEC * d_pad * chains->n_chains * sizeof(double), &ws);
+    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * chains->n_chains * sizeof(double), &ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = static_cast<double*>(ws);
     prm.draws = sc.dev.draws;

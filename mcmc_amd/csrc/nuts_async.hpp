@@ -1,0 +1,408 @@
+// nuts_async.hpp -- many-chain NUTS, asynchronous per-chain state machine (the production NUTS kernel).
+//
+// Same algorithm, arithmetic and workspace layout as nuts_dense.hpp (see the derivation of the
+// iterative tree there; reference: /root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241),
+// but the 16 chains of a wavefront no longer wait for each other at draw or doubling boundaries.
+// Every chain carries its own (draw, doubling depth j, leaf index i, direction, step size, RNG slot);
+// one "tick" of the wave = one leapfrog (one MFMA mat-vec) for every chain that is inside a tree,
+// each on its own state.  Tree sizes differ by up to 2^9 leapfrogs between chains and draws
+// (measured: lock-step per draw keeps only 17 % of the lanes busy at BASELINE config 4); here a chain
+// that finishes its tree starts its next doubling / next draw on the following tick.
+// Momentum refresh (16 Philox blocks + Box-Muller per lane) is batched: chains wait at the draw
+// boundary until `refresh_batch` of them are waiting (or nothing else can run).
+// P*theta of every pending proposal is stored next to it, so accepting a proposal needs no extra
+// mat-vec at the next doubling.
+#pragma once
+
+#include "nuts_dense.hpp"
+
+namespace mi {
+
+enum : int { V_PPW0 = 52, NUTS_NVEC_ASYNC = 64 };   // P*theta of the pending proposal of level l at 52 + l
+enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
+{
+    constexpr int NS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds_P = lds_all;
+    double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
+    stage_precision<NT>(prm.P, prm.d, lds_P);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j4 = lane >> 4;
+    const int cw = wave * 16 + (lane & 15);
+    const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const bool live = cl < prm.C;
+    const uint64_t cld = live ? cl : prm.C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double* afrag = lds_P + lane;
+    const size_t lane_off = (size_t)j4 * C + cld;
+    const size_t vstride = (size_t)(16 * NT) * C;
+
+    auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
+    auto wsp = [&](int v, int s) -> double* { return prm.ws + (size_t)v * vstride + (size_t)(4 * s) * C + lane_off; };
+    auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
+
+    double th[NS], pm[NS], w[NS];
+
+    auto load_vec = [&](int v, double (&x)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
+    };
+    // x <- ws[v] for lanes with pred, unchanged otherwise (v may be any valid id on the other lanes)
+    auto load_vec_if = [&](int v, double (&x)[NS], bool pred) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { const double t = *wsp(v, s); x[s] = pred ? t : x[s]; }
+    };
+    auto store_vec = [&](int v, const double (&x)[NS], bool pred) __attribute__((always_inline)) {
+        if (pred && live) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *wsp(v, s) = x[s];
+        }
+    };
+    auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
+        double tmp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(vsrc, s);
+        if (pred && live) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *wsp(vdst, s) = tmp[s];
+        }
+    };
+    auto leapfrog = [&](double e) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            pm[s] = pm[s] - (e * w[s]) / 2.0;
+            th[s] = th[s] + e * pm[s];
+        }
+        matvec_mfma<NT>(afrag, th, w);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
+    };
+    auto potential = [&]() __attribute__((always_inline)) -> double {
+        double u = 0.5 * dot4<NS>(th, w);
+        if (!is_finite(u)) u = INF;
+        return u;
+    };
+    auto kinetic = [&]() __attribute__((always_inline)) -> double { return dot4<NS>(pm, pm) / 2.0; };
+    // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1
+    auto uturn_ok = [&](int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
+        double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double t1 = *wsp(vt1, s);
+            const double p1 = *wsp(vp1, s);
+            const double t2 = n2_in_regs ? th[s] : *wsp(vt2, s);
+            const double p2 = n2_in_regs ? pm[s] : *wsp(vp2, s);
+            const double dd = (vdir > 0) ? (t2 - t1) : (t1 - t2);
+            q1 = dfma(dd, p1, q1);
+            q2 = dfma(dd, p2, q2);
+        }
+        q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
+        q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
+        return (q1 >= 0.0) && (q2 >= 0.0);
+    };
+
+    // ---------------------------------------------------------------- setup (nuts.cpp:156-195), all chains together
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dimc = dim_ok(s) ? (uint32_t)(4 * s + j4) : 0u;
+        const double v = prm.theta[(size_t)dimc * C + cld];
+        th[s] = dim_ok(s) ? v : 0.0;
+    }
+    matvec_mfma<NT>(afrag, th, w);
+    store_vec(V_PREV, th, true);
+    store_vec(V_WPREV, w, true);
+    double prev_U = 0.5 * dot4<NS>(th, w);               // nuts.cpp:181
+
+    uint64_t n_leap = 0;
+    double eps;
+    {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, L z_init), nuts.cpp:166-172
+#pragma unroll
+        for (int b = 0; b < NS / 2; ++b) {
+            double z0, z1;
+            rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
+            pm[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
+            pm[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double U0 = prev_U;
+        if (!is_finite(U0)) U0 = INF;
+        const double K0 = kinetic();
+        const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
+        eps = 1.0;
+        leapfrog(eps);
+        n_leap++;
+        double dH = -(potential() + kinetic()) + (U0 + K0);
+        int a_val = 2 * (dH > log_half ? 1 : 0) - 1;
+        bool cond = dH > neg_log2;
+        while (__ballot(cond) != 0ull) {
+            const double e_new = eps * ((a_val == 1) ? 2.0 : 0.5);
+            if (cond) { eps = e_new; n_leap++; }
+            leapfrog(eps);
+            const double dH2 = -(potential() + kinetic()) + (U0 + K0);
+            if (cond) {
+                a_val = 2 * (dH2 > log_half ? 1 : 0) - 1;
+                cond = dH2 > neg_log2;
+            }
+        }
+    }
+    const double mu_val = det_log(10 * eps);             // nuts.cpp:174
+    double h_val = 0.0;
+    double eps_bar = prm.eps_bar0;
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const uint32_t n_adapt = prm.n_adapt <= n_total ? prm.n_adapt : n_total;
+    const uint32_t max_depth = prm.max_depth;
+
+    // ---------------------------------------------------------------- per-chain state
+    int state = (n_total > 0) ? NS_NEED_DRAW : NS_DONE;
+    uint32_t draw = 0;           // this chain's draw index
+    uint32_t jd = 0;             // depth of the doubling in progress
+    uint32_t li = 0;             // next leaf of that doubling
+    uint32_t uslot = 0;
+    int vdir = 1;
+    double e_signed = 0.0, H0 = 0.0, prev_K = 0.0, log_u = 0.0, n_val = 1.0;
+    double alpha_val = 0.0, n_alpha_val = 0.0;
+    int good_round = 0;
+
+    // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
+    auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
+        const double zdir = rng_uniform(prm.seed, chain, draw, uslot);
+        if (p) {
+            uslot++;
+            vdir = (zdir <= 0.5) ? -1 : 1;
+            e_signed = (double)vdir * eps;
+            H0 = prev_U + prev_K;
+            li = 0;
+        }
+    };
+    // end of a draw (dual averaging nuts.cpp:294-302, row store :306-309) for lanes with `p`
+    auto finish_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
+        if (__ballot(p) == 0ull) return;
+        if (p && prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
+        if (p) {
+            if (draw < n_adapt) {
+                const double it = (double)(draw + 1);
+                h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
+                eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
+                eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
+            } else {
+                eps = eps_bar;
+            }
+        }
+        const bool kept = p && draw >= prm.n_burnin;
+        if (kept) n_acc += (uint64_t)good_round;
+        if (__ballot(kept && prm.draws != nullptr) != 0ull) {
+            double tmp[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
+            if (kept && prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (dim_ok(s)) (out + (size_t)(4 * s) * C)[lane_off] = tmp[s];
+            }
+        }
+        if (p) {
+            draw++;
+            state = (draw < n_total) ? NS_NEED_DRAW : NS_DONE;
+        }
+    };
+
+#pragma unroll 1
+    while (__ballot(state != NS_DONE) != 0ull) {
+        // ------------------------------------------------------------ A. momentum refresh for waiting chains
+        const unsigned n_wait = __popcll(__ballot(state == NS_NEED_DRAW)) / 4;
+        const unsigned n_run = __popcll(__ballot(state == NS_TREE)) / 4;
+        if (n_wait >= refresh_batch || (n_run == 0 && n_wait > 0)) {
+            const bool p = state == NS_NEED_DRAW;
+            double pnew[NS];
+#pragma unroll
+            for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
+                double z0, z1;
+                rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+                pnew[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
+                pnew[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const double kk = dot4<NS>(pnew, pnew) / 2.0;     // :204
+            const double lu = det_log(rng_uniform(prm.seed, chain, draw, 0u));
+            store_vec(V_MNTM, pnew, p);
+            store_vec(V_TPOS_P, pnew, p);                     // :212-215
+            store_vec(V_TNEG_P, pnew, p);
+            copy_vec(V_PREV, V_TPOS_T, p);
+            copy_vec(V_PREV, V_TNEG_T, p);
+            if (p) {
+                prev_K = kk;
+                log_u = lu - prev_U - prev_K;                 // :206
+                uslot = 1;
+                jd = 0; n_val = 1.0; alpha_val = 0.0; n_alpha_val = 0.0; good_round = 0;
+                state = NS_TREE;
+            }
+            if (max_depth > 0) begin_doubling(p);
+            else finish_draw(p, 0u);                          // while-loop of :227 never entered
+        }
+        const bool run = state == NS_TREE;
+        if (__ballot(run) == 0ull) continue;
+
+        // ------------------------------------------------------------ B. one leaf for every running chain
+        {   // start state of leaf li (per chain)
+            const int cz = (li == 0) ? 0 : __builtin_ctz(li);
+            const bool from_prev = run && li == 0;
+            const bool from_slot = run && li != 0 && cz >= 2;
+            if (__ballot(from_prev || from_slot) != 0ull) {
+                const int vt = from_prev ? V_PREV : (from_slot ? V_LEAF0 + 3 * cz : V_PREV);
+                const int vp = from_prev ? V_MNTM : (from_slot ? V_LEAF0 + 3 * cz + 1 : V_MNTM);
+                const int vw = from_prev ? V_WPREV : (from_slot ? V_LEAF0 + 3 * cz + 2 : V_WPREV);
+                load_vec_if(vt, th, from_prev || from_slot);
+                load_vec_if(vp, pm, from_prev || from_slot);
+                load_vec_if(vw, w, from_prev || from_slot);
+            }
+        }
+        leapfrog(e_signed);                              // nuts.ipp:132 (idle chains: harmless garbage)
+        const double pU = potential();
+        const double pK = kinetic();
+        double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
+        const bool cs = log_u < 1000.0 - pU - pK;        // :147
+        const double dd = -(pU + pK) + H0;
+        double ca = det_exp((dd < 0.0) ? dd : 0.0);      // :157
+        double cna = 1.0;
+        double cU = pU;
+        int cref = -1;
+        if (run) n_leap++;
+        {
+            const bool st_leaf = run && (((li & 1u) == 0u) || jd == 1u);
+            if (__ballot(st_leaf) != 0ull) {
+                const int slot = (li == 0) ? 0 : (__builtin_ctz(li) + 1);
+                store_vec(V_LEAF0 + 3 * slot, th, st_leaf);
+                store_vec(V_LEAF0 + 3 * slot + 1, pm, st_leaf);
+                store_vec(V_LEAF0 + 3 * slot + 2, w, st_leaf);
+            }
+        }
+        // ---- unwind (nuts.ipp:212-229), per-chain leaf index
+        bool failed = run && !cs;
+        bool walking = run;
+        uint32_t pend_level = jd + 1;
+#pragma unroll 1
+        for (uint32_t l = 1; l <= (uint32_t)NUTS_MAX_DEPTH; ++l) {
+            if (walking && l > jd) walking = false;                      // reached the root of its own tree
+            const bool bit = ((li >> (l - 1)) & 1u) != 0u;
+            if (walking && !failed && !bit) { pend_level = l; walking = false; }   // first half: wait here
+            if (__ballot(walking) == 0ull) break;
+            const bool mrg = walking && bit;
+            if (__ballot(mrg) == 0ull) continue;
+            const double z = rng_uniform(prm.seed, chain, draw, uslot);  // :213
+            if (mrg) {
+                uslot++;
+                const double p_n = lvl(l, 0), p_a = lvl(l, 1), p_na = lvl(l, 2), p_U = lvl(l, 3);
+                const double prob = cn / (p_n + cn);                     // :212
+                if (!(z < prob)) { cref = V_PP0 + (int)l; cU = p_U; }    // :215-217
+                cn = p_n + cn;                                           // :220-222
+                ca = p_a + ca;
+                cna = p_na + cna;
+            }
+            const bool need_ut = mrg && !failed;
+            if (__ballot(need_ut) != 0ull) {
+                const uint32_t b = li - (1u << l) + 1;                   // first leaf of the node (valid where need_ut)
+                const int slot1 = (!need_ut || b == 0) ? 0 : (__builtin_ctz(b) + 1);
+                const bool ok = uturn_ok(V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1, l == 1,
+                                         V_LEAF0 + 3 * (int)l, V_LEAF0 + 3 * (int)l + 1, vdir);   // :226-227
+                if (need_ut && !ok) failed = true;                       // :229
+            }
+        }
+        // ---- pending first half / tree result: proposal and its P*theta by value, scalars to LDS
+        const bool keep = run && !failed;
+        if (keep) {
+            lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
+            lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
+        }
+        if (__ballot(keep) != 0ull) {
+            const int pl = keep ? (int)pend_level : 1;
+            const bool from_ws = keep && cref >= 0;
+            double t1[NS], t2[NS];
+            if (__ballot(from_ws) != 0ull) {
+                const int c1 = from_ws ? cref : V_PREV;
+                const int c2 = from_ws ? cref + (V_PPW0 - V_PP0) : V_WPREV;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { t1[s] = *wsp(c1, s); t2[s] = *wsp(c2, s); }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { t1[s] = 0.0; t2[s] = 0.0; }
+            }
+            if (keep && live) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    *wsp(V_PP0 + pl, s) = from_ws ? t1[s] : th[s];
+                    *wsp(V_PPW0 + pl, s) = from_ws ? t2[s] : w[s];
+                }
+            }
+        }
+        // ---- end of the doubling? (src/nuts.cpp:258-289)
+        const bool complete = keep && (li == (1u << jd) - 1u);
+        const bool fin = run && (failed || complete);
+        if (__ballot(fin) != 0ull) {
+            if (fin) { alpha_val = ca; n_alpha_val = cna; }              // overwritten by every doubling (:246,255)
+            bool take = false;
+            const double z = rng_uniform(prm.seed, chain, draw, uslot);  // :261
+            if (complete) {
+                uslot++;
+                take = z < cn / n_val;                                   // :263
+                if (take) { prev_U = cU; good_round = 1; }               // :264-277
+            }
+            if (__ballot(take) != 0ull) {
+                const int pj = take ? (int)jd + 1 : 1;
+                copy_vec(V_PP0 + pj, V_PREV, take);
+                copy_vec(V_PPW0 + pj, V_WPREV, take);
+            }
+            if (__ballot(complete) != 0ull) {
+                const int fslot = (!complete || jd == 0) ? 0 : (int)jd;  // far edge = near edge of the second half
+                const int vt = (vdir > 0) ? V_TPOS_T : V_TNEG_T, vp = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+                copy_vec(V_LEAF0 + 3 * fslot, vt, complete);
+                copy_vec(V_LEAF0 + 3 * fslot + 1, vp, complete);
+            }
+            if (fin) n_val = n_val + cn;                                 // :283
+            bool s_ok = false;
+            if (__ballot(complete) != 0ull) {
+                double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double tp = *wsp(V_TPOS_T, s), tn = *wsp(V_TNEG_T, s);
+                    const double pp = *wsp(V_TPOS_P, s), pn = *wsp(V_TNEG_P, s);
+                    const double df = tp - tn;
+                    q1 = dfma(df, pn, q1);                               // :286
+                    q2 = dfma(df, pp, q2);                               // :287
+                }
+                q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
+                q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
+                s_ok = complete && (q1 >= 0.0) && (q2 >= 0.0);           // :289
+            }
+            uint32_t my_depth = jd + 1;                                  // tree_depth after :284
+            const bool more = fin && s_ok && (jd + 1 < max_depth);
+            if (fin) jd = jd + 1;
+            begin_doubling(more);
+            finish_draw(fin && !more, my_depth);
+        }
+        if (run && !fin) li = li + 1;
+    }
+
+    if (live) {
+        double tmp[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (dim_ok(s)) prm.theta[(size_t)(4 * s) * C + lane_off] = tmp[s];
+        if (j4 == 0) {
+            if (prm.n_accept) prm.n_accept[cl] = n_acc;
+            if (prm.n_leap) prm.n_leap[cl] = n_leap;
+            if (prm.step_out) prm.step_out[cl] = eps;
+        }
+    }
+}
+
+}  // namespace mi
