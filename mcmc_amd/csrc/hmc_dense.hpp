@@ -36,7 +36,7 @@ struct HmcParams {
     uint64_t C;             // chains in this launch
     uint64_t chain0;        // global id of local chain 0
     double* theta;          // [d][C] in/out: always the last accepted state
-    double* wsave;          // [2][16*NT][C] workspace: last accepted theta and P*theta, rows padded
+    double* wsave;          // [n_waves][2][NS][64] workspace: last accepted theta and P*theta
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -136,8 +136,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     double th[NS], pm[NS], w[NS];
     // addresses = wave-uniform row base (SGPR) + one per-lane element offset (VGPR)
     const size_t lane_off = (size_t)j * C + cld;
-    auto th_mem = [&](int s) -> double* { return prm.wsave + (size_t)(4 * s) * C + lane_off; };
-    auto w_mem = [&](int s) -> double* { return prm.wsave + (size_t)(16 * NT + 4 * s) * C + lane_off; };
+    // last accepted (theta, P*theta): wave-local contiguous [wave][2][NS][64 lanes] (512-B coalesced per slice)
+    double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)2 * NS * 64) + lane;
+    auto th_mem = [&](int s) -> double* { return ws_wave + (size_t)s * 64; };
+    auto w_mem = [&](int s) -> double* { return ws_wave + (size_t)(NS + s) * 64; };
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

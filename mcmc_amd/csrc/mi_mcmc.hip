@@ -207,7 +207,7 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
     } else {
-        uint32_t batch = 2;
+        uint32_t batch = 8;
         if (const char* e = getenv("MI_NUTS_BATCH")) batch = (uint32_t)atoi(e);
         if (batch < 1) batch = 1;
         auto kern = mi::nuts_gauss_async_kernel<NT>;
@@ -328,7 +328,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
     void* wsave = nullptr;
     const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, 2 * d_pad_h * chains->n_chains * sizeof(double), &wsave);
+    rc = ws_get(st, 2 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), &wsave);
     if (rc) return rc;
     prm.wsave = static_cast<double*>(wsave);
     prm.draws = sc.dev.draws;
@@ -489,7 +489,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.theta = sc.dev.theta;
     void* ws = nullptr;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * chains->n_chains * sizeof(double), &ws);
+    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), &ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = static_cast<double*>(ws);
     prm.draws = sc.dev.draws;
@@ -497,6 +497,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_leap = sc.dev.n_leapfrogs;
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
+    DevBuf prof_buf;
+    if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(16 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 128)); prm.prof = prof_buf.as<unsigned long long>(); }
     prm.seed = settings->rng_seed_value;
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
     prm.n_keep = (uint32_t)settings->n_keep_draws;
@@ -517,6 +519,16 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
+    if (prm.prof) {
+        unsigned long long h[12];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));
+        const char* names[8] = {"refresh", "start-gather", "leapfrog", "energy+leaf-store", "merge-loop", "take+pending-store", "fin", "loop-head"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; ++k) tot += h[k];
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "[nuts prof] %-20s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+        fprintf(stderr, "[nuts prof] ticks %llu, active chain-ticks %llu (%.2f of 16 per tick), refresh phases %llu, fin blocks %llu\n", h[8], h[9], (double)h[9] / (h[8] ? h[8] : 1), h[10], h[11]);
+    }
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }

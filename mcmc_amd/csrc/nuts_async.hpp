@@ -16,6 +16,10 @@
 
 #include "nuts_dense.hpp"
 
+#ifndef MI_NUTS_CH
+#define MI_NUTS_CH 32
+#endif
+
 namespace mi {
 
 enum : int { V_PPW0 = 52, NUTS_NVEC_ASYNC = 64 };   // P*theta of the pending proposal of level l at 52 + l
@@ -25,6 +29,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     constexpr int NS = 4 * NT;
+    constexpr int WS_NVEC = NUTS_NVEC_ASYNC;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
@@ -41,10 +46,12 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
-    const size_t vstride = (size_t)(16 * NT) * C;
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
-    auto wsp = [&](int v, int s) -> double* { return prm.ws + (size_t)v * vstride + (size_t)(4 * s) * C + lane_off; };
+    // workspace layout [wave][vec][slice][lane]: a vector of a wave's 16 chains is 16 KiB contiguous (one 512-B
+    // coalesced access per slice, 4 pages per vector) instead of 128 fragments 4*C*8 bytes apart
+    double* const ws_wave = prm.ws + ((size_t)blockIdx.x * 4 + wave) * ((size_t)WS_NVEC * NS * 64) + lane;
+    auto wsp = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NS + s) * 64; };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
 
     double th[NS], pm[NS], w[NS];
@@ -54,9 +61,13 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
     };
     // x <- ws[v] for lanes with pred, unchanged otherwise (v may be any valid id on the other lanes)
+    // ONE exec-masked region around the whole vector (idle lanes generate no memory traffic); never a
+    // branch per element (that serialises the loads)
     auto load_vec_if = [&](int v, double (&x)[NS], bool pred) __attribute__((always_inline)) {
+        if (pred) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { const double t = *wsp(v, s); x[s] = pred ? t : x[s]; }
+            for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
+        }
     };
     auto store_vec = [&](int v, const double (&x)[NS], bool pred) __attribute__((always_inline)) {
         if (pred && live) {
@@ -64,13 +75,19 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
             for (int s = 0; s < NS; ++s) *wsp(v, s) = x[s];
         }
     };
+    // vector ops touch 8 slices at a time (16 VGPRs in flight): the register file is full of theta / p / P*theta
+    constexpr int CH = (NS < MI_NUTS_CH) ? NS : MI_NUTS_CH;
     auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
-        double tmp[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(vsrc, s);
         if (pred && live) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) *wsp(vdst, s) = tmp[s];
+            for (int c0 = 0; c0 < NS; c0 += CH) {
+                double tmp[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) tmp[k] = *wsp(vsrc, c0 + k);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) *wsp(vdst, c0 + k) = tmp[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     auto leapfrog = [&](double e) __attribute__((always_inline)) {
@@ -90,17 +107,27 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
     };
     auto kinetic = [&]() __attribute__((always_inline)) -> double { return dot4<NS>(pm, pm) / 2.0; };
     // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1
-    auto uturn_ok = [&](int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
+    auto uturn_ok = [&](bool pred, int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
         double q1 = 0.0, q2 = 0.0;
+        if (pred) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double t1 = *wsp(vt1, s);
-            const double p1 = *wsp(vp1, s);
-            const double t2 = n2_in_regs ? th[s] : *wsp(vt2, s);
-            const double p2 = n2_in_regs ? pm[s] : *wsp(vp2, s);
-            const double dd = (vdir > 0) ? (t2 - t1) : (t1 - t2);
-            q1 = dfma(dd, p1, q1);
-            q2 = dfma(dd, p2, q2);
+            for (int c0 = 0; c0 < NS; c0 += CH) {
+                double t1[CH], p1[CH], t2[CH], p2[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    t1[k] = *wsp(vt1, c0 + k);
+                    p1[k] = *wsp(vp1, c0 + k);
+                    t2[k] = n2_in_regs ? th[c0 + k] : *wsp(vt2, c0 + k);
+                    p2[k] = n2_in_regs ? pm[c0 + k] : *wsp(vp2, c0 + k);
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const double dd = (vdir > 0) ? (t2[k] - t1[k]) : (t1[k] - t2[k]);
+                    q1 = dfma(dd, p1[k], q1);
+                    q2 = dfma(dd, p2[k], q2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
         q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
@@ -169,6 +196,8 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
     double e_signed = 0.0, H0 = 0.0, prev_K = 0.0, log_u = 0.0, n_val = 1.0;
     double alpha_val = 0.0, n_alpha_val = 0.0;
     int good_round = 0;
+    bool fin_pending = false;    // the draw's epilogue (dual averaging, row store) is done in the next refresh phase
+    uint32_t fin_depth = 0;
 
     // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
@@ -185,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
     auto finish_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
         if (__ballot(p) == 0ull) return;
         if (p && prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
+        if (p) fin_pending = false;
         if (p) {
             if (draw < n_adapt) {
                 const double it = (double)(draw + 1);
@@ -198,14 +228,18 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         const bool kept = p && draw >= prm.n_burnin;
         if (kept) n_acc += (uint64_t)good_round;
         if (__ballot(kept && prm.draws != nullptr) != 0ull) {
-            double tmp[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
             if (kept && prm.draws != nullptr && live) {
                 double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if (dim_ok(s)) (out + (size_t)(4 * s) * C)[lane_off] = tmp[s];
+                for (int c0 = 0; c0 < NS; c0 += CH) {
+                    double tmp[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) tmp[k] = *wsp(V_PREV, c0 + k);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k)
+                        if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (p) {
@@ -214,28 +248,40 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         }
     };
 
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_ticks = 0, n_active = 0, n_refresh = 0, n_finblk = 0;
+    unsigned long long tmark = clock64();
+#define MI_PROF(k) { const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
 #pragma unroll 1
     while (__ballot(state != NS_DONE) != 0ull) {
+        MI_PROF(7)
         // ------------------------------------------------------------ A. momentum refresh for waiting chains
         const unsigned n_wait = __popcll(__ballot(state == NS_NEED_DRAW)) / 4;
         const unsigned n_run = __popcll(__ballot(state == NS_TREE)) / 4;
         if (n_wait >= refresh_batch || (n_run == 0 && n_wait > 0)) {
+            n_refresh++;
+            finish_draw(state == NS_NEED_DRAW && fin_pending, fin_depth);   // epilogue of the draws that just ended
             const bool p = state == NS_NEED_DRAW;
-            double pnew[NS];
-#pragma unroll
+            double kq = 0.0;
+#pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
                 rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
-                pnew[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
-                pnew[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                __builtin_amdgcn_sched_barrier(0);
+                const double pa = (8u * b + j4 < d) ? z0 : 0.0;
+                const double pb = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                kq = dfma(pa, pa, kq);
+                kq = dfma(pb, pb, kq);
+                if (p && live) {                              // mntm_vec, mntm_pos, mntm_neg (:202, :214-215)
+                    *wsp(V_MNTM, 2 * b) = pa;   *wsp(V_MNTM, 2 * b + 1) = pb;
+                    *wsp(V_TPOS_P, 2 * b) = pa; *wsp(V_TPOS_P, 2 * b + 1) = pb;
+                    *wsp(V_TNEG_P, 2 * b) = pa; *wsp(V_TNEG_P, 2 * b + 1) = pb;
+                }
             }
-            const double kk = dot4<NS>(pnew, pnew) / 2.0;     // :204
+            kq = kq + __shfl_xor(kq, 32);
+            kq = kq + __shfl_xor(kq, 16);
+            const double kk = kq / 2.0;                       // :204
             const double lu = det_log(rng_uniform(prm.seed, chain, draw, 0u));
-            store_vec(V_MNTM, pnew, p);
-            store_vec(V_TPOS_P, pnew, p);                     // :212-215
-            store_vec(V_TNEG_P, pnew, p);
-            copy_vec(V_PREV, V_TPOS_T, p);
+            copy_vec(V_PREV, V_TPOS_T, p);                    // draw_pos = draw_neg = prev_draw (:212-213)
             copy_vec(V_PREV, V_TNEG_T, p);
             if (p) {
                 prev_K = kk;
@@ -245,8 +291,9 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
                 state = NS_TREE;
             }
             if (max_depth > 0) begin_doubling(p);
-            else finish_draw(p, 0u);                          // while-loop of :227 never entered
+            else if (p) { fin_pending = true; fin_depth = 0u; state = NS_NEED_DRAW; }   // while-loop of :227 never entered
         }
+        MI_PROF(0)
         const bool run = state == NS_TREE;
         if (__ballot(run) == 0ull) continue;
 
@@ -264,7 +311,10 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
                 load_vec_if(vw, w, from_prev || from_slot);
             }
         }
+        MI_PROF(1)
+        n_ticks++; n_active += __popcll(__ballot(run)) / 4;
         leapfrog(e_signed);                              // nuts.ipp:132 (idle chains: harmless garbage)
+        MI_PROF(2)
         const double pU = potential();
         const double pK = kinetic();
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
@@ -276,14 +326,23 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         int cref = -1;
         if (run) n_leap++;
         {
-            const bool st_leaf = run && (((li & 1u) == 0u) || jd == 1u);
+            const bool st_leaf = run && ((li & 1u) == 0u);
             if (__ballot(st_leaf) != 0ull) {
                 const int slot = (li == 0) ? 0 : (__builtin_ctz(li) + 1);
                 store_vec(V_LEAF0 + 3 * slot, th, st_leaf);
                 store_vec(V_LEAF0 + 3 * slot + 1, pm, st_leaf);
                 store_vec(V_LEAF0 + 3 * slot + 2, w, st_leaf);
             }
+            // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a
+            // successful doubling leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw,
+            // so it can be written in place as soon as that leaf exists
+            const bool st_edge = run && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
+            if (__ballot(st_edge) != 0ull) {
+                store_vec((vdir > 0) ? V_TPOS_T : V_TNEG_T, th, st_edge);
+                store_vec((vdir > 0) ? V_TPOS_P : V_TNEG_P, pm, st_edge);
+            }
         }
+        MI_PROF(3)
         // ---- unwind (nuts.ipp:212-229), per-chain leaf index
         bool failed = run && !cs;
         bool walking = run;
@@ -310,84 +369,96 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
             if (__ballot(need_ut) != 0ull) {
                 const uint32_t b = li - (1u << l) + 1;                   // first leaf of the node (valid where need_ut)
                 const int slot1 = (!need_ut || b == 0) ? 0 : (__builtin_ctz(b) + 1);
-                const bool ok = uturn_ok(V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1, l == 1,
+                const bool ok = uturn_ok(need_ut, V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1, l == 1,
                                          V_LEAF0 + 3 * (int)l, V_LEAF0 + 3 * (int)l + 1, vdir);   // :226-227
                 if (need_ut && !ok) failed = true;                       // :229
             }
         }
-        // ---- pending first half / tree result: proposal and its P*theta by value, scalars to LDS
+        MI_PROF(4)
+        // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279), so that an accepted
+        //      proposal goes straight to prev_draw instead of through a pending slot
         const bool keep = run && !failed;
-        if (keep) {
-            lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
-            lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
-        }
-        if (__ballot(keep) != 0ull) {
-            const int pl = keep ? (int)pend_level : 1;
-            const bool from_ws = keep && cref >= 0;
-            double t1[NS], t2[NS];
-            if (__ballot(from_ws) != 0ull) {
-                const int c1 = from_ws ? cref : V_PREV;
-                const int c2 = from_ws ? cref + (V_PPW0 - V_PP0) : V_WPREV;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { t1[s] = *wsp(c1, s); t2[s] = *wsp(c2, s); }
-            } else {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { t1[s] = 0.0; t2[s] = 0.0; }
-            }
-            if (keep && live) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    *wsp(V_PP0 + pl, s) = from_ws ? t1[s] : th[s];
-                    *wsp(V_PPW0 + pl, s) = from_ws ? t2[s] : w[s];
-                }
-            }
-        }
-        // ---- end of the doubling? (src/nuts.cpp:258-289)
         const bool complete = keep && (li == (1u << jd) - 1u);
         const bool fin = run && (failed || complete);
-        if (__ballot(fin) != 0ull) {
-            if (fin) { alpha_val = ca; n_alpha_val = cna; }              // overwritten by every doubling (:246,255)
-            bool take = false;
+        bool take = false;
+        if (__ballot(complete) != 0ull) {
             const double z = rng_uniform(prm.seed, chain, draw, uslot);  // :261
             if (complete) {
                 uslot++;
                 take = z < cn / n_val;                                   // :263
                 if (take) { prev_U = cU; good_round = 1; }               // :264-277
             }
-            if (__ballot(take) != 0ull) {
-                const int pj = take ? (int)jd + 1 : 1;
-                copy_vec(V_PP0 + pj, V_PREV, take);
-                copy_vec(V_PPW0 + pj, V_WPREV, take);
+        }
+        // ---- pending first half: proposal and its P*theta by value, scalars to LDS
+        if (keep && !complete) {
+            lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
+            lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
+        }
+        {
+            const bool do_store = keep && (!complete || take);
+            if (__ballot(do_store) != 0ull) {
+                const int pl = do_store ? (int)pend_level : 1;
+                const int dst_t = take ? V_PREV : V_PP0 + pl;
+                const int dst_w = take ? V_WPREV : V_PPW0 + pl;
+                const bool from_ws = do_store && cref >= 0;
+#pragma unroll
+                for (int c0 = 0; c0 < NS; c0 += CH) {
+                    double t1[CH], t2[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) { t1[k] = th[c0 + k]; t2[k] = w[c0 + k]; }
+                    if (from_ws) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) { t1[k] = *wsp(cref, c0 + k); t2[k] = *wsp(cref + (V_PPW0 - V_PP0), c0 + k); }
+                    }
+                    if (do_store && live) {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) { *wsp(dst_t, c0 + k) = t1[k]; *wsp(dst_w, c0 + k) = t2[k]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (__ballot(complete) != 0ull) {
-                const int fslot = (!complete || jd == 0) ? 0 : (int)jd;  // far edge = near edge of the second half
-                const int vt = (vdir > 0) ? V_TPOS_T : V_TNEG_T, vp = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
-                copy_vec(V_LEAF0 + 3 * fslot, vt, complete);
-                copy_vec(V_LEAF0 + 3 * fslot + 1, vp, complete);
-            }
-            if (fin) n_val = n_val + cn;                                 // :283
+        }
+        MI_PROF(5)
+        if (__ballot(fin) != 0ull) {
+            n_finblk++;
+            if (fin) { alpha_val = ca; n_alpha_val = cna; n_val = n_val + cn; }   // :246,255 ; :283
             bool s_ok = false;
             if (__ballot(complete) != 0ull) {
                 double q1 = 0.0, q2 = 0.0;
+                if (complete) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double tp = *wsp(V_TPOS_T, s), tn = *wsp(V_TNEG_T, s);
-                    const double pp = *wsp(V_TPOS_P, s), pn = *wsp(V_TNEG_P, s);
-                    const double df = tp - tn;
-                    q1 = dfma(df, pn, q1);                               // :286
-                    q2 = dfma(df, pp, q2);                               // :287
+                    for (int c0 = 0; c0 < NS; c0 += CH) {
+                        double tp[CH], tn[CH], pp[CH], pn[CH];
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            tp[k] = *wsp(V_TPOS_T, c0 + k); tn[k] = *wsp(V_TNEG_T, c0 + k);
+                            pp[k] = *wsp(V_TPOS_P, c0 + k); pn[k] = *wsp(V_TNEG_P, c0 + k);
+                        }
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const double df = tp[k] - tn[k];
+                            q1 = dfma(df, pn[k], q1);                    // :286
+                            q2 = dfma(df, pp[k], q2);                    // :287
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
                 q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
                 s_ok = complete && (q1 >= 0.0) && (q2 >= 0.0);           // :289
             }
-            uint32_t my_depth = jd + 1;                                  // tree_depth after :284
             const bool more = fin && s_ok && (jd + 1 < max_depth);
-            if (fin) jd = jd + 1;
+            if (fin) jd = jd + 1;                                        // :284
             begin_doubling(more);
-            finish_draw(fin && !more, my_depth);
+            if (fin && !more) { fin_pending = true; fin_depth = jd; state = NS_NEED_DRAW; }
         }
         if (run && !fin) li = li + 1;
+        MI_PROF(6)
+    }
+    if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
+        prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_refresh; prm.prof[11] = n_finblk;
     }
 
     if (live) {

@@ -39,12 +39,13 @@ struct NutsParams {
     uint32_t d;
     uint64_t C, chain0;
     double* theta;          // [d][C] in: initial_vals, out: last state
-    double* ws;             // [NUTS_NVEC][16*NT][C] workspace (rows padded: no per-element predicates)
+    double* ws;             // [n_waves][64 vectors][NS][64 lanes] workspace, wave-local and contiguous
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
     double* step_out;       // [C] or nullptr: final step size
     uint32_t* depth_trace;  // [n_total][C] or nullptr (tests)
+    unsigned long long* prof;   // [16] or nullptr: section cycle counters of workgroup 0 wave 0 (profiling builds)
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_adapt, max_depth;
     double delta, eps_bar0, gamma, t0, kappa;
@@ -63,6 +64,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParams prm)
 {
     constexpr int NS = 4 * NT;
+    constexpr int WS_NVEC = 64;     // same allocation as the asynchronous kernel
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
@@ -79,11 +81,13 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_mfma_kernel(const NutsParam
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
-    const size_t vstride = (size_t)(16 * NT) * C;       // padded rows hold zeros (theta, p, P*theta pads are 0)
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
     // element (4s + j4) of workspace vector v of this lane's chain
-    auto wsp = [&](int v, int s) -> double* { return prm.ws + (size_t)v * vstride + (size_t)(4 * s) * C + lane_off; };
+    // workspace layout [wave][vec][slice][lane]: a vector of a wave's 16 chains is 16 KiB contiguous (one 512-B
+    // coalesced access per slice, 4 pages per vector) instead of 128 fragments 4*C*8 bytes apart
+    double* const ws_wave = prm.ws + ((size_t)blockIdx.x * 4 + wave) * ((size_t)WS_NVEC * NS * 64) + lane;
+    auto wsp = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NS + s) * 64; };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
 
     double th[NS], pm[NS], w[NS];
