@@ -27,6 +27,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= vector) peak; not in the in-image guide
+# HBM bytes per launch of the default workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+# command (profiles/r1_hmc_pmc.json): (23.0 + 35.9) GB. Not re-measured here (counters cannot be read in-process);
+# reported only for the exact profiled configuration, null otherwise.  FETCH_SIZE is uncorrected (8-B-per-lane loads).
+PROFILED_TRAFFIC_BYTES = {(65536, 128, 16, 100, 100): 5.89e10}
 
 WORKLOAD = dict(d=128, chains_per_gpu=65536, n_leap_steps=16, step_size=0.05,
                 n_burnin_draws=100, n_keep_draws=100, seed=2024)
@@ -185,8 +189,9 @@ def main():
                        "parallelism": f"chains sharded x{world}, no data-path collective",
                        "accept_rate": acc_rate},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "hmc_gauss_mfma_kernel<8>", "kernel_ms": k_ms,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+                         "traffic": PROFILED_TRAFFIC_BYTES.get((C, d, cfg["n_leap_steps"], cfg["n_burnin_draws"], n_keep)),
+                         "kernel": "hmc_gauss_mfma_kernel<8, 8>", "kernel_ms": k_ms,
                          "flop_per_unit": flop_per_unit},
         }
         if collate_ms is not None:
