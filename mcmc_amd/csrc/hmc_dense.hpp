@@ -43,6 +43,9 @@ struct HmcParams {
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_leap_steps;
     double eps;
+    const int* btype;       // bounded runs: per-dimension bounds type 1..4 (determine_bounds_type.hpp:27-57), device
+    const double* lb;       // lower / upper bounds, device, d values
+    const double* ub;
     uint32_t ablate;        // profiling only: 1 = skip kick/drift, 2 = skip mat-vec (results meaningless)
     uint32_t stagger;       // start delay of the second wave of each SIMD, in s_sleep(127) units
 };
@@ -110,14 +113,85 @@ __device__ __forceinline__ void stage_precision(const double* __restrict__ P, ui
     __syncthreads();
 }
 
+
+// ---- box constraints (element-wise maps of /root/reference/include/misc/transform_vals.hpp:25-119,
+//      log_jacobian.hpp:25-58, inv_jacobian_adjust.hpp:25-56), one dimension at a time
+constexpr double EPS_DBL = 2.220446049250313e-16;    // mcmc_options.hpp:103
+
+__device__ __forceinline__ double box_transform(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return det_log(v - lb + EPS_DBL);
+    case 3: return -det_log(ub - v + EPS_DBL);
+    case 4: return det_log(v - lb + EPS_DBL) - det_log(ub - v + EPS_DBL);
+    default: return v;
+    }
+}
+__device__ __forceinline__ double box_inv_transform(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return !is_finite(v) ? lb + EPS_DBL : lb + EPS_DBL + det_exp(v);
+    case 3: return !is_finite(v) ? ub - EPS_DBL : ub - EPS_DBL - det_exp(-v);
+    case 4: {
+        if (!is_finite(v)) {
+            if (v != v) return (ub - lb) / 2;
+            return (v < 0.0) ? lb + EPS_DBL : ub - EPS_DBL;
+        }
+        const double e = det_exp(v);
+        const double r = (lb - EPS_DBL + (ub + EPS_DBL) * e) / (1.0 + e);
+        return is_finite(r) ? r : ub - EPS_DBL;
+    }
+    default: return v;
+    }
+}
+// diagonal entry of inv_jacobian_adjust
+__device__ __forceinline__ double box_inv_jacobian(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return det_exp(-v);
+    case 3: return det_exp(v);
+    case 4: { const double e = det_exp(v); return ((e + 1) * (e + 1)) / (e * (ub - lb)); }
+    default: return 1.0;
+    }
+}
+// one summand of log_jacobian (callers skip bt == 1: the reference adds nothing for it)
+__device__ __forceinline__ double box_log_jacobian_term(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return v;
+    case 3: return -v;
+    case 4: {
+        const double e = det_exp(v);
+        if (is_finite(e)) return det_log(ub - lb) + v - 2 * det_log(1 + e);
+        return det_log(ub - lb) - v;
+    }
+    default: return 0.0;
+    }
+}
+
 // WPB = waves per workgroup: 4 (one wave per SIMD, 512-register budget) or 8 (two waves per SIMD,
 // 256 registers each: one wave's VALU phases -- kick/drift, RNG, accept -- hide under the other's MFMAs).
-template <int NT, int WPB>
+// BOUNDED: settings.vals_bound (hmc.cpp:84-95,107-122,134-136,211-218): the chain lives in the transformed
+// space; the target is evaluated at x = inv_transform(theta), the kick uses inv_jacobian * grad, the energy
+// adds log_jacobian (summed sequentially over dimensions, as the reference's scalar loop does).
+template <int NT, int WPB, bool BOUNDED = false>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
     stage_precision<NT>(prm.P, prm.d, lds_P);
+    double* lds_lb = lds_P + NT * NS * 64;                 // [16*NT] each, BOUNDED only
+    double* lds_ub = lds_lb + 16 * NT;
+    int* lds_bt = reinterpret_cast<int*>(lds_ub + 16 * NT);
+    if (BOUNDED) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_lb[i] = in ? prm.lb[i] : 0.0;
+            lds_ub[i] = in ? prm.ub[i] : 0.0;
+            lds_bt[i] = in ? prm.btype[i] : 1;
+        }
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
@@ -134,6 +208,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     // The last accepted (theta, P*theta) lives in HBM (prm.theta / prm.wsave): written on accept,
     // re-read on reject, so a rejection costs 2 KiB of traffic per chain instead of 128 VGPRs.
     double th[NS], pm[NS], w[NS];
+    double kw[BOUNDED ? NS : 1];   // BOUNDED: inv_jacobian * (P x), what the momentum kick uses (hmc.cpp:122)
+    double xs[BOUNDED ? NS : 1];   // BOUNDED: x = inv_transform(theta), where the target is evaluated (hmc.cpp:108)
     // addresses = wave-uniform row base (SGPR) + one per-lane element offset (VGPR)
     const size_t lane_off = (size_t)j * C + cld;
     // last accepted (theta, P*theta): wave-local contiguous [wave][2][NS][64 lanes] (512-B coalesced per slice)
@@ -141,18 +217,63 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     auto th_mem = [&](int s) -> double* { return ws_wave + (size_t)s * 64; };
     auto w_mem = [&](int s) -> double* { return ws_wave + (size_t)(NS + s) * 64; };
 
+    // w = P * (theta or inv_transform(theta)); BOUNDED also refreshes xs and kw
+    auto gradient = [&]() __attribute__((always_inline)) {
+        if constexpr (BOUNDED) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = 4 * s + j;
+                xs[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+            }
+            matvec_mfma<NT>(afrag, xs, w);
+        } else {
+            matvec_mfma<NT>(afrag, th, w);
+        }
+    };
+    auto refresh_kw = [&]() __attribute__((always_inline)) {
+        if constexpr (BOUNDED) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = 4 * s + j;
+                kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];   // J_ii * grad_i (gemv with a diagonal J)
+            }
+        }
+    };
+    // U = -box_log_kernel(theta) at the state whose w (and xs) are current (hmc.cpp:84-95,140,178)
+    auto potential = [&]() __attribute__((always_inline)) -> double {
+        if constexpr (BOUNDED) {
+            const double kval = -0.5 * dot4<NS>(xs, w);
+            double lj = 0.0;                             // log_jacobian.hpp:36-57: scalar loop, i ascending
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i0 = 4 * s;
+                const int bt = lds_bt[4 * s + j];
+                const double term = box_log_jacobian_term(th[s], bt, lds_lb[4 * s + j], lds_ub[4 * s + j]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double tg = __shfl(term, (lane & 15) + 16 * g);
+                    if ((uint32_t)(i0 + g) < d && lds_bt[i0 + g] != 1) lj = lj + tg;
+                }
+            }
+            return -(kval + lj);
+        } else {
+            return 0.5 * dot4<NS>(th, w);
+        }
+    };
+
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t dim = 4 * s + j;
         const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];   // clamped row: unconditional load
-        th[s] = (dim < d) ? v : 0.0;
+        if constexpr (BOUNDED) th[s] = (dim < d) ? box_transform(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]) : 0.0;   // hmc.cpp:134-136
+        else th[s] = (dim < d) ? v : 0.0;
     }
-    matvec_mfma<NT>(afrag, th, w);
+    gradient();
     if (live) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) { *th_mem(s) = th[s]; *w_mem(s) = w[s]; }
     }
-    double prev_U = 0.5 * dot4<NS>(th, w);              // -box_log_kernel(first_draw), hmc.cpp:140
+    double prev_U = potential();                        // -box_log_kernel(first_draw), hmc.cpp:140
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
 
@@ -174,24 +295,31 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
             __builtin_amdgcn_sched_barrier(0);
         }
         const double prev_K = dot4<NS>(pm, pm) / 2.0;   // hmc.cpp:160
+        refresh_kw();
 
 #pragma unroll 1
         for (uint32_t k = 0; k < prm.n_leap_steps; ++k) {   // hmc.cpp:164-176, grad = -w
             if (prm.ablate != 1) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                pm[s] = pm[s] - (eps * w[s]) / 2.0;     // first half-step (:167,126)
+                const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
+                pm[s] = pm[s] - (eps * gw) / 2.0;       // first half-step (:167,126 / :122)
                 th[s] = th[s] + eps * pm[s];            // (:171)
             }
             }
-            if (prm.ablate != 2) matvec_mfma<NT>(afrag, th, w);
+            if (prm.ablate != 2) gradient();
+            refresh_kw();
             if (prm.ablate != 1) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * w[s]) / 2.0;   // second half-step (:175)
+            for (int s = 0; s < NS; ++s) {
+                const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
+                pm[s] = pm[s] - (eps * gw) / 2.0;       // second half-step (:175)
+            }
             }
         }
+        if constexpr (BOUNDED) { if (prm.n_leap_steps == 0) gradient(); }   // xs must match theta for the energy
 
-        double prop_U = 0.5 * dot4<NS>(th, w);          // -box_log_kernel(new_draw), hmc.cpp:178
+        double prop_U = potential();                    // -box_log_kernel(new_draw), hmc.cpp:178
         if (!is_finite(prop_U)) prop_U = INF;           // :180-182
         const double prop_K = dot4<NS>(pm, pm) / 2.0;   // :184
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
@@ -215,7 +343,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t dim = 4 * s + j;
-                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = th[s];
+                    // bounded runs store inv_transform(row) (the reference does it in the epilogue, :211-218)
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] =
+                        BOUNDED ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
                 }
             }
         }
@@ -225,7 +355,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;
-            if (dim < d) prm.theta[(size_t)dim * C + cl] = th[s];
+            if (dim < d) prm.theta[(size_t)dim * C + cl] =
+                BOUNDED ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
         }
     }
     if (live && j == 0) {

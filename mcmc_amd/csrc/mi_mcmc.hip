@@ -4,6 +4,7 @@
 // does not implement returns MI_ERR_UNSUPPORTED.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -219,6 +220,19 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 }
 
 template <int NT>
+int launch_hmc_mfma_bounded(const mi::HmcParams& prm, hipStream_t st)
+{
+    constexpr int WPB = 4;      // one wave per SIMD: the bounded variant holds two more register-resident vectors
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (2 * sizeof(double) + sizeof(int));
+    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+template <int NT>
 int launch_hmc_mfma(const mi::HmcParams& prm, hipStream_t st)
 {
     constexpr int WPB = MI_HMC_WPB;
@@ -267,14 +281,17 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound is not implemented on the device path yet");
     if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat is not implemented on the device path yet");
     const uint64_t d = target->d;
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
+    const bool bounded = settings->vals_bound != 0;
+    if (bounded && (!settings->lower_bounds || !settings->upper_bounds))
+        return fail(MI_ERR_BAD_ARG, "hmc: vals_bound needs lower_bounds and upper_bounds");
+    if (bounded && d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound with d > 128 is not implemented");
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     const bool separable = target->kind != MI_TARGET_GAUSS_DENSE;
-    const bool force_diag = getenv("MI_HMC_FORCE_DIAG") != nullptr;          // tests: same bits from both kernels
+    const bool force_diag = !bounded && getenv("MI_HMC_FORCE_DIAG") != nullptr;   // tests: same bits from both kernels
     if (d > 128 && !separable)
         return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
     if (separable && (d > 128 || force_diag)) {
@@ -344,7 +361,26 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (const char* e = getenv("MI_HMC_ABLATE")) prm.ablate = (uint32_t)atoi(e);
 
     const int nt = (int)((d + 15) / 16);
-    if (nt <= 1) rc = launch_hmc_mfma<1>(prm, st);
+    DevBuf bt_dev, lb_dev, ub_dev;
+    if (bounded) {
+        // determine_bounds_type (determine_bounds_type.hpp:27-57): 1 none, 2 lower, 3 upper, 4 both
+        std::vector<int> bt(d, 1);
+        for (uint64_t i = 0; i < d; ++i) {
+            const bool fl = std::isfinite(settings->lower_bounds[i]), fu = std::isfinite(settings->upper_bounds[i]);
+            bt[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+        }
+        HIP_TRY(bt_dev.alloc(d * sizeof(int))); HIP_TRY(lb_dev.alloc(d * 8)); HIP_TRY(ub_dev.alloc(d * 8));
+        HIP_TRY(hipMemcpy(bt_dev.p, bt.data(), d * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lb_dev.p, settings->lower_bounds, d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ub_dev.p, settings->upper_bounds, d * 8, hipMemcpyHostToDevice));
+        prm.btype = bt_dev.as<int>(); prm.lb = lb_dev.as<double>(); prm.ub = ub_dev.as<double>();
+        if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
+        else if (nt == 2) rc = launch_hmc_mfma_bounded<2>(prm, st);
+        else if (nt <= 4) rc = launch_hmc_mfma_bounded<4>(prm, st);
+        else rc = launch_hmc_mfma_bounded<8>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // bounds buffers are ours
+    }
+    else if (nt <= 1) rc = launch_hmc_mfma<1>(prm, st);
     else if (nt == 2) rc = launch_hmc_mfma<2>(prm, st);
     else if (nt <= 4) rc = launch_hmc_mfma<4>(prm, st);
     else rc = launch_hmc_mfma<8>(prm, st);

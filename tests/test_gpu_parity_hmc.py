@@ -196,3 +196,63 @@ def test_both_hmc_kernels_agree_bitwise_on_a_diagonal_target(monkeypatch):
     monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
     b, gb = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec)          # elementwise kernel
     assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
+
+
+# ---------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("d,C,L,burn,keep", [
+    (1, 1, 3, 2, 4),        # smallest problem: one chain, one dimension
+    (128, 1, 2, 0, 1),      # a single chain in a 16-chain wave
+    (16, 16, 0, 1, 3),      # n_leap_steps = 0: proposal = current state, still draws momentum and a uniform
+    (8, 5, 4, 3, 0),        # n_keep_draws = 0: burn-in only, draws_out empty, state still advances
+])
+def test_hmc_edge_cases_match_oracle(d, C, L, burn, keep):
+    init = synth.initial_states(C, d, seed=13)
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    st = mcmc_amd.default_settings(rng_seed_value=31, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=0.1)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    o_draws, o = _oracle_many(orc.TARGET_DENSE, d, init, st, prec=prec)
+    assert g_draws.shape == (keep, d, C)
+    assert np.array_equal(g_draws, o_draws) and np.array_equal(g["n_accept"], o["n_accept"])
+    if keep == 0:       # final state = oracle state after the burn-in (re-run the oracle keeping the last burn-in draw)
+        st2 = mcmc_amd.default_settings(rng_seed_value=31, n_burnin_draws=burn - 1, n_keep_draws=1, n_leap_steps=L, step_size=0.1)
+        o2, _ = _oracle_many(orc.TARGET_DENSE, d, init, st2, prec=prec)
+        assert np.array_equal(g["theta"], o2[-1])
+
+
+def test_non_finite_energy_is_rejected_like_the_reference():
+    """hmc.cpp:180-182: a non-finite proposal energy becomes +inf and the move is rejected."""
+    d, C = 4, 16
+    init = np.full((C, d), 1e154)                       # theta^T P theta overflows -> U = +inf from the start
+    prec = np.eye(d) * 4.0
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=0, n_keep_draws=3, n_leap_steps=2, step_size=0.5)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    o_draws, o = _oracle_many(orc.TARGET_DENSE, d, init, st, prec=prec)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+# ---------------------------------------------------------------- box constraints (settings.vals_bound), SURVEY 8(f-1)
+def _bounds(d, seed=0):
+    """A mix of the four bounds types of determine_bounds_type.hpp:27-57."""
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(1, 5, d)
+    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
+    ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+    return lb, ub
+
+
+@pytest.mark.parametrize("d,C,L,eps,burn,keep", [(6, 16, 4, 0.05, 4, 12), (128, 48, 3, 0.02, 2, 5), (37, 20, 2, 0.05, 0, 6)])
+def test_bounded_hmc_bit_exact_vs_oracle(d, C, L, eps, burn, keep):
+    lb, ub = _bounds(d, seed=d)
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    init = np.clip(synth.initial_states(C, d, seed=14) * 0.3, -1.0, 1.5)     # inside every box
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L,
+                                   step_size=eps, vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=4)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=77, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, lower=lb, upper=ub)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=4)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    inside = (g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])
+    assert inside.all()                                  # draws are reported in the constrained space
