@@ -148,7 +148,7 @@ def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want
     initial_vals = init[c]).  Returns draws [n_keep, d, C] and a dict of per-chain outputs."""
     init = np.ascontiguousarray(init, dtype=np.float64)
     n_chains, d = init.shape
-    theta = np.ascontiguousarray(init.T)            # [d][C]
+    theta = np.array(init.T, dtype=np.float64, order="C", copy=True)   # [d][C]; always a copy (the run overwrites it)
     n_keep = int(settings.n_keep_draws)
     draws = np.zeros((n_keep, d, n_chains)) if want_draws else None
     n_accept = np.zeros(n_chains, dtype=np.uint64)
