@@ -46,6 +46,8 @@ struct HmcParams {
     const int* btype;       // bounded runs: per-dimension bounds type 1..4 (determine_bounds_type.hpp:27-57), device
     const double* lb;       // lower / upper bounds, device, d values
     const double* ub;
+    const double* m_sqrt;   // general runs: diag of CHOL_LOWER(precond) (hmc.cpp:59), device, d values (ones = identity)
+    const double* m_inv;    // diag of INV(precond) (hmc.cpp:58)
     uint32_t ablate;        // profiling only: 1 = skip kick/drift, 2 = skip mat-vec (results meaningless)
     uint32_t stagger;       // start delay of the second wave of each SIMD, in s_sleep(127) units
 };
@@ -171,7 +173,8 @@ __device__ __forceinline__ double box_log_jacobian_term(double v, int bt, double
 
 // WPB = waves per workgroup: 4 (one wave per SIMD, 512-register budget) or 8 (two waves per SIMD,
 // 256 registers each: one wave's VALU phases -- kick/drift, RNG, accept -- hide under the other's MFMAs).
-// BOUNDED: settings.vals_bound (hmc.cpp:84-95,107-122,134-136,211-218): the chain lives in the transformed
+// BOUNDED (the general variant): settings.vals_bound and / or a diagonal precond_mat.
+// vals_bound (hmc.cpp:84-95,107-122,134-136,211-218): the chain lives in the transformed
 // space; the target is evaluated at x = inv_transform(theta), the kick uses inv_jacobian * grad, the energy
 // adds log_jacobian (summed sequentially over dimensions, as the reference's scalar loop does).
 template <int NT, int WPB, bool BOUNDED = false>
@@ -182,13 +185,17 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     stage_precision<NT>(prm.P, prm.d, lds_P);
     double* lds_lb = lds_P + NT * NS * 64;                 // [16*NT] each, BOUNDED only
     double* lds_ub = lds_lb + 16 * NT;
-    int* lds_bt = reinterpret_cast<int*>(lds_ub + 16 * NT);
+    double* lds_ms = lds_ub + 16 * NT;                     // diag of chol(M) and of inv(M): a DIAGONAL precond_mat
+    double* lds_mi = lds_ms + 16 * NT;                     // (hmc.cpp:57-59) is an element-wise scaling
+    int* lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
     if (BOUNDED) {
         for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
             const bool in = (uint32_t)i < prm.d;
             lds_lb[i] = in ? prm.lb[i] : 0.0;
             lds_ub[i] = in ? prm.ub[i] : 0.0;
             lds_bt[i] = in ? prm.btype[i] : 1;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+            lds_mi[i] = in ? prm.m_inv[i] : 1.0;
         }
         __syncthreads();
     }
@@ -237,6 +244,19 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
                 const int i = 4 * s + j;
                 kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];   // J_ii * grad_i (gemv with a diagonal J)
             }
+        }
+    };
+    // K = p . (Minv p) / 2 (hmc.cpp:160,184)
+    auto kinetic = [&]() __attribute__((always_inline)) -> double {
+        if constexpr (BOUNDED) {
+            double q = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j] * pm[s], q);
+            q = q + __shfl_xor(q, 32);
+            q = q + __shfl_xor(q, 16);
+            return q / 2.0;
+        } else {
+            return dot4<NS>(pm, pm) / 2.0;
         }
     };
     // U = -box_log_kernel(theta) at the state whose w (and xs) are current (hmc.cpp:84-95,140,178)
@@ -292,9 +312,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
             rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
+            if constexpr (BOUNDED) {                    // p = L z with a diagonal L (:158)
+                pm[2 * b] = lds_ms[8 * b + j] * pm[2 * b];
+                pm[2 * b + 1] = lds_ms[8 * b + 4 + j] * pm[2 * b + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const double prev_K = dot4<NS>(pm, pm) / 2.0;   // hmc.cpp:160
+        const double prev_K = kinetic();                // hmc.cpp:160
         refresh_kw();
 
 #pragma unroll 1
@@ -304,7 +328,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
             for (int s = 0; s < NS; ++s) {
                 const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
                 pm[s] = pm[s] - (eps * gw) / 2.0;       // first half-step (:167,126 / :122)
-                th[s] = th[s] + eps * pm[s];            // (:171)
+                if constexpr (BOUNDED) th[s] = th[s] + eps * (lds_mi[4 * s + j] * pm[s]);   // theta += eps * Minv p (:171)
+                else th[s] = th[s] + eps * pm[s];
             }
             }
             if (prm.ablate != 2) gradient();
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
 
         double prop_U = potential();                    // -box_log_kernel(new_draw), hmc.cpp:178
         if (!is_finite(prop_U)) prop_U = INF;           // :180-182
-        const double prop_K = dot4<NS>(pm, pm) / 2.0;   // :184
+        const double prop_K = kinetic();                // :184
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;  // std::min(0.01, x), :188
         const double z = rng_uniform(prm.seed, chain, draw, 0u);   // :189

@@ -223,7 +223,7 @@ template <int NT>
 int launch_hmc_mfma_bounded(const mi::HmcParams& prm, hipStream_t st)
 {
     constexpr int WPB = 4;      // one wave per SIMD: the bounded variant holds two more register-resident vectors
-    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (2 * sizeof(double) + sizeof(int));
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
     auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
@@ -281,12 +281,24 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat is not implemented on the device path yet");
     const uint64_t d = target->d;
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
-    const bool bounded = settings->vals_bound != 0;
-    if (bounded && (!settings->lower_bounds || !settings->upper_bounds))
+    // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
+    // element-wise 1/m and sqrt(m), exactly what the oracle's Gauss-Jordan / Cholesky produce); dense is not yet
+    std::vector<double> m_sqrt, m_inv;
+    if (settings->precond_mat) {
+        if (d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with d > 128 is not implemented");
+        m_sqrt.resize(d); m_inv.resize(d);
+        for (uint64_t i = 0; i < d; ++i)
+            for (uint64_t k = 0; k < d; ++k) {
+                const double v = settings->precond_mat[i * d + k];
+                if (i != k && v != 0.0) return fail(MI_ERR_UNSUPPORTED, "hmc: only a diagonal precond_mat is implemented on the device path");
+                if (i == k) { m_sqrt[i] = __builtin_sqrt(v); m_inv[i] = 1.0 / v; }
+            }
+    }
+    const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
         return fail(MI_ERR_BAD_ARG, "hmc: vals_bound needs lower_bounds and upper_bounds");
     if (bounded && d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound with d > 128 is not implemented");
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
@@ -365,15 +377,24 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (bounded) {
         // determine_bounds_type (determine_bounds_type.hpp:27-57): 1 none, 2 lower, 3 upper, 4 both
         std::vector<int> bt(d, 1);
-        for (uint64_t i = 0; i < d; ++i) {
-            const bool fl = std::isfinite(settings->lower_bounds[i]), fu = std::isfinite(settings->upper_bounds[i]);
-            bt[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
-        }
+        std::vector<double> lbv(d, 0.0), ubv(d, 0.0);
+        if (settings->vals_bound)
+            for (uint64_t i = 0; i < d; ++i) {
+                lbv[i] = settings->lower_bounds[i]; ubv[i] = settings->upper_bounds[i];
+                const bool fl = std::isfinite(lbv[i]), fu = std::isfinite(ubv[i]);
+                bt[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+            }
+        if (m_sqrt.empty()) { m_sqrt.assign(d, 1.0); m_inv.assign(d, 1.0); }
+        DevBuf ms_dev, mi_dev;
         HIP_TRY(bt_dev.alloc(d * sizeof(int))); HIP_TRY(lb_dev.alloc(d * 8)); HIP_TRY(ub_dev.alloc(d * 8));
+        HIP_TRY(ms_dev.alloc(d * 8)); HIP_TRY(mi_dev.alloc(d * 8));
         HIP_TRY(hipMemcpy(bt_dev.p, bt.data(), d * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(lb_dev.p, settings->lower_bounds, d * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ub_dev.p, settings->upper_bounds, d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lb_dev.p, lbv.data(), d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ub_dev.p, ubv.data(), d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ms_dev.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(mi_dev.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
         prm.btype = bt_dev.as<int>(); prm.lb = lb_dev.as<double>(); prm.ub = ub_dev.as<double>();
+        prm.m_sqrt = ms_dev.as<double>(); prm.m_inv = mi_dev.as<double>();
         if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
         else if (nt == 2) rc = launch_hmc_mfma_bounded<2>(prm, st);
         else if (nt <= 4) rc = launch_hmc_mfma_bounded<4>(prm, st);

@@ -256,3 +256,32 @@ def test_bounded_hmc_bit_exact_vs_oracle(d, C, L, eps, burn, keep):
     assert np.array_equal(g_draws, o_draws)
     inside = (g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])
     assert inside.all()                                  # draws are reported in the constrained space
+
+
+# ---------------------------------------------------------------- precond_mat (diagonal), SURVEY 8(f-2)
+@pytest.mark.parametrize("d,C,L,eps,bounded", [(8, 16, 5, 0.1, False), (128, 40, 3, 0.03, False), (20, 24, 4, 0.05, True)])
+def test_diagonal_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    M = np.diag(1.0 / np.diag(prec) * np.linspace(0.5, 2.0, d))        # a diagonal mass matrix
+    init = np.clip(synth.initial_states(C, d, seed=15) * 0.3, -1.0, 1.5)
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = _bounds(d, seed=3)
+        kw = dict(vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+        okw = dict(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=3, n_keep_draws=7, n_leap_steps=L, step_size=eps,
+                                   precond_mat=M, **kw)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=5, n_burnin=3, n_keep=7, n_leap=L, step=eps, W=4, precond=M, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+
+
+def test_dense_precond_is_refused_not_approximated():
+    d = 8
+    M = np.eye(d); M[0, 1] = M[1, 0] = 0.1
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:
+        mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
