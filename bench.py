@@ -164,6 +164,12 @@ def main():
         barrier()
         collate_ms = (time.perf_counter() - tc) * 1e3
 
+    # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, from a
+    # 256-chain sample of the kept draws of the last step, scaled to all chains; computed outside the timed region
+    from mcmc_amd.ess import ess_min_total
+    sub = draws[:, :, : min(C, 256)].cpu().numpy()
+    ess_total_rank, _ = ess_min_total(sub, n_chains_total=C)
+
     leap_per_chain = int(n_leap[0].item())
     acc_rate = float(n_accept.double().mean().item()) / n_keep
     assert leap_per_chain == n_tot * cfg["n_leap_steps"]
@@ -194,6 +200,8 @@ def main():
                          "kernel": "hmc_gauss_mfma_kernel<8, 8>", "kernel_ms": k_ms,
                          "flop_per_unit": flop_per_unit},
         }
+        out["ess_per_sec"] = ess_total_rank * world / (elapsed / args.steps)
+        out["ess_note"] = "min-over-dims Geyer-IPS ESS of the 100 kept draws, pooled over a 256-chain sample, x chains, / seconds per step"
         if collate_ms is not None:
             out["collate_last_draw_allgather_ms"] = collate_ms
         if not args.no_cpu_baseline and world == 1:

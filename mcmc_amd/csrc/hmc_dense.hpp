@@ -26,6 +26,10 @@
 
 #include "det_math.hpp"
 
+#ifndef MI_HMC_RNG_STAGED
+#define MI_HMC_RNG_STAGED 0
+#endif
+
 namespace mi {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -220,9 +224,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     // addresses = wave-uniform row base (SGPR) + one per-lane element offset (VGPR)
     const size_t lane_off = (size_t)j * C + cld;
     // last accepted (theta, P*theta): wave-local contiguous [wave][2][NS][64 lanes] (512-B coalesced per slice)
-    double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)2 * NS * 64) + lane;
+    double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)3 * NS * 64) + lane;
     auto th_mem = [&](int s) -> double* { return ws_wave + (size_t)s * 64; };
     auto w_mem = [&](int s) -> double* { return ws_wave + (size_t)(NS + s) * 64; };
+    auto z_mem = [&](int s) -> double* { return ws_wave + (size_t)(2 * NS + s) * 64; };   // fresh normals, staged
 
     // w = P * (theta or inv_transform(theta)); BOUNDED also refreshes xs and kw
     auto gradient = [&]() __attribute__((always_inline)) {
@@ -305,11 +310,31 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
-        // momentum ~ N(0, I): hmc.cpp:156-158 (L = chol(I) = I)
+#if MI_HMC_RNG_STAGED
+        // momentum ~ N(0, I): hmc.cpp:156-158.  The 16 Philox blocks + Box-Muller pairs run as a ROLLED loop that
+        // stages the normals through the wave-local workspace (16 KiB, cache-resident): few live registers next
+        // to the 128 VGPRs of theta / P*theta, no spills, small code; then one burst of 32 coalesced loads.
+#pragma unroll 1
+        for (int b = 0; b < NS / 2; ++b) {
+            double z0, z1;
+            if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
+            else rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            *z_mem(2 * b) = (8u * b + j < d) ? z0 : 0.0;
+            *z_mem(2 * b + 1) = (8u * b + 4 + j < d) ? z1 : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pm[s] = *z_mem(s);
+        if constexpr (BOUNDED) {                        // p = L z with a diagonal L (:158)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = lds_ms[4 * s + j] * pm[s];
+        }
+#else
+        // momentum ~ N(0, I): hmc.cpp:156-158, fully unrolled into the momentum registers
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
+            else rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
             if constexpr (BOUNDED) {                    // p = L z with a diagonal L (:158)
@@ -318,12 +343,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         const double prev_K = kinetic();                // hmc.cpp:160
         refresh_kw();
 
 #pragma unroll 1
         for (uint32_t k = 0; k < prm.n_leap_steps; ++k) {   // hmc.cpp:164-176, grad = -w
-            if (prm.ablate != 1) {
+            if ((prm.ablate & 3u) != 1u) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
@@ -332,9 +358,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
                 else th[s] = th[s] + eps * pm[s];
             }
             }
-            if (prm.ablate != 2) gradient();
+            if ((prm.ablate & 3u) != 2u) gradient();
             refresh_kw();
-            if (prm.ablate != 1) {
+            if ((prm.ablate & 3u) != 1u) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
         const bool accept = z < det_exp(comp_val);      // :191
         if (accept) {                                   // prev_draw = new_draw (:192-194)
             prev_U = prop_U;
-            if (live) {
+            if (live && !(prm.ablate & 8u)) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { *th_mem(s) = th[s]; *w_mem(s) = w[s]; }
             }
@@ -363,7 +389,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
         }
         if (draw >= prm.n_burnin) {                     // :196-204
             n_acc += accept ? 1u : 0u;
-            if (prm.draws != nullptr && live) {
+            if (prm.draws != nullptr && live && !(prm.ablate & 16u)) {
                 double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {

@@ -357,7 +357,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
     void* wsave = nullptr;
     const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, 2 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), &wsave);
+    rc = ws_get(st, 3 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), &wsave);
     if (rc) return rc;
     prm.wsave = static_cast<double*>(wsave);
     prm.draws = sc.dev.draws;

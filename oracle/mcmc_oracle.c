@@ -156,7 +156,6 @@ static double orc_log_det_from_chol(const double* L, size_t d)
 
 /* stats_mcmc::dmvnorm(X, mu, Sigma, true)  (ref: include/stats/dmvnorm.hpp:28-54)
  * QUAD_FORM_INV(x,S) restated as dot(x, INV(S) x). */
-static int g_dummy_unused;
 static double orc_dmvnorm_core_b(const double* x, const double* mu, size_t d, const double* Sinv,
                                  double log_det, int W, int nblk, size_t bs, double* xc, double* t)
 {
@@ -164,7 +163,6 @@ static double orc_dmvnorm_core_b(const double* x, const double* mu, size_t d, co
     for (size_t i = 0; i < d; ++i) xc[i] = x[i] - mu[i];                 /* :37 */
     orc_gemv(Sinv, xc, d, t);
     const double quad_term = orc_dot_b(xc, t, d, W, nblk, bs);           /* :39 */
-    (void)g_dummy_unused;
     return cons_term - 0.5 * (log_det + quad_term);                      /* :41 */
 }
 
