@@ -43,6 +43,7 @@ struct MalaLogitParams {
     uint32_t d, n_rows, NB;
     uint64_t C, chain0;
     double* theta;          // [d][C] in/out
+    double* state;          // workspace: current (beta, grad) of every chain, wave-local layout (see kernel)
     double* draws;
     uint64_t* n_accept;
     uint64_t seed;
@@ -73,28 +74,37 @@ __global__ void pack_logistic_kernel(const double* __restrict__ X, const double*
     }
 }
 
-template <int NTQ>
+// CT = chain tiles (of 16 chains) per workgroup: every X fragment fetched from L2 feeds CT MFMAs, which is
+// what lifts the kernel off the X stream.  The current state (beta, grad) of the chains lives in a wave-local
+// workspace ([workgroup][wave][beta|grad][tile][slice][lane], 8 KiB per chain in total, touched twice per draw);
+// registers hold the proposal, its gradient accumulators and the X fragments in flight.
+template <int NTQ, int CT>
 __global__ __launch_bounds__(256, 1) void mala_logistic_kernel(const MalaLogitParams prm)
 {
     constexpr int NSQ = 4 * NTQ, DQ = 16 * NTQ;
-    __shared__ double lds_part[2][4][4][64];     // partial eta tiles  [buf][wave][reg][lane]
-    __shared__ double lds_rt[2][4][2][64];       // residual / log-lik term of row group q  [buf][q][0/1][lane]
-    __shared__ double lds_dot[4][4][64];         // block dot exchange [which][wave][lane]
+    __shared__ double lds_part[2][4][CT][4][64];     // partial eta tiles  [buf][wave][tile][reg][lane]
+    __shared__ double lds_rt[2][4][CT][2][64];       // residual / log-lik term of row group q  [buf][q][tile][0/1][lane]
+    __shared__ double lds_dot[2 * CT][4][64];        // block dot exchange [which][wave][lane]
 
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int j4 = lane >> 4;
-    const uint64_t cl = (uint64_t)blockIdx.x * 16 + (lane & 15);
-    const bool live = cl < prm.C;
-    const uint64_t cld = live ? cl : prm.C - 1;
-    const uint64_t chain = prm.chain0 + cl;
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
     const double eps = prm.eps, s2 = prm.s2, rs = prm.rs;
     const uint32_t NB = prm.NB;
+    uint64_t cl[CT], chain[CT];
+    bool live[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        cl[c] = ((uint64_t)blockIdx.x * CT + c) * 16 + (lane & 15);
+        live[c] = cl[c] < C;
+        chain[c] = prm.chain0 + cl[c];
+    }
+    double* const ws_wave = prm.state + ((size_t)blockIdx.x * 4 + q) * ((size_t)2 * CT * NSQ * 64) + lane;
+    auto st = [&](int v, int c, int s) -> double* { return ws_wave + (((size_t)v * CT + c) * NSQ + s) * 64; };
 
-    double be[NSQ], gr[NSQ];       // current state and its gradient (this wave's dims)
-    double bp[NSQ], gp[NSQ];       // proposal and its gradient
-    double ae[NSQ], ag[4 * NTQ];   // X fragments in flight
+    double bp[CT][NSQ], gp[CT][NSQ];   // proposal and its gradient (this wave's dims)
+    double ae[NSQ], ag[4 * NTQ];       // X fragments in flight
 
     auto dim_of = [&](int s) -> uint32_t { return (uint32_t)(q * DQ + 4 * s + j4); };
     auto load_xe = [&](uint32_t b) __attribute__((always_inline)) {
@@ -107,153 +117,209 @@ __global__ __launch_bounds__(256, 1) void mala_logistic_kernel(const MalaLogitPa
 #pragma unroll
         for (int k = 0; k < 4 * NTQ; ++k) ag[k] = src[(size_t)k * 64];
     };
-    // ((S0 + S1) + S2) + S3 of up to 3 per-wave partial dots (each already butterflied inside the wave)
-    auto exchange3 = [&](double& a, double& b2, double& c) __attribute__((always_inline)) {
+    // ((S0 + S1) + S2) + S3 of per-wave partial dots (each already butterflied inside the wave), 2*CT values
+    auto exchange = [&](double (&v)[2 * CT]) __attribute__((always_inline)) {
         __syncthreads();
-        lds_dot[0][q][lane] = a; lds_dot[1][q][lane] = b2; lds_dot[2][q][lane] = c;
+#pragma unroll
+        for (int k = 0; k < 2 * CT; ++k) lds_dot[k][q][lane] = v[k];
         __syncthreads();
-        a = ((lds_dot[0][0][lane] + lds_dot[0][1][lane]) + lds_dot[0][2][lane]) + lds_dot[0][3][lane];
-        b2 = ((lds_dot[1][0][lane] + lds_dot[1][1][lane]) + lds_dot[1][2][lane]) + lds_dot[1][3][lane];
-        c = ((lds_dot[2][0][lane] + lds_dot[2][1][lane]) + lds_dot[2][2][lane]) + lds_dot[2][3][lane];
+#pragma unroll
+        for (int k = 0; k < 2 * CT; ++k)
+            v[k] = ((lds_dot[k][0][lane] + lds_dot[k][1][lane]) + lds_dot[k][2][lane]) + lds_dot[k][3][lane];
     };
 
-    // value and gradient at x: returns log K(x), fills gout (gradient on this wave's dims)
-    auto evaluate = [&](const double (&x)[NSQ], double (&gout)[NSQ]) __attribute__((always_inline)) -> double {
-        double4_t gacc[NTQ];
+    // value and gradient at x (all CT tiles): lp[c] = log K, gout = gradient on this wave's dims
+    auto evaluate = [&](const double (&x)[CT][NSQ], double (&gout)[CT][NSQ], double (&lp)[CT]) __attribute__((always_inline)) {
+        double4_t gacc[CT][NTQ];
+        double llq[CT];
 #pragma unroll
-        for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-        double llq = 0.0;
+        for (int c = 0; c < CT; ++c) {
+            llq[c] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) gacc[c][t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        }
         load_xe(0);
         load_xg(0);
 #pragma unroll 1
         for (uint32_t b = 0; b < NB; ++b) {
             const int buf = (int)(b & 1u);
-            if (!MI_LOGIT_PREFETCH && b > 0) { load_xe(b); load_xg(b); }
-            double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+            double4_t acc[CT];
 #pragma unroll
-            for (int s = 0; s < NSQ; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[s], x[s], acc, 0, 0, 0);
-            if (MI_LOGIT_PREFETCH && b + 1 < NB) load_xe(b + 1);
-#if MI_LOGIT_EXTRA_NOPS
-            asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
-#endif
-            lds_part[buf][q][0][lane] = acc[0]; lds_part[buf][q][1][lane] = acc[1];
-            lds_part[buf][q][2][lane] = acc[2]; lds_part[buf][q][3][lane] = acc[3];
+            for (int c = 0; c < CT; ++c) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[s], x[c][s], acc[c], 0, 0, 0);
+            }
+            if (b + 1 < NB) load_xe(b + 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                lds_part[buf][q][c][0][lane] = acc[c][0]; lds_part[buf][q][c][1][lane] = acc[c][1];
+                lds_part[buf][q][c][2][lane] = acc[c][2]; lds_part[buf][q][c][3][lane] = acc[c][3];
+            }
             __syncthreads();
             {   // row group q: rows 16b + 4q + j4
-                const double eta = ((lds_part[buf][0][q][lane] + lds_part[buf][1][q][lane]) + lds_part[buf][2][q][lane])
-                                   + lds_part[buf][3][q][lane];
                 const uint32_t row = 16 * b + 4 * q + j4;
                 const double yv = prm.ypad[row];
                 const bool valid = row < prm.n_rows;
-                // softplus / sigmoid share e = exp(-|eta|) (the oracle evaluates it once per function; same bits)
-                const double e = det_exp(eta > 0.0 ? -eta : eta);
-                const double l1p = det_log(1.0 + e);
-                const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
-                const double sg = (eta >= 0.0) ? (1.0 / (1.0 + e)) : (e / (1.0 + e));
-                lds_rt[buf][q][0][lane] = valid ? (yv - sg) : 0.0;
-                lds_rt[buf][q][1][lane] = valid ? (yv * eta - sp) : 0.0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const double eta = ((lds_part[buf][0][c][q][lane] + lds_part[buf][1][c][q][lane]) + lds_part[buf][2][c][q][lane])
+                                       + lds_part[buf][3][c][q][lane];
+                    // softplus / sigmoid share e = exp(-|eta|) (the oracle evaluates it once per function; same bits)
+                    const double e = det_exp(eta > 0.0 ? -eta : eta);
+                    const double l1p = det_log(1.0 + e);
+                    const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
+                    const double sg = (eta >= 0.0) ? (1.0 / (1.0 + e)) : (e / (1.0 + e));
+                    lds_rt[buf][q][c][0][lane] = valid ? (yv - sg) : 0.0;
+                    lds_rt[buf][q][c][1][lane] = valid ? (yv * eta - sp) : 0.0;
+                }
             }
             __syncthreads();
-            double res[4];
+            double res[CT][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { res[r] = lds_rt[buf][r][0][lane]; llq = llq + lds_rt[buf][r][1][lane]; }
+            for (int c = 0; c < CT; ++c) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { res[c][r] = lds_rt[buf][r][c][0][lane]; llq[c] = llq[c] + lds_rt[buf][r][c][1][lane]; }
+            }
 #pragma unroll
             for (int t = 0; t < NTQ; ++t) {
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp)
-                    gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[t * 4 + sp], res[sp], gacc[t], 0, 0, 0);
+                for (int sp = 0; sp < 4; ++sp) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        gacc[c][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[t * 4 + sp], res[c][sp], gacc[c][t], 0, 0, 0);
+                }
             }
-            if (MI_LOGIT_PREFETCH && b + 1 < NB) load_xg(b + 1);
+            if (b + 1 < NB) load_xg(b + 1);
         }
-        llq = llq + __shfl_xor(llq, 32);
-        llq = llq + __shfl_xor(llq, 16);
-        double nrm = 0.0;
+        double v[2 * CT];
 #pragma unroll
-        for (int s = 0; s < NSQ; ++s) nrm = dfma(x[s], x[s], nrm);
-        nrm = nrm + __shfl_xor(nrm, 32);
-        nrm = nrm + __shfl_xor(nrm, 16);
-        double u1 = 0.0, u2 = 0.0;
-        exchange3(nrm, u1, u2);
+        for (int c = 0; c < CT; ++c) {
+            llq[c] = llq[c] + __shfl_xor(llq[c], 32);
+            llq[c] = llq[c] + __shfl_xor(llq[c], 16);
+            double nrm = 0.0;
 #pragma unroll
-        for (int t = 0; t < NTQ; ++t) {
-            gout[4 * t + 0] = gacc[t][0] - x[4 * t + 0];
-            gout[4 * t + 1] = gacc[t][1] - x[4 * t + 1];
-            gout[4 * t + 2] = gacc[t][2] - x[4 * t + 2];
-            gout[4 * t + 3] = gacc[t][3] - x[4 * t + 3];
+            for (int s = 0; s < NSQ; ++s) nrm = dfma(x[c][s], x[c][s], nrm);
+            nrm = nrm + __shfl_xor(nrm, 32);
+            nrm = nrm + __shfl_xor(nrm, 16);
+            v[2 * c] = nrm; v[2 * c + 1] = 0.0;
         }
-        return llq - 0.5 * nrm;
+        exchange(v);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) {
+                gout[c][4 * t + 0] = gacc[c][t][0] - x[c][4 * t + 0];
+                gout[c][4 * t + 1] = gacc[c][t][1] - x[c][4 * t + 1];
+                gout[c][4 * t + 2] = gacc[c][t][2] - x[c][4 * t + 2];
+                gout[c][4 * t + 3] = gacc[c][t][3] - x[c][4 * t + 3];
+            }
+            lp[c] = llq[c] - 0.5 * v[2 * c];
+        }
     };
 
+    double prev_LP[CT], prop_LP[CT];
 #pragma unroll
-    for (int s = 0; s < NSQ; ++s) {
-        const uint32_t dim = dim_of(s);
-        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];
-        be[s] = (dim < d) ? v : 0.0;
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) {
+            const uint32_t dim = dim_of(s);
+            const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + (live[c] ? cl[c] : C - 1)];
+            bp[c][s] = (dim < d) ? v : 0.0;
+        }
     }
-    double prev_LP = evaluate(be, gr);                   // box_log_kernel(first_draw), mala.cpp:138
-    uint64_t n_acc = 0;
+    evaluate(bp, gp, prev_LP);                           // box_log_kernel(first_draw), mala.cpp:138
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) { *st(0, c, s) = bp[c][s]; *st(1, c, s) = gp[c][s]; }
+    }
+    uint64_t n_acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) n_acc[c] = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
         // proposal = mala_mean_fn(prev) + eps * z   (mala.cpp:150,159)
 #pragma unroll
-        for (int m = 0; m < NSQ / 2; ++m) {
-            double z0, z1;
-            const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
-            rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1);
-            const double za = (dim_of(2 * m) < d) ? z0 : 0.0;
-            const double zb = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
-            bp[2 * m] = (be[2 * m] + (s2 * gr[2 * m]) / 2.0) + eps * za;           // :123, :159
-            bp[2 * m + 1] = (be[2 * m + 1] + (s2 * gr[2 * m + 1]) / 2.0) + eps * zb;
-            __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int m = 0; m < NSQ / 2; ++m) {
+                double z0, z1;
+                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
+                rng_normal_pair(prm.seed, chain[c], draw, slot, STREAM_NORMAL, z0, z1);
+                const double za = (dim_of(2 * m) < d) ? z0 : 0.0;
+                const double zb = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                bp[c][2 * m] = (*st(0, c, 2 * m) + (s2 * *st(1, c, 2 * m)) / 2.0) + eps * za;           // :123, :159
+                bp[c][2 * m + 1] = (*st(0, c, 2 * m + 1) + (s2 * *st(1, c, 2 * m + 1)) / 2.0) + eps * zb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        double prop_LP = evaluate(bp, gp);               // :162
-        if (!is_finite(prop_LP)) prop_LP = -INF;         // :164-166
+        evaluate(bp, gp, prop_LP);                       // :162
         // mala_prop_adjustment (mala.ipp:59-64)
-        double qa = 0.0, qb = 0.0, dummy = 0.0;
+        double qv[2 * CT];
 #pragma unroll
-        for (int s = 0; s < NSQ; ++s) {
-            const double mean_prop = bp[s] + (s2 * gp[s]) / 2.0;
-            const double xa = be[s] - mean_prop;         // dmvnorm.hpp:37
-            qa = dfma(xa, rs * xa, qa);
-            const double mean_prev = be[s] + (s2 * gr[s]) / 2.0;
-            const double xb = bp[s] - mean_prev;
-            qb = dfma(xb, rs * xb, qb);
+        for (int c = 0; c < CT; ++c) {
+            double qa = 0.0, qb = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) {
+                const double be = *st(0, c, s), gr = *st(1, c, s);
+                const double mean_prop = bp[c][s] + (s2 * gp[c][s]) / 2.0;
+                const double xa = be - mean_prop;        // dmvnorm.hpp:37
+                qa = dfma(xa, rs * xa, qa);
+                const double mean_prev = be + (s2 * gr) / 2.0;
+                const double xb = bp[c][s] - mean_prev;
+                qb = dfma(xb, rs * xb, qb);
+            }
+            qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
+            qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
+            qv[2 * c] = qa; qv[2 * c + 1] = qb;
         }
-        qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
-        qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
-        exchange3(qa, qb, dummy);
-        const double da = prm.cons_term - 0.5 * (prm.log_det + qa);               // dmvnorm.hpp:41
-        const double db = prm.cons_term - 0.5 * (prm.log_det + qb);
-        const double x = prop_LP - prev_LP + (da - db);
-        const double comp_val = (x < 0.01) ? x : 0.01;   // mala.cpp:170
-        const double z = rng_uniform(prm.seed, chain, draw, 0u);                  // :171
-        const bool accept = z < det_exp(comp_val);       // :173
-        if (accept) {
+        exchange(qv);
 #pragma unroll
-            for (int s = 0; s < NSQ; ++s) { be[s] = bp[s]; gr[s] = gp[s]; }
-            prev_LP = prop_LP;
-        }
-        if (draw >= prm.n_burnin) {
-            n_acc += accept ? 1u : 0u;
-            if (prm.draws != nullptr && live) {
-                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C + cl;
+        for (int c = 0; c < CT; ++c) {
+            double pl = prop_LP[c];
+            if (!is_finite(pl)) pl = -INF;               // mala.cpp:164-166
+            const double da = prm.cons_term - 0.5 * (prm.log_det + qv[2 * c]);   // dmvnorm.hpp:41
+            const double db = prm.cons_term - 0.5 * (prm.log_det + qv[2 * c + 1]);
+            const double x = pl - prev_LP[c] + (da - db);
+            const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
+            const double z = rng_uniform(prm.seed, chain[c], draw, 0u);          // :171
+            const bool accept = z < det_exp(comp_val);                           // :173
+            if (accept) {
+                prev_LP[c] = pl;
+                if (live[c]) {
 #pragma unroll
-                for (int s = 0; s < NSQ; ++s) {
-                    const uint32_t dim = dim_of(s);
-                    if (dim < d) out[(size_t)dim * C] = be[s];
+                    for (int s = 0; s < NSQ; ++s) { *st(0, c, s) = bp[c][s]; *st(1, c, s) = gp[c][s]; }
+                }
+            }
+            if (draw >= prm.n_burnin) {
+                n_acc[c] += accept ? 1u : 0u;
+                if (prm.draws != nullptr && live[c]) {
+                    double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C + cl[c];
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) {
+                        const uint32_t dim = dim_of(s);
+                        const double v = accept ? bp[c][s] : *st(0, c, s);
+                        if (dim < d) out[(size_t)dim * C] = v;
+                    }
                 }
             }
         }
     }
-    if (live) {
 #pragma unroll
-        for (int s = 0; s < NSQ; ++s) {
-            const uint32_t dim = dim_of(s);
-            if (dim < d) prm.theta[(size_t)dim * C + cl] = be[s];
+    for (int c = 0; c < CT; ++c) {
+        if (live[c]) {
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) {
+                const uint32_t dim = dim_of(s);
+                const double v = *st(0, c, s);
+                if (dim < d) prm.theta[(size_t)dim * C + cl[c]] = v;
+            }
+            if (q == 0 && j4 == 0 && prm.n_accept) prm.n_accept[cl[c]] = n_acc[c];
         }
-        if (q == 0 && j4 == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
     }
 }
 

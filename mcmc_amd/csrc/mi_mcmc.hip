@@ -163,27 +163,37 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     return MI_OK;
 }
 
-template <int NTQ>
-int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+template <int NTQ, int CT>
+int launch_mala_logistic_ct(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
 {
     constexpr int NSQ = 4 * NTQ;
     const size_t NB = prm.NB;
+    const size_t n_wg = (prm.C + 16 * CT - 1) / (16 * CT);
     const size_t n_xe = NB * 4 * NSQ * 64, n_xg = NB * 4 * NTQ * 4 * 64, n_yp = NB * 16;
+    const size_t n_state = n_wg * 4 * 2 * CT * NSQ * 64;
     void* base = nullptr;
-    int rcw = ws_get(st, (n_xe + n_xg + n_yp) * sizeof(double), &base);
+    int rcw = ws_get(st, (n_xe + n_xg + n_yp + n_state) * sizeof(double), &base);
     if (rcw) return rcw;
-    void* xe = base;
-    void* xg = static_cast<double*>(base) + n_xe;
-    void* yp = static_cast<double*>(base) + n_xe + n_xg;
+    double* xe = static_cast<double*>(base);
+    double* xg = xe + n_xe;
+    double* yp = xg + n_xg;
+    prm.state = yp + n_yp;
     hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
-                       prm.NB, static_cast<double*>(xe), static_cast<double*>(xg), static_cast<double*>(yp));
-    prm.XE = static_cast<const double*>(xe);
-    prm.XG = static_cast<const double*>(xg);
-    prm.ypad = static_cast<const double*>(yp);
-
-    hipLaunchKernelGGL(mi::mala_logistic_kernel<NTQ>, dim3((unsigned)((prm.C + 15) / 16)), dim3(256), 0, st, prm);
+                       prm.NB, xe, xg, yp);
+    prm.XE = xe; prm.XG = xg; prm.ypad = yp;
+    hipLaunchKernelGGL((mi::mala_logistic_kernel<NTQ, CT>), dim3((unsigned)n_wg), dim3(256), 0, st, prm);
     HIP_TRY(hipGetLastError());
     return MI_OK;
+}
+
+template <int NTQ>
+int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+{
+    // CT = 2 (every X fragment feeds two MFMAs) halves the L2 stream but currently spills (2.7 KiB scratch per lane)
+    // and measures 2.7x slower than CT = 1 at config 3; it stays selectable for the next round of tuning
+    int ct = 1;
+    if (const char* e = getenv("MI_MALA_CT")) ct = atoi(e) == 2 ? 2 : 1;
+    return ct == 2 ? launch_mala_logistic_ct<NTQ, 2>(prm, X_dev, y_dev, st) : launch_mala_logistic_ct<NTQ, 1>(prm, X_dev, y_dev, st);
 }
 
 template <int NT>
