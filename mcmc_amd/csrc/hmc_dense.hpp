@@ -308,6 +308,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     if (WPB > 4 && wave >= 4)
         for (uint32_t k = 0; k < prm.stagger; ++k) __builtin_amdgcn_s_sleep(127);
 
+    const unsigned long long t_loop0 = clock64();
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
 #if MI_HMC_RNG_STAGED
@@ -412,7 +413,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     }
     if (live && j == 0) {
         if (prm.n_accept) prm.n_accept[cl] = n_acc;                            // hmc.cpp:220-222
-        if (prm.n_leap) prm.n_leap[cl] = (uint64_t)n_total * prm.n_leap_steps;
+        if (prm.n_leap) prm.n_leap[cl] = (prm.ablate & 32u) ? (uint64_t)(clock64() - t_loop0)      // profiling: shader cycles of the draw loop
+                                                            : (uint64_t)n_total * prm.n_leap_steps;
     }
 }
 

@@ -40,4 +40,4 @@ for rep in range(args.reps):
     print(json.dumps({"algo": args.algo, "chains": C, "d": d, "ms": ms, "leapfrogs_executed": leaps,
                       "units_per_s": leaps * d / (ms * 1e-3), "mean_leaps_per_draw": leaps / C / (args.burn + args.keep),
                       "max_over_mean_leaps": float(n_leap.max().item()) / (leaps / C),
-                      "accept": float(n_accept.double().mean().item()) / args.keep, "eps_mean": float(eps.mean().item())}))
+                      "accept": float(n_accept.double().mean().item()) / args.keep, "n_leap0": int(n_leap[0].item()), "eps_mean": float(eps.mean().item())}))
