@@ -16,6 +16,9 @@
 
 #include "nuts_dense.hpp"
 
+#ifndef MI_NUTS_CHU
+#define MI_NUTS_CHU 32
+#endif
 #ifndef MI_NUTS_CH
 #define MI_NUTS_CH 32
 #endif
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
     };
     // vector ops touch 8 slices at a time (16 VGPRs in flight): the register file is full of theta / p / P*theta
     constexpr int CH = (NS < MI_NUTS_CH) ? NS : MI_NUTS_CH;
+    constexpr int CHU = (NS < MI_NUTS_CHU) ? NS : MI_NUTS_CHU;   // U-turn operands: 4 vectors in flight per chunk
     auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
         if (pred && live) {
 #pragma unroll
@@ -111,22 +115,22 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         double q1 = 0.0, q2 = 0.0;
         if (pred) {
 #pragma unroll
-            for (int c0 = 0; c0 < NS; c0 += CH) {
-                double t1[CH], p1[CH], t2[CH], p2[CH];
+            for (int c0 = 0; c0 < NS; c0 += CHU) {
+                double t1[CHU], p1[CHU], t2[CHU], p2[CHU];
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
+                for (int k = 0; k < CHU; ++k) {
                     t1[k] = *wsp(vt1, c0 + k);
                     p1[k] = *wsp(vp1, c0 + k);
                     t2[k] = n2_in_regs ? th[c0 + k] : *wsp(vt2, c0 + k);
                     p2[k] = n2_in_regs ? pm[c0 + k] : *wsp(vp2, c0 + k);
                 }
 #pragma unroll
-                for (int k = 0; k < CH; ++k) {
+                for (int k = 0; k < CHU; ++k) {
                     const double dd = (vdir > 0) ? (t2[k] - t1[k]) : (t1[k] - t2[k]);
                     q1 = dfma(dd, p1[k], q1);
                     q2 = dfma(dd, p2[k], q2);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (CHU < NS) __builtin_amdgcn_sched_barrier(0);
             }
         }
         q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);

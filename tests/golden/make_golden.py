@@ -1,0 +1,70 @@
+"""Generates tests/golden/oracle_kat.npz -- ORACLE regression vectors, NOT reference outputs.
+
+kthohr/mcmc ships no golden vectors and cannot be built in this image, so nothing here
+comes from the reference.  These vectors freeze the CPU oracle's own outputs on the known-answer shapes SURVEY.md
+8(c) lists (HMC / MALA / NUTS x {iso Gaussian d=3, dense Gaussian d=8, logistic d=5}, n_burnin=5, n_keep=20, fixed
+seeds), so that a later change of the oracle, of its math, or of the RNG layout is caught on the CPU, and so that
+the GPU tests have a second, committed reference next to the live oracle.
+
+    python tests/golden/make_golden.py        # rewrites oracle_kat.npz (only when the definition changes on purpose)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import orc  # noqa: E402
+from mcmc_amd import synth  # noqa: E402
+
+SEED, BURN, KEEP, C = 20240926, 5, 20, 4
+
+
+def cases():
+    P8 = synth.dense_gaussian_precision(8, seed=5)
+    X5, y5 = synth.logistic_problem(5, 40, seed=4)
+    targets = {
+        "iso3": dict(kind=orc.TARGET_ISO, d=3),
+        "dense8": dict(kind=orc.TARGET_DENSE, d=8, prec=P8),
+        "logit5": dict(kind=orc.TARGET_LOGISTIC, d=5, X=X5, y=y5, blocks=4, block_size=16),
+    }
+    algos = {
+        "hmc": dict(algo=orc.ALGO_HMC, n_leap=5, step=0.2),
+        "mala": dict(algo=orc.ALGO_MALA, step=0.15),
+        "nuts": dict(algo=orc.ALGO_NUTS, step=1.0, n_adapt=10),
+    }
+    for tn, t in targets.items():
+        for an, a in algos.items():
+            yield f"{an}_{tn}", t, a
+
+
+def run_case(t, a):
+    d = t["d"]
+    blocks, bs = t.get("blocks", 0), t.get("block_size", 0)
+    tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=4, blocks=blocks, block_size=bs)
+    init = synth.initial_states(C, d, seed=99) * 0.5
+    out = dict(draws=[], accept=[], depth=[], eps=[], n_leap=[])
+    for c in range(C):
+        s = orc.make_settings(seed=SEED, n_burnin=BURN, n_keep=KEEP, n_leap=a.get("n_leap", 1), step=a["step"],
+                              n_adapt=a.get("n_adapt", 1000), W=4, hoist=1, blocks=blocks, block_size=bs, chain_id=c)
+        dr, info = orc.run_chain(a["algo"], tgt, init[c], s, traces=True)
+        out["draws"].append(dr); out["accept"].append(info["accept"]); out["depth"].append(info["depth"])
+        out["eps"].append(info["eps"]); out["n_leap"].append(info["n_leap"])
+    return init, {k: np.array(v) for k, v in out.items()}
+
+
+def main():
+    blob = {}
+    for name, t, a in cases():
+        init, out = run_case(t, a)
+        blob[f"{name}/init"] = init
+        for k, v in out.items():
+            blob[f"{name}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "oracle_kat.npz"), **blob)
+    print("wrote", len(blob), "arrays")
+
+
+if __name__ == "__main__":
+    main()
