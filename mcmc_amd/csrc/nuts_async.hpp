@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         return u;
     };
     auto kinetic = [&]() __attribute__((always_inline)) -> double { return dot4<NS>(pm, pm) / 2.0; };
-    // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1
-    auto uturn_ok = [&](bool pred, int vt1, int vp1, bool n2_in_regs, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
+    // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1;
+    // all four operands come from the level records in the workspace
+    auto uturn_ok = [&](bool pred, int vt1, int vp1, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
         double q1 = 0.0, q2 = 0.0;
         if (pred) {
 #pragma unroll
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
                 for (int k = 0; k < CHU; ++k) {
                     t1[k] = *wsp(vt1, c0 + k);
                     p1[k] = *wsp(vp1, c0 + k);
-                    t2[k] = n2_in_regs ? th[c0 + k] : *wsp(vt2, c0 + k);
-                    p2[k] = n2_in_regs ? pm[c0 + k] : *wsp(vp2, c0 + k);
+                    t2[k] = *wsp(vt2, c0 + k);
+                    p2[k] = *wsp(vp2, c0 + k);
                 }
 #pragma unroll
                 for (int k = 0; k < CHU; ++k) {
@@ -302,50 +303,69 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
         if (__ballot(run) == 0ull) continue;
 
         // ------------------------------------------------------------ B. one leaf for every running chain
-        {   // start state of leaf li (per chain)
-            const int cz = (li == 0) ? 0 : __builtin_ctz(li);
-            const bool from_prev = run && li == 0;
-            const bool from_slot = run && li != 0 && cz >= 2;
-            if (__ballot(from_prev || from_slot) != 0ull) {
-                const int vt = from_prev ? V_PREV : (from_slot ? V_LEAF0 + 3 * cz : V_PREV);
-                const int vp = from_prev ? V_MNTM : (from_slot ? V_LEAF0 + 3 * cz + 1 : V_MNTM);
-                const int vw = from_prev ? V_WPREV : (from_slot ? V_LEAF0 + 3 * cz + 2 : V_WPREV);
-                load_vec_if(vt, th, from_prev || from_slot);
-                load_vec_if(vp, pm, from_prev || from_slot);
-                load_vec_if(vw, w, from_prev || from_slot);
+        // The register-resident state is TICK-LOCAL: start state <- workspace record, one leapfrog, energies,
+        // leaf record -> workspace.  Nothing large is live across the tree bookkeeping below (which reads the
+        // records), so the register file is not spilled around it.  slot_of(k): record slot of leaf k.
+        auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
+        const int slot_i = slot_of(li);
+        double pU, pK;
+        {
+            double th[NS], pm[NS], w[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { th[s] = 0.0; pm[s] = 0.0; w[s] = 0.0; }
+            {
+                const int cz = (li == 0) ? 0 : __builtin_ctz(li);
+                const int sslot = (li == 0) ? 0 : ((cz >= 2) ? cz : slot_of(li - 1));   // leaf li - 2^(cz-1), or leaf li - 1
+                const int vt = (li == 0) ? V_PREV : V_LEAF0 + 3 * sslot;
+                const int vp = (li == 0) ? V_MNTM : V_LEAF0 + 3 * sslot + 1;
+                const int vw = (li == 0) ? V_WPREV : V_LEAF0 + 3 * sslot + 2;
+                if (run) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { th[s] = *wsp(vt, s); pm[s] = *wsp(vp, s); w[s] = *wsp(vw, s); }
+                }
+            }
+            MI_PROF(1)
+            n_ticks++; n_active += __popcll(__ballot(run)) / 4;
+            // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
+                th[s] = th[s] + e_signed * pm[s];
+            }
+            matvec_mfma<NT>(afrag, th, w);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
+            MI_PROF(2)
+            pU = 0.5 * dot4<NS>(th, w);                  // nuts.ipp:134-138
+            if (!is_finite(pU)) pU = INF;
+            pK = dot4<NS>(pm, pm) / 2.0;                 // :140
+            if (run && live) {                           // leaf record (every leaf: odd ones live in slot 1 for one tick)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    *wsp(V_LEAF0 + 3 * slot_i, s) = th[s];
+                    *wsp(V_LEAF0 + 3 * slot_i + 1, s) = pm[s];
+                    *wsp(V_LEAF0 + 3 * slot_i + 2, s) = w[s];
+                }
+            }
+            // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a
+            // successful doubling leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw,
+            // so it can be written in place as soon as that leaf exists
+            const bool st_edge = run && live && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
+            if (st_edge) {
+                const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { *wsp(et, s) = th[s]; *wsp(ep, s) = pm[s]; }
             }
         }
-        MI_PROF(1)
-        n_ticks++; n_active += __popcll(__ballot(run)) / 4;
-        leapfrog(e_signed);                              // nuts.ipp:132 (idle chains: harmless garbage)
-        MI_PROF(2)
-        const double pU = potential();
-        const double pK = kinetic();
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
         const bool cs = log_u < 1000.0 - pU - pK;        // :147
         const double dd = -(pU + pK) + H0;
         double ca = det_exp((dd < 0.0) ? dd : 0.0);      // :157
         double cna = 1.0;
         double cU = pU;
-        int cref = -1;
+        int cref_t = V_LEAF0 + 3 * slot_i;               // carried proposal: this leaf's record (theta, P*theta)
+        int cref_w = V_LEAF0 + 3 * slot_i + 2;
         if (run) n_leap++;
-        {
-            const bool st_leaf = run && ((li & 1u) == 0u);
-            if (__ballot(st_leaf) != 0ull) {
-                const int slot = (li == 0) ? 0 : (__builtin_ctz(li) + 1);
-                store_vec(V_LEAF0 + 3 * slot, th, st_leaf);
-                store_vec(V_LEAF0 + 3 * slot + 1, pm, st_leaf);
-                store_vec(V_LEAF0 + 3 * slot + 2, w, st_leaf);
-            }
-            // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a
-            // successful doubling leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw,
-            // so it can be written in place as soon as that leaf exists
-            const bool st_edge = run && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
-            if (__ballot(st_edge) != 0ull) {
-                store_vec((vdir > 0) ? V_TPOS_T : V_TNEG_T, th, st_edge);
-                store_vec((vdir > 0) ? V_TPOS_P : V_TNEG_P, pm, st_edge);
-            }
-        }
         MI_PROF(3)
         // ---- unwind (nuts.ipp:212-229), per-chain leaf index
         bool failed = run && !cs;
@@ -364,7 +384,12 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
                 uslot++;
                 const double p_n = lvl(l, 0), p_a = lvl(l, 1), p_na = lvl(l, 2), p_U = lvl(l, 3);
                 const double prob = cn / (p_n + cn);                     // :212
-                if (!(z < prob)) { cref = V_PP0 + (int)l; cU = p_U; }    // :215-217
+                if (!(z < prob)) {                                       // keep new_draw_p (:215-217)
+                    const int ps = slot_of(li - 1);                      // level 1: the previous (even) leaf's record
+                    cref_t = (l == 1) ? V_LEAF0 + 3 * ps : V_PP0 + (int)l;
+                    cref_w = (l == 1) ? V_LEAF0 + 3 * ps + 2 : V_PPW0 + (int)l;
+                    cU = p_U;
+                }
                 cn = p_n + cn;                                           // :220-222
                 ca = p_a + ca;
                 cna = p_na + cna;
@@ -373,8 +398,9 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
             if (__ballot(need_ut) != 0ull) {
                 const uint32_t b = li - (1u << l) + 1;                   // first leaf of the node (valid where need_ut)
                 const int slot1 = (!need_ut || b == 0) ? 0 : (__builtin_ctz(b) + 1);
-                const bool ok = uturn_ok(need_ut, V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1, l == 1,
-                                         V_LEAF0 + 3 * (int)l, V_LEAF0 + 3 * (int)l + 1, vdir);   // :226-227
+                const int slot2 = (l == 1) ? slot_i : (int)l;            // first leaf of the second half
+                const bool ok = uturn_ok(need_ut, V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1,
+                                         V_LEAF0 + 3 * slot2, V_LEAF0 + 3 * slot2 + 1, vdir);     // :226-227
                 if (need_ut && !ok) failed = true;                       // :229
             }
         }
@@ -399,26 +425,23 @@ __global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsPara
             lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
         }
         {
-            const bool do_store = keep && (!complete || take);
+            // a pending first half at level 1 IS the leaf record just written (referenced, not copied); deeper
+            // levels and accepted proposals are copied record -> slot
+            const bool do_store = keep && (complete ? take : (pend_level > 1u));
             if (__ballot(do_store) != 0ull) {
                 const int pl = do_store ? (int)pend_level : 1;
                 const int dst_t = take ? V_PREV : V_PP0 + pl;
                 const int dst_w = take ? V_WPREV : V_PPW0 + pl;
-                const bool from_ws = do_store && cref >= 0;
+                if (do_store && live) {
 #pragma unroll
-                for (int c0 = 0; c0 < NS; c0 += CH) {
-                    double t1[CH], t2[CH];
+                    for (int c0 = 0; c0 < NS; c0 += CH) {
+                        double t1[CH], t2[CH];
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) { t1[k] = th[c0 + k]; t2[k] = w[c0 + k]; }
-                    if (from_ws) {
-#pragma unroll
-                        for (int k = 0; k < CH; ++k) { t1[k] = *wsp(cref, c0 + k); t2[k] = *wsp(cref + (V_PPW0 - V_PP0), c0 + k); }
-                    }
-                    if (do_store && live) {
+                        for (int k = 0; k < CH; ++k) { t1[k] = *wsp(cref_t, c0 + k); t2[k] = *wsp(cref_w, c0 + k); }
 #pragma unroll
                         for (int k = 0; k < CH; ++k) { *wsp(dst_t, c0 + k) = t1[k]; *wsp(dst_w, c0 + k) = t2[k]; }
+                        if (CH < NS) __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
