@@ -16,6 +16,17 @@
 
 namespace mi {
 
+// Polynomial coefficients as scalar operands: on the device every coefficient is pinned to an SGPR pair at its point of
+// use.  Left alone, the compiler hoists the 64-bit literals of the inlined exp / log / sincos polynomials into dozens of
+// long-lived VGPR pairs (and spills some of them inside the hot loops); the value is unchanged.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_KC_DISABLE)
+__device__ __forceinline__ double mi_kc(double c) { asm volatile("" : "+s"(c)); return c; }
+#define MI_KC(c) ::mi::mi_kc(c)
+#else
+#define MI_KC(c) (c)
+#endif
+
+
 MI_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 MI_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
 MI_HD double pow2i(int k) { return u2d((uint64_t)(k + 1023) << 52); }
@@ -38,21 +49,21 @@ MI_HD double det_exp(double x)
     const int k = (int)kf;
     double r = dfma(-kf, LN2_HI, x);
     r = dfma(-kf, LN2_LO, r);
-    double p = 1.0 / 87178291200.0;
-    p = dfma(p, r, 1.0 / 6227020800.0);
-    p = dfma(p, r, 1.0 / 479001600.0);
-    p = dfma(p, r, 1.0 / 39916800.0);
-    p = dfma(p, r, 1.0 / 3628800.0);
-    p = dfma(p, r, 1.0 / 362880.0);
-    p = dfma(p, r, 1.0 / 40320.0);
-    p = dfma(p, r, 1.0 / 5040.0);
-    p = dfma(p, r, 1.0 / 720.0);
-    p = dfma(p, r, 1.0 / 120.0);
-    p = dfma(p, r, 1.0 / 24.0);
-    p = dfma(p, r, 1.0 / 6.0);
-    p = dfma(p, r, 0.5);
-    p = dfma(p, r, 1.0);
-    p = dfma(p, r, 1.0);
+    double p = MI_KC(1.0 / 87178291200.0);
+    p = dfma(p, r, MI_KC(1.0 / 6227020800.0));
+    p = dfma(p, r, MI_KC(1.0 / 479001600.0));
+    p = dfma(p, r, MI_KC(1.0 / 39916800.0));
+    p = dfma(p, r, MI_KC(1.0 / 3628800.0));
+    p = dfma(p, r, MI_KC(1.0 / 362880.0));
+    p = dfma(p, r, MI_KC(1.0 / 40320.0));
+    p = dfma(p, r, MI_KC(1.0 / 5040.0));
+    p = dfma(p, r, MI_KC(1.0 / 720.0));
+    p = dfma(p, r, MI_KC(1.0 / 120.0));
+    p = dfma(p, r, MI_KC(1.0 / 24.0));
+    p = dfma(p, r, MI_KC(1.0 / 6.0));
+    p = dfma(p, r, MI_KC(0.5));
+    p = dfma(p, r, MI_KC(1.0));
+    p = dfma(p, r, MI_KC(1.0));
     const int k1 = k / 2, k2 = k - k1;
     return (p * pow2i(k1)) * pow2i(k2);
 }
@@ -74,18 +85,18 @@ MI_HD double det_log(double x)
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s;
-    double p = 1.0 / 23.0;
-    p = dfma(p, z, 1.0 / 21.0);
-    p = dfma(p, z, 1.0 / 19.0);
-    p = dfma(p, z, 1.0 / 17.0);
-    p = dfma(p, z, 1.0 / 15.0);
-    p = dfma(p, z, 1.0 / 13.0);
-    p = dfma(p, z, 1.0 / 11.0);
-    p = dfma(p, z, 1.0 / 9.0);
-    p = dfma(p, z, 1.0 / 7.0);
-    p = dfma(p, z, 1.0 / 5.0);
-    p = dfma(p, z, 1.0 / 3.0);
-    p = dfma(p, z, 1.0);
+    double p = MI_KC(1.0 / 23.0);
+    p = dfma(p, z, MI_KC(1.0 / 21.0));
+    p = dfma(p, z, MI_KC(1.0 / 19.0));
+    p = dfma(p, z, MI_KC(1.0 / 17.0));
+    p = dfma(p, z, MI_KC(1.0 / 15.0));
+    p = dfma(p, z, MI_KC(1.0 / 13.0));
+    p = dfma(p, z, MI_KC(1.0 / 11.0));
+    p = dfma(p, z, MI_KC(1.0 / 9.0));
+    p = dfma(p, z, MI_KC(1.0 / 7.0));
+    p = dfma(p, z, MI_KC(1.0 / 5.0));
+    p = dfma(p, z, MI_KC(1.0 / 3.0));
+    p = dfma(p, z, MI_KC(1.0));
     const double lm = (2.0 * s) * p;
     const double ef = (double)e;
     return dfma(ef, LN2_HI, dfma(ef, LN2_LO, lm));
@@ -96,27 +107,27 @@ MI_HD double det_pow(double x, double y) { return det_exp(y * det_log(x)); }
 MI_HD void sincos_kernel(double a, double& s, double& c)
 {
     const double z = a * a;
-    double ps = -1.0 / 121645100408832000.0;
-    ps = dfma(ps, z, 1.0 / 355687428096000.0);
-    ps = dfma(ps, z, -1.0 / 1307674368000.0);
-    ps = dfma(ps, z, 1.0 / 6227020800.0);
-    ps = dfma(ps, z, -1.0 / 39916800.0);
-    ps = dfma(ps, z, 1.0 / 362880.0);
-    ps = dfma(ps, z, -1.0 / 5040.0);
-    ps = dfma(ps, z, 1.0 / 120.0);
-    ps = dfma(ps, z, -1.0 / 6.0);
-    ps = dfma(ps, z, 1.0);
+    double ps = MI_KC(-1.0 / 121645100408832000.0);
+    ps = dfma(ps, z, MI_KC(1.0 / 355687428096000.0));
+    ps = dfma(ps, z, MI_KC(-1.0 / 1307674368000.0));
+    ps = dfma(ps, z, MI_KC(1.0 / 6227020800.0));
+    ps = dfma(ps, z, MI_KC(-1.0 / 39916800.0));
+    ps = dfma(ps, z, MI_KC(1.0 / 362880.0));
+    ps = dfma(ps, z, MI_KC(-1.0 / 5040.0));
+    ps = dfma(ps, z, MI_KC(1.0 / 120.0));
+    ps = dfma(ps, z, MI_KC(-1.0 / 6.0));
+    ps = dfma(ps, z, MI_KC(1.0));
     s = a * ps;
-    double pc = 1.0 / 6402373705728000.0;
-    pc = dfma(pc, z, -1.0 / 20922789888000.0);
-    pc = dfma(pc, z, 1.0 / 87178291200.0);
-    pc = dfma(pc, z, -1.0 / 479001600.0);
-    pc = dfma(pc, z, 1.0 / 3628800.0);
-    pc = dfma(pc, z, -1.0 / 40320.0);
-    pc = dfma(pc, z, 1.0 / 720.0);
-    pc = dfma(pc, z, -1.0 / 24.0);
-    pc = dfma(pc, z, 0.5);
-    c = dfma(-pc, z, 1.0);
+    double pc = MI_KC(1.0 / 6402373705728000.0);
+    pc = dfma(pc, z, MI_KC(-1.0 / 20922789888000.0));
+    pc = dfma(pc, z, MI_KC(1.0 / 87178291200.0));
+    pc = dfma(pc, z, MI_KC(-1.0 / 479001600.0));
+    pc = dfma(pc, z, MI_KC(1.0 / 3628800.0));
+    pc = dfma(pc, z, MI_KC(-1.0 / 40320.0));
+    pc = dfma(pc, z, MI_KC(1.0 / 720.0));
+    pc = dfma(pc, z, MI_KC(-1.0 / 24.0));
+    pc = dfma(pc, z, MI_KC(0.5));
+    c = dfma(-pc, z, MI_KC(1.0));
 }
 
 // sin, cos of 2 pi u for u in [0,1): octant reduction, odd octants reflected.

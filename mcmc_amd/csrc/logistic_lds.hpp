@@ -1,0 +1,397 @@
+// logistic_lds.hpp -- many-chain MALA and HMC for the Bayesian logistic-regression target, X staged through LDS
+//   log K(beta) = sum_r [ y_r eta_r - log(1 + e^eta_r) ] - 1/2 |beta|^2,   eta = X beta,
+//   grad        = X^T (y - sigmoid(eta)) - beta
+// (BASELINE config 3: d = 512, N = 1024 rows, 262 144 chains) on the fp64 matrix cores.
+//
+// Replaces the draw loops of mcmc::internal::mala_impl (/root/reference/src/mala.cpp:149-186, with mala_mean_fn :97-125,
+// mala_prop_adjustment /root/reference/include/mcmc/mala.ipp:30-70, stats_mcmc::dmvnorm
+// /root/reference/include/stats/dmvnorm.hpp:28-54) and mcmc::internal::hmc_impl (/root/reference/src/hmc.cpp:155-205),
+// identity preconditioner, no bounds.  The fused value+gradient evaluation is the reference's target_log_kernel callback.
+//
+// Why LDS: with X fragments streamed from L2 into registers (mala_logistic.hpp) every 8-byte operand feeds one MFMA of one
+// 16-chain tile: 4 flop per L2 byte, and the kernel sat on the L2/MALL stream (6 TB/s at 25 TFLOP/s).  Here a workgroup of
+// 8 waves = 2 chain tiles x 4 dimension quarters shares ONE copy of each 16-row block of X in LDS: the same bytes serve
+// the eta = X beta product (A = X rows, 16 rows x 4 dims per fragment) and the X^T r product (A = X columns, 4 rows x 16
+// dims per fragment) of both tiles -- 16 flop per L2 byte -- and arrive by direct-to-LDS loads (global_load_lds_dwordx4,
+// no register staging) one block ahead.  Row pair p, parity e, dim j of a block lives at p*RSP + e*(DP+16) + j doubles,
+// RSP = 2*DP + 34: the bank slot is (j + 16 e + 2 p) mod 32, conflict-free for both fragment shapes.
+//
+// Mapping and reduction orders are those of mala_logistic.hpp (the oracle states the same): wave (g, q) owns chain tile g
+// and dims [q*DQ, (q+1)*DQ) in the MFMA B/D register layout; eta_r = ((e0+e1)+e2)+e3 with e_q the fma chain over wave q's
+// dims; X^T r rows ascending as one fma chain; the log-likelihood row sum 4-strided + butterfly; dot products over
+// dimensions ((S0+S1)+S2)+S3 with S_q the 4-strided dot of block q.
+#pragma once
+
+#include "hmc_dense.hpp"
+
+namespace mi {
+
+struct LogitParams {
+    const double* Xp;       // [NB][XBUF_PAD]  blocks of 16 rows (and their labels) in the LDS image layout (see LogitGeo)
+    uint32_t d, n_rows, NB;
+    uint64_t C, chain0;
+    double* theta;          // [d][C] in/out
+    double* state;          // workspace: accepted (beta, grad) of every chain, wave-local layout (see kernel)
+    double* draws;
+    uint64_t* n_accept;
+    uint64_t seed;
+    uint32_t n_burnin, n_keep, n_leap;
+    double eps, s2, rs, cons_term, log_det;
+};
+
+template <int NTQ>
+struct LogitGeo {
+    static constexpr int NSQ = 4 * NTQ;          // 4-dim slices per wave
+    static constexpr int DQ = 16 * NTQ;          // dims per wave
+    static constexpr int DP = 64 * NTQ;          // padded dims
+    static constexpr int RSP = 2 * DP + 34;      // doubles per row pair
+    static constexpr int XBUF = 8 * RSP;         // doubles per 16-row block
+    static constexpr int CHUNKS = (XBUF * 8 + 1023) / 1024;   // 1 KiB wave-loads per block
+    static constexpr int XBUF_PAD = CHUNKS * 128;             // >= XBUF + 16: the 16 labels of the block sit at [XBUF, XBUF+16)
+    static_assert(CHUNKS * 128 >= XBUF + 16, "no room for the labels");
+    static constexpr int EXCH = 2 * (4 * 4 * 64 + 4 * 2 * 64);          // doubles: [g] partial eta tiles + [g] row terms
+    static constexpr size_t LDS_BYTES = (size_t)(2 * XBUF_PAD + EXCH) * sizeof(double);
+    __host__ __device__ static constexpr int xaddr(int row, int dim) { return (row >> 1) * RSP + (row & 1) * (DP + 16) + dim; }
+};
+
+// pack X (row-major n_rows x d) into per-block LDS images; zero padding outside
+template <int NTQ>
+__global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double* __restrict__ y, uint32_t d, uint32_t n_rows,
+                                      double* Xp)
+{
+    using G = LogitGeo<NTQ>;
+    const uint32_t b = blockIdx.x;
+    double* img = Xp + (size_t)b * G::XBUF_PAD;
+    for (int i = threadIdx.x; i < G::XBUF_PAD; i += blockDim.x) img[i] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * G::DP; i += blockDim.x) {
+        const int r = i / G::DP, j = i % G::DP;
+        const uint32_t row = 16 * b + r;
+        if (row < n_rows && (uint32_t)j < d) img[G::xaddr(r, j)] = X[(size_t)row * d + j];
+    }
+    if (threadIdx.x < 16) {
+        const uint32_t row = 16 * b + threadIdx.x;
+        img[G::XBUF + threadIdx.x] = row < n_rows ? y[row] : 0.0;        // labels in the image's tail padding
+    }
+}
+
+enum { LOGIT_MALA = 0, LOGIT_HMC = 1 };
+
+template <int NTQ, int ALGO>
+__global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
+{
+    using G = LogitGeo<NTQ>;
+    constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
+    extern __shared__ double smem[];
+    double* const Xs = smem;                                   // [2][XBUF_PAD]
+    double* const part_all = smem + 2 * G::XBUF_PAD;           // [g][wave q][reg][lane]
+    double* const rt_all = part_all + 2 * 4 * 4 * 64;          // [g][q][0/1][lane]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = w >> 2, q = w & 3;
+    const int j4 = lane >> 4;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps;
+    const uint32_t NB = prm.NB;
+    const uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
+    const bool live = cl < C;
+    const uint64_t chain = prm.chain0 + cl;
+    double* const part = part_all + g * (4 * 4 * 64);
+    double* const rt = rt_all + g * (4 * 2 * 64);
+    double* const ws_wave = prm.state + ((size_t)blockIdx.x * 8 + w) * ((size_t)2 * NSQ * 64) + lane;
+    auto st = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NSQ + s) * 64; };
+    auto dim_of = [&](int s) -> uint32_t { return (uint32_t)(q * DQ + 4 * s + j4); };
+
+    // per-lane LDS offsets of this wave's fragments inside a block image
+    const int eta_off = G::xaddr(lane & 15, q * DQ + j4);                       // + 4 s
+    const int grad_off = (j4 >> 1) * RSP + (j4 & 1) * (DP + 16) + q * DQ + (lane & 15);   // + 2 sp RSP + 16 t
+
+    // Direct-to-LDS block copy: wave w moves the 1 KiB chunks w, w+8, ... (lane l -> bytes [16 l, 16 l + 16) of the chunk).
+    // Issued from inline asm so that the compiler does not serialise them against its own LDS traffic (it waits vmcnt(0)
+    // before every ds_write otherwise); wait_loads() + a barrier is the explicit completion point.
+    const uint32_t xs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)Xs;
+    auto issue_block = [&](uint32_t b, int buf) __attribute__((always_inline)) {
+        const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + lane * 2;
+        const uint32_t dst = xs_lds + (uint32_t)buf * (uint32_t)(G::XBUF_PAD * sizeof(double));
+#pragma unroll
+        for (int c0 = 0; c0 < G::CHUNKS; c0 += 8) {
+            const int c = c0 + w;
+            if (c < G::CHUNKS) {
+                uint32_t m0_saved;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(m0_saved) : "v"(src + (size_t)c * 128), "s"(dst + (uint32_t)c * 1024u) : "memory");
+            }
+        }
+    };
+    auto wait_loads = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+    // ((S0 + S1) + S2) + S3 of per-wave partial dots (each already butterflied inside the wave)
+    auto exchange = [&](double (&v)[2]) __attribute__((always_inline)) {
+        __syncthreads();
+        part[(0 * 4 + q) * 64 + lane] = v[0];
+        part[(1 * 4 + q) * 64 + lane] = v[1];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            v[k] = ((part[(k * 4 + 0) * 64 + lane] + part[(k * 4 + 1) * 64 + lane]) + part[(k * 4 + 2) * 64 + lane])
+                   + part[(k * 4 + 3) * 64 + lane];
+    };
+
+    // value and gradient at x: lp = log K, gout = gradient on this wave's dims
+    auto evaluate = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+        double4_t gacc[NTQ];
+        double llq = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        __syncthreads();                                 // nobody still reads the exchange area or an X buffer
+        issue_block(0, 0);
+        wait_loads();
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t b = 0; b < NB; ++b) {
+            const double* xb = Xs + (b & 1u) * G::XBUF_PAD;
+            if (b + 1 < NB) issue_block(b + 1, (int)((b + 1) & 1u));
+            double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+            {   // software pipeline: fragments of group k+1 are read from LDS while the 4 MFMAs of group k issue
+                const double* xe = xb + eta_off;
+                double a_cur[4], a_nxt[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_cur[i] = xe[4 * i];
+#pragma unroll
+                for (int k = 0; k < NSQ / 4; ++k) {
+                    if (k + 1 < NSQ / 4) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a_nxt[i] = xe[4 * (4 * (k + 1) + i)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], x[4 * k + i], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
+                }
+            }
+            part[(q * 4 + 0) * 64 + lane] = acc[0]; part[(q * 4 + 1) * 64 + lane] = acc[1];
+            part[(q * 4 + 2) * 64 + lane] = acc[2]; part[(q * 4 + 3) * 64 + lane] = acc[3];
+            __syncthreads();
+            const double* xg = xb + grad_off;
+            double g_cur[4], g_nxt[4];                   // first X^T r fragments: in flight across the row-term phase
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) g_cur[sp] = xg[2 * sp * RSP];
+            {   // row group q: rows 16b + 4q + j4
+                const uint32_t row = 16 * b + 4 * q + j4;
+                const double yv = xb[G::XBUF + 4 * q + j4];          // labels ride in the block image
+                const bool valid = row < prm.n_rows;
+                const double eta = ((part[(0 * 4 + q) * 64 + lane] + part[(1 * 4 + q) * 64 + lane]) + part[(2 * 4 + q) * 64 + lane])
+                                   + part[(3 * 4 + q) * 64 + lane];
+                // softplus / sigmoid share e = exp(-|eta|) (the oracle evaluates it once per function; same bits)
+                const double e = det_exp(eta > 0.0 ? -eta : eta);
+                const double l1p = det_log(1.0 + e);
+                const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
+                const double sg = (eta >= 0.0) ? (1.0 / (1.0 + e)) : (e / (1.0 + e));
+                rt[(q * 2 + 0) * 64 + lane] = valid ? (yv - sg) : 0.0;
+                rt[(q * 2 + 1) * 64 + lane] = valid ? (yv * eta - sp) : 0.0;
+            }
+            __syncthreads();
+            double res[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { res[r] = rt[(r * 2 + 0) * 64 + lane]; llq = llq + rt[(r * 2 + 1) * 64 + lane]; }
+            {
+#pragma unroll
+                for (int t = 0; t < NTQ; ++t) {
+                    if (t + 1 < NTQ) {
+#pragma unroll
+                        for (int sp = 0; sp < 4; ++sp) g_nxt[sp] = xg[2 * sp * RSP + 16 * (t + 1)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp)
+                        gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[sp], res[sp], gacc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) g_cur[sp] = g_nxt[sp];
+                }
+            }
+            wait_loads();                                // block b+1 landed (this wave's chunks) ...
+            __syncthreads();                             // ... everybody's, and buffer b&1 is free for block b+2
+        }
+        llq = llq + __shfl_xor(llq, 32);
+        llq = llq + __shfl_xor(llq, 16);
+        double v[2];
+        {
+            double nrm = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) nrm = dfma(x[s], x[s], nrm);
+            nrm = nrm + __shfl_xor(nrm, 32);
+            nrm = nrm + __shfl_xor(nrm, 16);
+            v[0] = nrm; v[1] = 0.0;
+        }
+        exchange(v);
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            gout[4 * t + 0] = gacc[t][0] - x[4 * t + 0];
+            gout[4 * t + 1] = gacc[t][1] - x[4 * t + 1];
+            gout[4 * t + 2] = gacc[t][2] - x[4 * t + 2];
+            gout[4 * t + 3] = gacc[t][3] - x[4 * t + 3];
+        }
+        lp = llq - 0.5 * v[0];
+    };
+
+    double bp[NSQ], gp[NSQ];            // position / proposal and its gradient (this wave's dims)
+#pragma unroll
+    for (int s = 0; s < NSQ; ++s) {
+        const uint32_t dim = dim_of(s);
+        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + (live ? cl : C - 1)];
+        bp[s] = (dim < d) ? v : 0.0;
+    }
+    double first_lp;
+    evaluate(bp, gp, first_lp);         // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
+#pragma unroll
+    for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+
+    auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
+        if (draw >= prm.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            if (prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C + cl;
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) {
+                    const uint32_t dim = dim_of(s);
+                    const double v = accept ? bp[s] : *st(0, s);
+                    if (dim < d) out[(size_t)dim * C] = v;
+                }
+            }
+        }
+    };
+
+    if constexpr (ALGO == LOGIT_MALA) {
+        const double s2 = prm.s2, rs = prm.rs;
+        double prev_LP = first_lp, prop_LP;
+#pragma unroll 1
+        for (uint32_t draw = 0; draw < n_total; ++draw) {
+            // proposal = mala_mean_fn(prev) + eps * z   (mala.cpp:150,159)
+#pragma unroll
+            for (int m = 0; m < NSQ / 2; ++m) {
+                double z0, z1;
+                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
+                rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1);
+                const double za = (dim_of(2 * m) < d) ? z0 : 0.0;
+                const double zb = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                bp[2 * m] = (*st(0, 2 * m) + (s2 * *st(1, 2 * m)) / 2.0) + eps * za;           // :123, :159
+                bp[2 * m + 1] = (*st(0, 2 * m + 1) + (s2 * *st(1, 2 * m + 1)) / 2.0) + eps * zb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            evaluate(bp, gp, prop_LP);                   // :162
+            // mala_prop_adjustment (mala.ipp:59-64)
+            double qv[2];
+            {
+                double qa = 0.0, qb = 0.0;
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) {
+                    const double be = *st(0, s), gr = *st(1, s);
+                    const double mean_prop = bp[s] + (s2 * gp[s]) / 2.0;
+                    const double xa = be - mean_prop;    // dmvnorm.hpp:37
+                    qa = dfma(xa, rs * xa, qa);
+                    const double mean_prev = be + (s2 * gr) / 2.0;
+                    const double xb = bp[s] - mean_prev;
+                    qb = dfma(xb, rs * xb, qb);
+                }
+                qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
+                qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
+                qv[0] = qa; qv[1] = qb;
+            }
+            exchange(qv);
+            double pl = prop_LP;
+            if (!is_finite(pl)) pl = -INF;               // mala.cpp:164-166
+            const double da = prm.cons_term - 0.5 * (prm.log_det + qv[0]);       // dmvnorm.hpp:41
+            const double db = prm.cons_term - 0.5 * (prm.log_det + qv[1]);
+            const double x = pl - prev_LP + (da - db);
+            const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
+            const double z = rng_uniform(prm.seed, chain, draw, 0u);             // :171
+            const bool accept = z < det_exp(comp_val);                           // :173
+            if (accept) {
+                prev_LP = pl;
+                if (live) {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
+                }
+            }
+            keep_draw(draw, accept);
+        }
+    } else {
+        // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step
+        // k+1 are at the same position -- and the value of the last one is prop_U.
+        const uint32_t n_leap = prm.n_leap;
+        double pm[NSQ];
+        double prev_U = -first_lp;                       // hmc.cpp:140
+        auto kinetic = [&]() __attribute__((always_inline)) -> double {   // p.p / 2, block order (:160,184)
+            double v[2];
+            double a = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) a = dfma(pm[s], pm[s], a);
+            a = a + __shfl_xor(a, 32);
+            a = a + __shfl_xor(a, 16);
+            v[0] = a; v[1] = 0.0;
+            exchange(v);
+            return v[0] / 2.0;
+        };
+#pragma unroll 1
+        for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+            for (int m = 0; m < NSQ / 2; ++m) {          // momentum ~ N(0, I), :156-158
+                double z0, z1;
+                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
+                rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1);
+                pm[2 * m] = (dim_of(2 * m) < d) ? z0 : 0.0;
+                pm[2 * m + 1] = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) { bp[s] = *st(0, s); gp[s] = *st(1, s); }   // new_draw = prev_draw (:162)
+            const double prev_K = kinetic();
+            double lp = -prev_U;
+#pragma unroll 1
+            for (uint32_t k = 0; k < n_leap; ++k) {      // :164-176
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) {
+                    pm[s] = pm[s] + (eps * gp[s]) / 2.0; // first half-step (:126)
+                    bp[s] = bp[s] + eps * pm[s];         // (:171)
+                }
+                evaluate(bp, gp, lp);
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) pm[s] = pm[s] + (eps * gp[s]) / 2.0;     // second half-step (:175)
+            }
+            const double prop_K = kinetic();
+            double prop_U = -lp;                         // :178 (n_leap = 0: the value at the unchanged position)
+            if (!is_finite(prop_U)) prop_U = INF;        // :180-182
+            const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+            const double comp_val = (x < 0.01) ? x : 0.01;                       // :188
+            const double z = rng_uniform(prm.seed, chain, draw, 0u);             // :189
+            const bool accept = z < det_exp(comp_val);                           // :191
+            if (accept) {
+                prev_U = prop_U;
+                if (live) {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
+                }
+            }
+            keep_draw(draw, accept);
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) {
+            const uint32_t dim = dim_of(s);
+            const double v = *st(0, s);
+            if (dim < d) prm.theta[(size_t)dim * C + cl] = v;
+        }
+        if (q == 0 && j4 == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
+    }
+}
+
+}  // namespace mi

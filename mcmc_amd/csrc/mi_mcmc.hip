@@ -26,6 +26,7 @@
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
 #include "mala_logistic.hpp"
+#include "logistic_lds.hpp"
 
 namespace {
 
@@ -186,6 +187,71 @@ int launch_mala_logistic_ct(mi::MalaLogitParams& prm, const double* X_dev, const
     return MI_OK;
 }
 
+// LDS-staged logistic kernels (logistic_lds.hpp): 32 chains per workgroup of 8 waves
+template <int NTQ, int ALGO>
+int launch_logit_lds(mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+{
+    using G = mi::LogitGeo<NTQ>;
+    const size_t NB = prm.NB;
+    const size_t n_wg = (prm.C + 31) / 32;
+    const size_t n_xp = NB * G::XBUF_PAD;
+    const size_t n_state = n_wg * 8 * 2 * G::NSQ * 64;
+    void* base = nullptr;
+    int rcw = ws_get(st, (n_xp + n_state) * sizeof(double), &base);
+    if (rcw) return rcw;
+    double* xp = static_cast<double*>(base);
+    prm.state = xp + n_xp;
+    hipLaunchKernelGGL(mi::pack_logit_lds_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
+    prm.Xp = xp;
+    auto kern = mi::logit_lds_kernel<NTQ, ALGO>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+template <int ALGO>
+int launch_logit_lds_any(mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+{
+    if (prm.d <= 64) return launch_logit_lds<1, ALGO>(prm, X_dev, y_dev, st);
+    if (prm.d <= 128) return launch_logit_lds<2, ALGO>(prm, X_dev, y_dev, st);
+    if (prm.d <= 256) return launch_logit_lds<4, ALGO>(prm, X_dev, y_dev, st);
+    return launch_logit_lds<8, ALGO>(prm, X_dev, y_dev, st);
+}
+
+inline mi::LogitParams to_lds_params(const mi::MalaLogitParams& q, uint32_t n_leap)
+{
+    mi::LogitParams r{};
+    r.d = q.d; r.n_rows = q.n_rows; r.NB = q.NB; r.C = q.C; r.chain0 = q.chain0;
+    r.theta = q.theta; r.draws = q.draws; r.n_accept = q.n_accept; r.seed = q.seed;
+    r.n_burnin = q.n_burnin; r.n_keep = q.n_keep; r.n_leap = n_leap;
+    r.eps = q.eps; r.s2 = q.s2; r.rs = q.rs; r.cons_term = q.cons_term; r.log_det = q.log_det;
+    return r;
+}
+
+template <int NTQ>
+int launch_hmc_logistic(mi::MalaLogitParams& prm, uint32_t n_leap_steps, const double* X_dev, const double* y_dev, hipStream_t st)
+{
+    constexpr int NSQ = 4 * NTQ, CT = 1;
+    const size_t NB = prm.NB;
+    const size_t n_wg = (prm.C + 16 * CT - 1) / (16 * CT);
+    const size_t n_xe = NB * 4 * NSQ * 64, n_xg = NB * 4 * NTQ * 4 * 64, n_yp = NB * 16;
+    const size_t n_state = n_wg * 4 * 2 * CT * NSQ * 64;
+    void* base = nullptr;
+    int rcw = ws_get(st, (n_xe + n_xg + n_yp + n_state) * sizeof(double), &base);
+    if (rcw) return rcw;
+    double* xe = static_cast<double*>(base);
+    double* xg = xe + n_xe;
+    double* yp = xg + n_xg;
+    prm.state = yp + n_yp;
+    hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
+                       prm.NB, xe, xg, yp);
+    prm.XE = xe; prm.XG = xg; prm.ypad = yp;
+    hipLaunchKernelGGL((mi::hmc_logistic_kernel<NTQ, CT>), dim3((unsigned)n_wg), dim3(256), 0, st, prm, n_leap_steps);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 template <int NTQ>
 int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
 {
@@ -292,6 +358,45 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
+    if (target->kind == MI_TARGET_LOGISTIC) {
+        if (settings->vals_bound || settings->precond_mat)
+            return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound / precond_mat with the logistic target are not implemented");
+        if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+        if (d > 512) return fail(MI_ERR_UNSUPPORTED, "hmc: logistic target with d = %llu > 512 not implemented", (unsigned long long)d);
+        if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+        const uint64_t n = target->n_rows;
+        DevBuf Xo, yo;
+        const double *X_dev = target->X, *y_dev = target->y;
+        if (target->mem == MI_MEM_HOST) {
+            HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
+            HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
+            X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+        }
+        StagedChains sc;
+        rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        mi::MalaLogitParams q{};
+        q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
+        q.C = chains->n_chains; q.chain0 = chains->chain0;
+        q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
+        q.seed = settings->rng_seed_value;
+        q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+        q.eps = settings->step_size;
+        const uint32_t L = (uint32_t)settings->n_leap_steps;
+        if (!getenv("MI_LOGIT_STREAM")) {
+            mi::LogitParams r = to_lds_params(q, L);
+            rc = launch_logit_lds_any<mi::LOGIT_HMC>(r, X_dev, y_dev, st);
+        } else if (d <= 64) rc = launch_hmc_logistic<1>(q, L, X_dev, y_dev, st);
+        else if (d <= 128) rc = launch_hmc_logistic<2>(q, L, X_dev, y_dev, st);
+        else if (d <= 256) rc = launch_hmc_logistic<4>(q, L, X_dev, y_dev, st);
+        else rc = launch_hmc_logistic<8>(q, L, X_dev, y_dev, st);
+        if (rc) return rc;
+        rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+        if (rc) return rc;
+        if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+        return MI_OK;
+    }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
     // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
@@ -465,7 +570,10 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.eps = settings->step_size; q.s2 = s2_; q.rs = 1.0 / s2_;
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
         q.log_det = log_det_;
-        if (d <= 64) rc = launch_mala_logistic<1>(q, X_dev, y_dev, st);
+        if (!getenv("MI_LOGIT_STREAM")) {
+            mi::LogitParams r = to_lds_params(q, 0);
+            rc = launch_logit_lds_any<mi::LOGIT_MALA>(r, X_dev, y_dev, st);
+        } else if (d <= 64) rc = launch_mala_logistic<1>(q, X_dev, y_dev, st);
         else if (d <= 128) rc = launch_mala_logistic<2>(q, X_dev, y_dev, st);
         else if (d <= 256) rc = launch_mala_logistic<4>(q, X_dev, y_dev, st);
         else rc = launch_mala_logistic<8>(q, X_dev, y_dev, st);
@@ -840,9 +948,14 @@ int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cyc
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     const int grid = 256 * waves_per_simd;      // 256-thread blocks: 1 wave per SIMD each
+    const int nacc_req = (use_lds >> 8) & 0xff;  // independent accumulator chains per wave (1, 2, 4; default 8)
+    const int nacc = (nacc_req == 1 || nacc_req == 2 || nacc_req == 4) ? nacc_req : 8;
     for (int rep = 0; rep < 2; ++rep) {
         HIP_TRY(hipEventRecord(e0, 0));
-        if (use_lds) hipLaunchKernelGGL((mfma_cycles_kernel<8, true>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        if (nacc == 1) hipLaunchKernelGGL((mfma_cycles_kernel<1, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        else if (nacc == 2) hipLaunchKernelGGL((mfma_cycles_kernel<2, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        else if (nacc == 4) hipLaunchKernelGGL((mfma_cycles_kernel<4, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
+        else if (use_lds & 1) hipLaunchKernelGGL((mfma_cycles_kernel<8, true>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
         else hipLaunchKernelGGL((mfma_cycles_kernel<8, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
         HIP_TRY(hipEventRecord(e1, 0));
         HIP_TRY(hipEventSynchronize(e1));
@@ -851,8 +964,8 @@ int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cyc
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long c = 0;
     HIP_TRY(hipMemcpy(&c, cyc.p, 8, hipMemcpyDeviceToHost));
-    *cycles_per_mfma = (double)c / ((double)iters * 8.0);
-    *tflops_out = (double)grid * 4 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
+    *cycles_per_mfma = (double)c / ((double)iters * nacc);
+    *tflops_out = (double)grid * 4 * iters * (double)nacc * 2048.0 / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return MI_OK;
 }

@@ -285,3 +285,29 @@ def test_dense_precond_is_refused_not_approximated():
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
         mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
     assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- HMC on the logistic-regression target
+HMC_LOGIT_CASES = [
+    # d, N, C, eps, L, burn, keep
+    (5, 40, 16, 0.05, 8, 5, 20),        # SURVEY 8(c) golden shape "logistic d=5"
+    (64, 100, 33, 0.02, 4, 2, 6),
+    (100, 37, 20, 0.03, 5, 0, 8),       # ragged rows and dims
+    (512, 1024, 32, 0.01, 3, 1, 3),     # config 3 dimensions
+    (300, 64, 17, 0.30, 6, 0, 10),      # big step: rejections and non-finite energies
+    (16, 50, 16, 0.05, 0, 0, 4),        # n_leap_steps = 0
+]
+
+
+@pytest.mark.parametrize("d,N,C,eps,L,burn,keep", HMC_LOGIT_CASES)
+def test_hmc_logistic_bit_exact_vs_oracle(d, N, C, eps, L, burn, keep):
+    X, y = synth.logistic_problem(d, N, seed=4)
+    init = synth.initial_states(C, d, seed=41) * 0.1
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps, n_leap_steps=L)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
+    dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=dq)
+    s = orc.make_settings(seed=77, n_burnin=burn, n_keep=keep, step=eps, n_leap=L, W=4, hoist=1, blocks=4, block_size=dq)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=5)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
