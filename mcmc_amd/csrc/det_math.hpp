@@ -14,16 +14,47 @@
 
 #define MI_HD __host__ __device__ __forceinline__
 
+// Kernels whose MFMA operands come from LDS: keep every fragment read a ds_read_b64 (2 LDS cycles, 64 banks, 32-lane groups).
+// The DS load/store merger would pair them into ds_read2_b64 / ds_read2st64_b64, which the LDS services as two 4 x 16-lane
+// accesses over 32 banks (8 cycles, half the bandwidth, and conflicts for layouts built for the 64-bank mapping).
+#define MI_NO_DS_MERGE __attribute__((target("no-load-store-opt")))
+
 namespace mi {
 
-// Polynomial coefficients as scalar operands: on the device every coefficient is pinned to an SGPR pair at its point of
-// use.  Left alone, the compiler hoists the 64-bit literals of the inlined exp / log / sincos polynomials into dozens of
-// long-lived VGPR pairs (and spills some of them inside the hot loops); the value is unchanged.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_KC_DISABLE)
+// Polynomial coefficients as scalar operands (device code).  Left alone (MI_KC_MODE 0) the compiler hoists the 64-bit
+// literals of the inlined exp / log / sincos polynomials out of the loops into dozens of long-lived VGPR pairs and spills
+// some of them inside the hot loops.  The value is the same in every mode.
+//   MI_KC_MODE 1 (default): each coefficient passes through an SGPR pair (volatile asm "+s"); the literal moves feeding them
+//     are still hoisted, into SGPRs -- best for the RNG-heavy kernels, whose SGPR file has room.
+//   MI_KC_MODE 2: each coefficient is materialised by two s_mov_b32 literals AT its point of use, ordered after the Horner
+//     value that needs it: nothing lives across loops -- for kernels whose SGPR file is full (logistic_lds.hpp).
+#ifndef MI_KC_MODE
+#define MI_KC_MODE 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && MI_KC_MODE == 1
 __device__ __forceinline__ double mi_kc(double c) { asm volatile("" : "+s"(c)); return c; }
 #define MI_KC(c) ::mi::mi_kc(c)
+#define MI_KCD(c, dep) ::mi::mi_kc(c)
+#elif defined(__HIP_DEVICE_COMPILE__) && MI_KC_MODE == 2
+template <uint64_t BITS>
+__device__ __forceinline__ double mi_kc()
+{
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((uint32_t)BITS), "n"((uint32_t)(BITS >> 32)));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+template <uint64_t BITS>
+__device__ __forceinline__ double mi_kcd(double dep)
+{
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((uint32_t)BITS), "n"((uint32_t)(BITS >> 32)), "v"(dep));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+#define MI_KC(c) (::mi::mi_kc<__builtin_bit_cast(uint64_t, (double)(c))>())
+#define MI_KCD(c, dep) (::mi::mi_kcd<__builtin_bit_cast(uint64_t, (double)(c))>(dep))
 #else
 #define MI_KC(c) (c)
+#define MI_KCD(c, dep) (c)
 #endif
 
 
@@ -49,21 +80,21 @@ MI_HD double det_exp(double x)
     const int k = (int)kf;
     double r = dfma(-kf, LN2_HI, x);
     r = dfma(-kf, LN2_LO, r);
-    double p = MI_KC(1.0 / 87178291200.0);
-    p = dfma(p, r, MI_KC(1.0 / 6227020800.0));
-    p = dfma(p, r, MI_KC(1.0 / 479001600.0));
-    p = dfma(p, r, MI_KC(1.0 / 39916800.0));
-    p = dfma(p, r, MI_KC(1.0 / 3628800.0));
-    p = dfma(p, r, MI_KC(1.0 / 362880.0));
-    p = dfma(p, r, MI_KC(1.0 / 40320.0));
-    p = dfma(p, r, MI_KC(1.0 / 5040.0));
-    p = dfma(p, r, MI_KC(1.0 / 720.0));
-    p = dfma(p, r, MI_KC(1.0 / 120.0));
-    p = dfma(p, r, MI_KC(1.0 / 24.0));
-    p = dfma(p, r, MI_KC(1.0 / 6.0));
-    p = dfma(p, r, MI_KC(0.5));
-    p = dfma(p, r, MI_KC(1.0));
-    p = dfma(p, r, MI_KC(1.0));
+    double p = MI_KCD(1.0 / 87178291200.0, r);
+    p = dfma(p, r, MI_KCD(1.0 / 6227020800.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 479001600.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 39916800.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 3628800.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 362880.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 40320.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 5040.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 720.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 120.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 24.0, p));
+    p = dfma(p, r, MI_KCD(1.0 / 6.0, p));
+    p = dfma(p, r, 0.5);
+    p = dfma(p, r, 1.0);
+    p = dfma(p, r, 1.0);
     const int k1 = k / 2, k2 = k - k1;
     return (p * pow2i(k1)) * pow2i(k2);
 }
@@ -85,18 +116,18 @@ MI_HD double det_log(double x)
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
     const double z = s * s;
-    double p = MI_KC(1.0 / 23.0);
-    p = dfma(p, z, MI_KC(1.0 / 21.0));
-    p = dfma(p, z, MI_KC(1.0 / 19.0));
-    p = dfma(p, z, MI_KC(1.0 / 17.0));
-    p = dfma(p, z, MI_KC(1.0 / 15.0));
-    p = dfma(p, z, MI_KC(1.0 / 13.0));
-    p = dfma(p, z, MI_KC(1.0 / 11.0));
-    p = dfma(p, z, MI_KC(1.0 / 9.0));
-    p = dfma(p, z, MI_KC(1.0 / 7.0));
-    p = dfma(p, z, MI_KC(1.0 / 5.0));
-    p = dfma(p, z, MI_KC(1.0 / 3.0));
-    p = dfma(p, z, MI_KC(1.0));
+    double p = MI_KCD(1.0 / 23.0, z);
+    p = dfma(p, z, MI_KCD(1.0 / 21.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 19.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 17.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 15.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 13.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 11.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 9.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 7.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 5.0, p));
+    p = dfma(p, z, MI_KCD(1.0 / 3.0, p));
+    p = dfma(p, z, 1.0);
     const double lm = (2.0 * s) * p;
     const double ef = (double)e;
     return dfma(ef, LN2_HI, dfma(ef, LN2_LO, lm));
@@ -107,27 +138,27 @@ MI_HD double det_pow(double x, double y) { return det_exp(y * det_log(x)); }
 MI_HD void sincos_kernel(double a, double& s, double& c)
 {
     const double z = a * a;
-    double ps = MI_KC(-1.0 / 121645100408832000.0);
-    ps = dfma(ps, z, MI_KC(1.0 / 355687428096000.0));
-    ps = dfma(ps, z, MI_KC(-1.0 / 1307674368000.0));
-    ps = dfma(ps, z, MI_KC(1.0 / 6227020800.0));
-    ps = dfma(ps, z, MI_KC(-1.0 / 39916800.0));
-    ps = dfma(ps, z, MI_KC(1.0 / 362880.0));
-    ps = dfma(ps, z, MI_KC(-1.0 / 5040.0));
-    ps = dfma(ps, z, MI_KC(1.0 / 120.0));
-    ps = dfma(ps, z, MI_KC(-1.0 / 6.0));
-    ps = dfma(ps, z, MI_KC(1.0));
+    double ps = MI_KCD(-1.0 / 121645100408832000.0, z);
+    ps = dfma(ps, z, MI_KCD(1.0 / 355687428096000.0, ps));
+    ps = dfma(ps, z, MI_KCD(-1.0 / 1307674368000.0, ps));
+    ps = dfma(ps, z, MI_KCD(1.0 / 6227020800.0, ps));
+    ps = dfma(ps, z, MI_KCD(-1.0 / 39916800.0, ps));
+    ps = dfma(ps, z, MI_KCD(1.0 / 362880.0, ps));
+    ps = dfma(ps, z, MI_KCD(-1.0 / 5040.0, ps));
+    ps = dfma(ps, z, MI_KCD(1.0 / 120.0, ps));
+    ps = dfma(ps, z, MI_KCD(-1.0 / 6.0, ps));
+    ps = dfma(ps, z, 1.0);
     s = a * ps;
-    double pc = MI_KC(1.0 / 6402373705728000.0);
-    pc = dfma(pc, z, MI_KC(-1.0 / 20922789888000.0));
-    pc = dfma(pc, z, MI_KC(1.0 / 87178291200.0));
-    pc = dfma(pc, z, MI_KC(-1.0 / 479001600.0));
-    pc = dfma(pc, z, MI_KC(1.0 / 3628800.0));
-    pc = dfma(pc, z, MI_KC(-1.0 / 40320.0));
-    pc = dfma(pc, z, MI_KC(1.0 / 720.0));
-    pc = dfma(pc, z, MI_KC(-1.0 / 24.0));
-    pc = dfma(pc, z, MI_KC(0.5));
-    c = dfma(-pc, z, MI_KC(1.0));
+    double pc = MI_KCD(1.0 / 6402373705728000.0, z);
+    pc = dfma(pc, z, MI_KCD(-1.0 / 20922789888000.0, pc));
+    pc = dfma(pc, z, MI_KCD(1.0 / 87178291200.0, pc));
+    pc = dfma(pc, z, MI_KCD(-1.0 / 479001600.0, pc));
+    pc = dfma(pc, z, MI_KCD(1.0 / 3628800.0, pc));
+    pc = dfma(pc, z, MI_KCD(-1.0 / 40320.0, pc));
+    pc = dfma(pc, z, MI_KCD(1.0 / 720.0, pc));
+    pc = dfma(pc, z, MI_KCD(-1.0 / 24.0, pc));
+    pc = dfma(pc, z, 0.5);
+    c = dfma(-pc, z, 1.0);
 }
 
 // sin, cos of 2 pi u for u in [0,1): octant reduction, odd octants reflected.

@@ -182,7 +182,7 @@ __device__ __forceinline__ double box_log_jacobian_term(double v, int bt, double
 // space; the target is evaluated at x = inv_transform(theta), the kick uses inv_jacobian * grad, the energy
 // adds log_jacobian (summed sequentially over dimensions, as the reference's scalar loop does).
 template <int NT, int WPB, bool BOUNDED = false>
-__global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
+__global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const
     double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)3 * NS * 64) + lane;
     auto th_mem = [&](int s) -> double* { return ws_wave + (size_t)s * 64; };
     auto w_mem = [&](int s) -> double* { return ws_wave + (size_t)(NS + s) * 64; };
-    auto z_mem = [&](int s) -> double* { return ws_wave + (size_t)(2 * NS + s) * 64; };   // fresh normals, staged
+    [[maybe_unused]] auto z_mem = [&](int s) -> double* { return ws_wave + (size_t)(2 * NS + s) * 64; };   // fresh normals, staged
 
     // w = P * (theta or inv_transform(theta)); BOUNDED also refreshes xs and kw
     auto gradient = [&]() __attribute__((always_inline)) {

@@ -1,0 +1,33 @@
+// logistic_launch.hpp -- host-side interface of the logistic-regression kernels (logistic_lds.hpp).
+// The kernels live in their own translation unit (logistic_lds.hip) because they are compiled with MI_KC_MODE 2
+// (det_math.hpp): their SGPR file has no room for hoisted polynomial coefficients, the RNG-bound kernels of mi_mcmc.hip
+// want exactly that.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mi {
+
+struct LogitParams {
+    const double* Xp;       // [NB][XBUF_PAD]  blocks of 16 rows (and their labels) in the LDS image layout (see LogitGeo)
+    uint32_t d, n_rows, NB;
+    uint64_t C, chain0;
+    double* theta;          // [d][C] in/out
+    double* state;          // workspace: accepted (beta, grad) of every chain, wave-local layout (see kernel)
+    double* draws;
+    uint64_t* n_accept;
+    uint64_t seed;
+    uint32_t n_burnin, n_keep, n_leap;
+    double eps, s2, rs, cons_term, log_det;
+};
+
+enum { LOGIT_MALA = 0, LOGIT_HMC = 1 };
+
+// bytes of device workspace a launch needs (block images of X, accepted state of every chain)
+size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C);
+// packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)
+int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st);
+
+}  // namespace mi

@@ -8,36 +8,32 @@
 // /root/reference/include/stats/dmvnorm.hpp:28-54) and mcmc::internal::hmc_impl (/root/reference/src/hmc.cpp:155-205),
 // identity preconditioner, no bounds.  The fused value+gradient evaluation is the reference's target_log_kernel callback.
 //
-// Why LDS: with X fragments streamed from L2 into registers (mala_logistic.hpp) every 8-byte operand feeds one MFMA of one
-// 16-chain tile: 4 flop per L2 byte, and the kernel sat on the L2/MALL stream (6 TB/s at 25 TFLOP/s).  Here a workgroup of
+// Why LDS: with X fragments streamed from L2 into registers (the first version of this kernel) every 8-byte operand fed one
+// MFMA of one 16-chain tile: 4 flop per L2 byte, and the kernel sat on the L2/MALL stream (6 TB/s at 25 TFLOP/s).  Here a workgroup of
 // 8 waves = 2 chain tiles x 4 dimension quarters shares ONE copy of each 16-row block of X in LDS: the same bytes serve
 // the eta = X beta product (A = X rows, 16 rows x 4 dims per fragment) and the X^T r product (A = X columns, 4 rows x 16
 // dims per fragment) of both tiles -- 16 flop per L2 byte -- and arrive by direct-to-LDS loads (global_load_lds_dwordx4,
 // no register staging) one block ahead.  Row pair p, parity e, dim j of a block lives at p*RSP + e*(DP+16) + j doubles,
 // RSP = 2*DP + 34: the bank slot is (j + 16 e + 2 p) mod 32, conflict-free for both fragment shapes.
 //
-// Mapping and reduction orders are those of mala_logistic.hpp (the oracle states the same): wave (g, q) owns chain tile g
-// and dims [q*DQ, (q+1)*DQ) in the MFMA B/D register layout; eta_r = ((e0+e1)+e2)+e3 with e_q the fma chain over wave q's
-// dims; X^T r rows ascending as one fma chain; the log-likelihood row sum 4-strided + butterfly; dot products over
+// Mapping and reduction orders (the oracle states the same, oracle/mcmc_oracle.c ORC_TARGET_LOGISTIC): wave (g, q) owns chain tile g
+// and dims [q*DQ, (q+1)*DQ) in the MFMA B/D register layout; eta_r = ((e0+e1)+e2)+e3 with e_q = h_q0 + h_q1 the two fma
+// chains over the halves of wave q's dims; X^T r rows ascending as one fma chain; the log-likelihood row sum 4-strided + butterfly; dot products over
 // dimensions ((S0+S1)+S2)+S3 with S_q the 4-strided dot of block q.
 #pragma once
 
 #include "hmc_dense.hpp"
+#include "logistic_launch.hpp"
+
+#ifndef MI_LOGIT_ABLATE
+#define MI_LOGIT_ABLATE 0
+#endif
+#ifndef MI_LOGIT_BATCH
+#define MI_LOGIT_BATCH 8
+#endif
 
 namespace mi {
 
-struct LogitParams {
-    const double* Xp;       // [NB][XBUF_PAD]  blocks of 16 rows (and their labels) in the LDS image layout (see LogitGeo)
-    uint32_t d, n_rows, NB;
-    uint64_t C, chain0;
-    double* theta;          // [d][C] in/out
-    double* state;          // workspace: accepted (beta, grad) of every chain, wave-local layout (see kernel)
-    double* draws;
-    uint64_t* n_accept;
-    uint64_t seed;
-    uint32_t n_burnin, n_keep, n_leap;
-    double eps, s2, rs, cons_term, log_det;
-};
 
 template <int NTQ>
 struct LogitGeo {
@@ -75,10 +71,8 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
     }
 }
 
-enum { LOGIT_MALA = 0, LOGIT_HMC = 1 };
-
 template <int NTQ, int ALGO>
-__global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
+__global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
 {
     using G = LogitGeo<NTQ>;
     constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
@@ -95,6 +89,12 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
     const uint64_t C = prm.C;
     const double eps = prm.eps;
     const uint32_t NB = prm.NB;
+    // timing experiments only (tools/logit_bench.hip): 1 no row-term math, 2 no eta MFMAs, 4 no gradient MFMAs,
+    // 8 no block DMA, 16 no barriers in the block loop, 32 no LDS fragment reads, 64 no normal draws, 128 no DMA wait,
+    // 256 DMA always from block 0, 512 all DMA pieces after the first barrier of the block, 4096 all at its top (default: one per MFMA group),
+    // 1024 report shader cycles and 100 MHz wall ticks of workgroup 0 in n_accept[0..1]
+    constexpr uint32_t ablate = MI_LOGIT_ABLATE;
+    const uint64_t t0_clk = (ablate & 1024u) ? clock64() : 0, t0_wall = (ablate & 1024u) ? wall_clock64() : 0;
     const uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
     const bool live = cl < C;
     const uint64_t chain = prm.chain0 + cl;
@@ -102,7 +102,14 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
     double* const rt = rt_all + g * (4 * 2 * 64);
     double* const ws_wave = prm.state + ((size_t)blockIdx.x * 8 + w) * ((size_t)2 * NSQ * 64) + lane;
     auto st = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NSQ + s) * 64; };
-    auto dim_of = [&](int s) -> uint32_t { return (uint32_t)(q * DQ + 4 * s + j4); };
+    // the dimension of slice s in this lane.  Opaque on purpose: the `dim < d` predicates of the fully unrolled per-draw loops
+    // are loop invariants, and the compiler would otherwise keep dozens of 64-bit lane masks alive in SGPRs across the whole
+    // kernel (hundreds of SGPR spills); recomputing a compare where it is used costs nothing.
+    auto dim_of = [&](int s) -> uint32_t {
+        uint32_t j = (uint32_t)j4;
+        asm volatile("" : "+v"(j));
+        return (uint32_t)(q * DQ + 4 * s) + j;
+    };
 
     // per-lane LDS offsets of this wave's fragments inside a block image
     const int eta_off = G::xaddr(lane & 15, q * DQ + j4);                       // + 4 s
@@ -125,6 +132,23 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
             }
         }
     };
+    // one 1 KiB piece of a block: the LDS-DMA path of a CU moves ~25 B/clk and the issuing wave stalls behind its own
+    // queued pieces (measured ~320 cycles per piece when a wave issues its 9 pieces back to back), so inside the block
+    // loop the pieces are issued one at a time, spread over the three phases
+    auto issue_piece = [&](uint32_t b, int buf, int i) __attribute__((always_inline)) {
+        const int c = i * 8 + w;
+        if (c < G::CHUNKS) {
+            const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + lane * 2 + (size_t)c * 128;
+            const uint32_t dst = xs_lds + (uint32_t)buf * (uint32_t)(G::XBUF_PAD * sizeof(double)) + (uint32_t)c * 1024u;
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    // schedule of the NP pieces a wave issues per block: NP_E behind every other eta MFMA group, one at the head of the
+    // row-term phase, the rest behind every other gradient tile
+    constexpr int NP = (G::CHUNKS + 7) / 8, NP_E = (NTQ + 1) / 2;
+    static_assert(NP_E + 1 + (NTQ + 1) / 2 >= NP, "piece schedule does not cover the block");
     auto wait_loads = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     // ((S0 + S1) + S2) + S3 of per-wave partial dots (each already butterflied inside the wave)
@@ -140,46 +164,75 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
     };
 
     // value and gradient at x: lp = log K, gout = gradient on this wave's dims
+    auto blk_sync = [&]() __attribute__((always_inline)) { if constexpr (!(ablate & 16u)) __syncthreads(); };
+    // phase profile (ablate & 2048): shader cycles of wave (blockIdx 0) per phase, summed over all blocks and evaluations
+    uint64_t prof[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&]() __attribute__((always_inline)) -> uint64_t { if constexpr ((ablate & 2048u) != 0) return clock64(); else return 0; };
+    auto lap = [&](uint64_t& tp, int i) __attribute__((always_inline)) {
+        if constexpr ((ablate & 2048u) != 0) { const uint64_t t = clock64(); prof[i] += t - tp; tp = t; }
+    };
+    uint32_t xbuf0 = 0;                 // buffer that holds block 0 when an evaluation starts
     auto evaluate = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
         double4_t gacc[NTQ];
         double llq = 0.0;
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-        __syncthreads();                                 // nobody still reads the exchange area or an X buffer
-        issue_block(0, 0);
-        wait_loads();
-        __syncthreads();
+        uint64_t te = stamp();
+        __syncthreads();                                 // nobody still reads the exchange area
+        lap(te, 8);
+        // Block 0 is already resident in buffer xbuf0: the last iteration of the previous evaluation fetched it (the
+        // block stream wraps around; X does not change), so an evaluation starts without a DMA round trip.
 #pragma unroll 1
         for (uint32_t b = 0; b < NB; ++b) {
-            const double* xb = Xs + (b & 1u) * G::XBUF_PAD;
-            if (b + 1 < NB) issue_block(b + 1, (int)((b + 1) & 1u));
-            double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+            const double* xb = Xs + ((xbuf0 + b) & 1u) * G::XBUF_PAD;
+            uint64_t tp = stamp();
+            const bool prefetch = !(ablate & 8u);
+            const uint32_t nblk = (b + 1 < NB) ? b + 1 : 0u;
+            const int nbuf = (int)((xbuf0 + b + 1) & 1u);
+            if (prefetch && (ablate & 4096u)) issue_block(nblk, nbuf);
+            // eta tile of this wave's dims as TWO fma chains (slices [0, NSQ/2) and [NSQ/2, NSQ)), summed at the end: a
+            // single chain of NSQ dependent MFMAs runs the matrix pipe at half rate (measured 155 cycles per MFMA).
+            double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0}, acc1 = double4_t{0.0, 0.0, 0.0, 0.0};
             {   // software pipeline: fragments of group k+1 are read from LDS while the 4 MFMAs of group k issue
                 const double* xe = xb + eta_off;
+                constexpr int H = NSQ / 2;
                 double a_cur[4], a_nxt[4];
+                auto frag = [&](int k, int i) -> const double* { return xe + 4 * ((i & 1) * H + 2 * k + (i >> 1)); };
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a_cur[i] = xe[4 * i];
+                for (int i = 0; i < 4; ++i) a_cur[i] = (ablate & 32u) ? 1.0 : *frag(0, i);
 #pragma unroll
                 for (int k = 0; k < NSQ / 4; ++k) {
                     if (k + 1 < NSQ / 4) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a_nxt[i] = xe[4 * (4 * (k + 1) + i)];
+                        for (int i = 0; i < 4; ++i) a_nxt[i] = (ablate & 32u) ? 1.0 : *frag(k + 1, i);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[i], x[4 * k + i], acc, 0, 0, 0);
+                    if ((k & 1) == 0 && k / 2 < NP_E && prefetch && !(ablate & (512u | 4096u))) issue_piece(nblk, nbuf, k / 2);
+                    if constexpr (!(ablate & 2u)) {
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[0], x[2 * k], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[1], x[H + 2 * k], acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[2], x[2 * k + 1], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[3], x[H + 2 * k + 1], acc1, 0, 0, 0);
+                    } else {
+                        acc[0] += a_cur[0] + a_cur[1] + a_cur[2] + a_cur[3];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a_cur[i] = a_nxt[i];
                 }
+                acc[0] = acc[0] + acc1[0]; acc[1] = acc[1] + acc1[1]; acc[2] = acc[2] + acc1[2]; acc[3] = acc[3] + acc1[3];
             }
+            lap(tp, 0);
             part[(q * 4 + 0) * 64 + lane] = acc[0]; part[(q * 4 + 1) * 64 + lane] = acc[1];
             part[(q * 4 + 2) * 64 + lane] = acc[2]; part[(q * 4 + 3) * 64 + lane] = acc[3];
-            __syncthreads();
+            blk_sync();
+            lap(tp, 1);
+            if (prefetch && (ablate & 512u)) issue_block(nblk, nbuf);
+            if (prefetch && !(ablate & (512u | 4096u))) issue_piece(nblk, nbuf, NP_E);
             const double* xg = xb + grad_off;
             double g_cur[4], g_nxt[4];                   // first X^T r fragments: in flight across the row-term phase
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) g_cur[sp] = xg[2 * sp * RSP];
+            for (int sp = 0; sp < 4; ++sp) g_cur[sp] = (ablate & 32u) ? 1.0 : xg[2 * sp * RSP];
             {   // row group q: rows 16b + 4q + j4
                 const uint32_t row = 16 * b + 4 * q + j4;
                 const double yv = xb[G::XBUF + 4 * q + j4];          // labels ride in the block image
@@ -187,14 +240,16 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
                 const double eta = ((part[(0 * 4 + q) * 64 + lane] + part[(1 * 4 + q) * 64 + lane]) + part[(2 * 4 + q) * 64 + lane])
                                    + part[(3 * 4 + q) * 64 + lane];
                 // softplus / sigmoid share e = exp(-|eta|) (the oracle evaluates it once per function; same bits)
-                const double e = det_exp(eta > 0.0 ? -eta : eta);
-                const double l1p = det_log(1.0 + e);
+                const double e = (ablate & 1u) ? eta * 0.25 : det_exp(eta > 0.0 ? -eta : eta);
+                const double l1p = (ablate & 1u) ? e * 0.5 : det_log(1.0 + e);
                 const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
                 const double sg = (eta >= 0.0) ? (1.0 / (1.0 + e)) : (e / (1.0 + e));
                 rt[(q * 2 + 0) * 64 + lane] = valid ? (yv - sg) : 0.0;
                 rt[(q * 2 + 1) * 64 + lane] = valid ? (yv * eta - sp) : 0.0;
             }
-            __syncthreads();
+            lap(tp, 2);
+            blk_sync();
+            lap(tp, 3);
             double res[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { res[r] = rt[(r * 2 + 0) * 64 + lane]; llq = llq + rt[(r * 2 + 1) * 64 + lane]; }
@@ -203,20 +258,26 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
                 for (int t = 0; t < NTQ; ++t) {
                     if (t + 1 < NTQ) {
 #pragma unroll
-                        for (int sp = 0; sp < 4; ++sp) g_nxt[sp] = xg[2 * sp * RSP + 16 * (t + 1)];
+                        for (int sp = 0; sp < 4; ++sp) g_nxt[sp] = (ablate & 32u) ? 1.0 : xg[2 * sp * RSP + 16 * (t + 1)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if ((t & 1) == 0 && NP_E + 1 + t / 2 < NP && prefetch && !(ablate & (512u | 4096u))) issue_piece(nblk, nbuf, NP_E + 1 + t / 2);
 #pragma unroll
                     for (int sp = 0; sp < 4; ++sp)
-                        gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[sp], res[sp], gacc[t], 0, 0, 0);
+                    { if constexpr (!(ablate & 4u)) gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[sp], res[sp], gacc[t], 0, 0, 0); else gacc[t][0] += g_cur[sp]; }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int sp = 0; sp < 4; ++sp) g_cur[sp] = g_nxt[sp];
                 }
             }
-            wait_loads();                                // block b+1 landed (this wave's chunks) ...
-            __syncthreads();                             // ... everybody's, and buffer b&1 is free for block b+2
+            lap(tp, 4);
+            if constexpr (!(ablate & 128u)) wait_loads();    // block b+1 landed (this wave's chunks) ...
+            lap(tp, 5);
+            blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2
+            lap(tp, 6);
         }
+        xbuf0 = (xbuf0 + NB) & 1u;
+        te = stamp();
         llq = llq + __shfl_xor(llq, 32);
         llq = llq + __shfl_xor(llq, 16);
         double v[2];
@@ -237,6 +298,7 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
             gout[4 * t + 3] = gacc[t][3] - x[4 * t + 3];
         }
         lp = llq - 0.5 * v[0];
+        lap(te, 9);
     };
 
     double bp[NSQ], gp[NSQ];            // position / proposal and its gradient (this wave's dims)
@@ -246,6 +308,8 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
         const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + (live ? cl : C - 1)];
         bp[s] = (dim < d) ? v : 0.0;
     }
+    issue_block(0, 0);
+    wait_loads();
     double first_lp;
     evaluate(bp, gp, first_lp);         // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
 #pragma unroll
@@ -253,16 +317,30 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
 
+    constexpr int SB = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);   // slices per batch of workspace loads
     auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
         if (draw >= prm.n_burnin) {
             n_acc += accept ? 1u : 0u;
-            if (prm.draws != nullptr && live) {
+            if (prm.draws != nullptr) {
                 double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C + cl;
+                if (__any(!accept)) {                    // some chain of the wave repeats its previous draw: fetch it
 #pragma unroll
-                for (int s = 0; s < NSQ; ++s) {
-                    const uint32_t dim = dim_of(s);
-                    const double v = accept ? bp[s] : *st(0, s);
-                    if (dim < d) out[(size_t)dim * C] = v;
+                    for (int s0 = 0; s0 < NSQ; s0 += SB) {
+                        double old[SB];
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) old[i] = *st(0, s0 + i);
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) {
+                            const uint32_t dim = dim_of(s0 + i);
+                            if (live && dim < d) out[(size_t)dim * C] = accept ? bp[s0 + i] : old[i];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) {
+                        const uint32_t dim = dim_of(s);
+                        if (live && dim < d) out[(size_t)dim * C] = bp[s];
+                    }
                 }
             }
         }
@@ -273,32 +351,67 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
         double prev_LP = first_lp, prop_LP;
 #pragma unroll 1
         for (uint32_t draw = 0; draw < n_total; ++draw) {
-            // proposal = mala_mean_fn(prev) + eps * z   (mala.cpp:150,159)
+            uint64_t td = stamp();
+            // proposal = mala_mean_fn(prev) + eps * z   (mala.cpp:150,159).  The accepted (beta, grad) come from the wave's
+            // workspace in batches of SB slices, one batch ahead of the normals that consume them.
+            {
+                double be_c[SB], gr_c[SB], be_n[SB], gr_n[SB];
 #pragma unroll
-            for (int m = 0; m < NSQ / 2; ++m) {
-                double z0, z1;
-                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
-                rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1);
-                const double za = (dim_of(2 * m) < d) ? z0 : 0.0;
-                const double zb = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
-                bp[2 * m] = (*st(0, 2 * m) + (s2 * *st(1, 2 * m)) / 2.0) + eps * za;           // :123, :159
-                bp[2 * m + 1] = (*st(0, 2 * m + 1) + (s2 * *st(1, 2 * m + 1)) / 2.0) + eps * zb;
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < SB; ++i) { be_c[i] = *st(0, i); gr_c[i] = *st(1, i); }
+#pragma unroll
+                for (int s0 = 0; s0 < NSQ; s0 += SB) {
+                    if (s0 + SB < NSQ) {
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) { be_n[i] = *st(0, s0 + SB + i); gr_n[i] = *st(1, s0 + SB + i); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < SB / 2; ++m) {
+                        const int mm = s0 / 2 + m;
+                        double z0, z1;
+                        const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * mm + j4);
+                        if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
+                        const double za = (dim_of(2 * mm) < d) ? z0 : 0.0;
+                        const double zb = (dim_of(2 * mm + 1) < d) ? z1 : 0.0;
+                        bp[2 * mm] = (be_c[2 * m] + (s2 * gr_c[2 * m]) / 2.0) + eps * za;           // :123, :159
+                        bp[2 * mm + 1] = (be_c[2 * m + 1] + (s2 * gr_c[2 * m + 1]) / 2.0) + eps * zb;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) { be_c[i] = be_n[i]; gr_c[i] = gr_n[i]; }
+                }
             }
+            lap(td, 7);
             evaluate(bp, gp, prop_LP);                   // :162
+            td = stamp();
             // mala_prop_adjustment (mala.ipp:59-64)
             double qv[2];
             {
                 double qa = 0.0, qb = 0.0;
+                double be_c[SB], gr_c[SB], be_n[SB], gr_n[SB];
 #pragma unroll
-                for (int s = 0; s < NSQ; ++s) {
-                    const double be = *st(0, s), gr = *st(1, s);
-                    const double mean_prop = bp[s] + (s2 * gp[s]) / 2.0;
-                    const double xa = be - mean_prop;    // dmvnorm.hpp:37
-                    qa = dfma(xa, rs * xa, qa);
-                    const double mean_prev = be + (s2 * gr) / 2.0;
-                    const double xb = bp[s] - mean_prev;
-                    qb = dfma(xb, rs * xb, qb);
+                for (int i = 0; i < SB; ++i) { be_c[i] = *st(0, i); gr_c[i] = *st(1, i); }
+#pragma unroll
+                for (int s0 = 0; s0 < NSQ; s0 += SB) {
+                    if (s0 + SB < NSQ) {
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) { be_n[i] = *st(0, s0 + SB + i); gr_n[i] = *st(1, s0 + SB + i); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        const int s = s0 + i;
+                        const double be = be_c[i], gr = gr_c[i];
+                        const double mean_prop = bp[s] + (s2 * gp[s]) / 2.0;
+                        const double xa = be - mean_prop;    // dmvnorm.hpp:37
+                        qa = dfma(xa, rs * xa, qa);
+                        const double mean_prev = be + (s2 * gr) / 2.0;
+                        const double xb = bp[s] - mean_prev;
+                        qb = dfma(xb, rs * xb, qb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) { be_c[i] = be_n[i]; gr_c[i] = gr_n[i]; }
                 }
                 qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
                 qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
@@ -321,6 +434,7 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
                 }
             }
             keep_draw(draw, accept);
+            lap(td, 10);
         }
     } else {
         // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step
@@ -345,7 +459,7 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
             for (int m = 0; m < NSQ / 2; ++m) {          // momentum ~ N(0, I), :156-158
                 double z0, z1;
                 const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
-                rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1);
+                if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
                 pm[2 * m] = (dim_of(2 * m) < d) ? z0 : 0.0;
                 pm[2 * m + 1] = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
                 __builtin_amdgcn_sched_barrier(0);
@@ -383,6 +497,13 @@ __global__ __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
         }
     }
 
+    if constexpr ((ablate & 2048u) != 0) {
+        if (blockIdx.x == 0 && lane == 0 && prm.n_accept) { for (int i = 0; i < 11; ++i) prm.n_accept[2 + w * 11 + i] = prof[i]; }
+    }
+    if constexpr ((ablate & 1024u) != 0) {           // shader clock over the 100 MHz wall clock, workgroup 0 (n_accept[0..1])
+        if (blockIdx.x == 0 && threadIdx.x == 0 && prm.n_accept) { prm.n_accept[0] = clock64() - t0_clk; prm.n_accept[1] = wall_clock64() - t0_wall; }
+        return;
+    }
     if (live) {
 #pragma unroll
         for (int s = 0; s < NSQ; ++s) {

@@ -32,7 +32,7 @@ struct MalaParams {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(const MalaParams prm)
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(const MalaParams prm)
 {
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];

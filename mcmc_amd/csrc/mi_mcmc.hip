@@ -25,8 +25,7 @@
 #include "mala_dense.hpp"
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
-#include "mala_logistic.hpp"
-#include "logistic_lds.hpp"
+#include "logistic_launch.hpp"
 
 namespace {
 
@@ -164,103 +163,18 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     return MI_OK;
 }
 
-template <int NTQ, int CT>
-int launch_mala_logistic_ct(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+// LDS-staged logistic kernels (logistic_lds.hip): workspace from the per-stream cache, launch in their own translation unit
+int launch_logit(int algo, const mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
 {
-    constexpr int NSQ = 4 * NTQ;
-    const size_t NB = prm.NB;
-    const size_t n_wg = (prm.C + 16 * CT - 1) / (16 * CT);
-    const size_t n_xe = NB * 4 * NSQ * 64, n_xg = NB * 4 * NTQ * 4 * 64, n_yp = NB * 16;
-    const size_t n_state = n_wg * 4 * 2 * CT * NSQ * 64;
     void* base = nullptr;
-    int rcw = ws_get(st, (n_xe + n_xg + n_yp + n_state) * sizeof(double), &base);
+    int rcw = ws_get(st, mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), &base);
     if (rcw) return rcw;
-    double* xe = static_cast<double*>(base);
-    double* xg = xe + n_xe;
-    double* yp = xg + n_xg;
-    prm.state = yp + n_yp;
-    hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
-                       prm.NB, xe, xg, yp);
-    prm.XE = xe; prm.XG = xg; prm.ypad = yp;
-    hipLaunchKernelGGL((mi::mala_logistic_kernel<NTQ, CT>), dim3((unsigned)n_wg), dim3(256), 0, st, prm);
-    HIP_TRY(hipGetLastError());
+    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base, st);
+    if (e != 0) return fail(MI_ERR_HIP, "logistic kernel launch: %s", hipGetErrorString((hipError_t)e));
     return MI_OK;
 }
 
-// LDS-staged logistic kernels (logistic_lds.hpp): 32 chains per workgroup of 8 waves
-template <int NTQ, int ALGO>
-int launch_logit_lds(mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
-{
-    using G = mi::LogitGeo<NTQ>;
-    const size_t NB = prm.NB;
-    const size_t n_wg = (prm.C + 31) / 32;
-    const size_t n_xp = NB * G::XBUF_PAD;
-    const size_t n_state = n_wg * 8 * 2 * G::NSQ * 64;
-    void* base = nullptr;
-    int rcw = ws_get(st, (n_xp + n_state) * sizeof(double), &base);
-    if (rcw) return rcw;
-    double* xp = static_cast<double*>(base);
-    prm.state = xp + n_xp;
-    hipLaunchKernelGGL(mi::pack_logit_lds_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
-    prm.Xp = xp;
-    auto kern = mi::logit_lds_kernel<NTQ, ALGO>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
 
-template <int ALGO>
-int launch_logit_lds_any(mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
-{
-    if (prm.d <= 64) return launch_logit_lds<1, ALGO>(prm, X_dev, y_dev, st);
-    if (prm.d <= 128) return launch_logit_lds<2, ALGO>(prm, X_dev, y_dev, st);
-    if (prm.d <= 256) return launch_logit_lds<4, ALGO>(prm, X_dev, y_dev, st);
-    return launch_logit_lds<8, ALGO>(prm, X_dev, y_dev, st);
-}
-
-inline mi::LogitParams to_lds_params(const mi::MalaLogitParams& q, uint32_t n_leap)
-{
-    mi::LogitParams r{};
-    r.d = q.d; r.n_rows = q.n_rows; r.NB = q.NB; r.C = q.C; r.chain0 = q.chain0;
-    r.theta = q.theta; r.draws = q.draws; r.n_accept = q.n_accept; r.seed = q.seed;
-    r.n_burnin = q.n_burnin; r.n_keep = q.n_keep; r.n_leap = n_leap;
-    r.eps = q.eps; r.s2 = q.s2; r.rs = q.rs; r.cons_term = q.cons_term; r.log_det = q.log_det;
-    return r;
-}
-
-template <int NTQ>
-int launch_hmc_logistic(mi::MalaLogitParams& prm, uint32_t n_leap_steps, const double* X_dev, const double* y_dev, hipStream_t st)
-{
-    constexpr int NSQ = 4 * NTQ, CT = 1;
-    const size_t NB = prm.NB;
-    const size_t n_wg = (prm.C + 16 * CT - 1) / (16 * CT);
-    const size_t n_xe = NB * 4 * NSQ * 64, n_xg = NB * 4 * NTQ * 4 * 64, n_yp = NB * 16;
-    const size_t n_state = n_wg * 4 * 2 * CT * NSQ * 64;
-    void* base = nullptr;
-    int rcw = ws_get(st, (n_xe + n_xg + n_yp + n_state) * sizeof(double), &base);
-    if (rcw) return rcw;
-    double* xe = static_cast<double*>(base);
-    double* xg = xe + n_xe;
-    double* yp = xg + n_xg;
-    prm.state = yp + n_yp;
-    hipLaunchKernelGGL(mi::pack_logistic_kernel<NTQ>, dim3((unsigned)NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows,
-                       prm.NB, xe, xg, yp);
-    prm.XE = xe; prm.XG = xg; prm.ypad = yp;
-    hipLaunchKernelGGL((mi::hmc_logistic_kernel<NTQ, CT>), dim3((unsigned)n_wg), dim3(256), 0, st, prm, n_leap_steps);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NTQ>
-int launch_mala_logistic(mi::MalaLogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
-{
-    // CT = 2 (every X fragment feeds two MFMAs) halves the L2 stream but currently spills (2.7 KiB scratch per lane)
-    // and measures 2.7x slower than CT = 1 at config 3; it stays selectable for the next round of tuning
-    int ct = 1;
-    if (const char* e = getenv("MI_MALA_CT")) ct = atoi(e) == 2 ? 2 : 1;
-    return ct == 2 ? launch_mala_logistic_ct<NTQ, 2>(prm, X_dev, y_dev, st) : launch_mala_logistic_ct<NTQ, 1>(prm, X_dev, y_dev, st);
-}
 
 template <int NT>
 int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
@@ -376,21 +290,15 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         StagedChains sc;
         rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
-        mi::MalaLogitParams q{};
+        mi::LogitParams q{};
         q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
         q.C = chains->n_chains; q.chain0 = chains->chain0;
         q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
         q.seed = settings->rng_seed_value;
         q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+        q.n_leap = (uint32_t)settings->n_leap_steps;
         q.eps = settings->step_size;
-        const uint32_t L = (uint32_t)settings->n_leap_steps;
-        if (!getenv("MI_LOGIT_STREAM")) {
-            mi::LogitParams r = to_lds_params(q, L);
-            rc = launch_logit_lds_any<mi::LOGIT_HMC>(r, X_dev, y_dev, st);
-        } else if (d <= 64) rc = launch_hmc_logistic<1>(q, L, X_dev, y_dev, st);
-        else if (d <= 128) rc = launch_hmc_logistic<2>(q, L, X_dev, y_dev, st);
-        else if (d <= 256) rc = launch_hmc_logistic<4>(q, L, X_dev, y_dev, st);
-        else rc = launch_hmc_logistic<8>(q, L, X_dev, y_dev, st);
+        rc = launch_logit(mi::LOGIT_HMC, q, X_dev, y_dev, st);
         if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
@@ -561,7 +469,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         StagedChains sc;
         rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
-        mi::MalaLogitParams q{};
+        mi::LogitParams q{};
         q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
         q.C = chains->n_chains; q.chain0 = chains->chain0;
         q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
@@ -570,13 +478,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.eps = settings->step_size; q.s2 = s2_; q.rs = 1.0 / s2_;
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
         q.log_det = log_det_;
-        if (!getenv("MI_LOGIT_STREAM")) {
-            mi::LogitParams r = to_lds_params(q, 0);
-            rc = launch_logit_lds_any<mi::LOGIT_MALA>(r, X_dev, y_dev, st);
-        } else if (d <= 64) rc = launch_mala_logistic<1>(q, X_dev, y_dev, st);
-        else if (d <= 128) rc = launch_mala_logistic<2>(q, X_dev, y_dev, st);
-        else if (d <= 256) rc = launch_mala_logistic<4>(q, X_dev, y_dev, st);
-        else rc = launch_mala_logistic<8>(q, X_dev, y_dev, st);
+        rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st);
         if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;

@@ -29,7 +29,7 @@ enum : int { V_PPW0 = 52, NUTS_NVEC_ASYNC = 64 };   // P*theta of the pending pr
 enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     constexpr int NS = 4 * NT;
     constexpr int WS_NVEC = NUTS_NVEC_ASYNC;

@@ -340,10 +340,19 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
             const double* x = t->X + r * d;
             if (nblk <= 1 || bs == 0) {
                 for (size_t j = 0; j < d; ++j) acc = fma(x[j], th[j], acc);
-            } else {                     /* ((e0 + e1) + e2) + ...: one fma chain per dimension block */
+            } else {                     /* ((e0 + e1) + e2) + ...: e_k the eta of dimension block k; inside a block
+                                          * eta_chains contiguous fma sub-chains summed left to right */
+                const int nch = t->eta_chains > 1 ? t->eta_chains : 1;
+                const size_t sub = bs / (size_t)nch;
                 for (int k = 0; k < nblk; ++k) {
                     double e = 0.0;
-                    for (size_t j = (size_t)k * bs; j < d && j < (size_t)(k + 1) * bs; ++j) e = fma(x[j], th[j], e);
+                    for (int c = 0; c < nch; ++c) {
+                        const size_t lo = (size_t)k * bs + (size_t)c * sub;
+                        const size_t hi = (c == nch - 1) ? (size_t)(k + 1) * bs : lo + sub;
+                        double h = 0.0;
+                        for (size_t j = lo; j < d && j < hi; ++j) h = fma(x[j], th[j], h);
+                        e = (c == 0) ? h : e + h;
+                    }
                     acc = (k == 0) ? e : acc + e;
                 }
             }

@@ -53,6 +53,8 @@ typedef struct orc_target {
     int           reduce_width;  /* W of orc_dot used inside the target (see below) */
     int           reduce_blocks; /* >1: dimension-blocked reductions (see orc_dot_b), block size reduce_block_size */
     size_t        reduce_block_size;
+    int           eta_chains;    /* LOGISTIC: the eta fma chain of every dimension block is cut into this many contiguous
+                                    sub-chains of reduce_block_size/eta_chains dims, summed left to right (<=1: one chain) */
     uint64_t      n_grad_calls;  /* instrumentation */
     uint64_t      n_value_calls;
 } orc_target;

@@ -28,7 +28,7 @@ def cases():
     targets = {
         "iso3": dict(kind=orc.TARGET_ISO, d=3),
         "dense8": dict(kind=orc.TARGET_DENSE, d=8, prec=P8),
-        "logit5": dict(kind=orc.TARGET_LOGISTIC, d=5, X=X5, y=y5, blocks=4, block_size=16),
+        "logit5": dict(kind=orc.TARGET_LOGISTIC, d=5, X=X5, y=y5, blocks=4, block_size=16, eta_chains=2),
     }
     algos = {
         "hmc": dict(algo=orc.ALGO_HMC, n_leap=5, step=0.2),
@@ -43,7 +43,8 @@ def cases():
 def run_case(t, a):
     d = t["d"]
     blocks, bs = t.get("blocks", 0), t.get("block_size", 0)
-    tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=4, blocks=blocks, block_size=bs)
+    tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=4, blocks=blocks, block_size=bs,
+                         eta_chains=t.get("eta_chains", 1))
     init = synth.initial_states(C, d, seed=99) * 0.5
     out = dict(draws=[], accept=[], depth=[], eps=[], n_leap=[])
     for c in range(C):

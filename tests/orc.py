@@ -16,7 +16,7 @@ _dp = C.POINTER(C.c_double)
 class Target(C.Structure):
     _fields_ = [("kind", C.c_int), ("d", C.c_size_t), ("prec", _dp), ("X", _dp), ("y", _dp),
                 ("n_rows", C.c_size_t), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
-                ("reduce_block_size", C.c_size_t),
+                ("reduce_block_size", C.c_size_t), ("eta_chains", C.c_int),
                 ("n_grad_calls", C.c_uint64), ("n_value_calls", C.c_uint64)]
 
 
@@ -65,11 +65,11 @@ def _f64(a):
 class TargetSpec:
     """Holds the numpy buffers alive next to the C struct."""
 
-    def __init__(self, kind, d, prec=None, X=None, y=None, W=4, blocks=0, block_size=0):
+    def __init__(self, kind, d, prec=None, X=None, y=None, W=4, blocks=0, block_size=0, eta_chains=1):
         self.kind, self.d, self.W = kind, int(d), W
         self.prec, self.X, self.y = _f64(prec), _f64(X), _f64(y)
         self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y),
-                        0 if self.X is None else self.X.shape[0], W, blocks, block_size, 0, 0)
+                        0 if self.X is None else self.X.shape[0], W, blocks, block_size, eta_chains, 0, 0)
 
     def kernel(self, theta, want_grad=True):
         theta = _f64(theta)

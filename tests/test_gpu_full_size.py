@@ -19,7 +19,7 @@ def test_config3_mala_logistic_d512_262144_chains():
     draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
     assert draws.shape == (2, d, C) and np.isfinite(draws).all()
     pick = [0, 17, 4095, 131072, 262143]
-    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=128)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=128, eta_chains=2)
     for c in pick:
         s = orc.make_settings(seed=6, n_burnin=3, n_keep=2, step=0.02, W=4, hoist=1, blocks=4, block_size=128, chain_id=c)
         o, info = orc.run_chain(orc.ALGO_MALA, t, init[c], s)

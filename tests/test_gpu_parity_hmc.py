@@ -306,7 +306,7 @@ def test_hmc_logistic_bit_exact_vs_oracle(d, N, C, eps, L, burn, keep):
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps, n_leap_steps=L)
     g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
     dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
-    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=dq)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=dq, eta_chains=2)
     s = orc.make_settings(seed=77, n_burnin=burn, n_keep=keep, step=eps, n_leap=L, W=4, hoist=1, blocks=4, block_size=dq)
     o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=5)
     assert np.array_equal(g["n_accept"], o["n_accept"])

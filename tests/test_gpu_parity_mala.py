@@ -74,7 +74,7 @@ def test_mala_logistic_bit_exact_vs_oracle(d, N, C, eps, burn, keep):
     st = mcmc_amd.default_settings(rng_seed_value=123, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps)
     g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=3)
     nb, bs = _blocks(d)
-    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=nb, block_size=bs)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=nb, block_size=bs, eta_chains=2)
     s = orc.make_settings(seed=123, n_burnin=burn, n_keep=keep, step=eps, W=4, hoist=1, blocks=nb, block_size=bs)
     o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s, chain0=3)
     assert np.array_equal(g["n_accept"], o["n_accept"])
