@@ -101,7 +101,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     double* const part = part_all + g * (4 * 4 * 64);
     double* const rt = rt_all + g * (4 * 2 * 64);
     double* const ws_wave = prm.state + ((size_t)blockIdx.x * 8 + w) * ((size_t)2 * NSQ * 64) + lane;
-    auto st = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NSQ + s) * 64; };
+    // Address of slice s of state vector v.  The base of each group of 8 slices is made opaque where it is used: otherwise the
+    // compiler hoists all 2*NSQ loop-invariant 64-bit addresses out of the draw loop, spills them, and serialises every
+    // workspace access behind a scratch reload of its address (reload, wait, load, wait).  Inside a group the 512-byte
+    // slice stride folds into the instruction's immediate offset.
+    auto st = [&](int v, int s) -> double* {
+        double* b = ws_wave + ((size_t)v * NSQ + (s & ~7)) * 64;
+        asm volatile("" : "+v"(b));
+        return b + (s & 7) * 64;
+    };
     // the dimension of slice s in this lane.  Opaque on purpose: the `dim < d` predicates of the fully unrolled per-draw loops
     // are loop invariants, and the compiler would otherwise keep dozens of 64-bit lane masks alive in SGPRs across the whole
     // kernel (hundreds of SGPR spills); recomputing a compare where it is used costs nothing.

@@ -22,6 +22,14 @@
 #ifndef MI_NUTS_CH
 #define MI_NUTS_CH 32
 #endif
+// chunk sizes of the two places where several vectors are in flight per chunk (a chunk that does not fit the 256 arch VGPRs
+// is spilled to scratch, and a scratch reload waits behind every store of the tick: vmcnt is in order)
+#ifndef MI_NUTS_CHF
+#define MI_NUTS_CHF 8      // end-of-doubling U-turn dots: 4 vectors
+#endif
+#ifndef MI_NUTS_CHC
+#define MI_NUTS_CHC 16     // proposal copies: 2 vectors
+#endif
 
 namespace mi {
 
@@ -53,8 +61,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
     // workspace layout [wave][vec][slice][lane]: a vector of a wave's 16 chains is 16 KiB contiguous (one 512-B
     // coalesced access per slice, 4 pages per vector) instead of 128 fragments 4*C*8 bytes apart
-    double* const ws_wave = prm.ws + ((size_t)blockIdx.x * 4 + wave) * ((size_t)WS_NVEC * NS * 64) + lane;
-    auto wsp = [&](int v, int s) -> double* { return ws_wave + ((size_t)v * NS + s) * 64; };
+    // Addressing: wave-uniform base (SGPR pair) + one 32-bit byte offset per access, so that every access is the
+    // `global_load/store v, v_off, s[base]` form.  With a per-lane 64-bit base the compiler precomputed a 64-bit address
+    // pair per (vector, slice) -- hundreds of VGPRs of loop invariants, spilled, and reloaded from scratch in front of every
+    // load (a scratch reload waits behind every store in flight: vmcnt is in order).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    char* const ws_wave_u = reinterpret_cast<char*>(prm.ws + ((size_t)blockIdx.x * 4 + wave_u) * ((size_t)WS_NVEC * NS * 64));
+    uint32_t lane_b = (uint32_t)lane * 8u;      // redefined (opaquely) at the top of every tick: no address outlives a tick
+    auto wsp = [&](int v, int s) -> double* {
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)(v * NS + s) * 512u + lane_b));
+    };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
 
     double th[NS], pm[NS], w[NS];
@@ -80,6 +96,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     };
     // vector ops touch 8 slices at a time (16 VGPRs in flight): the register file is full of theta / p / P*theta
     constexpr int CH = (NS < MI_NUTS_CH) ? NS : MI_NUTS_CH;
+    constexpr int CHF = (NS < MI_NUTS_CHF) ? NS : MI_NUTS_CHF;
+    constexpr int CHC = (NS < MI_NUTS_CHC) ? NS : MI_NUTS_CHC;
     constexpr int CHU = (NS < MI_NUTS_CHU) ? NS : MI_NUTS_CHU;   // U-turn operands: 4 vectors in flight per chunk
     auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
         if (pred && live) {
@@ -259,6 +277,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #define MI_PROF(k) { const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
 #pragma unroll 1
     while (__ballot(state != NS_DONE) != 0ull) {
+        asm volatile("" : "+v"(lane_b));
         MI_PROF(7)
         // ------------------------------------------------------------ A. momentum refresh for waiting chains
         const unsigned n_wait = __popcll(__ballot(state == NS_NEED_DRAW)) / 4;
@@ -434,13 +453,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 const int dst_w = take ? V_WPREV : V_PPW0 + pl;
                 if (do_store && live) {
 #pragma unroll
-                    for (int c0 = 0; c0 < NS; c0 += CH) {
-                        double t1[CH], t2[CH];
+                    for (int c0 = 0; c0 < NS; c0 += CHC) {
+                        double t1[CHC], t2[CHC];
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) { t1[k] = *wsp(cref_t, c0 + k); t2[k] = *wsp(cref_w, c0 + k); }
+                        for (int k = 0; k < CHC; ++k) { t1[k] = *wsp(cref_t, c0 + k); t2[k] = *wsp(cref_w, c0 + k); }
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) { *wsp(dst_t, c0 + k) = t1[k]; *wsp(dst_w, c0 + k) = t2[k]; }
-                        if (CH < NS) __builtin_amdgcn_sched_barrier(0);
+                        for (int k = 0; k < CHC; ++k) { *wsp(dst_t, c0 + k) = t1[k]; *wsp(dst_w, c0 + k) = t2[k]; }
+                        if (CHC < NS) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -454,15 +473,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 double q1 = 0.0, q2 = 0.0;
                 if (complete) {
 #pragma unroll
-                    for (int c0 = 0; c0 < NS; c0 += CH) {
-                        double tp[CH], tn[CH], pp[CH], pn[CH];
+                    for (int c0 = 0; c0 < NS; c0 += CHF) {
+                        double tp[CHF], tn[CHF], pp[CHF], pn[CHF];
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) {
+                        for (int k = 0; k < CHF; ++k) {
                             tp[k] = *wsp(V_TPOS_T, c0 + k); tn[k] = *wsp(V_TNEG_T, c0 + k);
                             pp[k] = *wsp(V_TPOS_P, c0 + k); pn[k] = *wsp(V_TNEG_P, c0 + k);
                         }
 #pragma unroll
-                        for (int k = 0; k < CH; ++k) {
+                        for (int k = 0; k < CHF; ++k) {
                             const double df = tp[k] - tn[k];
                             q1 = dfma(df, pn[k], q1);                    // :286
                             q2 = dfma(df, pp[k], q2);                    // :287
