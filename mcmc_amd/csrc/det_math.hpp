@@ -237,6 +237,11 @@ MI_HD double rng_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t 
 MI_HD void rng_normal_pair(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, uint32_t stream,
                            double& z0, double& z1)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the slot opaque: in the fully unrolled per-draw loops the compiler otherwise hoists the slot-only part of the first
+    // Philox round of every slot out of the draw loop (3 registers per slot), spills it, and reloads it from scratch per draw
+    asm volatile("" : "+v"(slot));
+#endif
     const u32x4 w = rng_block(seed, chain, draw, slot, stream);
     const double u1 = u01(w.x, w.y);
     const double u2 = u01(w.z, w.w);

@@ -225,8 +225,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     const size_t lane_off = (size_t)j * C + cld;
     // last accepted (theta, P*theta): wave-local contiguous [wave][2][NS][64 lanes] (512-B coalesced per slice)
     double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)3 * NS * 64) + lane;
-    auto th_mem = [&](int s) -> double* { return ws_wave + (size_t)s * 64; };
-    auto w_mem = [&](int s) -> double* { return ws_wave + (size_t)(NS + s) * 64; };
+    // The base of every group of 8 slices is made opaque where it is used: the 2*NS addresses are loop invariants, and the
+    // compiler otherwise hoists them out of the draw loop as 64-bit pairs, spills them, and serialises each workspace access
+    // behind a scratch reload of its own address.  Inside a group the 512-byte slice stride is the instruction's immediate.
+    auto ws_group = [&](int k) -> double* {
+        double* b = ws_wave + (size_t)(k & ~7) * 64;
+        asm volatile("" : "+v"(b));
+        return b + (k & 7) * 64;
+    };
+    auto th_mem = [&](int s) -> double* { return ws_group(s); };
+    auto w_mem = [&](int s) -> double* { return ws_group(NS + s); };
     [[maybe_unused]] auto z_mem = [&](int s) -> double* { return ws_wave + (size_t)(2 * NS + s) * 64; };   // fresh normals, staged
 
     // w = P * (theta or inv_transform(theta)); BOUNDED also refreshes xs and kw
