@@ -9,6 +9,16 @@
 // The reference evaluates the gradient three times per draw (mu(theta), mu(theta'), mu(theta) again);
 // the values are deterministic, so P*theta of the current state is cached and ONE mat-vec per draw
 // (at the proposal) reproduces all of them bit for bit.
+//
+// GENERAL variant: settings.vals_bound (mala.cpp:84-95,105-121,132-134,152-157,193-200 with transform_vals.hpp,
+// log_jacobian.hpp, inv_jacobian_adjust.hpp) and / or a DIAGONAL precond_mat M.  Every matrix of the reference's formulas is
+// then diagonal (J = inv_jacobian_adjust, J*M, CHOL_LOWER(J), Sigma = eps^2 J M, INV(Sigma)), and Gauss-Jordan / Cholesky /
+// the fma-chain products of the oracle's BMO shim applied to a diagonal matrix are the element-wise 1/x, sqrt(x) and a*b:
+//   unbounded: mu(v) = v + (eps^2 (M g)) / 2,           proposal = mu + eps (sqrt(M) z),        Sigma = eps^2 M (hoisted)
+//   bounded:   mu(v) = v + ((eps^2 (J(v) M)) g) / 2,    proposal = mu + ((eps (sqrt(J) sqrt(M))) z),
+//              Sigma = eps^2 (J(proposal) M) in BOTH dmvnorm terms (mala.ipp:52-53), LOG_DET summed over dimensions in order,
+//              log kernel = K(inv_transform(v)) + log_jacobian(v), draws reported through inv_transform.
+// Identity bounds / unit M reproduce the plain kernel's bits.
 #pragma once
 
 #include "hmc_dense.hpp"
@@ -28,15 +38,38 @@ struct MalaParams {
     double s2;              // eps*eps (mala.cpp:123, mala.ipp:41)
     double rs;              // 1.0 / s2: diagonal of INV(eps^2 I)
     double cons_term;       // -0.5 * d * log(2 pi)   (dmvnorm.hpp:36)
-    double log_det;         // LOG_DET(eps^2 I)
+    double log_det;         // LOG_DET(eps^2 M), hoisted (unbounded runs)
+    // general variant (GENERAL = true): settings.vals_bound and / or a diagonal precond_mat M
+    int vals_bound;
+    const int* btype;       // [d] determine_bounds_type (1 none, 2 lower, 3 upper, 4 both)
+    const double* lb;
+    const double* ub;
+    const double* m;        // [d] diagonal of precond_mat
+    const double* m_sqrt;   // [d] diagonal of CHOL_LOWER(precond_mat)
 };
 
-template <int NT>
+template <int NT, bool GENERAL = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(const MalaParams prm)
 {
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
-    stage_precision<NT>(prm.P, prm.d, lds_P);
+    // GENERAL: per-dimension bounds / preconditioner tables behind the precision fragments
+    double* const lds_lb = lds_P + (size_t)NT * 4 * NT * 64;
+    double* const lds_ub = lds_lb + 16 * NT;
+    double* const lds_m = lds_ub + 16 * NT;
+    double* const lds_ms = lds_m + 16 * NT;
+    int* const lds_bt = reinterpret_cast<int*>(lds_ms + 16 * NT);
+    if constexpr (GENERAL) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_lb[i] = in ? prm.lb[i] : 0.0;
+            lds_ub[i] = in ? prm.ub[i] : 0.0;
+            lds_bt[i] = in ? prm.btype[i] : 1;
+            lds_m[i] = in ? prm.m[i] : 1.0;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+        }
+    }
+    stage_precision<NT>(prm.P, prm.d, lds_P);           // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
@@ -50,55 +83,146 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
     const double* afrag = lds_P + lane;
     const size_t lane_off = (size_t)j * C + cld;
 
-    double th[NS], w[NS];        // current state and P*theta (grad = -w)
-    double tp[NS], wp[NS];       // proposal and P*theta'
-    double xc[NS], tt[NS];
+    double th[NS], w[NS];        // current state (transformed space when bounded) and P*x(theta) (grad = -w)
+    double tp[NS], wp[NS];       // proposal and P*x(theta')
+    double xp[GENERAL ? NS : 1]; // GENERAL: x(theta') = inv_transform(theta')
+    const bool vb = GENERAL && prm.vals_bound != 0;
+
+    // mala_mean_fn (mala.cpp:97-125) for one dimension; jm_out = eps^2 (J M) when bounded (= Sigma_ii with J = J(v))
+    auto mean_of = [&](double v, double pw, int dim, double& jm_out) __attribute__((always_inline)) -> double {
+        if constexpr (GENERAL) {
+            const double M = lds_m[dim];
+            if (vb) {
+                const double J = box_inv_jacobian(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]);   // :113
+                const double JM = s2 * (J * M);                                                // :115-117
+                jm_out = JM;
+                return v + (JM * (-pw)) / 2.0;                                                 // :121
+            }
+            jm_out = s2 * M;
+            return v + (s2 * (M * (-pw))) / 2.0;                                               // :123
+        } else {
+            jm_out = s2;
+            return v - (s2 * pw) / 2.0;
+        }
+    };
+    // box_log_kernel at the state whose x / P x are (xx, ww) (mala.cpp:84-95): K(x) [+ log_jacobian(theta), i ascending]
+    auto log_kernel = [&](const double (&tt_)[NS], const double (&xx)[GENERAL ? NS : 1], const double (&ww)[NS]) __attribute__((always_inline)) -> double {
+        if constexpr (GENERAL) {
+            const double kval = -0.5 * dot4<NS>(xx, ww);
+            if (!vb) return kval;
+            double lj = 0.0;                             // log_jacobian.hpp:36-57: scalar loop
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i0 = 4 * s;
+                const double term = box_log_jacobian_term(tt_[s], lds_bt[i0 + j], lds_lb[i0 + j], lds_ub[i0 + j]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double tg = __shfl(term, (lane & 15) + 16 * g);
+                    if ((uint32_t)(i0 + g) < d && lds_bt[i0 + g] != 1) lj = lj + tg;
+                }
+            }
+            return kval + lj;
+        } else {
+            return -0.5 * dot4<NS>(tt_, ww);
+        }
+    };
 
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t dim = 4 * s + j;
-        th[s] = (dim < d) ? prm.theta[(size_t)(4 * s) * C + lane_off] : 0.0;
+        const double v = (dim < d) ? prm.theta[(size_t)(4 * s) * C + lane_off] : 0.0;
+        if constexpr (GENERAL) th[s] = (vb && dim < d) ? box_transform(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]) : v;   // mala.cpp:132-134
+        else th[s] = v;
     }
-    matvec_mfma<NT>(afrag, th, w);
-    double prev_LP = -0.5 * dot4<NS>(th, w);            // box_log_kernel(first_draw), mala.cpp:138
+    if constexpr (GENERAL) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int dim = 4 * s + j;
+            xp[s] = vb ? (((uint32_t)dim < d) ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : 0.0) : th[s];
+        }
+        matvec_mfma<NT>(afrag, xp, w);
+    } else {
+        matvec_mfma<NT>(afrag, th, w);
+    }
+    double prev_LP = log_kernel(th, xp, w);             // box_log_kernel(first_draw), mala.cpp:138
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
-        // proposal: mala_mean_fn(prev) + eps * L z   (mala.cpp:150,159; L = I)
+        // proposal: mala_mean_fn(prev) + eps * L z   (mala.cpp:150-159)
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
             rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             const double za = (8u * b + j < d) ? z0 : 0.0;
             const double zb = (8u * b + 4 + j < d) ? z1 : 0.0;
-            const double ma = th[2 * b] - (s2 * w[2 * b]) / 2.0;           // theta + (s2*grad)/2, :123
-            const double mb = th[2 * b + 1] - (s2 * w[2 * b + 1]) / 2.0;
-            tp[2 * b] = ma + eps * za;
-            tp[2 * b + 1] = mb + eps * zb;
+            double jma, jmb;
+            const double ma = mean_of(th[2 * b], w[2 * b], 8 * b + j, jma);
+            const double mb = mean_of(th[2 * b + 1], w[2 * b + 1], 8 * b + 4 + j, jmb);
+            if constexpr (GENERAL) {
+                const double sa = lds_ms[8 * b + j], sb = lds_ms[8 * b + 4 + j];
+                if (vb) {                                // CHOL_LOWER(J) * sqrt_precond, scaled by eps (mala.cpp:155-157)
+                    const double Ja = box_inv_jacobian(th[2 * b], lds_bt[8 * b + j], lds_lb[8 * b + j], lds_ub[8 * b + j]);
+                    const double Jb = box_inv_jacobian(th[2 * b + 1], lds_bt[8 * b + 4 + j], lds_lb[8 * b + 4 + j], lds_ub[8 * b + 4 + j]);
+                    tp[2 * b] = ma + (eps * (__builtin_sqrt(Ja) * sa)) * za;
+                    tp[2 * b + 1] = mb + (eps * (__builtin_sqrt(Jb) * sb)) * zb;
+                } else {
+                    tp[2 * b] = ma + eps * (sa * za);    // :159
+                    tp[2 * b + 1] = mb + eps * (sb * zb);
+                }
+            } else {
+                tp[2 * b] = ma + eps * za;
+                tp[2 * b + 1] = mb + eps * zb;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        matvec_mfma<NT>(afrag, tp, wp);
-        double prop_LP = -0.5 * dot4<NS>(tp, wp);        // :162
+        if constexpr (GENERAL) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int dim = 4 * s + j;
+                xp[s] = vb ? (((uint32_t)dim < d) ? box_inv_transform(tp[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : 0.0) : tp[s];
+            }
+            matvec_mfma<NT>(afrag, xp, wp);
+        } else {
+            matvec_mfma<NT>(afrag, tp, wp);
+        }
+        double prop_LP = log_kernel(tp, xp, wp);         // :162
         if (!is_finite(prop_LP)) prop_LP = -INF;         // :164-166
-        // mala_prop_adjustment (mala.ipp:59-64): dmvnorm(prev | mu(prop)) - dmvnorm(prop | mu(prev))
+        // mala_prop_adjustment (mala.ipp:45-65): dmvnorm(prev | mu(prop), Sigma) - dmvnorm(prop | mu(prev), Sigma),
+        // Sigma = eps^2 [J(prop)] M in both terms; quadratic forms in dot4 order, accumulated on the fly
+        double qa = 0.0, qb = 0.0, ld_term[GENERAL ? NS : 1];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const double mean_prop = tp[s] - (s2 * wp[s]) / 2.0;
-            xc[s] = th[s] - mean_prop;                   // dmvnorm.hpp:37
-            tt[s] = rs * xc[s];                          // INV(Sigma) * X_cent
+            const int dim = 4 * s + j;
+            double sig_p, sig_c;
+            const double mean_prop = mean_of(tp[s], wp[s], dim, sig_p);
+            const double mean_prev = mean_of(th[s], w[s], dim, sig_c);
+            const double sinv = GENERAL ? 1.0 / sig_p : rs;              // INV(Sigma)_ii
+            const double xa = th[s] - mean_prop;                          // dmvnorm.hpp:37
+            qa = dfma(xa, sinv * xa, qa);                                 // :39
+            const double xb = tp[s] - mean_prev;
+            qb = dfma(xb, sinv * xb, qb);
+            if constexpr (GENERAL) ld_term[s] = 2.0 * det_log(__builtin_sqrt(sig_p));   // LOG_DET via CHOL_LOWER, term i
         }
-        const double quad_a = dot4<NS>(xc, tt);          // :39
-        const double da = prm.cons_term - 0.5 * (prm.log_det + quad_a);   // :41
+        qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
+        qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
+        double log_det = prm.log_det;
+        if constexpr (GENERAL) {
+            if (vb) {                                    // Sigma depends on the proposal: sum_i 2 log L_ii, i ascending
+                log_det = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double mean_prev = th[s] - (s2 * w[s]) / 2.0;
-            xc[s] = tp[s] - mean_prev;
-            tt[s] = rs * xc[s];
+                for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double tg = __shfl(ld_term[s], (lane & 15) + 16 * g);
+                        if ((uint32_t)(4 * s + g) < d) log_det = log_det + tg;
+                    }
+                }
+            }
         }
-        const double quad_b = dot4<NS>(xc, tt);
-        const double db = prm.cons_term - 0.5 * (prm.log_det + quad_b);
+        const double da = prm.cons_term - 0.5 * (log_det + qa);          // :41
+        const double db = prm.cons_term - 0.5 * (log_det + qb);
         const double x = prop_LP - prev_LP + (da - db);
         const double comp_val = (x < 0.01) ? x : 0.01;   // std::min(0.01, x), mala.cpp:170
         const double z = rng_uniform(prm.seed, chain, draw, 0u);          // :171
@@ -115,7 +239,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t dim = 4 * s + j;
-                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = th[s];
+                    double v = th[s];
+                    if constexpr (GENERAL) { if (vb && dim < d) v = box_inv_transform(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]); }   // :193-200
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = v;
                 }
             }
         }
@@ -124,7 +250,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;
-            if (dim < d) prm.theta[(size_t)(4 * s) * C + lane_off] = th[s];
+            double v = th[s];
+            if constexpr (GENERAL) { if (vb && dim < d) v = box_inv_transform(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]); }
+            if (dim < d) prm.theta[(size_t)(4 * s) * C + lane_off] = v;
         }
         if (j == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
     }

@@ -176,11 +176,53 @@ int launch_logit(int algo, const mi::LogitParams& prm, const double* X_dev, cons
 
 
 
-template <int NT>
+// Per-dimension tables of the general kernel variants (settings.vals_bound and / or a diagonal precond_mat):
+// determine_bounds_type (determine_bounds_type.hpp:27-57: 1 none, 2 lower, 3 upper, 4 both), the bounds, and the diagonal of
+// precond_mat with its CHOL_LOWER / INV (element-wise sqrt / reciprocal for a diagonal matrix, as the oracle's BMO shim gives).
+struct GeneralTables {
+    bool active = false;
+    std::vector<double> m, m_sqrt, m_inv;     // host copies (diagonal)
+    DevBuf bt, lb, ub, m_dev, ms_dev, mi_dev;
+};
+
+int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTables& g)
+{
+    g.active = s->vals_bound != 0 || s->precond_mat != nullptr;
+    if (!g.active) return MI_OK;
+    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "%s: vals_bound / precond_mat with d > 128 is not implemented", who);
+    if (s->vals_bound && (!s->lower_bounds || !s->upper_bounds)) return fail(MI_ERR_BAD_ARG, "%s: vals_bound needs lower_bounds and upper_bounds", who);
+    g.m.assign(d, 1.0); g.m_sqrt.assign(d, 1.0); g.m_inv.assign(d, 1.0);
+    if (s->precond_mat)
+        for (uint64_t i = 0; i < d; ++i)
+            for (uint64_t k = 0; k < d; ++k) {
+                const double v = s->precond_mat[i * d + k];
+                if (i != k && v != 0.0) return fail(MI_ERR_UNSUPPORTED, "%s: only a diagonal precond_mat is implemented on the device path", who);
+                if (i == k) { g.m[i] = v; g.m_sqrt[i] = __builtin_sqrt(v); g.m_inv[i] = 1.0 / v; }
+            }
+    std::vector<int> bt(d, 1);
+    std::vector<double> lbv(d, 0.0), ubv(d, 0.0);
+    if (s->vals_bound)
+        for (uint64_t i = 0; i < d; ++i) {
+            lbv[i] = s->lower_bounds[i]; ubv[i] = s->upper_bounds[i];
+            const bool fl = std::isfinite(lbv[i]), fu = std::isfinite(ubv[i]);
+            bt[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+        }
+    HIP_TRY(g.bt.alloc(d * sizeof(int))); HIP_TRY(g.lb.alloc(d * 8)); HIP_TRY(g.ub.alloc(d * 8));
+    HIP_TRY(g.m_dev.alloc(d * 8)); HIP_TRY(g.ms_dev.alloc(d * 8)); HIP_TRY(g.mi_dev.alloc(d * 8));
+    HIP_TRY(hipMemcpy(g.bt.p, bt.data(), d * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.lb.p, lbv.data(), d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.ub.p, ubv.data(), d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.m_dev.p, g.m.data(), d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.ms_dev.p, g.m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.mi_dev.p, g.m_inv.data(), d * 8, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+template <int NT, bool GENERAL>
 int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
 {
-    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
-    auto kern = mi::mala_gauss_mfma_kernel<NT>;
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
+    auto kern = mi::mala_gauss_mfma_kernel<NT, GENERAL>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 63) / 64);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
@@ -442,10 +484,10 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound is not implemented on the device path yet");
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "mala: precond_mat is not implemented on the device path yet");
     const uint64_t d = target->d;
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat))
+        return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound / precond_mat with the logistic target are not implemented");
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
     const double s2_ = settings->step_size * settings->step_size;
@@ -522,10 +564,27 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
 
     const int nt = (int)((d + 15) / 16);
-    if (nt <= 1) rc = launch_mala_mfma<1>(prm, st);
-    else if (nt == 2) rc = launch_mala_mfma<2>(prm, st);
-    else if (nt <= 4) rc = launch_mala_mfma<4>(prm, st);
-    else rc = launch_mala_mfma<8>(prm, st);
+    GeneralTables gt;
+    rc = general_tables("mala", settings, d, gt);
+    if (rc) return rc;
+    if (gt.active) {
+        // unbounded runs hoist LOG_DET(eps^2 M) = sum_i 2 log sqrt(eps^2 M_ii), i ascending (bounded runs sum it per draw)
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(__builtin_sqrt(prm.s2 * gt.m[i]));
+        prm.log_det = ld;
+        prm.vals_bound = settings->vals_bound ? 1 : 0;
+        prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
+        prm.m = gt.m_dev.as<double>(); prm.m_sqrt = gt.ms_dev.as<double>();
+        if (nt <= 1) rc = launch_mala_mfma<1, true>(prm, st);
+        else if (nt == 2) rc = launch_mala_mfma<2, true>(prm, st);
+        else if (nt <= 4) rc = launch_mala_mfma<4, true>(prm, st);
+        else rc = launch_mala_mfma<8, true>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+    }
+    else if (nt <= 1) rc = launch_mala_mfma<1, false>(prm, st);
+    else if (nt == 2) rc = launch_mala_mfma<2, false>(prm, st);
+    else if (nt <= 4) rc = launch_mala_mfma<4, false>(prm, st);
+    else rc = launch_mala_mfma<8, false>(prm, st);
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);

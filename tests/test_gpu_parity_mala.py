@@ -94,3 +94,57 @@ def test_mala_logistic_posterior_is_sane():
     t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y)
     _, grad = t.kernel(post_mean)
     assert np.abs(grad).max() < 2.0
+
+
+# ---------------------------------------------------------------- box constraints and diagonal precond_mat
+def _bounds(d, seed=0):
+    """A mix of the four bounds types of determine_bounds_type.hpp:27-57."""
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(1, 5, d)
+    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
+    ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+    return lb, ub
+
+
+@pytest.mark.parametrize("d,C,eps,burn,keep", [(6, 16, 0.15, 4, 12), (128, 48, 0.03, 2, 5), (37, 20, 0.08, 0, 6)])
+def test_bounded_mala_bit_exact_vs_oracle(d, C, eps, burn, keep):
+    lb, ub = _bounds(d, seed=d)
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    init = np.clip(synth.initial_states(C, d, seed=14) * 0.3, -1.0, 1.5)     # inside every box
+    st = mcmc_amd.default_settings(rng_seed_value=78, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps,
+                                   vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=4)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=78, n_burnin=burn, n_keep=keep, step=eps, W=4, lower=lb, upper=ub)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s, chain0=4)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert ((g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])).all()   # reported in the constrained space
+    assert 0 < g["n_accept"].sum() < C * keep                                          # both branches of the accept step ran
+
+
+@pytest.mark.parametrize("d,C,eps,bounded", [(8, 16, 0.3, False), (128, 40, 0.05, False), (20, 24, 0.15, True)])
+def test_diagonal_precond_mala_bit_exact_vs_oracle(d, C, eps, bounded):
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    M = np.diag(1.0 / np.diag(prec) * np.linspace(0.5, 2.0, d))
+    init = np.clip(synth.initial_states(C, d, seed=15) * 0.3, -1.0, 1.5)
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = _bounds(d, seed=3)
+        kw = dict(vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+        okw = dict(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=3, n_keep_draws=7, step_size=eps, precond_mat=M, **kw)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=6, n_burnin=3, n_keep=7, step=eps, W=4, precond=M, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+
+
+def test_dense_precond_mala_is_refused_not_approximated():
+    d = 8
+    M = np.eye(d); M[0, 1] = M[1, 0] = 0.1
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:
+        mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
