@@ -230,12 +230,13 @@ int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
     return MI_OK;
 }
 
-template <int NT>
+template <int NT, bool GENERAL>
 int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double);
+    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double)
+                     + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    if (getenv("MI_NUTS_LOCKSTEP")) {           // first-generation kernel: chains of a wave in lock-step per draw
+    if (!GENERAL && getenv("MI_NUTS_LOCKSTEP")) {   // first-generation kernel: chains of a wave in lock-step per draw
         auto kern = mi::nuts_gauss_mfma_kernel<NT>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
@@ -243,7 +244,7 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
         uint32_t batch = 8;
         if (const char* e = getenv("MI_NUTS_BATCH")) batch = (uint32_t)atoi(e);
         if (batch < 1) batch = 1;
-        auto kern = mi::nuts_gauss_async_kernel<NT>;
+        auto kern = mi::nuts_gauss_async_kernel<NT, GENERAL>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm, batch);
     }
@@ -598,8 +599,6 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "nuts: vals_bound is not implemented on the device path yet");
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "nuts: precond_mat is not implemented on the device path yet");
     const uint64_t d = target->d;
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
@@ -647,10 +646,22 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.kappa = settings->kappa_val;
 
     const int nt = (int)((d + 15) / 16);
-    if (nt <= 1) rc = launch_nuts_mfma<1>(prm, st);
-    else if (nt == 2) rc = launch_nuts_mfma<2>(prm, st);
-    else if (nt <= 4) rc = launch_nuts_mfma<4>(prm, st);
-    else rc = launch_nuts_mfma<8>(prm, st);
+    GeneralTables gt;
+    rc = general_tables("nuts", settings, d, gt);
+    if (rc) return rc;
+    if (gt.active) {
+        prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
+        prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
+        if (nt <= 1) rc = launch_nuts_mfma<1, true>(prm, st);
+        else if (nt == 2) rc = launch_nuts_mfma<2, true>(prm, st);
+        else if (nt <= 4) rc = launch_nuts_mfma<4, true>(prm, st);
+        else rc = launch_nuts_mfma<8, true>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+    }
+    else if (nt <= 1) rc = launch_nuts_mfma<1, false>(prm, st);
+    else if (nt == 2) rc = launch_nuts_mfma<2, false>(prm, st);
+    else if (nt <= 4) rc = launch_nuts_mfma<4, false>(prm, st);
+    else rc = launch_nuts_mfma<8, false>(prm, st);
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);

@@ -36,7 +36,12 @@ namespace mi {
 enum : int { V_PPW0 = 52, NUTS_NVEC_ASYNC = 64 };   // P*theta of the pending proposal of level l at 52 + l
 enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
 
-template <int NT>
+// GENERAL: settings.vals_bound and / or a diagonal precond_mat, with the arithmetic of the general HMC variant
+// (hmc_dense.hpp; the reference's NUTS shares mntm_update_fn / leap_frog_fn / box_log_kernel with HMC, nuts.cpp:84-154):
+// x = inv_transform(theta) feeds the mat-vec, the kick uses J^-1_ii (P x)_i, the drift M^-1 p, K = p.(M^-1 p)/2,
+// U = -(K(x) + log_jacobian(theta)) summed over dimensions in order, p = sqrt(M) z; the tree lives in the transformed space
+// (the U-turn dots are plain), draws are reported through inv_transform.  Identity tables reproduce the plain kernel's bits.
+template <int NT, bool GENERAL = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     constexpr int NS = 4 * NT;
@@ -44,7 +49,22 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
-    stage_precision<NT>(prm.P, prm.d, lds_P);
+    double* const lds_lb = lds_lvl + NUTS_LVLS * 4 * 64;
+    double* const lds_ub = lds_lb + 16 * NT;
+    double* const lds_ms = lds_ub + 16 * NT;
+    double* const lds_mi = lds_ms + 16 * NT;
+    int* const lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
+    if constexpr (GENERAL) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_lb[i] = in ? prm.lb[i] : 0.0;
+            lds_ub[i] = in ? prm.ub[i] : 0.0;
+            lds_bt[i] = in ? prm.btype[i] : 1;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+            lds_mi[i] = in ? prm.m_inv[i] : 1.0;
+        }
+    }
+    stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j4 = lane >> 4;
@@ -112,22 +132,80 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             }
         }
     };
-    auto leapfrog = [&](double e) __attribute__((always_inline)) {
+    // GENERAL helpers on the register-resident (th, pm, w): x = inv_transform(theta), w = P x, kick vector J^-1 w
+    auto general_gradient = [&](double (&xs_)[GENERAL ? NS : 1]) __attribute__((always_inline)) {
+        if constexpr (GENERAL) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i = 4 * s + j4;
+                xs_[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+            }
+            matvec_mfma<NT>(afrag, xs_, w);
+        }
+    };
+    auto kick = [&](double e) __attribute__((always_inline)) {         // p += e [J] grad / 2, grad = -w (nuts.cpp:108-135)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            pm[s] = pm[s] - (e * w[s]) / 2.0;
-            th[s] = th[s] + e * pm[s];
+            if constexpr (GENERAL) {
+                const int i = 4 * s + j4;
+                const double kw = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                pm[s] = pm[s] - (e * kw) / 2.0;
+            } else {
+                pm[s] = pm[s] - (e * w[s]) / 2.0;
+            }
         }
-        matvec_mfma<NT>(afrag, th, w);
+    };
+    auto drift = [&](double e) __attribute__((always_inline)) {        // theta += e Minv p
 #pragma unroll
-        for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (GENERAL) th[s] = th[s] + e * (lds_mi[4 * s + j4] * pm[s]);
+            else th[s] = th[s] + e * pm[s];
+        }
+    };
+    double xs[GENERAL ? NS : 1];                                       // setup phase: x of the register-resident theta
+    auto leapfrog = [&](double e) __attribute__((always_inline)) {
+        kick(e);
+        drift(e);
+        if constexpr (GENERAL) general_gradient(xs); else matvec_mfma<NT>(afrag, th, w);
+        kick(e);
+    };
+    // U = -box_log_kernel(theta) of the register-resident state whose x / P x are (xs_, w) (nuts.cpp:84-95)
+    auto potential_raw = [&](const double (&xs_)[GENERAL ? NS : 1]) __attribute__((always_inline)) -> double {
+        if constexpr (GENERAL) {
+            const double kval = -0.5 * dot4<NS>(xs_, w);
+            double lj = 0.0;                             // log_jacobian.hpp:36-57: scalar loop, i ascending
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int i0 = 4 * s;
+                const double term = box_log_jacobian_term(th[s], lds_bt[i0 + j4], lds_lb[i0 + j4], lds_ub[i0 + j4]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const double tg = __shfl(term, (lane & 15) + 16 * g);
+                    if ((uint32_t)(i0 + g) < d && lds_bt[i0 + g] != 1) lj = lj + tg;
+                }
+            }
+            return -(kval + lj);
+        } else {
+            return 0.5 * dot4<NS>(th, w);
+        }
     };
     auto potential = [&]() __attribute__((always_inline)) -> double {
-        double u = 0.5 * dot4<NS>(th, w);
+        double u = potential_raw(xs);
         if (!is_finite(u)) u = INF;
         return u;
     };
-    auto kinetic = [&]() __attribute__((always_inline)) -> double { return dot4<NS>(pm, pm) / 2.0; };
+    auto kinetic = [&]() __attribute__((always_inline)) -> double {    // K = p . (Minv p) / 2
+        if constexpr (GENERAL) {
+            double q = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j4] * pm[s], q);
+            q = q + __shfl_xor(q, 32);
+            q = q + __shfl_xor(q, 16);
+            return q / 2.0;
+        } else {
+            return dot4<NS>(pm, pm) / 2.0;
+        }
+    };
     // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1;
     // all four operands come from the level records in the workspace
     auto uturn_ok = [&](bool pred, int vt1, int vp1, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
@@ -162,12 +240,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     for (int s = 0; s < NS; ++s) {
         const uint32_t dimc = dim_ok(s) ? (uint32_t)(4 * s + j4) : 0u;
         const double v = prm.theta[(size_t)dimc * C + cld];
-        th[s] = dim_ok(s) ? v : 0.0;
+        if constexpr (GENERAL) th[s] = dim_ok(s) ? box_transform(v, lds_bt[dimc], lds_lb[dimc], lds_ub[dimc]) : 0.0;   // nuts.cpp:160-162
+        else th[s] = dim_ok(s) ? v : 0.0;
     }
-    matvec_mfma<NT>(afrag, th, w);
+    if constexpr (GENERAL) general_gradient(xs); else matvec_mfma<NT>(afrag, th, w);
     store_vec(V_PREV, th, true);
     store_vec(V_WPREV, w, true);
-    double prev_U = 0.5 * dot4<NS>(th, w);               // nuts.cpp:181
+    double prev_U = potential_raw(xs);                   // nuts.cpp:181
 
     uint64_t n_leap = 0;
     double eps;
@@ -178,6 +257,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
             pm[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+            if constexpr (GENERAL) {                     // L z with a diagonal L (nuts.cpp:170)
+                pm[2 * b] = lds_ms[8 * b + j4] * pm[2 * b];
+                pm[2 * b + 1] = lds_ms[8 * b + 4 + j4] * pm[2 * b + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         double U0 = prev_U;
@@ -259,8 +342,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                     for (int k = 0; k < CH; ++k) tmp[k] = *wsp(V_PREV, c0 + k);
 #pragma unroll
-                    for (int k = 0; k < CH; ++k)
+                    for (int k = 0; k < CH; ++k) {
+                        if constexpr (GENERAL) {             // the stored row goes through inv_transform (nuts.cpp:320-327)
+                            const int i = 4 * (c0 + k) + j4;
+                            if (dim_ok(c0 + k)) tmp[k] = box_inv_transform(tmp[k], lds_bt[i], lds_lb[i], lds_ub[i]);
+                        }
                         if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -291,10 +379,17 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
                 rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
-                const double pa = (8u * b + j4 < d) ? z0 : 0.0;
-                const double pb = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                kq = dfma(pa, pa, kq);
-                kq = dfma(pb, pb, kq);
+                double pa = (8u * b + j4 < d) ? z0 : 0.0;
+                double pb = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                if constexpr (GENERAL) {                      // p = L z, K = p . (Minv p) / 2
+                    pa = lds_ms[8 * b + j4] * pa;
+                    pb = lds_ms[8 * b + 4 + j4] * pb;
+                    kq = dfma(pa, lds_mi[8 * b + j4] * pa, kq);
+                    kq = dfma(pb, lds_mi[8 * b + 4 + j4] * pb, kq);
+                } else {
+                    kq = dfma(pa, pa, kq);
+                    kq = dfma(pb, pb, kq);
+                }
                 if (p && live) {                              // mntm_vec, mntm_pos, mntm_neg (:202, :214-215)
                     *wsp(V_MNTM, 2 * b) = pa;   *wsp(V_MNTM, 2 * b + 1) = pb;
                     *wsp(V_TPOS_P, 2 * b) = pa; *wsp(V_TPOS_P, 2 * b + 1) = pb;
@@ -346,18 +441,62 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             MI_PROF(1)
             n_ticks++; n_active += __popcll(__ballot(run)) / 4;
             // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
+            double xl[GENERAL ? NS : 1];
+            auto kick_l = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if constexpr (GENERAL) {
+                        const int i = 4 * s + j4;
+                        const double kw = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                        pm[s] = pm[s] - (e_signed * kw) / 2.0;
+                    } else {
+                        pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
+                    }
+                }
+            };
+            kick_l();
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
-                th[s] = th[s] + e_signed * pm[s];
+                if constexpr (GENERAL) th[s] = th[s] + e_signed * (lds_mi[4 * s + j4] * pm[s]);
+                else th[s] = th[s] + e_signed * pm[s];
             }
-            matvec_mfma<NT>(afrag, th, w);
+            if constexpr (GENERAL) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
+                for (int s = 0; s < NS; ++s) {
+                    const int i = 4 * s + j4;
+                    xl[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                }
+                matvec_mfma<NT>(afrag, xl, w);
+            } else {
+                matvec_mfma<NT>(afrag, th, w);
+            }
+            kick_l();
             MI_PROF(2)
-            pU = 0.5 * dot4<NS>(th, w);                  // nuts.ipp:134-138
+            if constexpr (GENERAL) {                     // nuts.ipp:134-140 with box_log_kernel and K = p.(Minv p)/2
+                const double kval = -0.5 * dot4<NS>(xl, w);
+                double lj = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int i0 = 4 * s;
+                    const double term = box_log_jacobian_term(th[s], lds_bt[i0 + j4], lds_lb[i0 + j4], lds_ub[i0 + j4]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double tg = __shfl(term, (lane & 15) + 16 * g);
+                        if ((uint32_t)(i0 + g) < d && lds_bt[i0 + g] != 1) lj = lj + tg;
+                    }
+                }
+                pU = -(kval + lj);
+                double q = 0.0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j4] * pm[s], q);
+                q = q + __shfl_xor(q, 32);
+                q = q + __shfl_xor(q, 16);
+                pK = q / 2.0;
+            } else {
+                pU = 0.5 * dot4<NS>(th, w);              // nuts.ipp:134-138
+                pK = dot4<NS>(pm, pm) / 2.0;             // :140
+            }
             if (!is_finite(pU)) pU = INF;
-            pK = dot4<NS>(pm, pm) / 2.0;                 // :140
             if (run && live) {                           // leaf record (every leaf: odd ones live in slot 1 for one tick)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -512,8 +651,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
         for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (GENERAL) {
+                const int i = 4 * s + j4;
+                if (dim_ok(s)) tmp[s] = box_inv_transform(tmp[s], lds_bt[i], lds_lb[i], lds_ub[i]);
+            }
             if (dim_ok(s)) prm.theta[(size_t)(4 * s) * C + lane_off] = tmp[s];
+        }
         if (j4 == 0) {
             if (prm.n_accept) prm.n_accept[cl] = n_acc;
             if (prm.n_leap) prm.n_leap[cl] = n_leap;

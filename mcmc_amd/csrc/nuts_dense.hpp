@@ -49,6 +49,12 @@ struct NutsParams {
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_adapt, max_depth;
     double delta, eps_bar0, gamma, t0, kappa;
+    // general variant of the asynchronous kernel (settings.vals_bound and / or a diagonal precond_mat), see nuts_async.hpp
+    const int* btype;
+    const double* lb;
+    const double* ub;
+    const double* m_sqrt;   // diagonal of CHOL_LOWER(precond_mat)
+    const double* m_inv;    // diagonal of INV(precond_mat)
 };
 
 enum : int {

@@ -78,3 +78,37 @@ def test_nuts_sharding_independence_and_statistics():
     assert abs(np.trace(cov) / np.trace(want) - 1) < 0.15
     assert (gf["depth"] <= 10).all() and gf["depth"].max() >= 2
     assert 0.3 < gf["n_accept"].mean() / 40 <= 1.0
+
+
+# ---------------------------------------------------------------- box constraints and diagonal precond_mat
+def _bounds(d, seed=0):
+    """A mix of the four bounds types of determine_bounds_type.hpp:27-57."""
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(1, 5, d)
+    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
+    ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+    return lb, ub
+
+
+@pytest.mark.parametrize("d,C,burn,keep,bounded,precond", [
+    (6, 16, 6, 10, True, False), (128, 32, 3, 4, True, False), (20, 24, 5, 8, False, True), (37, 20, 4, 6, True, True)])
+def test_general_nuts_bit_exact_vs_oracle(d, C, burn, keep, bounded, precond):
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    init = np.clip(synth.initial_states(C, d, seed=14) * 0.3, -1.0, 1.5)     # inside every box
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = _bounds(d, seed=d)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    if precond:
+        M = np.diag(1.0 / np.diag(prec) * np.linspace(0.5, 2.0, d))
+        kw.update(precond_mat=M); okw.update(precond=M)
+    st = mcmc_amd.default_settings(rng_seed_value=79, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn, max_tree_depth=6, **kw)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=4)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=79, n_burnin=burn, n_keep=keep, n_adapt=burn, max_depth=6, W=4, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=4)
+    assert np.array_equal(g["n_leap"], o["n_leap"])
+    assert np.array_equal(g["eps"], o["eps"])
+    assert np.array_equal(g_draws, o_draws)
+    if bounded:
+        assert ((g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])).all()   # reported in the constrained space

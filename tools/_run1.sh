@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_parity_mala.py -m gpu -x -q 2>&1 | tail -15
+timeout 600 python -m pytest tests/test_gpu_parity_nuts.py -m gpu -x -q 2>&1 | tail -15
