@@ -68,9 +68,10 @@ def lib():
     """Load libmi_mcmc.so (built in-tree by __graft_entry__.build() / mcmc_amd/csrc/Makefile)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise MiMcmcError(-1, f"{LIB_PATH} not built: run `make -C mcmc_amd/csrc` (no CPU fallback)")
-        _lib = C.CDLL(LIB_PATH)
+        path = os.environ.get("MI_MCMC_LIB", LIB_PATH)      # A/B builds of the same engine (tools/), never a fallback
+        if not os.path.exists(path):
+            raise MiMcmcError(-1, f"{path} not built: run `make -C mcmc_amd/csrc` (no CPU fallback)")
+        _lib = C.CDLL(path)
         _lib.mi_mcmc_last_error.restype = C.c_char_p
     return _lib
 
