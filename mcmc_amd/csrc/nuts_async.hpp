@@ -86,32 +86,51 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     // pair per (vector, slice) -- hundreds of VGPRs of loop invariants, spilled, and reloaded from scratch in front of every
     // load (a scratch reload waits behind every store in flight: vmcnt is in order).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    char* const ws_wave_u = reinterpret_cast<char*>(prm.ws + ((size_t)blockIdx.x * 4 + wave_u) * ((size_t)WS_NVEC * NS * 64));
-    uint32_t lane_b = (uint32_t)lane * 8u;      // redefined (opaquely) at the top of every tick: no address outlives a tick
+    char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * ((size_t)WS_NVEC * NS * 512);
+    // [wave][vector][lane][slice]: a lane's NS values of a vector are one contiguous 16-byte-aligned row, moved 16 bytes per
+    // instruction, and a lane that is masked off touches no cache line at all.  With [vector][slice][lane] every access moved
+    // whole 128-byte lines of 16 chains although only ~9 of a wave's 16 chains are inside a tree on an average tick
+    // (25 KB per chain-leaf for 13 KB of records): config 4 went from 3.75 s to 2.03 s on this change of layout alone.
+    uint32_t lane_b = (uint32_t)lane * (uint32_t)(NS * 8);   // redefined (opaquely) at the top of every tick
     auto wsp = [&](int v, int s) -> double* {
-        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)(v * NS + s) * 512u + lane_b));
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)s * 8u));
+    };
+    auto ld_row = [&](int v, int s0, auto& dst) __attribute__((always_inline)) {      // dst[0..N) <- slices s0.. of vector v
+        constexpr int N = (int)(sizeof(dst) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(wsp(v, s0 + k));
+            dst[k] = t.x; dst[k + 1] = t.y;
+        }
+    };
+    auto st_row = [&](int v, int s0, const auto& src) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(src) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) *reinterpret_cast<double2*>(wsp(v, s0 + k)) = double2{src[k], src[k + 1]};
+    };
+    auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
+        *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
     };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
 
     double th[NS], pm[NS], w[NS];
 
     auto load_vec = [&](int v, double (&x)[NS]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
+        ld_row(v, 0, x);
     };
     // x <- ws[v] for lanes with pred, unchanged otherwise (v may be any valid id on the other lanes)
     // ONE exec-masked region around the whole vector (idle lanes generate no memory traffic); never a
     // branch per element (that serialises the loads)
     auto load_vec_if = [&](int v, double (&x)[NS], bool pred) __attribute__((always_inline)) {
         if (pred) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) x[s] = *wsp(v, s);
+            ld_row(v, 0, x);
         }
     };
     auto store_vec = [&](int v, const double (&x)[NS], bool pred) __attribute__((always_inline)) {
         if (pred && live) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) *wsp(v, s) = x[s];
+            st_row(v, 0, x);
         }
     };
     // vector ops touch 8 slices at a time (16 VGPRs in flight): the register file is full of theta / p / P*theta
@@ -124,10 +143,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
             for (int c0 = 0; c0 < NS; c0 += CH) {
                 double tmp[CH];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) tmp[k] = *wsp(vsrc, c0 + k);
-#pragma unroll
-                for (int k = 0; k < CH; ++k) *wsp(vdst, c0 + k) = tmp[k];
+                ld_row(vsrc, c0, tmp);
+                st_row(vdst, c0, tmp);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -214,13 +231,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
             for (int c0 = 0; c0 < NS; c0 += CHU) {
                 double t1[CHU], p1[CHU], t2[CHU], p2[CHU];
-#pragma unroll
-                for (int k = 0; k < CHU; ++k) {
-                    t1[k] = *wsp(vt1, c0 + k);
-                    p1[k] = *wsp(vp1, c0 + k);
-                    t2[k] = *wsp(vt2, c0 + k);
-                    p2[k] = *wsp(vp2, c0 + k);
-                }
+                ld_row(vt1, c0, t1); ld_row(vp1, c0, p1); ld_row(vt2, c0, t2); ld_row(vp2, c0, p2);
 #pragma unroll
                 for (int k = 0; k < CHU; ++k) {
                     const double dd = (vdir > 0) ? (t2[k] - t1[k]) : (t1[k] - t2[k]);
@@ -339,8 +350,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                 for (int c0 = 0; c0 < NS; c0 += CH) {
                     double tmp[CH];
-#pragma unroll
-                    for (int k = 0; k < CH; ++k) tmp[k] = *wsp(V_PREV, c0 + k);
+                    ld_row(V_PREV, c0, tmp);
 #pragma unroll
                     for (int k = 0; k < CH; ++k) {
                         if constexpr (GENERAL) {             // the stored row goes through inv_transform (nuts.cpp:320-327)
@@ -391,9 +401,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                     kq = dfma(pb, pb, kq);
                 }
                 if (p && live) {                              // mntm_vec, mntm_pos, mntm_neg (:202, :214-215)
-                    *wsp(V_MNTM, 2 * b) = pa;   *wsp(V_MNTM, 2 * b + 1) = pb;
-                    *wsp(V_TPOS_P, 2 * b) = pa; *wsp(V_TPOS_P, 2 * b + 1) = pb;
-                    *wsp(V_TNEG_P, 2 * b) = pa; *wsp(V_TNEG_P, 2 * b + 1) = pb;
+                    st_pair(V_MNTM, 2 * b, pa, pb);
+                    st_pair(V_TPOS_P, 2 * b, pa, pb);
+                    st_pair(V_TNEG_P, 2 * b, pa, pb);
                 }
             }
             kq = kq + __shfl_xor(kq, 32);
@@ -434,8 +444,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 const int vp = (li == 0) ? V_MNTM : V_LEAF0 + 3 * sslot + 1;
                 const int vw = (li == 0) ? V_WPREV : V_LEAF0 + 3 * sslot + 2;
                 if (run) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { th[s] = *wsp(vt, s); pm[s] = *wsp(vp, s); w[s] = *wsp(vw, s); }
+                    ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w);
                 }
             }
             MI_PROF(1)
@@ -498,12 +507,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             }
             if (!is_finite(pU)) pU = INF;
             if (run && live) {                           // leaf record (every leaf: odd ones live in slot 1 for one tick)
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    *wsp(V_LEAF0 + 3 * slot_i, s) = th[s];
-                    *wsp(V_LEAF0 + 3 * slot_i + 1, s) = pm[s];
-                    *wsp(V_LEAF0 + 3 * slot_i + 2, s) = w[s];
-                }
+                st_row(V_LEAF0 + 3 * slot_i, 0, th); st_row(V_LEAF0 + 3 * slot_i + 1, 0, pm); st_row(V_LEAF0 + 3 * slot_i + 2, 0, w);
             }
             // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a
             // successful doubling leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw,
@@ -511,8 +515,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             const bool st_edge = run && live && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
             if (st_edge) {
                 const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { *wsp(et, s) = th[s]; *wsp(ep, s) = pm[s]; }
+                st_row(et, 0, th); st_row(ep, 0, pm);
             }
         }
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
@@ -594,10 +597,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                     for (int c0 = 0; c0 < NS; c0 += CHC) {
                         double t1[CHC], t2[CHC];
-#pragma unroll
-                        for (int k = 0; k < CHC; ++k) { t1[k] = *wsp(cref_t, c0 + k); t2[k] = *wsp(cref_w, c0 + k); }
-#pragma unroll
-                        for (int k = 0; k < CHC; ++k) { *wsp(dst_t, c0 + k) = t1[k]; *wsp(dst_w, c0 + k) = t2[k]; }
+                        ld_row(cref_t, c0, t1); ld_row(cref_w, c0, t2);
+                        st_row(dst_t, c0, t1); st_row(dst_w, c0, t2);
                         if (CHC < NS) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -614,11 +615,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                     for (int c0 = 0; c0 < NS; c0 += CHF) {
                         double tp[CHF], tn[CHF], pp[CHF], pn[CHF];
-#pragma unroll
-                        for (int k = 0; k < CHF; ++k) {
-                            tp[k] = *wsp(V_TPOS_T, c0 + k); tn[k] = *wsp(V_TNEG_T, c0 + k);
-                            pp[k] = *wsp(V_TPOS_P, c0 + k); pn[k] = *wsp(V_TNEG_P, c0 + k);
-                        }
+                        ld_row(V_TPOS_T, c0, tp); ld_row(V_TNEG_T, c0, tn); ld_row(V_TPOS_P, c0, pp); ld_row(V_TNEG_P, c0, pn);
 #pragma unroll
                         for (int k = 0; k < CHF; ++k) {
                             const double df = tp[k] - tn[k];
@@ -648,8 +645,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 
     if (live) {
         double tmp[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) tmp[s] = *wsp(V_PREV, s);
+        ld_row(V_PREV, 0, tmp);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if constexpr (GENERAL) {
