@@ -28,9 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= vector) peak; not in the in-image guide
 # HBM bytes per launch of the default workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-# command (profiles/r1_hmc_pmc.json): (18.6 + 34.2) GB. Not re-measured here (counters cannot be read in-process);
+# command (profiles/r1_hmc_pmc.json): (2.3 + 34.0) GB. Not re-measured here (counters cannot be read in-process);
 # reported only for the exact profiled configuration, null otherwise.  FETCH_SIZE is uncorrected (8-B-per-lane loads).
-PROFILED_TRAFFIC_BYTES = {(65536, 128, 16, 100, 100): 5.28e10}
+PROFILED_TRAFFIC_BYTES = {(65536, 128, 16, 100, 100): 3.64e10}
 
 WORKLOAD = dict(d=128, chains_per_gpu=65536, n_leap_steps=16, step_size=0.05,
                 n_burnin_draws=100, n_keep_draws=100, seed=2024)
