@@ -784,7 +784,7 @@ static void nuts_build_tree(orc_ctx* c, int direction_val, double step_size, dou
         memcpy(new_mntm_pos, new_mntm, nb);
         memcpy(new_mntm_neg, new_mntm, nb);
         const double dd = -(prop_U + prop_K) + (prev_U + prev_K);
-        *alpha_val = orc_exp((0.0 < dd) ? 0.0 : dd);                    /* std::min(0, dd) :157 */
+        *alpha_val = orc_exp((dd < 0.0) ? dd : 0.0);                    /* std::min(0, dd) = (dd < 0) ? dd : 0, so NaN -> 0 :157 */
         *n_alpha_val = 1;
         free(new_mntm);
     } else {

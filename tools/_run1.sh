@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 300 python tools/_repro.py 2>&1 | tail -25
+timeout 900 python tools/fuzz_parity.py 150 11 2>&1 | grep -v "^ok" | tail -30

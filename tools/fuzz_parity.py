@@ -68,13 +68,16 @@ for case in range(n_cases):
         fl, fu = np.isfinite(lbv), np.isfinite(ubv)
         img = np.where(fl & fu, (ubv - lbv) / 2, np.where(fl, lbv + 2.220446049250313e-16, np.where(fu, ubv - 2.220446049250313e-16, np.nan)))
         badc = sorted(set(np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))[:, 2].tolist()))
-        poisoned = all(np.array_equal(o_draws[-1, :, c], img, equal_nan=True) for c in badc)
+        poisoned = len(badc) > 0 and all(np.array_equal(o_draws[-1, :, c], img, equal_nan=True) for c in badc)
         if poisoned:
             print("NONFINITE-REGIME", desc, "chains", badc); continue
     if not ok:
         fails += 1
         bad = np.argwhere(~np.isclose(g_draws, o_draws, rtol=0, atol=0, equal_nan=True))
-        print("MISMATCH", desc, "first bad index", bad[:1].tolist(), "max abs diff", np.nanmax(np.abs(g_draws - o_draws)))
+        fields = [k for k in ("n_accept", "n_leap", "eps") if k in o and not np.array_equal(g[k], o[k], equal_nan=True)]
+        print("MISMATCH", desc, "first bad index", bad[:1].tolist(), "fields", fields,
+              {k: [(int(i), float(g[k][i]), float(o[k][i])) for i in np.flatnonzero(~((g[k] == o[k]) | (np.isnan(g[k].astype(float)) & np.isnan(o[k].astype(float)))))[:4]] for k in fields},
+              'n_leap', [(int(g['n_leap'][i]), int(o['n_leap'][i])) for i in np.flatnonzero(g['eps'] != o['eps'])[:4]] if 'eps' in fields else '')
     else:
         print("ok      ", desc)
 print(f"{n_cases} cases, {fails} mismatches")
