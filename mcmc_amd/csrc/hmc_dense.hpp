@@ -41,6 +41,7 @@ struct HmcParams {
     uint64_t chain0;        // global id of local chain 0
     double* theta;          // [d][C] in/out: always the last accepted state
     double* wsave;          // [n_waves][2][NS][64] workspace: last accepted theta and P*theta
+    int vals_bound;         // general variant: settings.vals_bound (0: only a diagonal precond_mat)
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -65,6 +66,27 @@ __device__ __forceinline__ double dot4(const double (&x)[NS], const double (&y)[
     q = q + __shfl_xor(q, 32);
     q = q + __shfl_xor(q, 16);
     return q;
+}
+
+// The reference multiplies by its (identity / diagonal) matrices as DENSE products (inv_precond_matrix * mntm, hmc.cpp:171;
+// jacob_matrix * grad_obj, :122), and the oracle restates them as dense fma chains: one entry x_k = +-inf or NaN makes
+// 0 * x_k = NaN in every OTHER row.  The kernels apply the diagonal element-wise (y_i = D_ii x_i) and then call this to
+// reproduce that poisoning: y_i = NaN wherever another dimension of the same chain is non-finite.  n_valid = d (padding
+// dimensions are never touched).  The common path is one is_finite per slice, two shuffles and a ballot.
+template <int NS>
+__device__ __forceinline__ void dense_product_poison(const double (&x)[NS], double (&y)[NS], int j, uint32_t d)
+{
+    int nloc = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) nloc += is_finite(x[s]) ? 0 : 1;
+    int n = nloc + __shfl_xor(nloc, 16);
+    n = n + __shfl_xor(n, 32);
+    if (__ballot(n != 0) == 0ull) return;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int others = n - (is_finite(x[s]) ? 0 : 1);
+        if (others > 0 && (uint32_t)(4 * s + j) < d) y[s] = __builtin_nan("");
+    }
 }
 
 // w = P * th for the wave's 16 chains. afrag points at this lane's column of the LDS fragments.
@@ -257,14 +279,19 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                 const int i = 4 * s + j;
                 kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];   // J_ii * grad_i (gemv with a diagonal J)
             }
+            if (prm.vals_bound) dense_product_poison<NS>(w, kw, j, d);   // jacob_matrix * grad_obj is a dense product (:122)
         }
     };
     // K = p . (Minv p) / 2 (hmc.cpp:160,184)
     auto kinetic = [&]() __attribute__((always_inline)) -> double {
         if constexpr (BOUNDED) {
+            double mp[NS];                               // inv_precond_matrix * mntm, a dense product
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
+            dense_product_poison<NS>(pm, mp, j, d);
             double q = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j] * pm[s], q);
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
             q = q + __shfl_xor(q, 32);
             q = q + __shfl_xor(q, 16);
             return q / 2.0;
@@ -359,12 +386,22 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
 #pragma unroll 1
         for (uint32_t k = 0; k < prm.n_leap_steps; ++k) {   // hmc.cpp:164-176, grad = -w
             if ((prm.ablate & 3u) != 1u) {
+            if constexpr (BOUNDED) {
+                double mp[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double gw = BOUNDED ? kw[BOUNDED ? s : 0] : w[s];
-                pm[s] = pm[s] - (eps * gw) / 2.0;       // first half-step (:167,126 / :122)
-                if constexpr (BOUNDED) th[s] = th[s] + eps * (lds_mi[4 * s + j] * pm[s]);   // theta += eps * Minv p (:171)
-                else th[s] = th[s] + eps * pm[s];
+                for (int s = 0; s < NS; ++s) {
+                    pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;       // first half-step (:122)
+                    mp[s] = lds_mi[4 * s + j] * pm[s];
+                }
+                dense_product_poison<NS>(pm, mp, j, d);                     // inv_precond_matrix * new_mntm (:171)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * mp[s];  // theta += eps * Minv p (:171)
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    pm[s] = pm[s] - (eps * w[s]) / 2.0;                     // first half-step (:167,126)
+                    th[s] = th[s] + eps * pm[s];
+                }
             }
             }
             if ((prm.ablate & 3u) != 2u) gradient();

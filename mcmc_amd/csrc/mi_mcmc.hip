@@ -461,6 +461,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         HIP_TRY(hipMemcpy(mi_dev.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
         prm.btype = bt_dev.as<int>(); prm.lb = lb_dev.as<double>(); prm.ub = ub_dev.as<double>();
         prm.m_sqrt = ms_dev.as<double>(); prm.m_inv = mi_dev.as<double>();
+        prm.vals_bound = settings->vals_bound ? 1 : 0;
         if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
         else if (nt == 2) rc = launch_hmc_mfma_bounded<2>(prm, st);
         else if (nt <= 4) rc = launch_hmc_mfma_bounded<4>(prm, st);
@@ -652,6 +653,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (gt.active) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
+        prm.vals_bound = settings->vals_bound ? 1 : 0;
         if (nt <= 1) rc = launch_nuts_mfma<1, true>(prm, st);
         else if (nt == 2) rc = launch_nuts_mfma<2, true>(prm, st);
         else if (nt <= 4) rc = launch_nuts_mfma<4, true>(prm, st);

@@ -161,22 +161,32 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         }
     };
     auto kick = [&](double e) __attribute__((always_inline)) {         // p += e [J] grad / 2, grad = -w (nuts.cpp:108-135)
+        if constexpr (GENERAL) {
+            double kw[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if constexpr (GENERAL) {
+            for (int s = 0; s < NS; ++s) {
                 const int i = 4 * s + j4;
-                const double kw = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
-                pm[s] = pm[s] - (e * kw) / 2.0;
-            } else {
-                pm[s] = pm[s] - (e * w[s]) / 2.0;
+                kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
             }
+            if (prm.vals_bound) dense_product_poison<NS>(w, kw, j4, d);   // jacob_matrix * grad_obj is a dense product
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * kw[s]) / 2.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
         }
     };
-    auto drift = [&](double e) __attribute__((always_inline)) {        // theta += e Minv p
+    auto drift = [&](double e) __attribute__((always_inline)) {        // theta += e Minv p (a dense product in the reference)
+        if constexpr (GENERAL) {
+            double mp[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if constexpr (GENERAL) th[s] = th[s] + e * (lds_mi[4 * s + j4] * pm[s]);
-            else th[s] = th[s] + e * pm[s];
+            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+            dense_product_poison<NS>(pm, mp, j4, d);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * mp[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
         }
     };
     double xs[GENERAL ? NS : 1];                                       // setup phase: x of the register-resident theta
@@ -213,9 +223,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     };
     auto kinetic = [&]() __attribute__((always_inline)) -> double {    // K = p . (Minv p) / 2
         if constexpr (GENERAL) {
+            double mp[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+            dense_product_poison<NS>(pm, mp, j4, d);
             double q = 0.0;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j4] * pm[s], q);
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
             q = q + __shfl_xor(q, 32);
             q = q + __shfl_xor(q, 16);
             return q / 2.0;
@@ -452,22 +466,32 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
             double xl[GENERAL ? NS : 1];
             auto kick_l = [&]() __attribute__((always_inline)) {
+                if constexpr (GENERAL) {
+                    double kw[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if constexpr (GENERAL) {
+                    for (int s = 0; s < NS; ++s) {
                         const int i = 4 * s + j4;
-                        const double kw = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
-                        pm[s] = pm[s] - (e_signed * kw) / 2.0;
-                    } else {
-                        pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
+                        kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
                     }
+                    if (prm.vals_bound) dense_product_poison<NS>(w, kw, j4, d);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_signed * kw[s]) / 2.0;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
                 }
             };
             kick_l();
+            if constexpr (GENERAL) {
+                double mp[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if constexpr (GENERAL) th[s] = th[s] + e_signed * (lds_mi[4 * s + j4] * pm[s]);
-                else th[s] = th[s] + e_signed * pm[s];
+                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                dense_product_poison<NS>(pm, mp, j4, d);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + e_signed * mp[s];
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + e_signed * pm[s];
             }
             if constexpr (GENERAL) {
 #pragma unroll
@@ -495,9 +519,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                     }
                 }
                 pU = -(kval + lj);
+                double mp[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                dense_product_poison<NS>(pm, mp, j4, d);
                 double q = 0.0;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) q = dfma(pm[s], lds_mi[4 * s + j4] * pm[s], q);
+                for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
                 q = q + __shfl_xor(q, 32);
                 q = q + __shfl_xor(q, 16);
                 pK = q / 2.0;
