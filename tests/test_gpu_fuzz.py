@@ -1,0 +1,15 @@
+"""GPU: randomised parity sweep (tools/fuzz_parity.py) -- every device sampler against the oracle on random small cases:
+three samplers x four targets x bounds / diagonal precond / degenerate sizes / step sizes that blow the chain up."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+
+
+@pytest.mark.parametrize("seed", [7, 11])
+def test_random_cases_are_bit_exact(seed):
+    import fuzz_parity
+    assert fuzz_parity.sweep(60, seed, verbose=False) == 0

@@ -7,78 +7,86 @@ import numpy as np
 import mcmc_amd, orc
 from mcmc_amd import synth
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-fails = 0
 
 
-def bounds(d):
-    kind = rng.integers(1, 5, d)
-    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
-    ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
-    return lb, ub
+def sweep(n_cases=60, seed=1, verbose=True):
+    """Returns the number of mismatching cases."""
+    rng = np.random.default_rng(seed)
+    fails = 0
+    say = print if verbose else (lambda *a, **k: None)
+    def bounds(d):
+        kind = rng.integers(1, 5, d)
+        lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
+        ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+        return lb, ub
 
 
-for case in range(n_cases):
-    algo = ["hmc", "mala", "nuts"][case % 3]
-    tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo != "nuts" else ["dense", "iso", "diag"])
-    d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 128])) if tgt != "logit" else int(rng.choice([3, 17, 64, 65, 130, 300]))
-    C = int(rng.choice([1, 3, 16, 17, 33, 70]))
-    seed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
-    burn, keep = int(rng.integers(0, 4)), int(rng.integers(1, 7))
-    eps = float(rng.choice([0.01, 0.05, 0.2, 0.7, 1.5]))
-    L = int(rng.integers(0, 6))
-    general = tgt != "logit" and rng.random() < 0.4
-    kw, okw = {}, {}
-    prec = X = y = None
-    if tgt == "dense": prec, kg, ko = synth.dense_gaussian_precision(d, seed=seed % 97), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
-    elif tgt == "diag": prec, kg, ko = synth.ill_conditioned_diag(d, 20.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
-    elif tgt == "iso": kg, ko = mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
-    else:
-        N = int(rng.choice([1, 15, 16, 40, 100])); X, y = synth.logistic_problem(d, N, seed=seed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
-    scale = float(rng.choice([0.1, 1.0, 3.0]))
-    init = synth.initial_states(C, d, seed=seed % 1013) * scale
-    if general:
-        if rng.random() < 0.7:
-            lb, ub = bounds(d); kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
-            init = np.clip(init, -1.0, 1.5)
-        if rng.random() < 0.6 or not kw:
-            M = np.diag(rng.uniform(0.3, 3.0, d)); kw.update(precond_mat=M); okw.update(precond=M)
-    tkw = {}
-    if tgt == "logit":
-        dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
-        tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
-    st = mcmc_amd.default_settings(rng_seed_value=seed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps,
-                                   n_adapt_draws=burn, max_tree_depth=int(rng.integers(0, 7)), **kw)
-    t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
-    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, n_adapt=burn, max_depth=int(st.max_tree_depth), W=4, hoist=1, **okw)
-    desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} general={sorted(kw)} depth={int(st.max_tree_depth)}"
-    try:
-        g_draws, g = mcmc_amd.sample(algo, kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
-    except mcmc_amd.MiMcmcError as e:
-        print("REFUSED", desc, "->", str(e)[:90]); continue
-    o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS}[algo], t, init, s, chain0=chain0)
-    ok = np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
-    if algo == "nuts": ok = ok and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
-    if not ok and algo == "mala" and (kw.get("vals_bound") or np.isnan(o_draws).any()):
-        # the reference's dense `inv_precond * mntm` / `J * grad` products turn 0 * inf into NaN for every other dimension;
-        # the device keeps dimensions separate ("non-finite regime").  Such a chain's oracle rows are the
-        # image of NaN: NaN (no bound), lb+eps / ub-eps (one bound), (ub-lb)/2 (two bounds).
-        lbv = kw.get("lower_bounds", np.full(d, -np.inf)); ubv = kw.get("upper_bounds", np.full(d, np.inf))
-        fl, fu = np.isfinite(lbv), np.isfinite(ubv)
-        img = np.where(fl & fu, (ubv - lbv) / 2, np.where(fl, lbv + 2.220446049250313e-16, np.where(fu, ubv - 2.220446049250313e-16, np.nan)))
-        badc = sorted(set(np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))[:, 2].tolist()))
-        poisoned = len(badc) > 0 and all(np.array_equal(o_draws[-1, :, c], img, equal_nan=True) for c in badc)
-        if poisoned:
-            print("NONFINITE-REGIME", desc, "chains", badc); continue
-    if not ok:
-        fails += 1
-        bad = np.argwhere(~np.isclose(g_draws, o_draws, rtol=0, atol=0, equal_nan=True))
-        fields = [k for k in ("n_accept", "n_leap", "eps") if k in o and not np.array_equal(g[k], o[k], equal_nan=True)]
-        print("MISMATCH", desc, "first bad index", bad[:1].tolist(), "fields", fields,
-              {k: [(int(i), float(g[k][i]), float(o[k][i])) for i in np.flatnonzero(~((g[k] == o[k]) | (np.isnan(g[k].astype(float)) & np.isnan(o[k].astype(float)))))[:4]] for k in fields},
-              'n_leap', [(int(g['n_leap'][i]), int(o['n_leap'][i])) for i in np.flatnonzero(g['eps'] != o['eps'])[:4]] if 'eps' in fields else '')
-    else:
-        print("ok      ", desc)
-print(f"{n_cases} cases, {fails} mismatches")
-sys.exit(1 if fails else 0)
+    for case in range(n_cases):
+        algo = ["hmc", "mala", "nuts"][case % 3]
+        tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo != "nuts" else ["dense", "iso", "diag"])
+        d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 128])) if tgt != "logit" else int(rng.choice([3, 17, 64, 65, 130, 300]))
+        C = int(rng.choice([1, 3, 16, 17, 33, 70]))
+        rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
+        burn, keep = int(rng.integers(0, 4)), int(rng.integers(1, 7))
+        eps = float(rng.choice([0.01, 0.05, 0.2, 0.7, 1.5]))
+        L = int(rng.integers(0, 6))
+        general = tgt != "logit" and rng.random() < 0.4
+        kw, okw = {}, {}
+        prec = X = y = None
+        if tgt == "dense": prec, kg, ko = synth.dense_gaussian_precision(d, seed=rseed % 97), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+        elif tgt == "diag": prec, kg, ko = synth.ill_conditioned_diag(d, 20.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+        elif tgt == "iso": kg, ko = mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+        else:
+            N = int(rng.choice([1, 15, 16, 40, 100])); X, y = synth.logistic_problem(d, N, seed=rseed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
+        scale = float(rng.choice([0.1, 1.0, 3.0]))
+        init = synth.initial_states(C, d, seed=rseed % 1013) * scale
+        if general:
+            if rng.random() < 0.7:
+                lb, ub = bounds(d); kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+                init = np.clip(init, -1.0, 1.5)
+            if rng.random() < 0.6 or not kw:
+                M = np.diag(rng.uniform(0.3, 3.0, d)); kw.update(precond_mat=M); okw.update(precond=M)
+        tkw = {}
+        if tgt == "logit":
+            dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+            tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
+        st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps,
+                                       n_adapt_draws=burn, max_tree_depth=int(rng.integers(0, 7)), **kw)
+        t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
+        s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, n_adapt=burn, max_depth=int(st.max_tree_depth), W=4, hoist=1, **okw)
+        desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} general={sorted(kw)} depth={int(st.max_tree_depth)}"
+        try:
+            g_draws, g = mcmc_amd.sample(algo, kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
+        except mcmc_amd.MiMcmcError as e:
+            say("REFUSED", desc, "->", str(e)[:90]); continue
+        o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS}[algo], t, init, s, chain0=chain0)
+        ok = np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
+        if algo == "nuts": ok = ok and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+        if not ok and algo == "mala" and (kw.get("vals_bound") or np.isnan(o_draws).any()):
+            # the reference's dense `inv_precond * mntm` / `J * grad` products turn 0 * inf into NaN for every other dimension;
+            # the device keeps dimensions separate (DESIGN.md section 3, "non-finite regime").  Such a chain's oracle rows are the
+            # image of NaN: NaN (no bound), lb+eps / ub-eps (one bound), (ub-lb)/2 (two bounds).
+            lbv = kw.get("lower_bounds", np.full(d, -np.inf)); ubv = kw.get("upper_bounds", np.full(d, np.inf))
+            fl, fu = np.isfinite(lbv), np.isfinite(ubv)
+            img = np.where(fl & fu, (ubv - lbv) / 2, np.where(fl, lbv + 2.220446049250313e-16, np.where(fu, ubv - 2.220446049250313e-16, np.nan)))
+            badc = sorted(set(np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))[:, 2].tolist()))
+            poisoned = len(badc) > 0 and all(np.array_equal(o_draws[-1, :, c], img, equal_nan=True) for c in badc)
+            if poisoned:
+                say("NONFINITE-REGIME", desc, "chains", badc); continue
+        if not ok:
+            fails += 1
+            bad = np.argwhere(~np.isclose(g_draws, o_draws, rtol=0, atol=0, equal_nan=True))
+            fields = [k for k in ("n_accept", "n_leap", "eps") if k in o and not np.array_equal(g[k], o[k], equal_nan=True)]
+            say("MISMATCH", desc, "first bad index", bad[:1].tolist(), "fields", fields,
+                  {k: [(int(i), float(g[k][i]), float(o[k][i])) for i in np.flatnonzero(~((g[k] == o[k]) | (np.isnan(g[k].astype(float)) & np.isnan(o[k].astype(float)))))[:4]] for k in fields},
+                  'n_leap', [(int(g['n_leap'][i]), int(o['n_leap'][i])) for i in np.flatnonzero(g['eps'] != o['eps'])[:4]] if 'eps' in fields else '')
+        else:
+            say("ok      ", desc)
+    return fails
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    f = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n} cases, {f} mismatches")
+    sys.exit(1 if f else 0)
