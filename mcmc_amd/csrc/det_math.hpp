@@ -202,9 +202,9 @@ MI_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = u32x4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        // one 32x32->64 product per multiplier (a single v_mad_u64_u32 on the device) instead of a mul_hi and a mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        c = u32x4{(uint32_t)(p1 >> 32) ^ c.y ^ k0, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k1, (uint32_t)p0};
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

@@ -1,3 +1,2 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -3
-timeout 300 python tools/fuzz_parity.py 30 5 | tail -3
+for sk in 0 1; do timeout 120 tools/bin/lb_sk$sk 65536 20 0; timeout 120 tools/bin/lb_sk$sk 65536 5 1 4; done
