@@ -53,7 +53,7 @@ def cpu_baseline(cfg, prec):
     import orc   # tests/orc.py: ctypes binding of oracle/liboracle.so
     from mcmc_amd import synth
     cores = usable_cores()
-    n_chains = 8 * cores
+    n_chains = 128 * cores      # ~10 s of CPU work on the box's 16 granted cores (0.09 s per chain of this workload)
     d = cfg["d"]
     init = synth.initial_states(n_chains, d, seed=3)
     tgt = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
