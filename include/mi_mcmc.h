@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000100
+#define MI_MCMC_VERSION 0x000101
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -99,6 +99,11 @@ typedef struct mi_chains {
     double*   step_size;      /* nuts out [C]: adapted step size per chain, may be NULL */
     uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain, may be NULL */
     uint32_t* nuts_depth;     /* nuts out [n_burnin+n_keep][C]: tree depth reached per draw, may be NULL */
+    uint64_t  draw0;          /* index of this call's first draw in every chain's random stream: 0 for a fresh run; the
+                               * n_burnin+n_keep of the call(s) before to CONTINUE them from their final theta -- the
+                               * concatenation is then bit-identical to one long run (checkpoint / resume, chunked output).
+                               * nuts: a continuation must start after the adaptation window (draw0 >= n_adapt_draws) and
+                               * takes the adapted step sizes back in through step_size. */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);

@@ -45,7 +45,7 @@ class mi_chains(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mem", C.c_int32), ("n_chains", C.c_uint64),
                 ("chain0", C.c_uint64), ("theta", C.c_void_p), ("draws", C.c_void_p),
                 ("n_accept", C.c_void_p), ("step_size", C.c_void_p), ("n_leapfrogs", C.c_void_p),
-                ("nuts_depth", C.c_void_p)]
+                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64)]
 
 
 class MiMcmcError(RuntimeError):
@@ -125,10 +125,10 @@ def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST):
 
 
 def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=None, n_leapfrogs=None,
-                nuts_depth=None, mem=MEM_HOST):
+                nuts_depth=None, mem=MEM_HOST, draw0=0):
     c = mi_chains()
     c.struct_size = C.sizeof(mi_chains)
-    c.mem, c.n_chains, c.chain0 = mem, int(n_chains), int(chain0)
+    c.mem, c.n_chains, c.chain0, c.draw0 = mem, int(n_chains), int(chain0), int(draw0)
     c.theta, c.draws, c.n_accept = _ptr(theta), _ptr(draws), _ptr(n_accept)
     c.step_size, c.n_leapfrogs, c.nuts_depth = _ptr(step_size), _ptr(n_leapfrogs), _ptr(nuts_depth)
     c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth]
@@ -144,7 +144,7 @@ def run(algo, target, settings, chains, stream=None):
     _check(fn(C.byref(target), C.byref(settings), C.byref(chains), C.c_void_p(stream or 0)))
 
 
-def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True):
+def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0, step_size_in=None):
     """Host-buffer convenience: init is [C, d] (row per chain, like C calls of mcmc::<algo> with
     initial_vals = init[c]).  Returns draws [n_keep, d, C] and a dict of per-chain outputs."""
     init = np.ascontiguousarray(init, dtype=np.float64)
@@ -154,12 +154,12 @@ def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want
     draws = np.zeros((n_keep, d, n_chains)) if want_draws else None
     n_accept = np.zeros(n_chains, dtype=np.uint64)
     n_leap = np.zeros(n_chains, dtype=np.uint64)
-    eps = np.zeros(n_chains)
+    eps = np.zeros(n_chains) if step_size_in is None else np.array(step_size_in, dtype=np.float64, copy=True)
     n_tot = int(settings.n_burnin_draws) + n_keep
     depth = np.zeros((n_tot, n_chains), dtype=np.uint32) if algo == "nuts" else None
     t = make_target(kind, d, prec=prec, X=X, y=y)
     c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept,
-                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth)
+                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0)
     run(algo, t, settings, c)
     return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth)
 

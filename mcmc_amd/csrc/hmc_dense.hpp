@@ -42,6 +42,7 @@ struct HmcParams {
     double* theta;          // [d][C] in/out: always the last accepted state
     double* wsave;          // [n_waves][2][NS][64] workspace: last accepted theta and P*theta
     int vals_bound;         // general variant: settings.vals_bound (0: only a diagonal precond_mat)
+    uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -354,7 +355,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
             if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
-            else rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            else rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             *z_mem(2 * b) = (8u * b + j < d) ? z0 : 0.0;
             *z_mem(2 * b + 1) = (8u * b + 4 + j < d) ? z1 : 0.0;
         }
@@ -370,7 +371,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
             if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
-            else rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            else rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
             if constexpr (BOUNDED) {                    // p = L z with a diagonal L (:158)
@@ -421,7 +422,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         const double prop_K = kinetic();                // :184
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;  // std::min(0.01, x), :188
-        const double z = rng_uniform(prm.seed, chain, draw, 0u);   // :189
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);   // :189
         const bool accept = z < det_exp(comp_val);      // :191
         if (accept) {                                   // prev_draw = new_draw (:192-194)
             prev_U = prop_U;

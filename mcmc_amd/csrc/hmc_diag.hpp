@@ -32,6 +32,7 @@ struct HmcDiagParams {
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_leap_steps;
     double eps;
+    uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
 };
 
 __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
         for (uint32_t b = 0; b * 8 < d; ++b) {
             double z[8], th[8], pm[8], lam[8], w[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rng_normal_pair(prm.seed, chain, draw, 4 * b + j, STREAM_NORMAL, z[j], z[4 + j]);
+            for (int j = 0; j < 4; ++j) rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * b + j, STREAM_NORMAL, z[j], z[4 + j]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uint32_t i = 8 * b + r;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
         const double prop_K = ((qk1[0] + qk1[2]) + (qk1[1] + qk1[3])) / 2.0;   // :184
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;
-        const double zu = rng_uniform(prm.seed, chain, draw, 0u);
+        const double zu = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
         const bool accept = zu < det_exp(comp_val);
         if (accept) {
             cur = dst;

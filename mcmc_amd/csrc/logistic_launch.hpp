@@ -20,6 +20,7 @@ struct LogitParams {
     uint64_t* n_accept;
     uint64_t seed;
     uint32_t n_burnin, n_keep, n_leap;
+    uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     double eps, s2, rs, cons_term, log_det;
 };
 

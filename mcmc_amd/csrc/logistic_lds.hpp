@@ -378,7 +378,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                         const int mm = s0 / 2 + m;
                         double z0, z1;
                         const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * mm + j4);
-                        if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
+                        if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
                         const double za = (dim_of(2 * mm) < d) ? z0 : 0.0;
                         const double zb = (dim_of(2 * mm + 1) < d) ? z1 : 0.0;
                         bp[2 * mm] = (be_c[2 * m] + (s2 * gr_c[2 * m]) / 2.0) + eps * za;           // :123, :159
@@ -432,7 +432,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             const double db = prm.cons_term - 0.5 * (prm.log_det + qv[1]);
             const double x = pl - prev_LP + (da - db);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
-            const double z = rng_uniform(prm.seed, chain, draw, 0u);             // :171
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :171
             const bool accept = z < det_exp(comp_val);                           // :173
             if (accept) {
                 prev_LP = pl;
@@ -467,7 +467,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             for (int m = 0; m < NSQ / 2; ++m) {          // momentum ~ N(0, I), :156-158
                 double z0, z1;
                 const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
-                if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
+                if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
                 pm[2 * m] = (dim_of(2 * m) < d) ? z0 : 0.0;
                 pm[2 * m + 1] = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
                 __builtin_amdgcn_sched_barrier(0);
@@ -492,7 +492,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             if (!is_finite(prop_U)) prop_U = INF;        // :180-182
             const double x = -(prop_U + prop_K) + (prev_U + prev_K);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // :188
-            const double z = rng_uniform(prm.seed, chain, draw, 0u);             // :189
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :189
             const bool accept = z < det_exp(comp_val);                           // :191
             if (accept) {
                 prev_U = prop_U;

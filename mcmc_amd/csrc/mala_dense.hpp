@@ -35,6 +35,7 @@ struct MalaParams {
     uint64_t seed;
     uint32_t n_burnin, n_keep;
     double eps;             // step_size
+    uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     double s2;              // eps*eps (mala.cpp:123, mala.ipp:41)
     double rs;              // 1.0 / s2: diagonal of INV(eps^2 I)
     double cons_term;       // -0.5 * d * log(2 pi)   (dmvnorm.hpp:36)
@@ -154,7 +155,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             const double za = (8u * b + j < d) ? z0 : 0.0;
             const double zb = (8u * b + 4 + j < d) ? z1 : 0.0;
             double jma, jmb;
@@ -225,7 +226,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
         const double db = prm.cons_term - 0.5 * (log_det + qb);
         const double x = prop_LP - prev_LP + (da - db);
         const double comp_val = (x < 0.01) ? x : 0.01;   // std::min(0.01, x), mala.cpp:170
-        const double z = rng_uniform(prm.seed, chain, draw, 0u);          // :171
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);          // :171
         const bool accept = z < det_exp(comp_val);       // :173
         if (accept) {
 #pragma unroll

@@ -89,6 +89,7 @@ int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
         return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
     if (t->d == 0 || c->n_chains == 0) return fail(MI_ERR_BAD_ARG, "d and n_chains must be positive");
     if (!c->theta) return fail(MI_ERR_BAD_ARG, "chains.theta is required");
+    if (c->draw0 + s->n_burnin_draws + s->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw0 + draws exceeds the 32-bit draw counter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
@@ -142,7 +143,10 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
     sc.dev.theta = sc.theta.as<double>();
     if (c->draws) { HIP_TRY(sc.draws.alloc(n_keep * d * C * sizeof(double))); sc.dev.draws = sc.draws.as<double>(); }
     if (c->n_accept) { HIP_TRY(sc.n_accept.alloc(C * sizeof(uint64_t))); sc.dev.n_accept = sc.n_accept.as<uint64_t>(); }
-    if (c->step_size) { HIP_TRY(sc.step.alloc(C * sizeof(double))); sc.dev.step_size = sc.step.as<double>(); }
+    if (c->step_size) {
+        HIP_TRY(sc.step.alloc(C * sizeof(double))); sc.dev.step_size = sc.step.as<double>();
+        if (c->draw0 > 0) HIP_TRY(hipMemcpyAsync(sc.step.p, c->step_size, C * sizeof(double), hipMemcpyHostToDevice, st));   // nuts continuation
+    }
     if (c->n_leapfrogs) { HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>(); }
     if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
     sc.dev.mem = MI_MEM_DEVICE;
@@ -341,6 +345,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
         q.n_leap = (uint32_t)settings->n_leap_steps;
         q.eps = settings->step_size;
+        q.draw0 = (uint32_t)chains->draw0;
         rc = launch_logit(mi::LOGIT_HMC, q, X_dev, y_dev, st);
         if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -394,6 +399,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.seed = settings->rng_seed_value;
         q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
         q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
+        q.draw0 = (uint32_t)chains->draw0;
         void* scratch = nullptr;
         rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), &scratch);
         if (rc) return rc;
@@ -434,6 +440,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     prm.n_keep = (uint32_t)settings->n_keep_draws;
     prm.n_leap_steps = (uint32_t)settings->n_leap_steps;
     prm.eps = settings->step_size;
+    prm.draw0 = (uint32_t)chains->draw0;
     prm.stagger = 40;
     if (const char* e = getenv("MI_HMC_STAGGER")) prm.stagger = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_HMC_ABLATE")) prm.ablate = (uint32_t)atoi(e);
@@ -522,6 +529,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.eps = settings->step_size; q.s2 = s2_; q.rs = 1.0 / s2_;
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
         q.log_det = log_det_;
+        q.draw0 = (uint32_t)chains->draw0;
         rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st);
         if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -553,6 +561,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
     prm.n_keep = (uint32_t)settings->n_keep_draws;
     prm.eps = settings->step_size;
+    prm.draw0 = (uint32_t)chains->draw0;
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
     prm.s2 = settings->step_size * settings->step_size;
@@ -639,6 +648,15 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
     prm.n_keep = (uint32_t)settings->n_keep_draws;
     prm.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+    prm.draw0 = (uint32_t)chains->draw0;
+    if (chains->draw0 > 0) {
+        // continuation (checkpoint / resume): only after the adaptation window, with the adapted step sizes handed back in
+        if (chains->draw0 <= settings->n_adapt_draws)
+            return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
+        if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
+        if (getenv("MI_NUTS_LOCKSTEP")) return fail(MI_ERR_UNSUPPORTED, "nuts: the lock-step kernel does not continue runs");
+        prm.n_adapt = 0;
+    }
     prm.max_depth = (uint32_t)settings->max_tree_depth;
     prm.delta = settings->target_accept_rate;
     prm.eps_bar0 = settings->step_size;

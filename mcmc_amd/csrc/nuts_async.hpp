@@ -275,7 +275,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 
     uint64_t n_leap = 0;
     double eps;
-    {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, L z_init), nuts.cpp:166-172
+    if (prm.draw0 == 0) {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, L z_init), nuts.cpp:166-172
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
@@ -308,10 +308,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 cond = dH2 > neg_log2;
             }
         }
+    } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
+        eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
     }
     const double mu_val = det_log(10 * eps);             // nuts.cpp:174
     double h_val = 0.0;
-    double eps_bar = prm.eps_bar0;
+    double eps_bar = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     const uint32_t n_adapt = prm.n_adapt <= n_total ? prm.n_adapt : n_total;
@@ -332,7 +334,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 
     // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
-        const double zdir = rng_uniform(prm.seed, chain, draw, uslot);
+        const double zdir = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);
         if (p) {
             uslot++;
             vdir = (zdir <= 0.5) ? -1 : 1;
@@ -402,7 +404,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
-                rng_normal_pair(prm.seed, chain, draw, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+                rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
                 double pa = (8u * b + j4 < d) ? z0 : 0.0;
                 double pb = (8u * b + 4 + j4 < d) ? z1 : 0.0;
                 if constexpr (GENERAL) {                      // p = L z, K = p . (Minv p) / 2
@@ -423,7 +425,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             kq = kq + __shfl_xor(kq, 32);
             kq = kq + __shfl_xor(kq, 16);
             const double kk = kq / 2.0;                       // :204
-            const double lu = det_log(rng_uniform(prm.seed, chain, draw, 0u));
+            const double lu = det_log(rng_uniform(prm.seed, chain, draw + prm.draw0, 0u));
             copy_vec(V_PREV, V_TPOS_T, p);                    // draw_pos = draw_neg = prev_draw (:212-213)
             copy_vec(V_PREV, V_TNEG_T, p);
             if (p) {
@@ -568,7 +570,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             if (__ballot(walking) == 0ull) break;
             const bool mrg = walking && bit;
             if (__ballot(mrg) == 0ull) continue;
-            const double z = rng_uniform(prm.seed, chain, draw, uslot);  // :213
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :213
             if (mrg) {
                 uslot++;
                 const double p_n = lvl(l, 0), p_a = lvl(l, 1), p_na = lvl(l, 2), p_U = lvl(l, 3);
@@ -601,7 +603,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         const bool fin = run && (failed || complete);
         bool take = false;
         if (__ballot(complete) != 0ull) {
-            const double z = rng_uniform(prm.seed, chain, draw, uslot);  // :261
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :261
             if (complete) {
                 uslot++;
                 take = z < cn / n_val;                                   // :263

@@ -50,6 +50,8 @@ struct NutsParams {
     uint32_t n_burnin, n_keep, n_adapt, max_depth;
     double delta, eps_bar0, gamma, t0, kappa;
     // general variant of the asynchronous kernel (settings.vals_bound and / or a diagonal precond_mat), see nuts_async.hpp
+    uint32_t draw0;         // asynchronous kernel: index of this call's first draw (mi_chains.draw0); > 0 = continuation after the
+                            // adaptation window, step sizes come in through step_out
     int vals_bound;         // settings.vals_bound (0: only a diagonal precond_mat)
     const int* btype;
     const double* lb;

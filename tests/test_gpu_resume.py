@@ -1,0 +1,51 @@
+"""GPU: checkpoint / resume through mi_chains.draw0 -- a run cut in two calls (second call: draw0 = draws done so far,
+initial values = final theta of the first) is bit-identical to the uncut run.  SURVEY 8 (f-3)."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cut_vs_whole(algo, kind, d, C, k1, k2, burn, tkw, **skw):
+    init = synth.initial_states(C, d, seed=8) * 0.5
+    whole = mcmc_amd.default_settings(rng_seed_value=321, n_burnin_draws=burn, n_keep_draws=k1 + k2, **skw)
+    w_draws, w = mcmc_amd.sample(algo, kind, init, whole, chain0=9, **tkw)
+    first = mcmc_amd.default_settings(rng_seed_value=321, n_burnin_draws=burn, n_keep_draws=k1, **skw)
+    a_draws, a = mcmc_amd.sample(algo, kind, init, first, chain0=9, **tkw)
+    second = mcmc_amd.default_settings(rng_seed_value=321, n_burnin_draws=0, n_keep_draws=k2, **skw)
+    b_draws, b = mcmc_amd.sample(algo, kind, a["theta"].T.copy(), second, chain0=9, draw0=burn + k1,
+                                 step_size_in=a["eps"] if algo == "nuts" else None, **tkw)
+    assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
+    assert np.array_equal(a["n_accept"] + b["n_accept"], w["n_accept"])
+    assert np.array_equal(b["theta"], w["theta"])
+    return w, a, b
+
+
+@pytest.mark.parametrize("algo,kind,d", [("hmc", "dense", 128), ("hmc", "iso", 200), ("mala", "dense", 40), ("hmc", "diag", 24)])
+def test_gaussian_runs_resume_bit_exactly(algo, kind, d):
+    tkw, k = {}, mcmc_amd.TARGET_GAUSS_ISO
+    if kind == "dense": tkw, k = dict(prec=synth.dense_gaussian_precision(d, seed=2)), mcmc_amd.TARGET_GAUSS_DENSE
+    if kind == "diag": tkw, k = dict(prec=synth.ill_conditioned_diag(d, 10.0)), mcmc_amd.TARGET_GAUSS_DIAG
+    _cut_vs_whole(algo, k, d, 37, 5, 6, 3, tkw, n_leap_steps=4, step_size=0.1)
+
+
+@pytest.mark.parametrize("algo", ["mala", "hmc"])
+def test_logistic_runs_resume_bit_exactly(algo):
+    d, N = 70, 60
+    X, y = synth.logistic_problem(d, N, seed=3)
+    _cut_vs_whole(algo, mcmc_amd.TARGET_LOGISTIC, d, 40, 4, 3, 2, dict(X=X, y=y), n_leap_steps=3, step_size=0.05)
+
+
+def test_nuts_resumes_after_its_adaptation_window():
+    d = 32
+    tkw = dict(prec=synth.dense_gaussian_precision(d, seed=2))
+    w, a, b = _cut_vs_whole("nuts", mcmc_amd.TARGET_GAUSS_DENSE, d, 24, 4, 5, 6, tkw, n_adapt_draws=6, max_tree_depth=6)
+    assert np.array_equal(a["n_leap"] + b["n_leap"], w["n_leap"]) and np.array_equal(b["eps"], w["eps"])
+    # a continuation inside the adaptation window is refused, not approximated
+    st = mcmc_amd.default_settings(n_burnin_draws=0, n_keep_draws=2, n_adapt_draws=6)
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:
+        mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, np.zeros((4, d)), st, draw0=3, step_size_in=np.ones(4), **tkw)
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
