@@ -43,6 +43,8 @@ struct HmcParams {
     double* wsave;          // [n_waves][2][NS][64] workspace: last accepted theta and P*theta
     int vals_bound;         // general variant: settings.vals_bound (0: only a diagonal precond_mat)
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
+    const double* Minv;     // DENSE_M: INV(precond_mat), d*d row-major (device)
+    const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), d*d row-major (device)
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -204,9 +206,14 @@ __device__ __forceinline__ double box_log_jacobian_term(double v, int bt, double
 // vals_bound (hmc.cpp:84-95,107-122,134-136,211-218): the chain lives in the transformed
 // space; the target is evaluated at x = inv_transform(theta), the kick uses inv_jacobian * grad, the energy
 // adds log_jacobian (summed sequentially over dimensions, as the reference's scalar loop does).
-template <int NT, int WPB, bool BOUNDED = false>
+// DENSE_M (with BOUNDED): a dense precond_mat (hmc.cpp:57-59,158-160,171,184).  INV(M) and CHOL_LOWER(M) are computed on the
+// host with the oracle's Gauss-Jordan / Cholesky and staged into LDS as two more sets of MFMA A-fragments: p = L z,
+// theta += eps (Minv p) and K = p.(Minv p)/2 are mat-vecs with the same fma order as the oracle's dense products (so the
+// NaN poisoning of section 3 of DESIGN.md happens by itself).  d <= 64: three matrices have to share the LDS.
+template <int NT, int WPB, bool BOUNDED = false, bool DENSE_M = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
+    static_assert(!DENSE_M || BOUNDED, "the dense preconditioner rides the general variant");
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
     stage_precision<NT>(prm.P, prm.d, lds_P);
@@ -215,6 +222,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     double* lds_ms = lds_ub + 16 * NT;                     // diag of chol(M) and of inv(M): a DIAGONAL precond_mat
     double* lds_mi = lds_ms + 16 * NT;                     // (hmc.cpp:57-59) is an element-wise scaling
     int* lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
+    double* lds_Minv = lds_mi + 16 * NT + 8 * NT;          // after the int table (16*NT ints = 8*NT doubles), DENSE_M only
+    double* lds_L = lds_Minv + NT * NS * 64;
+    if constexpr (DENSE_M) {
+        stage_precision<NT>(prm.Minv, prm.d, lds_Minv);
+        stage_precision<NT>(prm.Lchol, prm.d, lds_L);
+    }
     if (BOUNDED) {
         for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
             const bool in = (uint32_t)i < prm.d;
@@ -237,6 +250,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     const uint64_t C = prm.C;
     const double eps = prm.eps;
     const double* afrag = lds_P + lane;
+    [[maybe_unused]] const double* afrag_minv = lds_Minv + lane;
+    [[maybe_unused]] const double* afrag_l = lds_L + lane;
 
     // Register-resident state of the wave's 16 chains: position, momentum, P*position.
     // The last accepted (theta, P*theta) lives in HBM (prm.theta / prm.wsave): written on accept,
@@ -287,9 +302,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     auto kinetic = [&]() __attribute__((always_inline)) -> double {
         if constexpr (BOUNDED) {
             double mp[NS];                               // inv_precond_matrix * mntm, a dense product
+            if constexpr (DENSE_M) {
+                matvec_mfma<NT>(afrag_minv, pm, mp);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
-            dense_product_poison<NS>(pm, mp, j, d);
+                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
+                dense_product_poison<NS>(pm, mp, j, d);
+            }
             double q = 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
@@ -361,7 +380,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) pm[s] = *z_mem(s);
-        if constexpr (BOUNDED) {                        // p = L z with a diagonal L (:158)
+        if constexpr (DENSE_M) {                        // p = L z (:158)
+            double zz[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zz[s] = pm[s];
+            matvec_mfma<NT>(afrag_l, zz, pm);
+        } else if constexpr (BOUNDED) {                 // p = L z with a diagonal L (:158)
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = lds_ms[4 * s + j] * pm[s];
         }
@@ -374,11 +398,17 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             else rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
-            if constexpr (BOUNDED) {                    // p = L z with a diagonal L (:158)
+            if constexpr (BOUNDED && !DENSE_M) {        // p = L z with a diagonal L (:158)
                 pm[2 * b] = lds_ms[8 * b + j] * pm[2 * b];
                 pm[2 * b + 1] = lds_ms[8 * b + 4 + j] * pm[2 * b + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (DENSE_M) {                        // p = L z (:158)
+            double zz[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zz[s] = pm[s];
+            matvec_mfma<NT>(afrag_l, zz, pm);
         }
 #endif
         const double prev_K = kinetic();                // hmc.cpp:160
@@ -390,11 +420,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             if constexpr (BOUNDED) {
                 double mp[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;       // first half-step (:122)
-                    mp[s] = lds_mi[4 * s + j] * pm[s];
+                for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;   // first half-step (:122)
+                if constexpr (DENSE_M) {
+                    matvec_mfma<NT>(afrag_minv, pm, mp);                    // inv_precond_matrix * new_mntm (:171)
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
+                    dense_product_poison<NS>(pm, mp, j, d);                 // inv_precond_matrix * new_mntm (:171)
                 }
-                dense_product_poison<NS>(pm, mp, j, d);                     // inv_precond_matrix * new_mntm (:171)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * mp[s];  // theta += eps * Minv p (:171)
             } else {

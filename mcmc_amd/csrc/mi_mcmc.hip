@@ -180,6 +180,51 @@ int launch_logit(int algo, const mi::LogitParams& prm, const double* X_dev, cons
 
 
 
+// INV and CHOL_LOWER of a dense precond_mat on the host, with the operation order the oracle states for the reference's
+// BMO_MATOPS_INV / BMO_MATOPS_CHOL_LOWER (Gauss-Jordan with partial pivoting; column Cholesky).  Compiled with
+// -ffp-contract=off like everything else, so the bits are the oracle's.
+void host_inverse(const double* A, size_t d, std::vector<double>& Ainv)
+{
+    std::vector<double> a(A, A + d * d);
+    Ainv.assign(d * d, 0.0);
+    for (size_t i = 0; i < d; ++i) Ainv[i * d + i] = 1.0;
+    for (size_t c = 0; c < d; ++c) {
+        size_t piv = c;
+        double best = std::fabs(a[c * d + c]);
+        for (size_t r = c + 1; r < d; ++r)
+            if (std::fabs(a[r * d + c]) > best) { best = std::fabs(a[r * d + c]); piv = r; }
+        if (piv != c)
+            for (size_t j = 0; j < d; ++j) { std::swap(a[c * d + j], a[piv * d + j]); std::swap(Ainv[c * d + j], Ainv[piv * d + j]); }
+        const double pv = a[c * d + c];
+        for (size_t j = 0; j < d; ++j) { a[c * d + j] = a[c * d + j] / pv; Ainv[c * d + j] = Ainv[c * d + j] / pv; }
+        for (size_t r = 0; r < d; ++r) {
+            if (r == c) continue;
+            const double f = a[r * d + c];
+            if (f == 0.0) continue;
+            for (size_t j = 0; j < d; ++j) {
+                a[r * d + j] = a[r * d + j] - f * a[c * d + j];
+                Ainv[r * d + j] = Ainv[r * d + j] - f * Ainv[c * d + j];
+            }
+        }
+    }
+}
+
+void host_cholesky_lower(const double* A, size_t d, std::vector<double>& L)
+{
+    L.assign(d * d, 0.0);
+    for (size_t j = 0; j < d; ++j) {
+        double sum = A[j * d + j];
+        for (size_t k = 0; k < j; ++k) sum = sum - L[j * d + k] * L[j * d + k];
+        const double ljj = std::sqrt(sum);
+        L[j * d + j] = ljj;
+        for (size_t i = j + 1; i < d; ++i) {
+            double t = A[i * d + j];
+            for (size_t k = 0; k < j; ++k) t = t - L[i * d + k] * L[j * d + k];
+            L[i * d + j] = t / ljj;
+        }
+    }
+}
+
 // Per-dimension tables of the general kernel variants (settings.vals_bound and / or a diagonal precond_mat):
 // determine_bounds_type (determine_bounds_type.hpp:27-57: 1 none, 2 lower, 3 upper, 4 both), the bounds, and the diagonal of
 // precond_mat with its CHOL_LOWER / INV (element-wise sqrt / reciprocal for a diagonal matrix, as the oracle's BMO shim gives).
@@ -256,12 +301,13 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
     return MI_OK;
 }
 
-template <int NT>
+template <int NT, bool DENSE_M = false>
 int launch_hmc_mfma_bounded(const mi::HmcParams& prm, hipStream_t st)
 {
     constexpr int WPB = 4;      // one wave per SIMD: the bounded variant holds two more register-resident vectors
-    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
-    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB, true>;
+    const size_t mat = (size_t)NT * 4 * NT * 64 * sizeof(double);
+    const size_t lds = mat * (DENSE_M ? 3 : 1) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
+    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB, true, DENSE_M>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
@@ -358,15 +404,19 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
     // element-wise 1/m and sqrt(m), exactly what the oracle's Gauss-Jordan / Cholesky produce); dense is not yet
     std::vector<double> m_sqrt, m_inv;
+    bool dense_m = false;
     if (settings->precond_mat) {
         if (d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with d > 128 is not implemented");
         m_sqrt.resize(d); m_inv.resize(d);
         for (uint64_t i = 0; i < d; ++i)
             for (uint64_t k = 0; k < d; ++k) {
                 const double v = settings->precond_mat[i * d + k];
-                if (i != k && v != 0.0) return fail(MI_ERR_UNSUPPORTED, "hmc: only a diagonal precond_mat is implemented on the device path");
+                if (i != k && v != 0.0) dense_m = true;
                 if (i == k) { m_sqrt[i] = __builtin_sqrt(v); m_inv[i] = 1.0 / v; }
             }
+        // a dense matrix: INV / CHOL_LOWER on the host, three fragment sets in LDS (d <= 64); target must be an MFMA one
+        if (dense_m && d > 64) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 64 (diagonal: d <= 128)");
+        if (dense_m && target->kind == MI_TARGET_LOGISTIC) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with the logistic target is not implemented");
     }
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
     if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
@@ -469,7 +519,20 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         prm.btype = bt_dev.as<int>(); prm.lb = lb_dev.as<double>(); prm.ub = ub_dev.as<double>();
         prm.m_sqrt = ms_dev.as<double>(); prm.m_inv = mi_dev.as<double>();
         prm.vals_bound = settings->vals_bound ? 1 : 0;
-        if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
+        DevBuf minv_dev, l_dev;
+        if (dense_m) {
+            std::vector<double> Minv, L;
+            host_inverse(settings->precond_mat, d, Minv);
+            host_cholesky_lower(settings->precond_mat, d, L);
+            HIP_TRY(minv_dev.alloc(d * d * 8)); HIP_TRY(l_dev.alloc(d * d * 8));
+            HIP_TRY(hipMemcpy(minv_dev.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(l_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+            prm.Minv = minv_dev.as<double>(); prm.Lchol = l_dev.as<double>();
+            if (nt <= 1) rc = launch_hmc_mfma_bounded<1, true>(prm, st);
+            else if (nt == 2) rc = launch_hmc_mfma_bounded<2, true>(prm, st);
+            else rc = launch_hmc_mfma_bounded<4, true>(prm, st);
+        }
+        else if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
         else if (nt == 2) rc = launch_hmc_mfma_bounded<2>(prm, st);
         else if (nt <= 4) rc = launch_hmc_mfma_bounded<4>(prm, st);
         else rc = launch_hmc_mfma_bounded<8>(prm, st);

@@ -278,9 +278,36 @@ def test_diagonal_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
 
 
-def test_dense_precond_is_refused_not_approximated():
-    d = 8
-    M = np.eye(d); M[0, 1] = M[1, 0] = 0.1
+def _spd(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
+
+
+@pytest.mark.parametrize("d,C,L,eps,bounded", [(8, 16, 5, 0.1, False), (37, 40, 3, 0.05, False), (64, 33, 4, 0.04, False), (20, 24, 4, 0.05, True)])
+def test_dense_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
+    """precond_mat dense: p = L z, theta += eps Minv p, K = p.Minv p / 2 as MFMA mat-vecs; INV / CHOL on the host."""
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    M = _spd(d, seed=d)
+    init = np.clip(synth.initial_states(C, d, seed=16) * 0.3, -1.0, 1.5)
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = _bounds(d, seed=4)
+        kw = dict(vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+        okw = dict(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=8, n_burnin_draws=3, n_keep_draws=7, n_leap_steps=L, step_size=eps,
+                                   precond_mat=M, **kw)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=2)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=8, n_burnin=3, n_keep=7, n_leap=L, step=eps, W=4, precond=M, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=2)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert 0 < g["n_accept"].sum()
+
+
+def test_dense_precond_beyond_lds_is_refused_not_approximated():
+    d = 100                                              # three 100x100 fragment sets do not fit the LDS
+    M = _spd(d, seed=1)
     st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
         mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
