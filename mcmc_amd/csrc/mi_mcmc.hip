@@ -230,11 +230,13 @@ void host_cholesky_lower(const double* A, size_t d, std::vector<double>& L)
 // precond_mat with its CHOL_LOWER / INV (element-wise sqrt / reciprocal for a diagonal matrix, as the oracle's BMO shim gives).
 struct GeneralTables {
     bool active = false;
+    bool dense = false;                       // precond_mat has off-diagonal entries: INV / CHOL_LOWER as dense matrices
+    DevBuf minv_full, l_full;
     std::vector<double> m, m_sqrt, m_inv;     // host copies (diagonal)
     DevBuf bt, lb, ub, m_dev, ms_dev, mi_dev;
 };
 
-int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTables& g)
+int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTables& g, bool allow_dense = false)
 {
     g.active = s->vals_bound != 0 || s->precond_mat != nullptr;
     if (!g.active) return MI_OK;
@@ -245,9 +247,21 @@ int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTab
         for (uint64_t i = 0; i < d; ++i)
             for (uint64_t k = 0; k < d; ++k) {
                 const double v = s->precond_mat[i * d + k];
-                if (i != k && v != 0.0) return fail(MI_ERR_UNSUPPORTED, "%s: only a diagonal precond_mat is implemented on the device path", who);
+                if (i != k && v != 0.0) {
+                    if (!allow_dense) return fail(MI_ERR_UNSUPPORTED, "%s: only a diagonal precond_mat is implemented on the device path", who);
+                    g.dense = true;
+                }
                 if (i == k) { g.m[i] = v; g.m_sqrt[i] = __builtin_sqrt(v); g.m_inv[i] = 1.0 / v; }
             }
+    if (g.dense) {
+        if (d > 64) return fail(MI_ERR_UNSUPPORTED, "%s: a dense precond_mat is implemented for d <= 64 (diagonal: d <= 128)", who);
+        std::vector<double> Minv, L;
+        host_inverse(s->precond_mat, d, Minv);
+        host_cholesky_lower(s->precond_mat, d, L);
+        HIP_TRY(g.minv_full.alloc(d * d * 8)); HIP_TRY(g.l_full.alloc(d * d * 8));
+        HIP_TRY(hipMemcpy(g.minv_full.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g.l_full.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+    }
     std::vector<int> bt(d, 1);
     std::vector<double> lbv(d, 0.0), ubv(d, 0.0);
     if (s->vals_bound)
@@ -279,10 +293,10 @@ int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
     return MI_OK;
 }
 
-template <int NT, bool GENERAL>
+template <int NT, bool GENERAL, bool DENSE_M = false>
 int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double)
+    const size_t lds = ((size_t)NT * 4 * NT * 64 * (DENSE_M ? 3 : 1) + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double)
                      + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     const unsigned grid = (unsigned)((prm.C + 63) / 64);
     if (!GENERAL && getenv("MI_NUTS_LOCKSTEP")) {   // first-generation kernel: chains of a wave in lock-step per draw
@@ -293,7 +307,7 @@ int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
         uint32_t batch = 8;
         if (const char* e = getenv("MI_NUTS_BATCH")) batch = (uint32_t)atoi(e);
         if (batch < 1) batch = 1;
-        auto kern = mi::nuts_gauss_async_kernel<NT, GENERAL>;
+        auto kern = mi::nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm, batch);
     }
@@ -729,9 +743,19 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
-    rc = general_tables("nuts", settings, d, gt);
+    rc = general_tables("nuts", settings, d, gt, true);
     if (rc) return rc;
-    if (gt.active) {
+    if (gt.active && gt.dense) {
+        prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
+        prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
+        prm.Minv = gt.minv_full.as<double>(); prm.Lchol = gt.l_full.as<double>();
+        prm.vals_bound = settings->vals_bound ? 1 : 0;
+        if (nt <= 1) rc = launch_nuts_mfma<1, true, true>(prm, st);
+        else if (nt == 2) rc = launch_nuts_mfma<2, true, true>(prm, st);
+        else rc = launch_nuts_mfma<4, true, true>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+    }
+    else if (gt.active) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
         prm.vals_bound = settings->vals_bound ? 1 : 0;

@@ -41,9 +41,12 @@ enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
 // x = inv_transform(theta) feeds the mat-vec, the kick uses J^-1_ii (P x)_i, the drift M^-1 p, K = p.(M^-1 p)/2,
 // U = -(K(x) + log_jacobian(theta)) summed over dimensions in order, p = sqrt(M) z; the tree lives in the transformed space
 // (the U-turn dots are plain), draws are reported through inv_transform.  Identity tables reproduce the plain kernel's bits.
-template <int NT, bool GENERAL = false>
+// DENSE_M (with GENERAL): a dense precond_mat, as in hmc_dense.hpp: INV(M) and CHOL_LOWER(M) from the host as two more sets of
+// MFMA A-fragments in LDS (d <= 64), p = L z, Minv p and the kinetic energy as mat-vecs.
+template <int NT, bool GENERAL = false, bool DENSE_M = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
+    static_assert(!DENSE_M || GENERAL, "the dense preconditioner rides the general variant");
     constexpr int NS = 4 * NT;
     constexpr int WS_NVEC = NUTS_NVEC_ASYNC;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -54,6 +57,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     double* const lds_ms = lds_ub + 16 * NT;
     double* const lds_mi = lds_ms + 16 * NT;
     int* const lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
+    double* const lds_Minv = lds_mi + 16 * NT + 8 * NT;   // after the int table, DENSE_M only
+    double* const lds_L = lds_Minv + NT * NS * 64;
+    if constexpr (DENSE_M) {
+        stage_precision<NT>(prm.Minv, prm.d, lds_Minv);
+        stage_precision<NT>(prm.Lchol, prm.d, lds_L);
+    }
     if constexpr (GENERAL) {
         for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
             const bool in = (uint32_t)i < prm.d;
@@ -76,6 +85,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
+    [[maybe_unused]] const double* afrag_minv = lds_Minv + lane;
+    [[maybe_unused]] const double* afrag_l = lds_L + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
@@ -179,9 +190,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     auto drift = [&](double e) __attribute__((always_inline)) {        // theta += e Minv p (a dense product in the reference)
         if constexpr (GENERAL) {
             double mp[NS];
+            if constexpr (DENSE_M) {
+                matvec_mfma<NT>(afrag_minv, pm, mp);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
-            dense_product_poison<NS>(pm, mp, j4, d);
+                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                dense_product_poison<NS>(pm, mp, j4, d);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) th[s] = th[s] + e * mp[s];
         } else {
@@ -224,9 +239,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     auto kinetic = [&]() __attribute__((always_inline)) -> double {    // K = p . (Minv p) / 2
         if constexpr (GENERAL) {
             double mp[NS];
+            if constexpr (DENSE_M) {
+                matvec_mfma<NT>(afrag_minv, pm, mp);
+            } else {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
-            dense_product_poison<NS>(pm, mp, j4, d);
+                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                dense_product_poison<NS>(pm, mp, j4, d);
+            }
             double q = 0.0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
@@ -282,11 +301,17 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
             pm[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-            if constexpr (GENERAL) {                     // L z with a diagonal L (nuts.cpp:170)
+            if constexpr (GENERAL && !DENSE_M) {         // L z with a diagonal L (nuts.cpp:170)
                 pm[2 * b] = lds_ms[8 * b + j4] * pm[2 * b];
                 pm[2 * b + 1] = lds_ms[8 * b + 4 + j4] * pm[2 * b + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (DENSE_M) {                         // L z (nuts.cpp:170)
+            double zz[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) zz[s] = pm[s];
+            matvec_mfma<NT>(afrag_l, zz, pm);
         }
         double U0 = prev_U;
         if (!is_finite(U0)) U0 = INF;
@@ -401,6 +426,21 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             finish_draw(state == NS_NEED_DRAW && fin_pending, fin_depth);   // epilogue of the draws that just ended
             const bool p = state == NS_NEED_DRAW;
             double kq = 0.0;
+            if constexpr (DENSE_M) {                          // p = L z and K = p . (Minv p) / 2 as mat-vecs (nuts.cpp:200-204)
+                double zz[NS], pp[NS], mp[NS];
+#pragma unroll 1
+                for (int b = 0; b < NS / 2; ++b) {
+                    double z0, z1;
+                    rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+                    zz[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
+                    zz[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                }
+                matvec_mfma<NT>(afrag_l, zz, pp);
+                matvec_mfma<NT>(afrag_minv, pp, mp);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) kq = dfma(pp[s], mp[s], kq);
+                if (p && live) { st_row(V_MNTM, 0, pp); st_row(V_TPOS_P, 0, pp); st_row(V_TNEG_P, 0, pp); }
+            } else {
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
@@ -421,6 +461,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                     st_pair(V_TPOS_P, 2 * b, pa, pb);
                     st_pair(V_TNEG_P, 2 * b, pa, pb);
                 }
+            }
             }
             kq = kq + __shfl_xor(kq, 32);
             kq = kq + __shfl_xor(kq, 16);
@@ -486,9 +527,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             kick_l();
             if constexpr (GENERAL) {
                 double mp[NS];
+                if constexpr (DENSE_M) {
+                    matvec_mfma<NT>(afrag_minv, pm, mp);
+                } else {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
-                dense_product_poison<NS>(pm, mp, j4, d);
+                    for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                    dense_product_poison<NS>(pm, mp, j4, d);
+                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) th[s] = th[s] + e_signed * mp[s];
             } else {
@@ -522,9 +567,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 }
                 pU = -(kval + lj);
                 double mp[NS];
+                if constexpr (DENSE_M) {
+                    matvec_mfma<NT>(afrag_minv, pm, mp);
+                } else {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
-                dense_product_poison<NS>(pm, mp, j4, d);
+                    for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                    dense_product_poison<NS>(pm, mp, j4, d);
+                }
                 double q = 0.0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);

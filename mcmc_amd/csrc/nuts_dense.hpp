@@ -58,6 +58,8 @@ struct NutsParams {
     const double* ub;
     const double* m_sqrt;   // diagonal of CHOL_LOWER(precond_mat)
     const double* m_inv;    // diagonal of INV(precond_mat)
+    const double* Minv;     // DENSE_M: INV(precond_mat), d*d row-major (device)
+    const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), d*d row-major (device)
 };
 
 enum : int {

@@ -112,3 +112,27 @@ def test_general_nuts_bit_exact_vs_oracle(d, C, burn, keep, bounded, precond):
     assert np.array_equal(g_draws, o_draws)
     if bounded:
         assert ((g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])).all()   # reported in the constrained space
+
+
+def _spd(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
+
+
+@pytest.mark.parametrize("d,C,bounded", [(8, 16, False), (37, 24, False), (64, 20, False), (20, 24, True)])
+def test_dense_precond_nuts_bit_exact_vs_oracle(d, C, bounded):
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    M = _spd(d, seed=d)
+    init = np.clip(synth.initial_states(C, d, seed=14) * 0.3, -1.0, 1.5)
+    kw, okw = dict(precond_mat=M), dict(precond=M)
+    if bounded:
+        lb, ub = _bounds(d, seed=d)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=80, n_burnin_draws=4, n_keep_draws=6, n_adapt_draws=4, max_tree_depth=6, **kw)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=4)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=80, n_burnin=4, n_keep=6, n_adapt=4, max_depth=6, W=4, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=4)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"])
+    assert np.array_equal(g_draws, o_draws)

@@ -45,7 +45,10 @@ def sweep(n_cases=60, seed=1, verbose=True):
                 lb, ub = bounds(d); kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
                 init = np.clip(init, -1.0, 1.5)
             if rng.random() < 0.6 or not kw:
-                M = np.diag(rng.uniform(0.3, 3.0, d)); kw.update(precond_mat=M); okw.update(precond=M)
+                M = np.diag(rng.uniform(0.3, 3.0, d))
+                if algo != "mala" and d <= 64 and rng.random() < 0.4:       # dense preconditioner (HMC / NUTS, d <= 64)
+                    A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
+                kw.update(precond_mat=M); okw.update(precond=M)
         tkw = {}
         if tgt == "logit":
             dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
