@@ -73,6 +73,8 @@ int main()
     s2.mala_settings.step_size = 0.3;
     s2.mala_settings.n_burnin_draws = 50; s2.mala_settings.n_keep_draws = 50;
     s2.nuts_settings.n_burnin_draws = 50; s2.nuts_settings.n_keep_draws = 50; s2.nuts_settings.n_adapt_draws = 50;
+    s2.rwmh_settings.par_scale = 0.3;
+    s2.rwmh_settings.n_burnin_draws = 50; s2.rwmh_settings.n_keep_draws = 50;
 
     mcmc::Mat_t dr;
     bool ok2 = mcmc::hmc(init, mcmc::mi355x::device_kernel, dr, &tgt, s2);
@@ -84,6 +86,11 @@ int main()
     ok2 = mcmc::nuts(init, mcmc::mi355x::device_kernel, dr, &tgt, s2);
     std::printf("device nuts ok=%d rows=%zu cols=%zu acc0=%.3f eps0=%.4f\n", int(ok2), size_t(dr.rows()), size_t(dr.cols()),
                 double(s2.nuts_settings.n_accept_draws) / 50.0, tgt.step_size[0]);
+
+    bool ok3 = mcmc::rwmh(init, mcmc::mi355x::device_value_kernel, dr, &tgt, s2);
+    std::printf("device rwmh ok=%d rows=%zu cols=%zu acc0=%.3f\n", int(ok3), size_t(dr.rows()), size_t(dr.cols()),
+                double(s2.rwmh_settings.n_accept_draws) / 50.0);
+    if (!ok3) return 1;
 
     // a host callback with mala / nuts is refused (no CPU sampler behind this header)
     const bool refused = !mcmc::nuts(initial_val, log_target_dens, draws_out, &dta, settings);

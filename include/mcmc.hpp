@@ -257,6 +257,16 @@ inline bool is_device_route(const log_kernel_fn_t& f)
     return p && *p == &device_kernel;
 }
 
+// the same tag for mcmc::rwmh, whose callback takes no gradient (ref: include/mcmc/rwmh.hpp:42-47)
+inline fp_t device_value_kernel(const ColVec_t&, void*) { return std::numeric_limits<fp_t>::quiet_NaN(); }
+
+inline bool is_device_route(const std::function<fp_t (const ColVec_t&, void*)>& f)
+{
+    using fptr_t = fp_t (*)(const ColVec_t&, void*);
+    const fptr_t* p = f.target<fptr_t>();
+    return p && *p == &device_value_kernel;
+}
+
 }  // namespace mi355x
 
 // ---------------------------------------------------------------------------------------------
@@ -295,6 +305,7 @@ inline bool run_device(int algo, const ColVec_t& initial_vals, mi355x::target_t&
     tgt.desc.struct_size = sizeof(mi_target);
     const int rc = (algo == 0) ? mi_mcmc_hmc_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 1) ? mi_mcmc_mala_run(&tgt.desc, &m, &ch, nullptr)
+                 : (algo == 3) ? mi_mcmc_rwmh_run(&tgt.desc, &m, &ch, nullptr)
                                : mi_mcmc_nuts_run(&tgt.desc, &m, &ch, nullptr);
     if (rc != MI_OK) { tgt.last_error = mi_mcmc_last_error(); return false; }
     draws_out.resize(n_keep, d * C);                                  // BMO_MATOPS_SET_SIZE(draws_out, n_keep, n_vals)
@@ -392,6 +403,25 @@ nuts_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t
     return ok;
 }
 
+inline bool
+rwmh_impl(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals_inp, void* target_data)> target_log_kernel,
+          Mat_t& draws_out, void* target_data, algo_settings_t* settings_inp)
+{
+    // ref: src/rwmh.cpp:30-175.  par_scale and cov_mat travel in the POD mirror's step_size / precond_mat (mi_mcmc.h)
+    algo_settings_t settings;
+    if (settings_inp) settings = *settings_inp;
+    if (!mi355x::is_device_route(target_log_kernel)) return false;   // host callbacks: hmc only (no CPU fallback)
+    mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
+    mi_settings m = flatten_common(settings);
+    m.n_burnin_draws = settings.rwmh_settings.n_burnin_draws;
+    m.n_keep_draws = settings.rwmh_settings.n_keep_draws;
+    m.step_size = settings.rwmh_settings.par_scale;
+    m.precond_mat = precond_or_null(settings.rwmh_settings.cov_mat, tgt.desc.d);
+    const bool ok = run_device(3, initial_vals, tgt, draws_out, m);
+    if (ok && settings_inp) settings_inp->rwmh_settings.n_accept_draws = size_t(tgt.n_accept_draws[0]);
+    return ok;
+}
+
 }  // namespace internal
 
 // ---------------------------------------------------------------------------------------------
@@ -417,6 +447,14 @@ inline bool nuts(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel
 inline bool nuts(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t& draws_out, void* target_data,
                  algo_settings_t& settings)
 { return internal::nuts_impl(initial_vals, target_log_kernel, draws_out, target_data, &settings); }
+
+inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals_inp, void* target_data)> target_log_kernel,
+                 Mat_t& draws_out, void* target_data)
+{ return internal::rwmh_impl(initial_vals, target_log_kernel, draws_out, target_data, nullptr); }
+
+inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals_inp, void* target_data)> target_log_kernel,
+                 Mat_t& draws_out, void* target_data, algo_settings_t& settings)
+{ return internal::rwmh_impl(initial_vals, target_log_kernel, draws_out, target_data, &settings); }
 
 }  // namespace mcmc
 

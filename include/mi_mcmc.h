@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000101
+#define MI_MCMC_VERSION 0x000102
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -117,6 +117,9 @@ int         mi_mcmc_device_count(void);
 int mi_mcmc_hmc_run (const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
+/* mcmc::rwmh (/root/reference/include/mcmc/rwmh.hpp, src/rwmh.cpp:30-175) for many chains: settings->step_size carries
+ * rwmh_settings_t::par_scale (mcmc_structs.hpp:145) and settings->precond_mat carries rwmh_settings_t::cov_mat (:146). */
+int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 
 /* Host-callback form of mcmc::hmc for ONE chain: the reference's own target contract
  * (std::function<fp_t(const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>, hmc.hpp:42-48)

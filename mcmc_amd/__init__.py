@@ -58,7 +58,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_hmc_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_hmc_run_callback",
     "mi_mcmc_draws_to_chain_major",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -135,7 +135,7 @@ def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=
     return c
 
 
-_RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run"}
+_RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run", "rwmh": "mi_mcmc_rwmh_run"}
 
 
 def run(algo, target, settings, chains, stream=None):
@@ -175,6 +175,11 @@ def mala(kind, init, settings, **kw):
 
 def nuts(kind, init, settings, **kw):
     return sample("nuts", kind, init, settings, **kw)
+
+
+def rwmh(kind, init, settings, **kw):
+    """mcmc::rwmh: settings.step_size carries par_scale, settings.precond_mat carries cov_mat."""
+    return sample("rwmh", kind, init, settings, **kw)
 
 
 LOG_KERNEL_CB = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)

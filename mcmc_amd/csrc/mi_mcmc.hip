@@ -23,6 +23,7 @@
 #include "nuts_dense.hpp"
 #include "nuts_async.hpp"
 #include "mala_dense.hpp"
+#include "rwmh_dense.hpp"
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
@@ -278,6 +279,19 @@ int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTab
     HIP_TRY(hipMemcpy(g.m_dev.p, g.m.data(), d * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(g.ms_dev.p, g.m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(g.mi_dev.p, g.m_inv.data(), d * 8, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+template <int NT, bool GENERAL, bool DENSE_C>
+int launch_rwmh_mfma(const mi::RwmhParams& prm, hipStream_t st)
+{
+    const size_t mat = (size_t)NT * 4 * NT * 64 * sizeof(double);
+    const size_t lds = mat * (DENSE_C ? 2 : 1) + (GENERAL ? (size_t)16 * NT * (3 * sizeof(double) + sizeof(int)) : 0);
+    auto kern = mi::rwmh_gauss_mfma_kernel<NT, GENERAL, DENSE_C>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 63) / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 
@@ -673,6 +687,77 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     else if (nt == 2) rc = launch_mala_mfma<2, false>(prm, st);
     else if (nt <= 4) rc = launch_mala_mfma<4, false>(prm, st);
     else rc = launch_mala_mfma<8, false>(prm, st);
+    if (rc) return rc;
+
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// mcmc::rwmh (src/rwmh.cpp:30-175) for many chains.  settings->step_size carries rwmh_settings.par_scale and
+// settings->precond_mat carries rwmh_settings.cov_mat (identity when NULL, rwmh.cpp:58).
+int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t d = target->d;
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
+        return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
+    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "rwmh: d = %llu > 128 not implemented", (unsigned long long)d);
+
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+
+    mi::RwmhParams prm{};
+    prm.P = P_dev; prm.d = (uint32_t)d; prm.C = chains->n_chains; prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta; prm.draws = sc.dev.draws; prm.n_accept = sc.dev.n_accept;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws; prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.draw0 = (uint32_t)chains->draw0;
+    prm.par_scale = settings->step_size;
+
+    const int nt = (int)((d + 15) / 16);
+    GeneralTables gt;
+    rc = general_tables("rwmh", settings, d, gt, true);
+    if (rc) return rc;
+    DevBuf c_dev, lc_dev;
+    if (gt.active) {
+        // cov_mcmc_chol = par_scale * CHOL_LOWER(cov_mat), element by element (rwmh.cpp:119)
+        std::vector<double> c(d);
+        for (uint64_t i = 0; i < d; ++i) c[i] = prm.par_scale * gt.m_sqrt[i];
+        HIP_TRY(c_dev.alloc(d * 8));
+        HIP_TRY(hipMemcpy(c_dev.p, c.data(), d * 8, hipMemcpyHostToDevice));
+        prm.vals_bound = settings->vals_bound ? 1 : 0;
+        prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
+        prm.c_diag = c_dev.as<double>();
+        if (gt.dense) {
+            std::vector<double> L;
+            host_cholesky_lower(settings->precond_mat, d, L);
+            for (auto& v : L) v = prm.par_scale * v;
+            HIP_TRY(lc_dev.alloc(d * d * 8));
+            HIP_TRY(hipMemcpy(lc_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+            prm.Lc = lc_dev.as<double>();
+            if (nt <= 1) rc = launch_rwmh_mfma<1, true, true>(prm, st);
+            else if (nt == 2) rc = launch_rwmh_mfma<2, true, true>(prm, st);
+            else rc = launch_rwmh_mfma<4, true, true>(prm, st);
+        }
+        else if (nt <= 1) rc = launch_rwmh_mfma<1, true, false>(prm, st);
+        else if (nt == 2) rc = launch_rwmh_mfma<2, true, false>(prm, st);
+        else if (nt <= 4) rc = launch_rwmh_mfma<4, true, false>(prm, st);
+        else rc = launch_rwmh_mfma<8, true, false>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+    }
+    else if (nt <= 1) rc = launch_rwmh_mfma<1, false, false>(prm, st);
+    else if (nt == 2) rc = launch_rwmh_mfma<2, false, false>(prm, st);
+    else if (nt <= 4) rc = launch_rwmh_mfma<4, false, false>(prm, st);
+    else rc = launch_rwmh_mfma<8, false, false>(prm, st);
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);

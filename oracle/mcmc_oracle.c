@@ -721,6 +721,57 @@ int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
     return 0;
 }
 
+/* ------------------------------------------------------------------ RWMH */
+
+/* ref: src/rwmh.cpp:30-175.  settings: step_size carries rwmh_settings.par_scale (mcmc_structs.hpp:145), precond_mat carries
+ * rwmh_settings.cov_mat (:146, identity when absent, rwmh.cpp:58). */
+int orc_rwmh(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st)
+{
+    orc_ctx c;
+    ctx_init(&c, d, kernel, data, s, 0);
+    const size_t n_burnin = s->n_burnin_draws, n_keep = s->n_keep_draws, n_total = n_burnin + n_keep;
+    const double par_scale = s->step_size;
+
+    double* first_draw = dvec(d);
+    memcpy(first_draw, initial_vals, d * sizeof(double));
+    if (c.vals_bound) orc_transform(initial_vals, c.btype, c.lb, c.ub, d, first_draw);   /* :105-107 */
+    double prev_LP = box_log_kernel(&c, first_draw);                    /* :113 */
+    double prop_LP = prev_LP;
+    double* prev_draw = dvec(d); memcpy(prev_draw, first_draw, d * sizeof(double));
+    double* new_draw = dvec(d);  memcpy(new_draw, first_draw, d * sizeof(double));
+    double* cov_chol = dvec(d * d);                                     /* par_scale * CHOL_LOWER(cov) :119 */
+    for (size_t i = 0; i < d * d; ++i) cov_chol[i] = par_scale * c.sqrt_precond[i];
+    double* rand_vec = dvec(d);
+    double* t = dvec(d);
+    size_t n_accept = 0;
+
+    for (size_t draw_ind = 0; draw_ind < n_total; ++draw_ind) {         /* :123 */
+        orc_rng_normal_vec(c.seed, c.chain, (uint32_t)draw_ind, ORC_STREAM_NORMAL, d, rand_vec);   /* :124 */
+        orc_gemv(cov_chol, rand_vec, d, t);
+        for (size_t i = 0; i < d; ++i) new_draw[i] = prev_draw[i] + t[i];            /* :126 */
+        prop_LP = box_log_kernel(&c, new_draw);                         /* :128 */
+        if (!isfinite(prop_LP)) prop_LP = -INFINITY;                    /* :130-132 */
+        const double x = prop_LP - prev_LP;
+        const double comp_val = (x < 0.0) ? x : 0.0;                    /* std::min(0.0, x): NaN -> 0 :136 */
+        const double z = orc_rng_uniform(c.seed, c.chain, (uint32_t)draw_ind, 0);    /* :137 */
+        int acc = 0;
+        if (z < orc_exp(comp_val)) {                                    /* :139 */
+            memcpy(prev_draw, new_draw, d * sizeof(double));
+            prev_LP = prop_LP;
+            acc = 1;
+            if (draw_ind >= n_burnin) n_accept++;
+        }
+        if (draw_ind >= n_burnin) store_row(draws_out, draw_ind - n_burnin, d, prev_draw);   /* :148-150 */
+        if (st && st->accept_trace) st->accept_trace[draw_ind] = (uint8_t)acc;
+    }
+    epilogue_inv_transform(&c, draws_out, n_keep);                      /* :157-166 */
+    if (st) { st->n_accept_draws = n_accept; st->n_leapfrogs = 0; st->final_step_size = par_scale; }
+    free(first_draw); free(prev_draw); free(new_draw); free(cov_chol); free(rand_vec); free(t);
+    ctx_free(&c);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ NUTS */
 
 /* ref: include/mcmc/nuts.ipp:30-93 */
@@ -989,6 +1040,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
         int r;
         if (algo == 0) r = orc_hmc(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else if (algo == 1) r = orc_mala(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
+        else if (algo == 3) r = orc_rwmh(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else r = orc_nuts(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         if (r) rc = r;
         if (draws_out)

@@ -107,11 +107,14 @@ int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
              const orc_settings* s, double* draws_out, orc_stats* st);
 int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
+/* mcmc::rwmh (src/rwmh.cpp:30-175): step_size carries par_scale, precond_mat carries cov_mat */
+int orc_rwmh(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st);
 
 /* many independent chains of a built-in target, OpenMP over chains (the CPU
  * baseline of BASELINE.md section 3).  init: n_chains x d (row per chain).
  * draws_out: [n_keep][d][n_chains] (the engine's device layout) or NULL.
- * algo: 0 hmc, 1 mala, 2 nuts.  Chain c uses chain_id = chain0 + c. */
+ * algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh.  Chain c uses chain_id = chain0 + c. */
 int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t n_chains,
                  uint64_t chain0, const double* init, double* draws_out,
                  uint64_t* n_accept_out, uint64_t* n_leap_out, double* eps_out, int n_threads);

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_LOGISTIC = 1, 2, 3, 4
-ALGO_HMC, ALGO_MALA, ALGO_NUTS = 0, 1, 2
+ALGO_HMC, ALGO_MALA, ALGO_NUTS, ALGO_RWMH = 0, 1, 2, 3   # rwmh: step = par_scale, precond = cov_mat
 
 _dp = C.POINTER(C.c_double)
 
@@ -106,7 +106,7 @@ def run_chain(algo, target, init, settings, traces=False):
         st.depth_trace = dep.ctypes.data_as(C.POINTER(C.c_uint32))
         st.leap_trace = lea.ctypes.data_as(C.POINTER(C.c_uint32))
         st.eps_trace = _p(eps)
-    fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts][algo]
+    fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts, lib().orc_rwmh][algo]
     kern = C.cast(lib().orc_target_kernel, C.c_void_p)
     rc = fn(_p(init), C.c_size_t(d), kern, C.byref(target.c), C.byref(settings), _p(draws), C.byref(st))
     assert rc == 0

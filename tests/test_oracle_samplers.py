@@ -230,3 +230,37 @@ def test_logistic_target_gradient_is_the_derivative_of_the_value():
         e[i] = 1e-6
         num = (t.kernel(b + e, False)[0] - t.kernel(b - e, False)[0]) / 2e-6
         assert abs(num - g[i]) < 1e-6
+
+
+# ---------------------------------------------------------------- RWMH (ref: src/rwmh.cpp:30-175)
+def test_rwmh_samples_a_gaussian_and_matches_a_numpy_restatement():
+    d = 4
+    prec = synth.dense_gaussian_precision(d, seed=3)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=1)
+    cov = np.linalg.inv(prec)
+    s = orc.make_settings(seed=11, n_burnin=200, n_keep=3000, step=0.9, precond=cov, W=1)
+    draws, info = orc.run_chain(orc.ALGO_RWMH, t, np.zeros(d), s, traces=True)
+    assert 0.15 < info["n_accept"] / 3000 < 0.85
+    emp = np.cov(draws.T)
+    assert np.allclose(emp, cov, atol=0.35 * np.abs(cov).max())
+    # numpy restatement of the loop for the first draws (same normals / uniforms, same accept decisions)
+    L = 0.9 * np.linalg.cholesky(cov)
+    x, lp = np.zeros(d), 0.0
+    for k in range(30):
+        z = orc.normal_vec(11, 0, k, 0, d)
+        y = x + L @ z
+        lpy = -0.5 * y @ prec @ y
+        if orc.uniform(11, 0, k, 0) < np.exp(min(0.0, lpy - lp)):
+            x, lp = y, lpy
+            assert info["accept"][k] == 1
+        else:
+            assert info["accept"][k] == 0
+
+
+def test_rwmh_bounded_draws_stay_inside_the_box():
+    d = 5
+    lb = np.array([-1.0, -np.inf, 0.0, -np.inf, -2.0]); ub = np.array([1.0, 2.0, np.inf, np.inf, 3.0])
+    t = orc.TargetSpec(orc.TARGET_ISO, d, W=4)
+    s = orc.make_settings(seed=5, n_burnin=50, n_keep=400, step=0.5, W=4, lower=lb, upper=ub)
+    draws, info = orc.run_chain(orc.ALGO_RWMH, t, np.array([0.1, 0.2, 0.5, 0.0, 1.0]), s)
+    assert (draws >= lb).all() and (draws <= ub).all() and 0 < info["n_accept"] < 400

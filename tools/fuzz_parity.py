@@ -22,8 +22,8 @@ def sweep(n_cases=60, seed=1, verbose=True):
 
 
     for case in range(n_cases):
-        algo = ["hmc", "mala", "nuts"][case % 3]
-        tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo != "nuts" else ["dense", "iso", "diag"])
+        algo = ["hmc", "mala", "nuts", "rwmh"][case % 4]
+        tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo in ("hmc", "mala") else ["dense", "iso", "diag"])
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 128])) if tgt != "logit" else int(rng.choice([3, 17, 64, 65, 130, 300]))
         C = int(rng.choice([1, 3, 16, 17, 33, 70]))
         rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
@@ -62,7 +62,7 @@ def sweep(n_cases=60, seed=1, verbose=True):
             g_draws, g = mcmc_amd.sample(algo, kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
         except mcmc_amd.MiMcmcError as e:
             say("REFUSED", desc, "->", str(e)[:90]); continue
-        o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS}[algo], t, init, s, chain0=chain0)
+        o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=chain0)
         ok = np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
         if algo == "nuts": ok = ok and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
         if not ok and algo == "mala" and (kw.get("vals_bound") or np.isnan(o_draws).any()):
