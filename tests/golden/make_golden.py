@@ -34,6 +34,7 @@ def cases():
         "hmc": dict(algo=orc.ALGO_HMC, n_leap=5, step=0.2),
         "mala": dict(algo=orc.ALGO_MALA, step=0.15),
         "nuts": dict(algo=orc.ALGO_NUTS, step=1.0, n_adapt=10),
+        "rwmh": dict(algo=orc.ALGO_RWMH, step=0.4),
     }
     for tn, t in targets.items():
         for an, a in algos.items():
