@@ -47,6 +47,10 @@ struct MalaParams {
     const double* ub;
     const double* m;        // [d] diagonal of precond_mat
     const double* m_sqrt;   // [d] diagonal of CHOL_LOWER(precond_mat)
+    // dense precond_mat (mala_gauss_dense_m_kernel): d*d row-major device matrices from the host
+    const double* Mfull;    // precond_mat
+    const double* Lchol;    // CHOL_LOWER(precond_mat)
+    const double* Sinv;     // INV(eps^2 precond_mat)
 };
 
 template <int NT, bool GENERAL = false>
@@ -254,6 +258,115 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
             double v = th[s];
             if constexpr (GENERAL) { if (vb && dim < d) v = box_inv_transform(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]); }
             if (dim < d) prm.theta[(size_t)(4 * s) * C + lane_off] = v;
+        }
+        if (j == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
+    }
+}
+
+// MALA with a DENSE precond_mat M, unbounded (mala.cpp:123,159; mala.ipp:60-64), d <= 64: four fragment sets share the LDS
+// (P, M, L = CHOL_LOWER(M), INV(eps^2 M); the last two and LOG_DET(eps^2 M) come from the host in the oracle's operation order).
+//   mu(v) = v + (eps^2 (M g)) / 2,   proposal = mu + eps (L z),   dmvnorm terms with INV(Sigma) as mat-vecs:
+// five mat-vecs per draw (P x', M g', L z, Sinv xa, Sinv xb); M g of the current state is carried.  A bounded run would need
+// INV(eps^2 J(theta') M) per draw and is refused on the host.
+template <int NT>
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kernel(const MalaParams prm)
+{
+    constexpr int NS = 4 * NT;
+    constexpr int MAT = NT * NS * 64;
+    extern __shared__ __attribute__((aligned(16))) double lds_P[];
+    stage_precision<NT>(prm.Mfull, prm.d, lds_P + MAT);
+    stage_precision<NT>(prm.Lchol, prm.d, lds_P + 2 * MAT);
+    stage_precision<NT>(prm.Sinv, prm.d, lds_P + 3 * MAT);
+    stage_precision<NT>(prm.P, prm.d, lds_P);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 4;
+    const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+    const bool live = cl < prm.C;
+    const uint64_t cld = live ? cl : prm.C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps, s2 = prm.s2;
+    const double* afrag = lds_P + lane;
+    const double* afrag_m = lds_P + MAT + lane;
+    const double* afrag_l = lds_P + 2 * MAT + lane;
+    const double* afrag_si = lds_P + 3 * MAT + lane;
+    const size_t lane_off = (size_t)j * C + cld;
+
+    double th[NS], w[NS], mg[NS];      // current state, P theta, M grad (grad = -w)
+    double tp[NS], wp[NS], mgp[NS];    // the same at the proposal
+    double a[NS], b[NS];
+    auto m_times_grad = [&](const double (&ww)[NS], double (&out)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = -ww[s];
+        matvec_mfma<NT>(afrag_m, a, out);                // precond_matrix * grad_obj (mala.cpp:123)
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dim = 4 * s + j;
+        th[s] = (dim < d) ? prm.theta[(size_t)(4 * s) * C + lane_off] : 0.0;
+    }
+    matvec_mfma<NT>(afrag, th, w);
+    m_times_grad(w, mg);
+    double prev_LP = -0.5 * dot4<NS>(th, w);            // mala.cpp:138
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+
+#pragma unroll 1
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+        for (int bb = 0; bb < NS / 2; ++bb) {           // rand_vec (:150)
+            double z0, z1;
+            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * bb + j), STREAM_NORMAL, z0, z1);
+            a[2 * bb] = (8u * bb + j < d) ? z0 : 0.0;
+            a[2 * bb + 1] = (8u * bb + 4 + j < d) ? z1 : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        matvec_mfma<NT>(afrag_l, a, b);                  // sqrt_precond_matrix * rand_vec (:159)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) tp[s] = (th[s] + (s2 * mg[s]) / 2.0) + eps * b[s];   // :123, :159
+        matvec_mfma<NT>(afrag, tp, wp);
+        double prop_LP = -0.5 * dot4<NS>(tp, wp);        // :162
+        if (!is_finite(prop_LP)) prop_LP = -INF;         // :164-166
+        m_times_grad(wp, mgp);
+        // mala_prop_adjustment (mala.ipp:60-64): dmvnorm(prev | mu(prop), Sigma) - dmvnorm(prop | mu(prev), Sigma)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = th[s] - (tp[s] + (s2 * mgp[s]) / 2.0);       // X - mu (dmvnorm.hpp:37)
+        matvec_mfma<NT>(afrag_si, a, b);
+        const double quad_a = dot4<NS>(a, b);            // :39
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a[s] = tp[s] - (th[s] + (s2 * mg[s]) / 2.0);
+        matvec_mfma<NT>(afrag_si, a, b);
+        const double quad_b = dot4<NS>(a, b);
+        const double da = prm.cons_term - 0.5 * (prm.log_det + quad_a);   // :41
+        const double db = prm.cons_term - 0.5 * (prm.log_det + quad_b);
+        const double x = prop_LP - prev_LP + (da - db);
+        const double comp_val = (x < 0.01) ? x : 0.01;   // mala.cpp:170
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);   // :171
+        const bool accept = z < det_exp(comp_val);       // :173
+        if (accept) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { th[s] = tp[s]; w[s] = wp[s]; mg[s] = mgp[s]; }
+            prev_LP = prop_LP;
+        }
+        if (draw >= prm.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            if (prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t dim = 4 * s + j;
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = th[s];
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t dim = 4 * s + j;
+            if (dim < d) prm.theta[(size_t)(4 * s) * C + lane_off] = th[s];
         }
         if (j == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
     }

@@ -295,6 +295,18 @@ int launch_rwmh_mfma(const mi::RwmhParams& prm, hipStream_t st)
     return MI_OK;
 }
 
+template <int NT>
+int launch_mala_dense_m(const mi::MalaParams& prm, hipStream_t st)
+{
+    const size_t lds = (size_t)4 * NT * 4 * NT * 64 * sizeof(double);
+    auto kern = mi::mala_gauss_dense_m_kernel<NT>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 63) / 64);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 template <int NT, bool GENERAL>
 int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
 {
@@ -667,9 +679,29 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
-    rc = general_tables("mala", settings, d, gt);
+    rc = general_tables("mala", settings, d, gt, true);
     if (rc) return rc;
-    if (gt.active) {
+    if (gt.active && gt.dense) {
+        // dense precond_mat, unbounded: Sigma = eps^2 M is constant, so INV / CHOL_LOWER / LOG_DET come from the host once
+        if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "mala: a dense precond_mat together with vals_bound is not implemented (INV of eps^2 J M per draw)");
+        std::vector<double> Sigma(d * d), Sinv, Ls;
+        for (uint64_t i = 0; i < d * d; ++i) Sigma[i] = prm.s2 * settings->precond_mat[i];
+        host_inverse(Sigma.data(), d, Sinv);
+        host_cholesky_lower(Sigma.data(), d, Ls);
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(Ls[i * d + i]);
+        prm.log_det = ld;
+        DevBuf m_full, sinv_full;
+        HIP_TRY(m_full.alloc(d * d * 8)); HIP_TRY(sinv_full.alloc(d * d * 8));
+        HIP_TRY(hipMemcpy(m_full.p, settings->precond_mat, d * d * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sinv_full.p, Sinv.data(), d * d * 8, hipMemcpyHostToDevice));
+        prm.Mfull = m_full.as<double>(); prm.Lchol = gt.l_full.as<double>(); prm.Sinv = sinv_full.as<double>();
+        if (nt <= 1) rc = launch_mala_dense_m<1>(prm, st);
+        else if (nt == 2) rc = launch_mala_dense_m<2>(prm, st);
+        else rc = launch_mala_dense_m<4>(prm, st);
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the matrices are ours
+    }
+    else if (gt.active) {
         // unbounded runs hoist LOG_DET(eps^2 M) = sum_i 2 log sqrt(eps^2 M_ii), i ascending (bounded runs sum it per draw)
         double ld = 0.0;
         for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(__builtin_sqrt(prm.s2 * gt.m[i]));

@@ -141,10 +141,31 @@ def test_diagonal_precond_mala_bit_exact_vs_oracle(d, C, eps, bounded):
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
 
 
-def test_dense_precond_mala_is_refused_not_approximated():
+def _spd(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
+
+
+@pytest.mark.parametrize("d,C,eps", [(8, 16, 0.3), (37, 40, 0.1), (64, 33, 0.08)])
+def test_dense_precond_mala_bit_exact_vs_oracle(d, C, eps):
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    M = _spd(d, seed=d)
+    init = synth.initial_states(C, d, seed=15) * 0.3
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=3, n_keep_draws=7, step_size=eps, precond_mat=M)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=1)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=6, n_burnin=3, n_keep=7, step=eps, W=4, precond=M, hoist=1)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s, chain0=1)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert 0 < g["n_accept"].sum()
+
+
+def test_dense_precond_mala_with_bounds_is_refused_not_approximated():
     d = 8
-    M = np.eye(d); M[0, 1] = M[1, 0] = 0.1
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
+    M = _spd(d, seed=2)
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M, vals_bound=1,
+                                   lower_bounds=np.full(d, -1.0), upper_bounds=np.full(d, 1.0))
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
         mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
     assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
