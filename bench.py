@@ -164,11 +164,11 @@ def main():
         barrier()
         collate_ms = (time.perf_counter() - tc) * 1e3
 
-    # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, from a
-    # 256-chain sample of the kept draws of the last step, scaled to all chains; computed outside the timed region
-    from mcmc_amd.ess import ess_min_total
-    sub = draws[:, :, : min(C, 256)].cpu().numpy()
-    ess_total_rank, _ = ess_min_total(sub, n_chains_total=C)
+    # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, autocovariances pooled
+    # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region
+    stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+    ess_total_rank = float(stats["ess"].min()) * C
+    rhat_max = float(stats["rhat"].max())
 
     leap_per_chain = int(n_leap[0].item())
     acc_rate = float(n_accept.double().mean().item()) / n_keep
@@ -201,7 +201,9 @@ def main():
                          "flop_per_unit": flop_per_unit},
         }
         out["ess_per_sec"] = ess_total_rank * world / (elapsed / args.steps)
-        out["ess_note"] = "min-over-dims Geyer-IPS ESS of the 100 kept draws, pooled over a 256-chain sample, x chains, / seconds per step"
+        out["ess_note"] = ("min-over-dims Geyer-IPS ESS of the 100 kept draws (autocovariance pooled over all chains on the device), "
+                           "x chains, / seconds per step")
+        out["rhat_max"] = rhat_max
         if collate_ms is not None:
             out["collate_last_draw_allgather_ms"] = collate_ms
         if not args.no_cpu_baseline and world == 1:

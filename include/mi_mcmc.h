@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000102
+#define MI_MCMC_VERSION 0x000103
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -137,6 +137,16 @@ int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kern
  * src/hmc.cpp:138,197). Host memory. */
 int mi_mcmc_draws_to_chain_major(const double* draws_kdc, uint64_t n_keep, uint64_t d, uint64_t n_chains,
                                  double* out_c_colmajor /* [C][d][n_keep] */);
+
+/* Reducers over a draws_out slab [n_keep][d][C] (in `mem`), on the device (the reference has no ESS / R-hat
+ * code, definitions as in mcmc_amd/ess.py).  Outputs are HOST arrays, any of them may be NULL:
+ *   mean [d]          pooled mean over draws and chains
+ *   acov [n_keep][d]  autocovariance at lag k, pooled over chains, unbiased per lag (divided by n_keep - k)
+ *   rhat [d]          Gelman-Rubin potential scale reduction over the C chains
+ *   ess  [d]          per-chain effective sample size (Geyer's initial positive sequence on acov); the many-chain ESS is
+ *                     C times it.  n_keep <= 160.  Blocking. */
+int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
+                       double* mean, double* acov, double* rhat, double* ess, void* stream);
 
 /* Diagnostics used by the GPU tests (host pointers, blocking). */
 int mi_probe_mfma_f64(const double* A16x4, const double* B4x16, const double* C16x16, double* D16x16);

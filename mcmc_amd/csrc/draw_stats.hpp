@@ -1,0 +1,75 @@
+// draw_stats.hpp -- reducers over the engine's draws_out slabs [n_keep][d][C] on the device: per dimension the
+// pooled mean, the autocovariance function pooled over chains (what ESS needs), and the Gelman-Rubin R-hat ingredients.
+// The reference has no ESS / R-hat code; these are the caller-side reductions next to the path, so that ESS/sec (the second
+// half of BASELINE.json's metric) does not need the draws on the host.  Definitions are those of mcmc_amd/ess.py.
+//
+// One wave per (dimension j, chain group g): for 64 chains at a time the centred series v[t] = x[t][j][c] - mean_j sit in
+// LDS as [t][lane] (conflict-free columns), every lane forms its own lagged products s_k = sum_t v[t] v[t+k] for all lags and
+// adds them to per-lag LDS accumulators; at the end the 64 lanes of each lag are summed with a fixed butterfly.  The host
+// adds the G partials in order: the result does not depend on scheduling.  n_keep <= 160 (two [n][64] fp64 arrays in LDS).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+constexpr int STATS_MAX_N = 160;
+
+// partial sums of x over (t, chains of group g) per dimension: out[g][j]
+__global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict__ draws, uint32_t n, uint32_t d, uint64_t C,
+                                                       uint32_t G, double* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x, g = blockIdx.y;
+    const uint64_t c_lo = (uint64_t)g * ((C + G - 1) / G), c_hi = (c_lo + (C + G - 1) / G < C) ? c_lo + (C + G - 1) / G : C;
+    double s = 0.0;
+    for (uint64_t c = c_lo + threadIdx.x; c < c_hi; c += 64)
+        for (uint32_t t = 0; t < n; ++t) s += draws[((size_t)t * d + j) * C + c];
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (threadIdx.x == 0) out[(size_t)g * d + j] = s;
+}
+
+// out[g][j][0..n): sum over the group's chains of sum_t v[t] v[t+k];  out2[g][j][0..3): sum_c m_c, sum_c m_c^2, sum_c var_c
+// (m_c = chain mean of the centred series, var_c = its unbiased variance) for R-hat
+__global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
+                                                        uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                        double* __restrict__ out, double* __restrict__ out2)
+{
+    extern __shared__ double lds[];
+    double* v = lds;                       // [n][64]
+    double* acc = lds + (size_t)n * 64;    // [n][64]
+    const uint32_t j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const uint64_t per = (C + G - 1) / G;
+    const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
+    const double mj = mean[j];
+    for (uint32_t k = 0; k < n; ++k) acc[(size_t)k * 64 + lane] = 0.0;
+    double sm = 0.0, sm2 = 0.0, sv = 0.0;
+    for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
+        const uint64_t c = c0 + lane;
+        const bool on = c < c_hi;
+        double s1 = 0.0;
+        for (uint32_t t = 0; t < n; ++t) {
+            const double x = on ? draws[((size_t)t * d + j) * C + c] - mj : 0.0;
+            v[(size_t)t * 64 + lane] = x;
+            s1 += x;
+        }
+        const double mc = s1 / (double)n;
+        double ss = 0.0;
+        for (uint32_t t = 0; t < n; ++t) { const double e = v[(size_t)t * 64 + lane] - mc; ss = __builtin_fma(e, e, ss); }
+        if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? ss / (double)(n - 1) : 0.0; }
+        for (uint32_t k = 0; k < n; ++k) {
+            double s = 0.0;
+            for (uint32_t t = 0; t + k < n; ++t) s = __builtin_fma(v[(size_t)t * 64 + lane], v[(size_t)(t + k) * 64 + lane], s);
+            acc[(size_t)k * 64 + lane] += s;   // lanes beyond the group hold zeros
+        }
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        double s = acc[(size_t)k * 64 + lane];
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) out[((size_t)g * d + j) * n + k] = s;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
+    if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+}
+
+}  // namespace mi

@@ -4,6 +4,7 @@
 // does not implement returns MI_ERR_UNSUPPORTED.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include "nuts_async.hpp"
 #include "mala_dense.hpp"
 #include "rwmh_dense.hpp"
+#include "draw_stats.hpp"
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
@@ -962,6 +964,81 @@ int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kern
     HIP_TRY(hipDeviceSynchronize());
     if (n_keep) HIP_TRY(hipMemcpy(draws_out, draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
     if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
+                       double* mean, double* acov, double* rhat, double* ess, void* stream)
+{
+    if (!draws_kdc || n_keep == 0 || d == 0 || n_chains == 0) return fail(MI_ERR_BAD_ARG, "draw_stats: empty input");
+    if (n_keep > (uint64_t)mi::STATS_MAX_N) return fail(MI_ERR_UNSUPPORTED, "draw_stats: n_keep > %d not implemented", mi::STATS_MAX_N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = n_keep, C = n_chains;
+    DevBuf staged;
+    const double* x = draws_kdc;
+    if (mem == MI_MEM_HOST) {
+        HIP_TRY(staged.alloc(n * d * C * 8));
+        HIP_TRY(hipMemcpyAsync(staged.p, draws_kdc, n * d * C * 8, hipMemcpyHostToDevice, st));
+        x = staged.as<double>();
+    }
+    const uint32_t G = (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);      // chain groups (partials are added in order on the host)
+    DevBuf sum_dev, mean_dev, acov_dev, mom_dev;
+    HIP_TRY(sum_dev.alloc((size_t)G * d * 8)); HIP_TRY(mean_dev.alloc(d * 8));
+    HIP_TRY(acov_dev.alloc((size_t)G * d * n * 8)); HIP_TRY(mom_dev.alloc((size_t)G * d * 3 * 8));
+    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, sum_dev.as<double>());
+    std::vector<double> part((size_t)G * d), mean_h(d);
+    HIP_TRY(hipMemcpyAsync(part.data(), sum_dev.p, part.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < d; ++j) {
+        double s = 0.0;
+        for (uint32_t g = 0; g < G; ++g) s += part[(size_t)g * d + j];
+        mean_h[j] = s / ((double)n * (double)C);
+    }
+    if (mean) std::memcpy(mean, mean_h.data(), d * 8);
+    if (!acov && !rhat && !ess) return MI_OK;
+    HIP_TRY(hipMemcpyAsync(mean_dev.p, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
+    const size_t lds = 2 * n * 64 * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
+                       (uint64_t)C, G, acov_dev.as<double>(), mom_dev.as<double>());
+    HIP_TRY(hipGetLastError());
+    std::vector<double> ap((size_t)G * d * n), mp((size_t)G * d * 3), ac((size_t)n * d);
+    HIP_TRY(hipMemcpyAsync(ap.data(), acov_dev.p, ap.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t j = 0; j < d; ++j)
+        for (size_t k = 0; k < n; ++k) {
+            double s = 0.0;
+            for (uint32_t g = 0; g < G; ++g) s += ap[((size_t)g * d + j) * n + k];
+            ac[k * d + j] = s / (double)C / (double)(n - k);          // pooled over chains, unbiased per lag
+        }
+    if (acov) std::memcpy(acov, ac.data(), ac.size() * 8);
+    if (rhat)
+        for (size_t j = 0; j < d; ++j) {
+            double sm = 0.0, sm2 = 0.0, sv = 0.0;
+            for (uint32_t g = 0; g < G; ++g) { const double* o = &mp[((size_t)g * d + j) * 3]; sm += o[0]; sm2 += o[1]; sv += o[2]; }
+            const double W = sv / (double)C;                                                  // mean within-chain variance
+            const double mbar = sm / (double)C;
+            const double B_over_n = (C > 1) ? (sm2 - (double)C * mbar * mbar) / (double)(C - 1) : 0.0;   // variance of the chain means
+            const double var_plus = ((double)(n - 1) / (double)n) * W + B_over_n;
+            rhat[j] = (W > 0.0) ? std::sqrt(var_plus / W) : 1.0;
+        }
+    if (ess)
+        for (size_t j = 0; j < d; ++j) {                               // Geyer's initial positive sequence (mcmc_amd/ess.py)
+            if (n < 4) { ess[j] = (double)n; continue; }
+            const double a0 = ac[j];
+            const double den = (a0 > 0.0) ? a0 : 1.0;
+            double tau = -1.0;
+            size_t t = 0;
+            while (t + 1 < n) {
+                const double pair = ac[t * d + j] / den + ac[(t + 1) * d + j] / den;
+                if (pair <= 0.0) break;
+                tau += 2.0 * pair;
+                t += 2;
+            }
+            double e = (tau > 0.0) ? (double)n / std::max(tau, 1.0 / (double)n) : (double)n;
+            ess[j] = std::min(e, (double)n * 10.0);
+        }
     return MI_OK;
 }
 
