@@ -1,5 +1,5 @@
 /*
- * mi_mcmc.h -- C ABI of the MI355X many-chain HMC / MALA / NUTS engine (libmi_mcmc.so).
+ * mi_mcmc.h -- C ABI of the MI355X many-chain HMC / MALA / NUTS (and RWMH) engine (libmi_mcmc.so).
  *
  * This is the drop-in boundary for the one hot path of kthohr/mcmc that BASELINE.json names.
  * Each entry point replaces, for C independent chains at once, one reference function:
@@ -10,7 +10,9 @@
  *                                                            /root/reference/src/mala.cpp:30-208, include/mcmc/mala.ipp:30-70
  *   mi_mcmc_nuts_*  <->  mcmc::nuts -> internal::nuts_impl  /root/reference/include/mcmc/nuts.hpp:42-48,65-72,78-85
  *                                                            /root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241
- *   mi_settings     <->  algo_settings_t + hmc_/mala_/nuts_settings_t
+ *   mi_mcmc_rwmh_*  <->  mcmc::rwmh -> internal::rwmh_impl  /root/reference/include/mcmc/rwmh.hpp:42-47,64-70,79-85
+ *                                                            /root/reference/src/rwmh.cpp:30-175
+ *   mi_settings     <->  algo_settings_t + hmc_/mala_/nuts_/rwmh_settings_t
  *                                                            /root/reference/include/misc/mcmc_structs.hpp:66-101,123-134,151-184
  *
  * The reference's std::function callback cannot run on the GPU, so the target density is
