@@ -79,8 +79,8 @@ typedef struct mi_settings {
     uint64_t n_burnin_draws;      /* default 1000 (:68) */
     uint64_t n_keep_draws;        /* default 1000 (:69) */
     uint64_t n_leap_steps;        /* hmc_settings_t::n_leap_steps, default 1 (:73) */
-    double   step_size;           /* default 1.0 (:74, :94, :130); nuts: epsilon_bar_0 */
-    const double* precond_mat;    /* d*d (host) or NULL = identity (src/hmc.cpp:57) */
+    double   step_size;           /* default 1.0 (:74, :94, :130); nuts: epsilon_bar_0; rwmh: par_scale (:145) */
+    const double* precond_mat;    /* d*d (host) or NULL = identity (src/hmc.cpp:57); rwmh: cov_mat (:146, src/rwmh.cpp:58) */
     uint64_t n_adapt_draws;       /* nuts, default 1000 (:89) */
     double   target_accept_rate;  /* nuts, default 0.55 (:90) */
     uint64_t max_tree_depth;      /* nuts, default 10 (:92) */
