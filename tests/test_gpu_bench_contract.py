@@ -1,0 +1,37 @@
+"""GPU: bench.py's output contract, at N=1 and through the N=2 code path (two ranks sharing GPU 0 over gloo: BENCH_TEST_SHARE_GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _line(out):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_gpu_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--chains", "8192", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 1 and j["steps"] == 2 and j["vs_baseline"] is None and j["dtype"] == "f64"
+    assert j["roofline"]["bound"] == "mfma" and 0.0 < j["roofline"]["frac"] < 1.0 and "workload" in j["config"]
+
+
+def test_two_rank_code_path():
+    env = dict(os.environ, BENCH_TEST_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "8192",
+           "--no-cpu-baseline", "--collate"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["chains_total"] == 2 * 8192 and j["scaling"] == "weak"
+    assert "collate_last_draw_allgather_ms" in j
