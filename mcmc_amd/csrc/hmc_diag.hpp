@@ -33,8 +33,14 @@ struct HmcDiagParams {
     uint32_t n_burnin, n_keep, n_leap_steps;
     double eps;
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
+    const double* m_sqrt;   // PRECOND: diagonal of CHOL_LOWER(precond_mat) (device, d values)
+    const double* m_inv;    // PRECOND: diagonal of INV(precond_mat)
 };
 
+// PRECOND: a diagonal precond_mat M (hmc.cpp:57-59,158-160,171,184): p = sqrt(M) z, theta += eps (Minv p), K = p.(Minv p)/2 --
+// still one independent trajectory per dimension.  (The NaN poisoning of the reference's dense products, DESIGN.md section 3,
+// is not reproduced by this kernel, with or without M.)
+template <bool PRECOND>
 __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
         if (dst == cur) { pp ^= 1u; dst = prm.scratch + (size_t)pp * slab + c; }   // never overwrite prev_draw
         double qk0[4] = {0, 0, 0, 0}, qu1[4] = {0, 0, 0, 0}, qk1[4] = {0, 0, 0, 0};
         for (uint32_t b = 0; b * 8 < d; ++b) {
-            double z[8], th[8], pm[8], lam[8], w[8];
+            double z[8], th[8], pm[8], lam[8], w[8], mi_[PRECOND ? 8 : 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * b + j, STREAM_NORMAL, z[j], z[4 + j]);
 #pragma unroll
@@ -79,16 +85,18 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
                 const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
                 th[r] = cur[(size_t)ic * C];
                 lam[r] = prec ? prec[ic] : 1.0;
-                pm[r] = z[r];                                             // p = L z, L = I (hmc.cpp:158)
+                if constexpr (PRECOND) { pm[r] = prm.m_sqrt[ic] * z[r]; mi_[r] = prm.m_inv[ic]; }   // p = L z (hmc.cpp:158)
+                else pm[r] = z[r];                                        // L = I
                 w[r] = lam[r] * th[r];
             }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (8 * b + r < d) qk0[r & 3] = dfma(pm[r], pm[r], qk0[r & 3]);
+            for (int r = 0; r < 8; ++r) if (8 * b + r < d) qk0[r & 3] = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk0[r & 3]);
             for (uint32_t k = 0; k < L; ++k) {                            // hmc.cpp:164-176
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     pm[r] = pm[r] - (eps * w[r]) / 2.0;
-                    th[r] = th[r] + eps * pm[r];
+                    if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
+                    else th[r] = th[r] + eps * pm[r];
                     w[r] = lam[r] * th[r];
                     pm[r] = pm[r] - (eps * w[r]) / 2.0;
                 }
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
                 const uint32_t i = 8 * b + r;
                 if (i < d) {
                     qu1[r & 3] = dfma(th[r], w[r], qu1[r & 3]);
-                    qk1[r & 3] = dfma(pm[r], pm[r], qk1[r & 3]);
+                    qk1[r & 3] = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk1[r & 3]);
                     dst[(size_t)i * C] = th[r];
                 }
             }

@@ -448,7 +448,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     std::vector<double> m_sqrt, m_inv;
     bool dense_m = false;
     if (settings->precond_mat) {
-        if (d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with d > 128 is not implemented");
+        if (d > 128 && !(target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG))
+            return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with d > 128 is implemented for the separable Gaussian targets only");
         m_sqrt.resize(d); m_inv.resize(d);
         for (uint64_t i = 0; i < d; ++i)
             for (uint64_t k = 0; k < d; ++k) {
@@ -463,13 +464,17 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
     if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
         return fail(MI_ERR_BAD_ARG, "hmc: vals_bound needs lower_bounds and upper_bounds");
-    if (bounded && d > 128) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound with d > 128 is not implemented");
+    const bool separable_kind = target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG;
+    // separable target + diagonal precond_mat (no bounds): the elementwise kernel, any d
+    const bool diag_precond_elementwise = separable_kind && !settings->vals_bound && settings->precond_mat && !dense_m && d > 128;
+    if (bounded && d > 128 && !diag_precond_elementwise) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound with d > 128 is not implemented");
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     const bool separable = target->kind != MI_TARGET_GAUSS_DENSE;
     const bool force_diag = !bounded && getenv("MI_HMC_FORCE_DIAG") != nullptr;   // tests: same bits from both kernels
     if (d > 128 && !separable)
         return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
     if (separable && (d > 128 || force_diag)) {
+        if (dense_m) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 64");
         // no contraction: the elementwise (lane-per-chain) kernel
         DevBuf prec_owned;
         const double* prec_dev = nullptr;
@@ -496,7 +501,17 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), &scratch);
         if (rc) return rc;
         q.scratch = static_cast<double*>(scratch);
-        hipLaunchKernelGGL(mi::hmc_diag_kernel, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+        DevBuf ms_d, mi_d;
+        if (diag_precond_elementwise) {
+            HIP_TRY(ms_d.alloc(d * 8)); HIP_TRY(mi_d.alloc(d * 8));
+            HIP_TRY(hipMemcpy(ms_d.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(mi_d.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
+            q.m_sqrt = ms_d.as<double>(); q.m_inv = mi_d.as<double>();
+            hipLaunchKernelGGL(mi::hmc_diag_kernel<true>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
+        } else
+        hipLaunchKernelGGL(mi::hmc_diag_kernel<false>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;

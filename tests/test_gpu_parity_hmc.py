@@ -338,3 +338,19 @@ def test_hmc_logistic_bit_exact_vs_oracle(d, N, C, eps, L, burn, keep):
     o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=5)
     assert np.array_equal(g["n_accept"], o["n_accept"])
     assert np.array_equal(g_draws, o_draws)
+
+
+# ---------------------------------------------------------------- diagonal precond_mat on the elementwise kernel (any d)
+@pytest.mark.parametrize("kind,d,C,L,eps", [("diag", 200, 70, 6, 0.2), ("iso", 1024, 33, 4, 0.08), ("diag", 129, 300, 3, 0.1)])
+def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps):
+    prec = synth.ill_conditioned_diag(d, 50.0) if kind == "diag" else None
+    M = np.diag((prec if prec is not None else np.ones(d)) * np.linspace(0.7, 1.4, d))   # mass matrix ~ the precision: every dimension at unit frequency
+    init = synth.initial_states(C, d, seed=18) * 0.5
+    st = mcmc_amd.default_settings(rng_seed_value=12, n_burnin_draws=2, n_keep_draws=6, n_leap_steps=L, step_size=eps, precond_mat=M)
+    k_gpu, k_orc = (mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG) if kind == "diag" else (mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)
+    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=6)
+    t = orc.TargetSpec(k_orc, d, prec=prec, W=4)
+    s = orc.make_settings(seed=12, n_burnin=2, n_keep=6, n_leap=L, step=eps, W=4, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=6)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert g["n_accept"].sum() > 0
