@@ -1,8 +1,8 @@
 """Randomised parity sweep: every device sampler against the oracle on random small cases (bit-exact or report).
-Usage (GPU box): python tools/fuzz_parity.py [n_cases] [seed]"""
+Usage (GPU box): python tests/fuzz_parity.py [n_cases] [seed]   (test infrastructure: it drives the oracle)"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import mcmc_amd, orc
 from mcmc_amd import synth

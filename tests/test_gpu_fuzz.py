@@ -1,4 +1,4 @@
-"""GPU: randomised parity sweep (tools/fuzz_parity.py) -- every device sampler against the oracle on random small cases:
+"""GPU: randomised parity sweep (tests/fuzz_parity.py) -- every device sampler against the oracle on random small cases:
 three samplers x four targets x bounds / diagonal precond / degenerate sizes / step sizes that blow the chain up."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [7, 11])
