@@ -30,6 +30,10 @@
 #define MI_HMC_RNG_STAGED 0
 #endif
 
+#ifndef MI_HMC_WPB
+#define MI_HMC_WPB 8     // waves per workgroup of the plain kernel (two per SIMD)
+#endif
+
 namespace mi {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));

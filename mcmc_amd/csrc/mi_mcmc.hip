@@ -16,9 +16,6 @@
 #include <vector>
 
 #include "../../include/mi_mcmc.h"
-#ifndef MI_HMC_WPB
-#define MI_HMC_WPB 8
-#endif
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
@@ -29,6 +26,7 @@
 #include "callback_mode.hpp"
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
+#include "launchers.hpp"
 
 namespace {
 
@@ -284,89 +282,10 @@ int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTab
     return MI_OK;
 }
 
-template <int NT, bool GENERAL, bool DENSE_C>
-int launch_rwmh_mfma(const mi::RwmhParams& prm, hipStream_t st)
+// Kernel families live in their own translation units (launchers.hpp); these wrappers turn their hipError_t into a status.
+int launched(const char* what, int hip_err)
 {
-    const size_t mat = (size_t)NT * 4 * NT * 64 * sizeof(double);
-    const size_t lds = mat * (DENSE_C ? 2 : 1) + (GENERAL ? (size_t)16 * NT * (3 * sizeof(double) + sizeof(int)) : 0);
-    auto kern = mi::rwmh_gauss_mfma_kernel<NT, GENERAL, DENSE_C>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NT>
-int launch_mala_dense_m(const mi::MalaParams& prm, hipStream_t st)
-{
-    const size_t lds = (size_t)4 * NT * 4 * NT * 64 * sizeof(double);
-    auto kern = mi::mala_gauss_dense_m_kernel<NT>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NT, bool GENERAL>
-int launch_mala_mfma(const mi::MalaParams& prm, hipStream_t st)
-{
-    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
-    auto kern = mi::mala_gauss_mfma_kernel<NT, GENERAL>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NT, bool GENERAL, bool DENSE_M = false>
-int launch_nuts_mfma(const mi::NutsParams& prm, hipStream_t st)
-{
-    const size_t lds = ((size_t)NT * 4 * NT * 64 * (DENSE_M ? 3 : 1) + (size_t)mi::NUTS_LVLS * 4 * 64) * sizeof(double)
-                     + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
-    const unsigned grid = (unsigned)((prm.C + 63) / 64);
-    if (!GENERAL && getenv("MI_NUTS_LOCKSTEP")) {   // first-generation kernel: chains of a wave in lock-step per draw
-        auto kern = mi::nuts_gauss_mfma_kernel<NT>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm);
-    } else {
-        uint32_t batch = 8;
-        if (const char* e = getenv("MI_NUTS_BATCH")) batch = (uint32_t)atoi(e);
-        if (batch < 1) batch = 1;
-        auto kern = mi::nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prm, batch);
-    }
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NT, bool DENSE_M = false>
-int launch_hmc_mfma_bounded(const mi::HmcParams& prm, hipStream_t st)
-{
-    constexpr int WPB = 4;      // one wave per SIMD: the bounded variant holds two more register-resident vectors
-    const size_t mat = (size_t)NT * 4 * NT * 64 * sizeof(double);
-    const size_t lds = mat * (DENSE_M ? 3 : 1) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
-    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB, true, DENSE_M>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-template <int NT>
-int launch_hmc_mfma(const mi::HmcParams& prm, hipStream_t st)
-{
-    constexpr int WPB = MI_HMC_WPB;
-    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
-    auto kern = mi::hmc_gauss_mfma_kernel<NT, WPB>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
-    HIP_TRY(hipGetLastError());
+    if (hip_err != 0) return fail(MI_ERR_HIP, "%s kernel launch: %s", what, hipGetErrorString((hipError_t)hip_err));
     return MI_OK;
 }
 
@@ -585,20 +504,11 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             HIP_TRY(hipMemcpy(minv_dev.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(l_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
             prm.Minv = minv_dev.as<double>(); prm.Lchol = l_dev.as<double>();
-            if (nt <= 1) rc = launch_hmc_mfma_bounded<1, true>(prm, st);
-            else if (nt == 2) rc = launch_hmc_mfma_bounded<2, true>(prm, st);
-            else rc = launch_hmc_mfma_bounded<4, true>(prm, st);
         }
-        else if (nt <= 1) rc = launch_hmc_mfma_bounded<1>(prm, st);
-        else if (nt == 2) rc = launch_hmc_mfma_bounded<2>(prm, st);
-        else if (nt <= 4) rc = launch_hmc_mfma_bounded<4>(prm, st);
-        else rc = launch_hmc_mfma_bounded<8>(prm, st);
+        rc = launched("hmc", mi::launch_hmc_gauss(prm, nt, true, dense_m, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // bounds buffers are ours
     }
-    else if (nt <= 1) rc = launch_hmc_mfma<1>(prm, st);
-    else if (nt == 2) rc = launch_hmc_mfma<2>(prm, st);
-    else if (nt <= 4) rc = launch_hmc_mfma<4>(prm, st);
-    else rc = launch_hmc_mfma<8>(prm, st);
+    else rc = launched("hmc", mi::launch_hmc_gauss(prm, nt, false, false, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -713,9 +623,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         HIP_TRY(hipMemcpy(m_full.p, settings->precond_mat, d * d * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(sinv_full.p, Sinv.data(), d * d * 8, hipMemcpyHostToDevice));
         prm.Mfull = m_full.as<double>(); prm.Lchol = gt.l_full.as<double>(); prm.Sinv = sinv_full.as<double>();
-        if (nt <= 1) rc = launch_mala_dense_m<1>(prm, st);
-        else if (nt == 2) rc = launch_mala_dense_m<2>(prm, st);
-        else rc = launch_mala_dense_m<4>(prm, st);
+        rc = launched("mala", mi::launch_mala_gauss(prm, nt, 2, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the matrices are ours
     }
     else if (gt.active) {
@@ -726,16 +634,10 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         prm.vals_bound = settings->vals_bound ? 1 : 0;
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m = gt.m_dev.as<double>(); prm.m_sqrt = gt.ms_dev.as<double>();
-        if (nt <= 1) rc = launch_mala_mfma<1, true>(prm, st);
-        else if (nt == 2) rc = launch_mala_mfma<2, true>(prm, st);
-        else if (nt <= 4) rc = launch_mala_mfma<4, true>(prm, st);
-        else rc = launch_mala_mfma<8, true>(prm, st);
+        rc = launched("mala", mi::launch_mala_gauss(prm, nt, 1, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else if (nt <= 1) rc = launch_mala_mfma<1, false>(prm, st);
-    else if (nt == 2) rc = launch_mala_mfma<2, false>(prm, st);
-    else if (nt <= 4) rc = launch_mala_mfma<4, false>(prm, st);
-    else rc = launch_mala_mfma<8, false>(prm, st);
+    else rc = launched("mala", mi::launch_mala_gauss(prm, nt, 0, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -793,20 +695,11 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
             HIP_TRY(lc_dev.alloc(d * d * 8));
             HIP_TRY(hipMemcpy(lc_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
             prm.Lc = lc_dev.as<double>();
-            if (nt <= 1) rc = launch_rwmh_mfma<1, true, true>(prm, st);
-            else if (nt == 2) rc = launch_rwmh_mfma<2, true, true>(prm, st);
-            else rc = launch_rwmh_mfma<4, true, true>(prm, st);
         }
-        else if (nt <= 1) rc = launch_rwmh_mfma<1, true, false>(prm, st);
-        else if (nt == 2) rc = launch_rwmh_mfma<2, true, false>(prm, st);
-        else if (nt <= 4) rc = launch_rwmh_mfma<4, true, false>(prm, st);
-        else rc = launch_rwmh_mfma<8, true, false>(prm, st);
+        rc = launched("rwmh", mi::launch_rwmh_gauss(prm, nt, true, gt.dense, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else if (nt <= 1) rc = launch_rwmh_mfma<1, false, false>(prm, st);
-    else if (nt == 2) rc = launch_rwmh_mfma<2, false, false>(prm, st);
-    else if (nt <= 4) rc = launch_rwmh_mfma<4, false, false>(prm, st);
-    else rc = launch_rwmh_mfma<8, false, false>(prm, st);
+    else rc = launched("rwmh", mi::launch_rwmh_gauss(prm, nt, false, false, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
@@ -877,6 +770,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
+    uint32_t nuts_batch = 8;                 // momentum-refresh batch of the asynchronous kernel
+    if (const char* e = getenv("MI_NUTS_BATCH")) nuts_batch = (uint32_t)atoi(e);
     rc = general_tables("nuts", settings, d, gt, true);
     if (rc) return rc;
     if (gt.active && gt.dense) {
@@ -884,25 +779,17 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
         prm.Minv = gt.minv_full.as<double>(); prm.Lchol = gt.l_full.as<double>();
         prm.vals_bound = settings->vals_bound ? 1 : 0;
-        if (nt <= 1) rc = launch_nuts_mfma<1, true, true>(prm, st);
-        else if (nt == 2) rc = launch_nuts_mfma<2, true, true>(prm, st);
-        else rc = launch_nuts_mfma<4, true, true>(prm, st);
+        rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, true, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
     else if (gt.active) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
         prm.vals_bound = settings->vals_bound ? 1 : 0;
-        if (nt <= 1) rc = launch_nuts_mfma<1, true>(prm, st);
-        else if (nt == 2) rc = launch_nuts_mfma<2, true>(prm, st);
-        else if (nt <= 4) rc = launch_nuts_mfma<4, true>(prm, st);
-        else rc = launch_nuts_mfma<8, true>(prm, st);
+        rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, false, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else if (nt <= 1) rc = launch_nuts_mfma<1, false>(prm, st);
-    else if (nt == 2) rc = launch_nuts_mfma<2, false>(prm, st);
-    else if (nt <= 4) rc = launch_nuts_mfma<4, false>(prm, st);
-    else rc = launch_nuts_mfma<8, false>(prm, st);
+    else rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, getenv("MI_NUTS_LOCKSTEP") != nullptr, nuts_batch, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
