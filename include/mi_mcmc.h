@@ -12,6 +12,7 @@
  *                                                            /root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241
  *   mi_mcmc_rwmh_*  <->  mcmc::rwmh -> internal::rwmh_impl  /root/reference/include/mcmc/rwmh.hpp:42-47,64-70,79-85
  *                                                            /root/reference/src/rwmh.cpp:30-175
+ *   mi_mcmc_rmhmc_* <->  mcmc::rmhmc -> internal::rmhmc_impl /root/reference/include/mcmc/rmhmc.hpp, src/rmhmc.cpp:30-287
  *   mi_settings     <->  algo_settings_t + hmc_/mala_/nuts_/rwmh_settings_t
  *                                                            /root/reference/include/misc/mcmc_structs.hpp:66-101,123-134,151-184
  *
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000103
+#define MI_MCMC_VERSION 0x000104
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -51,7 +52,11 @@ typedef enum mi_target_kind {
     MI_TARGET_GAUSS_ISO = 1,    /* log K = -1/2 |theta|^2 */
     MI_TARGET_GAUSS_DIAG = 2,   /* log K = -1/2 sum_i prec_i theta_i^2;       prec: d values */
     MI_TARGET_GAUSS_DENSE = 3,  /* log K = -1/2 theta^T P theta;              prec: d*d, symmetric, row-major */
-    MI_TARGET_LOGISTIC = 4      /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta */
+    MI_TARGET_LOGISTIC = 4,     /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta */
+    MI_TARGET_NORMAL_MODEL = 5  /* d = 2, vals = (mu, sigma), observations x_1..x_n in y[0..n_rows): the model of the reference's
+                                 * example programs (/root/reference/examples/eigen/rmhmc_normal.cpp:44-106),
+                                 * log K = -n (log(2 pi)/2 + log sigma) - sum_r (x_r - mu)^2 / (2 sigma^2); its metric tensor for
+                                 * rmhmc is the Fisher information diag(n / sigma^2, 2 n / sigma^2).  rmhmc only. */
 } mi_target_kind;
 
 typedef enum mi_mem { MI_MEM_HOST = 0, MI_MEM_DEVICE = 1 } mi_mem;
@@ -87,6 +92,7 @@ typedef struct mi_settings {
     double   gamma_val;           /* 0.05 (:95) */
     double   t0_val;              /* 10 (:96) */
     double   kappa_val;           /* 0.75 (:97) */
+    uint64_t n_fp_steps;          /* rmhmc_settings_t::n_fp_steps, default 5 (:116) */
 } mi_settings;
 
 /* One shard of chains. All pointers live in `mem` (host or device). */
@@ -122,6 +128,11 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 /* mcmc::rwmh (/root/reference/include/mcmc/rwmh.hpp, src/rwmh.cpp:30-175) for many chains: settings->step_size carries
  * rwmh_settings_t::par_scale (mcmc_structs.hpp:145) and settings->precond_mat carries rwmh_settings_t::cov_mat (:146). */
 int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
+
+/* mcmc::rmhmc (/root/reference/include/mcmc/rmhmc.hpp, src/rmhmc.cpp:30-287) for many chains.  The reference takes the metric
+ * tensor as a second callback (tensor_fn); here it is the one tied to the target kind (see mi_target_kind).  Reads
+ * n_leap_steps, step_size, n_fp_steps, vals_bound / bounds from the settings; there is no precond_mat in rmhmc. */
+int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 
 /* Host-callback form of mcmc::hmc for ONE chain: the reference's own target contract
  * (std::function<fp_t(const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>, hmc.hpp:42-48)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi_mcmc.so")
 
 MI_OK, MI_ERR_BAD_ARG, MI_ERR_HIP, MI_ERR_UNSUPPORTED, MI_ERR_OOM, MI_ERR_NO_DEVICE = range(6)
-TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC = 1, 2, 3, 4
+TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_NORMAL_MODEL = 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -38,7 +38,7 @@ class mi_settings(C.Structure):
                 ("step_size", C.c_double), ("precond_mat", C.c_void_p),
                 ("n_adapt_draws", C.c_uint64), ("target_accept_rate", C.c_double),
                 ("max_tree_depth", C.c_uint64), ("gamma_val", C.c_double),
-                ("t0_val", C.c_double), ("kappa_val", C.c_double)]
+                ("t0_val", C.c_double), ("kappa_val", C.c_double), ("n_fp_steps", C.c_uint64)]
 
 
 class mi_chains(C.Structure):
@@ -58,7 +58,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_hmc_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -119,7 +119,7 @@ def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST):
         y = None if y is None else np.ascontiguousarray(y, dtype=np.float64)
     keep += [prec, X, y]
     t.prec, t.X, t.y = _ptr(prec), _ptr(X), _ptr(y)
-    t.n_rows = 0 if X is None else int(X.shape[0])
+    t.n_rows = int(X.shape[0]) if X is not None else (int(y.shape[0]) if (y is not None and kind == TARGET_NORMAL_MODEL) else 0)
     t._keep = keep
     return t
 
@@ -135,7 +135,8 @@ def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=
     return c
 
 
-_RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run", "rwmh": "mi_mcmc_rwmh_run"}
+_RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run", "rwmh": "mi_mcmc_rwmh_run",
+        "rmhmc": "mi_mcmc_rmhmc_run"}
 
 
 def run(algo, target, settings, chains, stream=None):
@@ -180,6 +181,11 @@ def nuts(kind, init, settings, **kw):
 def rwmh(kind, init, settings, **kw):
     """mcmc::rwmh: settings.step_size carries par_scale, settings.precond_mat carries cov_mat."""
     return sample("rwmh", kind, init, settings, **kw)
+
+
+def rmhmc(kind, init, settings, **kw):
+    """mcmc::rmhmc with the metric tensor built into the target kind (TARGET_NORMAL_MODEL: Fisher information)."""
+    return sample("rmhmc", kind, init, settings, **kw)
 
 
 LOG_KERNEL_CB = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)

@@ -1,6 +1,6 @@
 // launchers.hpp -- host-side interface between the C ABI (mi_mcmc.hip) and the kernel translation units.
 // Every kernel family is compiled in its own .hip file (hmc_launch.hip, mala_launch.hip, nuts_launch.hip, rwmh_launch.hip,
-// logistic_lds.hip) so that the gfx950 code generation of the ~50 template instantiations runs in parallel; the functions
+// small_launch.hip, logistic_lds.hip) so that the gfx950 code generation of the ~50 template instantiations runs in parallel; the functions
 // below pick the instantiation for (padded dimension tiles nt, variant) and enqueue it on `st`.
 // Return value: a hipError_t as int (0 = enqueued).
 #pragma once
@@ -13,6 +13,7 @@ struct HmcParams;
 struct MalaParams;
 struct NutsParams;
 struct RwmhParams;
+struct SmallParams;
 
 // nt = ceil(d / 16) in {1, 2, 3..4, 5..8}; general: bounds and / or diagonal precond; dense_m: dense precond (nt <= 4)
 int launch_hmc_gauss(const HmcParams& prm, int nt, bool general, bool dense_m, hipStream_t st);
@@ -21,5 +22,7 @@ int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);
+// one lane per chain, d = 2 normal model (rmhmc_small.hpp)
+int launch_rmhmc_normal_model(const SmallParams& prm, hipStream_t st);
 
 }  // namespace mi

@@ -27,6 +27,7 @@
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
 #include "launchers.hpp"
+#include "rmhmc_small.hpp"
 
 namespace {
 
@@ -309,6 +310,7 @@ void mi_settings_default(mi_settings* s)
     s->gamma_val = 0.05;
     s->t0_val = 10.0;
     s->kappa_val = 0.75;
+    s->n_fp_steps = 5;
 }
 
 const char* mi_mcmc_last_error(void) { return g_last_error.c_str(); }
@@ -805,6 +807,56 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         fprintf(stderr, "[nuts prof] ticks %llu, active chain-ticks %llu (%.2f of 16 per tick), refresh phases %llu, fin blocks %llu\n", h[8], h[9], (double)h[9] / (h[8] ? h[8] : 1), h[10], h[11]);
     }
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// mcmc::rmhmc (src/rmhmc.cpp:30-287) for many chains of a small-dimensional target with a built-in metric tensor.
+int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t d = target->d;
+    if (target->kind != MI_TARGET_NORMAL_MODEL)
+        return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path", target->kind);
+    if (d != 2) return fail(MI_ERR_BAD_ARG, "rmhmc: NORMAL_MODEL has d = 2 (mu, sigma)");
+    if (!target->y || target->n_rows == 0 || target->n_rows > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "NORMAL_MODEL needs its observations in y[0..n_rows)");
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
+        return fail(MI_ERR_BAD_ARG, "rmhmc: vals_bound needs lower_bounds and upper_bounds");
+
+    DevBuf x_owned;
+    const double* x_dev = target->y;
+    if (target->mem == MI_MEM_HOST) {
+        HIP_TRY(x_owned.alloc(target->n_rows * sizeof(double)));
+        HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
+        x_dev = x_owned.as<double>();
+    }
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+
+    mi::SmallParams prm{};
+    prm.data = x_dev; prm.n_rows = (uint32_t)target->n_rows; prm.d = (uint32_t)d;
+    prm.C = chains->n_chains; prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta; prm.draws = sc.dev.draws; prm.n_accept = sc.dev.n_accept; prm.n_leap = sc.dev.n_leapfrogs;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws; prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.n_leap_steps = (uint32_t)settings->n_leap_steps; prm.n_fp_steps = (uint32_t)settings->n_fp_steps;
+    prm.draw0 = (uint32_t)chains->draw0;
+    prm.eps = settings->step_size;
+    prm.vals_bound = settings->vals_bound ? 1 : 0;
+    for (uint64_t i = 0; i < 4; ++i) { prm.btype[i] = 1; prm.lb[i] = 0.0; prm.ub[i] = 0.0; }
+    if (settings->vals_bound)
+        for (uint64_t i = 0; i < d; ++i) {       // determine_bounds_type.hpp:27-57
+            prm.lb[i] = settings->lower_bounds[i]; prm.ub[i] = settings->upper_bounds[i];
+            const bool fl = std::isfinite(prm.lb[i]), fu = std::isfinite(prm.ub[i]);
+            prm.btype[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+        }
+    rc = launched("rmhmc", mi::launch_rmhmc_normal_model(prm, st));
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (x_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 

@@ -372,7 +372,49 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
         free(eta);
         return ret;
     }
+    case ORC_TARGET_NORMAL_MODEL: {
+        /* the user code of the reference's examples (ref: examples/eigen/rmhmc_normal.cpp:44-73), restated with plain
+         * sequential sums over the data:  m1 = sum (x - mu),  m2 = sum (x - mu)^2 */
+        const double mu = th[0], sigma = th[1];
+        const double n = (double)t->n_rows;
+        double m1 = 0.0, m2 = 0.0;
+        for (size_t r = 0; r < t->n_rows; ++r) {
+            const double e = t->y[r] - mu;
+            m1 = m1 + e;
+            m2 = fma(e, e, m2);
+        }
+        const double s2 = sigma * sigma;
+        const double ret = -(n * (0.5 * ORC_LOG_2PI + orc_log(sigma))) - m2 / (2.0 * s2);
+        if (grad_out) {
+            grad_out[0] = m1 / s2;
+            grad_out[1] = m2 / (s2 * sigma) - n / sigma;
+        }
+        return ret;
+    }
     default: return NAN;
+    }
+}
+
+void orc_target_tensor(const double* th, double* G, double* dG, void* data)
+{
+    const orc_target* t = (const orc_target*)data;
+    const size_t d = t->d;
+    for (size_t i = 0; i < d * d; ++i) G[i] = 0.0;
+    if (dG) for (size_t i = 0; i < d * d * d; ++i) dG[i] = 0.0;
+    switch (t->kind) {
+    case ORC_TARGET_GAUSS_ISO:  for (size_t i = 0; i < d; ++i) G[i * d + i] = 1.0; break;
+    case ORC_TARGET_GAUSS_DIAG: for (size_t i = 0; i < d; ++i) G[i * d + i] = t->prec[i]; break;
+    case ORC_TARGET_GAUSS_DENSE: for (size_t i = 0; i < d * d; ++i) G[i] = t->prec[i]; break;
+    case ORC_TARGET_NORMAL_MODEL: {                       /* ref: examples/eigen/rmhmc_normal.cpp:75-106 */
+        const double sigma = th[1];
+        const double n = (double)t->n_rows;
+        const double s2 = sigma * sigma;
+        G[0] = n / s2;
+        G[3] = (2.0 * n) / s2;
+        if (dG) for (size_t i = 0; i < 4; ++i) dG[4 + i] = (-2.0 * G[i]) / sigma;    /* mat(1) = -2 G / sigma; mat(0) = 0 */
+        break;
+    }
+    default: for (size_t i = 0; i < d * d; ++i) G[i] = NAN;
     }
 }
 
@@ -1017,6 +1059,187 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
     return 0;
 }
 
+/* ------------------------------------------------------------------ RM-HMC */
+
+typedef struct rm_ctx {
+    orc_ctx* c;
+    orc_tensor_fn tensor;
+    void* tensor_data;
+} rm_ctx;
+
+/* box_tensor_fn lambda (ref: src/rmhmc.cpp:152-164) */
+static void box_tensor(rm_ctx* r, const double* vals, double* G, double* dG)
+{
+    orc_ctx* c = r->c;
+    if (c->vals_bound) {
+        double* vi = dvec(c->d);
+        orc_inv_transform(vals, c->btype, c->lb, c->ub, c->d, vi);
+        r->tensor(vi, G, dG, r->tensor_data);
+        free(vi);
+    } else r->tensor(vals, G, dG, r->tensor_data);
+}
+
+/* mntm_update_fn lambda (ref: src/rmhmc.cpp:99-150): returns the INCREMENT step * [J] grad_obj / 2 in out.
+ *   grad_obj(i) = -grad(i) + 0.5 * ( trace(T_i) - dot(T_i^T p, Ginv p) ),  T_i = Ginv * dG_i       (:112-116, :135-139)
+ * all sums sequential, index ascending; products with fma as in orc_gemv / orc_matmul. */
+static void rm_mntm_update(rm_ctx* r, const double* pos, const double* mntm, double step, const double* Ginv,
+                           const double* dG, double* out)
+{
+    orc_ctx* c = r->c;
+    const size_t d = c->d;
+    double* grad = dvec(d);
+    double* gobj = dvec(d);
+    double* T = dvec(d * d);
+    double* a = dvec(d);
+    double* b = dvec(d);
+    if (c->vals_bound) {
+        double* pi = dvec(d);
+        orc_inv_transform(pos, c->btype, c->lb, c->ub, d, pi);         /* :107 */
+        c->kernel(pi, grad, c->data);                                  /* :108 */
+        free(pi);
+    } else c->kernel(pos, grad, c->data);                              /* :131 */
+    for (size_t i = 0; i < d; ++i) {
+        orc_matmul(Ginv, dG + i * d * d, d, T);                        /* tmp_mat = inv_tensor_mat * tensor_deriv.mat(i) */
+        double tr = 0.0;
+        for (size_t j = 0; j < d; ++j) tr = tr + T[j * d + j];
+        for (size_t j = 0; j < d; ++j) {                               /* a = T^T p */
+            double acc = 0.0;
+            for (size_t k = 0; k < d; ++k) acc = fma(T[k * d + j], mntm[k], acc);
+            a[j] = acc;
+        }
+        orc_gemv(Ginv, mntm, d, b);                                    /* b = Ginv p */
+        double dp = 0.0;
+        for (size_t j = 0; j < d; ++j) dp = fma(a[j], b[j], dp);
+        gobj[i] = -grad[i] + 0.5 * (tr - dp);
+    }
+    if (c->vals_bound) {
+        double* J = dvec(d * d);
+        double* jg = dvec(d);
+        orc_inv_jacobian_adjust(pos, c->btype, c->lb, c->ub, d, J);    /* :121 */
+        orc_gemv(J, gobj, d, jg);
+        for (size_t i = 0; i < d; ++i) out[i] = (step * jg[i]) / 2.0;  /* :129 */
+        free(J); free(jg);
+    } else {
+        for (size_t i = 0; i < d; ++i) out[i] = (step * gobj[i]) / 2.0;   /* :145 */
+    }
+    free(grad); free(gobj); free(T); free(a); free(b);
+}
+
+/* ref: src/rmhmc.cpp:30-287.  The reference draws one extra normal vector before the loop (:184) whose values are never
+ * used; with the counter-based generator nothing needs to be consumed for it. */
+int orc_rmhmc(const double* initial_vals, size_t d, orc_kernel_fn kernel, orc_tensor_fn tensor, void* data, void* tensor_data,
+              const orc_settings* s, double* draws_out, orc_stats* st)
+{
+    orc_ctx c;
+    orc_settings s0 = *s;
+    s0.precond_mat = NULL;                                              /* rmhmc has no precond_mat */
+    ctx_init(&c, d, kernel, data, &s0, 0);
+    rm_ctx r = { &c, tensor, tensor_data };
+    const size_t n_burnin = s->n_burnin_draws, n_keep = s->n_keep_draws, n_total = n_burnin + n_keep;
+    const double step_size = s->step_size;
+    const size_t n_leap_steps = s->n_leap_steps, n_fp_steps = s->n_fp_steps;
+    const size_t dd = d * d;
+
+    double* first_draw = dvec(d);
+    memcpy(first_draw, initial_vals, d * sizeof(double));
+    if (c.vals_bound) orc_transform(initial_vals, c.btype, c.lb, c.ub, d, first_draw);   /* :170-172 */
+
+    double* prev_draw = dvec(d); memcpy(prev_draw, first_draw, d * sizeof(double));
+    double* new_draw = dvec(d);  memcpy(new_draw, first_draw, d * sizeof(double));
+    double* prop_draw = dvec(d);
+    double* new_mntm = dvec(d);
+    double* prop_mntm = dvec(d);
+    double* incr = dvec(d);
+    double* rand_vec = dvec(d);
+    double* tmpv = dvec(d);
+    double* new_tensor = dvec(dd); double* prev_tensor = dvec(dd);
+    double* inv_new = dvec(dd);    double* inv_prev = dvec(dd);
+    double* new_deriv = dvec(dd * d); double* prev_deriv = dvec(dd * d);
+    double* L = dvec(dd); double* S = dvec(dd); double* Tn = dvec(dd);
+
+    box_tensor(&r, new_draw, new_tensor, new_deriv);                    /* :187 */
+    memcpy(prev_tensor, new_tensor, dd * sizeof(double));
+    orc_inv(new_tensor, d, inv_new);                                    /* :190 */
+    memcpy(inv_prev, inv_new, dd * sizeof(double));
+    memcpy(prev_deriv, new_deriv, dd * d * sizeof(double));
+
+    const double cons_term = 0.5 * (double)d * ORC_LOG_2PI;             /* :195 */
+    orc_chol_lower(new_tensor, d, L);
+    double prev_U = cons_term - box_log_kernel(&c, first_draw) + 0.5 * orc_log_det_from_chol(L, d);   /* :197 */
+    double prop_U = prev_U, prop_K, prev_K;
+    size_t n_accept = 0;
+
+    for (size_t draw_ind = 0; draw_ind < n_total; ++draw_ind) {         /* :206 */
+        orc_rng_normal_vec(c.seed, c.chain, (uint32_t)draw_ind, ORC_STREAM_NORMAL, d, rand_vec);   /* :207 */
+        orc_chol_lower(prev_tensor, d, L);
+        orc_gemv(L, rand_vec, d, new_mntm);                             /* :209 */
+        orc_gemv(inv_prev, new_mntm, d, tmpv);
+        prev_K = 0.0;
+        for (size_t i = 0; i < d; ++i) prev_K = fma(new_mntm[i], tmpv[i], prev_K);
+        prev_K = prev_K / 2.0;                                          /* :211 */
+        memcpy(new_draw, prev_draw, d * sizeof(double));                /* :213 */
+
+        for (size_t k = 0; k < n_leap_steps; ++k) {                     /* :215 */
+            memcpy(prop_mntm, new_mntm, d * sizeof(double));
+            for (size_t kk = 0; kk < n_fp_steps; ++kk) {                /* :220-222 */
+                rm_mntm_update(&r, new_draw, prop_mntm, step_size, inv_prev, prev_deriv, incr);
+                for (size_t i = 0; i < d; ++i) prop_mntm[i] = new_mntm[i] + incr[i];
+            }
+            memcpy(new_mntm, prop_mntm, d * sizeof(double));            /* :224 */
+
+            memcpy(prop_draw, new_draw, d * sizeof(double));            /* :228 */
+            for (size_t kk = 0; kk < n_fp_steps; ++kk) {                /* :231-235 */
+                box_tensor(&r, prop_draw, Tn, NULL);
+                orc_inv(Tn, d, inv_new);
+                for (size_t i = 0; i < dd; ++i) S[i] = inv_prev[i] + inv_new[i];
+                orc_gemv(S, new_mntm, d, tmpv);
+                for (size_t i = 0; i < d; ++i) prop_draw[i] = new_draw[i] + (0.5 * step_size) * tmpv[i];
+            }
+            memcpy(new_draw, prop_draw, d * sizeof(double));            /* :237 */
+
+            box_tensor(&r, new_draw, new_tensor, new_deriv);            /* :239 */
+            orc_inv(new_tensor, d, inv_new);                            /* :240 */
+            rm_mntm_update(&r, new_draw, new_mntm, step_size, inv_new, new_deriv, incr);   /* :244 */
+            for (size_t i = 0; i < d; ++i) new_mntm[i] = new_mntm[i] + incr[i];
+            c.n_leap++;
+        }
+
+        orc_chol_lower(new_tensor, d, L);
+        prop_U = cons_term - box_log_kernel(&c, new_draw) + 0.5 * orc_log_det_from_chol(L, d);   /* :247 */
+        if (!isfinite(prop_U)) prop_U = INFINITY;                       /* :249-251 */
+        orc_gemv(inv_new, new_mntm, d, tmpv);
+        prop_K = 0.0;
+        for (size_t i = 0; i < d; ++i) prop_K = fma(new_mntm[i], tmpv[i], prop_K);
+        prop_K = prop_K / 2.0;                                          /* :253 */
+
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;                  /* std::min(0.01, x) :257 */
+        const double z = orc_rng_uniform(c.seed, c.chain, (uint32_t)draw_ind, 0);   /* :258 */
+        int acc = 0;
+        if (z < orc_exp(comp_val)) {                                    /* :260 */
+            memcpy(prev_draw, new_draw, d * sizeof(double));
+            prev_U = prop_U;
+            prev_K = prop_K;
+            memcpy(prev_tensor, new_tensor, dd * sizeof(double));
+            memcpy(inv_prev, inv_new, dd * sizeof(double));
+            memcpy(prev_deriv, new_deriv, dd * d * sizeof(double));
+            acc = 1;
+            if (draw_ind >= n_burnin) { store_row(draws_out, draw_ind - n_burnin, d, new_draw); n_accept++; }
+        } else {
+            if (draw_ind >= n_burnin) store_row(draws_out, draw_ind - n_burnin, d, prev_draw);
+        }
+        if (st && st->accept_trace) st->accept_trace[draw_ind] = (uint8_t)acc;
+    }
+    (void)prev_K;
+    epilogue_inv_transform(&c, draws_out, n_keep);                      /* :277-284 */
+    if (st) { st->n_accept_draws = n_accept; st->n_leapfrogs = c.n_leap; st->final_step_size = step_size; }
+    free(first_draw); free(prev_draw); free(new_draw); free(prop_draw); free(new_mntm); free(prop_mntm); free(incr);
+    free(rand_vec); free(tmpv); free(new_tensor); free(prev_tensor); free(inv_new); free(inv_prev);
+    free(new_deriv); free(prev_deriv); free(L); free(S); free(Tn);
+    ctx_free(&c);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ many chains (CPU baseline harness) */
 
 int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t n_chains,
@@ -1041,6 +1264,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
         if (algo == 0) r = orc_hmc(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else if (algo == 1) r = orc_mala(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else if (algo == 3) r = orc_rwmh(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
+        else if (algo == 4) r = orc_rmhmc(init + (size_t)ci * d, d, orc_target_kernel, orc_target_tensor, &t, &t, &sc, local, &st);
         else r = orc_nuts(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         if (r) rc = r;
         if (draws_out)

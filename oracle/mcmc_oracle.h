@@ -9,6 +9,8 @@
  *   mcmc::internal::nuts_impl  /root/reference/src/nuts.cpp:30-332
  *       + nuts_find_initial_step_size / nuts_build_tree
  *                              /root/reference/include/mcmc/nuts.ipp:30-241
+ *   mcmc::internal::rmhmc_impl /root/reference/src/rmhmc.cpp:30-287
+ *   mcmc::internal::rwmh_impl  /root/reference/src/rwmh.cpp:30-175
  *   box-constraint helpers     /root/reference/include/misc/{determine_bounds_type,
  *                              transform_vals,log_jacobian,inv_jacobian_adjust}.hpp
  *
@@ -41,7 +43,10 @@ typedef double (*orc_kernel_fn)(const double* vals, double* grad_out, void* data
 
 /* built-in targets (ours; the reference has none).  data points to orc_target. */
 enum { ORC_TARGET_GAUSS_ISO = 1, ORC_TARGET_GAUSS_DIAG = 2, ORC_TARGET_GAUSS_DENSE = 3,
-       ORC_TARGET_LOGISTIC = 4 };
+       ORC_TARGET_LOGISTIC = 4,
+       ORC_TARGET_NORMAL_MODEL = 5 /* d = 2, vals = (mu, sigma), data x_1..x_n in y[0..n_rows): the model of the reference's own
+                                      example programs (ref: examples/eigen/{hmc,mala,nuts,rmhmc}_normal.cpp):
+                                      log K = -n (log(2 pi)/2 + log sigma) - sum (x - mu)^2 / (2 sigma^2) */ };
 
 typedef struct orc_target {
     int           kind;
@@ -61,6 +66,13 @@ typedef struct orc_target {
 
 double orc_target_kernel(const double* vals, double* grad_out, void* data);
 
+/* metric tensor contract of the reference (rmhmc.hpp: std::function<Mat_t (vals_inp, Cube_t* tensor_deriv_out, tensor_data)>):
+ * writes the d x d tensor (row-major) and, when deriv_out is not NULL, the d matrices dG/dvals_i (deriv_out + i*d*d). */
+typedef void (*orc_tensor_fn)(const double* vals, double* tensor_out, double* deriv_out, void* data);
+/* built-in tensors (data points to orc_target): NORMAL_MODEL: the Fisher information diag(n/sigma^2, 2n/sigma^2) and its
+ * derivative (ref: examples/eigen/rmhmc_normal.cpp:75-106); GAUSS_*: the constant precision, zero derivative. */
+void orc_target_tensor(const double* vals, double* tensor_out, double* deriv_out, void* data);
+
 /* POD mirror of algo_settings_t (mcmc_structs.hpp:151-184) restricted to the
  * fields hmc/mala/nuts read. */
 typedef struct orc_settings {
@@ -78,6 +90,7 @@ typedef struct orc_settings {
     double   target_accept_rate;
     size_t   max_tree_depth;
     double   gamma_val, t0_val, kappa_val;
+    size_t   n_fp_steps;          /* rmhmc: fixed-point iterations (mcmc_structs.hpp:116, default 5) */
     /* oracle-only knobs */
     int      reduce_width;        /* W: number of strided partial sums in dot products (1,4,64,...) */
     int      reduce_blocks;       /* >1: dot products are ((B0+B1)+B2)+... over contiguous dimension blocks of
@@ -111,10 +124,14 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
 int orc_rwmh(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
 
+/* mcmc::rmhmc (src/rmhmc.cpp:30-287).  Reductions here are plain sequential chains (the reduce_* knobs are not used). */
+int orc_rmhmc(const double* initial_vals, size_t d, orc_kernel_fn kernel, orc_tensor_fn tensor, void* data, void* tensor_data,
+              const orc_settings* s, double* draws_out, orc_stats* st);
+
 /* many independent chains of a built-in target, OpenMP over chains (the CPU
  * baseline of BASELINE.md section 3).  init: n_chains x d (row per chain).
  * draws_out: [n_keep][d][n_chains] (the engine's device layout) or NULL.
- * algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh.  Chain c uses chain_id = chain0 + c. */
+ * algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.  Chain c uses chain_id = chain0 + c. */
 int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t n_chains,
                  uint64_t chain0, const double* init, double* draws_out,
                  uint64_t* n_accept_out, uint64_t* n_leap_out, double* eps_out, int n_threads);

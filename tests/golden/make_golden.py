@@ -2,8 +2,8 @@
 
 kthohr/mcmc ships no golden vectors and cannot be built in this image, so nothing here
 comes from the reference.  These vectors freeze the CPU oracle's own outputs on the known-answer shapes SURVEY.md
-8(c) lists (HMC / MALA / NUTS x {iso Gaussian d=3, dense Gaussian d=8, logistic d=5}, n_burnin=5, n_keep=20, fixed
-seeds), so that a later change of the oracle, of its math, or of the RNG layout is caught on the CPU, and so that
+8(c) lists (HMC / MALA / NUTS / RWMH x {iso Gaussian d=3, dense Gaussian d=8, logistic d=5}, and RM-HMC on the d=2 normal
+model; n_burnin=5, n_keep=20, fixed seeds), so that a later change of the oracle, of its math, or of the RNG layout is caught on the CPU, and so that
 the GPU tests have a second, committed reference next to the live oracle.
 
     python tests/golden/make_golden.py        # rewrites oracle_kat.npz (only when the definition changes on purpose)
@@ -39,6 +39,10 @@ def cases():
     for tn, t in targets.items():
         for an, a in algos.items():
             yield f"{an}_{tn}", t, a
+    # mcmc::rmhmc on the d = 2 normal model of the reference's example (examples/eigen/rmhmc_normal.cpp), Fisher metric
+    x = 2.0 + 2.0 * synth.initial_states(60, 1, seed=17)[:, 0]
+    normal2 = dict(kind=orc.TARGET_NORMAL_MODEL, d=2, y=x, init_shift=np.array([2.0, 2.5]))
+    yield "rmhmc_normal2", normal2, dict(algo=orc.ALGO_RMHMC, n_leap=2, step=0.03, n_fp=5)
 
 
 def run_case(t, a):
@@ -46,11 +50,12 @@ def run_case(t, a):
     blocks, bs = t.get("blocks", 0), t.get("block_size", 0)
     tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=4, blocks=blocks, block_size=bs,
                          eta_chains=t.get("eta_chains", 1))
-    init = synth.initial_states(C, d, seed=99) * 0.5
+    init = synth.initial_states(C, d, seed=99) * 0.5 + t.get("init_shift", 0.0)
     out = dict(draws=[], accept=[], depth=[], eps=[], n_leap=[])
     for c in range(C):
         s = orc.make_settings(seed=SEED, n_burnin=BURN, n_keep=KEEP, n_leap=a.get("n_leap", 1), step=a["step"],
-                              n_adapt=a.get("n_adapt", 1000), W=4, hoist=1, blocks=blocks, block_size=bs, chain_id=c)
+                              n_adapt=a.get("n_adapt", 1000), W=4, hoist=1, blocks=blocks, block_size=bs, chain_id=c,
+                              n_fp=a.get("n_fp", 5))
         dr, info = orc.run_chain(a["algo"], tgt, init[c], s, traces=True)
         out["draws"].append(dr); out["accept"].append(info["accept"]); out["depth"].append(info["depth"])
         out["eps"].append(info["eps"]); out["n_leap"].append(info["n_leap"])

@@ -7,8 +7,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
-TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_LOGISTIC = 1, 2, 3, 4
-ALGO_HMC, ALGO_MALA, ALGO_NUTS, ALGO_RWMH = 0, 1, 2, 3   # rwmh: step = par_scale, precond = cov_mat
+TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_LOGISTIC, TARGET_NORMAL_MODEL = 1, 2, 3, 4, 5
+ALGO_HMC, ALGO_MALA, ALGO_NUTS, ALGO_RWMH, ALGO_RMHMC = 0, 1, 2, 3, 4   # rwmh: step = par_scale, precond = cov_mat
 
 _dp = C.POINTER(C.c_double)
 
@@ -27,7 +27,7 @@ class Settings(C.Structure):
                 ("n_leap_steps", C.c_size_t), ("step_size", C.c_double), ("precond_mat", _dp),
                 ("n_adapt_draws", C.c_size_t), ("target_accept_rate", C.c_double),
                 ("max_tree_depth", C.c_size_t), ("gamma_val", C.c_double), ("t0_val", C.c_double),
-                ("kappa_val", C.c_double), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
+                ("kappa_val", C.c_double), ("n_fp_steps", C.c_size_t), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
                 ("reduce_block_size", C.c_size_t),
                 ("hoist_factorizations", C.c_int), ("chain_id", C.c_uint64)]
 
@@ -68,8 +68,8 @@ class TargetSpec:
     def __init__(self, kind, d, prec=None, X=None, y=None, W=4, blocks=0, block_size=0, eta_chains=1):
         self.kind, self.d, self.W = kind, int(d), W
         self.prec, self.X, self.y = _f64(prec), _f64(X), _f64(y)
-        self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y),
-                        0 if self.X is None else self.X.shape[0], W, blocks, block_size, eta_chains, 0, 0)
+        n_rows = self.X.shape[0] if self.X is not None else (self.y.shape[0] if self.y is not None else 0)
+        self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y), n_rows, W, blocks, block_size, eta_chains, 0, 0)
 
     def kernel(self, theta, want_grad=True):
         theta = _f64(theta)
@@ -80,11 +80,11 @@ class TargetSpec:
 
 def make_settings(seed=1, n_burnin=0, n_keep=10, n_leap=1, step=1.0, precond=None, n_adapt=1000,
                   delta=0.55, max_depth=10, gamma=0.05, t0=10.0, kappa=0.75, W=4, hoist=1, chain_id=0,
-                  lower=None, upper=None, blocks=0, block_size=0):
+                  lower=None, upper=None, blocks=0, block_size=0, n_fp=5):
     keep = dict(precond=_f64(precond), lower=_f64(lower), upper=_f64(upper))
     s = Settings(seed, 0 if lower is None else 1, _p(keep["lower"]), _p(keep["upper"]),
                  n_burnin, n_keep, n_leap, step, _p(keep["precond"]), n_adapt, delta, max_depth,
-                 gamma, t0, kappa, W, blocks, block_size, hoist, chain_id)
+                 gamma, t0, kappa, n_fp, W, blocks, block_size, hoist, chain_id)
     s._keep = keep
     return s
 
@@ -106,9 +106,14 @@ def run_chain(algo, target, init, settings, traces=False):
         st.depth_trace = dep.ctypes.data_as(C.POINTER(C.c_uint32))
         st.leap_trace = lea.ctypes.data_as(C.POINTER(C.c_uint32))
         st.eps_trace = _p(eps)
-    fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts, lib().orc_rwmh][algo]
     kern = C.cast(lib().orc_target_kernel, C.c_void_p)
-    rc = fn(_p(init), C.c_size_t(d), kern, C.byref(target.c), C.byref(settings), _p(draws), C.byref(st))
+    if algo == ALGO_RMHMC:
+        tens = C.cast(lib().orc_target_tensor, C.c_void_p)
+        rc = lib().orc_rmhmc(_p(init), C.c_size_t(d), kern, tens, C.byref(target.c), C.byref(target.c),
+                             C.byref(settings), _p(draws), C.byref(st))
+    else:
+        fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts, lib().orc_rwmh][algo]
+        rc = fn(_p(init), C.c_size_t(d), kern, C.byref(target.c), C.byref(settings), _p(draws), C.byref(st))
     assert rc == 0
     info = dict(n_accept=st.n_accept_draws, n_leap=st.n_leapfrogs, eps=st.final_step_size,
                 accept=acc, depth=dep, leaps=lea, eps_trace=eps)

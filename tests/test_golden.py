@@ -42,9 +42,11 @@ def test_engine_reproduces_golden(name):
     import mcmc_amd
     algo, tname = name.split("_")
     t, a = {n: (t, a) for n, t, a in G.cases()}[name]
-    kind = {"iso3": mcmc_amd.TARGET_GAUSS_ISO, "dense8": mcmc_amd.TARGET_GAUSS_DENSE, "logit5": mcmc_amd.TARGET_LOGISTIC}[tname]
+    kind = {"iso3": mcmc_amd.TARGET_GAUSS_ISO, "dense8": mcmc_amd.TARGET_GAUSS_DENSE, "logit5": mcmc_amd.TARGET_LOGISTIC,
+            "normal2": mcmc_amd.TARGET_NORMAL_MODEL}[tname]
     st = mcmc_amd.default_settings(rng_seed_value=G.SEED, n_burnin_draws=G.BURN, n_keep_draws=G.KEEP,
-                                   n_leap_steps=a.get("n_leap", 1), step_size=a["step"], n_adapt_draws=a.get("n_adapt", 1000))
+                                   n_leap_steps=a.get("n_leap", 1), step_size=a["step"], n_adapt_draws=a.get("n_adapt", 1000),
+                                   n_fp_steps=a.get("n_fp", 5))
     draws, g = mcmc_amd.sample(algo, kind, KAT[f"{name}/init"], st, prec=t.get("prec"), X=t.get("X"), y=t.get("y"))
     want = np.transpose(KAT[f"{name}/draws"], (1, 2, 0))            # [C, n_keep, d] -> [n_keep, d, C]
     assert np.array_equal(draws, want)

@@ -264,3 +264,88 @@ def test_rwmh_bounded_draws_stay_inside_the_box():
     s = orc.make_settings(seed=5, n_burnin=50, n_keep=400, step=0.5, W=4, lower=lb, upper=ub)
     draws, info = orc.run_chain(orc.ALGO_RWMH, t, np.array([0.1, 0.2, 0.5, 0.0, 1.0]), s)
     assert (draws >= lb).all() and (draws <= ub).all() and 0 < info["n_accept"] < 400
+
+
+# ---------------------------------------------------------------- RM-HMC (src/rmhmc.cpp) and the d = 2 normal model
+
+def _normal_model(n=200, seed=0):
+    rng = np.random.default_rng(seed)
+    x = 2.0 + 2.0 * rng.standard_normal(n)
+    return x, orc.TargetSpec(orc.TARGET_NORMAL_MODEL, 2, y=x, W=1)
+
+
+def test_normal_model_kernel_matches_the_example_formula_and_its_gradient():
+    x, t = _normal_model()
+    v = np.array([1.7, 2.3])
+    val, g = t.kernel(v)
+    n = x.size
+    want = -n * (0.5 * np.log(2 * np.pi) + np.log(v[1])) - ((x - v[0]) ** 2).sum() / (2 * v[1] ** 2)   # rmhmc_normal.cpp:56
+    assert abs(val - want) < 1e-10 * abs(want)
+    h = 1e-6
+    for i in range(2):
+        e = np.zeros(2); e[i] = h
+        fd = (t.kernel(v + e, want_grad=False)[0] - t.kernel(v - e, want_grad=False)[0]) / (2 * h)
+        assert abs(fd - g[i]) < 1e-5 * max(1.0, abs(g[i]))
+
+
+def test_normal_model_tensor_is_the_fisher_information_and_its_derivative():
+    import ctypes as C
+    x, t = _normal_model(n=50)
+    lib = orc.lib()
+
+    def tensor(v, want_deriv=True):
+        G = np.zeros((2, 2)); dG = np.zeros((2, 2, 2))
+        vv = np.ascontiguousarray(v, dtype=np.float64)
+        lib.orc_target_tensor(vv.ctypes.data_as(C.POINTER(C.c_double)), G.ctypes.data_as(C.POINTER(C.c_double)),
+                              dG.ctypes.data_as(C.POINTER(C.c_double)) if want_deriv else None, C.byref(t.c))
+        return G, dG
+
+    v = np.array([0.3, 1.9])
+    G, dG = tensor(v)
+    assert np.allclose(G, np.diag([50 / v[1] ** 2, 100 / v[1] ** 2]), rtol=1e-15)     # rmhmc_normal.cpp:89-90
+    h = 1e-6
+    for i in range(2):
+        e = np.zeros(2); e[i] = h
+        fd = (tensor(v + e, False)[0] - tensor(v - e, False)[0]) / (2 * h)
+        assert np.allclose(fd, dG[i], atol=1e-6 * np.abs(G).max())
+
+
+def test_rmhmc_work_accounting_determinism_and_chain_ids():
+    x, t = _normal_model()
+    init = np.array([[2.5, 2.4], [1.8, 2.9], [2.2, 2.0]])
+    s = orc.make_settings(seed=3, n_burnin=4, n_keep=30, n_leap=3, step=0.03, n_fp=4, W=1)
+    d1, i1 = orc.run_many(orc.ALGO_RMHMC, t, init, s, chain0=10)
+    d2, i2 = orc.run_many(orc.ALGO_RMHMC, t, init, s, chain0=10)
+    assert np.array_equal(d1, d2) and np.isfinite(d1).all()
+    assert (i1["n_leap"] == 34 * 3).all()                                  # one count per leapfrog step (rmhmc.cpp:215)
+    assert 0 < i1["n_accept"].sum() <= 3 * 30
+    # chain c of a many-chain run is the single-chain run with chain_id = chain0 + c
+    s1 = orc.make_settings(seed=3, n_burnin=4, n_keep=30, n_leap=3, step=0.03, n_fp=4, W=1, chain_id=11)
+    single, _ = orc.run_chain(orc.ALGO_RMHMC, t, init[1], s1)
+    assert np.array_equal(single, d1[:, :, 1])
+    # callbacks per leapfrog: n_fp + 1 gradient calls; per draw one value call (+ one at setup)
+    t.c.n_grad_calls = 0; t.c.n_value_calls = 0
+    orc.run_chain(orc.ALGO_RMHMC, t, init[0], s1)
+    assert t.c.n_grad_calls == 34 * 3 * 5 and t.c.n_value_calls == 34 + 1
+
+
+def test_rmhmc_with_a_constant_metric_and_no_fixed_point_drift_is_a_valid_sampler():
+    # GAUSS target, tensor = precision (constant, zero derivative): the fixed-point loops converge at once.  The reference adds
+    # the momentum increment with the opposite sign of Hamilton's equations (rmhmc.cpp:116,139,145), which keeps the map
+    # reversible and volume preserving: the chain still targets the right distribution, with a lower acceptance rate.
+    d = 3
+    P = synth.dense_gaussian_precision(d, seed=2)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=P, W=1)
+    s = orc.make_settings(seed=8, n_burnin=500, n_keep=20000, n_leap=1, step=0.6, n_fp=3, W=1)
+    draws, info = orc.run_chain(orc.ALGO_RMHMC, t, np.zeros(d), s)
+    assert 0.2 < info["n_accept"] / 20000 < 0.6
+    cov = np.cov(draws.T)
+    assert np.allclose(cov, np.linalg.inv(P), atol=0.15)
+
+
+def test_rmhmc_bounded_draws_stay_inside_the_box():
+    x, t = _normal_model(n=80, seed=4)
+    lb, ub = np.array([-1.0, 0.5]), np.array([5.0, 6.0])
+    s = orc.make_settings(seed=2, n_burnin=5, n_keep=60, n_leap=2, step=0.03, n_fp=3, W=1, lower=lb, upper=ub)
+    draws, info = orc.run_chain(orc.ALGO_RMHMC, t, np.array([2.0, 2.0]), s)
+    assert (draws > lb).all() and (draws < ub).all() and info["n_accept"] > 0
