@@ -92,6 +92,22 @@ int main()
                 double(s2.rwmh_settings.n_accept_draws) / 50.0);
     if (!ok3) return 1;
 
+    // mcmc::rmhmc on the reference's own example model (examples/eigen/rmhmc_normal.cpp): (mu, sigma) of normal data,
+    // Fisher-information metric; 64 chains
+    std::vector<double> x_obs(1000);
+    { unsigned long long st = 88172645463325252ULL;      // xorshift -> Irwin-Hall(12) - 6: near-normal observations
+      for (auto& v : x_obs) { double a = 0; for (int k = 0; k < 12; ++k) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; a += double(st >> 11) / 9007199254740992.0; } v = 2.0 + 2.0 * (a - 6.0); } }
+    mcmc::mi355x::target_t nm = mcmc::mi355x::normal_model(x_obs.size(), x_obs.data());
+    nm.n_chains = 64;
+    mcmc::ColVec_t init2(2); init2(0) = 3.0; init2(1) = 3.0;
+    mcmc::algo_settings_t s4;
+    s4.rng_seed_value = 9;
+    s4.rmhmc_settings.step_size = 0.02; s4.rmhmc_settings.n_burnin_draws = 200; s4.rmhmc_settings.n_keep_draws = 200;
+    const bool ok4 = mcmc::rmhmc(init2, mcmc::mi355x::device_kernel, mcmc::mi355x::device_tensor, dr, &nm, &nm, s4);
+    std::printf("device rmhmc ok=%d rows=%zu cols=%zu acc0=%.3f mu0=%.3f sigma0=%.3f\n", int(ok4), size_t(dr.rows()), size_t(dr.cols()),
+                double(s4.rmhmc_settings.n_accept_draws) / 200.0, ok4 ? dr.col_mean(0) : 0.0, ok4 ? dr.col_mean(1) : 0.0);
+    if (!ok4) return 1;
+
     // a host callback with mala / nuts is refused (no CPU sampler behind this header)
     const bool refused = !mcmc::nuts(initial_val, log_target_dens, draws_out, &dta, settings);
     std::printf("nuts with host callback refused=%d\n", int(refused));

@@ -106,6 +106,20 @@ private:
 using RowVec_t = ColVec_t;
 #endif
 
+// bmo::Cube_t<fp_t> (mcmc_options.hpp:212): n_slice matrices of n_row x n_col; tensor_fn fills mat(i) = dG/dvals_i
+class Cube_t
+{
+public:
+    Cube_t() = default;
+    Cube_t(size_t r, size_t c, size_t s) { setZero(r, c, s); }
+    void setZero(size_t r, size_t c, size_t s) { mats_.assign(s, Mat_t(r, c)); for (auto& m : mats_) m.setZero(); }
+    Mat_t& mat(size_t i) { return mats_[i]; }
+    const Mat_t& mat(size_t i) const { return mats_[i]; }
+    size_t n_mat() const { return mats_.size(); }
+private:
+    std::vector<Mat_t> mats_;
+};
+
 // ---------------------------------------------------------------------------------------------
 // settings (field for field the reference's; only hmc / mala / nuts are read by this engine)
 
@@ -212,6 +226,7 @@ struct algo_settings_t
 };
 
 using log_kernel_fn_t = std::function<fp_t (const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>;
+using tensor_fn_t = std::function<Mat_t (const ColVec_t& vals_inp, Cube_t* tensor_deriv_out, void* tensor_data)>;
 
 // ---------------------------------------------------------------------------------------------
 // device targets
@@ -241,6 +256,12 @@ inline target_t gaussian_dense(size_t d, const double* prec_row_major)
 {
     target_t t = gaussian_iso(d); t.desc.kind = MI_TARGET_GAUSS_DENSE; t.desc.prec = prec_row_major; return t;
 }
+// the d = 2 (mu, sigma) model of the reference's example programs (examples/eigen/rmhmc_normal.cpp); x must outlive the run
+inline target_t normal_model(size_t n_obs, const double* x)
+{
+    target_t t; t.desc.struct_size = sizeof(mi_target); t.desc.kind = MI_TARGET_NORMAL_MODEL; t.desc.d = 2;
+    t.desc.y = x; t.desc.n_rows = n_obs; t.desc.mem = MI_MEM_HOST; return t;
+}
 inline target_t logistic_regression(size_t d, size_t n_rows, const double* X_row_major, const double* y)
 {
     target_t t = gaussian_iso(d); t.desc.kind = MI_TARGET_LOGISTIC; t.desc.X = X_row_major; t.desc.y = y;
@@ -258,6 +279,14 @@ inline bool is_device_route(const log_kernel_fn_t& f)
 }
 
 // the same tag for mcmc::rwmh, whose callback takes no gradient (ref: include/mcmc/rwmh.hpp:42-47)
+// mcmc::rmhmc: the metric tensor built into the target kind (normal_model: Fisher information, mi_mcmc.h)
+inline Mat_t device_tensor(const ColVec_t&, Cube_t*, void*) { return Mat_t(); }
+inline bool is_device_route(const tensor_fn_t& f)
+{
+    using fn_t = Mat_t (*)(const ColVec_t&, Cube_t*, void*);
+    const fn_t* p = f.target<fn_t>();
+    return p && *p == &device_tensor;
+}
 inline fp_t device_value_kernel(const ColVec_t&, void*) { return std::numeric_limits<fp_t>::quiet_NaN(); }
 
 inline bool is_device_route(const std::function<fp_t (const ColVec_t&, void*)>& f)
@@ -306,6 +335,7 @@ inline bool run_device(int algo, const ColVec_t& initial_vals, mi355x::target_t&
     const int rc = (algo == 0) ? mi_mcmc_hmc_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 1) ? mi_mcmc_mala_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 3) ? mi_mcmc_rwmh_run(&tgt.desc, &m, &ch, nullptr)
+                 : (algo == 4) ? mi_mcmc_rmhmc_run(&tgt.desc, &m, &ch, nullptr)
                                : mi_mcmc_nuts_run(&tgt.desc, &m, &ch, nullptr);
     if (rc != MI_OK) { tgt.last_error = mi_mcmc_last_error(); return false; }
     draws_out.resize(n_keep, d * C);                                  // BMO_MATOPS_SET_SIZE(draws_out, n_keep, n_vals)
@@ -422,6 +452,27 @@ rwmh_impl(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals
     return ok;
 }
 
+inline bool
+rmhmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,
+           void* target_data, void* tensor_data, algo_settings_t* settings_inp)
+{
+    // ref: src/rmhmc.cpp:30-287
+    algo_settings_t settings;
+    if (settings_inp) settings = *settings_inp;
+    (void)tensor_data;
+    if (!mi355x::is_device_route(target_log_kernel) || !mi355x::is_device_route(tensor_fn)) return false;   // no CPU fallback
+    mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
+    mi_settings m = flatten_common(settings);
+    m.n_burnin_draws = settings.rmhmc_settings.n_burnin_draws;
+    m.n_keep_draws = settings.rmhmc_settings.n_keep_draws;
+    m.n_leap_steps = settings.rmhmc_settings.n_leap_steps;
+    m.step_size = settings.rmhmc_settings.step_size;
+    m.n_fp_steps = settings.rmhmc_settings.n_fp_steps;
+    const bool ok = run_device(4, initial_vals, tgt, draws_out, m);
+    if (ok && settings_inp) settings_inp->rmhmc_settings.n_accept_draws = size_t(tgt.n_accept_draws[0]);
+    return ok;
+}
+
 }  // namespace internal
 
 // ---------------------------------------------------------------------------------------------
@@ -455,6 +506,15 @@ inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_
 inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals_inp, void* target_data)> target_log_kernel,
                  Mat_t& draws_out, void* target_data, algo_settings_t& settings)
 { return internal::rwmh_impl(initial_vals, target_log_kernel, draws_out, target_data, &settings); }
+
+// ref: include/mcmc/rmhmc.hpp (both overloads)
+inline bool rmhmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,
+                  void* target_data, void* tensor_data)
+{ return internal::rmhmc_impl(initial_vals, target_log_kernel, tensor_fn, draws_out, target_data, tensor_data, nullptr); }
+
+inline bool rmhmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,
+                  void* target_data, void* tensor_data, algo_settings_t& settings)
+{ return internal::rmhmc_impl(initial_vals, target_log_kernel, tensor_fn, draws_out, target_data, tensor_data, &settings); }
 
 }  // namespace mcmc
 

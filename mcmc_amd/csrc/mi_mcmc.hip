@@ -290,6 +290,58 @@ int launched(const char* what, int hip_err)
     return MI_OK;
 }
 
+// The one-lane-per-chain engine for the d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh and rmhmc with
+// any precond_mat / cov_mat and any bounds.  algo: 0 hmc, 1 mala, 3 rwmh, 4 rmhmc.
+int run_small_normal_model(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    const uint64_t d = target->d;
+    if (d != 2) return fail(MI_ERR_BAD_ARG, "%s: NORMAL_MODEL has d = 2 (mu, sigma)", who);
+    if (!target->y || target->n_rows == 0 || target->n_rows > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "NORMAL_MODEL needs its observations in y[0..n_rows)");
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
+        return fail(MI_ERR_BAD_ARG, "%s: vals_bound needs lower_bounds and upper_bounds", who);
+
+    DevBuf x_owned;
+    const double* x_dev = target->y;
+    if (target->mem == MI_MEM_HOST) {
+        HIP_TRY(x_owned.alloc(target->n_rows * sizeof(double)));
+        HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
+        x_dev = x_owned.as<double>();
+    }
+    StagedChains sc;
+    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+
+    mi::SmallParams prm{};
+    prm.data = x_dev; prm.n_rows = (uint32_t)target->n_rows; prm.d = (uint32_t)d;
+    prm.C = chains->n_chains; prm.chain0 = chains->chain0;
+    prm.theta = sc.dev.theta; prm.draws = sc.dev.draws; prm.n_accept = sc.dev.n_accept; prm.n_leap = sc.dev.n_leapfrogs;
+    prm.seed = settings->rng_seed_value;
+    prm.n_burnin = (uint32_t)settings->n_burnin_draws; prm.n_keep = (uint32_t)settings->n_keep_draws;
+    prm.n_leap_steps = (uint32_t)settings->n_leap_steps; prm.n_fp_steps = (uint32_t)settings->n_fp_steps;
+    prm.draw0 = (uint32_t)chains->draw0;
+    prm.eps = settings->step_size;
+    prm.vals_bound = settings->vals_bound ? 1 : 0;
+    for (uint64_t i = 0; i < 4; ++i) {
+        prm.btype[i] = 1; prm.lb[i] = 0.0; prm.ub[i] = 0.0;
+        for (uint64_t k = 0; k < 4; ++k) prm.M[i][k] = (i == k) ? 1.0 : 0.0;
+    }
+    if (settings->precond_mat && algo != 4)          // hmc.cpp:57, mala.cpp:57, rwmh.cpp:58 (rmhmc has none)
+        for (uint64_t i = 0; i < d; ++i)
+            for (uint64_t k = 0; k < d; ++k) prm.M[i][k] = settings->precond_mat[i * d + k];
+    if (settings->vals_bound)
+        for (uint64_t i = 0; i < d; ++i) {       // determine_bounds_type.hpp:27-57
+            prm.lb[i] = settings->lower_bounds[i]; prm.ub[i] = settings->upper_bounds[i];
+            const bool fl = std::isfinite(prm.lb[i]), fu = std::isfinite(prm.ub[i]);
+            prm.btype[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+        }
+    rc = launched(who, mi::launch_small_normal_model(algo, prm, st));
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (x_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -328,6 +380,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
+    if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC) {
         if (settings->vals_bound || settings->precond_mat)
             return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound / precond_mat with the logistic target are not implemented");
@@ -527,6 +580,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("mala", 1, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat))
         return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound / precond_mat with the logistic target are not implemented");
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
@@ -656,6 +710,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
+    if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "rwmh: d = %llu > 128 not implemented", (unsigned long long)d);
@@ -815,49 +870,9 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
 {
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint64_t d = target->d;
     if (target->kind != MI_TARGET_NORMAL_MODEL)
         return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path", target->kind);
-    if (d != 2) return fail(MI_ERR_BAD_ARG, "rmhmc: NORMAL_MODEL has d = 2 (mu, sigma)");
-    if (!target->y || target->n_rows == 0 || target->n_rows > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "NORMAL_MODEL needs its observations in y[0..n_rows)");
-    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
-        return fail(MI_ERR_BAD_ARG, "rmhmc: vals_bound needs lower_bounds and upper_bounds");
-
-    DevBuf x_owned;
-    const double* x_dev = target->y;
-    if (target->mem == MI_MEM_HOST) {
-        HIP_TRY(x_owned.alloc(target->n_rows * sizeof(double)));
-        HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
-        x_dev = x_owned.as<double>();
-    }
-    StagedChains sc;
-    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
-    if (rc) return rc;
-
-    mi::SmallParams prm{};
-    prm.data = x_dev; prm.n_rows = (uint32_t)target->n_rows; prm.d = (uint32_t)d;
-    prm.C = chains->n_chains; prm.chain0 = chains->chain0;
-    prm.theta = sc.dev.theta; prm.draws = sc.dev.draws; prm.n_accept = sc.dev.n_accept; prm.n_leap = sc.dev.n_leapfrogs;
-    prm.seed = settings->rng_seed_value;
-    prm.n_burnin = (uint32_t)settings->n_burnin_draws; prm.n_keep = (uint32_t)settings->n_keep_draws;
-    prm.n_leap_steps = (uint32_t)settings->n_leap_steps; prm.n_fp_steps = (uint32_t)settings->n_fp_steps;
-    prm.draw0 = (uint32_t)chains->draw0;
-    prm.eps = settings->step_size;
-    prm.vals_bound = settings->vals_bound ? 1 : 0;
-    for (uint64_t i = 0; i < 4; ++i) { prm.btype[i] = 1; prm.lb[i] = 0.0; prm.ub[i] = 0.0; }
-    if (settings->vals_bound)
-        for (uint64_t i = 0; i < d; ++i) {       // determine_bounds_type.hpp:27-57
-            prm.lb[i] = settings->lower_bounds[i]; prm.ub[i] = settings->upper_bounds[i];
-            const bool fl = std::isfinite(prm.lb[i]), fu = std::isfinite(prm.ub[i]);
-            prm.btype[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
-        }
-    rc = launched("rmhmc", mi::launch_rmhmc_normal_model(prm, st));
-    if (rc) return rc;
-    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
-    if (rc) return rc;
-    if (x_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
-    return MI_OK;
+    return run_small_normal_model("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
 }
 
 int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,

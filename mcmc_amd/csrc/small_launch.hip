@@ -1,15 +1,23 @@
-// small_launch.hip -- translation unit of the one-lane-per-chain kernels for small-dimensional targets (rmhmc_small.hpp)
-#include "rmhmc_small.hpp"
+// small_launch.hip -- translation unit of the one-lane-per-chain kernels for small-dimensional targets
+// (rmhmc_small.hpp, small_samplers.hpp)
+#include "small_samplers.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
 
 namespace mi {
 
-int launch_rmhmc_normal_model(const SmallParams& prm, hipStream_t st)
+int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st)
 {
     NormalModel tgt{prm.data, prm.n_rows};
     const unsigned block = 64;        // one wave per workgroup: C chains spread over as many CUs as possible
-    hipLaunchKernelGGL(rmhmc_small_kernel<NormalModel>, dim3((unsigned)((prm.C + block - 1) / block)), dim3(block), 0, st, prm, tgt);
+    const dim3 grid((unsigned)((prm.C + block - 1) / block));
+    switch (algo) {
+    case 0: hipLaunchKernelGGL(hmc_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
+    case 1: hipLaunchKernelGGL(mala_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
+    case 3: hipLaunchKernelGGL(rwmh_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
+    case 4: hipLaunchKernelGGL(rmhmc_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
+    default: return (int)hipErrorInvalidValue;
+    }
     return (int)hipGetLastError();
 }
 

@@ -40,10 +40,12 @@ def test_settings_structs_keep_reference_names_and_defaults():
                  "size_t max_tree_depth = size_t(10);", "fp_t gamma_val = 0.05;", "fp_t t0_val = 10;",
                  "fp_t kappa_val = 0.75;", "size_t rng_seed_value = std::random_device{}();",
                  "bool vals_bound = false;", "ColVec_t lower_bounds;", "ColVec_t upper_bounds;",
-                 "hmc_settings_t hmc_settings;", "nuts_settings_t nuts_settings;", "mala_settings_t mala_settings;"]:
+                 "hmc_settings_t hmc_settings;", "nuts_settings_t nuts_settings;", "mala_settings_t mala_settings;",
+                 "size_t n_fp_steps = 5;", "rmhmc_settings_t rmhmc_settings;"]:
         assert frag in src, frag
     for sig in ["hmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t& draws_out, void* target_data,",
-                "mala(const ColVec_t& initial_vals", "nuts(const ColVec_t& initial_vals", "algo_settings_t& settings)"]:
+                "mala(const ColVec_t& initial_vals", "nuts(const ColVec_t& initial_vals", "algo_settings_t& settings)",
+                "rmhmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,"]:
         assert sig in src, sig
 
 
@@ -62,6 +64,9 @@ def test_example_runs_on_the_gpu(tmp_path):
         mm = re.search(rf"device {algo} ok=1 rows=50 cols=1024 acc0=(\S+)", out.stdout)
         assert mm, out.stdout
         assert 0.2 < float(mm.group(1)) <= 1.0
+    mm = re.search(r"device rmhmc ok=1 rows=200 cols=128 acc0=(\S+) mu0=(\S+) sigma0=(\S+)", out.stdout)
+    assert mm, out.stdout
+    assert 0.2 < float(mm.group(1)) <= 1.0 and 1.5 < float(mm.group(2)) < 3.2 and 1.5 < float(mm.group(3)) < 3.2
     assert "refused=1" in out.stdout
 
 
