@@ -88,8 +88,56 @@ def sweep(n_cases=60, seed=1, verbose=True):
     return fails
 
 
+def sweep_small(n_cases=60, seed=1, verbose=True):
+    """The one-lane-per-chain engine (hmc / mala / rwmh / rmhmc on the d = 2 normal model): random observations, bounds of every
+    type, diagonal / dense preconditioners, degenerate sizes, step sizes that blow the chain up.  Returns the number of mismatches."""
+    rng = np.random.default_rng(seed)
+    fails = 0
+    say = print if verbose else (lambda *a, **k: None)
+    algos = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "rwmh": orc.ALGO_RWMH, "rmhmc": orc.ALGO_RMHMC}
+    for case in range(n_cases):
+        algo = ["hmc", "mala", "rwmh", "rmhmc"][case % 4]
+        n = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 100, 1000]))
+        C = int(rng.choice([1, 3, 63, 64, 65, 130]))
+        rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
+        burn, keep = int(rng.integers(0, 4)), int(rng.integers(1, 8))
+        eps = float(rng.choice([0.005, 0.02, 0.08, 0.3, 1.0, 4.0]))
+        L, n_fp = int(rng.integers(0, 5)), int(rng.integers(0, 6))
+        x = float(rng.uniform(-3, 3)) + float(rng.uniform(0.2, 3.0)) * rng.standard_normal(n)
+        init = np.stack([x.mean() + rng.uniform(-1.0, 1.0, C), np.abs(x.std()) + rng.uniform(0.2, 2.0, C)], axis=1)
+        if rng.random() < 0.1: init[:, 1] = -init[:, 1]                      # sigma < 0: log of a negative number from the start
+        kw, okw = {}, {}
+        if rng.random() < 0.5:
+            kind = rng.integers(1, 5, 2)
+            lo, hi = init.min(axis=0) - rng.uniform(0.1, 2.0, 2), init.max(axis=0) + rng.uniform(0.1, 2.0, 2)
+            lb = np.where((kind == 2) | (kind == 4), lo, -np.inf); ub = np.where((kind == 3) | (kind == 4), hi, np.inf)
+            kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+        if algo != "rmhmc" and rng.random() < 0.6:
+            M = np.diag(rng.uniform(0.3, 3.0, 2))
+            if rng.random() < 0.6:
+                A = rng.standard_normal((2, 2)); M = A @ A.T / 2 + M
+            kw.update(precond_mat=M); okw.update(precond=M)
+        st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps,
+                                       n_fp_steps=n_fp, **kw)
+        t = orc.TargetSpec(orc.TARGET_NORMAL_MODEL, 2, y=x, W=1)
+        s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, n_fp=n_fp, W=1, hoist=int(rng.integers(0, 2)), **okw)
+        desc = f"{algo} normal-model n={n} C={C} eps={eps} L={L} n_fp={n_fp} burn={burn} keep={keep} general={sorted(kw)}"
+        g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_NORMAL_MODEL, init, st, y=x, chain0=chain0)
+        o_draws, o = orc.run_many(algos[algo], t, init, s, chain0=chain0)
+        ok = (np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
+              and np.array_equal(g["n_leap"], o["n_leap"]))
+        if not ok:
+            fails += 1
+            bad = np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))
+            say("MISMATCH", desc, "first bad index", bad[:1].tolist(), "nan in oracle", bool(np.isnan(o_draws).any()))
+        else:
+            say("ok      ", desc, "nan" if np.isnan(o_draws).any() else "")
+    return fails
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    f = sweep(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    print(f"{n} cases, {f} mismatches")
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f = sweep(n, sd) + sweep_small(n, sd)
+    print(f"2 x {n} cases, {f} mismatches")
     sys.exit(1 if f else 0)

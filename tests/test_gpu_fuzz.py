@@ -13,3 +13,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def test_random_cases_are_bit_exact(seed):
     import fuzz_parity
     assert fuzz_parity.sweep(60, seed, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [3, 5])
+def test_random_normal_model_cases_are_bit_exact(seed):
+    """hmc / mala / rwmh / rmhmc on the one-lane-per-chain engine (d = 2 normal model)"""
+    import fuzz_parity
+    assert fuzz_parity.sweep_small(80, seed, verbose=False) == 0
