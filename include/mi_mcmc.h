@@ -56,8 +56,8 @@ typedef enum mi_target_kind {
     MI_TARGET_NORMAL_MODEL = 5  /* d = 2, vals = (mu, sigma), observations x_1..x_n in y[0..n_rows): the model of the reference's
                                  * example programs (/root/reference/examples/eigen/rmhmc_normal.cpp:44-106),
                                  * log K = -n (log(2 pi)/2 + log sigma) - sum_r (x_r - mu)^2 / (2 sigma^2); its metric tensor for
-                                 * rmhmc is the Fisher information diag(n / sigma^2, 2 n / sigma^2).  hmc, mala, rwmh, rmhmc (any
-                                 * precond_mat / cov_mat, any bounds); nuts is not implemented for it. */
+                                 * rmhmc is the Fisher information diag(n / sigma^2, 2 n / sigma^2).  hmc, mala, nuts, rwmh, rmhmc (any
+                                 * precond_mat / cov_mat, any bounds). */
 } mi_target_kind;
 
 typedef enum mi_mem { MI_MEM_HOST = 0, MI_MEM_DEVICE = 1 } mi_mem;

@@ -27,7 +27,7 @@
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
 #include "launchers.hpp"
-#include "rmhmc_small.hpp"
+#include "small_samplers.hpp"
 
 namespace {
 
@@ -291,7 +291,7 @@ int launched(const char* what, int hip_err)
 }
 
 // The one-lane-per-chain engine for the d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh and rmhmc with
-// any precond_mat / cov_mat and any bounds.  algo: 0 hmc, 1 mala, 3 rwmh, 4 rmhmc.
+// any precond_mat / cov_mat and any bounds, and nuts.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.
 int run_small_normal_model(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
 {
     const uint64_t d = target->d;
@@ -307,8 +307,18 @@ int run_small_normal_model(const char* who, int algo, const mi_target* target, c
         HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
         x_dev = x_owned.as<double>();
     }
+    const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (algo == 2) {
+        if (settings->max_tree_depth > (uint64_t)mi::NUTS_SMALL_MAX_DEPTH)
+            return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented for this target", (int)mi::NUTS_SMALL_MAX_DEPTH);
+        if (chains->draw0 > 0) {          // continuation: as for the other nuts kernels
+            if (chains->draw0 <= settings->n_adapt_draws)
+                return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
+            if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
+        }
+    }
     StagedChains sc;
-    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
 
     mi::SmallParams prm{};
@@ -334,9 +344,16 @@ int run_small_normal_model(const char* who, int algo, const mi_target* target, c
             const bool fl = std::isfinite(prm.lb[i]), fu = std::isfinite(prm.ub[i]);
             prm.btype[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
         }
+    if (algo == 2) {
+        prm.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+        if (chains->draw0 > 0) prm.n_adapt = 0;
+        prm.max_depth = (uint32_t)settings->max_tree_depth;
+        prm.delta = settings->target_accept_rate; prm.gamma = settings->gamma_val; prm.t0 = settings->t0_val; prm.kappa = settings->kappa_val;
+        prm.step_out = sc.dev.step_size; prm.depth_trace = sc.dev.nuts_depth;
+    }
     rc = launched(who, mi::launch_small_normal_model(algo, prm, st));
     if (rc) return rc;
-    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
     if (x_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
@@ -771,6 +788,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
+    if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("nuts", 2, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "nuts: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);

@@ -128,17 +128,6 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 
     double th[NS], pm[NS], w[NS];
 
-    auto load_vec = [&](int v, double (&x)[NS]) __attribute__((always_inline)) {
-        ld_row(v, 0, x);
-    };
-    // x <- ws[v] for lanes with pred, unchanged otherwise (v may be any valid id on the other lanes)
-    // ONE exec-masked region around the whole vector (idle lanes generate no memory traffic); never a
-    // branch per element (that serialises the loads)
-    auto load_vec_if = [&](int v, double (&x)[NS], bool pred) __attribute__((always_inline)) {
-        if (pred) {
-            ld_row(v, 0, x);
-        }
-    };
     auto store_vec = [&](int v, const double (&x)[NS], bool pred) __attribute__((always_inline)) {
         if (pred && live) {
             st_row(v, 0, x);

@@ -35,7 +35,12 @@ struct SmallParams {
     int vals_bound;
     int btype[4];
     double lb[4], ub[4];
-    double M[4][4];         // hmc / mala: precond_mat; rwmh: cov_mat (identity when the settings carry none); unused by rmhmc
+    double M[4][4];         // hmc / mala / nuts: precond_mat; rwmh: cov_mat (identity when the settings carry none); unused by rmhmc
+    // nuts (nuts_settings_t, mcmc_structs.hpp:82-101); eps carries epsilon_bar_0
+    uint32_t n_adapt, max_depth;
+    double delta, gamma, t0, kappa;
+    double* step_out;       // [C] or nullptr: in (continuation, draw0 > 0) / out: step size
+    uint32_t* depth_trace;  // [n_burnin + n_keep][C] or nullptr
 };
 
 // ---- the d = 2 normal model of the reference's example programs (examples/eigen/rmhmc_normal.cpp:44-106):

@@ -14,6 +14,7 @@ int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st)
     switch (algo) {
     case 0: hipLaunchKernelGGL(hmc_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
     case 1: hipLaunchKernelGGL(mala_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
+    case 2: hipLaunchKernelGGL(nuts_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
     case 3: hipLaunchKernelGGL(rwmh_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
     case 4: hipLaunchKernelGGL(rmhmc_small_kernel<NormalModel>, grid, dim3(block), 0, st, prm, tgt); break;
     default: return (int)hipErrorInvalidValue;

@@ -356,4 +356,248 @@ __global__ __launch_bounds__(256) void rwmh_small_kernel(const SmallParams prm, 
     if (prm.n_leap) prm.n_leap[c] = 0;
 }
 
+// ------------------------------------------------------------------ mcmc::nuts (src/nuts.cpp:30-332, nuts.ipp:30-241)
+// The recursive nuts_build_tree runs as an explicit call / return machine over a per-lane frame stack (one frame per tree
+// level, in private memory), keeping the reference's argument plumbing: every doubling restarts from (prev_draw, mntm_vec)
+// (nuts.cpp:241-256), the second-half calls cross their edge outputs (nuts.ipp:195,207), one runif per completed second
+// half in post-order.  Lanes of a wave diverge freely (each chain has its own tree); cost is irrelevant at d = 2.
+constexpr int NUTS_SMALL_MAX_DEPTH = 12;
+
+template <int D>
+struct NutsRes {            // what one nuts_build_tree call hands back
+    double new_draw[D], pos[D], neg[D], mpos[D], mneg[D];
+    uint32_t n, s, n_alpha;
+    double alpha;
+};
+template <int D>
+struct NutsFrame {
+    double start_draw[D], start_mntm[D];
+    NutsRes<D> res;         // results of the first half, then of the node
+    uint32_t depth, phase;
+};
+
+template <class Target>
+__global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, const Target tgt)
+{
+    constexpr int D = Target::D;
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= prm.C) return;
+    const SmallChain<Target> ch(prm, tgt, c);
+    double M[D][D], Minv[D][D], L[D][D];
+    ch.precond(M);
+    sm_inv<D>(M, Minv);                                              // nuts.cpp:62-64
+    sm_chol<D>(M, L);
+    uint64_t n_leap = 0;
+
+    auto mntm_update = [&](const double (&pos)[D], double (&p)[D], double step) {    // nuts.cpp:108-135
+        double grad[D];
+        ch.grad_at(pos, grad);
+        if (ch.bounded) {
+            double J[D][D], jg[D];
+            ch.jacobian(pos, J);
+            sm_gemv<D>(J, grad, jg);
+#pragma unroll
+            for (int i = 0; i < D; ++i) p[i] = p[i] + (step * jg[i]) / 2.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) p[i] = p[i] + (step * grad[i]) / 2.0;
+        }
+    };
+    auto leap_frog = [&](double step, double (&draw)[D], double (&p)[D]) {           // one step of nuts.cpp:139-154
+        mntm_update(draw, p, step);
+        double mp[D];
+        sm_gemv<D>(Minv, p, mp);
+#pragma unroll
+        for (int i = 0; i < D; ++i) draw[i] = draw[i] + step * mp[i];
+        mntm_update(draw, p, step);
+        ++n_leap;
+    };
+    auto kinetic = [&](const double (&p)[D]) -> double {
+        double t[D];
+        sm_gemv<D>(Minv, p, t);
+        return sm_dot<D>(p, t) / 2.0;
+    };
+    auto potential = [&](const double (&v)[D]) -> double {           // -box_log_kernel, non-finite -> +inf
+        const double u = -ch.box_log_kernel(v);
+        return is_finite(u) ? u : INF;
+    };
+    auto uturn_ok = [&](const double (&pos)[D], const double (&neg)[D], const double (&mpos)[D], const double (&mneg)[D]) -> uint32_t {
+        double diff[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) diff[i] = pos[i] - neg[i];
+        const uint32_t c1 = sm_dot<D>(diff, mneg) >= 0.0 ? 1u : 0u;  // nuts.ipp:226 / nuts.cpp:286
+        const uint32_t c2 = sm_dot<D>(diff, mpos) >= 0.0 ? 1u : 0u;  // :227 / :287
+        return c1 * c2;
+    };
+
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const size_t slab = (size_t)prm.d * prm.C;
+    double prev_draw[D];
+    ch.load_state(prev_draw);                                        // nuts.cpp:160-162
+    double step_size, mu_val = 0.0, h_val = 0.0, epsilon_bar = prm.eps;
+    if (prm.draw0 == 0) {
+        // nuts_find_initial_step_size (nuts.ipp:30-93) from the INIT-stream momentum (nuts.cpp:166-172)
+        double z[D], p0[D], nd[D], np_[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double z0, z1;
+            rng_normal_pair(prm.seed, ch.chain, 0u, (uint32_t)(i & 3), STREAM_INIT, z0, z1);
+            z[i] = (i >> 2) ? z1 : z0;
+        }
+        sm_gemv<D>(L, z, p0);
+        step_size = 1.0;
+        const double pU = potential(prev_draw), pK = kinetic(p0);
+#pragma unroll
+        for (int i = 0; i < D; ++i) { nd[i] = prev_draw[i]; np_[i] = p0[i]; }
+        leap_frog(step_size, nd, np_);
+        double qU = potential(nd), qK = kinetic(np_);
+        const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
+        int a_val = 2 * ((-(qU + qK) + (pU + pK)) > log_half ? 1 : 0) - 1;
+        bool check_cond = (-(qU + qK) + (pU + pK)) > neg_log2;
+        while (check_cond) {
+            step_size *= (a_val == 1) ? 2.0 : 0.5;
+            leap_frog(step_size, nd, np_);
+            qU = potential(nd); qK = kinetic(np_);
+            a_val = 2 * ((-(qU + qK) + (pU + pK)) > log_half ? 1 : 0) - 1;
+            check_cond = (-(qU + qK) + (pU + pK)) > neg_log2;
+        }
+        mu_val = det_log(10 * step_size);                            // nuts.cpp:174
+    } else {
+        step_size = prm.step_out[c];                                 // continuation after the adaptation window
+    }
+    double prev_U = -ch.box_log_kernel(prev_draw);                   // :181
+    uint64_t n_acc = 0;
+
+    NutsFrame<D> F[NUTS_SMALL_MAX_DEPTH];
+    for (uint32_t draw = 0; draw < n_total; ++draw) {                // :199
+        const uint32_t gd = draw + prm.draw0;                        // index in the chain's random stream / adaptation schedule
+        uint32_t uslot = 0;
+        double z[D], mntm_vec[D];
+        ch.normals(draw, z);
+        sm_gemv<D>(L, z, mntm_vec);                                  // :202
+        const double prev_K = kinetic(mntm_vec);                     // :204
+        const double log_rand_val = det_log(rng_uniform(prm.seed, ch.chain, gd, uslot++)) - prev_U - prev_K;   // :206
+        double new_draw[D], draw_pos[D], draw_neg[D], mntm_pos[D], mntm_neg[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            new_draw[i] = prev_draw[i]; draw_pos[i] = prev_draw[i]; draw_neg[i] = prev_draw[i];
+            mntm_pos[i] = mntm_vec[i]; mntm_neg[i] = mntm_vec[i];
+        }
+        uint32_t tree_depth = 0, n_val = 1, s_val = 1, n_alpha_val = 0, good_round = 0;
+        double alpha_val = 0.0;
+
+        while (s_val == 1 && tree_depth < prm.max_depth) {           // :227
+            const double zd = rng_uniform(prm.seed, ch.chain, gd, uslot++);        // :233
+            const int dir = (zd <= 0.5) ? -1 : 1;                    // :235
+            const double dstep = (double)dir * step_size;
+
+            // ---- nuts_build_tree(dir, ..., start = (prev_draw, mntm_vec), depth = tree_depth)
+            NutsRes<D> R;
+            uint32_t sp = 0, cur_depth = tree_depth;
+            double cur_draw[D], cur_mntm[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { cur_draw[i] = prev_draw[i]; cur_mntm[i] = mntm_vec[i]; }
+            bool calling = true;
+            for (;;) {
+                if (calling) {
+                    if (cur_depth == 0) {                            // nuts.ipp:126-160
+                        double nd[D], np_[D];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { nd[i] = cur_draw[i]; np_[i] = cur_mntm[i]; }
+                        leap_frog(dstep, nd, np_);
+                        const double pU = potential(nd), pK = kinetic(np_);
+                        R.n = (log_rand_val <= -pU - pK) ? 1u : 0u;  // :146
+                        R.s = (log_rand_val < 1000.0 - pU - pK) ? 1u : 0u;   // :147
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { R.new_draw[i] = nd[i]; R.pos[i] = nd[i]; R.neg[i] = nd[i]; R.mpos[i] = np_[i]; R.mneg[i] = np_[i]; }
+                        const double dd = -(pU + pK) + (prev_U + prev_K);
+                        R.alpha = det_exp((dd < 0.0) ? dd : 0.0);    // :157
+                        R.n_alpha = 1;
+                        calling = false;
+                    } else {                                         // first half: same start, one level down (:166-171)
+                        NutsFrame<D>& f = F[sp];
+#pragma unroll
+                        for (int i = 0; i < D; ++i) { f.start_draw[i] = cur_draw[i]; f.start_mntm[i] = cur_mntm[i]; }
+                        f.depth = cur_depth; f.phase = 1;
+                        ++sp; --cur_depth;
+                    }
+                } else {
+                    if (sp == 0) break;                              // R is the result of the top call
+                    NutsFrame<D>& g = F[sp - 1];
+                    if (g.phase == 1) {
+                        g.res = R;
+                        if (R.s == 1) {                              // second half from the edge on the dir side (:186-208)
+                            g.phase = 2;
+#pragma unroll
+                            for (int i = 0; i < D; ++i) {
+                                cur_draw[i] = (dir == -1) ? g.res.neg[i] : g.res.pos[i];
+                                cur_mntm[i] = (dir == -1) ? g.res.mneg[i] : g.res.mpos[i];
+                            }
+                            cur_depth = g.depth - 1;
+                            calling = true;
+                        } else {
+                            R = g.res; --sp;                         // :234-239
+                        }
+                    } else {
+                        // crossed outputs: the callee's pos-side results land in the caller's neg side for dir = -1 (:195),
+                        // its neg-side results in the caller's pos side for dir = +1 (:207); the other pair is a dummy
+#pragma unroll
+                        for (int i = 0; i < D; ++i) {
+                            if (dir == -1) { g.res.neg[i] = R.pos[i]; g.res.mneg[i] = R.mpos[i]; }
+                            else           { g.res.pos[i] = R.neg[i]; g.res.mpos[i] = R.mneg[i]; }
+                        }
+                        const double prob_val = (double)R.n / (double)(g.res.n + R.n);                 // :212
+                        const double zz = rng_uniform(prm.seed, ch.chain, gd, uslot++);                // :213
+                        if (zz < prob_val) {
+#pragma unroll
+                            for (int i = 0; i < D; ++i) g.res.new_draw[i] = R.new_draw[i];           // :215-217
+                        }
+                        g.res.n += R.n; g.res.alpha += R.alpha; g.res.n_alpha += R.n_alpha;          // :220-222
+                        g.res.s = R.s * uturn_ok(g.res.pos, g.res.neg, g.res.mpos, g.res.mneg);      // :226-229
+                        R = g.res; --sp;
+                    }
+                }
+            }
+            // ---- back in nuts_impl: the top call's outputs (nuts.cpp:241-256)
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                new_draw[i] = R.new_draw[i];
+                if (dir == -1) { draw_neg[i] = R.neg[i]; mntm_neg[i] = R.mneg[i]; }
+                else           { draw_pos[i] = R.pos[i]; mntm_pos[i] = R.mpos[i]; }
+            }
+            alpha_val = R.alpha; n_alpha_val = R.n_alpha;
+            if (R.s == 1) {                                          // :260
+                const double za = rng_uniform(prm.seed, ch.chain, gd, uslot++);    // :261
+                if (za < (double)R.n / (double)n_val) {              // :263
+                    prev_U = potential(new_draw);                    // :264-270
+#pragma unroll
+                    for (int i = 0; i < D; ++i) prev_draw[i] = new_draw[i];       // :272
+                    good_round = 1;
+                }
+            }
+            n_val += R.n;                                            // :283
+            tree_depth += 1;
+            s_val = R.s * uturn_ok(draw_pos, draw_neg, mntm_pos, mntm_neg);       // :286-289
+        }
+
+        if (gd < prm.n_adapt) {                                      // :294-302
+            const double m = (double)(gd + 1);
+            h_val += (1 / (m + prm.t0)) * (prm.delta - (alpha_val / (double)n_alpha_val) - h_val);
+            step_size = det_exp(mu_val - h_val * __builtin_sqrt(m) / prm.gamma);
+            epsilon_bar *= det_exp(det_pow(m, -prm.kappa) * (det_log(step_size) - det_log(epsilon_bar)));
+        } else if (prm.draw0 == 0) {
+            step_size = epsilon_bar;
+        }
+        if (prm.depth_trace) prm.depth_trace[(size_t)draw * prm.C + c] = tree_depth;
+        if (draw >= prm.n_burnin) {                                  // :306-309
+            n_acc += good_round;
+            if (prm.draws) ch.store_natural(prm.draws + (size_t)(draw - prm.n_burnin) * slab + c, prev_draw);
+        }
+    }
+    ch.store_natural(prm.theta + c, prev_draw);
+    if (prm.n_accept) prm.n_accept[c] = n_acc;
+    if (prm.n_leap) prm.n_leap[c] = n_leap;
+    if (prm.step_out) prm.step_out[c] = step_size;
+}
+
 }  // namespace mi

@@ -89,14 +89,14 @@ def sweep(n_cases=60, seed=1, verbose=True):
 
 
 def sweep_small(n_cases=60, seed=1, verbose=True):
-    """The one-lane-per-chain engine (hmc / mala / rwmh / rmhmc on the d = 2 normal model): random observations, bounds of every
+    """The one-lane-per-chain engine (hmc / mala / rwmh / rmhmc / nuts on the d = 2 normal model): random observations, bounds of every
     type, diagonal / dense preconditioners, degenerate sizes, step sizes that blow the chain up.  Returns the number of mismatches."""
     rng = np.random.default_rng(seed)
     fails = 0
     say = print if verbose else (lambda *a, **k: None)
-    algos = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "rwmh": orc.ALGO_RWMH, "rmhmc": orc.ALGO_RMHMC}
+    algos = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "rwmh": orc.ALGO_RWMH, "rmhmc": orc.ALGO_RMHMC, "nuts": orc.ALGO_NUTS}
     for case in range(n_cases):
-        algo = ["hmc", "mala", "rwmh", "rmhmc"][case % 4]
+        algo = ["hmc", "mala", "rwmh", "rmhmc", "nuts"][case % 5]
         n = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 100, 1000]))
         C = int(rng.choice([1, 3, 63, 64, 65, 130]))
         rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
@@ -117,15 +117,18 @@ def sweep_small(n_cases=60, seed=1, verbose=True):
             if rng.random() < 0.6:
                 A = rng.standard_normal((2, 2)); M = A @ A.T / 2 + M
             kw.update(precond_mat=M); okw.update(precond=M)
+        n_adapt, depth = int(rng.integers(0, burn + keep + 2)), int(rng.integers(0, 8))
         st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps,
-                                       n_fp_steps=n_fp, **kw)
+                                       n_fp_steps=n_fp, n_adapt_draws=n_adapt, max_tree_depth=depth, **kw)
         t = orc.TargetSpec(orc.TARGET_NORMAL_MODEL, 2, y=x, W=1)
-        s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, n_fp=n_fp, W=1, hoist=int(rng.integers(0, 2)), **okw)
-        desc = f"{algo} normal-model n={n} C={C} eps={eps} L={L} n_fp={n_fp} burn={burn} keep={keep} general={sorted(kw)}"
+        s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, n_fp=n_fp, W=1, hoist=int(rng.integers(0, 2)),
+                              n_adapt=n_adapt, max_depth=depth, **okw)
+        desc = f"{algo} normal-model n={n} C={C} eps={eps} L={L} n_fp={n_fp} burn={burn} keep={keep} adapt={n_adapt} depth={depth} general={sorted(kw)}"
         g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_NORMAL_MODEL, init, st, y=x, chain0=chain0)
         o_draws, o = orc.run_many(algos[algo], t, init, s, chain0=chain0)
         ok = (np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
               and np.array_equal(g["n_leap"], o["n_leap"]))
+        if algo == "nuts": ok = ok and np.array_equal(g["eps"], o["eps"], equal_nan=True)
         if not ok:
             fails += 1
             bad = np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))

@@ -41,20 +41,26 @@ def cases():
             yield f"{an}_{tn}", t, a
     # mcmc::rmhmc on the d = 2 normal model of the reference's example (examples/eigen/rmhmc_normal.cpp), Fisher metric
     x = 2.0 + 2.0 * synth.initial_states(60, 1, seed=17)[:, 0]
-    normal2 = dict(kind=orc.TARGET_NORMAL_MODEL, d=2, y=x, init_shift=np.array([2.0, 2.5]))
+    normal2 = dict(kind=orc.TARGET_NORMAL_MODEL, d=2, y=x, init_shift=np.array([2.0, 2.5]), W=1)
     yield "rmhmc_normal2", normal2, dict(algo=orc.ALGO_RMHMC, n_leap=2, step=0.03, n_fp=5)
+    # the other samplers on the same model (examples/eigen/{hmc,mala,nuts}_normal.cpp), one-lane-per-chain engine: sequential dots
+    yield "hmc_normal2", normal2, dict(algo=orc.ALGO_HMC, n_leap=3, step=0.1)
+    yield "mala_normal2", normal2, dict(algo=orc.ALGO_MALA, step=0.15)
+    yield "nuts_normal2", normal2, dict(algo=orc.ALGO_NUTS, step=1.0, n_adapt=10)
+    yield "rwmh_normal2", normal2, dict(algo=orc.ALGO_RWMH, step=0.15)
 
 
 def run_case(t, a):
     d = t["d"]
     blocks, bs = t.get("blocks", 0), t.get("block_size", 0)
-    tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=4, blocks=blocks, block_size=bs,
+    W = t.get("W", 4)
+    tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=W, blocks=blocks, block_size=bs,
                          eta_chains=t.get("eta_chains", 1))
     init = synth.initial_states(C, d, seed=99) * 0.5 + t.get("init_shift", 0.0)
     out = dict(draws=[], accept=[], depth=[], eps=[], n_leap=[])
     for c in range(C):
         s = orc.make_settings(seed=SEED, n_burnin=BURN, n_keep=KEEP, n_leap=a.get("n_leap", 1), step=a["step"],
-                              n_adapt=a.get("n_adapt", 1000), W=4, hoist=1, blocks=blocks, block_size=bs, chain_id=c,
+                              n_adapt=a.get("n_adapt", 1000), W=W, hoist=1, blocks=blocks, block_size=bs, chain_id=c,
                               n_fp=a.get("n_fp", 5))
         dr, info = orc.run_chain(a["algo"], tgt, init[c], s, traces=True)
         out["draws"].append(dr); out["accept"].append(info["accept"]); out["depth"].append(info["depth"])

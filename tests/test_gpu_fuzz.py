@@ -17,6 +17,6 @@ def test_random_cases_are_bit_exact(seed):
 
 @pytest.mark.parametrize("seed", [3, 5])
 def test_random_normal_model_cases_are_bit_exact(seed):
-    """hmc / mala / rwmh / rmhmc on the one-lane-per-chain engine (d = 2 normal model)"""
+    """hmc / mala / rwmh / rmhmc / nuts on the one-lane-per-chain engine (d = 2 normal model)"""
     import fuzz_parity
     assert fuzz_parity.sweep_small(80, seed, verbose=False) == 0
