@@ -101,3 +101,24 @@ def test_python_callable_as_target():
     draws, nacc = mcmc_amd.hmc_callback(np.zeros(d) + 0.5, logk, st)
     assert draws.shape == (800, d) and 0.6 < nacc / 800 <= 1.0
     assert np.abs(draws.var(0) * prec - 1).max() < 0.6
+
+
+@pytest.mark.gpu
+def test_reference_example_programs_run_on_the_device(tmp_path):
+    """examples/normal_model.cpp: the flows of the reference's {hmc,mala,nuts,rmhmc}_normal.cpp examples with the device target.
+    The posterior of (mu, sigma) concentrates at (xbar, sd) +- sd / sqrt(n)."""
+    exe = str(tmp_path / "normal_model")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", f"-I{ROOT}/include", f"{ROOT}/examples/normal_model.cpp",
+                           f"-L{ROOT}/mcmc_amd", "-lmi_mcmc", f"-Wl,-rpath,{ROOT}/mcmc_amd", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"data n=1000 xbar=(\S+) sd=(\S+)", out.stdout)
+    xbar, sd = float(m.group(1)), float(m.group(2))
+    for algo in ("hmc", "mala", "nuts", "rwmh"):
+        mm = re.search(rf"{algo} ok=1 rows=2000 cols=512 mean_mu=(\S+) mean_sigma=(\S+) acc0=(\S+)", out.stdout)
+        assert mm, out.stdout
+        assert abs(float(mm.group(1)) - xbar) < 0.03 and abs(float(mm.group(2)) - sd) < 0.03, (algo, out.stdout)
+        assert 0.1 < float(mm.group(3)) <= 1.0
+    mm = re.search(r"rmhmc ok=1 rows=2000 cols=512 mean_mu=(\S+) mean_sigma=(\S+) acc0=(\S+)", out.stdout)
+    assert mm, out.stdout                      # the reference's momentum sign (DESIGN.md section 3): valid but slowly mixing
+    assert abs(float(mm.group(1)) - xbar) < 0.6 and abs(float(mm.group(2)) - sd) < 0.6
