@@ -2,18 +2,26 @@
 //
 // Replaces the draw loop of mcmc::internal::hmc_impl (/root/reference/src/hmc.cpp:155-205) for
 // targets without a contraction (BASELINE config 5: d = 1024 ill-conditioned diagonal Gaussian).
-// With a diagonal precision and the identity preconditioner every dimension's (theta_i, p_i)
+// With a diagonal precision and the identity (or a diagonal) preconditioner every dimension's (theta_i, p_i)
 // trajectory is independent of the others through all L leapfrog steps; only the energies couple
-// them.  So: one lane per chain, the lane walks its d dimensions in blocks of 8 (= 4 Philox slots),
-// keeps 8 trajectories in flight for ILP, runs all L steps of each in registers and touches HBM once
-// per dimension per draw: read theta_i, write the proposal.  State is [d][C] (chain contiguous ->
-// coalesced), the proposal is written straight into the slab it will live in if accepted
-// (the kept-draw slab, or a ping-pong scratch slab during burn-in); a rejection copies instead.
-// Bound: fp64 VALU (5 ops per chain.dim.step, ~2 B of HBM per unit at L = 32), not HBM.
+// them.  Two kernels, same arithmetic, picked by the number of chains (hmc_diag_pick_lanes):
+// hmc_diag4_kernel spreads a chain over FOUR lanes (lane = 16 j + chain-in-wave, the layout of the MFMA kernels): lane j owns the
+// dimensions i = j (mod 4), i.e. of every block of 8 dimensions the pair (8b + j, 8b + 4 + j) -- exactly the two normals of
+// Philox slot 4b + j, so no lane generates a number it does not use; hmc_diag1_kernel keeps one chain per lane.
+// Each lane runs all L steps of its trajectories in
+// registers and touches HBM once per dimension per draw: read theta_i, write the proposal.  State is [d][C] (chain contiguous ->
+// 128-byte segments per j), the proposal is written straight into the slab it will live in if accepted (the kept-draw slab,
+// or a ping-pong scratch slab during burn-in); a rejection copies instead.
+//
+// Why four lanes per chain: the bound is the fp64 VALU (9 instructions per chain.dim.step, ~2 B of HBM per unit at L = 32),
+// and ONE wave issues an fp64 VALU instruction only every ~8 cycles whatever its instruction-level parallelism; a SIMD reaches
+// ~6 cycles per instruction with two resident waves and ~5 with four or more (measured, tools/valu_rate.hip).  With one lane
+// per chain a run of C chains has C/64 waves for 1024 SIMDs (config 5: two per SIMD); four lanes per chain give four times
+// as many (config 5: eight per SIMD, 10 % faster, and a chain count that would leave SIMDs empty fills them).
 //
 // Arithmetic identical to the oracle / the MFMA kernel: w_i = prec_i * theta_i, kicks p - (eps*w)/2,
-// drift theta + eps*p, dot products as 4 strided fma chains (dimension i -> chain i mod 4, ascending)
-// combined (q0+q2)+(q1+q3) -- all inside one lane, no cross-lane traffic.
+// drift theta + eps*p, dot products as 4 strided fma chains (dimension i -> chain i mod 4, ascending: lane j's own chain)
+// combined (q0+q2)+(q1+q3) by two shuffles (xor 32, xor 16), as dot4 of hmc_dense.hpp.
 #pragma once
 
 #include "det_math.hpp"
@@ -37,11 +45,130 @@ struct HmcDiagParams {
     const double* m_inv;    // PRECOND: diagonal of INV(precond_mat)
 };
 
+constexpr int HMC_DIAG_CHAINS_PER_BLOCK = 64;     // 4 waves x 16 chains
+
+// (q0 + q2) + (q1 + q3) over the four lanes of a chain; every lane of the chain gets the same bits
+__device__ __forceinline__ double diag_combine(double q)
+{
+    q = q + __shfl_xor(q, 32);
+    q = q + __shfl_xor(q, 16);
+    return q;
+}
+
 // PRECOND: a diagonal precond_mat M (hmc.cpp:57-59,158-160,171,184): p = sqrt(M) z, theta += eps (Minv p), K = p.(Minv p)/2 --
 // still one independent trajectory per dimension.  (The NaN poisoning of the reference's dense products, DESIGN.md section 3,
 // is not reproduced by this kernel, with or without M.)
 template <bool PRECOND>
-__global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
+__global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t j = (uint32_t)(lane >> 4);
+    const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (uint64_t)(lane & 15);
+    if (((uint64_t)blockIdx.x * 4 + wave) * 16 >= prm.C) return;          // whole wave past the end
+    const bool live = cl < prm.C;
+    const uint64_t c = live ? cl : prm.C - 1;           // dead lanes shadow the last chain (loads only; shuffles stay wave-wide)
+    const uint64_t chain = prm.chain0 + c;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps;
+    const double* prec = prm.prec;
+    const uint32_t L = prm.n_leap_steps;
+    const size_t slab = (size_t)d * C;
+
+    const double* cur = prm.theta + c;                  // this chain's column of the slab holding prev_draw
+    // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
+    double prev_U;
+    {
+        double q = 0.0;
+        for (uint32_t i = j; i < d; i += 4) {
+            const double t = cur[(size_t)i * C];
+            const double w = (prec ? prec[i] : 1.0) * t;
+            q = dfma(t, w, q);
+        }
+        prev_U = 0.5 * diag_combine(q);
+    }
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    uint32_t pp = 0;                                    // ping-pong index of the next free scratch slab
+
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        const bool kept = draw >= prm.n_burnin;
+        double* dst = (kept && prm.draws) ? prm.draws + (size_t)(draw - prm.n_burnin) * slab + c
+                                          : prm.scratch + (size_t)pp * slab + c;
+        if (dst == cur) { pp ^= 1u; dst = prm.scratch + (size_t)pp * slab + c; }   // never overwrite prev_draw
+        double qk0 = 0.0, qu1 = 0.0, qk1 = 0.0;
+        // two blocks of 8 dimensions per iteration: 4 trajectories in flight per lane (dims 8b+j, 8b+4+j, 8b+8+j, 8b+12+j)
+        for (uint32_t b = 0; b * 8 < d; b += 2) {
+            double z[4], th[4], pm[4], lam[4], w[4], mi_[PRECOND ? 4 : 1];
+            rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * b + j, STREAM_NORMAL, z[0], z[1]);
+            rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * (b + 1) + j, STREAM_NORMAL, z[2], z[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t i = 8 * b + 4 * (uint32_t)r + j;
+                const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
+                th[r] = cur[(size_t)ic * C];
+                lam[r] = prec ? prec[ic] : 1.0;
+                if constexpr (PRECOND) { pm[r] = prm.m_sqrt[ic] * z[r]; mi_[r] = prm.m_inv[ic]; }   // p = L z (hmc.cpp:158)
+                else pm[r] = z[r];                                        // L = I
+                w[r] = lam[r] * th[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (8 * b + 4 * (uint32_t)r + j < d) qk0 = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk0);
+            for (uint32_t k = 0; k < L; ++k) {                            // hmc.cpp:164-176
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                    if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
+                    else th[r] = th[r] + eps * pm[r];
+                    w[r] = lam[r] * th[r];
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t i = 8 * b + 4 * (uint32_t)r + j;
+                if (i < d) {
+                    qu1 = dfma(th[r], w[r], qu1);
+                    qk1 = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk1);
+                    if (live) dst[(size_t)i * C] = th[r];
+                }
+            }
+        }
+        const double prev_K = diag_combine(qk0) / 2.0;                    // hmc.cpp:160
+        double prop_U = 0.5 * diag_combine(qu1);                          // :178
+        if (!is_finite(prop_U)) prop_U = INF;
+        const double prop_K = diag_combine(qk1) / 2.0;                    // :184
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;
+        const double zu = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
+        const bool accept = zu < det_exp(comp_val);                       // the same bits on the four lanes of the chain
+        if (accept) {
+            cur = dst;
+            prev_U = prop_U;
+            if (!(kept && prm.draws)) pp ^= 1u;
+        } else if (kept && prm.draws) {
+            if (live)
+                for (uint32_t i = j; i < d; i += 4) dst[(size_t)i * C] = cur[(size_t)i * C];   // row = prev_draw (:202)
+            cur = dst;
+        }
+        if (kept) n_acc += accept ? 1u : 0u;
+    }
+    if (!live) return;
+    double* out = prm.theta + c;
+    if (cur != out)
+        for (uint32_t i = j; i < d; i += 4) out[(size_t)i * C] = cur[(size_t)i * C];
+    if (j == 0) {
+        if (prm.n_accept) prm.n_accept[c] = n_acc;
+        if (prm.n_leap) prm.n_leap[c] = (uint64_t)n_total * L;
+    }
+}
+
+// One lane per chain: the lane walks its d dimensions in blocks of 8 (= 4 Philox slots) with 8 trajectories in flight.  Fewer
+// instructions per unit than the four-lane kernel (one uniform / exp / pointer set per chain instead of four); used once the
+// chains alone fill every SIMD with waves, see hmc_diag_pick_lanes.
+template <bool PRECOND>
+__global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= prm.C) return;
@@ -135,5 +262,9 @@ __global__ __launch_bounds__(256) void hmc_diag_kernel(const HmcDiagParams prm)
     if (prm.n_accept) prm.n_accept[c] = n_acc;
     if (prm.n_leap) prm.n_leap[c] = (uint64_t)n_total * L;
 }
+
+// lanes per chain: 4 until one lane per chain alone gives every SIMD eight waves (C >= 8 x 1024 x 64), then 1.
+// Measured on one box, config 5 (131 072 chains, two waves per SIMD with one lane per chain): 4 lanes 52-55 ms, 1 lane 58-60 ms.
+inline int hmc_diag_pick_lanes(uint64_t C) { return C >= 8ull * 1024ull * 64ull ? 1 : 4; }
 
 }  // namespace mi

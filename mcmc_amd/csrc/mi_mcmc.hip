@@ -492,17 +492,21 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), &scratch);
         if (rc) return rc;
         q.scratch = static_cast<double*>(scratch);
+        int diag_lanes = mi::hmc_diag_pick_lanes(q.C);          // lanes per chain (hmc_diag.hpp); MI_HMC_DIAG_LANES=1|4 forces one (tests)
+        if (const char* e = getenv("MI_HMC_DIAG_LANES")) diag_lanes = (atoi(e) == 4) ? 4 : 1;
         DevBuf ms_d, mi_d;
         if (diag_precond_elementwise) {
             HIP_TRY(ms_d.alloc(d * 8)); HIP_TRY(mi_d.alloc(d * 8));
             HIP_TRY(hipMemcpy(ms_d.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(mi_d.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
             q.m_sqrt = ms_d.as<double>(); q.m_inv = mi_d.as<double>();
-            hipLaunchKernelGGL(mi::hmc_diag_kernel<true>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+            if (diag_lanes == 4) hipLaunchKernelGGL(mi::hmc_diag4_kernel<true>, dim3((unsigned)((q.C + 63) / 64)), dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(mi::hmc_diag1_kernel<true>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
         } else
-        hipLaunchKernelGGL(mi::hmc_diag_kernel<false>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+        if (diag_lanes == 4) hipLaunchKernelGGL(mi::hmc_diag4_kernel<false>, dim3((unsigned)((q.C + 63) / 64)), dim3(256), 0, st, q);
+        else hipLaunchKernelGGL(mi::hmc_diag1_kernel<false>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
         HIP_TRY(hipGetLastError());
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;

@@ -166,9 +166,11 @@ DIAG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("lanes", [1, 4])           # one lane per chain (many chains) / four lanes per chain (fewer chains)
 @pytest.mark.parametrize("kind,d,C,L,eps,burn,keep", DIAG_CASES)
-def test_hmc_elementwise_kernel_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep, monkeypatch):
+def test_hmc_elementwise_kernel_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep, lanes, monkeypatch):
     monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
+    monkeypatch.setenv("MI_HMC_DIAG_LANES", str(lanes))
     init = synth.initial_states(C, d, seed=12)
     prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
     if kind == "diag":
@@ -341,8 +343,10 @@ def test_hmc_logistic_bit_exact_vs_oracle(d, N, C, eps, L, burn, keep):
 
 
 # ---------------------------------------------------------------- diagonal precond_mat on the elementwise kernel (any d)
+@pytest.mark.parametrize("lanes", [1, 4])
 @pytest.mark.parametrize("kind,d,C,L,eps", [("diag", 200, 70, 6, 0.2), ("iso", 1024, 33, 4, 0.08), ("diag", 129, 300, 3, 0.1)])
-def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps):
+def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps, lanes, monkeypatch):
+    monkeypatch.setenv("MI_HMC_DIAG_LANES", str(lanes))
     prec = synth.ill_conditioned_diag(d, 50.0) if kind == "diag" else None
     M = np.diag((prec if prec is not None else np.ones(d)) * np.linspace(0.7, 1.4, d))   # mass matrix ~ the precision: every dimension at unit frequency
     init = synth.initial_states(C, d, seed=18) * 0.5
