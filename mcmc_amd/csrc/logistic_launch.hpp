@@ -24,7 +24,7 @@ struct LogitParams {
     double eps, s2, rs, cons_term, log_det;
 };
 
-enum { LOGIT_MALA = 0, LOGIT_HMC = 1 };
+enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2 };   // RWMH: eps carries par_scale (identity cov_mat)
 
 // bytes of device workspace a launch needs (block images of X, accepted state of every chain)
 size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C);

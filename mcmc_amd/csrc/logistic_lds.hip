@@ -48,8 +48,9 @@ size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C)
 
 int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
-    return algo == LOGIT_HMC ? launch_any<LOGIT_HMC>(prm, X_dev, y_dev, workspace, st)
-                             : launch_any<LOGIT_MALA>(prm, X_dev, y_dev, workspace, st);
+    return algo == LOGIT_HMC  ? launch_any<LOGIT_HMC>(prm, X_dev, y_dev, workspace, st)
+         : algo == LOGIT_RWMH ? launch_any<LOGIT_RWMH>(prm, X_dev, y_dev, workspace, st)
+                              : launch_any<LOGIT_MALA>(prm, X_dev, y_dev, workspace, st);
 }
 
 }  // namespace mi

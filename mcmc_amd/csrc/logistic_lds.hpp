@@ -444,6 +444,38 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             keep_draw(draw, accept);
             lap(td, 10);
         }
+    } else if constexpr (ALGO == LOGIT_RWMH) {
+        // RWMH (rwmh.cpp:123-151), identity cov_mat: proposal = prev + par_scale * z, value-only use of the fused evaluation
+        double prev_LP = first_lp, prop_LP;
+#pragma unroll 1
+        for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+            for (int m = 0; m < NSQ / 2; ++m) {
+                double z0, z1;
+                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
+                rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1);
+                const double za = (dim_of(2 * m) < d) ? z0 : 0.0;
+                const double zb = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                bp[2 * m] = *st(0, 2 * m) + eps * za;                            // :126
+                bp[2 * m + 1] = *st(0, 2 * m + 1) + eps * zb;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            evaluate(bp, gp, prop_LP);                                           // :128
+            double pl = prop_LP;
+            if (!is_finite(pl)) pl = -INF;                                       // :130-132
+            const double x = pl - prev_LP;
+            const double comp_val = (x < 0.0) ? x : 0.0;                         // std::min(0.0, x): NaN -> 0 (:136)
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u); // :137
+            const bool accept = z < det_exp(comp_val);                           // :139
+            if (accept) {
+                prev_LP = pl;
+                if (live) {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
+                }
+            }
+            keep_draw(draw, accept);
+        }
     } else {
         // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step
         // k+1 are at the same position -- and the value of the last one is prop_U.

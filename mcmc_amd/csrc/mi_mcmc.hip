@@ -290,6 +290,46 @@ int launched(const char* what, int hip_err)
     return MI_OK;
 }
 
+// hmc / rwmh on the logistic-regression target (identity preconditioner / cov_mat, no bounds): logit_lds_kernel<., HMC | RWMH>;
+// settings->step_size is the leapfrog step resp. par_scale
+int run_logit_plain(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    int rc;
+    const uint64_t d = target->d;
+    if (settings->vals_bound || settings->precond_mat)
+        return fail(MI_ERR_UNSUPPORTED, "%s: vals_bound / precond_mat / cov_mat with the logistic target are not implemented", who);
+    if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+    if (d > 512) return fail(MI_ERR_UNSUPPORTED, "%s: logistic target with d = %llu > 512 not implemented", who, (unsigned long long)d);
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    const uint64_t n = target->n_rows;
+    DevBuf Xo, yo;
+    const double *X_dev = target->X, *y_dev = target->y;
+    if (target->mem == MI_MEM_HOST) {
+        HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
+        HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
+        X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+    }
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    mi::LogitParams q{};
+    q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
+    q.C = chains->n_chains; q.chain0 = chains->chain0;
+    q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
+    q.seed = settings->rng_seed_value;
+    q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+    q.n_leap = (uint32_t)settings->n_leap_steps;
+    q.eps = settings->step_size;
+    q.draw0 = (uint32_t)chains->draw0;
+    rc = launch_logit(algo, q, X_dev, y_dev, st);
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
 // The one-lane-per-chain engine for the d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh and rmhmc with
 // any precond_mat / cov_mat and any bounds, and nuts.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.
 int run_small_normal_model(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -398,40 +438,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC) {
-        if (settings->vals_bound || settings->precond_mat)
-            return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound / precond_mat with the logistic target are not implemented");
-        if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
-        if (d > 512) return fail(MI_ERR_UNSUPPORTED, "hmc: logistic target with d = %llu > 512 not implemented", (unsigned long long)d);
-        if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
-        const uint64_t n = target->n_rows;
-        DevBuf Xo, yo;
-        const double *X_dev = target->X, *y_dev = target->y;
-        if (target->mem == MI_MEM_HOST) {
-            HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
-            HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
-            X_dev = Xo.as<double>(); y_dev = yo.as<double>();
-        }
-        StagedChains sc;
-        rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
-        if (rc) return rc;
-        mi::LogitParams q{};
-        q.d = (uint32_t)d; q.n_rows = (uint32_t)n; q.NB = (uint32_t)((n + 15) / 16);
-        q.C = chains->n_chains; q.chain0 = chains->chain0;
-        q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
-        q.seed = settings->rng_seed_value;
-        q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
-        q.n_leap = (uint32_t)settings->n_leap_steps;
-        q.eps = settings->step_size;
-        q.draw0 = (uint32_t)chains->draw0;
-        rc = launch_logit(mi::LOGIT_HMC, q, X_dev, y_dev, st);
-        if (rc) return rc;
-        rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
-        if (rc) return rc;
-        if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
-        return MI_OK;
-    }
+    if (target->kind == MI_TARGET_LOGISTIC) return run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
     // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
@@ -732,6 +739,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC) return run_logit_plain("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "rwmh: d = %llu > 128 not implemented", (unsigned long long)d);

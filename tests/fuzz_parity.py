@@ -23,7 +23,7 @@ def sweep(n_cases=60, seed=1, verbose=True):
 
     for case in range(n_cases):
         algo = ["hmc", "mala", "nuts", "rwmh"][case % 4]
-        tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo in ("hmc", "mala") else ["dense", "iso", "diag"])
+        tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo in ("hmc", "mala", "rwmh") else ["dense", "iso", "diag"])
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 128])) if tgt != "logit" else int(rng.choice([3, 17, 64, 65, 130, 300]))
         C = int(rng.choice([1, 3, 16, 17, 33, 70]))
         rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))

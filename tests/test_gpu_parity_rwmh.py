@@ -72,3 +72,29 @@ def test_rwmh_resumes_bit_exactly():
     a_draws, a = mcmc_amd.rwmh(mcmc_amd.TARGET_GAUSS_DENSE, init, mk(2, 4), prec=prec)
     b_draws, b = mcmc_amd.rwmh(mcmc_amd.TARGET_GAUSS_DENSE, a["theta"].T.copy(), mk(0, 5), prec=prec, draw0=6)
     assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
+
+
+# ---------------------------------------------------------------- logistic-regression target (logit_lds_kernel<., RWMH>)
+LOGIT_CASES = [
+    # d,   N,    C,  par_scale, burn, keep
+    (5, 40, 16, 0.30, 5, 20),        # SURVEY 8(c) golden shape "logistic d=5"
+    (64, 100, 20, 0.05, 3, 8),       # one tile per wave, ragged N and C
+    (100, 333, 40, 0.03, 2, 6),      # d_pad 128, ragged everything
+    (512, 1024, 32, 0.01, 2, 4),     # config 3 dimensions
+    (300, 64, 17, 0.05, 0, 10),
+]
+
+
+@pytest.mark.parametrize("d,N,C,scale,burn,keep", LOGIT_CASES)
+def test_rwmh_logistic_bit_exact_vs_oracle(d, N, C, scale, burn, keep):
+    X, y = synth.logistic_problem(d, N, seed=4)
+    init = synth.initial_states(C, d, seed=41) * 0.1
+    st = mcmc_amd.default_settings(rng_seed_value=123, n_burnin_draws=burn, n_keep_draws=keep, step_size=scale)
+    g_draws, g = mcmc_amd.rwmh(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=3)
+    dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=dq, eta_chains=2)
+    s = orc.make_settings(seed=123, n_burnin=burn, n_keep=keep, step=scale, W=4, blocks=4, block_size=dq)
+    o_draws, o = orc.run_many(orc.ALGO_RWMH, t, init, s, chain0=3)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert 0 < int(g["n_accept"].sum()) < C * keep
