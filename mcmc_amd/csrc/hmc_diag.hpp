@@ -13,7 +13,7 @@
 // 128-byte segments per j), the proposal is written straight into the slab it will live in if accepted (the kept-draw slab,
 // or a ping-pong scratch slab during burn-in); a rejection copies instead.
 //
-// Why four lanes per chain: the bound is the fp64 VALU (9 instructions per chain.dim.step, ~2 B of HBM per unit at L = 32),
+// Why four lanes per chain: the bound is the fp64 VALU (7 instructions per chain.dim.step, ~2 B of HBM per unit at L = 32),
 // and ONE wave issues an fp64 VALU instruction only every ~8 cycles whatever its instruction-level parallelism; a SIMD reaches
 // ~6 cycles per instruction with two resident waves and ~5 with four or more (measured, tools/valu_rate.hip).  With one lane
 // per chain a run of C chains has C/64 waves for 1024 SIMDs (config 5: two per SIMD); four lanes per chain give four times
@@ -115,14 +115,30 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (8 * b + 4 * (uint32_t)r + j < d) qk0 = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk0);
-            for (uint32_t k = 0; k < L; ++k) {                            // hmc.cpp:164-176
+            // hmc.cpp:164-176.  The second half-step of step k and the first of step k+1 see the same gradient, hence the same
+            // (eps*w)/2: formed once, subtracted twice (the reference's two roundings) -- 7 instead of 9 operations per step.
+            if (L > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pm[r] = pm[r] - (eps * w[r]) / 2.0;                    // first half-step of step 0
+            }
+            for (uint32_t k = 0; k + 1 < L; ++k) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
                     if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
                     else th[r] = th[r] + eps * pm[r];
                     w[r] = lam[r] * th[r];
-                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                    const double t = (eps * w[r]) / 2.0;
+                    pm[r] = pm[r] - t;                                                             // second half-step of step k
+                    pm[r] = pm[r] - t;                                                             // first half-step of step k+1
+                }
+            }
+            if (L > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);
+                    else th[r] = th[r] + eps * pm[r];
+                    w[r] = lam[r] * th[r];
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;                                            // second half-step of the last step
                 }
             }
 #pragma unroll
@@ -218,14 +234,30 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) if (8 * b + r < d) qk0[r & 3] = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk0[r & 3]);
-            for (uint32_t k = 0; k < L; ++k) {                            // hmc.cpp:164-176
+            // hmc.cpp:164-176.  The second half-step of step k and the first of step k+1 see the same gradient, hence the same
+            // (eps*w)/2: formed once, subtracted twice (the reference's two roundings) -- 7 instead of 9 operations per step.
+            if (L > 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) pm[r] = pm[r] - (eps * w[r]) / 2.0;                    // first half-step of step 0
+            }
+            for (uint32_t k = 0; k + 1 < L; ++k) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
                     if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
                     else th[r] = th[r] + eps * pm[r];
                     w[r] = lam[r] * th[r];
-                    pm[r] = pm[r] - (eps * w[r]) / 2.0;
+                    const double t = (eps * w[r]) / 2.0;
+                    pm[r] = pm[r] - t;                                                             // second half-step of step k
+                    pm[r] = pm[r] - t;                                                             // first half-step of step k+1
+                }
+            }
+            if (L > 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);
+                    else th[r] = th[r] + eps * pm[r];
+                    w[r] = lam[r] * th[r];
+                    pm[r] = pm[r] - (eps * w[r]) / 2.0;                                            // second half-step of the last step
                 }
             }
 #pragma unroll
