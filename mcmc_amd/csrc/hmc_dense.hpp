@@ -106,16 +106,27 @@ __device__ __forceinline__ void matvec_mfma(const double* __restrict__ afrag, co
     constexpr int NS = 4 * NT;
     double4_t acc[NT];
     double a_cur[NT], a_nxt[NT];
+    // ds_read_b64 carries a 16-bit byte offset: fragments (t, s) with t >= 4 of a d = 128 matrix lie 64 KB or more past
+    // `afrag`, and the compiler then forms each of those 128 addresses with a VALU add per read (126 v_add_u32 per mat-vec,
+    // a quarter of the loop's VALU instructions).  A second, opaque base 64 KB up keeps every read on an immediate offset.
+    typedef const double __attribute__((address_space(3)))* lds_cptr;
+    lds_cptr lo = (lds_cptr)afrag;
+    uint32_t hi_off = (uint32_t)(uintptr_t)lo + (NT > 4 ? 4u * NS * 64u * 8u : 0u);
+    if constexpr (NT > 4) asm volatile("" : "+v"(hi_off));
+    lds_cptr hi = (lds_cptr)(uintptr_t)hi_off;
+    auto frag = [&](int t, int s) __attribute__((always_inline)) -> double {
+        return (NT > 4 && t >= 4) ? hi[((t - 4) * NS + s) * 64] : lo[(t * NS + s) * 64];
+    };
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-        a_cur[t] = afrag[(t * NS) * 64];
+        a_cur[t] = frag(t, 0);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a_nxt[t] = afrag[(t * NS + s + 1) * 64];
+            for (int t = 0; t < NT; ++t) a_nxt[t] = frag(t, s + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
