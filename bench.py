@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- leapfrog-steps/sec (chains x dims x steps / s) of the many-chain HMC hot path.
+"""bench.py -- throughput of the many-chain sampling hot path on MI355X, one JSON line per run.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8(d) "C2"): mcmc::hmc on a d=128 correlated
-Gaussian (P = A A^T / d + I, analytic gradient), 65 536 chains per GPU, fp64, step_size 0.05,
-n_leap_steps 16, 100 burn-in + 100 kept draws.  One "step" = one mi_mcmc_hmc_run call = that whole
-sampling run for every chain of the rank, with target, initial states and output buffers already
-resident in HBM.  Chains shard across ranks by global chain id with no data-path collective
-(scaling "weak": 65 536 chains per GPU; pass --scaling strong to keep 65 536 chains in total).
+Default workload = BASELINE.json configs[1] (SURVEY.md 8(d) "C2"): mcmc::hmc on a d=128 correlated Gaussian
+(P = A A^T / d + I, analytic gradient), 65 536 chains, fp64, step_size 0.05, n_leap_steps 16, 100 burn-in + 100 kept
+draws.  `--config 3|4|5` selects the other single-GPU BASELINE configs (MALA d=512 logistic regression, 262 144 chains;
+NUTS d=128, 65 536 chains, depth 10; one GPU's 131 072-chain shard of the d=1024 ill-conditioned HMC run), each with its
+own roofline object.  One "step" = one mi_mcmc_<algo>_run call = that whole sampling run for every chain of the rank, with
+target, initial states and output buffers already resident in HBM.
+
+Multi-GPU (torchrun, one rank per GPU): chains shard by global chain id (mcmc_amd.dist.shard_bounds) with no data-path
+collective.  north_star asks for STRONG scaling at 65 536 chains, so with WORLD_SIZE > 1 the total chain count stays
+fixed and every rank takes its shard ("scaling": "strong"); `--scaling weak` keeps the per-GPU count fixed instead.
+`--collate` additionally times the one exchange the path has (RCCL all-gather of the kept draws, HBM to HBM).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- fp64 matrix-core bound of the fused HMC kernel: algorithmic flops per launch
-                  (264 flop per chain.dim.leapfrog at d=128) / HIP-event duration
-  cpu_baseline -- the CPU oracle (oracle/liboracle.so, a port of the reference algorithm) timed on
-                  this box's host cores on a bounded sample of the same workload.
+  roofline     -- the dominant kernel against the resource that bounds it: algorithmic flops per launch
+                  / HIP-event duration measured here on the launch stream; `traffic` = HBM bytes per launch from the
+                  committed rocprofv3 PMC passes of this exact workload (profiles/r2_c<N>_pmc.json), else null
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores on a
+                  bounded sample of the same workload: Mode A (reference-faithful work profile) and Mode B
+                  (optimised CPU: same bits, gradient reuse, no identity mat-vecs, SIMD mat-vec), built with the
+                  reference's own flags (-O3 -march=native -ffp-contract=fast -fopenmp, ref: configure:196-214).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,14 +35,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= vector) peak; not in the in-image guide
-# HBM bytes per launch of the default workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-# command (profiles/r1_hmc_pmc.json): (2.3 + 34.0) GB. Not re-measured here (counters cannot be read in-process);
-# reported only for the exact profiled configuration, null otherwise.  FETCH_SIZE is uncorrected (8-B-per-lane loads).
-PROFILED_TRAFFIC_BYTES = {(65536, 128, 16, 100, 100): 3.64e10}
+FP64_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= vector) peak; the in-image guide lists no fp64 figure
 
-WORKLOAD = dict(d=128, chains_per_gpu=65536, n_leap_steps=16, step_size=0.05,
-                n_burnin_draws=100, n_keep_draws=100, seed=2024)
+# d, chains (per GPU when weak / total when strong), sampler settings: SURVEY.md 8(d), frozen in BASELINE.md
+WORKLOADS = {
+    2: dict(algo="hmc", d=128, chains=65536, n_leap_steps=16, step_size=0.05, n_burnin_draws=100, n_keep_draws=100, seed=2024,
+            name="BASELINE configs[1]: mcmc::hmc, d=128 dense-precision Gaussian (P=AA^T/d+I), analytic grad, fp64",
+            metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=128 correlated Gaussian, 65536 chains",
+            unit="chain*dim*leapfrog-steps/s", kernel="hmc_gauss_mfma_kernel<8, 8>", bound="mfma"),
+    3: dict(algo="mala", d=512, n_rows=1024, chains=262144, step_size=0.02, n_burnin_draws=100, n_keep_draws=100, seed=6,
+            name="BASELINE configs[2]: mcmc::mala, d=512 Bayesian logistic regression (N=1024 synthetic rows), fp64",
+            metric="MALA draws/sec (chains*dims*draws/s), d=512 logistic regression, 262144 chains",
+            unit="chain*dim*draws/s", kernel="logit_lds_kernel<8, MALA>", bound="mfma"),
+    4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
+            name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
+            metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",
+            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_async_kernel<8>", bound="mfma"),
+    5: dict(algo="hmc", d=1024, chains=131072, n_leap_steps=32, step_size=0.005, n_burnin_draws=20, n_keep_draws=8, seed=8,
+            name="BASELINE configs[4], one GPU's shard: mcmc::hmc, d=1024 diagonal Gaussian (cond 1e4), 131072 of 2^20 chains, fp64",
+            metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=1024 ill-conditioned Gaussian, 131072 chains per GPU",
+            unit="chain*dim*leapfrog-steps/s", kernel="hmc_diag4_kernel", bound="valu-fp64"),
+}
+
+
+def flop_per_unit(cfg):
+    """Algorithmic fp64 flops per metric unit."""
+    if cfg["algo"] == "mala":
+        return 4 * cfg["n_rows"]            # two N x d products (eta = X beta, X^T r) per evaluation, one evaluation per draw
+    if cfg["d"] <= 128:
+        return 2 * cfg["d"] + 8             # dense mat-vec with end-of-step gradient reuse + two half-kicks + drift
+    return 10                               # diagonal target: lambda*theta, kick (3), kick (3), drift (2) + the shared half-step
 
 
 def usable_cores():
@@ -48,24 +79,76 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, prec):
-    """Oracle (port of src/hmc.cpp, reference-faithful work profile) on the host cores."""
-    import orc   # tests/orc.py: ctypes binding of oracle/liboracle.so
+def build_inputs(cfg, C, chain0):
+    """Host-side synthetic inputs of a workload for chains [chain0, chain0 + C): (target kwargs, init [C, d])."""
     from mcmc_amd import synth
-    cores = usable_cores()
-    n_chains = 128 * cores      # ~10 s of CPU work on the box's 16 granted cores (0.09 s per chain of this workload)
     d = cfg["d"]
-    init = synth.initial_states(n_chains, d, seed=3)
-    tgt = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
-    st = orc.make_settings(seed=cfg["seed"], n_burnin=cfg["n_burnin_draws"], n_keep=cfg["n_keep_draws"],
-                           n_leap=cfg["n_leap_steps"], step=cfg["step_size"], W=4)
-    t0 = time.perf_counter()
-    _, info = orc.run_many(orc.ALGO_HMC, tgt, init, st, n_threads=cores, want_draws=False)
-    dt = time.perf_counter() - t0
-    units = float(info["n_leap"].sum()) * d
-    return {"value": units / dt, "unit": "chain*dim*leapfrog-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_chains} chains x {cfg['n_burnin_draws'] + cfg['n_keep_draws']} draws x "
-                      f"{cfg['n_leap_steps']} leapfrogs, d={d}, {dt:.2f}s wall, OpenMP over chains"}
+    if cfg["algo"] == "mala":
+        X, y = synth.logistic_problem(d, cfg["n_rows"])
+        init = np.zeros((C, d))
+        init[:, 0] = -0.5 + (chain0 + np.arange(C)) / float(max(1, cfg["chains"] - 1))       # distinct starts, by global chain id
+        return dict(X=X, y=y), init
+    if d > 128:
+        prec = synth.ill_conditioned_diag(d, 1.0e4)
+        return dict(prec=prec), synth.initial_states(C, d, seed=3, chain0=chain0) / np.sqrt(prec)[None, :]
+    return dict(prec=synth.dense_gaussian_precision(d)), synth.initial_states(C, d, seed=3, chain0=chain0)
+
+
+def cpu_baseline(cfg_id, cfg):
+    """The oracle on the host cores, bounded sample of the same workload; Mode A and (hmc) Mode B."""
+    cores = usable_cores()
+    flags = "-O3 -march=native -ffp-contract=fast -DNDEBUG -fopenmp (ref: configure:196-214), gcc"
+    fast = os.path.join(ROOT, "oracle", "liboracle_fast.so")
+    try:        # -march=native: built on the box it runs on
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.environ["ORC_LIB"] = fast
+    except (OSError, subprocess.CalledProcessError):
+        flags = "-O3 -mavx2 -mfma -ffp-contract=off -fopenmp (the parity build: no compiler on this box for the -march=native build)"
+    import orc   # tests/orc.py: ctypes binding of oracle/liboracle*.so
+    d = cfg["d"]
+    n_tot = cfg["n_burnin_draws"] + cfg["n_keep_draws"]
+    # chains per core so that each mode is ~5-15 s of wall time on the box's cores (measured per-chain costs, DESIGN.md 5)
+    per_core = {2: (64, 1024), 3: (1, None), 4: (16, None), 5: (6, 2048)}[cfg_id]
+    out = {"unit": cfg["unit"], "cores": cores, "kind": "port", "flags": flags}
+    for mode, tag in ((0, "mode_a"), (1, "mode_b")):
+        if per_core[mode] is None:
+            continue
+        n_chains = per_core[mode] * cores
+        kw, init = build_inputs(cfg, n_chains, 0)
+        kind = {"hmc": orc.TARGET_DENSE if d <= 128 else orc.TARGET_DIAG, "nuts": orc.TARGET_DENSE, "mala": orc.TARGET_LOGISTIC}[cfg["algo"]]
+        tgt = orc.TargetSpec(kind, d, W=1, **kw)                       # reference-shaped reduction order
+        st = orc.make_settings(seed=cfg["seed"], n_burnin=cfg["n_burnin_draws"], n_keep=cfg["n_keep_draws"],
+                               n_leap=cfg.get("n_leap_steps", 1), step=cfg.get("step_size", 1.0),
+                               n_adapt=cfg.get("n_adapt_draws", 1000), max_depth=cfg.get("max_tree_depth", 10),
+                               W=1, hoist=0, work_mode=mode)
+        algo = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS}[cfg["algo"]]
+        t0 = time.perf_counter()
+        _, info = orc.run_many(algo, tgt, init, st, n_threads=cores, want_draws=False)
+        dt = time.perf_counter() - t0
+        units = float(n_chains) * d * n_tot if cfg["algo"] == "mala" else float(info["n_leap"].sum()) * d
+        out[tag] = {"value": units / dt, "chains": n_chains, "wall_s": dt}
+    out["value"] = out["mode_a"]["value"]                               # the reference's work profile is THE baseline
+    out["mode_a"]["what"] = ("reference-faithful work profile: every callback of the reference (hmc: 2 gradient calls per leapfrog + "
+                             "1 value call per draw; mala: 3 gradient + 1 value, factorisation inside every dmvnorm), dense "
+                             "identity mat-vecs, allocation per call")
+    if "mode_b" in out:
+        out["mode_b"]["what"] = ("optimised CPU, bit-identical draws: gradient reuse, no identity mat-vecs, SIMD (axpy-form) mat-vec, "
+                                 "no allocation in the loop")
+    out["sample"] = (f"{out['mode_a']['chains']} chains (mode A) x {n_tot} draws of this workload, d={d}, OpenMP over chains on "
+                     f"{cores} cores; rates extrapolate linearly in the chain count (chains are independent)")
+    return out
+
+
+def profiled_traffic(cfg_id, key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes, if they are of this workload."""
+    p = os.path.join(ROOT, "profiles", f"r2_c{cfg_id}_pmc.json")
+    try:
+        j = json.load(open(p))
+        if j.get("workload_key") == list(key):
+            return j["derived"]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -73,27 +156,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / total (strong)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE config (2 = the headline)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when WORLD_SIZE > 1 (north_star), n/a at one GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains: total (strong) / per GPU (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collate", action="store_true",
-                    help="also time the RCCL all-gather of the last kept draw (not part of `value`)")
+                    help="also time the RCCL all-gather of the kept draws (not part of `value`)")
     args = ap.parse_args()
 
     import torch
     import mcmc_amd
-    from mcmc_amd import synth
+    from mcmc_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # BENCH_TEST_SHARE_GPU=1 (test only): all ranks on GPU 0 with the gloo backend, to exercise the N>1 code path on a 1-GPU box
+    # BENCH_TEST_SHARE_GPU=1 (test only): gloo backend and LOCAL_RANK folded onto the visible devices, to exercise the N>1 path on a 1-GPU box
     share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
-    if share:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+    dev = mdist.bind_device(None if share else int(os.environ.get("LOCAL_RANK", "0")))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -101,44 +183,49 @@ def main():
         if share:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    cfg = dict(WORKLOAD)
-    d = cfg["d"]
-    if args.scaling == "weak":
-        C = args.chains or cfg["chains_per_gpu"]
-        chain0 = rank * C
+    cfg = dict(WORKLOADS[args.config])
+    d, algo = cfg["d"], cfg["algo"]
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    if scaling == "weak":
+        C = args.chains or cfg["chains"]
+        chain0, total = rank * C, (args.chains or cfg["chains"]) * world
     else:
-        total = args.chains or cfg["chains_per_gpu"]
-        C = total // world
-        chain0 = rank * C
+        total = args.chains or cfg["chains"]
+        chain0, C = mdist.shard_bounds(total, world, rank)              # balanced, no chain dropped
     n_keep, n_tot = cfg["n_keep_draws"], cfg["n_burnin_draws"] + cfg["n_keep_draws"]
 
-    dev = torch.device("cuda", local_rank)
-    prec_h = synth.dense_gaussian_precision(d)
-    prec = torch.from_numpy(prec_h).to(dev)
-    theta0 = torch.from_numpy(np.ascontiguousarray(synth.initial_states(C, d, seed=3, chain0=chain0).T)).to(dev)
+    kw, init = build_inputs(cfg, max(C, 1), chain0)
+    kw_dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in kw.items()}
+    theta0 = torch.from_numpy(np.ascontiguousarray(init.T)).to(dev)
     theta = torch.empty_like(theta0)
-    draws = torch.empty((n_keep, d, C), dtype=torch.float64, device=dev)
-    n_accept = torch.zeros(C, dtype=torch.int64, device=dev)
-    n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
+    draws = torch.empty((n_keep, d, max(C, 1)), dtype=torch.float64, device=dev)
+    n_accept = torch.zeros(max(C, 1), dtype=torch.int64, device=dev)
+    n_leap = torch.zeros(max(C, 1), dtype=torch.int64, device=dev)
+    eps_out = torch.zeros(max(C, 1), dtype=torch.float64, device=dev)
 
-    target = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE)
-    settings = mcmc_amd.default_settings(rng_seed_value=cfg["seed"], n_burnin_draws=cfg["n_burnin_draws"],
-                                         n_keep_draws=n_keep, n_leap_steps=cfg["n_leap_steps"],
-                                         step_size=cfg["step_size"])
-    chains = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=draws, n_accept=n_accept,
-                                  n_leapfrogs=n_leap, mem=mcmc_amd.MEM_DEVICE)
+    kind = {"hmc": mcmc_amd.TARGET_GAUSS_DENSE if d <= 128 else mcmc_amd.TARGET_GAUSS_DIAG,
+            "nuts": mcmc_amd.TARGET_GAUSS_DENSE, "mala": mcmc_amd.TARGET_LOGISTIC}[algo]
+    target = mcmc_amd.make_target(kind, d, mem=mcmc_amd.MEM_DEVICE, **kw_dev)
+    skw = dict(rng_seed_value=cfg["seed"], n_burnin_draws=cfg["n_burnin_draws"], n_keep_draws=n_keep)
+    for k in ("n_leap_steps", "step_size", "n_adapt_draws", "max_tree_depth"):
+        if k in cfg:
+            skw[k] = cfg[k]
+    settings = mcmc_amd.default_settings(**skw)
+    chains = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=draws, n_accept=n_accept, n_leapfrogs=n_leap,
+                                  step_size=eps_out, mem=mcmc_amd.MEM_DEVICE)
     stream = torch.cuda.current_stream().cuda_stream
 
     def one_step():
         theta.copy_(theta0)                     # same start every step (device-to-device, untimed by events)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        mcmc_amd.run("hmc", target, settings, chains, stream=stream)
+        ev0.record()                            # torch's current stream IS the launch stream (passed to the engine below)
+        if C > 0:
+            mcmc_amd.run(algo, target, settings, chains, stream=stream)
         ev1.record()
         return ev0, ev1
 
@@ -156,66 +243,81 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
 
+    # units of this rank per step: executed leapfrog steps x dims (hmc, nuts) or draws x dims (mala)
+    if algo == "mala":
+        units_rank = float(C) * d * n_tot
+    else:
+        units_rank = float(n_leap[:C].double().sum().item()) * d if C else 0.0
+        if algo == "hmc" and C:
+            assert int(n_leap[0].item()) == n_tot * cfg["n_leap_steps"]
+    units_all = units_rank
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, units_rank], dtype=torch.float64, device=dev if not share else "cpu")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, units_all = float(tmax[0].item()), float(t[1].item())
 
     collate_ms = None
-    if args.collate and dist is not None:
-        last = draws[-1].contiguous()
-        gathered = torch.empty((world * last.shape[0],) + tuple(last.shape[1:]), dtype=last.dtype, device=dev)
+    if args.collate and dist is not None and not share:
+        c_max = mdist.shard_bounds(total, world, 0)[1] if scaling == "strong" else C
+        send = torch.zeros((n_keep, d, c_max), dtype=torch.float64, device=dev)
+        send[:, :, :C] = draws[:, :, :C]
+        gathered = torch.empty((world * n_keep, d, c_max), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, send)     # warm-up (communicator set-up)
         barrier()
         tc = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, last)
+        dist.all_gather_into_tensor(gathered, send)     # the path's one exchange: every rank ends with all kept draws, HBM to HBM
         barrier()
         collate_ms = (time.perf_counter() - tc) * 1e3
+        del gathered, send
 
     # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, autocovariances pooled
     # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region
-    stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
-    ess_total_rank = float(stats["ess"].min()) * C
-    rhat_max = float(stats["rhat"].max())
-
-    leap_per_chain = int(n_leap[0].item())
-    acc_rate = float(n_accept.double().mean().item()) / n_keep
-    assert leap_per_chain == n_tot * cfg["n_leap_steps"]
-    units_per_step_rank = float(C) * d * leap_per_chain
-    units_per_step = units_per_step_rank * world
-    value = units_per_step * args.steps / elapsed
+    ess_total_rank, rhat_max = 0.0, float("nan")
+    if C > 0 and rank == 0:
+        stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+        ess_total_rank = float(stats["ess"].min()) * C
+        rhat_max = float(stats["rhat"].max())
+    acc_rate = float(n_accept[:C].double().mean().item()) / n_keep if C else float("nan")
+    value = units_all * args.steps / elapsed
 
     if rank == 0:
-        flop_per_unit = 2 * d + 8                      # dense mat-vec with gradient reuse + leapfrog
+        fpu = flop_per_unit(cfg)
         k_ms = float(np.mean(kernel_ms))
-        achieved = units_per_step_rank * flop_per_unit / (k_ms * 1e-3) / 1e12
+        achieved = units_rank * fpu / (k_ms * 1e-3) / 1e12
+        key = (args.config, C, d, n_tot)
         out = {
-            "metric": "leapfrog-steps/sec (chains*dims*steps/s), HMC d=128 correlated Gaussian, 65536 chains/GPU",
-            "value": value, "unit": "chain*dim*leapfrog-steps/s",
+            "metric": cfg["metric"], "value": value, "unit": cfg["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: mcmc::hmc, d=128 dense-precision Gaussian "
-                                   "(P=AA^T/d+I), analytic grad, fp64",
-                       "chains_per_gpu": C, "chains_total": C * world, "d": d,
-                       "n_leap_steps": cfg["n_leap_steps"], "step_size": cfg["step_size"],
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": cfg["name"], "chains_per_gpu": C, "chains_total": total, "d": d,
                        "n_burnin_draws": cfg["n_burnin_draws"], "n_keep_draws": n_keep,
-                       "parallelism": f"chains sharded x{world}, no data-path collective",
+                       "parallelism": f"chains sharded x{world} by global chain id, no data-path collective",
                        "accept_rate": acc_rate},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
-                         "traffic": PROFILED_TRAFFIC_BYTES.get((C, d, cfg["n_leap_steps"], cfg["n_burnin_draws"], n_keep)),
-                         "kernel": "hmc_gauss_mfma_kernel<8, 8>", "kernel_ms": k_ms,
-                         "flop_per_unit": flop_per_unit},
+            "roofline": {"bound": cfg["bound"], "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": profiled_traffic(args.config, key),
+                         "kernel": cfg["kernel"], "kernel_ms": k_ms, "flop_per_unit": fpu},
         }
+        for k in ("n_leap_steps", "step_size", "n_adapt_draws", "max_tree_depth", "n_rows"):
+            if k in cfg:
+                out["config"][k] = cfg[k]
+        if algo != "mala" and C:
+            out["config"]["leapfrogs_per_chain_mean"] = units_rank / d / C
+        if algo == "nuts":
+            out["config"]["adapted_step_size_mean"] = float(eps_out[:C].mean().item())
         out["ess_per_sec"] = ess_total_rank * world / (elapsed / args.steps)
-        out["ess_note"] = ("min-over-dims Geyer-IPS ESS of the 100 kept draws (autocovariance pooled over all chains on the device), "
-                           "x chains, / seconds per step")
+        out["ess_note"] = (f"min-over-dims Geyer-IPS ESS of the {n_keep} kept draws (autocovariance pooled over all chains of rank 0 on "
+                           "the device), x chains x ranks, / seconds per step")
         out["rhat_max"] = rhat_max
         if collate_ms is not None:
-            out["collate_last_draw_allgather_ms"] = collate_ms
+            out["collate_allgather_ms"] = collate_ms
+            out["collate_bytes_per_rank"] = n_keep * d * C * 8
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, prec_h)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["cpu_baseline"] = cpu_baseline(args.config, cfg)
+            out["gpu_over_cpu"] = {k: value / out["cpu_baseline"][k]["value"] for k in ("mode_a", "mode_b") if k in out["cpu_baseline"]}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

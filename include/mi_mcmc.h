@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000104
+#define MI_MCMC_VERSION 0x000200
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -62,6 +62,15 @@ typedef enum mi_target_kind {
 
 typedef enum mi_mem { MI_MEM_HOST = 0, MI_MEM_DEVICE = 1 } mi_mem;
 
+/* Explicit kernel choice (mi_target.kernel_hint).  Every kernel that can serve a request produces the SAME bits, so a hint
+ * changes speed only; a hint the request cannot honour is ignored.  The library reads no environment variable. */
+typedef enum mi_kernel_hint {
+    MI_KERNEL_AUTO = 0,
+    MI_KERNEL_ELEMENTWISE_1LANE = 1,  /* hmc, separable Gaussian targets: one lane per chain (default for d > 128, many chains) */
+    MI_KERNEL_ELEMENTWISE_4LANE = 2,  /* hmc, separable Gaussian targets: four lanes per chain */
+    MI_KERNEL_NUTS_LOCKSTEP = 3       /* nuts, unbounded Gaussian targets: the lock-step predecessor of the asynchronous kernel */
+} mi_kernel_hint;
+
 typedef struct mi_target {
     uint32_t      struct_size;
     int32_t       kind;        /* mi_target_kind */
@@ -71,7 +80,7 @@ typedef struct mi_target {
     const double* y;           /* LOGISTIC: n_rows */
     uint64_t      n_rows;
     int32_t       mem;         /* mi_mem: where prec / X / y live */
-    int32_t       reserved;
+    int32_t       kernel_hint; /* mi_kernel_hint, 0 = automatic */
 } mi_target;
 
 /* POD mirror of algo_settings_t restricted to what hmc / mala / nuts read.
@@ -105,20 +114,28 @@ typedef struct mi_chains {
     double*   theta;          /* in: initial_vals [d][C]; out: last state of every chain */
     double*   draws;          /* out [n_keep][d][C], may be NULL (draws discarded) */
     uint64_t* n_accept;       /* out [C], may be NULL */
-    double*   step_size;      /* nuts out [C]: adapted step size per chain, may be NULL */
-    uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain, may be NULL */
+    double*   step_size;      /* nuts out [C]: adapted step size per chain (in: see draw0), may be NULL; other samplers leave it unchanged */
+    uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain (0 for mala / rwmh), may be NULL */
     uint32_t* nuts_depth;     /* nuts out [n_burnin+n_keep][C]: tree depth reached per draw, may be NULL */
     uint64_t  draw0;          /* index of this call's first draw in every chain's random stream: 0 for a fresh run; the
                                * n_burnin+n_keep of the call(s) before to CONTINUE them from their final theta -- the
                                * concatenation is then bit-identical to one long run (checkpoint / resume, chunked output).
-                               * nuts: a continuation must start after the adaptation window (draw0 >= n_adapt_draws) and
-                               * takes the adapted step sizes back in through step_size. */
+                               * nuts: a continuation must start strictly after the adaptation window (draw0 > n_adapt_draws:
+                               * draw n_adapt_draws itself still uses the last dual-averaging step, not epsilon_bar) and takes
+                               * the adapted step sizes back in through step_size; n_adapt_draws must be the same in every
+                               * call of one run, and a run whose first call is shorter than its adaptation window cannot
+                               * be continued (the dual-averaging state is not exported). */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);
 const char* mi_mcmc_last_error(void);
 int         mi_mcmc_version(void);
 int         mi_mcmc_device_count(void);
+
+/* Kernel workspaces are cached per (device, stream) and reused by later calls on that stream (NUTS at BASELINE configs[3]
+ * holds 4 GiB).  This frees the cache of the CURRENT device for `stream` (all_streams != 0: for every stream, e.g. before
+ * destroying streams); it synchronises first.  bytes_freed may be NULL.  Safe to call concurrently with runs. */
+int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed);
 
 /* Blocking calls. `stream` is a hipStream_t (NULL = default stream); with mem == MI_MEM_DEVICE the
  * kernels are enqueued on it and the call returns after enqueueing (asynchronous), so inputs can be

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmi_mcmc.so")
 MI_OK, MI_ERR_BAD_ARG, MI_ERR_HIP, MI_ERR_UNSUPPORTED, MI_ERR_OOM, MI_ERR_NO_DEVICE = range(6)
 TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET_NORMAL_MODEL = 1, 2, 3, 4, 5
 MEM_HOST, MEM_DEVICE = 0, 1
+KERNEL_AUTO, KERNEL_ELEMENTWISE_1LANE, KERNEL_ELEMENTWISE_4LANE, KERNEL_NUTS_LOCKSTEP = 0, 1, 2, 3   # mi_kernel_hint
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)
@@ -27,7 +28,7 @@ _u64p = C.POINTER(C.c_uint64)
 class mi_target(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("d", C.c_uint64),
                 ("prec", C.c_void_p), ("X", C.c_void_p), ("y", C.c_void_p),
-                ("n_rows", C.c_uint64), ("mem", C.c_int32), ("reserved", C.c_int32)]
+                ("n_rows", C.c_uint64), ("mem", C.c_int32), ("kernel_hint", C.c_int32)]
 
 
 class mi_settings(C.Structure):
@@ -57,7 +58,7 @@ class MiMcmcError(RuntimeError):
 _lib = None
 
 EXPORTS = [
-    "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count",
+    "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
@@ -108,10 +109,10 @@ def default_settings(**kw):
     return s
 
 
-def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST):
+def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST, kernel_hint=KERNEL_AUTO):
     t = mi_target()
     t.struct_size = C.sizeof(mi_target)
-    t.kind, t.d, t.mem = kind, int(d), mem
+    t.kind, t.d, t.mem, t.kernel_hint = kind, int(d), mem, int(kernel_hint)
     keep = []
     if mem == MEM_HOST:
         prec = None if prec is None else np.ascontiguousarray(prec, dtype=np.float64)
@@ -139,13 +140,21 @@ _RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_n
         "rmhmc": "mi_mcmc_rmhmc_run"}
 
 
+def release_workspace(stream=None, all_streams=True):
+    """mi_mcmc_release_workspace: free the cached kernel workspaces of the current device; returns the bytes freed."""
+    n = C.c_uint64(0)
+    _check(lib().mi_mcmc_release_workspace(C.c_void_p(stream or 0), C.c_int(1 if all_streams else 0), C.byref(n)))
+    return int(n.value)
+
+
 def run(algo, target, settings, chains, stream=None):
     """Raw call: mi_mcmc_<algo>_run(target, settings, chains, stream)."""
     fn = getattr(lib(), _RUN[algo])
     _check(fn(C.byref(target), C.byref(settings), C.byref(chains), C.c_void_p(stream or 0)))
 
 
-def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0, step_size_in=None):
+def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0, step_size_in=None,
+           kernel_hint=KERNEL_AUTO):
     """Host-buffer convenience: init is [C, d] (row per chain, like C calls of mcmc::<algo> with
     initial_vals = init[c]).  Returns draws [n_keep, d, C] and a dict of per-chain outputs."""
     init = np.ascontiguousarray(init, dtype=np.float64)
@@ -158,10 +167,40 @@ def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want
     eps = np.zeros(n_chains) if step_size_in is None else np.array(step_size_in, dtype=np.float64, copy=True)
     n_tot = int(settings.n_burnin_draws) + n_keep
     depth = np.zeros((n_tot, n_chains), dtype=np.uint32) if algo == "nuts" else None
-    t = make_target(kind, d, prec=prec, X=X, y=y)
+    t = make_target(kind, d, prec=prec, X=X, y=y, kernel_hint=kernel_hint)
     c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept,
                     step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0)
     run(algo, t, settings, c)
+    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth)
+
+
+def sample_device(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0,
+                  step_size_in=None, kernel_hint=KERNEL_AUTO, device=None, stream=None):
+    """Device-resident form of sample(): chain state, draws and counters are torch tensors in HBM on `device` (default:
+    the current CUDA device) and stay there -- what mcmc_amd.dist all-gathers over RCCL without a host round trip.
+    init: [C, d] numpy array or torch tensor.  Returns (draws [n_keep, d, C] or None, dict of per-chain tensors)."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        init_t = torch.as_tensor(init, dtype=torch.float64).to(dev)
+        n_chains, d = init_t.shape
+        theta = init_t.t().contiguous()                                    # [d][C]; a copy (the run overwrites it)
+        if theta.data_ptr() == init_t.data_ptr():
+            theta = theta.clone()
+        n_keep = int(settings.n_keep_draws)
+        n_tot = int(settings.n_burnin_draws) + n_keep
+        draws = torch.empty((n_keep, d, n_chains), dtype=torch.float64, device=dev) if want_draws else None
+        n_accept = torch.zeros(n_chains, dtype=torch.int64, device=dev)
+        n_leap = torch.zeros(n_chains, dtype=torch.int64, device=dev)
+        eps = (torch.zeros(n_chains, dtype=torch.float64, device=dev) if step_size_in is None
+               else torch.as_tensor(step_size_in, dtype=torch.float64).to(dev).clone())
+        depth = torch.zeros((n_tot, n_chains), dtype=torch.int32, device=dev) if algo == "nuts" else None
+        to_dev = lambda a: None if a is None else torch.as_tensor(a, dtype=torch.float64).to(dev).contiguous()
+        t = make_target(kind, d, prec=to_dev(prec), X=to_dev(X), y=to_dev(y), mem=MEM_DEVICE, kernel_hint=kernel_hint)
+        c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept, step_size=eps,
+                        n_leapfrogs=n_leap, nuts_depth=depth, mem=MEM_DEVICE, draw0=draw0)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        run(algo, t, settings, c, stream=st)
     return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth)
 
 

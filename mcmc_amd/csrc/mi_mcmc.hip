@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,26 +61,64 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-// Per-(device, stream) grow-only workspace.  Kernels of one stream are ordered, so the same buffer can
-// serve consecutive calls; it is reallocated (after a stream sync) only when a call needs more.
-// (hipMallocAsync / hipFreeAsync pool memory was observed to hand the pack -> sample kernel pair of the
-// logistic path buffers whose first blocks read back as zeros; a plain cached hipMalloc does not.)
-struct WsEntry { void* p = nullptr; size_t cap = 0; };
+// Per-(device, stream) workspace cache.  Kernels of one stream are ordered, so one buffer serves consecutive calls; it is
+// reallocated (after a stream sync) only when a call needs more, and released by mi_mcmc_release_workspace().  A call holds
+// the entry's mutex from ws_get() until its kernels are enqueued (WsLease), so a second host thread on the same stream can
+// neither free nor regrow the buffer between "pointer handed out" and "kernel enqueued"; after that the stream orders them.
+// (hipMallocAsync / hipFreeAsync pool memory was observed to hand the pack -> sample kernel pair of the logistic path
+// buffers whose first blocks read back as zeros; a plain cached hipMalloc does not.)
+struct WsEntry { void* p = nullptr; size_t cap = 0; std::mutex mu; };
 std::mutex g_ws_mu;
-std::map<std::pair<int, hipStream_t>, WsEntry> g_ws;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<WsEntry>> g_ws;
 
-int ws_get(hipStream_t st, size_t bytes, void** out)
+struct WsLease {
+    std::unique_lock<std::mutex> lk;
+    void* p = nullptr;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+int ws_get(hipStream_t st, size_t bytes, WsLease& lease)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_ws_mu);
-    WsEntry& w = g_ws[std::make_pair(dev, st)];
-    if (w.cap < bytes) {
-        if (w.p) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(w.p)); w.p = nullptr; w.cap = 0; }
-        HIP_TRY(hipMalloc(&w.p, bytes));
-        w.cap = bytes;
+    WsEntry* w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        std::unique_ptr<WsEntry>& slot = g_ws[std::make_pair(dev, st)];
+        if (!slot) slot.reset(new WsEntry);
+        w = slot.get();
     }
-    *out = w.p;
+    lease.lk = std::unique_lock<std::mutex>(w->mu);
+    if (w->cap < bytes) {
+        if (w->p) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(w->p)); w->p = nullptr; w->cap = 0; }
+        HIP_TRY(hipMalloc(&w->p, bytes));
+        w->cap = bytes;
+    }
+    lease.p = w->p;
+    return MI_OK;
+}
+
+// frees the cached workspace of (current device, st); all_streams: every entry of the current device
+int ws_release(hipStream_t st, bool all_streams, uint64_t* freed)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::vector<WsEntry*> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        for (auto& kv : g_ws)
+            if (kv.first.first == dev && (all_streams || kv.first.second == st)) victims.push_back(kv.second.get());
+    }
+    uint64_t total = 0;
+    for (WsEntry* w : victims) {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (!w->p) continue;
+        HIP_TRY(all_streams ? hipDeviceSynchronize() : hipStreamSynchronize(st));
+        HIP_TRY(hipFree(w->p));
+        total += w->cap;
+        w->p = nullptr; w->cap = 0;
+    }
+    if (freed) *freed = total;
     return MI_OK;
 }
 
@@ -147,9 +186,14 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
     if (c->n_accept) { HIP_TRY(sc.n_accept.alloc(C * sizeof(uint64_t))); sc.dev.n_accept = sc.n_accept.as<uint64_t>(); }
     if (c->step_size) {
         HIP_TRY(sc.step.alloc(C * sizeof(double))); sc.dev.step_size = sc.step.as<double>();
-        if (c->draw0 > 0) HIP_TRY(hipMemcpyAsync(sc.step.p, c->step_size, C * sizeof(double), hipMemcpyHostToDevice, st));   // nuts continuation
+        // in: the adapted step sizes of a nuts continuation; out: written by nuts only -- every other sampler hands the
+        // caller's values back unchanged (never uninitialised device memory)
+        HIP_TRY(hipMemcpyAsync(sc.step.p, c->step_size, C * sizeof(double), hipMemcpyHostToDevice, st));
     }
-    if (c->n_leapfrogs) { HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>(); }
+    if (c->n_leapfrogs) {
+        HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>();
+        HIP_TRY(hipMemsetAsync(sc.n_leap.p, 0, C * sizeof(uint64_t), st));    // samplers without leapfrog steps (mala, rwmh) report 0
+    }
     if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
     sc.dev.mem = MI_MEM_DEVICE;
     return MI_OK;
@@ -169,13 +213,29 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     return MI_OK;
 }
 
+// n_leapfrogs for the samplers whose kernels do not count leapfrog steps themselves (mala / rwmh: 0; hmc on the logistic
+// target: n_total * n_leap_steps), so that the caller's array is defined after every call, host or device memory
+__global__ void fill_u64_kernel(uint64_t* out, uint64_t n, uint64_t v)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+int fill_n_leap(uint64_t* dev_ptr, uint64_t n, uint64_t v, hipStream_t st)
+{
+    if (!dev_ptr) return MI_OK;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dev_ptr, n, v);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // LDS-staged logistic kernels (logistic_lds.hip): workspace from the per-stream cache, launch in their own translation unit
 int launch_logit(int algo, const mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
 {
-    void* base = nullptr;
-    int rcw = ws_get(st, mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), &base);
+    WsLease base;
+    int rcw = ws_get(st, mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), base);
     if (rcw) return rcw;
-    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base, st);
+    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st);
     if (e != 0) return fail(MI_ERR_HIP, "logistic kernel launch: %s", hipGetErrorString((hipError_t)e));
     return MI_OK;
 }
@@ -324,6 +384,9 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.draw0 = (uint32_t)chains->draw0;
     rc = launch_logit(algo, q, X_dev, y_dev, st);
     if (rc) return rc;
+    rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
+                     algo == mi::LOGIT_HMC ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
+    if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
     if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -431,6 +494,11 @@ int mi_mcmc_device_count(void)
     return n;
 }
 
+int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed)
+{
+    return ws_release(static_cast<hipStream_t>(stream), all_streams != 0, bytes_freed);
+}
+
 int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
     int rc = check_common(target, settings, chains);
@@ -468,7 +536,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (bounded && d > 128 && !diag_precond_elementwise) return fail(MI_ERR_UNSUPPORTED, "hmc: vals_bound with d > 128 is not implemented");
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     const bool separable = target->kind != MI_TARGET_GAUSS_DENSE;
-    const bool force_diag = !bounded && getenv("MI_HMC_FORCE_DIAG") != nullptr;   // tests: same bits from both kernels
+    // kernel_hint (mi_mcmc.h): an explicit request for the elementwise kernels where the MFMA kernel would be picked; every
+    // kernel produces the same bits, so the hint changes speed only
+    const bool force_diag = !bounded && (target->kernel_hint == MI_KERNEL_ELEMENTWISE_1LANE || target->kernel_hint == MI_KERNEL_ELEMENTWISE_4LANE);
     if (d > 128 && !separable)
         return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
     if (separable && (d > 128 || force_diag)) {
@@ -495,12 +565,13 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
         q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
         q.draw0 = (uint32_t)chains->draw0;
-        void* scratch = nullptr;
-        rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), &scratch);
+        WsLease scratch;
+        rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), scratch);
         if (rc) return rc;
-        q.scratch = static_cast<double*>(scratch);
-        int diag_lanes = mi::hmc_diag_pick_lanes(q.C);          // lanes per chain (hmc_diag.hpp); MI_HMC_DIAG_LANES=1|4 forces one (tests)
-        if (const char* e = getenv("MI_HMC_DIAG_LANES")) diag_lanes = (atoi(e) == 4) ? 4 : 1;
+        q.scratch = scratch.as<double>();
+        int diag_lanes = mi::hmc_diag_pick_lanes(q.C);          // lanes per chain (hmc_diag.hpp)
+        if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_1LANE) diag_lanes = 1;
+        if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_4LANE) diag_lanes = 4;
         DevBuf ms_d, mi_d;
         if (diag_precond_elementwise) {
             HIP_TRY(ms_d.alloc(d * 8)); HIP_TRY(mi_d.alloc(d * 8));
@@ -536,11 +607,11 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
-    void* wsave = nullptr;
+    WsLease wsave;
     const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, 3 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), &wsave);
+    rc = ws_get(st, 3 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), wsave);
     if (rc) return rc;
-    prm.wsave = static_cast<double*>(wsave);
+    prm.wsave = wsave.as<double>();
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -551,8 +622,10 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     prm.eps = settings->step_size;
     prm.draw0 = (uint32_t)chains->draw0;
     prm.stagger = 40;
+#ifdef MI_PROFILING     // A/B library only (make prof): the shipped library reads no environment variable
     if (const char* e = getenv("MI_HMC_STAGGER")) prm.stagger = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_HMC_ABLATE")) prm.ablate = (uint32_t)atoi(e);
+#endif
 
     const int nt = (int)((d + 15) / 16);
     DevBuf bt_dev, lb_dev, ub_dev;
@@ -646,6 +719,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.draw0 = (uint32_t)chains->draw0;
         rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st);
         if (rc) return rc;
+        rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
+        if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
         if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -723,6 +798,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     else rc = launched("mala", mi::launch_mala_gauss(prm, nt, 0, st));
     if (rc) return rc;
+    rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
+    if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
@@ -787,6 +864,8 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     else rc = launched("rwmh", mi::launch_rwmh_gauss(prm, nt, false, false, st));
     if (rc) return rc;
+    rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
+    if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
@@ -823,18 +902,21 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.C = chains->n_chains;
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;
-    void* ws = nullptr;
+    WsLease ws;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), &ws);
+    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
-    prm.ws = static_cast<double*>(ws);
+    prm.ws = ws.as<double>();
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
+    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP;      // the first-generation kernel, same bits
+#ifdef MI_PROFILING
     DevBuf prof_buf;
     if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(16 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 128)); prm.prof = prof_buf.as<unsigned long long>(); }
+#endif
     prm.seed = settings->rng_seed_value;
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
     prm.n_keep = (uint32_t)settings->n_keep_draws;
@@ -845,7 +927,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         if (chains->draw0 <= settings->n_adapt_draws)
             return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
         if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
-        if (getenv("MI_NUTS_LOCKSTEP")) return fail(MI_ERR_UNSUPPORTED, "nuts: the lock-step kernel does not continue runs");
+        if (lockstep) return fail(MI_ERR_UNSUPPORTED, "nuts: the lock-step kernel does not continue runs");
         prm.n_adapt = 0;
     }
     prm.max_depth = (uint32_t)settings->max_tree_depth;
@@ -858,7 +940,9 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
     uint32_t nuts_batch = 8;                 // momentum-refresh batch of the asynchronous kernel
+#ifdef MI_PROFILING
     if (const char* e = getenv("MI_NUTS_BATCH")) nuts_batch = (uint32_t)atoi(e);
+#endif
     rc = general_tables("nuts", settings, d, gt, true);
     if (rc) return rc;
     if (gt.active && gt.dense) {
@@ -876,11 +960,12 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, false, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, getenv("MI_NUTS_LOCKSTEP") != nullptr, nuts_batch, st));
+    else rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
+#ifdef MI_PROFILING
     if (prm.prof) {
         unsigned long long h[12];
         HIP_TRY(hipDeviceSynchronize());
@@ -891,6 +976,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         for (int k = 0; k < 8; ++k) fprintf(stderr, "[nuts prof] %-20s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
         fprintf(stderr, "[nuts prof] ticks %llu, active chain-ticks %llu (%.2f of 16 per tick), refresh phases %llu, fin blocks %llu\n", h[8], h[9], (double)h[9] / (h[8] ? h[8] : 1), h[10], h[11]);
     }
+#endif
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }

@@ -83,6 +83,18 @@ void orc_gemv(const double* A, const double* x, size_t d, double* y)
     }
 }
 
+/* the same mat-vec from the transposed matrix, in axpy form: per output row the identical k-ascending fma chain, but the
+ * inner loop runs over rows and vectorises (Mode B of the CPU baseline; At[k*d + i] = A[i*d + k]) */
+static void orc_gemv_t(const double* At, const double* x, size_t d, double* y)
+{
+    for (size_t i = 0; i < d; ++i) y[i] = 0.0;
+    for (size_t k = 0; k < d; ++k) {
+        const double xk = x[k];
+        const double* a = At + k * d;
+        for (size_t i = 0; i < d; ++i) y[i] = fma(a[i], xk, y[i]);
+    }
+}
+
 static void orc_matmul(const double* A, const double* B, size_t d, double* C)
 {
     for (size_t i = 0; i < d; ++i)
@@ -323,7 +335,7 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
     }
     case ORC_TARGET_GAUSS_DENSE: {
         double* w = (double*)malloc(d * sizeof(double));
-        orc_gemv(t->prec, th, d, w);
+        if (t->prec_t) orc_gemv_t(t->prec_t, th, d, w); else orc_gemv(t->prec, th, d, w);
         if (grad_out) for (size_t i = 0; i < d; ++i) grad_out[i] = -w[i];
         const double r = -0.5 * orc_dot_b(th, w, d, W, nblk, bs);
         free(w);
@@ -545,10 +557,76 @@ static void epilogue_inv_transform(orc_ctx* c, double* draws_out, size_t n_keep)
 
 /* ------------------------------------------------------------------ HMC */
 
+
+/* Mode B of the CPU baseline (orc_settings.work_mode = 1): hmc_impl with the work a tuned CPU
+ * implementation would do -- same arithmetic on the same values in the same order, so the draws are the bits of orc_hmc
+ * (asserted by tests/test_oracle_samplers.py).  Unbounded runs. */
+static int orc_hmc_mode_b(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+                          const orc_settings* s, double* draws_out, orc_stats* st)
+{
+    const size_t n_burnin = s->n_burnin_draws, n_keep = s->n_keep_draws, n_total = n_burnin + n_keep;
+    const double eps = s->step_size;
+    const size_t L = s->n_leap_steps;
+    const int W = s->reduce_width > 0 ? s->reduce_width : 1;
+    const int identity = (s->precond_mat == NULL);
+    double *Minv = NULL, *Lc = NULL;
+    if (!identity) {
+        Minv = dvec(d * d); Lc = dvec(d * d);
+        orc_inv(s->precond_mat, d, Minv);
+        orc_chol_lower(s->precond_mat, d, Lc);
+    }
+    double* buf = dvec(7 * d);
+    double *prev_draw = buf, *new_draw = buf + d, *mntm = buf + 2 * d, *z = buf + 3 * d, *mp = buf + 4 * d,
+           *g_prev = buf + 5 * d, *g = buf + 6 * d;
+    memcpy(prev_draw, initial_vals, d * sizeof(double));
+    double prev_U = -kernel(prev_draw, g_prev, data);       /* value and gradient at the current state, kept until it changes */
+    size_t n_accept = 0;
+    uint64_t n_leap = 0;
+    for (size_t draw_ind = 0; draw_ind < n_total; ++draw_ind) {
+        orc_rng_normal_vec(s->rng_seed_value, s->chain_id, (uint32_t)draw_ind, ORC_STREAM_NORMAL, d, z);
+        if (identity) memcpy(mntm, z, d * sizeof(double)); else orc_gemv(Lc, z, d, mntm);
+        const double* pm = mntm;
+        if (!identity) { orc_gemv(Minv, mntm, d, mp); pm = mp; }
+        const double prev_K = orc_dot_b(mntm, pm, d, W, s->reduce_blocks, s->reduce_block_size) / 2.0;
+        memcpy(new_draw, prev_draw, d * sizeof(double));
+        memcpy(g, g_prev, d * sizeof(double));
+        double val = -prev_U;
+        for (size_t k = 0; k < L; ++k) {
+            for (size_t i = 0; i < d; ++i) mntm[i] = mntm[i] + (eps * g[i]) / 2.0;
+            if (!identity) orc_gemv(Minv, mntm, d, mp);
+            for (size_t i = 0; i < d; ++i) new_draw[i] = new_draw[i] + eps * pm[i];
+            val = kernel(new_draw, g, data);
+            for (size_t i = 0; i < d; ++i) mntm[i] = mntm[i] + (eps * g[i]) / 2.0;
+            n_leap++;
+        }
+        double prop_U = -val;
+        if (!isfinite(prop_U)) prop_U = INFINITY;
+        if (!identity) orc_gemv(Minv, mntm, d, mp);
+        const double prop_K = orc_dot_b(mntm, pm, d, W, s->reduce_blocks, s->reduce_block_size) / 2.0;
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;
+        const double u = orc_rng_uniform(s->rng_seed_value, s->chain_id, (uint32_t)draw_ind, 0);
+        int acc = 0;
+        if (u < orc_exp(comp_val)) {
+            memcpy(prev_draw, new_draw, d * sizeof(double));
+            memcpy(g_prev, g, d * sizeof(double));
+            prev_U = prop_U;
+            acc = 1;
+            if (draw_ind >= n_burnin) n_accept++;
+        }
+        if (draw_ind >= n_burnin) store_row(draws_out, draw_ind - n_burnin, d, prev_draw);
+        if (st && st->accept_trace) st->accept_trace[draw_ind] = (uint8_t)acc;
+    }
+    if (st) { st->n_accept_draws = n_accept; st->n_leapfrogs = n_leap; st->final_step_size = eps; }
+    free(buf); free(Minv); free(Lc);
+    return 0;
+}
+
 /* ref: src/hmc.cpp:30-227 */
 int orc_hmc(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
             const orc_settings* s, double* draws_out, orc_stats* st)
 {
+    if (s->work_mode == 1 && !s->vals_bound) return orc_hmc_mode_b(initial_vals, d, kernel, data, s, draws_out, st);
     orc_ctx c;
     ctx_init(&c, d, kernel, data, s, 1);
     const size_t n_burnin = s->n_burnin_draws, n_keep = s->n_keep_draws, n_total = n_burnin + n_keep;
@@ -1248,6 +1326,11 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
 {
     const size_t d = tgt->d, n_keep = s->n_keep_draws;
     int rc = 0;
+    double* prec_t = NULL;          /* Mode B: transposed precision, shared by all chains (read-only) */
+    if (s->work_mode == 1 && tgt->kind == ORC_TARGET_GAUSS_DENSE && tgt->prec && !tgt->prec_t) {
+        prec_t = (double*)malloc(d * d * sizeof(double));
+        for (size_t i = 0; i < d; ++i) for (size_t k = 0; k < d; ++k) prec_t[k * d + i] = tgt->prec[i * d + k];
+    }
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -1256,6 +1339,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
     #pragma omp parallel for schedule(dynamic) num_threads(n_threads)
     for (long long ci = 0; ci < (long long)n_chains; ++ci) {
         orc_target t = *tgt;            /* private call counters */
+        if (prec_t) t.prec_t = prec_t;
         orc_settings sc = *s;
         sc.chain_id = chain0 + (uint64_t)ci;
         orc_stats st; memset(&st, 0, sizeof(st));
@@ -1276,6 +1360,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
         if (eps_out) eps_out[ci] = st.final_step_size;
         free(local);
     }
+    free(prec_t);
     return rc;
 }
 

@@ -62,6 +62,9 @@ typedef struct orc_target {
                                     sub-chains of reduce_block_size/eta_chains dims, summed left to right (<=1: one chain) */
     uint64_t      n_grad_calls;  /* instrumentation */
     uint64_t      n_value_calls;
+    const double* prec_t;        /* Mode B only (see orc_settings.work_mode): DENSE: the TRANSPOSE of prec, row-major; when set the
+                                    mat-vec runs in axpy form (y_i = fma(prec_t[k][i], x_k, y_i), k ascending): per row the same
+                                    sequential fma chain as orc_gemv, hence the same bits, but SIMD across rows */
 } orc_target;
 
 double orc_target_kernel(const double* vals, double* grad_out, void* data);
@@ -100,6 +103,14 @@ typedef struct orc_settings {
     int      hoist_factorizations;/* mala: 0 = factorise eps^2 M inside every dmvnorm call as the
                                      reference does (mala.ipp:63-64); 1 = once (same bits) */
     uint64_t chain_id;            /* Philox counter word: global chain index */
+    int      work_mode;           /* CPU-baseline work profile, hmc only; the draws are the same bits:
+                                     0 = Mode A "reference-faithful": two gradient callbacks per leapfrog step plus one
+                                         value callback per draw (ref: src/hmc.cpp:167,175,178), dense M^-1 / chol(M)
+                                         mat-vecs even for the identity (:57-59,158-160,171,184), buffers allocated per call;
+                                     1 = Mode B "optimised CPU": the gradient at the end of a leapfrog step is reused as the
+                                         start of the next, the value of the last gradient call is the draw's value call,
+                                         no mat-vec with an identity precond_mat, no allocation inside the draw loop;
+                                         unbounded runs only (a bounded run falls back to Mode A) */
 } orc_settings;
 
 typedef struct orc_stats {

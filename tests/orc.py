@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("ORC_LIB", os.path.join(ROOT, "oracle", "liboracle.so"))    # bench.py's timing build: liboracle_fast.so
 
 TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_LOGISTIC, TARGET_NORMAL_MODEL = 1, 2, 3, 4, 5
 ALGO_HMC, ALGO_MALA, ALGO_NUTS, ALGO_RWMH, ALGO_RMHMC = 0, 1, 2, 3, 4   # rwmh: step = par_scale, precond = cov_mat
@@ -17,7 +17,7 @@ class Target(C.Structure):
     _fields_ = [("kind", C.c_int), ("d", C.c_size_t), ("prec", _dp), ("X", _dp), ("y", _dp),
                 ("n_rows", C.c_size_t), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
                 ("reduce_block_size", C.c_size_t), ("eta_chains", C.c_int),
-                ("n_grad_calls", C.c_uint64), ("n_value_calls", C.c_uint64)]
+                ("n_grad_calls", C.c_uint64), ("n_value_calls", C.c_uint64), ("prec_t", _dp)]
 
 
 class Settings(C.Structure):
@@ -29,7 +29,7 @@ class Settings(C.Structure):
                 ("max_tree_depth", C.c_size_t), ("gamma_val", C.c_double), ("t0_val", C.c_double),
                 ("kappa_val", C.c_double), ("n_fp_steps", C.c_size_t), ("reduce_width", C.c_int), ("reduce_blocks", C.c_int),
                 ("reduce_block_size", C.c_size_t),
-                ("hoist_factorizations", C.c_int), ("chain_id", C.c_uint64)]
+                ("hoist_factorizations", C.c_int), ("chain_id", C.c_uint64), ("work_mode", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -69,7 +69,7 @@ class TargetSpec:
         self.kind, self.d, self.W = kind, int(d), W
         self.prec, self.X, self.y = _f64(prec), _f64(X), _f64(y)
         n_rows = self.X.shape[0] if self.X is not None else (self.y.shape[0] if self.y is not None else 0)
-        self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y), n_rows, W, blocks, block_size, eta_chains, 0, 0)
+        self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y), n_rows, W, blocks, block_size, eta_chains, 0, 0, None)
 
     def kernel(self, theta, want_grad=True):
         theta = _f64(theta)
@@ -80,11 +80,11 @@ class TargetSpec:
 
 def make_settings(seed=1, n_burnin=0, n_keep=10, n_leap=1, step=1.0, precond=None, n_adapt=1000,
                   delta=0.55, max_depth=10, gamma=0.05, t0=10.0, kappa=0.75, W=4, hoist=1, chain_id=0,
-                  lower=None, upper=None, blocks=0, block_size=0, n_fp=5):
+                  lower=None, upper=None, blocks=0, block_size=0, n_fp=5, work_mode=0):
     keep = dict(precond=_f64(precond), lower=_f64(lower), upper=_f64(upper))
     s = Settings(seed, 0 if lower is None else 1, _p(keep["lower"]), _p(keep["upper"]),
                  n_burnin, n_keep, n_leap, step, _p(keep["precond"]), n_adapt, delta, max_depth,
-                 gamma, t0, kappa, n_fp, W, blocks, block_size, hoist, chain_id)
+                 gamma, t0, kappa, n_fp, W, blocks, block_size, hoist, chain_id, work_mode)
     s._keep = keep
     return s
 

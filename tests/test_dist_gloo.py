@@ -29,8 +29,13 @@ def runner(algo, kind, init, settings, chain0=0, **kw):
 st = orc.make_settings(seed=11, n_burnin=3, n_keep=5, n_leap=4, step=0.1, W=4)
 init_fn = lambda chain0, c: synth.initial_states(c, d, seed=3, chain0=chain0)
 draws, nacc = mdist.run_sharded("hmc", None, init_fn, C_total, st, runner=runner)
+# more ranks than chains: rank 1's shard is empty, it must still join the collectives (and get the full result)
+draws1, nacc1 = mdist.run_sharded("hmc", None, init_fn, 1, st, runner=runner)
+assert draws1.shape == (5, d, 1) and nacc1.shape == (1,)
 if dist.get_rank() == 0:
-    np.savez(sys.argv[2], draws=draws, nacc=nacc)
+    np.savez(sys.argv[2], draws=draws, nacc=nacc, draws1=draws1, nacc1=nacc1)
+if dist.get_rank() == 1:
+    np.savez(sys.argv[2] + ".rank1.npz", draws1=draws1)
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -75,3 +80,6 @@ def test_two_rank_gloo_collation_equals_single_process(tmp_path):
     assert got["draws"].shape == (5, d, C)
     assert np.array_equal(got["draws"], want)
     assert np.array_equal(got["nacc"], info["n_accept"].astype(np.int64))
+    # world_size > n_chains: the one chain, identical on the rank that ran it and on the rank with the empty shard
+    assert np.array_equal(got["draws1"], want[:, :, :1]) and got["nacc1"][0] == info["n_accept"][0]
+    assert np.array_equal(np.load(str(out) + ".rank1.npz")["draws1"], want[:, :, :1])

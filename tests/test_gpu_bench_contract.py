@@ -28,10 +28,22 @@ def test_single_gpu_line():
 def test_two_rank_code_path():
     env = dict(os.environ, BENCH_TEST_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "8192",
-           "--no-cpu-baseline", "--collate"]
+           "--master-port", "29531", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "8193",
+           "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
-    assert j["n_gpus"] == 2 and j["config"]["chains_total"] == 2 * 8192 and j["scaling"] == "weak"
-    assert "collate_last_draw_allgather_ms" in j
+    # north_star: strong scaling -- with WORLD_SIZE > 1 the total chain count is fixed and sharded (8193: ragged, nothing dropped)
+    assert j["n_gpus"] == 2 and j["config"]["chains_total"] == 8193 and j["config"]["chains_per_gpu"] == 4097 and j["scaling"] == "strong"
+    assert j["value"] > 0
+
+
+@pytest.mark.parametrize("config,bound", [(3, "mfma"), (4, "mfma"), (5, "valu-fp64")])
+def test_other_baseline_configs_print_their_own_roofline(config, bound):
+    out = subprocess.run([sys.executable, "bench.py", "--config", str(config), "--steps", "1", "--warmup", "0", "--chains", "2048",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert KEYS <= set(j) and j["roofline"]["bound"] == bound and 0.0 < j["roofline"]["frac"] < 1.0
+    assert j["roofline"]["traffic"] is None          # not the profiled workload: no traffic figure is made up
+    assert j["config"]["chains_per_gpu"] == 2048

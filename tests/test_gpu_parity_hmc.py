@@ -168,36 +168,35 @@ DIAG_CASES = [
 
 @pytest.mark.parametrize("lanes", [1, 4])           # one lane per chain (many chains) / four lanes per chain (fewer chains)
 @pytest.mark.parametrize("kind,d,C,L,eps,burn,keep", DIAG_CASES)
-def test_hmc_elementwise_kernel_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep, lanes, monkeypatch):
-    monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
-    monkeypatch.setenv("MI_HMC_DIAG_LANES", str(lanes))
+def test_hmc_elementwise_kernel_bit_exact_vs_oracle(kind, d, C, L, eps, burn, keep, lanes):
+    hint = mcmc_amd.KERNEL_ELEMENTWISE_4LANE if lanes == 4 else mcmc_amd.KERNEL_ELEMENTWISE_1LANE
     init = synth.initial_states(C, d, seed=12)
     prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
     if kind == "diag":
         prec, k_gpu, k_orc = synth.ill_conditioned_diag(d, 1.0e4), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
     st = mcmc_amd.default_settings(rng_seed_value=55, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps)
-    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=9)
+    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=9, kernel_hint=hint)
     o_draws, o = _oracle_many(k_orc, d, init, st, prec=prec, chain0=9)
     assert np.array_equal(g["n_accept"], o["n_accept"])
     assert np.array_equal(g_draws, o_draws)
     assert np.array_equal(g["theta"], o_draws[-1])
     # draws discarded: same final state
-    t = mcmc_amd.make_target(k_gpu, d, prec=prec)
+    t = mcmc_amd.make_target(k_gpu, d, prec=prec, kernel_hint=hint)
     theta = np.ascontiguousarray(init.T)
     c = mcmc_amd.make_chains(theta, C, chain0=9)
     mcmc_amd.run("hmc", t, st, c)
     assert np.array_equal(theta, o_draws[-1])
 
 
-def test_both_hmc_kernels_agree_bitwise_on_a_diagonal_target(monkeypatch):
+def test_both_hmc_kernels_agree_bitwise_on_a_diagonal_target():
     d, C = 96, 80
     init = synth.initial_states(C, d, seed=12)
     prec = synth.ill_conditioned_diag(d, 100.0)
     st = mcmc_amd.default_settings(rng_seed_value=8, n_burnin_draws=3, n_keep_draws=6, n_leap_steps=7, step_size=0.05)
     a, ga = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec)          # MFMA kernel
-    monkeypatch.setenv("MI_HMC_FORCE_DIAG", "1")
-    b, gb = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec)          # elementwise kernel
-    assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
+    for hint in (mcmc_amd.KERNEL_ELEMENTWISE_1LANE, mcmc_amd.KERNEL_ELEMENTWISE_4LANE):
+        b, gb = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec, kernel_hint=hint)          # elementwise kernels
+        assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
 
 
 # ---------------------------------------------------------------- edge cases
@@ -345,14 +344,14 @@ def test_hmc_logistic_bit_exact_vs_oracle(d, N, C, eps, L, burn, keep):
 # ---------------------------------------------------------------- diagonal precond_mat on the elementwise kernel (any d)
 @pytest.mark.parametrize("lanes", [1, 4])
 @pytest.mark.parametrize("kind,d,C,L,eps", [("diag", 200, 70, 6, 0.2), ("iso", 1024, 33, 4, 0.08), ("diag", 129, 300, 3, 0.1)])
-def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps, lanes, monkeypatch):
-    monkeypatch.setenv("MI_HMC_DIAG_LANES", str(lanes))
+def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps, lanes):
+    hint = mcmc_amd.KERNEL_ELEMENTWISE_4LANE if lanes == 4 else mcmc_amd.KERNEL_ELEMENTWISE_1LANE
     prec = synth.ill_conditioned_diag(d, 50.0) if kind == "diag" else None
     M = np.diag((prec if prec is not None else np.ones(d)) * np.linspace(0.7, 1.4, d))   # mass matrix ~ the precision: every dimension at unit frequency
     init = synth.initial_states(C, d, seed=18) * 0.5
     st = mcmc_amd.default_settings(rng_seed_value=12, n_burnin_draws=2, n_keep_draws=6, n_leap_steps=L, step_size=eps, precond_mat=M)
     k_gpu, k_orc = (mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG) if kind == "diag" else (mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)
-    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=6)
+    g_draws, g = mcmc_amd.hmc(k_gpu, init, st, prec=prec, chain0=6, kernel_hint=hint)
     t = orc.TargetSpec(k_orc, d, prec=prec, W=4)
     s = orc.make_settings(seed=12, n_burnin=2, n_keep=6, n_leap=L, step=eps, W=4, precond=M)
     o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=6)

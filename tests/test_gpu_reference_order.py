@@ -1,0 +1,112 @@
+"""GPU: the engine against the oracle in its REFERENCE-SHAPED order, under BASELINE.json's stated tolerance.
+
+Everywhere else the oracle's reduction orders are set to the kernel's lane / wave layout (W = 4, dimension blocks, two
+eta sub-chains, hoisted factorisation) and the comparison is bit for bit.  Here the oracle runs the way the reference's
+scalar loops are written -- W = 1 (one sequential chain per dot product, ref: BMO_MATOPS_DOT_PROD as a plain
+accumulation), no dimension blocks, one eta chain, `dmvnorm` factorising eps^2 M inside every call (hoist = 0,
+ref: include/mcmc/mala.ipp:63-64), dense identity products -- for every BASELINE config at its dimension and settings.
+north_star tolerance: every kept draw within 1e-9 relative L2 of the reference, acceptance decisions identical for
+identical RNG streams.  A decision that flips (u within rounding distance of the acceptance probability) shows as an O(1)
+jump in a draw; flips are counted per chain and asserted rare, and the tolerance is asserted on every draw up to a
+chain's first flip.
+"""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1.0e-9          # BASELINE.json north_star: "draws within 1e-9 relative L2 of reference"
+N_CHAINS = 16
+
+
+def _compare(g_draws, o_draws, g_acc, o_acc, max_flipped_chains=1):
+    """g_draws, o_draws: [n_keep, d, C].  Returns (worst rel-L2 before any flip, flipped chains)."""
+    n_keep, d, C = o_draws.shape
+    num = np.sqrt(((g_draws - o_draws) ** 2).sum(axis=1))          # [n_keep, C]
+    den = np.sqrt((o_draws ** 2).sum(axis=1))
+    rel = num / np.where(den > 0, den, 1.0)
+    worst, flipped = 0.0, []
+    for c in range(C):
+        bad = np.nonzero(~(rel[:, c] <= TOL))[0]
+        upto = bad[0] if bad.size else n_keep
+        if bad.size:
+            flipped.append((c, int(bad[0]), float(rel[bad[0], c])))
+        if upto:
+            worst = max(worst, float(rel[:upto, c].max()))
+    print(f"reference-order parity: worst rel-L2 {worst:.3e} over {C} chains x {n_keep} kept draws; decision flips: {flipped}")
+    assert worst <= TOL
+    assert len(flipped) <= max_flipped_chains, flipped
+    ok = [c for c in range(C) if c not in {f[0] for f in flipped}]
+    assert np.array_equal(np.asarray(g_acc)[ok], np.asarray(o_acc)[ok])      # identical accept counts where nothing flipped
+    return worst, flipped
+
+
+def test_config2_hmc_d128_dense_gaussian_reference_order():
+    d, C = 128, N_CHAINS
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=3)
+    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=100, n_keep_draws=100, n_leap_steps=16, step_size=0.05)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=1)
+    s = orc.make_settings(seed=2024, n_burnin=100, n_keep=100, n_leap=16, step=0.05, W=1)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    _compare(g_draws, o_draws, g["n_accept"], o["n_accept"])
+    assert 0.5 < g["n_accept"].mean() / 100 <= 1.0
+
+
+def test_config3_mala_d512_logistic_reference_order():
+    d, N, C = 512, 1024, N_CHAINS
+    X, y = synth.logistic_problem(d, N)
+    init = np.zeros((C, d))
+    init[:, 0] = np.linspace(-0.5, 0.5, C)
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=100, n_keep_draws=100, step_size=0.02)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=1, blocks=0, block_size=0, eta_chains=1)
+    s = orc.make_settings(seed=6, n_burnin=100, n_keep=100, step=0.02, W=1, hoist=0)      # factorise inside every dmvnorm
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s)
+    _compare(g_draws, o_draws, g["n_accept"], o["n_accept"])
+
+
+def test_config4_nuts_d128_depth10_reference_order():
+    d, C = 128, N_CHAINS
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=3)
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=1)
+    s = orc.make_settings(seed=4, n_burnin=100, n_keep=100, n_adapt=100, step=1.0, W=1)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s)
+    # a NUTS draw makes dozens of threshold decisions (slice, U-turn signs, step-size search): allow two chains to flip
+    _, flipped = _compare(g_draws, o_draws, g["n_accept"], o["n_accept"], max_flipped_chains=2)
+    ok = [c for c in range(C) if c not in {f[0] for f in flipped}]
+    assert np.array_equal(g["n_leap"][ok], o["n_leap"][ok])                    # same trees: same leapfrog counts
+    assert np.allclose(g["eps"][ok], o["eps"][ok], rtol=1e-9, atol=0.0)       # same adapted step sizes
+
+
+def test_config5_hmc_d1024_ill_conditioned_diag_reference_order():
+    d, C = 1024, N_CHAINS
+    prec = synth.ill_conditioned_diag(d, 1.0e4)
+    chain0 = 3 * 131072                                          # as rank 3 of 8 would run its shard
+    init = synth.initial_states(C, d, seed=3, chain0=chain0) / np.sqrt(prec)[None, :]
+    st = mcmc_amd.default_settings(rng_seed_value=8, n_burnin_draws=20, n_keep_draws=20, n_leap_steps=32, step_size=0.005)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec, chain0=chain0)
+    t = orc.TargetSpec(orc.TARGET_DIAG, d, prec=prec, W=1)
+    s = orc.make_settings(seed=8, n_burnin=20, n_keep=20, n_leap=32, step=0.005, W=1)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=chain0)
+    _compare(g_draws, o_draws, g["n_accept"], o["n_accept"])
+
+
+def test_config1_plumbing_hmc_3d_isotropic_reference_order():
+    """configs[0]: mcmc::hmc on a 3-D isotropic Gaussian, one chain (the reference's examples/eigen plumbing case)."""
+    d = 3
+    init = np.array([[1.0, -0.5, 0.25]])
+    st = mcmc_amd.default_settings(rng_seed_value=1776, n_burnin_draws=50, n_keep_draws=200, n_leap_steps=5, step_size=0.3)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, init, st)
+    t = orc.TargetSpec(orc.TARGET_ISO, d, W=1)
+    s = orc.make_settings(seed=1776, n_burnin=50, n_keep=200, n_leap=5, step=0.3, W=1)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    _compare(g_draws, o_draws, g["n_accept"], o["n_accept"], max_flipped_chains=0)

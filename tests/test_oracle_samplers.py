@@ -349,3 +349,37 @@ def test_rmhmc_bounded_draws_stay_inside_the_box():
     s = orc.make_settings(seed=2, n_burnin=5, n_keep=60, n_leap=2, step=0.03, n_fp=3, W=1, lower=lb, upper=ub)
     draws, info = orc.run_chain(orc.ALGO_RMHMC, t, np.array([2.0, 2.0]), s)
     assert (draws > lb).all() and (draws < ub).all() and info["n_accept"] > 0
+
+
+# ---------------------------------------------------------------- CPU baseline Mode B
+@pytest.mark.parametrize("kind,d,precond", [("dense", 24, None), ("dense", 24, "diag"), ("dense", 9, "dense"), ("diag", 40, None),
+                                            ("iso", 5, None)])
+def test_hmc_mode_b_reproduces_mode_a_bit_for_bit(kind, d, precond):
+    """Mode B (gradient reuse, value of the last gradient call, no identity mat-vecs, axpy-form mat-vec from the transposed
+    precision, no allocation in the loop) is the same arithmetic as the reference-faithful Mode A: identical draws."""
+    rng = np.random.default_rng(5)
+    prec = {"dense": synth.dense_gaussian_precision(d, seed=7), "diag": synth.ill_conditioned_diag(d, 30.0), "iso": None}[kind]
+    k = {"dense": orc.TARGET_DENSE, "diag": orc.TARGET_DIAG, "iso": orc.TARGET_ISO}[kind]
+    M = None
+    if precond == "diag":
+        M = np.diag(np.linspace(0.5, 2.0, d))
+    elif precond == "dense":
+        A = rng.standard_normal((d, d)); M = A @ A.T / d + np.eye(d)
+    init = synth.initial_states(6, d, seed=2)
+    for W in (1, 4):
+        t = orc.TargetSpec(k, d, prec=prec, W=W)
+        out = []
+        for mode in (0, 1):
+            s = orc.make_settings(seed=31, n_burnin=4, n_keep=9, n_leap=5, step=0.11, W=W, precond=M, work_mode=mode)
+            out.append(orc.run_many(orc.ALGO_HMC, t, init, s, chain0=3, n_threads=2))
+        assert np.array_equal(out[0][0], out[1][0])
+        assert np.array_equal(out[0][1]["n_accept"], out[1][1]["n_accept"]) and np.array_equal(out[0][1]["n_leap"], out[1][1]["n_leap"])
+        assert 0 < out[0][1]["n_accept"].sum()
+
+
+def test_mode_b_makes_one_gradient_call_per_leapfrog_step():
+    d, L, n = 6, 4, 7
+    t = orc.TargetSpec(orc.TARGET_ISO, d, W=1)
+    s = orc.make_settings(seed=2, n_burnin=0, n_keep=n, n_leap=L, step=0.2, W=1, work_mode=1)
+    orc.run_chain(orc.ALGO_HMC, t, np.ones(d), s)
+    assert (t.c.n_grad_calls, t.c.n_value_calls) == (n * L + 1, 0)          # Mode A: 2 n L gradient + n + 1 value calls
