@@ -43,8 +43,13 @@ CASES = [
 ]
 
 
+# the asynchronous kernel is the default; its lock-step predecessor must give the same bits
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
+
+
+@pytest.mark.parametrize("hint", KERNELS)
 @pytest.mark.parametrize("kind,d,C,burn,keep,adapt,max_depth,eps0", CASES)
-def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0):
+def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0, hint):
     init = synth.initial_states(C, d, seed=21)
     prec, k_gpu, k_orc = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
     if kind == "dense":
@@ -53,7 +58,7 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
         prec, k_gpu, k_orc = synth.ill_conditioned_diag(d, 50.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
                                    n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
-    g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500)
+    g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
     assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs

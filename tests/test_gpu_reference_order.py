@@ -72,19 +72,36 @@ def test_config3_mala_d512_logistic_reference_order():
 
 
 def test_config4_nuts_d128_depth10_reference_order():
+    """NUTS feeds its dot products into DECISIONS only (slice, U-turn, accept) -- and, inside the adaptation window, into the
+    next step size (dual averaging, ref: src/nuts.cpp:294-302).  With the step size fixed (n_adapt_draws = 0) a different
+    summation order therefore changes a draw only through a flipped decision; with BASELINE's n_adapt_draws = 100 the
+    rounding of alpha / n_alpha re-enters the trajectory through epsilon and grows from draw to draw -- in ANY implementation,
+    the oracle against itself included (tests/test_oracle_samplers.py::test_nuts_adaptation_amplifies_...).  So: (a) fixed
+    step size, full length, tolerance on every draw; (b) BASELINE settings: identical tree decisions on every draw of every
+    chain, tolerance over the first ten draws, bounded drift afterwards."""
     d, C = 128, N_CHAINS
     prec = synth.dense_gaussian_precision(d)
     init = synth.initial_states(C, d, seed=3)
-    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10)
-    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
     t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=1)
-    s = orc.make_settings(seed=4, n_burnin=100, n_keep=100, n_adapt=100, step=1.0, W=1)
+    # (a) fixed step size
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=0, max_tree_depth=10, step_size=0.12)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    s = orc.make_settings(seed=4, n_burnin=100, n_keep=100, n_adapt=0, step=0.12, W=1)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s)
-    # a NUTS draw makes dozens of threshold decisions (slice, U-turn signs, step-size search): allow two chains to flip
-    _, flipped = _compare(g_draws, o_draws, g["n_accept"], o["n_accept"], max_flipped_chains=2)
+    _, flipped = _compare(g_draws, o_draws, g["n_accept"], o["n_accept"], max_flipped_chains=1)
     ok = [c for c in range(C) if c not in {f[0] for f in flipped}]
     assert np.array_equal(g["n_leap"][ok], o["n_leap"][ok])                    # same trees: same leapfrog counts
-    assert np.allclose(g["eps"][ok], o["eps"][ok], rtol=1e-9, atol=0.0)       # same adapted step sizes
+    # (b) BASELINE configs[3] settings, every draw kept
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=0, n_keep_draws=200, n_adapt_draws=100, max_tree_depth=10)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    s = orc.make_settings(seed=4, n_burnin=0, n_keep=200, n_adapt=100, step=1.0, W=1)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])     # no decision differs
+    rel = np.sqrt(((g_draws - o_draws) ** 2).sum(axis=1)) / np.sqrt((o_draws ** 2).sum(axis=1))
+    print(f"nuts, adapting: rel-L2 max over draws 0-9 {rel[:10].max():.2e}, 10-99 {rel[10:100].max():.2e}, 100-199 {rel[100:].max():.2e}; "
+          f"adapted step size rel diff max {np.abs(g['eps'] / o['eps'] - 1).max():.2e}")
+    assert rel[:10].max() <= TOL
+    assert rel.max() < 5e-2 and np.abs(g["eps"] / o["eps"] - 1).max() < 1e-3         # drift through epsilon, not divergence
 
 
 def test_config5_hmc_d1024_ill_conditioned_diag_reference_order():

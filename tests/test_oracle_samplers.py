@@ -383,3 +383,22 @@ def test_mode_b_makes_one_gradient_call_per_leapfrog_step():
     s = orc.make_settings(seed=2, n_burnin=0, n_keep=n, n_leap=L, step=0.2, W=1, work_mode=1)
     orc.run_chain(orc.ALGO_HMC, t, np.ones(d), s)
     assert (t.c.n_grad_calls, t.c.n_value_calls) == (n * L + 1, 0)          # Mode A: 2 n L gradient + n + 1 value calls
+
+
+def test_nuts_adaptation_amplifies_a_change_of_summation_order_but_a_fixed_step_size_does_not():
+    """CPU only, oracle against itself: with a fixed step size the dot-product order (W = 1 vs W = 4) reaches a NUTS draw only
+    through decisions -- none flips here, the draws are identical -- while inside the dual-averaging window the same change
+    re-enters through epsilon and grows (why tests/test_gpu_reference_order.py bounds, not pins, the adapting run)."""
+    d = 32
+    prec = synth.dense_gaussian_precision(d, seed=7)
+    init = synth.initial_states(4, d, seed=3)
+    out = {}
+    for adapt in (0, 60):
+        for W in (1, 4):
+            t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=W)
+            s = orc.make_settings(seed=4, n_burnin=0, n_keep=120, n_adapt=adapt, step=0.2 if adapt == 0 else 1.0, W=W)
+            out[adapt, W] = orc.run_many(orc.ALGO_NUTS, t, init, s, n_threads=2)
+    assert np.array_equal(out[0, 1][0], out[0, 4][0]) and np.array_equal(out[0, 1][1]["n_leap"], out[0, 4][1]["n_leap"])
+    a, b = out[60, 1][0], out[60, 4][0]
+    rel = np.sqrt(((a - b) ** 2).sum(axis=1)) / np.sqrt((a ** 2).sum(axis=1))
+    assert rel[:5].max() < 1e-11 and 1e-12 < rel.max() < 1e-1
