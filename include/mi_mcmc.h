@@ -68,7 +68,14 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_AUTO = 0,
     MI_KERNEL_ELEMENTWISE_1LANE = 1,  /* hmc, separable Gaussian targets: one lane per chain (default for d > 128, many chains) */
     MI_KERNEL_ELEMENTWISE_4LANE = 2,  /* hmc, separable Gaussian targets: four lanes per chain */
-    MI_KERNEL_NUTS_LOCKSTEP = 3       /* nuts, unbounded Gaussian targets: the lock-step predecessor of the asynchronous kernel */
+    MI_KERNEL_NUTS_LOCKSTEP = 3,      /* nuts, unbounded Gaussian targets: the lock-step predecessor of the asynchronous kernel */
+    /* hmc, dense-gradient Gaussian target, 64 < d <= 128, unbounded, identity precond_mat: the launch shape.  AUTO picks it from
+     * the number of chains and of compute units (the shapes below are what makes 65 536 chains strong-scale over 8 GPUs). */
+    MI_KERNEL_HMC_TWO_WAVES_PER_SIMD = 4,  /* 8 waves per workgroup, one 16-chain tile per wave: enough chains to fill the chip */
+    MI_KERNEL_HMC_ONE_WAVE_PER_SIMD = 5,   /* 4 waves per workgroup, one tile per wave */
+    MI_KERNEL_HMC_SPLIT2 = 6,              /* two waves share a tile (row halves of the mat-vec, theta exchanged through LDS) */
+    MI_KERNEL_HMC_SPLIT4 = 7,              /* four waves share a tile, one wave per SIMD (16 chains per workgroup) */
+    MI_KERNEL_HMC_SPLIT4_TWO_WAVES = 8     /* four waves share a tile, two waves per SIMD (32 chains per workgroup) */
 } mi_kernel_hint;
 
 typedef struct mi_target {

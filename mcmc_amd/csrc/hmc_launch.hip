@@ -1,5 +1,6 @@
 // hmc_launch.hip -- translation unit of the HMC MFMA kernels (hmc_dense.hpp)
 #include "hmc_dense.hpp"
+#include "hmc_split.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
 
@@ -15,6 +16,33 @@ int plain(const HmcParams& prm, hipStream_t st)
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
+    return (int)hipGetLastError();
+}
+
+// one wave per SIMD (WPB = 4): when the chains do not fill the chip at two waves per SIMD
+template <int NT>
+int plain4(const HmcParams& prm, hipStream_t st)
+{
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
+    auto kern = hmc_gauss_mfma_kernel<NT, 4>;
+    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
+    return (int)hipGetLastError();
+}
+
+// SPLIT waves per chain tile (hmc_split.hpp): fewer tiles than SIMDs
+template <int NT, int SPLIT, int WPB>
+int split(const HmcParams& prm, hipStream_t st)
+{
+    const size_t lds = hmc_split_lds_bytes<NT, SPLIT, WPB>();
+    int dev = 0, lds_max = 0;
+    MI_LAUNCH_TRY(hipGetDevice(&dev));
+    MI_LAUNCH_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    if ((size_t)lds_max < lds) return (int)hipErrorInvalidValue;
+    auto kern = hmc_gauss_split_kernel<NT, SPLIT, WPB>;
+    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned chains_per_wg = 16 * (WPB / SPLIT);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + chains_per_wg - 1) / chains_per_wg)), dim3(64 * WPB), lds, st, prm);
     return (int)hipGetLastError();
 }
 
@@ -41,6 +69,14 @@ int launch_hmc_gauss(const HmcParams& prm, int nt, bool gen, bool dense_m, hipSt
     }
     if (gen) return MI_DISPATCH_NT(nt, (general<1, false>(prm, st)), (general<2, false>(prm, st)), (general<4, false>(prm, st)), (general<8, false>(prm, st)));
     return MI_DISPATCH_NT(nt, plain<1>(prm, st), plain<2>(prm, st), plain<4>(prm, st), plain<8>(prm, st));
+}
+
+// plain case, 64 < d <= 128 (nt = 8), few chains: shape 1 = one wave per SIMD, one tile per wave; 2 = two waves per tile, one
+// wave per SIMD; 3 = four waves per tile, two waves per SIMD (32 chains per workgroup like shape 2); 4 = four waves per tile,
+// one wave per SIMD (16 chains per workgroup)
+int launch_hmc_gauss_few_chains(const HmcParams& prm, int shape, hipStream_t st)
+{
+    return shape == 1 ? plain4<8>(prm, st) : shape == 2 ? split<8, 2, 4>(prm, st) : shape == 3 ? split<8, 4, 8>(prm, st) : split<8, 4, 4>(prm, st);
 }
 
 }  // namespace mi

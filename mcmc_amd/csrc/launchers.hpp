@@ -17,6 +17,10 @@ struct SmallParams;
 
 // nt = ceil(d / 16) in {1, 2, 3..4, 5..8}; general: bounds and / or diagonal precond; dense_m: dense precond (nt <= 4)
 int launch_hmc_gauss(const HmcParams& prm, int nt, bool general, bool dense_m, hipStream_t st);
+// plain case with nt = 8 (64 < d <= 128) when the chains do not fill the chip at two waves per SIMD (strong scaling):
+// shape 1 = one wave per SIMD (hmc_gauss_mfma_kernel<8, 4>); hmc_split.hpp: 2 = two waves per 16-chain tile, 3 = four waves per
+// tile at two waves per SIMD, 4 = four waves per tile at one wave per SIMD
+int launch_hmc_gauss_few_chains(const HmcParams& prm, int shape, hipStream_t st);
 // variant: 0 plain, 1 general (bounds / diagonal precond), 2 dense precond (unbounded, nt <= 4)
 int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st);
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel

@@ -30,6 +30,14 @@
 #include "launchers.hpp"
 #include "small_samplers.hpp"
 
+// round time of the few-chain launch shapes of the plain HMC kernel relative to the default (two waves per SIMD), d = 128
+#ifndef MI_HMC_COST_1WAVE
+#define MI_HMC_COST_1WAVE 0.535       // 27.1 ms against 50.8 ms per round (tools/hmc_shapes.py)
+#define MI_HMC_COST_SPLIT2 0.287      // 14.55 ms
+#define MI_HMC_COST_SPLIT4X2 0.278    // 14.12 ms
+#define MI_HMC_COST_SPLIT4 0.153      // 7.78 ms
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -664,7 +672,33 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         rc = launched("hmc", mi::launch_hmc_gauss(prm, nt, true, dense_m, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // bounds buffers are ours
     }
-    else rc = launched("hmc", mi::launch_hmc_gauss(prm, nt, false, false, st));
+    else {
+        // launch shape of the plain kernel (64 < d <= 128): with fewer 16-chain tiles than the chip has wave slots, give a tile
+        // a whole SIMD, or two / four of them (hmc_split.hpp).  Estimated cost = rounds of workgroups x time of one round,
+        // the round times relative to the two-waves-per-SIMD shape as measured on MI355X.
+        int shape = 0;
+        if (nt > 4) {
+            int dev = 0, n_cu = 256;
+            HIP_TRY(hipGetDevice(&dev));
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            if (n_cu <= 0) n_cu = 256;
+            const uint64_t C = chains->n_chains;
+            auto rounds = [&](uint64_t chains_per_wg) { return (double)(((C + chains_per_wg - 1) / chains_per_wg + n_cu - 1) / n_cu); };
+            const double cost[5] = {rounds(128) * 1.00, rounds(64) * MI_HMC_COST_1WAVE, rounds(32) * MI_HMC_COST_SPLIT2,
+                                    rounds(32) * MI_HMC_COST_SPLIT4X2, rounds(16) * MI_HMC_COST_SPLIT4};
+            for (int k = 1; k < 5; ++k) if (cost[k] < cost[shape]) shape = k;
+            switch (target->kernel_hint) {
+            case MI_KERNEL_HMC_TWO_WAVES_PER_SIMD: shape = 0; break;
+            case MI_KERNEL_HMC_ONE_WAVE_PER_SIMD: shape = 1; break;
+            case MI_KERNEL_HMC_SPLIT2: shape = 2; break;
+            case MI_KERNEL_HMC_SPLIT4_TWO_WAVES: shape = 3; break;
+            case MI_KERNEL_HMC_SPLIT4: shape = 4; break;
+            default: break;
+            }
+        }
+        rc = shape == 0 ? launched("hmc", mi::launch_hmc_gauss(prm, nt, false, false, st))
+                        : launched("hmc", mi::launch_hmc_gauss_few_chains(prm, shape, st));
+    }
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);

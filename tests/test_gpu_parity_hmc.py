@@ -357,3 +357,36 @@ def test_diagonal_precond_beyond_128_dims_bit_exact_vs_oracle(kind, d, C, L, eps
     o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s, chain0=6)
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
     assert g["n_accept"].sum() > 0
+
+
+# ---------------------------------------------------------------- launch shapes of the plain kernel for few chains (strong scaling)
+@pytest.mark.parametrize("C", [1, 16, 33, 200])
+@pytest.mark.parametrize("d", [128, 100, 65])
+def test_few_chain_launch_shapes_give_the_bits_of_the_default_kernel(d, C):
+    """One wave per SIMD, two and four waves per 16-chain tile (hmc_split.hpp: row blocks of the mat-vec per wave, theta exchanged
+    through LDS, dot-product chains relayed in slice order) against the default shape and the oracle."""
+    prec = synth.dense_gaussian_precision(d, seed=9)
+    init = synth.initial_states(C, d, seed=14)
+    st = mcmc_amd.default_settings(rng_seed_value=41, n_burnin_draws=3, n_keep_draws=7, n_leap_steps=5, step_size=0.07)
+    ref, gr = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=77, kernel_hint=mcmc_amd.KERNEL_HMC_TWO_WAVES_PER_SIMD)
+    o_draws, o = _oracle_many(orc.TARGET_DENSE, d, init, st, prec=prec, chain0=77)
+    assert np.array_equal(ref, o_draws) and np.array_equal(gr["n_accept"], o["n_accept"])
+    for hint in (mcmc_amd.KERNEL_HMC_ONE_WAVE_PER_SIMD, mcmc_amd.KERNEL_HMC_SPLIT2, mcmc_amd.KERNEL_HMC_SPLIT4, mcmc_amd.KERNEL_HMC_SPLIT4_TWO_WAVES,
+                 mcmc_amd.KERNEL_AUTO):
+        got, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=77, kernel_hint=hint)
+        assert np.array_equal(got, ref), hint
+        assert np.array_equal(g["n_accept"], gr["n_accept"]) and np.array_equal(g["theta"], gr["theta"]) and np.array_equal(g["n_leap"], gr["n_leap"])
+
+
+def test_split_kernel_with_zero_leapfrog_steps_and_discarded_draws():
+    d, C = 128, 40
+    prec = synth.dense_gaussian_precision(d, seed=9)
+    init = synth.initial_states(C, d, seed=14)
+    for L in (0, 1):
+        st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=2, n_keep_draws=3, n_leap_steps=L, step_size=0.07)
+        ref, gr = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=mcmc_amd.KERNEL_HMC_TWO_WAVES_PER_SIMD)
+        for hint in (mcmc_amd.KERNEL_HMC_SPLIT2, mcmc_amd.KERNEL_HMC_SPLIT4, mcmc_amd.KERNEL_HMC_SPLIT4_TWO_WAVES):
+            got, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=hint)
+            assert np.array_equal(got, ref) and np.array_equal(g["n_accept"], gr["n_accept"])
+            _, g2 = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=hint, want_draws=False)
+            assert np.array_equal(g2["theta"], gr["theta"])
