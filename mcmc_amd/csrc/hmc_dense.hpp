@@ -47,8 +47,8 @@ struct HmcParams {
     double* wsave;          // [n_waves][2][NS][64] workspace: last accepted theta and P*theta
     int vals_bound;         // general variant: settings.vals_bound (0: only a diagonal precond_mat)
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
-    const double* Minv;     // DENSE_M: INV(precond_mat), d*d row-major (device)
-    const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), d*d row-major (device)
+    const double* Minv;     // DENSE_M: INV(precond_mat), device: d*d row-major (d <= 64, staged into LDS) / fragment order (d > 64)
+    const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), likewise
     double* draws;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept;     // [C] or nullptr
     uint64_t* n_leap;       // [C] or nullptr
@@ -160,6 +160,55 @@ __device__ __forceinline__ void stage_precision(const double* __restrict__ P, ui
 }
 
 
+// The same mat-vec with the A fragments read from GLOBAL memory in fragment order (gfrag[(t NS + s) 64 + lane], what
+// stage_precision writes to LDS): for the second and third matrix of a run whose d > 64 -- INV(precond_mat), CHOL_LOWER(precond_mat),
+// 128 KB each -- which do not fit next to the precision in the 160 KB of LDS.  Every wave of the launch reads the same 128 KB, so
+// they live in L2; a wave-load is one coalesced 512-byte segment.  PD slices are in flight ahead of the MFMAs (a slice of NT = 8
+// MFMAs lasts 512 cycles, an L2 hit ~ 500-900).  Same fma order as matvec_mfma, hence the same bits.
+template <int NT>
+__device__ __forceinline__ void matvec_mfma_g(const double* __restrict__ gfrag, const double (&th)[4 * NT], double (&w)[4 * NT])
+{
+    constexpr int NS = 4 * NT;
+    constexpr int PD = 3;
+    double4_t acc[NT];
+    double a[PD + 1][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < PD && p < NS; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[p][t] = gfrag[(size_t)(t * NS + p) * 64];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + PD < NS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[(s + PD) % (PD + 1)][t] = gfrag[(size_t)(t * NS + s + PD) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s % (PD + 1)][t], th[s], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        w[4 * t + 0] = acc[t][0];
+        w[4 * t + 1] = acc[t][1];
+        w[4 * t + 2] = acc[t][2];
+        w[4 * t + 3] = acc[t][3];
+    }
+}
+
+// second / third matrix of a dense-preconditioner run: LDS fragments (d <= 64) or global fragments (d > 64)
+template <int NT>
+constexpr bool dense_m_from_global() { return NT > 4; }
+template <int NT>
+__device__ __forceinline__ void matvec_m2(const double* __restrict__ frag_lane, const double (&x)[4 * NT], double (&y)[4 * NT])
+{
+    if constexpr (dense_m_from_global<NT>()) matvec_mfma_g<NT>(frag_lane, x, y);
+    else matvec_mfma<NT>(frag_lane, x, y);
+}
+
 // ---- box constraints (element-wise maps of /root/reference/include/misc/transform_vals.hpp:25-119,
 //      log_jacobian.hpp:25-58, inv_jacobian_adjust.hpp:25-56), one dimension at a time
 constexpr double EPS_DBL = 2.220446049250313e-16;    // mcmc_options.hpp:103
@@ -239,7 +288,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     int* lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
     double* lds_Minv = lds_mi + 16 * NT + 8 * NT;          // after the int table (16*NT ints = 8*NT doubles), DENSE_M only
     double* lds_L = lds_Minv + NT * NS * 64;
-    if constexpr (DENSE_M) {
+    if constexpr (DENSE_M && !dense_m_from_global<NT>()) {
         stage_precision<NT>(prm.Minv, prm.d, lds_Minv);
         stage_precision<NT>(prm.Lchol, prm.d, lds_L);
     }
@@ -265,8 +314,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     const uint64_t C = prm.C;
     const double eps = prm.eps;
     const double* afrag = lds_P + lane;
-    [[maybe_unused]] const double* afrag_minv = lds_Minv + lane;
-    [[maybe_unused]] const double* afrag_l = lds_L + lane;
+    // d > 64: prm.Minv / prm.Lchol are already in fragment order in global memory (host: pack_fragments)
+    [[maybe_unused]] const double* afrag_minv = (DENSE_M && dense_m_from_global<NT>()) ? prm.Minv + lane : lds_Minv + lane;
+    [[maybe_unused]] const double* afrag_l = (DENSE_M && dense_m_from_global<NT>()) ? prm.Lchol + lane : lds_L + lane;
 
     // Register-resident state of the wave's 16 chains: position, momentum, P*position.
     // The last accepted (theta, P*theta) lives in HBM (prm.theta / prm.wsave): written on accept,
@@ -318,7 +368,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         if constexpr (BOUNDED) {
             double mp[NS];                               // inv_precond_matrix * mntm, a dense product
             if constexpr (DENSE_M) {
-                matvec_mfma<NT>(afrag_minv, pm, mp);
+                matvec_m2<NT>(afrag_minv, pm, mp);
             } else {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
@@ -399,7 +449,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             double zz[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) zz[s] = pm[s];
-            matvec_mfma<NT>(afrag_l, zz, pm);
+            matvec_m2<NT>(afrag_l, zz, pm);
         } else if constexpr (BOUNDED) {                 // p = L z with a diagonal L (:158)
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = lds_ms[4 * s + j] * pm[s];
@@ -423,7 +473,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             double zz[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) zz[s] = pm[s];
-            matvec_mfma<NT>(afrag_l, zz, pm);
+            matvec_m2<NT>(afrag_l, zz, pm);
         }
 #endif
         const double prev_K = kinetic();                // hmc.cpp:160
@@ -469,7 +519,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
 #pragma unroll
                 for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;   // first half-step (:122)
                 if constexpr (DENSE_M) {
-                    matvec_mfma<NT>(afrag_minv, pm, mp);                    // inv_precond_matrix * new_mntm (:171)
+                    matvec_m2<NT>(afrag_minv, pm, mp);                    // inv_precond_matrix * new_mntm (:171)
                 } else {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];

@@ -263,7 +263,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
     }
 }
 
-// MALA with a DENSE precond_mat M, unbounded (mala.cpp:123,159; mala.ipp:60-64), d <= 64: four fragment sets share the LDS
+// MALA with a DENSE precond_mat M, unbounded (mala.cpp:123,159; mala.ipp:60-64): four fragment sets share the LDS (d <= 64; beyond, three of them stay in L2)
 // (P, M, L = CHOL_LOWER(M), INV(eps^2 M); the last two and LOG_DET(eps^2 M) come from the host in the oracle's operation order).
 //   mu(v) = v + (eps^2 (M g)) / 2,   proposal = mu + eps (L z),   dmvnorm terms with INV(Sigma) as mat-vecs:
 // five mat-vecs per draw (P x', M g', L z, Sinv xa, Sinv xb); M g of the current state is carried.  A bounded run would need
@@ -274,9 +274,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
     constexpr int NS = 4 * NT;
     constexpr int MAT = NT * NS * 64;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
-    stage_precision<NT>(prm.Mfull, prm.d, lds_P + MAT);
-    stage_precision<NT>(prm.Lchol, prm.d, lds_P + 2 * MAT);
-    stage_precision<NT>(prm.Sinv, prm.d, lds_P + 3 * MAT);
+    constexpr bool MG = dense_m_from_global<NT>();     // d > 64: M, L, INV(Sigma) are read from L2 in fragment order (hmc_dense.hpp)
+    if constexpr (!MG) {
+        stage_precision<NT>(prm.Mfull, prm.d, lds_P + MAT);
+        stage_precision<NT>(prm.Lchol, prm.d, lds_P + 2 * MAT);
+        stage_precision<NT>(prm.Sinv, prm.d, lds_P + 3 * MAT);
+    }
     stage_precision<NT>(prm.P, prm.d, lds_P);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,9 +292,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
     const uint64_t C = prm.C;
     const double eps = prm.eps, s2 = prm.s2;
     const double* afrag = lds_P + lane;
-    const double* afrag_m = lds_P + MAT + lane;
-    const double* afrag_l = lds_P + 2 * MAT + lane;
-    const double* afrag_si = lds_P + 3 * MAT + lane;
+    const double* afrag_m = MG ? prm.Mfull + lane : lds_P + MAT + lane;
+    const double* afrag_l = MG ? prm.Lchol + lane : lds_P + 2 * MAT + lane;
+    const double* afrag_si = MG ? prm.Sinv + lane : lds_P + 3 * MAT + lane;
     const size_t lane_off = (size_t)j * C + cld;
 
     double th[NS], w[NS], mg[NS];      // current state, P theta, M grad (grad = -w)
@@ -300,7 +303,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
     auto m_times_grad = [&](const double (&ww)[NS], double (&out)[NS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = -ww[s];
-        matvec_mfma<NT>(afrag_m, a, out);                // precond_matrix * grad_obj (mala.cpp:123)
+        matvec_m2<NT>(afrag_m, a, out);                // precond_matrix * grad_obj (mala.cpp:123)
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -323,7 +326,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
             a[2 * bb + 1] = (8u * bb + 4 + j < d) ? z1 : 0.0;
             __builtin_amdgcn_sched_barrier(0);
         }
-        matvec_mfma<NT>(afrag_l, a, b);                  // sqrt_precond_matrix * rand_vec (:159)
+        matvec_m2<NT>(afrag_l, a, b);                  // sqrt_precond_matrix * rand_vec (:159)
 #pragma unroll
         for (int s = 0; s < NS; ++s) tp[s] = (th[s] + (s2 * mg[s]) / 2.0) + eps * b[s];   // :123, :159
         matvec_mfma<NT>(afrag, tp, wp);
@@ -333,11 +336,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
         // mala_prop_adjustment (mala.ipp:60-64): dmvnorm(prev | mu(prop), Sigma) - dmvnorm(prop | mu(prev), Sigma)
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = th[s] - (tp[s] + (s2 * mgp[s]) / 2.0);       // X - mu (dmvnorm.hpp:37)
-        matvec_mfma<NT>(afrag_si, a, b);
+        matvec_m2<NT>(afrag_si, a, b);
         const double quad_a = dot4<NS>(a, b);            // :39
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = tp[s] - (th[s] + (s2 * mg[s]) / 2.0);
-        matvec_mfma<NT>(afrag_si, a, b);
+        matvec_m2<NT>(afrag_si, a, b);
         const double quad_b = dot4<NS>(a, b);
         const double da = prm.cons_term - 0.5 * (prm.log_det + quad_a);   // :41
         const double db = prm.cons_term - 0.5 * (prm.log_det + quad_b);

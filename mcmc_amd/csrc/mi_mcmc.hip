@@ -295,6 +295,36 @@ void host_cholesky_lower(const double* A, size_t d, std::vector<double>& L)
     }
 }
 
+// d x d row-major -> MFMA A-fragment order [t][s][lane] = M[16 t + (lane & 15)][4 s + (lane >> 4)], zero padded to 16 nt
+// (what stage_precision writes into LDS): the layout of matrices a kernel reads straight from global memory (d > 64:
+// INV / CHOL_LOWER of a dense precond_mat do not fit into LDS next to the precision, hmc_dense.hpp: matvec_mfma_g)
+std::vector<double> pack_fragments(const std::vector<double>& M, size_t d, int nt)
+{
+    const int ns = 4 * nt;
+    std::vector<double> out((size_t)nt * ns * 64, 0.0);
+    for (int t = 0; t < nt; ++t)
+        for (int sl = 0; sl < ns; ++sl)
+            for (int l = 0; l < 64; ++l) {
+                const size_t row = 16 * (size_t)t + (l & 15), col = 4 * (size_t)sl + (l >> 4);
+                if (row < d && col < d) out[((size_t)t * ns + sl) * 64 + l] = M[row * d + col];
+            }
+    return out;
+}
+// the device copy of a second / third matrix: row-major for d <= 64 (the kernel stages it into LDS), fragment order beyond
+int upload_matrix(const std::vector<double>& M, size_t d, DevBuf& buf)
+{
+    const int nt = (int)((d + 15) / 16);
+    if (nt > 4) {
+        const std::vector<double> f = pack_fragments(M, d, 8);
+        HIP_TRY(buf.alloc(f.size() * 8));
+        HIP_TRY(hipMemcpy(buf.p, f.data(), f.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(buf.alloc(d * d * 8));
+        HIP_TRY(hipMemcpy(buf.p, M.data(), d * d * 8, hipMemcpyHostToDevice));
+    }
+    return MI_OK;
+}
+
 // Per-dimension tables of the general kernel variants (settings.vals_bound and / or a diagonal precond_mat):
 // determine_bounds_type (determine_bounds_type.hpp:27-57: 1 none, 2 lower, 3 upper, 4 both), the bounds, and the diagonal of
 // precond_mat with its CHOL_LOWER / INV (element-wise sqrt / reciprocal for a diagonal matrix, as the oracle's BMO shim gives).
@@ -306,7 +336,7 @@ struct GeneralTables {
     DevBuf bt, lb, ub, m_dev, ms_dev, mi_dev;
 };
 
-int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTables& g, bool allow_dense = false)
+int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTables& g, bool allow_dense = false, bool dense_beyond_64 = false)
 {
     g.active = s->vals_bound != 0 || s->precond_mat != nullptr;
     if (!g.active) return MI_OK;
@@ -324,13 +354,12 @@ int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTab
                 if (i == k) { g.m[i] = v; g.m_sqrt[i] = __builtin_sqrt(v); g.m_inv[i] = 1.0 / v; }
             }
     if (g.dense) {
-        if (d > 64) return fail(MI_ERR_UNSUPPORTED, "%s: a dense precond_mat is implemented for d <= 64 (diagonal: d <= 128)", who);
+        if (d > 64 && !dense_beyond_64) return fail(MI_ERR_UNSUPPORTED, "%s: a dense precond_mat / cov_mat is implemented for d <= 64 (diagonal: d <= 128)", who);
         std::vector<double> Minv, L;
         host_inverse(s->precond_mat, d, Minv);
         host_cholesky_lower(s->precond_mat, d, L);
-        HIP_TRY(g.minv_full.alloc(d * d * 8)); HIP_TRY(g.l_full.alloc(d * d * 8));
-        HIP_TRY(hipMemcpy(g.minv_full.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g.l_full.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+        int rcu = upload_matrix(Minv, d, g.minv_full); if (rcu) return rcu;
+        rcu = upload_matrix(L, d, g.l_full); if (rcu) return rcu;
     }
     std::vector<int> bt(d, 1);
     std::vector<double> lbv(d, 0.0), ubv(d, 0.0);
@@ -531,8 +560,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
                 if (i != k && v != 0.0) dense_m = true;
                 if (i == k) { m_sqrt[i] = __builtin_sqrt(v); m_inv[i] = 1.0 / v; }
             }
-        // a dense matrix: INV / CHOL_LOWER on the host, three fragment sets in LDS (d <= 64); target must be an MFMA one
-        if (dense_m && d > 64) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 64 (diagonal: d <= 128)");
+        // a dense matrix: INV / CHOL_LOWER on the host; three fragment sets in LDS (d <= 64), or the two extra ones read from L2
+        // in fragment order (64 < d <= 128); target must be an MFMA one
         if (dense_m && target->kind == MI_TARGET_LOGISTIC) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with the logistic target is not implemented");
     }
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -550,7 +579,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (d > 128 && !separable)
         return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
     if (separable && (d > 128 || force_diag)) {
-        if (dense_m) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 64");
+        if (dense_m) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 128");
         // no contraction: the elementwise (lane-per-chain) kernel
         DevBuf prec_owned;
         const double* prec_dev = nullptr;
@@ -664,9 +693,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             std::vector<double> Minv, L;
             host_inverse(settings->precond_mat, d, Minv);
             host_cholesky_lower(settings->precond_mat, d, L);
-            HIP_TRY(minv_dev.alloc(d * d * 8)); HIP_TRY(l_dev.alloc(d * d * 8));
-            HIP_TRY(hipMemcpy(minv_dev.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(l_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+            rc = upload_matrix(Minv, d, minv_dev); if (rc) return rc;
+            rc = upload_matrix(L, d, l_dev); if (rc) return rc;
             prm.Minv = minv_dev.as<double>(); prm.Lchol = l_dev.as<double>();
         }
         rc = launched("hmc", mi::launch_hmc_gauss(prm, nt, true, dense_m, st));
@@ -799,7 +827,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
-    rc = general_tables("mala", settings, d, gt, true);
+    rc = general_tables("mala", settings, d, gt, true, true);
     if (rc) return rc;
     if (gt.active && gt.dense) {
         // dense precond_mat, unbounded: Sigma = eps^2 M is constant, so INV / CHOL_LOWER / LOG_DET come from the host once
@@ -812,9 +840,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(Ls[i * d + i]);
         prm.log_det = ld;
         DevBuf m_full, sinv_full;
-        HIP_TRY(m_full.alloc(d * d * 8)); HIP_TRY(sinv_full.alloc(d * d * 8));
-        HIP_TRY(hipMemcpy(m_full.p, settings->precond_mat, d * d * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(sinv_full.p, Sinv.data(), d * d * 8, hipMemcpyHostToDevice));
+        rc = upload_matrix(std::vector<double>(settings->precond_mat, settings->precond_mat + d * d), d, m_full); if (rc) return rc;
+        rc = upload_matrix(Sinv, d, sinv_full); if (rc) return rc;
         prm.Mfull = m_full.as<double>(); prm.Lchol = gt.l_full.as<double>(); prm.Sinv = sinv_full.as<double>();
         rc = launched("mala", mi::launch_mala_gauss(prm, nt, 2, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the matrices are ours
@@ -873,7 +900,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
 
     const int nt = (int)((d + 15) / 16);
     GeneralTables gt;
-    rc = general_tables("rwmh", settings, d, gt, true);
+    rc = general_tables("rwmh", settings, d, gt, true, true);
     if (rc) return rc;
     DevBuf c_dev, lc_dev;
     if (gt.active) {
@@ -889,8 +916,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
             std::vector<double> L;
             host_cholesky_lower(settings->precond_mat, d, L);
             for (auto& v : L) v = prm.par_scale * v;
-            HIP_TRY(lc_dev.alloc(d * d * 8));
-            HIP_TRY(hipMemcpy(lc_dev.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+            rc = upload_matrix(L, d, lc_dev); if (rc) return rc;
             prm.Lc = lc_dev.as<double>();
         }
         rc = launched("rwmh", mi::launch_rwmh_gauss(prm, nt, true, gt.dense, st));
@@ -977,7 +1003,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 #ifdef MI_PROFILING
     if (const char* e = getenv("MI_NUTS_BATCH")) nuts_batch = (uint32_t)atoi(e);
 #endif
-    rc = general_tables("nuts", settings, d, gt, true);
+    rc = general_tables("nuts", settings, d, gt, true, true);
     if (rc) return rc;
     if (gt.active && gt.dense) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();

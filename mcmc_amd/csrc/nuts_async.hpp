@@ -59,7 +59,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     int* const lds_bt = reinterpret_cast<int*>(lds_mi + 16 * NT);
     double* const lds_Minv = lds_mi + 16 * NT + 8 * NT;   // after the int table, DENSE_M only
     double* const lds_L = lds_Minv + NT * NS * 64;
-    if constexpr (DENSE_M) {
+    if constexpr (DENSE_M && !dense_m_from_global<NT>()) {
         stage_precision<NT>(prm.Minv, prm.d, lds_Minv);
         stage_precision<NT>(prm.Lchol, prm.d, lds_L);
     }
@@ -85,8 +85,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
-    [[maybe_unused]] const double* afrag_minv = lds_Minv + lane;
-    [[maybe_unused]] const double* afrag_l = lds_L + lane;
+    // d > 64: prm.Minv / prm.Lchol are in fragment order in global memory (hmc_dense.hpp: matvec_mfma_g)
+    [[maybe_unused]] const double* afrag_minv = (DENSE_M && dense_m_from_global<NT>()) ? prm.Minv + lane : lds_Minv + lane;
+    [[maybe_unused]] const double* afrag_l = (DENSE_M && dense_m_from_global<NT>()) ? prm.Lchol + lane : lds_L + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
@@ -180,7 +181,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         if constexpr (GENERAL) {
             double mp[NS];
             if constexpr (DENSE_M) {
-                matvec_mfma<NT>(afrag_minv, pm, mp);
+                matvec_m2<NT>(afrag_minv, pm, mp);
             } else {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
@@ -229,7 +230,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         if constexpr (GENERAL) {
             double mp[NS];
             if constexpr (DENSE_M) {
-                matvec_mfma<NT>(afrag_minv, pm, mp);
+                matvec_m2<NT>(afrag_minv, pm, mp);
             } else {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
@@ -300,7 +301,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             double zz[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) zz[s] = pm[s];
-            matvec_mfma<NT>(afrag_l, zz, pm);
+            matvec_m2<NT>(afrag_l, zz, pm);
         }
         double U0 = prev_U;
         if (!is_finite(U0)) U0 = INF;
@@ -424,8 +425,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                     zz[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
                     zz[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
                 }
-                matvec_mfma<NT>(afrag_l, zz, pp);
-                matvec_mfma<NT>(afrag_minv, pp, mp);
+                matvec_m2<NT>(afrag_l, zz, pp);
+                matvec_m2<NT>(afrag_minv, pp, mp);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) kq = dfma(pp[s], mp[s], kq);
                 if (p && live) { st_row(V_MNTM, 0, pp); st_row(V_TPOS_P, 0, pp); st_row(V_TNEG_P, 0, pp); }
@@ -517,7 +518,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             if constexpr (GENERAL) {
                 double mp[NS];
                 if constexpr (DENSE_M) {
-                    matvec_mfma<NT>(afrag_minv, pm, mp);
+                    matvec_m2<NT>(afrag_minv, pm, mp);
                 } else {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
@@ -557,7 +558,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 pU = -(kval + lj);
                 double mp[NS];
                 if constexpr (DENSE_M) {
-                    matvec_mfma<NT>(afrag_minv, pm, mp);
+                    matvec_m2<NT>(afrag_minv, pm, mp);
                 } else {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];

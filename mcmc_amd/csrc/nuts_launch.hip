@@ -9,7 +9,7 @@ namespace {
 template <int NT, bool GENERAL, bool DENSE_M>
 int async(const NutsParams& prm, uint32_t batch, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 * (DENSE_M ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double)
+    const size_t lds = ((size_t)NT * 4 * NT * 64 * ((DENSE_M && NT <= 4) ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double)
                      + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     auto kern = nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -32,10 +32,7 @@ int lockstep(const NutsParams& prm, hipStream_t st)
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, bool ls, uint32_t batch, hipStream_t st)
 {
     if (batch < 1) batch = 1;
-    if (dense_m) {
-        if (nt > 4) return (int)hipErrorInvalidValue;
-        return nt <= 1 ? async<1, true, true>(prm, batch, st) : nt == 2 ? async<2, true, true>(prm, batch, st) : async<4, true, true>(prm, batch, st);
-    }
+    if (dense_m) return MI_DISPATCH_NT(nt, (async<1, true, true>(prm, batch, st)), (async<2, true, true>(prm, batch, st)), (async<4, true, true>(prm, batch, st)), (async<8, true, true>(prm, batch, st)));
     if (gen) return MI_DISPATCH_NT(nt, (async<1, true, false>(prm, batch, st)), (async<2, true, false>(prm, batch, st)), (async<4, true, false>(prm, batch, st)), (async<8, true, false>(prm, batch, st)));
     if (ls) return MI_DISPATCH_NT(nt, lockstep<1>(prm, st), lockstep<2>(prm, st), lockstep<4>(prm, st), lockstep<8>(prm, st));
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));

@@ -56,7 +56,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void rwmh_gauss_mfma_kernel(
             lds_c[i] = in ? prm.c_diag[i] : 0.0;
         }
     }
-    if constexpr (DENSE_C) stage_precision<NT>(prm.Lc, prm.d, lds_Lc);
+    if constexpr (DENSE_C && !dense_m_from_global<NT>()) stage_precision<NT>(prm.Lc, prm.d, lds_Lc);      // d > 64: read from L2 in fragment order
     stage_precision<NT>(prm.P, prm.d, lds_P);           // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,7 +68,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void rwmh_gauss_mfma_kernel(
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
     const double* afrag = lds_P + lane;
-    [[maybe_unused]] const double* afrag_lc = lds_Lc + lane;
+    [[maybe_unused]] const double* afrag_lc = (DENSE_C && dense_m_from_global<NT>()) ? prm.Lc + lane : lds_Lc + lane;
     const size_t lane_off = (size_t)j * C + cld;
     const bool vb = GENERAL && prm.vals_bound != 0;
 
@@ -135,7 +135,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void rwmh_gauss_mfma_kernel(
         }
         if constexpr (DENSE_C) {
             double t[NS];
-            matvec_mfma<NT>(afrag_lc, zz, t);
+            matvec_m2<NT>(afrag_lc, zz, t);
 #pragma unroll
             for (int s = 0; s < NS; ++s) tp[s] = th[s] + t[s];
         }

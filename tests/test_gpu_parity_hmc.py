@@ -285,7 +285,9 @@ def _spd(d, seed):
     return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
 
 
-@pytest.mark.parametrize("d,C,L,eps,bounded", [(8, 16, 5, 0.1, False), (37, 40, 3, 0.05, False), (64, 33, 4, 0.04, False), (20, 24, 4, 0.05, True)])
+@pytest.mark.parametrize("d,C,L,eps,bounded", [(8, 16, 5, 0.1, False), (37, 40, 3, 0.05, False), (64, 33, 4, 0.04, False), (20, 24, 4, 0.05, True),
+                                               (128, 70, 16, 0.03, False),      # the BASELINE dimension: INV(M), CHOL(M) read from L2 in fragment order
+                                               (100, 33, 4, 0.03, True), (65, 16, 3, 0.04, False)])
 def test_dense_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
     """precond_mat dense: p = L z, theta += eps Minv p, K = p.Minv p / 2 as MFMA mat-vecs; INV / CHOL on the host."""
     prec = synth.dense_gaussian_precision(d, seed=5)
@@ -306,8 +308,8 @@ def test_dense_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
     assert 0 < g["n_accept"].sum()
 
 
-def test_dense_precond_beyond_lds_is_refused_not_approximated():
-    d = 100                                              # three 100x100 fragment sets do not fit the LDS
+def test_dense_precond_beyond_128_dims_is_refused_not_approximated():
+    d = 130
     M = _spd(d, seed=1)
     st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
     with pytest.raises(mcmc_amd.MiMcmcError) as e:

@@ -147,7 +147,7 @@ def _spd(d, seed):
     return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
 
 
-@pytest.mark.parametrize("d,C,eps", [(8, 16, 0.3), (37, 40, 0.1), (64, 33, 0.08)])
+@pytest.mark.parametrize("d,C,eps", [(8, 16, 0.3), (37, 40, 0.1), (64, 33, 0.08), (128, 40, 0.05), (90, 17, 0.06)])   # d > 64: M, L, INV(Sigma) from L2
 def test_dense_precond_mala_bit_exact_vs_oracle(d, C, eps):
     prec = synth.dense_gaussian_precision(d, seed=5)
     M = _spd(d, seed=d)

@@ -125,7 +125,8 @@ def _spd(d, seed):
     return A @ A.T + np.diag(rng.uniform(0.5, 1.5, d))
 
 
-@pytest.mark.parametrize("d,C,bounded", [(8, 16, False), (37, 24, False), (64, 20, False), (20, 24, True)])
+@pytest.mark.parametrize("d,C,bounded", [(8, 16, False), (37, 24, False), (64, 20, False), (20, 24, True),
+                                        (128, 40, False), (100, 20, True)])      # d > 64: INV(M), CHOL(M) from L2 in fragment order
 def test_dense_precond_nuts_bit_exact_vs_oracle(d, C, bounded):
     prec = synth.dense_gaussian_precision(d, seed=5)
     M = _spd(d, seed=d)

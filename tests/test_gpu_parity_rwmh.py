@@ -30,6 +30,8 @@ CASES = [
     ("dense", 100, 130, 0.10, 2, 6, "diag", False),
     ("diag", 40, 48, 0.20, 3, 9, "diag", True),
     ("dense", 64, 33, 0.15, 2, 8, "dense", False),
+    ("dense", 128, 40, 0.08, 2, 8, "dense", False),  # d > 64: par_scale * chol(cov_mat) read from L2 in fragment order
+    ("dense", 100, 20, 0.08, 1, 6, "dense", True),
     ("dense", 20, 24, 0.30, 3, 12, "dense", True),
     ("dense", 37, 20, 0.10, 0, 10, None, True),      # ragged d, bounds, no burn-in
 ]
