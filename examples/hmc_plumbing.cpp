@@ -1,7 +1,8 @@
 // examples/hmc_plumbing.cpp -- the call pattern of the reference examples
 // (/root/reference/examples/eigen/hmc_normal.cpp:83-118: settings, mcmc::hmc(initial_val, target, draws_out, &data, settings),
 // column means, acceptance rate) against this repository's mcmc.hpp.  BASELINE config[0]: 3-D isotropic Gaussian, 1 chain,
-// host std::function target; then the device-target route with many chains for hmc / mala / nuts.
+// host std::function target; then the device-target route with many chains for hmc / mala / nuts; then mcmc::mala and
+// mcmc::nuts with the host std::function target (examples/eigen/mala_normal.cpp:108, nuts_normal.cpp:107).
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/hmc_plumbing.cpp -Lmcmc_amd -lmi_mcmc -Wl,-rpath,$PWD/mcmc_amd -o hmc_plumbing
 #define MCMC_ENABLE_EIGEN_WRAPPERS
@@ -108,8 +109,29 @@ int main()
                 double(s4.rmhmc_settings.n_accept_draws) / 200.0, ok4 ? dr.col_mean(0) : 0.0, ok4 ? dr.col_mean(1) : 0.0);
     if (!ok4) return 1;
 
-    // a host callback with mala / nuts is refused (no CPU sampler behind this header)
-    const bool refused = !mcmc::nuts(initial_val, log_target_dens, draws_out, &dta, settings);
-    std::printf("nuts with host callback refused=%d\n", int(refused));
-    return (ok && ok2 && refused) ? 0 : 1;
+    // ---- mcmc::mala and mcmc::nuts with the SAME host std::function target: the call pattern of the reference's
+    //      examples/eigen/mala_normal.cpp:108 and nuts_normal.cpp:107 (settings, sampler call, column means, acceptance rate)
+    mcmc::algo_settings_t s5;
+    s5.rng_seed_value = 1234;
+    s5.mala_settings.step_size = 0.8;
+    s5.mala_settings.n_burnin_draws = 500; s5.mala_settings.n_keep_draws = 1000;
+    s5.nuts_settings.n_burnin_draws = 300; s5.nuts_settings.n_keep_draws = 600; s5.nuts_settings.n_adapt_draws = 300;
+    iso_data_t dm;
+    mcmc::Mat_t dmala;
+    const bool okm = mcmc::mala(initial_val, log_target_dens, dmala, &dm, s5);
+    std::printf("callback mala ok=%d rows=%zu cols=%zu mean=%.6f %.6f %.6f acc=%.4f grad_calls=%d value_calls=%d\n",
+                int(okm), size_t(dmala.rows()), size_t(dmala.cols()), okm ? col_mean(dmala, 0) : 0.0, okm ? col_mean(dmala, 1) : 0.0,
+                okm ? col_mean(dmala, 2) : 0.0, double(s5.mala_settings.n_accept_draws) / 1000.0, dm.n_calls_grad, dm.n_calls_value);
+    iso_data_t dn;
+    mcmc::Mat_t dnuts;
+    const bool okn = mcmc::nuts(initial_val, log_target_dens, dnuts, &dn, s5);
+    std::printf("callback nuts ok=%d rows=%zu cols=%zu mean=%.6f %.6f %.6f acc=%.4f grad_calls=%d value_calls=%d\n",
+                int(okn), size_t(dnuts.rows()), size_t(dnuts.cols()), okn ? col_mean(dnuts, 0) : 0.0, okn ? col_mean(dnuts, 1) : 0.0,
+                okn ? col_mean(dnuts, 2) : 0.0, double(s5.nuts_settings.n_accept_draws) / 600.0, dn.n_calls_grad, dn.n_calls_value);
+
+    // what the device path does not implement is refused with a reason, never run on the CPU: mcmc::rwmh with a host callback
+    mcmc::Mat_t drw;
+    const bool refused = !mcmc::rwmh(initial_val, [](const mcmc::ColVec_t&, void*) { return 0.0; }, drw, nullptr, s5);
+    std::printf("rwmh with host callback refused=%d reason=\"%s\"\n", int(refused), mcmc::mi355x::last_error().c_str());
+    return (ok && ok2 && okm && okn && refused) ? 0 : 1;
 }

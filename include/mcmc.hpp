@@ -244,6 +244,9 @@ struct target_t
     std::string last_error;      // out: mi_mcmc_last_error() when a sampler returns false
 };
 
+// why the last sampler call of this thread returned false when it had no target_t to report into (host-callback routes)
+inline std::string& last_error() { thread_local std::string e; return e; }
+
 inline target_t gaussian_iso(size_t d)
 {
     target_t t; t.desc.struct_size = sizeof(mi_target); t.desc.kind = MI_TARGET_GAUSS_ISO; t.desc.d = d; return t;
@@ -384,6 +387,7 @@ hmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t&
         draws_out.resize(m.n_keep_draws, d);
         uint64_t nacc = 0;
         ok = mi_mcmc_hmc_run_callback(initial_vals.data(), d, &callback_trampoline, &ctx, &m, draws_out.data(), &nacc) == MI_OK;
+        if (!ok) mi355x::last_error() = mi_mcmc_last_error();
         n_accept = size_t(nacc);
     }
     if (ok && settings_inp) settings_inp->hmc_settings.n_accept_draws = n_accept;     // src/hmc.cpp:220-222
@@ -396,7 +400,21 @@ mala_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t
 {
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
-    if (!mi355x::is_device_route(target_log_kernel)) return false;   // host callbacks: hmc only (no CPU fallback)
+    if (!mi355x::is_device_route(target_log_kernel)) {                // host std::function: one chain, callback on the host
+        const size_t d = size_t(initial_vals.size());
+        mi_settings m = flatten_common(settings);
+        m.n_burnin_draws = settings.mala_settings.n_burnin_draws;
+        m.n_keep_draws = settings.mala_settings.n_keep_draws;
+        m.step_size = settings.mala_settings.step_size;
+        m.precond_mat = precond_or_null(settings.mala_settings.precond_mat, d);
+        callback_ctx ctx{&target_log_kernel, target_data, d};
+        draws_out.resize(m.n_keep_draws, d);
+        uint64_t nacc = 0;
+        const bool okc = mi_mcmc_mala_run_callback(initial_vals.data(), d, &callback_trampoline, &ctx, &m, draws_out.data(), &nacc) == MI_OK;
+        if (!okc) mi355x::last_error() = mi_mcmc_last_error();
+        if (okc && settings_inp) settings_inp->mala_settings.n_accept_draws = size_t(nacc);
+        return okc;
+    }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);
     m.n_burnin_draws = settings.mala_settings.n_burnin_draws;
@@ -414,7 +432,22 @@ nuts_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t
 {
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
-    if (!mi355x::is_device_route(target_log_kernel)) return false;
+    if (!mi355x::is_device_route(target_log_kernel)) {                // host std::function: one chain, callback on the host
+        const size_t d = size_t(initial_vals.size());
+        mi_settings m = flatten_common(settings);
+        const nuts_settings_t& n = settings.nuts_settings;
+        m.n_burnin_draws = n.n_burnin_draws; m.n_keep_draws = n.n_keep_draws; m.n_adapt_draws = n.n_adapt_draws;
+        m.target_accept_rate = n.target_accept_rate; m.max_tree_depth = n.max_tree_depth; m.step_size = n.step_size;
+        m.gamma_val = n.gamma_val; m.t0_val = n.t0_val; m.kappa_val = n.kappa_val;
+        m.precond_mat = precond_or_null(n.precond_mat, d);
+        callback_ctx ctx{&target_log_kernel, target_data, d};
+        draws_out.resize(m.n_keep_draws, d);
+        uint64_t nacc = 0;
+        const bool okc = mi_mcmc_nuts_run_callback(initial_vals.data(), d, &callback_trampoline, &ctx, &m, draws_out.data(), &nacc, nullptr) == MI_OK;
+        if (!okc) mi355x::last_error() = mi_mcmc_last_error();
+        if (okc && settings_inp) settings_inp->nuts_settings.n_accept_draws = size_t(nacc);
+        return okc;
+    }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);
     const nuts_settings_t& n = settings.nuts_settings;
@@ -440,7 +473,11 @@ rwmh_impl(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals
     // ref: src/rwmh.cpp:30-175.  par_scale and cov_mat travel in the POD mirror's step_size / precond_mat (mi_mcmc.h)
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
-    if (!mi355x::is_device_route(target_log_kernel)) return false;   // host callbacks: hmc only (no CPU fallback)
+    if (!mi355x::is_device_route(target_log_kernel)) {
+        mi355x::last_error() = "mcmc::rwmh: a host std::function target is not implemented on the device path (hmc, mala and nuts are); "
+                               "pass mcmc::mi355x::device_value_kernel with a mi355x::target_t (no CPU fallback)";
+        return false;
+    }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);
     m.n_burnin_draws = settings.rwmh_settings.n_burnin_draws;
@@ -460,7 +497,11 @@ rmhmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tens
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
     (void)tensor_data;
-    if (!mi355x::is_device_route(target_log_kernel) || !mi355x::is_device_route(tensor_fn)) return false;   // no CPU fallback
+    if (!mi355x::is_device_route(target_log_kernel) || !mi355x::is_device_route(tensor_fn)) {
+        mi355x::last_error() = "mcmc::rmhmc: host std::function target / tensor callbacks are not implemented on the device path; pass "
+                               "mcmc::mi355x::device_kernel and device_tensor with a mi355x::target_t (no CPU fallback)";
+        return false;
+    }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);
     m.n_burnin_draws = settings.rmhmc_settings.n_burnin_draws;

@@ -170,6 +170,18 @@ int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kern
                              void* target_data, const mi_settings* settings, double* draws_out,
                              uint64_t* n_accept_draws);
 
+/* The same for mcmc::mala (mala.hpp:66-73: 3 gradient + 1 value callback per draw, src/mala.cpp:149-186 with
+ * include/mcmc/mala.ipp:58-64) and mcmc::nuts (nuts.hpp:65-72: two gradient callbacks per leaf of the recursive
+ * nuts_build_tree, one value callback per leaf and per accepted proposal; dual averaging; step_size_out = final step size,
+ * may be NULL).  One chain (global chain id 0), identity precond_mat, unbounded; bit-identical to the device kernels run
+ * on the same target. */
+int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
+                              void* target_data, const mi_settings* settings, double* draws_out,
+                              uint64_t* n_accept_draws);
+int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
+                              void* target_data, const mi_settings* settings, double* draws_out,
+                              uint64_t* n_accept_draws, double* step_size_out);
+
 /* Layout converters between the engine's [n_keep][d][C] slabs and the reference's per-chain
  * draws_out (n_keep x d, column-major as Eigen stores it: element (i,j) at i + j*n_keep;
  * src/hmc.cpp:138,197). Host memory. */

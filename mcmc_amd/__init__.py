@@ -60,7 +60,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -231,8 +231,8 @@ def rmhmc(kind, init, settings, **kw):
 LOG_KERNEL_CB = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
 
 
-def hmc_callback(initial_vals, callback, settings, target_data=None):
-    """mcmc::hmc with a host callback for one chain (mi_mcmc_hmc_run_callback).
+def hmc_callback(initial_vals, callback, settings, target_data=None, algo="hmc"):
+    """mcmc::hmc / mala / nuts with a host callback for one chain (mi_mcmc_<algo>_run_callback).
 
     callback: either a ctypes function pointer with the mi_log_kernel_cb signature or a Python
     callable f(vals: np.ndarray, want_grad: bool) -> (value, grad or None)."""
@@ -251,10 +251,21 @@ def hmc_callback(initial_vals, callback, settings, target_data=None):
         cb = LOG_KERNEL_CB(_tramp)
     else:
         cb = callback
-    fn = lib().mi_mcmc_hmc_run_callback
-    _check(fn(C.c_void_p(x0.ctypes.data), C.c_uint64(d), C.cast(cb, C.c_void_p), C.c_void_p(target_data or 0),
-              C.byref(settings), C.c_void_p(draws.ctypes.data), C.byref(n_acc)))
+    fn = getattr(lib(), f"mi_mcmc_{algo}_run_callback")
+    args = [C.c_void_p(x0.ctypes.data), C.c_uint64(d), C.cast(cb, C.c_void_p), C.c_void_p(target_data or 0),
+            C.byref(settings), C.c_void_p(draws.ctypes.data), C.byref(n_acc)]
+    if algo == "nuts":
+        args.append(C.c_void_p(0))
+    _check(fn(*args))
     return draws, int(n_acc.value)
+
+
+def mala_callback(initial_vals, callback, settings, target_data=None):
+    return hmc_callback(initial_vals, callback, settings, target_data, algo="mala")
+
+
+def nuts_callback(initial_vals, callback, settings, target_data=None):
+    return hmc_callback(initial_vals, callback, settings, target_data, algo="nuts")
 
 
 # ---------------------------------------------------------------- diagnostics (GPU tests)

@@ -80,4 +80,57 @@ __global__ void cb_accept(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t
     }
 }
 
+// ---- vector operations of the host-callback forms of mcmc::mala and mcmc::nuts (one chain, state resident in HBM): one wave,
+//      the element-wise expressions of the oracle operator for operator, dots in the canonical four-chain order (cb_dot4)
+
+// dst = a + (e * b) / 2          (mntm_update_fn: src/nuts.cpp:126; mala_mean_fn with e = eps^2: src/mala.cpp:123)
+__global__ void cb_add_half(uint32_t d, double e, const double* a, const double* b, double* dst)
+{
+    for (uint32_t i = threadIdx.x; i < d; i += blockDim.x) dst[i] = a[i] + (e * b[i]) / 2.0;
+}
+// dst = a + e * b                (leap_frog_fn drift: src/nuts.cpp:146; mala proposal: src/mala.cpp:159)
+__global__ void cb_add_scaled(uint32_t d, double e, const double* a, const double* b, double* dst)
+{
+    for (uint32_t i = threadIdx.x; i < d; i += blockDim.x) dst[i] = a[i] + e * b[i];
+}
+// dst[0..d) = N(0, I) of (chain, draw, stream)   (src/mala.cpp:150, src/nuts.cpp:166,200)
+__global__ void cb_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint32_t d, double* dst)
+{
+    const uint32_t nslots = 4 * ((d + 7) / 8);
+    for (uint32_t slot = threadIdx.x; slot < nslots; slot += blockDim.x) {
+        const uint32_t b = slot / 4, j = slot % 4, i0 = 8 * b + j, i1 = i0 + 4;
+        double z0, z1;
+        rng_normal_pair(seed, chain, draw, slot, stream, z0, z1);
+        if (i0 < d) dst[i0] = z0;
+        if (i1 < d) dst[i1] = z1;
+    }
+}
+// out[0] = uniform of (chain, draw, slot)   (src/mala.cpp:171; src/nuts.cpp:206,233,261; nuts.ipp:213)
+__global__ void cb_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out)
+{
+    if (threadIdx.x == 0) out[0] = rng_uniform(seed, chain, draw, slot);
+}
+// out[0] = x . y
+__global__ void cb_dot(uint32_t d, const double* x, const double* y, double* out)
+{
+    const double q = cb_dot4(x, y, d);
+    if (threadIdx.x == 0) out[0] = q;
+}
+// out[0] = (a - b) . p1, out[1] = (a - b) . p2     (U-turn tests: nuts.ipp:226-227, src/nuts.cpp:286-287); tmp: d values
+__global__ void cb_diff_dots(uint32_t d, const double* a, const double* b, const double* p1, const double* p2, double* tmp, double* out)
+{
+    for (uint32_t i = threadIdx.x; i < d; i += blockDim.x) tmp[i] = a[i] - b[i];
+    __syncthreads();
+    const double q1 = cb_dot4(tmp, p1, d), q2 = cb_dot4(tmp, p2, d);
+    if (threadIdx.x == 0) { out[0] = q1; out[1] = q2; }
+}
+// out[0] = (x - mu) . (rs * (x - mu))      (dmvnorm.hpp:37-39 with INV(eps^2 I) = diag(rs)); tmp: 2 d values
+__global__ void cb_quad_form(uint32_t d, double rs, const double* x, const double* mu, double* tmp, double* out)
+{
+    for (uint32_t i = threadIdx.x; i < d; i += blockDim.x) { const double c = x[i] - mu[i]; tmp[i] = c; tmp[d + i] = rs * c; }
+    __syncthreads();
+    const double q = cb_dot4(tmp, tmp + d, d);
+    if (threadIdx.x == 0) out[0] = q;
+}
+
 }  // namespace mi

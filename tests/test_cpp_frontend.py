@@ -9,6 +9,7 @@ import pytest
 
 import mcmc_amd
 import orc
+from mcmc_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -67,7 +68,15 @@ def test_example_runs_on_the_gpu(tmp_path):
     mm = re.search(r"device rmhmc ok=1 rows=200 cols=128 acc0=(\S+) mu0=(\S+) sigma0=(\S+)", out.stdout)
     assert mm, out.stdout
     assert 0.2 < float(mm.group(1)) <= 1.0 and 1.5 < float(mm.group(2)) < 3.2 and 1.5 < float(mm.group(3)) < 3.2
-    assert "refused=1" in out.stdout
+    assert "refused=1" in out.stdout and "not implemented on the device path" in out.stdout      # a reachable reason, no silent false
+    # mcmc::mala / mcmc::nuts with the host std::function (the reference's own example call pattern)
+    mm = re.search(r"callback mala ok=1 rows=1000 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+)", out.stdout)
+    assert mm, out.stdout
+    assert np.abs([float(mm.group(i)) for i in (1, 2, 3)]).max() < 0.25 and 0.3 < float(mm.group(4)) <= 1.0
+    assert int(mm.group(5)) == 3 * 1500 and int(mm.group(6)) == 1500 + 1             # 3 gradient + 1 value callback per draw
+    mm = re.search(r"callback nuts ok=1 rows=600 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+)", out.stdout)
+    assert mm, out.stdout
+    assert np.abs([float(mm.group(i)) for i in (1, 2, 3)]).max() < 0.25 and 0.3 < float(mm.group(4)) <= 1.0
 
 
 @pytest.mark.gpu
@@ -86,6 +95,39 @@ def test_host_callback_route_matches_oracle_and_fused_kernel_bitwise():
     assert tgt.c.n_grad_calls == t2.c.n_grad_calls == 2 * 10 * 150
     assert tgt.c.n_value_calls == t2.c.n_value_calls == 151
     f_draws, f = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.ones((1, d)), st)
+    assert np.array_equal(f_draws[:, :, 0], o_draws)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,d", [("iso", 3), ("dense", 9), ("diag", 17)])
+def test_mala_and_nuts_host_callback_routes_match_oracle_and_device_kernels_bitwise(kind, d):
+    """mcmc::mala / mcmc::nuts with a host callback (ref: mala.hpp:66-73, nuts.hpp:65-72): the oracle's own target function is
+    the callback; draws, accept counts and the callback pattern of the reference (mala: 3 gradient + 1 value per draw) agree
+    with the oracle and with the fused device kernels."""
+    prec = {"iso": None, "dense": synth.dense_gaussian_precision(d, seed=3), "diag": synth.ill_conditioned_diag(d, 20.0)}[kind]
+    ko = {"iso": orc.TARGET_ISO, "dense": orc.TARGET_DENSE, "diag": orc.TARGET_DIAG}[kind]
+    kg = {"iso": mcmc_amd.TARGET_GAUSS_ISO, "dense": mcmc_amd.TARGET_GAUSS_DENSE, "diag": mcmc_amd.TARGET_GAUSS_DIAG}[kind]
+    x0 = np.linspace(-0.5, 0.8, d)
+    cb = C.cast(orc.lib().orc_target_kernel, C.c_void_p)
+    # mala
+    st = mcmc_amd.default_settings(rng_seed_value=99, n_burnin_draws=20, n_keep_draws=60, step_size=0.3)
+    tgt = orc.TargetSpec(ko, d, prec=prec, W=4)
+    draws_cb, nacc_cb = mcmc_amd.mala_callback(x0, cb, st, target_data=C.addressof(tgt.c))
+    t2 = orc.TargetSpec(ko, d, prec=prec, W=4)
+    o_draws, o = orc.run_chain(orc.ALGO_MALA, t2, x0, orc.make_settings(seed=99, n_burnin=20, n_keep=60, step=0.3, W=4, hoist=0))
+    assert np.array_equal(np.asarray(draws_cb), o_draws) and nacc_cb == o["n_accept"] and 0 < nacc_cb
+    assert tgt.c.n_grad_calls == t2.c.n_grad_calls == 3 * 80 and tgt.c.n_value_calls == t2.c.n_value_calls == 81
+    f_draws, f = mcmc_amd.mala(kg, x0[None, :], st, prec=prec)
+    assert np.array_equal(f_draws[:, :, 0], o_draws)
+    # nuts, dual averaging on
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=15, n_keep_draws=25, n_adapt_draws=15, max_tree_depth=6)
+    tgt = orc.TargetSpec(ko, d, prec=prec, W=4)
+    draws_cb, nacc_cb = mcmc_amd.nuts_callback(x0, cb, st, target_data=C.addressof(tgt.c))
+    t2 = orc.TargetSpec(ko, d, prec=prec, W=4)
+    o_draws, o = orc.run_chain(orc.ALGO_NUTS, t2, x0, orc.make_settings(seed=7, n_burnin=15, n_keep=25, n_adapt=15, max_depth=6, step=1.0, W=4))
+    assert np.array_equal(np.asarray(draws_cb), o_draws) and nacc_cb == o["n_accept"]
+    assert tgt.c.n_grad_calls == t2.c.n_grad_calls and tgt.c.n_value_calls == t2.c.n_value_calls
+    f_draws, f = mcmc_amd.nuts(kg, x0[None, :], st, prec=prec)
     assert np.array_equal(f_draws[:, :, 0], o_draws)
 
 
