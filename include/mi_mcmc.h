@@ -52,7 +52,8 @@ typedef enum mi_target_kind {
     MI_TARGET_GAUSS_ISO = 1,    /* log K = -1/2 |theta|^2 */
     MI_TARGET_GAUSS_DIAG = 2,   /* log K = -1/2 sum_i prec_i theta_i^2;       prec: d values */
     MI_TARGET_GAUSS_DENSE = 3,  /* log K = -1/2 theta^T P theta;              prec: d*d, symmetric, row-major */
-    MI_TARGET_LOGISTIC = 4,     /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta */
+    MI_TARGET_LOGISTIC = 4,     /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta.  hmc / mala / rwmh: d <= 512
+                                 * (LDS-staged MFMA kernel); nuts, vals_bound, precond_mat / cov_mat: d <= 8 (one chain per lane, same bits) */
     MI_TARGET_NORMAL_MODEL = 5  /* d = 2, vals = (mu, sigma), observations x_1..x_n in y[0..n_rows): the model of the reference's
                                  * example programs (/root/reference/examples/eigen/rmhmc_normal.cpp:44-106),
                                  * log K = -n (log(2 pi)/2 + log sigma) - sum_r (x_r - mu)^2 / (2 sigma^2); its metric tensor for
@@ -139,6 +140,15 @@ const char* mi_mcmc_last_error(void);
 int         mi_mcmc_version(void);
 int         mi_mcmc_device_count(void);
 
+/* User-defined device targets (the reference's callback contract, hmc.hpp:42-48, as a compile-time __device__ functor; see
+ * include/mi_mcmc_target.hpp): the generic host driver of the one-chain-per-lane engine.  A target library built with
+ * MI_MCMC_DEFINE_TARGET calls this with its own `launch` function, which instantiates the kernels for its target type;
+ * this validates, stages the chains (host or device memory) and packs the launch parameters.  algo: 0 hmc, 1 mala, 2 nuts,
+ * 3 rwmh, 4 rmhmc; d <= 8; target_pod is handed through to `launch`. */
+typedef int (*mi_small_launch_fn)(int algo, const void* small_params, const void* target_pod, void* stream);
+int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
+                            const mi_settings* settings, mi_chains* chains, void* stream);
+
 /* Kernel workspaces are cached per (device, stream) and reused by later calls on that stream (NUTS at BASELINE configs[3]
  * holds 4 GiB).  This frees the cache of the CURRENT device for `stream` (all_streams != 0: for every stream, e.g. before
  * destroying streams); it synchronises first.  bytes_freed may be NULL.  Safe to call concurrently with runs. */
@@ -194,7 +204,9 @@ int mi_mcmc_draws_to_chain_major(const double* draws_kdc, uint64_t n_keep, uint6
  *   acov [n_keep][d]  autocovariance at lag k, pooled over chains, unbiased per lag (divided by n_keep - k)
  *   rhat [d]          Gelman-Rubin potential scale reduction over the C chains
  *   ess  [d]          per-chain effective sample size (Geyer's initial positive sequence on acov); the many-chain ESS is
- *                     C times it.  n_keep <= 160.  Blocking. */
+ *                     C times it.
+ * Every lag is computed for n_keep <= 160; for longer series (the reference's default is 1 000 kept draws) lags 0..127 are, the
+ * acov rows beyond hold NaN and Geyer's sum runs over the computed lags.  Blocking. */
 int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
                        double* mean, double* acov, double* rhat, double* ess, void* stream);
 

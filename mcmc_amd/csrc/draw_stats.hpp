@@ -6,7 +6,10 @@
 // One wave per (dimension j, chain group g): for 64 chains at a time the centred series v[t] = x[t][j][c] - mean_j sit in
 // LDS as [t][lane] (conflict-free columns), every lane forms its own lagged products s_k = sum_t v[t] v[t+k] for all lags and
 // adds them to per-lag LDS accumulators; at the end the 64 lanes of each lag are summed with a fixed butterfly.  The host
-// adds the G partials in order: the result does not depend on scheduling.  n_keep <= 160 (two [n][64] fp64 arrays in LDS).
+// adds the G partials in order: the result does not depend on scheduling.  Up to 160 kept draws the whole series and all lags
+// sit in LDS (two [n][64] fp64 arrays); longer series (the reference's default is 1 000 kept draws) are streamed through LDS in
+// time tiles with a halo, and the autocovariance is computed up to lag STATS_TILED_LAGS - 1 (Geyer's sum stops at the first
+// non-positive pair, long before that for any usable chain).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,7 +17,9 @@
 
 namespace mi {
 
-constexpr int STATS_MAX_N = 160;
+constexpr int STATS_MAX_N = 160;          // series length up to which every lag is computed
+constexpr int STATS_TILED_LAGS = 128;     // lags computed for longer series
+constexpr int STATS_TILE_T = 64;          // time steps per tile of the streamed variant: (TILE_T + 2 LAGS) x 64 doubles = 160 KB
 
 // partial sums of x over (t, chains of group g) per dimension: out[g][j]
 __global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict__ draws, uint32_t n, uint32_t d, uint64_t C,
@@ -67,6 +72,51 @@ __global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict
         double s = acc[(size_t)k * 64 + lane];
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
         if (lane == 0) out[((size_t)g * d + j) * n + k] = s;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
+    if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+}
+
+// The same for n > STATS_MAX_N: lags 0 .. STATS_TILED_LAGS - 1, the series streamed through LDS in tiles of STATS_TILE_T steps plus a
+// halo of STATS_TILED_LAGS.  out[g][j][0..STATS_TILED_LAGS), out2 as above.
+__global__ __launch_bounds__(64) void stats_acov_tiled_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
+                                                              uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                              double* __restrict__ out, double* __restrict__ out2)
+{
+    constexpr uint32_t L = STATS_TILED_LAGS, T = STATS_TILE_T;
+    extern __shared__ double lds[];
+    double* v = lds;                             // [T + L][64]
+    double* acc = lds + (size_t)(T + L) * 64;    // [L][64]
+    const uint32_t j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const uint64_t per = (C + G - 1) / G;
+    const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
+    const double mj = mean[j];
+    for (uint32_t k = 0; k < L; ++k) acc[(size_t)k * 64 + lane] = 0.0;
+    double sm = 0.0, sm2 = 0.0, sv = 0.0;
+    for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
+        const uint64_t c = c0 + lane;
+        const bool on = c < c_hi;
+        double s1 = 0.0;
+        for (uint32_t t = 0; t < n; ++t) s1 += on ? draws[((size_t)t * d + j) * C + c] - mj : 0.0;
+        const double mc = s1 / (double)n;
+        double ss = 0.0;
+        for (uint32_t t0 = 0; t0 < n; t0 += T) {
+            const uint32_t rows = (n - t0 < T + L) ? n - t0 : T + L;       // tile + halo
+            const uint32_t own = (n - t0 < T) ? n - t0 : T;
+            for (uint32_t r = 0; r < rows; ++r) v[(size_t)r * 64 + lane] = on ? draws[((size_t)(t0 + r) * d + j) * C + c] - mj : 0.0;
+            for (uint32_t r = 0; r < own; ++r) { const double e = v[(size_t)r * 64 + lane] - mc; ss = __builtin_fma(e, e, ss); }
+            for (uint32_t k = 0; k < L; ++k) {
+                double s_ = 0.0;
+                for (uint32_t r = 0; r < own && r + k < rows; ++r) s_ = __builtin_fma(v[(size_t)r * 64 + lane], v[(size_t)(r + k) * 64 + lane], s_);
+                acc[(size_t)k * 64 + lane] += s_;
+            }
+        }
+        if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? ss / (double)(n - 1) : 0.0; }
+    }
+    for (uint32_t k = 0; k < L; ++k) {
+        double s_ = acc[(size_t)k * 64 + lane];
+        for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m);
+        if (lane == 0) out[((size_t)g * d + j) * L + k] = s_;
     }
     for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
     if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }

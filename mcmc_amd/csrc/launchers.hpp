@@ -29,4 +29,7 @@ int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c,
 // one lane per chain, d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp); algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc
 int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st);
 
+// the same engine on LogisticSmallModel<d> (small_targets.hpp), d = 1..8; algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh
+int launch_small_logistic(int algo, int d, const SmallParams& prm, const double* X_dev, const double* y_dev, uint32_t n_rows, hipStream_t st);
+
 }  // namespace mi

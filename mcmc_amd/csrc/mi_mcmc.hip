@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -393,8 +394,6 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
 {
     int rc;
     const uint64_t d = target->d;
-    if (settings->vals_bound || settings->precond_mat)
-        return fail(MI_ERR_UNSUPPORTED, "%s: vals_bound / precond_mat / cov_mat with the logistic target are not implemented", who);
     if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
     if (d > 512) return fail(MI_ERR_UNSUPPORTED, "%s: logistic target with d = %llu > 512 not implemented", who, (unsigned long long)d);
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
@@ -430,24 +429,18 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     return MI_OK;
 }
 
-// The one-lane-per-chain engine for the d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh and rmhmc with
-// any precond_mat / cov_mat and any bounds, and nuts.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.
-int run_small_normal_model(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+// The one-lane-per-chain engine (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh with any precond_mat / cov_mat and any
+// bounds, nuts, rmhmc, for a target policy of dimension d <= SMALL_MAX_D.  Validates, stages the chains, packs the launch
+// parameters; `launch` instantiates the kernels for its target type (the built-in policies below, or a user's library through
+// mi_mcmc_run_user_target).  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.
+int run_small(const char* who, int algo, uint64_t d, const mi_settings* settings, mi_chains* chains, hipStream_t st,
+              const std::function<int(const mi::SmallParams&, hipStream_t)>& launch)
 {
-    const uint64_t d = target->d;
-    if (d != 2) return fail(MI_ERR_BAD_ARG, "%s: NORMAL_MODEL has d = 2 (mu, sigma)", who);
-    if (!target->y || target->n_rows == 0 || target->n_rows > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "NORMAL_MODEL needs its observations in y[0..n_rows)");
+    if (d == 0 || d > (uint64_t)mi::SMALL_MAX_D) return fail(MI_ERR_UNSUPPORTED, "%s: the one-lane-per-chain engine takes 1 <= d <= %d", who, (int)mi::SMALL_MAX_D);
     if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
         return fail(MI_ERR_BAD_ARG, "%s: vals_bound needs lower_bounds and upper_bounds", who);
-
-    DevBuf x_owned;
-    const double* x_dev = target->y;
-    if (target->mem == MI_MEM_HOST) {
-        HIP_TRY(x_owned.alloc(target->n_rows * sizeof(double)));
-        HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
-        x_dev = x_owned.as<double>();
-    }
     const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (algo == 2) {
         if (settings->max_tree_depth > (uint64_t)mi::NUTS_SMALL_MAX_DEPTH)
             return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented for this target", (int)mi::NUTS_SMALL_MAX_DEPTH);
@@ -462,7 +455,7 @@ int run_small_normal_model(const char* who, int algo, const mi_target* target, c
     if (rc) return rc;
 
     mi::SmallParams prm{};
-    prm.data = x_dev; prm.n_rows = (uint32_t)target->n_rows; prm.d = (uint32_t)d;
+    prm.d = (uint32_t)d;
     prm.C = chains->n_chains; prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta; prm.draws = sc.dev.draws; prm.n_accept = sc.dev.n_accept; prm.n_leap = sc.dev.n_leapfrogs;
     prm.seed = settings->rng_seed_value;
@@ -471,9 +464,9 @@ int run_small_normal_model(const char* who, int algo, const mi_target* target, c
     prm.draw0 = (uint32_t)chains->draw0;
     prm.eps = settings->step_size;
     prm.vals_bound = settings->vals_bound ? 1 : 0;
-    for (uint64_t i = 0; i < 4; ++i) {
+    for (int i = 0; i < mi::SMALL_MAX_D; ++i) {
         prm.btype[i] = 1; prm.lb[i] = 0.0; prm.ub[i] = 0.0;
-        for (uint64_t k = 0; k < 4; ++k) prm.M[i][k] = (i == k) ? 1.0 : 0.0;
+        for (int k = 0; k < mi::SMALL_MAX_D; ++k) prm.M[i][k] = (i == k) ? 1.0 : 0.0;
     }
     if (settings->precond_mat && algo != 4)          // hmc.cpp:57, mala.cpp:57, rwmh.cpp:58 (rmhmc has none)
         for (uint64_t i = 0; i < d; ++i)
@@ -491,11 +484,58 @@ int run_small_normal_model(const char* who, int algo, const mi_target* target, c
         prm.delta = settings->target_accept_rate; prm.gamma = settings->gamma_val; prm.t0 = settings->t0_val; prm.kappa = settings->kappa_val;
         prm.step_out = sc.dev.step_size; prm.depth_trace = sc.dev.nuts_depth;
     }
-    rc = launched(who, mi::launch_small_normal_model(algo, prm, st));
+    rc = launched(who, launch(prm, st));
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (x_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// the d = 2 normal model of the reference's example programs (MI_TARGET_NORMAL_MODEL)
+int run_small_normal_model(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    if (target->d != 2) return fail(MI_ERR_BAD_ARG, "%s: NORMAL_MODEL has d = 2 (mu, sigma)", who);
+    if (!target->y || target->n_rows == 0 || target->n_rows > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "NORMAL_MODEL needs its observations in y[0..n_rows)");
+    DevBuf x_owned;
+    const double* x_dev = target->y;
+    if (target->mem == MI_MEM_HOST) {
+        HIP_TRY(x_owned.alloc(target->n_rows * sizeof(double)));
+        HIP_TRY(hipMemcpy(x_owned.p, target->y, target->n_rows * sizeof(double), hipMemcpyHostToDevice));
+        x_dev = x_owned.as<double>();
+    }
+    const uint32_t n_rows = (uint32_t)target->n_rows;
+    const int rc = run_small(who, algo, 2, settings, chains, st, [&](const mi::SmallParams& p, hipStream_t s_) {
+        mi::SmallParams q = p; q.data = x_dev; q.n_rows = n_rows;
+        return mi::launch_small_normal_model(algo, q, s_);
+    });
+    if (rc) return rc;
+    if (x_owned.p) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// Logistic regression with d <= SMALL_MAX_D coefficients on the one-lane-per-chain engine (small_targets.hpp: the bits of
+// logit_lds_kernel): what the LDS kernel does not implement -- nuts, vals_bound, precond_mat / cov_mat
+int run_small_logistic(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    const uint64_t d = target->d, n = target->n_rows;
+    if (!target->X || !target->y || n == 0 || n > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+    if (d > (uint64_t)mi::SMALL_MAX_D)
+        return fail(MI_ERR_UNSUPPORTED, "%s: nuts / vals_bound / precond_mat / cov_mat on the logistic target are implemented for d <= %d "
+                                        "(one chain per lane); d = %llu", who, (int)mi::SMALL_MAX_D, (unsigned long long)d);
+    DevBuf Xo, yo;
+    const double *X_dev = target->X, *y_dev = target->y;
+    if (target->mem == MI_MEM_HOST) {
+        HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
+        HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
+        X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+    }
+    const int rc = run_small(who, algo, d, settings, chains, st, [&](const mi::SmallParams& p, hipStream_t s_) {
+        return mi::launch_small_logistic(algo, (int)d, p, X_dev, y_dev, (uint32_t)n, s_);
+    });
+    if (rc) return rc;
+    if (Xo.p) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -531,6 +571,25 @@ int mi_mcmc_device_count(void)
     return n;
 }
 
+int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
+                            const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    if (!launch || !settings || !chains) return fail(MI_ERR_BAD_ARG, "null launch / settings / chains");
+    if (algo < 0 || algo > 4) return fail(MI_ERR_BAD_ARG, "algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc");
+    if (small_params_bytes != sizeof(mi::SmallParams))
+        return fail(MI_ERR_BAD_ARG, "the target library was built against another version of the engine headers (SmallParams %llu vs %llu bytes)",
+                    (unsigned long long)small_params_bytes, (unsigned long long)sizeof(mi::SmallParams));
+    if (settings->struct_size != sizeof(mi_settings) || chains->struct_size != sizeof(mi_chains))
+        return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
+    if (chains->n_chains == 0 || !chains->theta) return fail(MI_ERR_BAD_ARG, "chains.theta and n_chains are required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    static const char* const names[5] = {"hmc", "mala", "nuts", "rwmh", "rmhmc"};
+    return run_small(names[algo], algo, d, settings, chains, static_cast<hipStream_t>(stream), [&](const mi::SmallParams& p, hipStream_t s_) {
+        return launch(algo, &p, target_pod, s_);
+    });
+}
+
 int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed)
 {
     return ws_release(static_cast<hipStream_t>(stream), all_streams != 0, bytes_freed);
@@ -543,7 +602,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC) return run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC)        // plain: the LDS-staged MFMA kernel (any d <= 512); bounds / precond_mat: one chain per lane (d <= 8)
+        return (settings->vals_bound || settings->precond_mat) ? run_small_logistic("hmc", 0, target, settings, chains, st)
+                                                               : run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
     // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
@@ -745,7 +806,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("mala", 1, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat))
-        return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound / precond_mat with the logistic target are not implemented");
+        return run_small_logistic("mala", 1, target, settings, chains, st);
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
     const double s2_ = settings->step_size * settings->step_size;
@@ -877,7 +938,9 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC) return run_logit_plain("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC)
+        return (settings->vals_bound || settings->precond_mat) ? run_small_logistic("rwmh", 3, target, settings, chains, st)
+                                                               : run_logit_plain("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "rwmh: d = %llu > 128 not implemented", (unsigned long long)d);
@@ -940,6 +1003,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("nuts", 2, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC) return run_small_logistic("nuts", 2, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
     if (d > 128) return fail(MI_ERR_UNSUPPORTED, "nuts: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
@@ -1447,7 +1511,7 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
                        double* mean, double* acov, double* rhat, double* ess, void* stream)
 {
     if (!draws_kdc || n_keep == 0 || d == 0 || n_chains == 0) return fail(MI_ERR_BAD_ARG, "draw_stats: empty input");
-    if (n_keep > (uint64_t)mi::STATS_MAX_N) return fail(MI_ERR_UNSUPPORTED, "draw_stats: n_keep > %d not implemented", mi::STATS_MAX_N);
+    if (n_keep > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw_stats: n_keep does not fit 32 bits");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = n_keep, C = n_chains;
     DevBuf staged;
@@ -1460,7 +1524,7 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
     const uint32_t G = (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);      // chain groups (partials are added in order on the host)
     DevBuf sum_dev, mean_dev, acov_dev, mom_dev;
     HIP_TRY(sum_dev.alloc((size_t)G * d * 8)); HIP_TRY(mean_dev.alloc(d * 8));
-    HIP_TRY(acov_dev.alloc((size_t)G * d * n * 8)); HIP_TRY(mom_dev.alloc((size_t)G * d * 3 * 8));
+    HIP_TRY(acov_dev.alloc((size_t)G * d * std::min<size_t>(n, (size_t)mi::STATS_MAX_N) * 8)); HIP_TRY(mom_dev.alloc((size_t)G * d * 3 * 8));
     hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, sum_dev.as<double>());
     std::vector<double> part((size_t)G * d), mean_h(d);
     HIP_TRY(hipMemcpyAsync(part.data(), sum_dev.p, part.size() * 8, hipMemcpyDeviceToHost, st));
@@ -1473,19 +1537,32 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
     if (mean) std::memcpy(mean, mean_h.data(), d * 8);
     if (!acov && !rhat && !ess) return MI_OK;
     HIP_TRY(hipMemcpyAsync(mean_dev.p, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
-    const size_t lds = 2 * n * 64 * sizeof(double);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                       (uint64_t)C, G, acov_dev.as<double>(), mom_dev.as<double>());
+    // every lag for series of up to STATS_MAX_N draws; beyond, lags below STATS_TILED_LAGS from the streamed kernel
+    const bool tiled = n > (size_t)mi::STATS_MAX_N;
+    const size_t nlag = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
+    DevBuf acov_t;
+    if (tiled) { HIP_TRY(acov_t.alloc((size_t)G * d * nlag * 8)); }
+    double* const acov_out = tiled ? acov_t.as<double>() : acov_dev.as<double>();
+    if (tiled) {
+        const size_t lds = (size_t)(mi::STATS_TILE_T + 2 * mi::STATS_TILED_LAGS) * 64 * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mi::stats_acov_tiled_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
+                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
+    } else {
+        const size_t lds = 2 * n * 64 * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
+                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
+    }
     HIP_TRY(hipGetLastError());
-    std::vector<double> ap((size_t)G * d * n), mp((size_t)G * d * 3), ac((size_t)n * d);
-    HIP_TRY(hipMemcpyAsync(ap.data(), acov_dev.p, ap.size() * 8, hipMemcpyDeviceToHost, st));
+    std::vector<double> ap((size_t)G * d * nlag), mp((size_t)G * d * 3), ac((size_t)n * d, std::nan(""));
+    HIP_TRY(hipMemcpyAsync(ap.data(), acov_out, ap.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t j = 0; j < d; ++j)
-        for (size_t k = 0; k < n; ++k) {
+        for (size_t k = 0; k < nlag; ++k) {
             double s = 0.0;
-            for (uint32_t g = 0; g < G; ++g) s += ap[((size_t)g * d + j) * n + k];
+            for (uint32_t g = 0; g < G; ++g) s += ap[((size_t)g * d + j) * nlag + k];
             ac[k * d + j] = s / (double)C / (double)(n - k);          // pooled over chains, unbiased per lag
         }
     if (acov) std::memcpy(acov, ac.data(), ac.size() * 8);
@@ -1506,7 +1583,7 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
             const double den = (a0 > 0.0) ? a0 : 1.0;
             double tau = -1.0;
             size_t t = 0;
-            while (t + 1 < n) {
+            while (t + 1 < nlag) {
                 const double pair = ac[t * d + j] / den + ac[(t + 1) * d + j] / den;
                 if (pair <= 0.0) break;
                 tau += 2.0 * pair;

@@ -4,7 +4,8 @@
 // SURVEY section 8 row f-4).  RM-HMC needs, per chain and per fixed-point iteration, a d x d inverse of a position-dependent
 // metric tensor and d products Ginv * dG_i: O(d^4) work on matrices that differ between chains, so nothing is shared across
 // a chain tile and there is no contraction for the matrix cores.  The kernel therefore keeps one chain per lane with the whole
-// state (position, momentum, three d x d matrices, two d x d x d derivative cubes) in registers, for compile-time D <= 4:
+// state (position, momentum, three d x d matrices, two d x d x d derivative cubes) in registers, for compile-time D (the cubes
+// make D <= 4 the practical range; the other samplers of small_samplers.hpp take D <= SMALL_MAX_D = 8):
 // the reference's own use of RM-HMC is the d = 2 normal model of examples/eigen/rmhmc_normal.cpp.  Bound: fp64 VALU (the
 // data sums of the target); HBM sees theta once per call and one slab per kept draw.
 //
@@ -20,8 +21,10 @@ namespace mi {
 
 constexpr double LOG_2PI = 1.83787706640934548356;   // /root/reference/include/stats/mcmc_stats.hpp:28-30
 
+constexpr int SMALL_MAX_D = 8;      // dimensions of a one-lane-per-chain target (Target::D <= SMALL_MAX_D; rmhmc: D <= 4 is practical)
+
 struct SmallParams {
-    const double* data;     // NORMAL_MODEL: the observations x_1..x_n (device)
+    const double* data;     // NORMAL_MODEL: the observations x_1..x_n (device); other targets carry their own data
     uint32_t n_rows;
     uint32_t d;
     uint64_t C, chain0;
@@ -33,9 +36,9 @@ struct SmallParams {
     uint32_t n_burnin, n_keep, n_leap_steps, n_fp_steps, draw0;
     double eps;
     int vals_bound;
-    int btype[4];
-    double lb[4], ub[4];
-    double M[4][4];         // hmc / mala / nuts: precond_mat; rwmh: cov_mat (identity when the settings carry none); unused by rmhmc
+    int btype[SMALL_MAX_D];
+    double lb[SMALL_MAX_D], ub[SMALL_MAX_D];
+    double M[SMALL_MAX_D][SMALL_MAX_D];   // hmc / mala / nuts: precond_mat; rwmh: cov_mat (identity when the settings carry none); unused by rmhmc
     // nuts (nuts_settings_t, mcmc_structs.hpp:82-101); eps carries epsilon_bar_0
     uint32_t n_adapt, max_depth;
     double delta, gamma, t0, kappa;

@@ -27,19 +27,35 @@ __device__ __forceinline__ void sm_matmul(const double (&A)[D][D], const double 
         }
 }
 
-template <int D>
+// BMO_MATOPS_DOT_PROD in the order the target's policy states (oracle: orc_dot): W = 1 one sequential fma chain; W = 4 four
+// strided chains q_j over i = j (mod 4), combined (q0 + q2) + (q1 + q3) -- the order of the MFMA-layout kernels, so that a
+// small-d run of this engine and of those kernels agree bit for bit (LogisticSmallModel)
+template <int D, int W = 1>
 __device__ __forceinline__ double sm_dot(const double (&x)[D], const double (&y)[D])
 {
-    double q = 0.0;
+    static_assert(W == 1 || W == 4, "reduction orders the oracle states");
+    if constexpr (W == 1) {
+        double q = 0.0;
 #pragma unroll
-    for (int i = 0; i < D; ++i) q = dfma(x[i], y[i], q);
-    return q;
+        for (int i = 0; i < D; ++i) q = dfma(x[i], y[i], q);
+        return q;
+    } else {
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < D; ++i) q[i & 3] = dfma(x[i], y[i], q[i & 3]);
+        return (q[0] + q[2]) + (q[1] + q[3]);
+    }
 }
+// reduction order of a target policy: Target::W when it declares one, else 1
+template <class T, class = void> struct small_reduce_width { static constexpr int value = 1; };
+template <class T> struct small_reduce_width<T, decltype((void)T::W)> { static constexpr int value = T::W; };
 
 // what every small sampler shares: the chain's lane, the box maps, the precond matrix and the draw bookkeeping
 template <class Target>
 struct SmallChain {
     static constexpr int D = Target::D;
+    static constexpr int W = small_reduce_width<Target>::value;
+    static_assert(D >= 1 && D <= SMALL_MAX_D, "Target::D out of range");
     const SmallParams& prm;
     const Target& tgt;
     const bool bounded;
@@ -97,8 +113,9 @@ struct SmallChain {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(i & 3), STREAM_NORMAL, z0, z1);
-            z[i] = (i >> 2) ? z1 : z0;
+            // dimension i = 8 b + 4 h + j takes component h of Philox slot 4 b + j (det_math.hpp)
+            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * (i / 8) + (i & 3)), STREAM_NORMAL, z0, z1);
+            z[i] = ((i >> 2) & 1) ? z1 : z0;
         }
     }
     __device__ __forceinline__ void precond(double (&M)[D][D]) const
@@ -115,6 +132,7 @@ template <class Target>
 __global__ __launch_bounds__(256) void hmc_small_kernel(const SmallParams prm, const Target tgt)
 {
     constexpr int D = Target::D;
+    [[maybe_unused]] constexpr int W = small_reduce_width<Target>::value;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= prm.C) return;
     const SmallChain<Target> ch(prm, tgt, c);
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(256) void hmc_small_kernel(const SmallParams prm, c
     auto kinetic = [&](const double (&p)[D]) -> double {
         double t[D];
         sm_gemv<D>(Minv, p, t);
-        return sm_dot<D>(p, t) / 2.0;
+        return sm_dot<D, W>(p, t) / 2.0;
     };
 
     double prev[D], cur[D];
@@ -192,6 +210,7 @@ template <class Target>
 __global__ __launch_bounds__(256) void mala_small_kernel(const SmallParams prm, const Target tgt)
 {
     constexpr int D = Target::D;
+    [[maybe_unused]] constexpr int W = small_reduce_width<Target>::value;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= prm.C) return;
     const SmallChain<Target> ch(prm, tgt, c);
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(256) void mala_small_kernel(const SmallParams prm, 
 #pragma unroll
         for (int i = 0; i < D; ++i) xc[i] = x[i] - mu[i];
         sm_gemv<D>(Sinv, xc, t);
-        return cons_term - 0.5 * (log_det + sm_dot<D>(xc, t));       // :41
+        return cons_term - 0.5 * (log_det + sm_dot<D, W>(xc, t));       // :41
     };
 
     double Sinv_h[D][D];                                             // unbounded: Sigma = eps^2 M never changes
@@ -313,6 +332,7 @@ template <class Target>
 __global__ __launch_bounds__(256) void rwmh_small_kernel(const SmallParams prm, const Target tgt)
 {
     constexpr int D = Target::D;
+    [[maybe_unused]] constexpr int W = small_reduce_width<Target>::value;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= prm.C) return;
     const SmallChain<Target> ch(prm, tgt, c);
@@ -380,6 +400,7 @@ template <class Target>
 __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, const Target tgt)
 {
     constexpr int D = Target::D;
+    [[maybe_unused]] constexpr int W = small_reduce_width<Target>::value;
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= prm.C) return;
     const SmallChain<Target> ch(prm, tgt, c);
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, c
     auto kinetic = [&](const double (&p)[D]) -> double {
         double t[D];
         sm_gemv<D>(Minv, p, t);
-        return sm_dot<D>(p, t) / 2.0;
+        return sm_dot<D, W>(p, t) / 2.0;
     };
     auto potential = [&](const double (&v)[D]) -> double {           // -box_log_kernel, non-finite -> +inf
         const double u = -ch.box_log_kernel(v);
@@ -425,8 +446,8 @@ __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, c
         double diff[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) diff[i] = pos[i] - neg[i];
-        const uint32_t c1 = sm_dot<D>(diff, mneg) >= 0.0 ? 1u : 0u;  // nuts.ipp:226 / nuts.cpp:286
-        const uint32_t c2 = sm_dot<D>(diff, mpos) >= 0.0 ? 1u : 0u;  // :227 / :287
+        const uint32_t c1 = sm_dot<D, W>(diff, mneg) >= 0.0 ? 1u : 0u;  // nuts.ipp:226 / nuts.cpp:286
+        const uint32_t c2 = sm_dot<D, W>(diff, mpos) >= 0.0 ? 1u : 0u;  // :227 / :287
         return c1 * c2;
     };
 

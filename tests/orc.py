@@ -89,9 +89,11 @@ def make_settings(seed=1, n_burnin=0, n_keep=10, n_leap=1, step=1.0, precond=Non
     return s
 
 
-def run_chain(algo, target, init, settings, traces=False):
-    """One chain through orc_hmc / orc_mala / orc_nuts. Returns (draws[n_keep,d], info dict)."""
-    d = target.d
+def run_chain(algo, target, init, settings, traces=False, kernel=None, data=None, d=None):
+    """One chain through orc_hmc / orc_mala / orc_nuts. Returns (draws[n_keep,d], info dict).
+    kernel / data: any callback with the reference's contract (a C function pointer + its void* target_data) instead of the
+    built-in targets -- what a user-defined target library exports (tests/test_user_target.py)."""
+    d = target.d if d is None else d
     init = _f64(init)
     n_keep = settings.n_keep_draws
     n_tot = settings.n_burnin_draws + n_keep
@@ -106,14 +108,15 @@ def run_chain(algo, target, init, settings, traces=False):
         st.depth_trace = dep.ctypes.data_as(C.POINTER(C.c_uint32))
         st.leap_trace = lea.ctypes.data_as(C.POINTER(C.c_uint32))
         st.eps_trace = _p(eps)
-    kern = C.cast(lib().orc_target_kernel, C.c_void_p)
+    kern = C.cast(lib().orc_target_kernel, C.c_void_p) if kernel is None else C.cast(kernel, C.c_void_p)
+    tdata = C.byref(target.c) if data is None else C.c_void_p(data)
     if algo == ALGO_RMHMC:
         tens = C.cast(lib().orc_target_tensor, C.c_void_p)
         rc = lib().orc_rmhmc(_p(init), C.c_size_t(d), kern, tens, C.byref(target.c), C.byref(target.c),
                              C.byref(settings), _p(draws), C.byref(st))
     else:
         fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts, lib().orc_rwmh][algo]
-        rc = fn(_p(init), C.c_size_t(d), kern, C.byref(target.c), C.byref(settings), _p(draws), C.byref(st))
+        rc = fn(_p(init), C.c_size_t(d), kern, tdata, C.byref(settings), _p(draws), C.byref(st))
     assert rc == 0
     info = dict(n_accept=st.n_accept_draws, n_leap=st.n_leapfrogs, eps=st.final_step_size,
                 accept=acc, depth=dep, leaps=lea, eps_trace=eps)

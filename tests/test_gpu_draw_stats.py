@@ -40,3 +40,21 @@ def test_draw_stats_of_a_real_run():
     s = mcmc_amd.draw_stats(draws)
     assert np.allclose(s["ess"], ess_per_chain(draws), rtol=1e-8)
     assert np.all(s["rhat"] < 1.05) and np.all(np.abs(s["mean"]) < 0.1)
+
+
+@pytest.mark.parametrize("n,d,C,phi", [(1000, 3, 200, 0.7), (161, 2, 130, 0.2), (517, 2, 64, 0.95)])
+def test_long_series_are_streamed_and_truncated_at_128_lags(n, d, C, phi):
+    """n_keep beyond 160 (the reference's default is 1 000 kept draws): lags 0..127 from the time-tiled kernel, NaN beyond;
+    mean, R-hat and Geyer's ESS (which stops at the first non-positive pair, long before lag 127 here) as defined in ess.py."""
+    x = _ar1(n, d, C, phi, seed=n)
+    s = mcmc_amd.draw_stats(x)
+    assert np.allclose(s["mean"], x.mean(axis=(0, 2)), rtol=1e-12, atol=1e-12)
+    xc = x - x.mean(axis=(0, 2), keepdims=True)
+    acov = np.stack([(xc[: n - k] * xc[k:]).sum(axis=0).mean(axis=1) / (n - k) for k in range(128)])
+    assert np.allclose(s["acov"][:128], acov, rtol=1e-10, atol=1e-12) and np.isnan(s["acov"][128:]).all()
+    m = x.mean(axis=0); W = x.var(axis=0, ddof=1).mean(axis=1); B_n = m.var(axis=1, ddof=1)
+    assert np.allclose(s["rhat"], np.sqrt(((n - 1) / n * W + B_n) / W), rtol=1e-10)
+    if phi < 0.9:
+        assert np.allclose(s["ess"], ess_per_chain(x), rtol=1e-8)
+    else:                                   # the sum may still be positive at lag 127: the device reports the truncated sum
+        assert np.all(s["ess"] >= ess_per_chain(x) * (1 - 1e-8)) and np.all(s["ess"] < n)
