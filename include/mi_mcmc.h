@@ -165,7 +165,9 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 
 /* mcmc::rmhmc (/root/reference/include/mcmc/rmhmc.hpp, src/rmhmc.cpp:30-287) for many chains.  The reference takes the metric
- * tensor as a second callback (tensor_fn); here it is the one tied to the target kind (see mi_target_kind).  Reads
+ * tensor as a second callback (tensor_fn); here it is the one tied to the target kind: NORMAL_MODEL (d = 2) its Fisher
+ * information; LOGISTIC with d <= 4 the Fisher information X^T diag(s(1-s)) X plus the prior precision I; a user-defined
+ * target (mi_mcmc_target.hpp) its own tensor().  Reads
  * n_leap_steps, step_size, n_fp_steps, vals_bound / bounds from the settings; there is no precond_mat in rmhmc. */
 int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 

@@ -1110,8 +1110,12 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
 {
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
+    if (target->kind == MI_TARGET_LOGISTIC) {           // Fisher information + prior precision (small_targets.hpp), d <= 4
+        if (target->d > 4) return fail(MI_ERR_UNSUPPORTED, "rmhmc: the logistic target's Fisher metric is implemented for d <= 4 (d x d x d derivative cubes per lane)");
+        return run_small_logistic("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
+    }
     if (target->kind != MI_TARGET_NORMAL_MODEL)
-        return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path", target->kind);
+        return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path (user targets: include/mi_mcmc_target.hpp)", target->kind);
     return run_small_normal_model("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
 }
 

@@ -1,5 +1,5 @@
 // small_logit_launch.hpp -- one translation unit per pair of dimensions of LogisticSmallModel (small_logit_d*.hip), so that the
-// 32 kernel instantiations (d = 1..8 x hmc / mala / nuts / rwmh) compile in parallel
+// kernel instantiations (d = 1..8 x hmc / mala / nuts / rwmh, d = 1..4 x rmhmc) compile in parallel
 #pragma once
 #include "small_samplers.hpp"
 #include "small_targets.hpp"
@@ -19,6 +19,9 @@ int launch_small_logistic_d(int algo, const SmallParams& prm, const double* X_de
     case 1: hipLaunchKernelGGL(mala_small_kernel<T>, grid, dim3(block), 0, st, prm, tgt); break;
     case 2: hipLaunchKernelGGL(nuts_small_kernel<T>, grid, dim3(block), 0, st, prm, tgt); break;
     case 3: hipLaunchKernelGGL(rwmh_small_kernel<T>, grid, dim3(block), 0, st, prm, tgt); break;
+    case 4:                 // mcmc::rmhmc with the Fisher metric: d x d x d derivative cubes per lane, d <= 4
+        if constexpr (D <= 4) { hipLaunchKernelGGL(rmhmc_small_kernel<T>, grid, dim3(block), 0, st, prm, tgt); break; }
+        else return (int)hipErrorInvalidValue;
     default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();

@@ -63,6 +63,45 @@ struct LogisticSmallModel {
         }
         return ll - 0.5 * ((b[0] + b[2]) + (b[1] + b[3]));
     }
+    // mcmc::rmhmc: the Fisher information plus the prior precision, G = X^T diag(lam) X + I, lam_r = s_r (1 - s_r), and
+    // dG/dbeta_i = X^T diag(lam_r (1 - 2 s_r) X_ri) X; rows ascending, one fma per row and entry (oracle: orc_target_tensor)
+    __device__ __forceinline__ void tensor(const double (&v)[D_], double (&G)[D_][D_], double (*dG)[D_][D_]) const
+    {
+        typedef const double __attribute__((address_space(4)))* cptr_t;
+        cptr_t Xc = (cptr_t)(uintptr_t)X;
+#pragma unroll
+        for (int r = 0; r < D_; ++r)
+#pragma unroll
+            for (int c = 0; c < D_; ++c) {
+                G[r][c] = 0.0;
+                if (dG) {
+#pragma unroll
+                    for (int i = 0; i < D_; ++i) dG[i][r][c] = 0.0;
+                }
+            }
+        for (uint32_t k = 0; k < n; ++k) {
+            double x[D_];
+            double eta = 0.0;
+#pragma unroll
+            for (int j = 0; j < D_; ++j) { x[j] = Xc[(size_t)k * D_ + j]; eta = dfma(x[j], v[j], eta); }
+            const double sg = sigmoid(eta);
+            const double lam = sg * (1.0 - sg);
+            const double dl = lam * (1.0 - 2.0 * sg);
+#pragma unroll
+            for (int r = 0; r < D_; ++r)
+#pragma unroll
+                for (int c = 0; c < D_; ++c) {
+                    const double xx = x[r] * x[c];
+                    G[r][c] = dfma(xx, lam, G[r][c]);
+                    if (dG) {
+#pragma unroll
+                        for (int i = 0; i < D_; ++i) dG[i][r][c] = dfma(xx, dl * x[i], dG[i][r][c]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < D_; ++r) G[r][r] = G[r][r] + 1.0;
+    }
 };
 
 }  // namespace mi

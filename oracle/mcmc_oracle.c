@@ -426,6 +426,27 @@ void orc_target_tensor(const double* th, double* G, double* dG, void* data)
         if (dG) for (size_t i = 0; i < 4; ++i) dG[4 + i] = (-2.0 * G[i]) / sigma;    /* mat(1) = -2 G / sigma; mat(0) = 0 */
         break;
     }
+    case ORC_TARGET_LOGISTIC: {
+        /* Fisher information of the Bayesian logistic regression plus the prior precision (the metric of Girolami & Calderhead's
+         * RM-HMC logistic example; ours -- the reference ships no tensor for it):  G = X^T diag(lam) X + I,  lam_k = s_k (1 - s_k),
+         * s_k = sigmoid(eta_k);  dG/dbeta_i = X^T diag(lam_k (1 - 2 s_k) X_ki) X.  Rows k ascending, one fma per row and entry. */
+        for (size_t k = 0; k < t->n_rows; ++k) {
+            const double* x = t->X + k * d;
+            double eta = 0.0;
+            for (size_t j = 0; j < d; ++j) eta = fma(x[j], th[j], eta);
+            const double sg = orc_sigmoid(eta);
+            const double lam = sg * (1.0 - sg);
+            const double dl = lam * (1.0 - 2.0 * sg);
+            for (size_t r = 0; r < d; ++r)
+                for (size_t c = 0; c < d; ++c) {
+                    const double xx = x[r] * x[c];
+                    G[r * d + c] = fma(xx, lam, G[r * d + c]);
+                    if (dG) for (size_t i = 0; i < d; ++i) dG[i * d * d + r * d + c] = fma(xx, dl * x[i], dG[i * d * d + r * d + c]);
+                }
+        }
+        for (size_t r = 0; r < d; ++r) G[r * d + r] = G[r * d + r] + 1.0;
+        break;
+    }
     default: for (size_t i = 0; i < d * d; ++i) G[i] = NAN;
     }
 }

@@ -73,7 +73,8 @@ double orc_target_kernel(const double* vals, double* grad_out, void* data);
  * writes the d x d tensor (row-major) and, when deriv_out is not NULL, the d matrices dG/dvals_i (deriv_out + i*d*d). */
 typedef void (*orc_tensor_fn)(const double* vals, double* tensor_out, double* deriv_out, void* data);
 /* built-in tensors (data points to orc_target): NORMAL_MODEL: the Fisher information diag(n/sigma^2, 2n/sigma^2) and its
- * derivative (ref: examples/eigen/rmhmc_normal.cpp:75-106); GAUSS_*: the constant precision, zero derivative. */
+ * derivative (ref: examples/eigen/rmhmc_normal.cpp:75-106); GAUSS_*: the constant precision, zero derivative; LOGISTIC: the
+ * Fisher information X^T diag(s (1 - s)) X plus the prior precision I, and its derivative (ours: the reference has none). */
 void orc_target_tensor(const double* vals, double* tensor_out, double* deriv_out, void* data);
 
 /* POD mirror of algo_settings_t (mcmc_structs.hpp:151-184) restricted to the

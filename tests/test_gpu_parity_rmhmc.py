@@ -75,3 +75,36 @@ def test_rmhmc_rejects_what_it_does_not_implement():
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
         mcmc_amd.rmhmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, 3)), st)
     assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------- beyond d = 2: Bayesian logistic regression, Fisher metric
+@pytest.mark.parametrize("d,N,C,eps,n_leap,n_fp,burn,keep,bounded", [(3, 60, 70, 0.05, 2, 5, 4, 16, False), (4, 80, 33, 0.04, 3, 3, 3, 12, False),
+                                                                  (1, 30, 64, 0.08, 2, 4, 2, 12, False), (2, 40, 40, 0.05, 2, 5, 3, 12, True),
+                                                                  (4, 50, 17, 0.03, 1, 0, 0, 10, True)])
+def test_rmhmc_logistic_fisher_metric_bit_exact_vs_oracle(d, N, C, eps, n_leap, n_fp, burn, keep, bounded):
+    """mcmc::rmhmc with a position-dependent d x d metric, d up to 4 (per lane: the d x d inverse and d products Ginv dG_i per
+    fixed-point step, ref: src/rmhmc.cpp:99-150,199-272): G = X^T diag(s (1 - s)) X + I on MI_TARGET_LOGISTIC."""
+    from mcmc_amd import synth
+    X, y = synth.logistic_problem(d, N, seed=8)
+    init = synth.initial_states(C, d, seed=7) * 0.3
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = np.full(d, -2.0), np.full(d, 2.5)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=43, n_burnin_draws=burn, n_keep_draws=keep, step_size=eps, n_leap_steps=n_leap,
+                                   n_fp_steps=n_fp, **kw)
+    g_draws, g = mcmc_amd.rmhmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=16, eta_chains=2)
+    s = orc.make_settings(seed=43, n_burnin=burn, n_keep=keep, n_leap=n_leap, step=eps, n_fp=n_fp, W=4, blocks=4, block_size=16, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_RMHMC, t, init, s, chain0=5)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert 0 < int(g["n_accept"].sum())
+
+
+def test_rmhmc_logistic_beyond_4_dims_is_refused():
+    from mcmc_amd import synth
+    X, y = synth.logistic_problem(5, 30, seed=8)
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:
+        mcmc_amd.rmhmc(mcmc_amd.TARGET_LOGISTIC, np.zeros((4, 5)), st, X=X, y=y)
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
