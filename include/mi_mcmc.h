@@ -171,6 +171,18 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
  * n_leap_steps, step_size, n_fp_steps, vals_bound / bounds from the settings; there is no precond_mat in rmhmc. */
 int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 
+/* mcmc::hmc with a DIAGONAL mass matrix adapted during burn-in -- NOT a reference mode (kthohr/mcmc has no mass adaptation;
+ * SURVEY 8 f-2 asks for it because an ill-conditioned target does not mix with precond_mat = I at any step size).  Many chains
+ * make the estimate cheap: the mass is POOLED over the chains, M = diag(1 / var_c(theta_i)), one matrix for all of them, taken
+ * from the spread of the chains' current states -- first from initial_vals, then again after each of `n_windows` equal parts
+ * of the burn-in.  Each part is an ordinary mi_mcmc_hmc_run call with that diagonal precond_mat (bit-exact against the oracle
+ * given the mass, tests/test_gpu_mass_adapt.py) chained through mi_chains.draw0, so the whole run is reproducible; the kept
+ * draws use the last estimate, returned in mass_diag_out[d] (host, may be NULL).  step_size is in the preconditioned metric
+ * (every dimension near unit scale).  Gaussian targets (any d for the separable ones, d <= 128 dense); settings->precond_mat
+ * must be NULL; a dimension whose pooled variance is 0 or not finite keeps mass 1. */
+int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
+                                 double* mass_diag_out, void* stream);
+
 /* Host-callback form of mcmc::hmc for ONE chain: the reference's own target contract
  * (std::function<fp_t(const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>, hmc.hpp:42-48)
  * flattened to a C function pointer. The callback runs on the host, called exactly where the

@@ -60,7 +60,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -139,6 +139,15 @@ def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=
 
 _RUN = {"hmc": "mi_mcmc_hmc_run", "mala": "mi_mcmc_mala_run", "nuts": "mi_mcmc_nuts_run", "rwmh": "mi_mcmc_rwmh_run",
         "rmhmc": "mi_mcmc_rmhmc_run"}
+
+
+def hmc_mass_adapted(target, settings, chains, n_windows=3, stream=None):
+    """mi_mcmc_hmc_run_mass_adapted (NOT a reference mode): hmc with a diagonal mass matrix pooled over the chains and
+    re-estimated after each of n_windows parts of the burn-in.  Returns the final mass diagonal [d]."""
+    mass = np.zeros(int(target.d))
+    _check(lib().mi_mcmc_hmc_run_mass_adapted(C.byref(target), C.byref(settings), C.byref(chains), C.c_uint32(n_windows),
+                                              C.c_void_p(mass.ctypes.data), C.c_void_p(stream or 0)))
+    return mass
 
 
 def release_workspace(stream=None, all_streams=True):

@@ -797,6 +797,90 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     return MI_OK;
 }
 
+// per-dimension variance of the chains' current states, pooled over the chains: out[d] (host); theta [d][C] in `mem`
+namespace {
+__global__ __launch_bounds__(256) void pooled_variance_kernel(const double* __restrict__ theta, uint64_t C, double* __restrict__ out)
+{
+    // one workgroup per dimension: mean, then the centred second moment (two passes, fixed reduction tree)
+    __shared__ double red[256];
+    const double* row = theta + (size_t)blockIdx.x * C;
+    auto block_sum = [&](double v) -> double {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int m = 128; m >= 1; m >>= 1) { if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m]; __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double s = 0.0;
+    for (uint64_t c = threadIdx.x; c < C; c += 256) s += row[c];
+    const double mean = block_sum(s) / (double)C;
+    double q = 0.0;
+    for (uint64_t c = threadIdx.x; c < C; c += 256) { const double e = row[c] - mean; q = __builtin_fma(e, e, q); }
+    const double var = block_sum(q) / (double)(C > 1 ? C - 1 : 1);
+    if (threadIdx.x == 0) out[blockIdx.x] = var;
+}
+}  // namespace
+
+int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
+                                 double* mass_diag_out, void* stream)
+{
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    if (settings->precond_mat) return fail(MI_ERR_BAD_ARG, "hmc (mass adapted): settings.precond_mat must be NULL, the mass matrix is estimated");
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
+        return fail(MI_ERR_UNSUPPORTED, "hmc (mass adapted): implemented for the Gaussian targets (a diagonal precond_mat on the device path)");
+    if (chains->n_chains < 2) return fail(MI_ERR_BAD_ARG, "hmc (mass adapted): the mass is pooled over the chains, at least 2 are needed");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t d = target->d, C = chains->n_chains;
+    std::vector<double> var(d), M(d * d, 0.0), mass(d, 1.0);
+    DevBuf var_dev, theta_stage;
+    HIP_TRY(var_dev.alloc(d * 8));
+    auto estimate = [&]() -> int {                       // mass_i = 1 / pooled variance of dimension i over the chains' current states
+        const double* th = chains->theta;
+        if (chains->mem == MI_MEM_HOST) {
+            if (!theta_stage.p) HIP_TRY(theta_stage.alloc(d * C * 8));
+            HIP_TRY(hipMemcpyAsync(theta_stage.p, chains->theta, d * C * 8, hipMemcpyHostToDevice, st));
+            th = theta_stage.as<double>();
+        }
+        hipLaunchKernelGGL(pooled_variance_kernel, dim3((unsigned)d), dim3(256), 0, st, th, C, var_dev.as<double>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(var.data(), var_dev.p, d * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < d; ++i) {
+            const double m = 1.0 / var[i];
+            mass[i] = (std::isfinite(m) && m > 0.0) ? m : 1.0;
+            M[i * d + i] = mass[i];
+        }
+        return MI_OK;
+    };
+    const uint64_t n_burnin = settings->n_burnin_draws;
+    const uint32_t n_parts = n_windows + 1;
+    uint64_t done = 0;
+    rc = estimate();                                     // from the spread of initial_vals
+    if (rc) return rc;
+    for (uint32_t part = 0; part < n_parts; ++part) {
+        const bool last = part + 1 == n_parts;
+        const uint64_t upto = last ? n_burnin : (n_burnin * (part + 1)) / n_parts;
+        mi_settings s_ = *settings;
+        s_.precond_mat = M.data();
+        s_.n_burnin_draws = upto - done;
+        s_.n_keep_draws = last ? settings->n_keep_draws : 0;
+        mi_chains c_ = *chains;
+        c_.draw0 = chains->draw0 + done;
+        if (!last) { c_.draws = nullptr; c_.n_accept = nullptr; }
+        if (s_.n_burnin_draws + s_.n_keep_draws > 0) {
+            rc = mi_mcmc_hmc_run(target, &s_, &c_, stream);
+            if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(st));           // M (host) is read during the call's staging; the next estimate reads theta
+        }
+        done = upto;
+        if (!last) { rc = estimate(); if (rc) return rc; }
+    }
+    if (mass_diag_out) std::memcpy(mass_diag_out, mass.data(), d * 8);
+    return MI_OK;
+}
+
 int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
     int rc = check_common(target, settings, chains);
