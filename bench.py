@@ -312,6 +312,21 @@ def main():
         out["ess_note"] = (f"min-over-dims Geyer-IPS ESS of the {n_keep} kept draws (autocovariance pooled over all chains of rank 0 on "
                            "the device), x chains x ranks, / seconds per step")
         out["rhat_max"] = rhat_max
+        if args.config == 5 and C > 1:
+            # the second half of BASELINE.json's metric on this target is decided by the mass matrix, not by the kernel:
+            # the same workload through mi_mcmc_hmc_run_mass_adapted (NOT a reference mode), outside the timed region
+            theta.copy_(theta0)
+            s_ad = mcmc_amd.default_settings(**dict(skw, step_size=0.12))
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            mass = mcmc_amd.hmc_mass_adapted(target, s_ad, chains, n_windows=3, stream=stream)
+            torch.cuda.synchronize()
+            t_ad = time.perf_counter() - ta
+            st_ad = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+            out["mass_adapted"] = {"what": "mi_mcmc_hmc_run_mass_adapted, pooled diagonal mass, 3 windows, step_size 0.12 (non-reference mode)",
+                                   "ms": t_ad * 1e3, "ess_per_sec": float(st_ad["ess"].min()) * C * world / t_ad,
+                                   "accept_rate": float(n_accept[:C].double().mean().item()) / n_keep,
+                                   "mass_over_precision_range": [float((mass / kw["prec"]).min()), float((mass / kw["prec"]).max())]}
         if collate_ms is not None:
             out["collate_allgather_ms"] = collate_ms
             out["collate_bytes_per_rank"] = n_keep * d * C * 8

@@ -206,6 +206,22 @@ int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
                               void* target_data, const mi_settings* settings, double* draws_out,
                               uint64_t* n_accept_draws, double* step_size_out);
 
+/* ---- multi-GPU: one process per GPU.  Chains are independent (the reference runs one per call), so the path shards with no
+ * data-path collective: rank r of world_size runs the global chains [chain0, chain0 + n_local) in its own mi_mcmc_*_run call
+ * (mi_chains.chain0 = chain0; the Philox counter uses the global id, so the union of the shards is bit-identical to one call).
+ * The one exchange the path has is the collation of draws_out. */
+void mi_mcmc_shard_bounds(uint64_t n_chains_total, uint32_t world_size, uint32_t rank, uint64_t* chain0, uint64_t* n_local);
+/* All-gather of the kept draws over xGMI: every rank contributes its slab local_draws [n_keep][d][n_local] and receives
+ * all_draws [n_keep][d][n_chains_total] (both DEVICE memory).  rccl_comm is the caller's ncclComm_t (one rank per GPU; RCCL is
+ * loaded on first use, MI_ERR_UNSUPPORTED if librccl.so is absent).  Ragged shards need no padding: one grouped broadcast per
+ * rank into a rank-major staging buffer (`scratch`, n_keep * d * n_chains_total doubles on the device), then a merge kernel
+ * that interleaves the chain axis.  Enqueued on `stream`; returns after enqueueing. */
+int mi_mcmc_allgather_draws(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
+                            uint64_t d, uint64_t n_chains_total, double* scratch, double* all_draws, void* stream);
+/* the merge step alone: rank-major shards [r][n_keep][d][n_local(r)] (device) -> [n_keep][d][n_chains_total] (device) */
+int mi_mcmc_merge_shards(const double* rank_major, uint32_t world_size, uint64_t n_keep, uint64_t d, uint64_t n_chains_total,
+                         double* all_draws, void* stream);
+
 /* Layout converters between the engine's [n_keep][d][C] slabs and the reference's per-chain
  * draws_out (n_keep x d, column-major as Eigen stores it: element (i,j) at i + j*n_keep;
  * src/hmc.cpp:138,197). Host memory. */

@@ -61,9 +61,34 @@ _lib = None
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback",
-    "mi_mcmc_draws_to_chain_major", "mi_mcmc_draw_stats",
+    "mi_mcmc_draws_to_chain_major", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
+
+
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 and dlopen them BY PATH on `import torch`.  If the
+    engine was loaded first (bound to /opt/rocm's copies) the process would then hold two HIP runtimes, and torch's streams and
+    device pointers mean nothing to the second one.  So: when torch is installed but not imported yet, load its runtime
+    libraries first; the engine's DT_NEEDED entries (same sonames) then resolve to them, whichever import comes first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def lib():
@@ -73,6 +98,7 @@ def lib():
         path = os.environ.get("MI_MCMC_LIB", LIB_PATH)      # A/B builds of the same engine (tools/), never a fallback
         if not os.path.exists(path):
             raise MiMcmcError(-1, f"{path} not built: run `make -C mcmc_amd/csrc` (no CPU fallback)")
+        _one_hip_runtime()
         _lib = C.CDLL(path)
         _lib.mi_mcmc_last_error.restype = C.c_char_p
     return _lib

@@ -3,6 +3,7 @@
 // chain state in HBM, launches the gfx950 kernels.  No CPU fallback: anything the device path
 // does not implement returns MI_ERR_UNSUPPORTED.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -143,6 +144,7 @@ int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    (void)hipGetLastError();      // a stale non-fatal status of the caller's own HIP use (e.g. hipErrorNotReady of an event query) is not ours
     return MI_OK;
 }
 
@@ -584,6 +586,7 @@ int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, con
     if (chains->n_chains == 0 || !chains->theta) return fail(MI_ERR_BAD_ARG, "chains.theta and n_chains are required");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    (void)hipGetLastError();
     static const char* const names[5] = {"hmc", "mala", "nuts", "rwmh", "rmhmc"};
     return run_small(names[algo], algo, d, settings, chains, static_cast<hipStream_t>(stream), [&](const mi::SmallParams& p, hipStream_t s_) {
         return launch(algo, &p, target_pod, s_);
@@ -1599,6 +1602,7 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
                        double* mean, double* acov, double* rhat, double* ess, void* stream)
 {
     if (!draws_kdc || n_keep == 0 || d == 0 || n_chains == 0) return fail(MI_ERR_BAD_ARG, "draw_stats: empty input");
+    (void)hipGetLastError();
     if (n_keep > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw_stats: n_keep does not fit 32 bits");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = n_keep, C = n_chains;
@@ -1681,6 +1685,99 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
             ess[j] = std::min(e, (double)n * 10.0);
         }
     return MI_OK;
+}
+
+// ---- multi-GPU helpers of the C ABI (one process per GPU; mcmc_amd/dist.py is the torch.distributed form of the same thing)
+void mi_mcmc_shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* chain0, uint64_t* n_local)
+{
+    // contiguous, balanced: the first (n % world) ranks get one extra chain
+    const uint64_t base = world ? n_total / world : 0, extra = world ? n_total % world : 0;
+    if (n_local) *n_local = base + (rank < extra ? 1 : 0);
+    if (chain0) *chain0 = (uint64_t)rank * base + (rank < extra ? rank : extra);
+}
+
+}  // extern "C"
+
+namespace {
+
+// all[k][j][chain0(r) + c] = rank_major[off(r) + (k d + j) n_local(r) + c]
+__global__ __launch_bounds__(256) void merge_shards_kernel(const double* __restrict__ src, uint32_t world, uint64_t rows, uint64_t row0,
+                                                          uint64_t C, double* __restrict__ dst)
+{
+    const uint64_t base = C / world, extra = C % world;
+    const uint64_t row = row0 + blockIdx.y;                        // k d + j
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (uint64_t)gridDim.x * blockDim.x) {
+        // rank of global chain c and its position inside the shard
+        const uint64_t cut = extra * (base + 1);
+        const uint64_t r = (c < cut) ? c / (base + 1) : extra + (base ? (c - cut) / base : 0);
+        const uint64_t c0 = r * base + (r < extra ? r : extra), nl = base + (r < extra ? 1 : 0);
+        const uint64_t off = rows * c0;                            // shards before r hold rows * chain0(r) doubles in total
+        dst[row * C + c] = src[off + row * nl + (c - c0)];
+    }
+}
+
+struct Rccl {
+    void* h = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*err)(int) = nullptr;
+};
+Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (!r.h) return;
+        r.group_start = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupEnd"));
+        r.broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.h, "ncclBroadcast"));
+        r.err = reinterpret_cast<const char* (*)(int)>(dlsym(r.h, "ncclGetErrorString"));
+    });
+    return (r.h && r.group_start && r.group_end && r.broadcast) ? &r : nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_mcmc_merge_shards(const double* rank_major, uint32_t world, uint64_t n_keep, uint64_t d, uint64_t C, double* all, void* stream)
+{
+    if (!rank_major || !all || world == 0) return fail(MI_ERR_BAD_ARG, "merge_shards: null buffer / empty world");
+    const uint64_t rows = n_keep * d;
+    if (rows == 0 || C == 0) return MI_OK;
+    const unsigned gx = (unsigned)std::min<uint64_t>((C + 255) / 256, 4096);
+    (void)hipGetLastError();
+    for (uint64_t r0 = 0; r0 < rows; r0 += 65535) {        // grid.y limit
+        const unsigned gy = (unsigned)std::min<uint64_t>(65535, rows - r0);
+        hipLaunchKernelGGL(merge_shards_kernel, dim3(gx, gy), dim3(256), 0, static_cast<hipStream_t>(stream), rank_major, world, rows, r0, C, all);
+    }
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                            double* scratch, double* all, void* stream)
+{
+    if (!comm || !scratch || !all || world == 0 || rank >= world) return fail(MI_ERR_BAD_ARG, "allgather_draws: bad communicator / buffers / rank");
+    Rccl* r = rccl();
+    if (!r) return fail(MI_ERR_UNSUPPORTED, "allgather_draws: librccl.so could not be loaded");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t rows = n_keep * d;
+    uint64_t c0 = 0, nl = 0;
+    mi_mcmc_shard_bounds(C, world, rank, &c0, &nl);
+    if (nl > 0 && !local) return fail(MI_ERR_BAD_ARG, "allgather_draws: local_draws is required for a non-empty shard");
+    int e = r->group_start();
+    for (uint32_t q = 0; q < world && e == 0; ++q) {       // ragged shards: one broadcast per rank, grouped into one launch
+        uint64_t qc0 = 0, qn = 0;
+        mi_mcmc_shard_bounds(C, world, q, &qc0, &qn);
+        if (qn == 0) continue;
+        e = r->broadcast(q == rank ? local : nullptr, scratch + rows * qc0, (size_t)(rows * qn), 8 /* ncclDouble */, (int)q, comm, st);
+    }
+    const int e2 = r->group_end();
+    if (e != 0 || e2 != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e ? e : e2) : "error");
+    return mi_mcmc_merge_shards(scratch, world, n_keep, d, C, all, stream);
 }
 
 int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
