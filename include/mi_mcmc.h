@@ -76,7 +76,10 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_HMC_ONE_WAVE_PER_SIMD = 5,   /* 4 waves per workgroup, one tile per wave */
     MI_KERNEL_HMC_SPLIT2 = 6,              /* two waves share a tile (row halves of the mat-vec, theta exchanged through LDS) */
     MI_KERNEL_HMC_SPLIT4 = 7,              /* four waves share a tile, one wave per SIMD (16 chains per workgroup) */
-    MI_KERNEL_HMC_SPLIT4_TWO_WAVES = 8     /* four waves share a tile, two waves per SIMD (32 chains per workgroup) */
+    MI_KERNEL_HMC_SPLIT4_TWO_WAVES = 8,    /* four waves share a tile, two waves per SIMD (32 chains per workgroup) */
+    MI_KERNEL_NUTS_TICK_LOCAL = 9          /* nuts, unbounded Gaussian targets, identity precond_mat: the asynchronous kernel that reloads
+                                            * every leaf's start record (what the bounded / preconditioned variants run) instead of the
+                                            * default one with register-carried leaf state */
 } mi_kernel_hint;
 
 typedef struct mi_target {

@@ -25,6 +25,8 @@ int launch_hmc_gauss_few_chains(const HmcParams& prm, int shape, hipStream_t st)
 int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st);
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
+// the plain case (unbounded, identity precond_mat) with register-carried leaf state (nuts_reg.hpp): the default NUTS kernel
+int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);
 // one lane per chain, d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp); algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc
 int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st);

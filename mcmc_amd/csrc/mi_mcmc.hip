@@ -1124,6 +1124,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
     const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP;      // the first-generation kernel, same bits
+    const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
 #ifdef MI_PROFILING
     DevBuf prof_buf;
     if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(16 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 128)); prm.prof = prof_buf.as<unsigned long long>(); }
@@ -1171,7 +1172,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, false, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));
+    else if (lockstep || tick_local) rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));
+    else rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);

@@ -1,5 +1,6 @@
 // nuts_launch.hip -- translation unit of the NUTS MFMA kernels (nuts_async.hpp, lock-step predecessor nuts_dense.hpp)
 #include "nuts_async.hpp"
+#include "nuts_reg.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
 
@@ -12,6 +13,17 @@ int async(const NutsParams& prm, uint32_t batch, hipStream_t st)
     const size_t lds = ((size_t)NT * 4 * NT * 64 * ((DENSE_M && NT <= 4) ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double)
                      + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     auto kern = nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
+    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
+    return (int)hipGetLastError();
+}
+
+// the plain case with register-carried leaf state (nuts_reg.hpp): the default kernel
+template <int NT>
+int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
+{
+    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double);
+    auto kern = nuts_gauss_reg_kernel<NT>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
     return (int)hipGetLastError();
@@ -36,6 +48,12 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, boo
     if (gen) return MI_DISPATCH_NT(nt, (async<1, true, false>(prm, batch, st)), (async<2, true, false>(prm, batch, st)), (async<4, true, false>(prm, batch, st)), (async<8, true, false>(prm, batch, st)));
     if (ls) return MI_DISPATCH_NT(nt, lockstep<1>(prm, st), lockstep<2>(prm, st), lockstep<4>(prm, st), lockstep<8>(prm, st));
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));
+}
+
+int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st)
+{
+    if (batch < 1) batch = 1;
+    return MI_DISPATCH_NT(nt, reg<1>(prm, batch, st), reg<2>(prm, batch, st), reg<4>(prm, batch, st), reg<8>(prm, batch, st));
 }
 
 }  // namespace mi

@@ -43,8 +43,9 @@ CASES = [
 ]
 
 
-# the asynchronous kernel is the default; its lock-step predecessor must give the same bits
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
+# default: the asynchronous kernel with register-carried leaf state (nuts_reg.hpp); the tick-local asynchronous kernel (what the
+# bounded / preconditioned variants run) and the lock-step predecessor must give the same bits
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
 
 
 @pytest.mark.parametrize("hint", KERNELS)
