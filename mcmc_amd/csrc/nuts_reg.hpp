@@ -14,16 +14,23 @@
 //     their own level-1 U-turn test (registers: the test's first operand, leaf li-1, IS the start state of this leapfrog, so
 //     d = theta_end - theta_start and d.p_start fall out of the kick / drift loop and d.p_end out of the second kick), and
 //     possibly the carried proposal (stored to its destination straight from registers);
-//   * U-turn tests of levels >= 2, pending copies and edges use the records in memory as before.
+//   * the U-turn test of a level-l node (l >= 2) is evaluated EAGERLY, at the tick of the first leaf of its second half (an even
+//     leaf, in registers) against the node's first leaf (two vectors from memory, fetched together with the start records at
+//     the top of the tick) instead of four vectors in a dependent round trip per level when the node closes: the unwind of a
+//     tick (nuts.ipp:212-229) then runs on LDS scalars and a bit mask;
+//   * pending copies, edges and the top-level test of a doubling use the records in memory as before.
 #pragma once
 
 #include "nuts_async.hpp"
 
 #ifndef MI_NUTS_R_CHU
-#define MI_NUTS_R_CHU 16     // U-turn operands of the levels >= 2: 4 vectors per chunk
+#define MI_NUTS_R_CHU 8      // top-level U-turn test of a doubling: 4 vectors per chunk
 #endif
 #ifndef MI_NUTS_R_CHC
 #define MI_NUTS_R_CHC 16     // record copies: 2 vectors per chunk
+#endif
+#ifndef MI_NUTS_R_CHE
+#define MI_NUTS_R_CHE 16     // eager U-turn operands (theta, p of the node's first leaf): slices per streamed chunk, two chunks in flight
 #endif
 
 namespace mi {
@@ -193,6 +200,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     double e_signed = 0.0, H0 = 0.0, prev_K = 0.0, log_u = 0.0, n_val = 1.0;
     double alpha_val = 0.0, n_alpha_val = 0.0;
     int good_round = 0;
+    uint32_t utpre = 0;          // bit l: the U-turn test of the open level-l node passed (set when the first leaf of its second half ran)
     bool fin_pending = false;    // the draw's epilogue (dual averaging, row store) is done in the next refresh phase
     uint32_t fin_depth = 0;
 
@@ -302,18 +310,49 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
                 if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
             }
         }
-        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w.  d = theta_end - theta_start (by direction)
-        // and q1 = d . p_start come out of the kick / drift loop: the level-1 U-turn test of an odd leaf (nuts.ipp:226-227 with
-        // first leaf li - 1 = this leapfrog's start, second-half leaf li = its end)
+        // EAGER U-turn tests.  The test of a level-l node (nuts.ipp:226-227) uses its first leaf b and the first leaf of its second
+        // half, b2 = b + 2^(l-1) (nuts_dense.hpp) -- both exist as soon as b2 does, 2^(l-1) - 1 ticks before the node closes.  An
+        // even leaf li > 0 is that b2 for exactly one node, level l = ctz(li) + 1 (if l <= jd), with b = li - 2^ctz(li).  So the
+        // test is evaluated HERE, with (theta, p)(b2) in registers and (theta, p)(b) fetched together with the start records
+        // (one round trip at the top of the tick, two vectors instead of four), and its bit kept for the tick that closes the
+        // node: the unwind below touches no memory.  An odd leaf is b2 of its own level-1 node with b = li - 1 = the start of this
+        // leapfrog: the same expressions with the start state as (theta, p)(b).
+        const uint32_t cz_i = (li == 0) ? 0u : (uint32_t)__builtin_ctz(li);
+        const bool eager = run && !odd && li != 0u && (cz_i + 1u <= jd);
+        const bool any_eager = __ballot(eager) != 0ull;
+        const uint32_t bleaf = li - (1u << cz_i);
+        const int sb = (!eager || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
+        const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;           // (theta, p) of leaf b for the eager lanes
+        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w;  d = theta(b2) - theta(b) (by direction),
+        // q1 = d . p(b) fall out of the kick / drift loop, q2 = d . p(b2) out of the second kick.  The rows of leaf b stream
+        // through in chunks of CHE slices, one chunk ahead of its use.
         double dd[NS];
         double q1 = 0.0, q2 = 0.0;
+        {
+            constexpr int CHE = (NS < MI_NUTS_R_CHE) ? NS : MI_NUTS_R_CHE;
+            constexpr int NCE = NS / CHE;
+            double ra_t[CHE], ra_p[CHE], rn_t[CHE], rn_p[CHE];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const double p0 = pm[s], t0 = th[s];
-            pm[s] = p0 - (e_signed * w[s]) / 2.0;
-            th[s] = t0 + e_signed * pm[s];
-            dd[s] = (vdir > 0) ? (th[s] - t0) : (t0 - th[s]);
-            q1 = dfma(dd[s], p0, q1);
+            for (int k = 0; k < CHE; ++k) { ra_t[k] = 0.0; ra_p[k] = 0.0; rn_t[k] = 0.0; rn_p[k] = 0.0; }
+            if (any_eager) { if (eager) { ld_row(eb_t, 0, ra_t); ld_row(eb_p, 0, ra_p); } }
+#pragma unroll
+            for (int c = 0; c < NCE; ++c) {
+                if (c + 1 < NCE && any_eager) { if (eager) { ld_row(eb_t, (c + 1) * CHE, rn_t); ld_row(eb_p, (c + 1) * CHE, rn_p); } }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < CHE; ++k) {
+                    const int s_ = c * CHE + k;
+                    const double p0 = pm[s_], t0 = th[s_];
+                    pm[s_] = p0 - (e_signed * w[s_]) / 2.0;
+                    th[s_] = t0 + e_signed * pm[s_];
+                    const double rt = odd ? t0 : ra_t[k], rp = odd ? p0 : ra_p[k];
+                    dd[s_] = (vdir > 0) ? (th[s_] - rt) : (rt - th[s_]);
+                    q1 = dfma(dd[s_], rp, q1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < CHE; ++k) { ra_t[k] = rn_t[k]; ra_p[k] = rn_p[k]; }
+            }
         }
         matvec_mfma<NT>(afrag, th, w);
 #pragma unroll
@@ -326,7 +365,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         if (!is_finite(pU)) pU = INF;
         q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
         q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
-        const bool ut1_ok = (q1 >= 0.0) && (q2 >= 0.0);  // level-1 test (meaningful where li is odd)
+        const bool ut_now = (q1 >= 0.0) && (q2 >= 0.0);  // odd leaf: its level-1 test; eager even leaf: the test of level ctz(li) + 1
+        if (eager) utpre = (utpre & ~(1u << (cz_i + 1u))) | ((ut_now ? 1u : 0u) << (cz_i + 1u));
         if (run && live && !odd) {                       // even leaves are the records later leaves and tests read
             st_row(rec_t, 0, th); st_row(rec_p, 0, pm); st_row(rec_w, 0, w);
         }
@@ -375,16 +415,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
                 cna = p_na + cna;
             }
             const bool need_ut = mrg && !failed;
-            if (l == 1) {
-                if (need_ut && !ut1_ok) failed = true;                   // :226-229 from the registers
-            } else if (__ballot(need_ut) != 0ull) {
-                const uint32_t b = li - (1u << l) + 1;                   // first leaf of the node (valid where need_ut): even
-                const int slot1 = (!need_ut || b == 0) ? 0 : (__builtin_ctz(b) + 1);
-                const int slot2 = (int)l;                                // first leaf of the second half: even, ctz = l - 1
-                const bool ok = uturn_ok(need_ut, V_LEAF0 + 3 * slot1, V_LEAF0 + 3 * slot1 + 1,
-                                         V_LEAF0 + 3 * slot2, V_LEAF0 + 3 * slot2 + 1, vdir);     // :226-227
-                if (need_ut && !ok) failed = true;                       // :229
-            }
+            const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227, evaluated when its second operand appeared
+            if (need_ut && !ok) failed = true;                                   // :229
         }
         // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279), so that an accepted
         //      proposal goes straight to prev_draw instead of through a pending slot
