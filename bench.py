@@ -50,7 +50,7 @@ WORKLOADS = {
     4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
             name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
             metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",
-            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_async_kernel<8>", bound="mfma"),
+            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_reg_kernel<8>", bound="mfma"),
     5: dict(algo="hmc", d=1024, chains=131072, n_leap_steps=32, step_size=0.005, n_burnin_draws=20, n_keep_draws=8, seed=8,
             name="BASELINE configs[4], one GPU's shard: mcmc::hmc, d=1024 diagonal Gaussian (cond 1e4), 131072 of 2^20 chains, fp64",
             metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=1024 ill-conditioned Gaussian, 131072 chains per GPU",
@@ -301,6 +301,9 @@ def main():
                          "traffic": profiled_traffic(args.config, key),
                          "kernel": cfg["kernel"], "kernel_ms": k_ms, "flop_per_unit": fpu},
         }
+        if out["roofline"]["traffic"] is not None:      # HBM side of the same launch, from the committed PMC passes
+            out["roofline"]["hbm_TBps"] = out["roofline"]["traffic"] / (k_ms * 1e-3) / 1e12
+            out["roofline"]["hbm_frac_of_8TBps"] = out["roofline"]["hbm_TBps"] / 8.0
         for k in ("n_leap_steps", "step_size", "n_adapt_draws", "max_tree_depth", "n_rows"):
             if k in cfg:
                 out["config"][k] = cfg[k]
