@@ -3,7 +3,6 @@
 // chain state in HBM, launches the gfx950 kernels.  No CPU fallback: anything the device path
 // does not implement returns MI_ERR_UNSUPPORTED.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -19,14 +18,13 @@
 #include <vector>
 
 #include "../../include/mi_mcmc.h"
+#include "host_common.hpp"
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
 #include "nuts_async.hpp"
 #include "mala_dense.hpp"
 #include "rwmh_dense.hpp"
-#include "draw_stats.hpp"
-#include "callback_mode.hpp"
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
 #include "launchers.hpp"
@@ -40,36 +38,16 @@
 #define MI_HMC_COST_SPLIT4 0.153      // 7.78 ms
 #endif
 
+namespace mi {
+namespace host {
+std::string& last_error() { thread_local std::string e; return e; }
+}  // namespace host
+}  // namespace mi
+
 namespace {
 
-thread_local std::string g_last_error;
-
-int fail(int code, const char* fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(e_ == hipErrorOutOfMemory ? MI_ERR_OOM : MI_ERR_HIP, "%s failed: %s", \
-                        #expr, hipGetErrorString(e_));                                        \
-    } while (0)
-
-// RAII device buffer
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
+using mi::host::fail;
+using mi::host::DevBuf;
 
 // Per-(device, stream) workspace cache.  Kernels of one stream are ordered, so one buffer serves consecutive calls; it is
 // reallocated (after a stream sync) only when a call needs more, and released by mi_mcmc_release_workspace().  A call holds
@@ -564,7 +542,7 @@ void mi_settings_default(mi_settings* s)
     s->n_fp_steps = 5;
 }
 
-const char* mi_mcmc_last_error(void) { return g_last_error.c_str(); }
+const char* mi_mcmc_last_error(void) { return mi::host::last_error().c_str(); }
 int mi_mcmc_version(void) { return MI_MCMC_VERSION; }
 int mi_mcmc_device_count(void)
 {
@@ -1206,807 +1184,6 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
     if (target->kind != MI_TARGET_NORMAL_MODEL)
         return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path (user targets: include/mi_mcmc_target.hpp)", target->kind);
     return run_small_normal_model("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
-}
-
-int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
-                             const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws)
-{
-    if (!initial_vals || !cb || !settings || d == 0) return fail(MI_ERR_BAD_ARG, "null / empty argument");
-    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): vals_bound not implemented on the device path yet");
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): precond_mat not implemented on the device path yet");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
-    const uint32_t dd = (uint32_t)d;
-    const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
-    if (n_keep && !draws_out) return fail(MI_ERR_BAD_ARG, "draws_out is required");
-    const double eps = settings->step_size;
-    const uint64_t seed = settings->rng_seed_value;
-
-    DevBuf prev, cur, mntm, grad, scal, draws, nacc;
-    HIP_TRY(prev.alloc(d * 8)); HIP_TRY(cur.alloc(d * 8)); HIP_TRY(mntm.alloc(d * 8)); HIP_TRY(grad.alloc(d * 8));
-    HIP_TRY(scal.alloc(4 * 8)); HIP_TRY(draws.alloc(n_keep * d * 8)); HIP_TRY(nacc.alloc(8));
-    HIP_TRY(hipMemset(nacc.p, 0, 8));
-    HIP_TRY(hipMemcpy(prev.p, initial_vals, d * 8, hipMemcpyHostToDevice));
-    std::vector<double> h_pos(d), h_grad(d);
-    double h_scal[4] = {0, 0, 0, 0};
-
-    // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
-    h_scal[1] = -cb(initial_vals, nullptr, target_data);
-    HIP_TRY(hipMemcpy(scal.p, h_scal, sizeof(h_scal), hipMemcpyHostToDevice));
-
-    auto grad_at_cur = [&]() -> int {   // mntm_update_fn's callback (hmc.cpp:124): gradient at new_draw
-        HIP_TRY(hipMemcpy(h_pos.data(), cur.p, d * 8, hipMemcpyDeviceToHost));
-        (void)cb(h_pos.data(), h_grad.data(), target_data);
-        HIP_TRY(hipMemcpy(grad.p, h_grad.data(), d * 8, hipMemcpyHostToDevice));
-        return MI_OK;
-    };
-
-    for (uint64_t draw = 0; draw < n_total; ++draw) {
-        hipLaunchKernelGGL(mi::cb_begin_draw, dim3(1), dim3(64), 0, 0, seed, 0ull, (uint32_t)draw, dd,
-                           prev.as<double>(), cur.as<double>(), mntm.as<double>(), scal.as<double>());
-        for (uint64_t k = 0; k < settings->n_leap_steps; ++k) {          // hmc.cpp:164-176
-            int rc = grad_at_cur(); if (rc) return rc;
-            hipLaunchKernelGGL(mi::cb_half_kick, dim3(1), dim3(64), 0, 0, dd, eps, grad.as<double>(), mntm.as<double>());
-            hipLaunchKernelGGL(mi::cb_drift, dim3(1), dim3(64), 0, 0, dd, eps, mntm.as<double>(), cur.as<double>());
-            rc = grad_at_cur(); if (rc) return rc;
-            hipLaunchKernelGGL(mi::cb_half_kick, dim3(1), dim3(64), 0, 0, dd, eps, grad.as<double>(), mntm.as<double>());
-        }
-        // prop_U = -box_log_kernel(new_draw)  (hmc.cpp:178): value-only callback
-        HIP_TRY(hipMemcpy(h_pos.data(), cur.p, d * 8, hipMemcpyDeviceToHost));
-        const double prop_U = -cb(h_pos.data(), nullptr, target_data);
-        HIP_TRY(hipMemcpy(scal.as<double>() + 2, &prop_U, 8, hipMemcpyHostToDevice));
-        double* row = (draw >= n_burnin) ? draws.as<double>() + (draw - n_burnin) : nullptr;   // column-major n_keep x d
-        hipLaunchKernelGGL(mi::cb_accept, dim3(1), dim3(64), 0, 0, seed, 0ull, (uint32_t)draw, dd, (uint32_t)n_burnin,
-                           cur.as<double>(), mntm.as<double>(), prev.as<double>(), scal.as<double>(), row, n_keep,
-                           nacc.as<unsigned long long>());
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    if (n_keep) HIP_TRY(hipMemcpy(draws_out, draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
-    if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
-    return MI_OK;
-}
-
-}  // extern "C"
-
-// ---- host-callback forms of mcmc::mala and mcmc::nuts for ONE chain (mala.hpp:66-73, nuts.hpp:65-72): the reference's own
-//      examples (examples/eigen/{mala,nuts}_normal.cpp) pass a std::function.  As in mi_mcmc_hmc_run_callback the host drives the
-//      control flow and calls the callback exactly where the reference does; the state and every vector operation live on the GPU.
-namespace {
-
-struct CbMachine {                  // device arena of d-vectors + a scalar mailbox
-    uint32_t d = 0;
-    DevBuf arena, scal;
-    std::vector<double> h_pos, h_grad;
-    mi_log_kernel_cb cb = nullptr;
-    void* user = nullptr;
-    uint64_t n_grad = 0, n_value = 0;
-    double* vec(int k) const { return arena.as<double>() + (size_t)k * d; }
-    int init(uint64_t dd, int n_vec, mi_log_kernel_cb f, void* u)
-    {
-        d = (uint32_t)dd; cb = f; user = u;
-        h_pos.resize(dd); h_grad.resize(dd);
-        HIP_TRY(arena.alloc((size_t)n_vec * dd * 8));
-        HIP_TRY(hipMemset(arena.p, 0, (size_t)n_vec * dd * 8));
-        HIP_TRY(scal.alloc(8 * 8));
-        return MI_OK;
-    }
-    int copy(int dst, int src) const { HIP_TRY(hipMemcpyAsync(vec(dst), vec(src), (size_t)d * 8, hipMemcpyDeviceToDevice, 0)); return MI_OK; }
-    int value_at(int v, double* out)                       // kernel(vals, nullptr, data)
-    {
-        HIP_TRY(hipMemcpy(h_pos.data(), vec(v), (size_t)d * 8, hipMemcpyDeviceToHost));
-        *out = cb(h_pos.data(), nullptr, user); ++n_value;
-        return MI_OK;
-    }
-    int grad_at(int v, int g)                              // kernel(vals, &grad, data), gradient to the device
-    {
-        HIP_TRY(hipMemcpy(h_pos.data(), vec(v), (size_t)d * 8, hipMemcpyDeviceToHost));
-        (void)cb(h_pos.data(), h_grad.data(), user); ++n_grad;
-        HIP_TRY(hipMemcpy(vec(g), h_grad.data(), (size_t)d * 8, hipMemcpyHostToDevice));
-        return MI_OK;
-    }
-    int fetch(int n, double* out) const { HIP_TRY(hipMemcpy(out, scal.p, (size_t)n * 8, hipMemcpyDeviceToHost)); return MI_OK; }
-    int dot(int x, int y, double* out) const
-    {
-        hipLaunchKernelGGL(mi::cb_dot, dim3(1), dim3(64), 0, 0, d, vec(x), vec(y), scal.as<double>());
-        return fetch(1, out);
-    }
-};
-
-int callback_common_checks(const char* who, const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, const mi_settings* settings,
-                           double* draws_out)
-{
-    if (!initial_vals || !cb || !settings || d == 0) return fail(MI_ERR_BAD_ARG, "%s(callback): null / empty argument", who);
-    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "%s(callback): vals_bound is implemented for the device targets only", who);
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "%s(callback): precond_mat is implemented for the device targets only", who);
-    if (settings->n_keep_draws && !draws_out) return fail(MI_ERR_BAD_ARG, "draws_out is required");
-    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
-    return MI_OK;
-}
-
-#define CB_TRY(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
-
-// leap_frog_fn with one step of signed size e on (pos, mntm) (src/nuts.cpp:139-154): two gradient callbacks
-int cb_leapfrog(CbMachine& m, double e, int pos, int mntm, int grad)
-{
-    CB_TRY(m.grad_at(pos, grad));
-    hipLaunchKernelGGL(mi::cb_add_half, dim3(1), dim3(64), 0, 0, m.d, e, m.vec(mntm), m.vec(grad), m.vec(mntm));
-    hipLaunchKernelGGL(mi::cb_add_scaled, dim3(1), dim3(64), 0, 0, m.d, e, m.vec(pos), m.vec(mntm), m.vec(pos));
-    CB_TRY(m.grad_at(pos, grad));
-    hipLaunchKernelGGL(mi::cb_add_half, dim3(1), dim3(64), 0, 0, m.d, e, m.vec(mntm), m.vec(grad), m.vec(mntm));
-    return MI_OK;
-}
-
-// vector ids of the nuts machine
-enum { NV_PREV = 0, NV_MNTM, NV_NEW, NV_POS_T, NV_NEG_T, NV_POS_P, NV_NEG_P, NV_DUMMY_T, NV_DUMMY_P, NV_GRAD, NV_TMP, NV_LEAF_P, NV_FIXED };
-
-struct CbNuts {
-    CbMachine m;
-    uint64_t seed = 0;
-    uint32_t draw = 0, uslot = 0;
-    double step = 0.0, log_u = 0.0, prev_U = 0.0, prev_K = 0.0;
-    uint64_t n_leap = 0;
-    int next_free = NV_FIXED;       // stack of temporaries of the recursion: 5 vectors per level
-
-    struct Out { uint64_t n = 0, s = 0, n_alpha = 0; double alpha = 0.0; };
-
-    int energy(int pos, int mntm, double* U, double* K)
-    {
-        double v;
-        CB_TRY(m.value_at(pos, &v));
-        *U = -v;
-        if (!std::isfinite(*U)) *U = INFINITY;
-        double q;
-        CB_TRY(m.dot(mntm, mntm, &q));
-        *K = q / 2.0;
-        return MI_OK;
-    }
-    // nuts_build_tree (nuts.ipp:97-241): subtree of the given depth from (draw_v, mntm_v) in direction v; writes the proposal to
-    // `prop` and the far / near edges through the (pos, neg) slots it is handed -- the caller crosses them as the reference does
-    int build(int v, int draw_v, int mntm_v, uint32_t depth, int prop, int pos_t, int neg_t, int pos_p, int neg_p, Out& o)
-    {
-        if (depth == 0) {
-            CB_TRY(m.copy(NV_TMP, draw_v));                               // the start may alias an output slot
-            CB_TRY(m.copy(NV_LEAF_P, mntm_v));
-            CB_TRY(m.copy(prop, NV_TMP));
-            CB_TRY(cb_leapfrog(m, (double)v * step, prop, NV_LEAF_P, NV_GRAD));   // :132
-            ++n_leap;
-            double U, K;
-            CB_TRY(energy(prop, NV_LEAF_P, &U, &K));                     // :134-140
-            o.n = (log_u <= -U - K) ? 1 : 0;                              // :146
-            o.s = (log_u < 1000.0 - U - K) ? 1 : 0;                       // :147
-            CB_TRY(m.copy(pos_t, prop)); CB_TRY(m.copy(neg_t, prop));    // :151-155
-            CB_TRY(m.copy(pos_p, NV_LEAF_P)); CB_TRY(m.copy(neg_p, NV_LEAF_P));
-            const double dd = -(U + K) + (prev_U + prev_K);
-            o.alpha = mi::det_exp((dd < 0.0) ? dd : 0.0);                 // :157
-            o.n_alpha = 1;
-            return MI_OK;
-        }
-        const int base = next_free;                                       // prop of the first half, then the second half's five
-        next_free += 6;
-        const int prop_p = base, prop_pp = base + 1, dum_t = base + 2, dum_p = base + 3, edge_t = base + 4, edge_p = base + 5;
-        Out a;
-        CB_TRY(build(v, draw_v, mntm_v, depth - 1, prop_p, pos_t, neg_t, pos_p, neg_p, a));     // :166-171
-        if (a.s == 1) {
-            Out b;
-            if (v == -1) {                                                // :186-196
-                CB_TRY(m.copy(dum_t, pos_t)); CB_TRY(m.copy(dum_p, pos_p));
-                CB_TRY(m.copy(edge_t, neg_t)); CB_TRY(m.copy(edge_p, neg_p));
-                CB_TRY(build(v, edge_t, edge_p, depth - 1, prop_pp, neg_t, dum_t, neg_p, dum_p, b));
-            } else {                                                      // :198-208
-                CB_TRY(m.copy(dum_t, neg_t)); CB_TRY(m.copy(dum_p, neg_p));
-                CB_TRY(m.copy(edge_t, pos_t)); CB_TRY(m.copy(edge_p, pos_p));
-                CB_TRY(build(v, edge_t, edge_p, depth - 1, prop_pp, dum_t, pos_t, dum_p, pos_p, b));
-            }
-            const double prob = (double)b.n / (double)(a.n + b.n);        // :212
-            double z;
-            hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, seed, 0ull, draw, uslot++, m.scal.as<double>());
-            CB_TRY(m.fetch(1, &z));                                       // :213
-            if (z < prob) CB_TRY(m.copy(prop_p, prop_pp));                // :215-217
-            a.n += b.n; a.alpha += b.alpha; a.n_alpha += b.n_alpha;       // :220-222
-            double q[2];
-            hipLaunchKernelGGL(mi::cb_diff_dots, dim3(1), dim3(64), 0, 0, m.d, m.vec(pos_t), m.vec(neg_t), m.vec(neg_p), m.vec(pos_p),
-                               m.vec(NV_TMP), m.scal.as<double>());
-            CB_TRY(m.fetch(2, q));
-            a.s = b.s * ((q[0] >= 0.0) ? 1 : 0) * ((q[1] >= 0.0) ? 1 : 0);   // :226-229
-        }
-        o = a;
-        CB_TRY(m.copy(prop, prop_p));                                     // :239
-        next_free = base;
-        return MI_OK;
-    }
-};
-
-}  // namespace
-
-extern "C" {
-
-int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
-                              const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws)
-{
-    int rc = callback_common_checks("mala", initial_vals, d, cb, settings, draws_out);
-    if (rc) return rc;
-    const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
-    const double eps = settings->step_size, s2 = eps * eps, rs = 1.0 / s2;
-    double log_det = 0.0;                                // LOG_DET(eps^2 I) = sum_i 2 log sqrt(s2), i ascending (oracle: orc_log_det_from_chol)
-    for (uint64_t i = 0; i < d; ++i) log_det = log_det + 2.0 * mi::det_log(__builtin_sqrt(s2));
-    const double cons_term = -0.5 * (double)d * 1.83787706640934548356;
-    enum { PREV = 0, PROP, Z, GRAD, MEAN_PREV, MEAN_PROP, TMP0, TMP1, NVEC };
-    CbMachine m;
-    rc = m.init(d, NVEC, cb, target_data);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(m.vec(PREV), initial_vals, d * 8, hipMemcpyHostToDevice));
-    std::vector<double> row(d);
-    double prev_LP;
-    CB_TRY(m.value_at(PREV, &prev_LP));                  // mala.cpp:138
-    uint64_t n_acc = 0;
-    const uint32_t dd = (uint32_t)d;
-    auto mean_of = [&](int v, int dst) -> int {          // mala_mean_fn (mala.cpp:97-125): one gradient callback
-        CB_TRY(m.grad_at(v, GRAD));
-        hipLaunchKernelGGL(mi::cb_add_half, dim3(1), dim3(64), 0, 0, dd, s2, m.vec(v), m.vec(GRAD), m.vec(dst));
-        return MI_OK;
-    };
-    for (uint64_t draw = 0; draw < n_total; ++draw) {
-        hipLaunchKernelGGL(mi::cb_normals, dim3(1), dim3(64), 0, 0, settings->rng_seed_value, 0ull, (uint32_t)draw, (uint32_t)mi::STREAM_NORMAL, dd, m.vec(Z));   // :150
-        CB_TRY(mean_of(PREV, MEAN_PREV));                // :159
-        hipLaunchKernelGGL(mi::cb_add_scaled, dim3(1), dim3(64), 0, 0, dd, eps, m.vec(MEAN_PREV), m.vec(Z), m.vec(PROP));
-        double prop_LP;
-        CB_TRY(m.value_at(PROP, &prop_LP));              // :162
-        if (!std::isfinite(prop_LP)) prop_LP = -INFINITY;   // :164-166
-        CB_TRY(mean_of(PROP, MEAN_PROP));                // mala.ipp:60
-        CB_TRY(mean_of(PREV, MEAN_PREV));                // :61 (the reference evaluates it again)
-        double qa, qb;
-        hipLaunchKernelGGL(mi::cb_quad_form, dim3(1), dim3(64), 0, 0, dd, rs, m.vec(PREV), m.vec(MEAN_PROP), m.vec(TMP0), m.scal.as<double>());
-        CB_TRY(m.fetch(1, &qa));
-        hipLaunchKernelGGL(mi::cb_quad_form, dim3(1), dim3(64), 0, 0, dd, rs, m.vec(PROP), m.vec(MEAN_PREV), m.vec(TMP0), m.scal.as<double>());
-        CB_TRY(m.fetch(1, &qb));
-        const double da = cons_term - 0.5 * (log_det + qa), db = cons_term - 0.5 * (log_det + qb);   // dmvnorm.hpp:41
-        const double x = prop_LP - prev_LP + (da - db);
-        const double comp_val = (x < 0.01) ? x : 0.01;   // mala.cpp:170
-        double z;
-        hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, settings->rng_seed_value, 0ull, (uint32_t)draw, 0u, m.scal.as<double>());
-        CB_TRY(m.fetch(1, &z));                          // :171
-        if (z < mi::det_exp(comp_val)) {                 // :173
-            CB_TRY(m.copy(PREV, PROP));
-            prev_LP = prop_LP;
-            if (draw >= n_burnin) ++n_acc;
-        }
-        if (draw >= n_burnin) {                          // row draw - n_burnin of the column-major n_keep x d matrix
-            HIP_TRY(hipMemcpy(row.data(), m.vec(PREV), d * 8, hipMemcpyDeviceToHost));
-            for (uint64_t j = 0; j < d; ++j) draws_out[(draw - n_burnin) + j * n_keep] = row[j];
-        }
-    }
-    if (n_accept_draws) *n_accept_draws = n_acc;
-    return MI_OK;
-}
-
-int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
-                              const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws, double* step_size_out)
-{
-    int rc = callback_common_checks("nuts", initial_vals, d, cb, settings, draws_out);
-    if (rc) return rc;
-    const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
-    const uint64_t n_adapt = settings->n_adapt_draws <= n_total ? settings->n_adapt_draws : n_total;      // nuts.cpp:54
-    const uint64_t max_depth = settings->max_tree_depth;
-    if (max_depth > 24) return fail(MI_ERR_UNSUPPORTED, "nuts(callback): max_tree_depth > 24 not implemented");
-    CbNuts t;
-    rc = t.m.init(d, NV_FIXED + 6 * ((int)max_depth + 1), cb, target_data);
-    if (rc) return rc;
-    CbMachine& m = t.m;
-    t.seed = settings->rng_seed_value;
-    const uint32_t dd = (uint32_t)d;
-    HIP_TRY(hipMemcpy(m.vec(NV_PREV), initial_vals, d * 8, hipMemcpyHostToDevice));
-    std::vector<double> row(d);
-    // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, z_init)
-    hipLaunchKernelGGL(mi::cb_normals, dim3(1), dim3(64), 0, 0, t.seed, 0ull, 0u, (uint32_t)mi::STREAM_INIT, dd, m.vec(NV_MNTM));   // nuts.cpp:166-168
-    double step = 1.0;
-    {
-        double U0, K0, U, K;
-        CB_TRY(t.energy(NV_PREV, NV_MNTM, &U0, &K0));
-        CB_TRY(m.copy(NV_NEW, NV_PREV)); CB_TRY(m.copy(NV_LEAF_P, NV_MNTM));
-        CB_TRY(cb_leapfrog(m, step, NV_NEW, NV_LEAF_P, NV_GRAD)); ++t.n_leap;
-        CB_TRY(t.energy(NV_NEW, NV_LEAF_P, &U, &K));
-        const double log_half = mi::det_log(0.5), neg_log2 = -mi::det_log(2.0);
-        int a_val = 2 * ((-(U + K) + (U0 + K0)) > log_half ? 1 : 0) - 1;
-        bool cond = (-(U + K) + (U0 + K0)) > neg_log2;
-        while (cond) {
-            step *= (a_val == 1) ? 2.0 : 0.5;
-            CB_TRY(cb_leapfrog(m, step, NV_NEW, NV_LEAF_P, NV_GRAD)); ++t.n_leap;
-            CB_TRY(t.energy(NV_NEW, NV_LEAF_P, &U, &K));
-            a_val = 2 * ((-(U + K) + (U0 + K0)) > log_half ? 1 : 0) - 1;
-            cond = (-(U + K) + (U0 + K0)) > neg_log2;
-        }
-    }
-    const double mu_val = mi::det_log(10 * step);        // nuts.cpp:174
-    double h_val = 0.0, eps_bar = settings->step_size;
-    double v0;
-    CB_TRY(m.value_at(NV_PREV, &v0));
-    t.prev_U = -v0;                                      // :181
-    uint64_t n_acc = 0;
-    for (uint64_t draw = 0; draw < n_total; ++draw) {
-        t.draw = (uint32_t)draw; t.uslot = 0; t.step = step;
-        hipLaunchKernelGGL(mi::cb_normals, dim3(1), dim3(64), 0, 0, t.seed, 0ull, t.draw, (uint32_t)mi::STREAM_NORMAL, dd, m.vec(NV_MNTM));   // :200-202
-        double q, z;
-        CB_TRY(m.dot(NV_MNTM, NV_MNTM, &q));
-        t.prev_K = q / 2.0;                              // :204
-        hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, t.seed, 0ull, t.draw, t.uslot++, m.scal.as<double>());
-        CB_TRY(m.fetch(1, &z));
-        t.log_u = mi::det_log(z) - t.prev_U - t.prev_K;  // :206
-        CB_TRY(m.copy(NV_NEW, NV_PREV)); CB_TRY(m.copy(NV_POS_T, NV_PREV)); CB_TRY(m.copy(NV_NEG_T, NV_PREV));   // :210-215
-        CB_TRY(m.copy(NV_POS_P, NV_MNTM)); CB_TRY(m.copy(NV_NEG_P, NV_MNTM));
-        uint64_t depth = 0, n_val = 1, s_val = 1;
-        CbNuts::Out o;
-        int good_round = 0;
-        while (s_val == 1 && depth < max_depth) {        // :227
-            hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, t.seed, 0ull, t.draw, t.uslot++, m.scal.as<double>());
-            CB_TRY(m.fetch(1, &z));                      // :233
-            const int v = (z <= 0.5) ? -1 : 1;           // :235
-            t.next_free = NV_FIXED;
-            if (v == -1) {                               // :238-246
-                CB_TRY(m.copy(NV_DUMMY_T, NV_POS_T)); CB_TRY(m.copy(NV_DUMMY_P, NV_POS_P));
-                CB_TRY(t.build(v, NV_PREV, NV_MNTM, (uint32_t)depth, NV_NEW, NV_DUMMY_T, NV_NEG_T, NV_DUMMY_P, NV_NEG_P, o));
-            } else {                                     // :248-256
-                CB_TRY(m.copy(NV_DUMMY_T, NV_NEG_T)); CB_TRY(m.copy(NV_DUMMY_P, NV_NEG_P));
-                CB_TRY(t.build(v, NV_PREV, NV_MNTM, (uint32_t)depth, NV_NEW, NV_POS_T, NV_DUMMY_T, NV_POS_P, NV_DUMMY_P, o));
-            }
-            if (o.s == 1) {                              // :260
-                hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, t.seed, 0ull, t.draw, t.uslot++, m.scal.as<double>());
-                CB_TRY(m.fetch(1, &z));                  // :261
-                if (z < (double)o.n / (double)n_val) {   // :263
-                    double v1;
-                    CB_TRY(m.value_at(NV_NEW, &v1));     // :264
-                    double pu = -v1;
-                    if (!std::isfinite(pu)) pu = INFINITY;
-                    CB_TRY(m.copy(NV_PREV, NV_NEW));     // :272-273
-                    t.prev_U = pu;
-                    good_round = 1;
-                }
-            }
-            n_val += o.n;                                // :283
-            depth += 1;
-            double qq[2];
-            hipLaunchKernelGGL(mi::cb_diff_dots, dim3(1), dim3(64), 0, 0, dd, m.vec(NV_POS_T), m.vec(NV_NEG_T), m.vec(NV_NEG_P), m.vec(NV_POS_P),
-                               m.vec(NV_TMP), m.scal.as<double>());
-            CB_TRY(m.fetch(2, qq));
-            s_val = o.s * ((qq[0] >= 0.0) ? 1 : 0) * ((qq[1] >= 0.0) ? 1 : 0);   // :286-289
-        }
-        if (draw < n_adapt) {                            // :294-302
-            const double it = (double)(draw + 1);
-            h_val = h_val + (1.0 / (it + settings->t0_val)) * (settings->target_accept_rate - (o.alpha / (double)o.n_alpha) - h_val);
-            step = mi::det_exp(mu_val - h_val * std::sqrt(it) / settings->gamma_val);
-            eps_bar = eps_bar * mi::det_exp(mi::det_pow(it, -settings->kappa_val) * (mi::det_log(step) - mi::det_log(eps_bar)));
-        } else {
-            step = eps_bar;
-        }
-        if (draw >= n_burnin) {                          // :306-309
-            n_acc += (uint64_t)good_round;
-            HIP_TRY(hipMemcpy(row.data(), m.vec(NV_PREV), d * 8, hipMemcpyDeviceToHost));
-            for (uint64_t j = 0; j < d; ++j) draws_out[(draw - n_burnin) + j * n_keep] = row[j];
-        }
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    if (n_accept_draws) *n_accept_draws = n_acc;
-    if (step_size_out) *step_size_out = step;
-    return MI_OK;
-}
-
-}  // extern "C"
-
-extern "C" {
-
-int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
-                       double* mean, double* acov, double* rhat, double* ess, void* stream)
-{
-    if (!draws_kdc || n_keep == 0 || d == 0 || n_chains == 0) return fail(MI_ERR_BAD_ARG, "draw_stats: empty input");
-    (void)hipGetLastError();
-    if (n_keep > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw_stats: n_keep does not fit 32 bits");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t n = n_keep, C = n_chains;
-    DevBuf staged;
-    const double* x = draws_kdc;
-    if (mem == MI_MEM_HOST) {
-        HIP_TRY(staged.alloc(n * d * C * 8));
-        HIP_TRY(hipMemcpyAsync(staged.p, draws_kdc, n * d * C * 8, hipMemcpyHostToDevice, st));
-        x = staged.as<double>();
-    }
-    const uint32_t G = (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);      // chain groups (partials are added in order on the host)
-    DevBuf sum_dev, mean_dev, acov_dev, mom_dev;
-    HIP_TRY(sum_dev.alloc((size_t)G * d * 8)); HIP_TRY(mean_dev.alloc(d * 8));
-    HIP_TRY(acov_dev.alloc((size_t)G * d * std::min<size_t>(n, (size_t)mi::STATS_MAX_N) * 8)); HIP_TRY(mom_dev.alloc((size_t)G * d * 3 * 8));
-    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, sum_dev.as<double>());
-    std::vector<double> part((size_t)G * d), mean_h(d);
-    HIP_TRY(hipMemcpyAsync(part.data(), sum_dev.p, part.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t j = 0; j < d; ++j) {
-        double s = 0.0;
-        for (uint32_t g = 0; g < G; ++g) s += part[(size_t)g * d + j];
-        mean_h[j] = s / ((double)n * (double)C);
-    }
-    if (mean) std::memcpy(mean, mean_h.data(), d * 8);
-    if (!acov && !rhat && !ess) return MI_OK;
-    HIP_TRY(hipMemcpyAsync(mean_dev.p, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
-    // every lag for series of up to STATS_MAX_N draws; beyond, lags below STATS_TILED_LAGS from the streamed kernel
-    const bool tiled = n > (size_t)mi::STATS_MAX_N;
-    const size_t nlag = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
-    DevBuf acov_t;
-    if (tiled) { HIP_TRY(acov_t.alloc((size_t)G * d * nlag * 8)); }
-    double* const acov_out = tiled ? acov_t.as<double>() : acov_dev.as<double>();
-    if (tiled) {
-        const size_t lds = (size_t)(mi::STATS_TILE_T + 2 * mi::STATS_TILED_LAGS) * 64 * sizeof(double);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mi::stats_acov_tiled_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
-    } else {
-        const size_t lds = 2 * n * 64 * sizeof(double);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
-    }
-    HIP_TRY(hipGetLastError());
-    std::vector<double> ap((size_t)G * d * nlag), mp((size_t)G * d * 3), ac((size_t)n * d, std::nan(""));
-    HIP_TRY(hipMemcpyAsync(ap.data(), acov_out, ap.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t j = 0; j < d; ++j)
-        for (size_t k = 0; k < nlag; ++k) {
-            double s = 0.0;
-            for (uint32_t g = 0; g < G; ++g) s += ap[((size_t)g * d + j) * nlag + k];
-            ac[k * d + j] = s / (double)C / (double)(n - k);          // pooled over chains, unbiased per lag
-        }
-    if (acov) std::memcpy(acov, ac.data(), ac.size() * 8);
-    if (rhat)
-        for (size_t j = 0; j < d; ++j) {
-            double sm = 0.0, sm2 = 0.0, sv = 0.0;
-            for (uint32_t g = 0; g < G; ++g) { const double* o = &mp[((size_t)g * d + j) * 3]; sm += o[0]; sm2 += o[1]; sv += o[2]; }
-            const double W = sv / (double)C;                                                  // mean within-chain variance
-            const double mbar = sm / (double)C;
-            const double B_over_n = (C > 1) ? (sm2 - (double)C * mbar * mbar) / (double)(C - 1) : 0.0;   // variance of the chain means
-            const double var_plus = ((double)(n - 1) / (double)n) * W + B_over_n;
-            rhat[j] = (W > 0.0) ? std::sqrt(var_plus / W) : 1.0;
-        }
-    if (ess)
-        for (size_t j = 0; j < d; ++j) {                               // Geyer's initial positive sequence (mcmc_amd/ess.py)
-            if (n < 4) { ess[j] = (double)n; continue; }
-            const double a0 = ac[j];
-            const double den = (a0 > 0.0) ? a0 : 1.0;
-            double tau = -1.0;
-            size_t t = 0;
-            while (t + 1 < nlag) {
-                const double pair = ac[t * d + j] / den + ac[(t + 1) * d + j] / den;
-                if (pair <= 0.0) break;
-                tau += 2.0 * pair;
-                t += 2;
-            }
-            double e = (tau > 0.0) ? (double)n / std::max(tau, 1.0 / (double)n) : (double)n;
-            ess[j] = std::min(e, (double)n * 10.0);
-        }
-    return MI_OK;
-}
-
-// ---- multi-GPU helpers of the C ABI (one process per GPU; mcmc_amd/dist.py is the torch.distributed form of the same thing)
-void mi_mcmc_shard_bounds(uint64_t n_total, uint32_t world, uint32_t rank, uint64_t* chain0, uint64_t* n_local)
-{
-    // contiguous, balanced: the first (n % world) ranks get one extra chain
-    const uint64_t base = world ? n_total / world : 0, extra = world ? n_total % world : 0;
-    if (n_local) *n_local = base + (rank < extra ? 1 : 0);
-    if (chain0) *chain0 = (uint64_t)rank * base + (rank < extra ? rank : extra);
-}
-
-}  // extern "C"
-
-namespace {
-
-// all[k][j][chain0(r) + c] = rank_major[off(r) + (k d + j) n_local(r) + c]
-__global__ __launch_bounds__(256) void merge_shards_kernel(const double* __restrict__ src, uint32_t world, uint64_t rows, uint64_t row0,
-                                                          uint64_t C, double* __restrict__ dst)
-{
-    const uint64_t base = C / world, extra = C % world;
-    const uint64_t row = row0 + blockIdx.y;                        // k d + j
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += (uint64_t)gridDim.x * blockDim.x) {
-        // rank of global chain c and its position inside the shard
-        const uint64_t cut = extra * (base + 1);
-        const uint64_t r = (c < cut) ? c / (base + 1) : extra + (base ? (c - cut) / base : 0);
-        const uint64_t c0 = r * base + (r < extra ? r : extra), nl = base + (r < extra ? 1 : 0);
-        const uint64_t off = rows * c0;                            // shards before r hold rows * chain0(r) doubles in total
-        dst[row * C + c] = src[off + row * nl + (c - c0)];
-    }
-}
-
-struct Rccl {
-    void* h = nullptr;
-    int (*group_start)() = nullptr;
-    int (*group_end)() = nullptr;
-    int (*broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    const char* (*err)(int) = nullptr;
-};
-Rccl* rccl()
-{
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
-        if (!r.h) return;
-        r.group_start = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupStart"));
-        r.group_end = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupEnd"));
-        r.broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.h, "ncclBroadcast"));
-        r.err = reinterpret_cast<const char* (*)(int)>(dlsym(r.h, "ncclGetErrorString"));
-    });
-    return (r.h && r.group_start && r.group_end && r.broadcast) ? &r : nullptr;
-}
-
-}  // namespace
-
-extern "C" {
-
-int mi_mcmc_merge_shards(const double* rank_major, uint32_t world, uint64_t n_keep, uint64_t d, uint64_t C, double* all, void* stream)
-{
-    if (!rank_major || !all || world == 0) return fail(MI_ERR_BAD_ARG, "merge_shards: null buffer / empty world");
-    const uint64_t rows = n_keep * d;
-    if (rows == 0 || C == 0) return MI_OK;
-    const unsigned gx = (unsigned)std::min<uint64_t>((C + 255) / 256, 4096);
-    (void)hipGetLastError();
-    for (uint64_t r0 = 0; r0 < rows; r0 += 65535) {        // grid.y limit
-        const unsigned gy = (unsigned)std::min<uint64_t>(65535, rows - r0);
-        hipLaunchKernelGGL(merge_shards_kernel, dim3(gx, gy), dim3(256), 0, static_cast<hipStream_t>(stream), rank_major, world, rows, r0, C, all);
-    }
-    HIP_TRY(hipGetLastError());
-    return MI_OK;
-}
-
-int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
-                            double* scratch, double* all, void* stream)
-{
-    if (!comm || !scratch || !all || world == 0 || rank >= world) return fail(MI_ERR_BAD_ARG, "allgather_draws: bad communicator / buffers / rank");
-    Rccl* r = rccl();
-    if (!r) return fail(MI_ERR_UNSUPPORTED, "allgather_draws: librccl.so could not be loaded");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint64_t rows = n_keep * d;
-    uint64_t c0 = 0, nl = 0;
-    mi_mcmc_shard_bounds(C, world, rank, &c0, &nl);
-    if (nl > 0 && !local) return fail(MI_ERR_BAD_ARG, "allgather_draws: local_draws is required for a non-empty shard");
-    int e = r->group_start();
-    for (uint32_t q = 0; q < world && e == 0; ++q) {       // ragged shards: one broadcast per rank, grouped into one launch
-        uint64_t qc0 = 0, qn = 0;
-        mi_mcmc_shard_bounds(C, world, q, &qc0, &qn);
-        if (qn == 0) continue;
-        e = r->broadcast(q == rank ? local : nullptr, scratch + rows * qc0, (size_t)(rows * qn), 8 /* ncclDouble */, (int)q, comm, st);
-    }
-    const int e2 = r->group_end();
-    if (e != 0 || e2 != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e ? e : e2) : "error");
-    return mi_mcmc_merge_shards(scratch, world, n_keep, d, C, all, stream);
-}
-
-int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
-{
-    if (!kdc || !out) return fail(MI_ERR_BAD_ARG, "null buffer");
-    for (uint64_t c = 0; c < C; ++c)
-        for (uint64_t j = 0; j < d; ++j)
-            for (uint64_t i = 0; i < n_keep; ++i)
-                out[(c * d + j) * n_keep + i] = kdc[(i * d + j) * C + c];
-    return MI_OK;
-}
-
-}  // extern "C"
-
-// ------------------------------------------------------------------ diagnostics
-namespace {
-
-__global__ void probe_mfma_kernel(const double* A, const double* B, const double* Cin, double* D)
-{
-    const int l = threadIdx.x;
-    const double a = A[(l & 15) * 4 + (l >> 4)];       // A[i][k], 16x4 row-major
-    const double b = B[(l >> 4) * 16 + (l & 15)];      // B[k][j], 4x16 row-major
-    mi::double4_t c;
-    for (int r = 0; r < 4; ++r) c[r] = Cin[((l >> 4) + 4 * r) * 16 + (l & 15)];
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
-}
-
-__global__ void probe_math_kernel(int fn, const double* x, uint64_t n, double* out, double* out2)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0, c = 0.0;
-    switch (fn) {
-    case 0: s = mi::det_exp(x[i]); break;
-    case 1: s = mi::det_log(x[i]); break;
-    case 2: mi::det_sincos2pi(x[i], s, c); break;
-    case 3: s = mi::softplus(x[i]); break;
-    case 4: s = mi::sigmoid(x[i]); break;
-    default: s = __builtin_nan("");
-    }
-    out[i] = s;
-    out2[i] = c;
-}
-
-__global__ void probe_normals_kernel(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out)
-{
-    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t nslots = 4 * ((d + 7) / 8);
-    if (slot >= nslots) return;
-    const uint64_t b = slot / 4, j = slot % 4;
-    const uint64_t i0 = 8 * b + j, i1 = i0 + 4;
-    double z0, z1;
-    mi::rng_normal_pair(seed, chain, draw, (uint32_t)slot, stream, z0, z1);
-    if (i0 < d) out[i0] = z0;
-    if (i1 < d) out[i1] = z1;
-}
-
-__global__ void probe_uniform_kernel(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out)
-{
-    out[0] = mi::rng_uniform(seed, chain, draw, slot);
-}
-
-// fp64 throughput ceilings: 8 independent accumulators per wave, no memory traffic.
-__global__ __launch_bounds__(256) void peak_mfma_kernel(int iters, double* sink)
-{
-    mi::double4_t acc[8];
-    for (int t = 0; t < 8; ++t) acc[t] = mi::double4_t{0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-    }
-    double s = 0.0;
-    for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-    if (s == 12345.678) sink[0] = s;
-}
-
-// cycles-per-MFMA probe: NACC independent accumulators per wave, optional LDS operand fetch
-template <int NACC, bool USE_LDS>
-__global__ __launch_bounds__(256) void mfma_cycles_kernel(int iters, unsigned long long* cyc, double* sink)
-{
-    __shared__ double lds[64 * 64];
-    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) lds[i] = 1.0 + i * 1e-9;
-    __syncthreads();
-    mi::double4_t acc[NACC];
-    for (int t = 0; t < NACC; ++t) acc[t] = mi::double4_t{0.0, 0.0, 0.0, 0.0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int t = 0; t < NACC; ++t) {
-            if (USE_LDS) a = lds[((it + t) & 63) * 64 + lane];
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
-    }
-    const unsigned long long t1 = clock64();
-    double s = 0.0;
-    for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-    if (s == 12345.678) sink[0] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
-}
-
-__global__ __launch_bounds__(256) void peak_fma_kernel(int iters, double* sink)
-{
-    double acc[16];
-    for (int t = 0; t < 16; ++t) acc[t] = threadIdx.x * 1e-3 + t;
-    const double a = 1.0000001, b = 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = __builtin_fma(acc[t], a, b);
-    }
-    double s = 0.0;
-    for (int t = 0; t < 16; ++t) s += acc[t];
-    if (s == 12345.678) sink[0] = s;
-}
-
-}  // namespace
-
-extern "C" {
-
-int mi_probe_mfma_f64(const double* A, const double* B, const double* Cin, double* D)
-{
-    if (!A || !B || !Cin || !D) return fail(MI_ERR_BAD_ARG, "null buffer");
-    DevBuf a, b, c, dd;
-    HIP_TRY(a.alloc(64 * 8)); HIP_TRY(b.alloc(64 * 8)); HIP_TRY(c.alloc(256 * 8)); HIP_TRY(dd.alloc(256 * 8));
-    HIP_TRY(hipMemcpy(a.p, A, 64 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b.p, B, 64 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c.p, Cin, 256 * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, 0, a.as<double>(), b.as<double>(), c.as<double>(), dd.as<double>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(D, dd.p, 256 * 8, hipMemcpyDeviceToHost));
-    return MI_OK;
-}
-
-int mi_probe_math(int fn, const double* x, uint64_t n, double* out, double* out2)
-{
-    if (!x || !out || !out2) return fail(MI_ERR_BAD_ARG, "null buffer");
-    DevBuf dx, d1, d2;
-    HIP_TRY(dx.alloc(n * 8)); HIP_TRY(d1.alloc(n * 8)); HIP_TRY(d2.alloc(n * 8));
-    HIP_TRY(hipMemcpy(dx.p, x, n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(probe_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, dx.as<double>(), n, d1.as<double>(), d2.as<double>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d1.p, n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out2, d2.p, n * 8, hipMemcpyDeviceToHost));
-    return MI_OK;
-}
-
-int mi_probe_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out)
-{
-    if (!out || d == 0) return fail(MI_ERR_BAD_ARG, "bad args");
-    DevBuf o;
-    HIP_TRY(o.alloc(d * 8));
-    const uint64_t nslots = 4 * ((d + 7) / 8);
-    hipLaunchKernelGGL(probe_normals_kernel, dim3((unsigned)((nslots + 63) / 64)), dim3(64), 0, 0, seed, chain, draw, stream, d, o.as<double>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, o.p, d * 8, hipMemcpyDeviceToHost));
-    return MI_OK;
-}
-
-int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out)
-{
-    if (!out) return fail(MI_ERR_BAD_ARG, "null buffer");
-    DevBuf o;
-    HIP_TRY(o.alloc(8));
-    hipLaunchKernelGGL(probe_uniform_kernel, dim3(1), dim3(1), 0, 0, seed, chain, draw, slot, o.as<double>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, o.p, 8, hipMemcpyDeviceToHost));
-    return MI_OK;
-}
-
-// mode: waves per SIMD (1,2,4,8) ; returns shader cycles per MFMA per wave and wall TFLOP/s
-int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cycles_per_mfma, double* tflops_out)
-{
-    if (!cycles_per_mfma || !tflops_out || iters <= 0) return fail(MI_ERR_BAD_ARG, "bad args");
-    DevBuf sink, cyc;
-    HIP_TRY(sink.alloc(8)); HIP_TRY(cyc.alloc(8));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    const int grid = 256 * waves_per_simd;      // 256-thread blocks: 1 wave per SIMD each
-    const int nacc_req = (use_lds >> 8) & 0xff;  // independent accumulator chains per wave (1, 2, 4; default 8)
-    const int nacc = (nacc_req == 1 || nacc_req == 2 || nacc_req == 4) ? nacc_req : 8;
-    for (int rep = 0; rep < 2; ++rep) {
-        HIP_TRY(hipEventRecord(e0, 0));
-        if (nacc == 1) hipLaunchKernelGGL((mfma_cycles_kernel<1, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
-        else if (nacc == 2) hipLaunchKernelGGL((mfma_cycles_kernel<2, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
-        else if (nacc == 4) hipLaunchKernelGGL((mfma_cycles_kernel<4, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
-        else if (use_lds & 1) hipLaunchKernelGGL((mfma_cycles_kernel<8, true>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
-        else hipLaunchKernelGGL((mfma_cycles_kernel<8, false>), dim3(grid), dim3(256), 0, 0, iters, cyc.as<unsigned long long>(), sink.as<double>());
-        HIP_TRY(hipEventRecord(e1, 0));
-        HIP_TRY(hipEventSynchronize(e1));
-    }
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long c = 0;
-    HIP_TRY(hipMemcpy(&c, cyc.p, 8, hipMemcpyDeviceToHost));
-    *cycles_per_mfma = (double)c / ((double)iters * nacc);
-    *tflops_out = (double)grid * 4 * iters * (double)nacc * 2048.0 / (ms * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return MI_OK;
-}
-
-int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out)
-{
-    if (!tflops_out || iters <= 0) return fail(MI_ERR_BAD_ARG, "bad args");
-    DevBuf sink;
-    HIP_TRY(sink.alloc(8));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    const int grid = 256 * 8;   // 8 workgroups (32 waves) per CU
-    for (int rep = 0; rep < 2; ++rep) {
-        HIP_TRY(hipEventRecord(e0, 0));
-        if (use_mfma) hipLaunchKernelGGL(peak_mfma_kernel, dim3(grid), dim3(256), 0, 0, iters, sink.as<double>());
-        else hipLaunchKernelGGL(peak_fma_kernel, dim3(grid), dim3(256), 0, 0, iters, sink.as<double>());
-        HIP_TRY(hipEventRecord(e1, 0));
-        HIP_TRY(hipEventSynchronize(e1));
-    }
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    const double waves = (double)grid * 4;
-    const double flop = use_mfma ? waves * iters * 8.0 * (16.0 * 16 * 4 * 2) : waves * iters * 16.0 * 64 * 2;
-    *tflops_out = flop / (ms * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return MI_OK;
 }
 
 }  // extern "C"
