@@ -17,6 +17,8 @@ struct SmallParams;
 
 // nt = ceil(d / 16) in {1, 2, 3..4, 5..8}; general: bounds and / or diagonal precond; dense_m: dense precond (nt <= 4)
 int launch_hmc_gauss(const HmcParams& prm, int nt, bool general, bool dense_m, hipStream_t st);
+int launch_hmc_gauss_general(const HmcParams& prm, int nt, hipStream_t st);      // hmc_general_launch.hip
+int launch_hmc_gauss_dense_m(const HmcParams& prm, int nt, hipStream_t st);      // hmc_dense_launch.hip
 // plain case with nt = 8 (64 < d <= 128) when the chains do not fill the chip at two waves per SIMD (strong scaling):
 // shape 1 = one wave per SIMD (hmc_gauss_mfma_kernel<8, 4>); hmc_split.hpp: 2 = two waves per 16-chain tile, 3 = four waves per
 // tile at two waves per SIMD, 4 = four waves per tile at one wave per SIMD
@@ -27,6 +29,8 @@ int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
 // the plain case (unbounded, identity precond_mat) with register-carried leaf state (nuts_reg.hpp): the default NUTS kernel
 int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);
+int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
+int launch_nuts_gauss_dense_m(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_dense_launch.hip
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);
 // one lane per chain, d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp); algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc
 int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st);

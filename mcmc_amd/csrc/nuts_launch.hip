@@ -1,22 +1,12 @@
-// nuts_launch.hip -- translation unit of the NUTS MFMA kernels (nuts_async.hpp, lock-step predecessor nuts_dense.hpp)
-#include "nuts_async.hpp"
+// nuts_launch.hip -- translation unit of the NUTS MFMA kernels of the plain case (nuts_reg.hpp, nuts_async.hpp, lock-step predecessor
+// nuts_dense.hpp); the bounded / preconditioned variants compile in nuts_general_launch.hip and nuts_dense_launch.hip
+#include "nuts_async_launch.hpp"
 #include "nuts_reg.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
 
 namespace mi {
 namespace {
-
-template <int NT, bool GENERAL, bool DENSE_M>
-int async(const NutsParams& prm, uint32_t batch, hipStream_t st)
-{
-    const size_t lds = ((size_t)NT * 4 * NT * 64 * ((DENSE_M && NT <= 4) ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double)
-                     + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
-    auto kern = nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
-    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
-    return (int)hipGetLastError();
-}
 
 // the plain case with register-carried leaf state (nuts_reg.hpp): the default kernel
 template <int NT>
@@ -44,8 +34,8 @@ int lockstep(const NutsParams& prm, hipStream_t st)
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, bool ls, uint32_t batch, hipStream_t st)
 {
     if (batch < 1) batch = 1;
-    if (dense_m) return MI_DISPATCH_NT(nt, (async<1, true, true>(prm, batch, st)), (async<2, true, true>(prm, batch, st)), (async<4, true, true>(prm, batch, st)), (async<8, true, true>(prm, batch, st)));
-    if (gen) return MI_DISPATCH_NT(nt, (async<1, true, false>(prm, batch, st)), (async<2, true, false>(prm, batch, st)), (async<4, true, false>(prm, batch, st)), (async<8, true, false>(prm, batch, st)));
+    if (dense_m) return launch_nuts_gauss_dense_m(prm, nt, batch, st);       // nuts_dense_launch.hip
+    if (gen) return launch_nuts_gauss_general(prm, nt, batch, st);          // nuts_general_launch.hip
     if (ls) return MI_DISPATCH_NT(nt, lockstep<1>(prm, st), lockstep<2>(prm, st), lockstep<4>(prm, st), lockstep<8>(prm, st));
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));
 }
