@@ -99,13 +99,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     // load (a scratch reload waits behind every store in flight: vmcnt is in order).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * ((size_t)WS_NVEC * NS * 512);
-    // [wave][vector][lane][slice]: a lane's NS values of a vector are one contiguous 16-byte-aligned row, moved 16 bytes per
-    // instruction, and a lane that is masked off touches no cache line at all.  With [vector][slice][lane] every access moved
-    // whole 128-byte lines of 16 chains although only ~9 of a wave's 16 chains are inside a tree on an average tick
-    // (25 KB per chain-leaf for 13 KB of records): config 4 went from 3.75 s to 2.03 s on this change of layout alone.
-    uint32_t lane_b = (uint32_t)lane * (uint32_t)(NS * 8);   // redefined (opaquely) at the top of every tick
-    auto wsp = [&](int v, int s) -> double* {
-        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)s * 8u));
+    // [wave][vector][chain][pair of slices][j4] in 16-byte granules: a chain's values of a vector are one contiguous block of
+    // NS * 32 bytes, its four lanes move 64 consecutive bytes per instruction, and a chain that is masked off touches no cache
+    // line at all.  With [vector][slice][lane] every access moved whole 128-byte lines of 16 chains although only ~9 of a wave's
+    // 16 chains are inside a tree on an average tick (25 KB per chain-leaf for 13 KB of records): config 4 went from 3.75 s to
+    // 2.03 s on that change of layout alone (round 1; the same happens with [vector][pair][lane], 0.87 -> 1.55 s in round 2).
+    // One row per LANE ([lane][slice], round 1) moves the same bytes with four times the cache lines per instruction: 6 % slower.
+    uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)(lane >> 4) * 16u;   // redefined (opaquely) at the top of every tick
+    auto wsp = [&](int v, int s) -> double* {                // s even: the pair (s, s + 1) of this lane
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)(s >> 1) * 64u));
     };
     auto ld_row = [&](int v, int s0, auto& dst) __attribute__((always_inline)) {      // dst[0..N) <- slices s0.. of vector v
         constexpr int N = (int)(sizeof(dst) / sizeof(double));

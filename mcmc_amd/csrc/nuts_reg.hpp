@@ -58,12 +58,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     const size_t lane_off = (size_t)j4 * C + cld;
 
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
-    // workspace: [wave][vector][lane][slice] rows, wave-uniform base + one 32-bit byte offset per access (nuts_async.hpp)
+    // workspace: [wave][vector] blocks of NS * 512 bytes, wave-uniform base + one 32-bit byte offset per access (nuts_async.hpp)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * ((size_t)WS_NVEC * NS * 512);
-    uint32_t lane_b = (uint32_t)lane * (uint32_t)(NS * 8);   // redefined (opaquely) at the top of every tick
-    auto wsp = [&](int v, int s) -> double* {
-        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)s * 8u));
+    // inside a vector: [chain][pair of slices][j4] in 16-byte granules (nuts_async.hpp: why)
+    uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)j4 * 16u;     // redefined (opaquely) at the top of every tick
+    auto wsp = [&](int v, int s) -> double* {                // s even: the pair (s, s + 1) of this lane
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)(s >> 1) * 64u));
     };
     auto ld_row = [&](int v, int s0, auto& dst) __attribute__((always_inline)) {      // dst[0..N) <- slices s0.. of vector v
         constexpr int N = (int)(sizeof(dst) / sizeof(double));
