@@ -5,9 +5,8 @@
 // /root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; the iterative leaf-indexed tree is derived in
 // nuts_dense.hpp), and the same bits.  nuts_async.hpp keeps the state of a leaf tick-local: every tick loads a start record
 // (theta, p, P theta: 3 KB per chain) and stores the leaf's record (3 KB), and the level-1 U-turn test of an odd leaf reloads
-// four vectors (4 KB) -- measured 11.3 KB of HBM traffic per chain-leaf, 3.7 TB/s (profiles/r2_c4_pmc.json): the kernel sits
-// on memory traffic, not on the matrix pipe (24 % busy).  But three leaves in four start from the RESULT OF THE PREVIOUS LEAF
-// (leaf i starts from leaf i-1 unless ctz(i) >= 2, nuts_dense.hpp), which is in registers when the tick ends.  So here:
+// four vectors (4 KB) -- measured 11.3 KB of HBM traffic per chain-leaf.  But three leaves in four start from the RESULT OF THE
+// PREVIOUS LEAF (leaf i starts from leaf i-1 unless ctz(i) >= 2, nuts_dense.hpp), which is in registers when the tick ends.  So:
 //   * (theta, p, P theta) of a chain's last leaf stay in registers across ticks; a tick loads a start record only for the
 //     lanes with li == 0 or ctz(li) >= 2;
 //   * ODD leaves never go to memory: their record is only ever the next leaf's start (registers), the second operand of
@@ -18,14 +17,16 @@
 //     leaf, in registers) against the node's first leaf (two vectors from memory, fetched together with the start records at
 //     the top of the tick) instead of four vectors in a dependent round trip per level when the node closes: the unwind of a
 //     tick (nuts.ipp:212-229) then runs on LDS scalars and a bit mask;
-//   * pending copies, edges and the top-level test of a doubling use the records in memory as before.
-#pragma once
+//   * the top-level test of a doubling (src/nuts.cpp:286-289) takes its four operands in one round trip, into the registers of
+//     the leaf state the finished doubling no longer needs;
+//   * a chain does not wait at a draw boundary: momenta are generated ahead, the epilogue runs on the spot (see "Draw
+//     boundaries" below).
+// Phase clocks of a tick (tools/nuts_prof.py, -DMI_NUTS_REG_PROF): the mat-vec, at 0.9 of the fp64 MFMA rate, is 37 % of a tick;
+// 12 of a wave's 16 chains are inside a tree on an average tick -- the rest is the spread of the chains' total work (a wave
+// ends with its slowest chain: max / mean = 1.39 over the 16 chains of a wave on configs[3], tools/nuts_balance.py).
 
 #include "nuts_async.hpp"
 
-#ifndef MI_NUTS_R_CHU
-#define MI_NUTS_R_CHU 8      // top-level U-turn test of a doubling: 4 vectors per chunk
-#endif
 #ifndef MI_NUTS_R_CHC
 #define MI_NUTS_R_CHC 16     // record copies: 2 vectors per chunk
 #endif
@@ -35,11 +36,16 @@
 
 namespace mi {
 
+// odd leaves are never stored here, so the record slot of ctz == 0 (vectors V_LEAF0 + 3 .. + 5) is free: the second momentum
+// vector and the second (prev_draw, P * prev_draw) pair
+enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
+
 template <int NT>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     constexpr int NS = 4 * NT;
     constexpr int WS_NVEC = NUTS_NVEC_ASYNC;
+    (void)refresh_batch;                                 // (the batched refresh of nuts_async.hpp; here any waiting chain triggers the phase)
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
@@ -86,41 +92,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
 
-    constexpr int CHU = (NS < MI_NUTS_R_CHU) ? NS : MI_NUTS_R_CHU;
     constexpr int CHC = (NS < MI_NUTS_R_CHC) ? NS : MI_NUTS_R_CHC;
-    auto copy_vec = [&](int vsrc, int vdst, bool pred) __attribute__((always_inline)) {
-        if (pred && live) {
-#pragma unroll
-            for (int c0 = 0; c0 < NS; c0 += CHC) {
-                double tmp[CHC];
-                ld_row(vsrc, c0, tmp);
-                st_row(vdst, c0, tmp);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    // [ (pos - neg) . p_1 >= 0 ] * [ (pos - neg) . p_2 >= 0 ], pos/neg = (t2,t1) for v=+1, (t1,t2) for v=-1; operands from the records
-    auto uturn_ok = [&](bool pred, int vt1, int vp1, int vt2, int vp2, int vdir) __attribute__((always_inline)) -> bool {
-        double q1 = 0.0, q2 = 0.0;
-        if (pred) {
-#pragma unroll
-            for (int c0 = 0; c0 < NS; c0 += CHU) {
-                double t1[CHU], p1[CHU], t2[CHU], p2[CHU];
-                ld_row(vt1, c0, t1); ld_row(vp1, c0, p1); ld_row(vt2, c0, t2); ld_row(vp2, c0, p2);
-#pragma unroll
-                for (int k = 0; k < CHU; ++k) {
-                    const double dd = (vdir > 0) ? (t2[k] - t1[k]) : (t1[k] - t2[k]);
-                    q1 = dfma(dd, p1[k], q1);
-                    q2 = dfma(dd, p2[k], q2);
-                }
-                if (CHU < NS) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
-        q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
-        return (q1 >= 0.0) && (q2 >= 0.0);
-    };
-
     // the chain's last leaf: position, momentum, P * position (MFMA B / D layout).  Loop-carried: see the header.
     double th[NS], pm[NS], w[NS];
 
@@ -202,8 +174,31 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     double alpha_val = 0.0, n_alpha_val = 0.0;
     int good_round = 0;
     uint32_t utpre = 0;          // bit l: the U-turn test of the open level-l node passed (set when the first leaf of its second half ran)
-    bool fin_pending = false;    // the draw's epilogue (dual averaging, row store) is done in the next refresh phase
-    uint32_t fin_depth = 0;
+    // Draw boundaries without waiting.  The lanes of a chain that waits at a draw boundary are dead weight in every wave-wide
+    // phase of a tick (the MFMA mat-vec alone is half of a tick), and with one refresh phase per batch of waiting chains the
+    // cohort that was refreshed together waits for its slowest member at the next boundary: 9.4 of a wave's 16 chains were
+    // inside a tree on an average tick.  What the next draw needs and does not depend on the chain's state -- the momentum
+    // (nuts.cpp:200-202), its kinetic energy (:204) and the slice uniform (:206): functions of (seed, chain, draw index) -- is
+    // therefore generated AHEAD, by a phase that serves every chain of the wave that lacks it (a phase costs a wave's time
+    // whatever the number of chains it serves), into the momentum vector the running draw does not use.  A chain that ends
+    // a draw runs the epilogue on the spot (dual averaging :294-302) and starts the next draw in the same tick; the kept row
+    // (:306-309) is written by the next phase, from a vector that stays intact meanwhile:
+    //   * prev_draw alternates between two vectors: an accepted proposal (:264-277) goes to the one that did NOT hold prev_draw
+    //     when the draw started, so that vector is, during the whole next draw, both the row still to be written and the
+    //     initial draw_pos = draw_neg (:212-213);
+    //   * mntm_pos = mntm_neg = mntm_vec (:214-215) likewise: the edges are the draw's initial vectors until a doubling has
+    //     written that side (pos_init / neg_init), no copies at the start of a draw.
+    // A chain waits (NS_NEED_DRAW) only if its next momentum is not there or its previous row is still unwritten, and any waiting
+    // chain triggers the phase: one phase per draw and chain, shared by (nearly) all 16 chains of the wave.
+    int mv = V_MNTM, mvn = V_MNTM2;          // momentum vector of the running draw / of the next one
+    int pb = 0, pb0 = 0;                     // which of the two vectors holds prev_draw now / held it when the draw started
+    bool mom_ready = false;                  // the next draw's momentum is in mvn (kinetic energy, log slice uniform: next_K, next_lu)
+    double next_K = 0.0, next_lu = 0.0;
+    bool row_pend = false, row2_pend = false;   // kept rows still to be written: draw row_draw from pvec(pb0); draw - 1 from pvec(pb)
+    uint32_t row_draw = 0;
+    bool pos_init = true, neg_init = true;
+    auto pvec = [](int b) -> int { return b ? V_PREVB : V_PREV; };
+    auto wvec = [](int b) -> int { return b ? V_WPREVB : V_WPREV; };
 
     // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
@@ -216,85 +211,105 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             li = 0;
         }
     };
-    // end of a draw (dual averaging nuts.cpp:294-302, row store :306-309) for lanes with `p`
-    auto finish_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
-        if (__ballot(p) == 0ull) return;
+    // end of a draw for lanes with `p` (dual averaging nuts.cpp:294-302; the row store :306-309 is left to the next phase)
+    auto end_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
         if (p && prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
-        if (p) fin_pending = false;
-        if (p) {
-            if (draw < n_adapt) {
+        if (__ballot(p && draw < n_adapt) != 0ull) {
+            if (p && draw < n_adapt) {
                 const double it = (double)(draw + 1);
                 h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
                 eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
                 eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
-            } else {
-                eps = eps_bar;
             }
         }
+        if (p && !(draw < n_adapt)) eps = eps_bar;
         const bool kept = p && draw >= prm.n_burnin;
         if (kept) n_acc += (uint64_t)good_round;
-        if (__ballot(kept && prm.draws != nullptr) != 0ull) {
-            if (kept && prm.draws != nullptr && live) {
-                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+        if (p) {
+            row2_pend = kept && prm.draws != nullptr;
+            draw++;
+        }
+    };
+    // kept row `idx` of lanes with `p` from workspace vector `vec`
+    auto store_row = [&](bool p, int vec, uint32_t idx) __attribute__((always_inline)) {
+        if (__ballot(p) == 0ull) return;
+        if (p && live) {
+            double* out = prm.draws + (size_t)(idx - prm.n_burnin) * d * C;
 #pragma unroll
-                for (int c0 = 0; c0 < NS; c0 += CHC) {
-                    double tmp[CHC];
-                    ld_row(V_PREV, c0, tmp);
+            for (int c0 = 0; c0 < NS; c0 += CHC) {
+                double tmp[CHC];
+                ld_row(vec, c0, tmp);
 #pragma unroll
-                    for (int k = 0; k < CHC; ++k)
-                        if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int k = 0; k < CHC; ++k)
+                    if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+    // lanes with `p` (next momentum ready, no older row pending) enter their next draw (nuts.cpp:200-219)
+    auto roll_state = [&](bool p) __attribute__((always_inline)) {
         if (p) {
-            draw++;
-            state = (draw < n_total) ? NS_NEED_DRAW : NS_DONE;
+            const int t_ = mv; mv = mvn; mvn = t_;
+            prev_K = next_K;
+            log_u = next_lu - prev_U - prev_K;            // :206
+            mom_ready = false;
+            row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
+            pb0 = pb; pos_init = true; neg_init = true;
+            uslot = 1;
+            jd = 0; n_val = 1.0; alpha_val = 0.0; n_alpha_val = 0.0; good_round = 0;
+            state = NS_TREE;
         }
     };
 
+#ifdef MI_NUTS_REG_PROF   // phase clocks of block 0, wave 0 (tools/nuts_prof.py; a variant build, never the shipped library)
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_ticks = 0, n_active = 0, n_refresh = 0, n_finblk = 0;
+    unsigned long long tmark = clock64();
+#define MI_RPROF(k) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
+#else
+#define MI_RPROF(k)
+#endif
 #pragma unroll 1
     while (__ballot(state != NS_DONE) != 0ull) {
         asm volatile("" : "+v"(lane_b));
-        // ------------------------------------------------------------ A. momentum refresh for waiting chains
-        const unsigned n_wait = __popcll(__ballot(state == NS_NEED_DRAW)) / 4;
-        const unsigned n_run = __popcll(__ballot(state == NS_TREE)) / 4;
-        if (n_wait >= refresh_batch || (n_run == 0 && n_wait > 0)) {
-            finish_draw(state == NS_NEED_DRAW && fin_pending, fin_depth);   // epilogue of the draws that just ended
-            const bool p = state == NS_NEED_DRAW;
+        MI_RPROF(7)
+        // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
+        if (__ballot(state == NS_NEED_DRAW) != 0ull) {
+#ifdef MI_NUTS_REG_PROF
+            n_refresh++;
+#endif
+            store_row(row_pend, pvec(pb0), row_draw);
+            store_row(row2_pend, pvec(pb), draw - 1u);
+            row_pend = false; row2_pend = false;
+            if (state == NS_NEED_DRAW && draw >= n_total) state = NS_DONE;
+            const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
+            const bool gen = state != NS_DONE && !mom_ready && nidx < n_total;
             double kq = 0.0;
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
-                rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+                rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
                 const double pa = (8u * b + j4 < d) ? z0 : 0.0;
-                const double pb = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                const double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
                 kq = dfma(pa, pa, kq);
-                kq = dfma(pb, pb, kq);
-                if (p && live) {                              // mntm_vec, mntm_pos, mntm_neg (:202, :214-215)
-                    st_pair(V_MNTM, 2 * b, pa, pb);
-                    st_pair(V_TPOS_P, 2 * b, pa, pb);
-                    st_pair(V_TNEG_P, 2 * b, pa, pb);
-                }
+                kq = dfma(pb_, pb_, kq);
+                if (gen && live) st_pair(mvn, 2 * b, pa, pb_);
             }
             kq = kq + __shfl_xor(kq, 32);
             kq = kq + __shfl_xor(kq, 16);
-            const double kk = kq / 2.0;                       // :204
-            const double lu = det_log(rng_uniform(prm.seed, chain, draw + prm.draw0, 0u));
-            copy_vec(V_PREV, V_TPOS_T, p);                    // draw_pos = draw_neg = prev_draw (:212-213)
-            copy_vec(V_PREV, V_TNEG_T, p);
-            if (p) {
-                prev_K = kk;
-                log_u = lu - prev_U - prev_K;                 // :206
-                uslot = 1;
-                jd = 0; n_val = 1.0; alpha_val = 0.0; n_alpha_val = 0.0; good_round = 0;
-                state = NS_TREE;
-            }
+            const double lu = det_log(rng_uniform(prm.seed, chain, nidx + prm.draw0, 0u));
+            if (gen) { next_K = kq / 2.0; next_lu = lu; mom_ready = true; }     // :204
+            const bool p = state == NS_NEED_DRAW;             // (all of them have a momentum now and no row pending)
+            roll_state(p);
             if (max_depth > 0) begin_doubling(p);
-            else if (p) { fin_pending = true; fin_depth = 0u; state = NS_NEED_DRAW; }   // while-loop of :227 never entered
+            else { end_draw(p, 0u); if (p) state = NS_NEED_DRAW; }              // while-loop of :227 never entered
         }
         const bool run = state == NS_TREE;
+        MI_RPROF(0)
         if (__ballot(run) == 0ull) continue;
+#ifdef MI_NUTS_REG_PROF
+        n_ticks++; n_active += __popcll(__ballot(run)) / 4;
+#endif
 
         // ------------------------------------------------------------ B. one leaf for every running chain
         auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
@@ -305,12 +320,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             const int cz = (li == 0) ? 0 : __builtin_ctz(li);
             const bool need = run && (li == 0 || cz >= 2);
             if (__ballot(need) != 0ull) {
-                const int vt = (li == 0) ? V_PREV : V_LEAF0 + 3 * cz;                    // leaf li - 2^(cz-1) sits in slot cz
-                const int vp = (li == 0) ? V_MNTM : V_LEAF0 + 3 * cz + 1;
-                const int vw = (li == 0) ? V_WPREV : V_LEAF0 + 3 * cz + 2;
+                const int vt = (li == 0) ? pvec(pb) : V_LEAF0 + 3 * cz;                  // leaf li - 2^(cz-1) sits in slot cz
+                const int vp = (li == 0) ? mv : V_LEAF0 + 3 * cz + 1;
+                const int vw = (li == 0) ? wvec(pb) : V_LEAF0 + 3 * cz + 2;
                 if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
             }
         }
+        MI_RPROF(1)
         // EAGER U-turn tests.  The test of a level-l node (nuts.ipp:226-227) uses its first leaf b and the first leaf of its second
         // half, b2 = b + 2^(l-1) (nuts_dense.hpp) -- both exist as soon as b2 does, 2^(l-1) - 1 ticks before the node closes.  An
         // even leaf li > 0 is that b2 for exactly one node, level l = ctz(li) + 1 (if l <= jd), with b = li - 2^ctz(li).  So the
@@ -355,7 +371,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
                 for (int k = 0; k < CHE; ++k) { ra_t[k] = rn_t[k]; ra_p[k] = rn_p[k]; }
             }
         }
+        MI_RPROF(2)
         matvec_mfma<NT>(afrag, th, w);
+        MI_RPROF(3)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
@@ -378,6 +396,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
             st_row(et, 0, th); st_row(ep, 0, pm);
         }
+        if (run && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))))) { if (vdir > 0) pos_init = false; else neg_init = false; }
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
         const bool cs = log_u < 1000.0 - pU - pK;        // :147
         const double dH = -(pU + pK) + H0;
@@ -387,6 +406,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         bool cref_regs = true;                           // carried proposal: this leaf (registers) ...
         int cref_t = rec_t, cref_w = rec_w;              // ... or a record (theta, P*theta)
         if (run) n_leap++;
+        MI_RPROF(4)
         // ---- unwind (nuts.ipp:212-229), per-chain leaf index
         bool failed = run && !cs;
         bool walking = run;
@@ -419,6 +439,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227, evaluated when its second operand appeared
             if (need_ut && !ok) failed = true;                                   // :229
         }
+        MI_RPROF(5)
         // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279), so that an accepted
         //      proposal goes straight to prev_draw instead of through a pending slot
         const bool keep = run && !failed;
@@ -430,7 +451,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             if (complete) {
                 uslot++;
                 take = z < cn / n_val;                                   // :263
-                if (take) { prev_U = cU; good_round = 1; }               // :264-277
+                if (take) { prev_U = cU; good_round = 1; pb = 1 - pb0; }  // :264-277; the proposal goes to pvec(pb) below
             }
         }
         // ---- pending first half: proposal and its P*theta by value, scalars to LDS
@@ -445,8 +466,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             const bool do_store = keep && (complete ? take : (pend_level > 1u)) && live;
             if (__ballot(do_store) != 0ull) {
                 const int pl = do_store ? (int)pend_level : 1;
-                const int dst_t = take ? V_PREV : V_PP0 + pl;
-                const int dst_w = take ? V_WPREV : V_PPW0 + pl;
+                const int dst_t = take ? pvec(1 - pb0) : V_PP0 + pl;
+                const int dst_w = take ? wvec(1 - pb0) : V_PPW0 + pl;
                 if (do_store && cref_regs) { st_row(dst_t, 0, th); st_row(dst_w, 0, w); }
                 const bool do_copy = do_store && !cref_regs;
                 if (__ballot(do_copy) != 0ull) {
@@ -462,24 +483,60 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
                 }
             }
         }
+        MI_RPROF(6)
+#ifdef MI_NUTS_REG_PROF
+        if (__ballot(fin) != 0ull) n_finblk++;
+#endif
         if (__ballot(fin) != 0ull) {
             if (fin) { alpha_val = ca; n_alpha_val = cna; n_val = n_val + cn; }   // :246,255 ; :283
             bool s_ok = false;
-            if (__ballot(complete) != 0ull)
-                s_ok = uturn_ok(complete, V_TNEG_T, V_TNEG_P, V_TPOS_T, V_TPOS_P, 1) && complete;   // :286-289
+            if (__ballot(complete) != 0ull) {
+                const int en_t = neg_init ? pvec(pb0) : V_TNEG_T, en_p = neg_init ? mv : V_TNEG_P;
+                const int ep_t = pos_init ? pvec(pb0) : V_TPOS_T, ep_p = pos_init ? mv : V_TPOS_P;
+                // [ (pos - neg) . p_neg >= 0 ] * [ (pos - neg) . p_pos >= 0 ] (:286-289).  The leaf state of a chain whose doubling
+                // is complete is dead (the next doubling starts from prev_draw), so its registers take the four operands in
+                // ONE round trip (with chains out of step, some chain of the wave is here in three ticks out of four)
+                double x4[NS];
+                double q1 = 0.0, q2 = 0.0;
+                if (complete) {
+                    ld_row(en_t, 0, th); ld_row(en_p, 0, pm); ld_row(ep_t, 0, w); ld_row(ep_p, 0, x4);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const double dd_ = w[k] - th[k];
+                        q1 = dfma(dd_, pm[k], q1);
+                        q2 = dfma(dd_, x4[k], q2);
+                    }
+                }
+                q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
+                q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
+                s_ok = complete && (q1 >= 0.0) && (q2 >= 0.0);
+            }
             const bool more = fin && s_ok && (jd + 1 < max_depth);
             if (fin) jd = jd + 1;                                        // :284
-            begin_doubling(more);
-            if (fin && !more) { fin_pending = true; fin_depth = jd; state = NS_NEED_DRAW; }
+            const bool ended = fin && !more;
+            bool roll = false;
+            if (__ballot(ended) != 0ull) {
+                end_draw(ended, jd);
+                roll = ended && draw < n_total && mom_ready && !row_pend;
+                if (ended && !roll) state = NS_NEED_DRAW;                // the phase: its row, its next momentum, or the end of its run
+                roll_state(roll);
+            }
+            begin_doubling(more || roll);
         }
         if (run && !fin) li = li + 1;
     }
+#ifdef MI_NUTS_REG_PROF
+    if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
+        prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_refresh; prm.prof[11] = n_finblk;
+    }
+#endif
 
     if (live) {
 #pragma unroll
         for (int c0 = 0; c0 < NS; c0 += CHC) {
             double tmp[CHC];
-            ld_row(V_PREV, c0, tmp);
+            ld_row(pvec(pb), c0, tmp);
 #pragma unroll
             for (int k = 0; k < CHC; ++k)
                 if (dim_ok(c0 + k)) prm.theta[(size_t)(4 * (c0 + k)) * C + lane_off] = tmp[k];
