@@ -25,13 +25,12 @@
 // 12 of a wave's 16 chains are inside a tree on an average tick -- the rest is the spread of the chains' total work (a wave
 // ends with its slowest chain: max / mean = 1.39 over the 16 chains of a wave on configs[3], tools/nuts_balance.py).
 
+#pragma once
+
 #include "nuts_async.hpp"
 
 #ifndef MI_NUTS_R_CHC
 #define MI_NUTS_R_CHC 16     // record copies: 2 vectors per chunk
-#endif
-#ifndef MI_NUTS_R_CHE
-#define MI_NUTS_R_CHE 16     // eager U-turn operands (theta, p of the node's first leaf): slices per streamed chunk, two chunks in flight
 #endif
 
 namespace mi {
@@ -340,40 +339,37 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         const uint32_t bleaf = li - (1u << cz_i);
         const int sb = (!eager || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
         const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;           // (theta, p) of leaf b for the eager lanes
-        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w;  d = theta(b2) - theta(b) (by direction),
-        // q1 = d . p(b) fall out of the kick / drift loop, q2 = d . p(b2) out of the second kick.  The rows of leaf b stream
-        // through in chunks of CHE slices, one chunk ahead of its use.
-        double dd[NS];
+        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w;  d = theta(b2) - theta(b) (by direction).
+        // Odd leaf: b is the start state, d and q1 = d . p(b) fall out of the kick / drift loop.  Eager even leaf: the rows of leaf b
+        // are requested here and used AFTER the mat-vec (8.6 us of matrix-pipe time in which the wave has nothing else in
+        // flight), so their latency costs nothing.  q2 = d . p(b2) comes out of the second kick in both cases.
+        double dd[NS];           // d; on an eager lane it first receives theta(b) (after the loop that writes d on every lane: a lane is
+        double Lp[NS];           // either odd or eager, and the load may not be pending when the VALU writes the register); p(b)
         double q1 = 0.0, q2 = 0.0;
-        {
-            constexpr int CHE = (NS < MI_NUTS_R_CHE) ? NS : MI_NUTS_R_CHE;
-            constexpr int NCE = NS / CHE;
-            double ra_t[CHE], ra_p[CHE], rn_t[CHE], rn_p[CHE];
 #pragma unroll
-            for (int k = 0; k < CHE; ++k) { ra_t[k] = 0.0; ra_p[k] = 0.0; rn_t[k] = 0.0; rn_p[k] = 0.0; }
-            if (any_eager) { if (eager) { ld_row(eb_t, 0, ra_t); ld_row(eb_p, 0, ra_p); } }
-#pragma unroll
-            for (int c = 0; c < NCE; ++c) {
-                if (c + 1 < NCE && any_eager) { if (eager) { ld_row(eb_t, (c + 1) * CHE, rn_t); ld_row(eb_p, (c + 1) * CHE, rn_p); } }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < CHE; ++k) {
-                    const int s_ = c * CHE + k;
-                    const double p0 = pm[s_], t0 = th[s_];
-                    pm[s_] = p0 - (e_signed * w[s_]) / 2.0;
-                    th[s_] = t0 + e_signed * pm[s_];
-                    const double rt = odd ? t0 : ra_t[k], rp = odd ? p0 : ra_p[k];
-                    dd[s_] = (vdir > 0) ? (th[s_] - rt) : (rt - th[s_]);
-                    q1 = dfma(dd[s_], rp, q1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < CHE; ++k) { ra_t[k] = rn_t[k]; ra_p[k] = rn_p[k]; }
-            }
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const double p0 = pm[s_], t0 = th[s_];
+            pm[s_] = p0 - (e_signed * w[s_]) / 2.0;
+            th[s_] = t0 + e_signed * pm[s_];
+            dd[s_] = (vdir > 0) ? (th[s_] - t0) : (t0 - th[s_]);
+            q1 = dfma(dd[s_], p0, q1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (any_eager) { if (eager) { ld_row(eb_t, 0, dd); ld_row(eb_p, 0, Lp); } }
         MI_RPROF(2)
         matvec_mfma<NT>(afrag, th, w);
         MI_RPROF(3)
+        if (any_eager) {
+            if (eager) {
+                double q1e = 0.0;
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) {
+                    dd[s_] = (vdir > 0) ? (th[s_] - dd[s_]) : (dd[s_] - th[s_]);
+                    q1e = dfma(dd[s_], Lp[s_], q1e);
+                }
+                q1 = q1e;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             pm[s] = pm[s] - (e_signed * w[s]) / 2.0;
