@@ -169,8 +169,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     uint32_t li = 0;             // next leaf of that doubling
     uint32_t uslot = 0;
     int vdir = 1;
-    double e_signed = 0.0, H0 = 0.0, prev_K = 0.0, log_u = 0.0, n_val = 1.0;
-    double alpha_val = 0.0, n_alpha_val = 0.0;
+    double e_signed = 0.0, H0 = 0.0, log_u = 0.0;
+    // per-chain scalars that are touched once per doubling or per draw live in row 0 of the level table (levels start at 1)
+    // instead of registers: the kinetic energy of the draw's momentum, n (nuts.cpp:283), alpha and n_alpha (:246,255)
+    auto prev_K_ = [&]() -> double& { return lvl(0, 0); };
+    auto n_val_ = [&]() -> double& { return lvl(0, 1); };
+    auto alpha_ = [&]() -> double& { return lvl(0, 2); };
+    auto n_alpha_ = [&]() -> double& { return lvl(0, 3); };
     int good_round = 0;
     uint32_t utpre = 0;          // bit l: the U-turn test of the open level-l node passed (set when the first leaf of its second half ran)
     // Draw boundaries without waiting.  The lanes of a chain that waits at a draw boundary are dead weight in every wave-wide
@@ -206,7 +211,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             uslot++;
             vdir = (zdir <= 0.5) ? -1 : 1;
             e_signed = (double)vdir * eps;
-            H0 = prev_U + prev_K;
+            H0 = prev_U + prev_K_();
             li = 0;
         }
     };
@@ -216,7 +221,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         if (__ballot(p && draw < n_adapt) != 0ull) {
             if (p && draw < n_adapt) {
                 const double it = (double)(draw + 1);
-                h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
+                h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_() / n_alpha_()) - h_val);
                 eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
                 eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
             }
@@ -249,13 +254,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     auto roll_state = [&](bool p) __attribute__((always_inline)) {
         if (p) {
             const int t_ = mv; mv = mvn; mvn = t_;
-            prev_K = next_K;
-            log_u = next_lu - prev_U - prev_K;            // :206
+            prev_K_() = next_K;
+            log_u = next_lu - prev_U - next_K;            // :206
             mom_ready = false;
             row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
             pb0 = pb; pos_init = true; neg_init = true;
             uslot = 1;
-            jd = 0; n_val = 1.0; alpha_val = 0.0; n_alpha_val = 0.0; good_round = 0;
+            jd = 0; n_val_() = 1.0; alpha_() = 0.0; n_alpha_() = 0.0; good_round = 0;
             state = NS_TREE;
         }
     };
@@ -446,7 +451,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :261
             if (complete) {
                 uslot++;
-                take = z < cn / n_val;                                   // :263
+                take = z < cn / n_val_();                                   // :263
                 if (take) { prev_U = cU; good_round = 1; pb = 1 - pb0; }  // :264-277; the proposal goes to pvec(pb) below
             }
         }
@@ -467,14 +472,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
                 if (do_store && cref_regs) { st_row(dst_t, 0, th); st_row(dst_w, 0, w); }
                 const bool do_copy = do_store && !cref_regs;
                 if (__ballot(do_copy) != 0ull) {
-                    if (do_copy) {
-#pragma unroll
-                        for (int c0 = 0; c0 < NS; c0 += CHC) {
-                            double t1[CHC], t2[CHC];
-                            ld_row(cref_t, c0, t1); ld_row(cref_w, c0, t2);
-                            st_row(dst_t, c0, t1); st_row(dst_w, c0, t2);
-                            if (CHC < NS) __builtin_amdgcn_sched_barrier(0);
-                        }
+                    if (do_copy) {       // both rows in ONE round trip, through the registers of d and p(b) (dead since the second kick)
+                        ld_row(cref_t, 0, dd); ld_row(cref_w, 0, Lp);
+                        st_row(dst_t, 0, dd); st_row(dst_w, 0, Lp);
                     }
                 }
             }
@@ -484,7 +484,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         if (__ballot(fin) != 0ull) n_finblk++;
 #endif
         if (__ballot(fin) != 0ull) {
-            if (fin) { alpha_val = ca; n_alpha_val = cna; n_val = n_val + cn; }   // :246,255 ; :283
+            if (fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
             bool s_ok = false;
             if (__ballot(complete) != 0ull) {
                 const int en_t = neg_init ? pvec(pb0) : V_TNEG_T, en_p = neg_init ? mv : V_TNEG_P;
