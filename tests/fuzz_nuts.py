@@ -1,0 +1,50 @@
+"""Randomised parity sweep of the plain NUTS kernel (nuts_reg.hpp) against the recursive oracle: draw counts, burn-in / adaptation
+windows, tree-depth caps (0 included), chain counts around the 16-chain wave, with and without kept draws.  Bit-exact or report.
+Usage (GPU box): python tests/fuzz_nuts.py [n_cases] [seed]   (test infrastructure: it drives the oracle)"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import mcmc_amd
+from mcmc_amd import synth
+from test_gpu_parity_nuts import _oracle
+import orc
+
+
+def sweep(n_cases=40, seed=1, verbose=True):
+    rng = np.random.default_rng(seed)
+    fails = 0
+    for case in range(n_cases):
+        d = int(rng.choice([1, 3, 8, 16, 17, 33, 64, 100, 128]))
+        C = int(rng.choice([1, 5, 16, 17, 40, 64, 70]))
+        burn, keep = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+        if burn + keep == 0: keep = 1
+        adapt = int(rng.integers(0, burn + keep + 3))
+        max_depth = int(rng.choice([0, 1, 2, 3, 5, 10]))
+        eps0 = float(rng.choice([0.02, 0.1, 0.5, 1.0, 3.0]))
+        kind = str(rng.choice(["dense", "iso", "diag"]))
+        prec, kg, ko = None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+        if kind == "dense": prec, kg, ko = synth.dense_gaussian_precision(d, seed=int(rng.integers(1, 90))), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+        elif kind == "diag": prec, kg, ko = synth.ill_conditioned_diag(d, 30.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+        init = synth.initial_states(C, d, seed=int(rng.integers(1, 1000)))
+        st = mcmc_amd.default_settings(rng_seed_value=int(rng.integers(1, 10**6)), n_burnin_draws=burn, n_keep_draws=keep,
+                                       n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
+        chain0 = int(rng.integers(0, 5000))
+        g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0)
+        o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0)
+        bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+        same = lambda a, b: np.array_equal(bits(a), bits(b)) or np.array_equal(a, b, equal_nan=True)     # (NaN payloads may differ)
+        ok = (same(g_draws, o_draws) and np.array_equal(g["depth"], o["depth"]) and np.array_equal(g["n_leap"], o["n_leap"])
+              and np.array_equal(g["n_accept"], o["n_accept"]) and same(g["eps"], o["eps"]))
+        if verbose or not ok:
+            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, C=C, burn=burn, keep=keep, adapt=adapt, max_depth=max_depth, eps0=eps0, chain0=chain0), flush=True)
+        fails += 0 if ok else 1
+    return fails
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    s = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f = sweep(n, s)
+    print("mismatching cases:", f)
+    sys.exit(1 if f else 0)
