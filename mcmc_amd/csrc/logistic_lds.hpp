@@ -143,14 +143,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     // one 1 KiB piece of a block: the LDS-DMA path of a CU moves ~25 B/clk and the issuing wave stalls behind its own
     // queued pieces (measured ~320 cycles per piece when a wave issues its 9 pieces back to back), so inside the block
     // loop the pieces are issued one at a time, spread over the three phases
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto issue_piece = [&](uint32_t b, int buf, int i) __attribute__((always_inline)) {
         const int c = i * 8 + w;
         if (c < G::CHUNKS) {
-            const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + lane * 2 + (size_t)c * 128;
+            // wave-uniform source (SGPR pair) + the lane's 16 bytes as a 32-bit offset: with a 64-bit address per lane the compiler
+            // kept one VGPR pair per piece as a loop invariant, spilled them, and reloaded three inside the block loop (a scratch
+            // reload waits behind the pieces in flight: vmcnt is in order)
+            const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + (size_t)c * 128;
             const uint32_t dst = xs_lds + (uint32_t)buf * (uint32_t)(G::XBUF_PAD * sizeof(double)) + (uint32_t)c * 1024u;
             uint32_t m0_saved;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_saved) : "v"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved) : "v"(lane16), "s"(dst), "s"(src) : "memory");
         }
     };
     // schedule of the NP pieces a wave issues per block: NP_E behind every other eta MFMA group, one at the head of the
