@@ -256,6 +256,18 @@ MI_HD void rng_normal_pair(uint64_t seed, uint64_t chain, uint32_t draw, uint32_
     z1 = r * s;
 }
 
+// The same with slot = base + j, j the lane's part of the slot (lane-varying, fixed for the whole kernel) made opaque BEFORE the
+// sum: otherwise `base + j` of every unrolled call is a loop invariant of the draw loop -- one VGPR per slot, spilled, and
+// reloaded from scratch in front of every pair (a reload waits for every store in flight: vmcnt is in order).
+MI_HD void rng_normal_pair_at(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t base, uint32_t j, uint32_t stream,
+                              double& z0, double& z1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(j));
+#endif
+    rng_normal_pair(seed, chain, draw, base + j, stream, z0, z1);
+}
+
 // Canonical dimension <-> slot map: i = 8b + 4h + j (j<4, h<2) -> slot 4b + j, component h.
 // A lane of the MFMA layout owns dims {4s + j}: both halves of a pair stay in the lane.
 

@@ -439,7 +439,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
             if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
-            else rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            else rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             *z_mem(2 * b) = (8u * b + j < d) ? z0 : 0.0;
             *z_mem(2 * b + 1) = (8u * b + 4 + j < d) ? z1 : 0.0;
         }
@@ -460,7 +460,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
             if (prm.ablate & 4u) { z0 = 0.25; z1 = -0.5; }               // profiling: no RNG
-            else rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            else rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
             if constexpr (BOUNDED && !DENSE_M) {        // p = L z with a diagonal L (:158)

@@ -156,7 +156,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
         for (int b = 0; b < NSO / 2; ++b) {
             const int bb = s0 / 2 + b;                  // Philox block of the chain: dimensions 8 bb + j and 8 bb + 4 + j
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * bb + j), STREAM_NORMAL, z0, z1);
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * bb), (uint32_t)j, STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * bb + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * bb + 4 + j < d) ? z1 : 0.0;
             __builtin_amdgcn_sched_barrier(0);

@@ -159,7 +159,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             const double za = (8u * b + j < d) ? z0 : 0.0;
             const double zb = (8u * b + 4 + j < d) ? z1 : 0.0;
             double jma, jmb;
@@ -321,7 +321,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
 #pragma unroll
         for (int bb = 0; bb < NS / 2; ++bb) {           // rand_vec (:150)
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * bb + j), STREAM_NORMAL, z0, z1);
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * bb), (uint32_t)j, STREAM_NORMAL, z0, z1);
             a[2 * bb] = (8u * bb + j < d) ? z0 : 0.0;
             a[2 * bb + 1] = (8u * bb + 4 + j < d) ? z1 : 0.0;
             __builtin_amdgcn_sched_barrier(0);

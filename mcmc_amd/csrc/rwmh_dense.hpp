@@ -119,7 +119,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void rwmh_gauss_mfma_kernel(
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {              // new_draw = prev_draw + cov_mcmc_chol * rand_vec (:124-126)
             double z0, z1;
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b + j), STREAM_NORMAL, z0, z1);
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             const double za = (8u * b + j < d) ? z0 : 0.0;
             const double zb = (8u * b + 4 + j < d) ? z1 : 0.0;
             if constexpr (DENSE_C) {
