@@ -129,9 +129,24 @@ int main()
                 int(okn), size_t(dnuts.rows()), size_t(dnuts.cols()), okn ? col_mean(dnuts, 0) : 0.0, okn ? col_mean(dnuts, 1) : 0.0,
                 okn ? col_mean(dnuts, 2) : 0.0, double(s5.nuts_settings.n_accept_draws) / 600.0, dn.n_calls_grad, dn.n_calls_value);
 
-    // what the device path does not implement is refused with a reason, never run on the CPU: mcmc::rwmh with a host callback
+    // mcmc::rwmh with a host std::function (value only, ref: include/mcmc/rwmh.hpp:42-47; the call pattern of examples/eigen/rwmh_normal.cpp)
+    s5.rwmh_settings.par_scale = 0.8;
+    s5.rwmh_settings.n_burnin_draws = 500; s5.rwmh_settings.n_keep_draws = 4000;
+    iso_data_t dw;
     mcmc::Mat_t drw;
-    const bool refused = !mcmc::rwmh(initial_val, [](const mcmc::ColVec_t&, void*) { return 0.0; }, drw, nullptr, s5);
-    std::printf("rwmh with host callback refused=%d reason=\"%s\"\n", int(refused), mcmc::mi355x::last_error().c_str());
-    return (ok && ok2 && okm && okn && refused) ? 0 : 1;
+    const bool okw = mcmc::rwmh(initial_val, [](const mcmc::ColVec_t& v, void* p) {
+        static_cast<iso_data_t*>(p)->n_calls_value++;
+        double ss = 0.0;
+        for (size_t i = 0; i < size_t(v.size()); ++i) ss += v(i) * v(i);
+        return -0.5 * ss; }, drw, &dw, s5);
+    std::printf("callback rwmh ok=%d rows=%zu cols=%zu mean=%.6f %.6f %.6f acc=%.4f value_calls=%d\n", int(okw), size_t(drw.rows()), size_t(drw.cols()),
+                okw ? col_mean(drw, 0) : 0.0, okw ? col_mean(drw, 1) : 0.0, okw ? col_mean(drw, 2) : 0.0,
+                double(s5.rwmh_settings.n_accept_draws) / 4000.0, dw.n_calls_value);
+
+    // what the device path does not implement is refused with a reason, never run on the CPU: mcmc::rmhmc with host callbacks
+    mcmc::Mat_t drm;
+    const bool refused = !mcmc::rmhmc(initial_val, log_target_dens, [](const mcmc::ColVec_t&, mcmc::Cube_t*, void*) { return mcmc::Mat_t(); },
+                                      drm, &dn, nullptr, s5);
+    std::printf("rmhmc with host callbacks refused=%d reason=\"%s\"\n", int(refused), mcmc::mi355x::last_error().c_str());
+    return (ok && ok2 && okm && okn && okw && refused) ? 0 : 1;
 }

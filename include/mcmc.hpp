@@ -394,6 +394,16 @@ hmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t&
     return ok;
 }
 
+struct value_callback_ctx { const std::function<fp_t (const ColVec_t&, void*)>* fn; void* user; size_t d; };
+
+inline double value_callback_trampoline(const double* vals, double*, void* p)     // mcmc::rwmh: no gradient (rwmh.hpp:42-47)
+{
+    value_callback_ctx* ctx = static_cast<value_callback_ctx*>(p);
+    ColVec_t v(ctx->d);
+    for (size_t i = 0; i < ctx->d; ++i) v(i) = vals[i];
+    return (*ctx->fn)(v, ctx->user);
+}
+
 inline bool
 mala_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, Mat_t& draws_out, void* target_data,
           algo_settings_t* settings_inp)
@@ -473,10 +483,20 @@ rwmh_impl(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals
     // ref: src/rwmh.cpp:30-175.  par_scale and cov_mat travel in the POD mirror's step_size / precond_mat (mi_mcmc.h)
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
-    if (!mi355x::is_device_route(target_log_kernel)) {
-        mi355x::last_error() = "mcmc::rwmh: a host std::function target is not implemented on the device path (hmc, mala and nuts are); "
-                               "pass mcmc::mi355x::device_value_kernel with a mi355x::target_t (no CPU fallback)";
-        return false;
+    if (!mi355x::is_device_route(target_log_kernel)) {               // host std::function: one chain, one value callback per draw
+        const size_t d = size_t(initial_vals.size());
+        mi_settings m = flatten_common(settings);
+        m.n_burnin_draws = settings.rwmh_settings.n_burnin_draws;
+        m.n_keep_draws = settings.rwmh_settings.n_keep_draws;
+        m.step_size = settings.rwmh_settings.par_scale;
+        m.precond_mat = precond_or_null(settings.rwmh_settings.cov_mat, d);
+        value_callback_ctx ctx{&target_log_kernel, target_data, d};
+        draws_out.resize(m.n_keep_draws, d);
+        uint64_t nacc = 0;
+        const bool okc = mi_mcmc_rwmh_run_callback(initial_vals.data(), d, &value_callback_trampoline, &ctx, &m, draws_out.data(), &nacc) == MI_OK;
+        if (!okc) mi355x::last_error() = mi_mcmc_last_error();
+        if (okc && settings_inp) settings_inp->rwmh_settings.n_accept_draws = size_t(nacc);
+        return okc;
     }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);

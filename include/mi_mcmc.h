@@ -208,6 +208,12 @@ int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
 int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
                               void* target_data, const mi_settings* settings, double* draws_out,
                               uint64_t* n_accept_draws, double* step_size_out);
+/* mcmc::rwmh (ref: include/mcmc/rwmh.hpp:42-47, src/rwmh.cpp:105-151): the callback is asked for the value only (grad_out is
+ * always NULL), once per draw and once for the initial point; settings.step_size carries rwmh_settings.par_scale; identity
+ * cov_mat, unbounded, one chain. */
+int mi_mcmc_rwmh_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
+                              void* target_data, const mi_settings* settings, double* draws_out,
+                              uint64_t* n_accept_draws);
 
 /* ---- multi-GPU: one process per GPU.  Chains are independent (the reference runs one per call), so the path shards with no
  * data-path collective: rank r of world_size runs the global chains [chain0, chain0 + n_local) in its own mi_mcmc_*_run call

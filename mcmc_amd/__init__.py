@@ -61,7 +61,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -302,6 +302,11 @@ def mala_callback(initial_vals, callback, settings, target_data=None):
 
 def nuts_callback(initial_vals, callback, settings, target_data=None):
     return hmc_callback(initial_vals, callback, settings, target_data, algo="nuts")
+
+
+def rwmh_callback(initial_vals, callback, settings, target_data=None):
+    """settings.step_size carries par_scale; the callback is asked for the value only"""
+    return hmc_callback(initial_vals, callback, settings, target_data, algo="rwmh")
 
 
 # ---------------------------------------------------------------- diagnostics (GPU tests)

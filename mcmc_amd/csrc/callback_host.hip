@@ -295,6 +295,50 @@ int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
     return MI_OK;
 }
 
+// mcmc::rwmh with a host callback (rwmh.hpp:42-47: the target returns the log-density only; src/rwmh.cpp:123-151): one value
+// callback per draw.  par_scale travels in settings.step_size; identity cov_mat.
+int mi_mcmc_rwmh_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
+                              const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws)
+{
+    int rc = callback_common_checks("rwmh", initial_vals, d, cb, settings, draws_out);
+    if (rc) return rc;
+    const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
+    const double par_scale = settings->step_size;
+    enum { PREV = 0, PROP, Z, NVEC };
+    CbMachine m;
+    rc = m.init(d, NVEC, cb, target_data);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(m.vec(PREV), initial_vals, d * 8, hipMemcpyHostToDevice));
+    std::vector<double> row(d);
+    double prev_LP;
+    CB_TRY(m.value_at(PREV, &prev_LP));                  // rwmh.cpp:113
+    uint64_t n_acc = 0;
+    const uint32_t dd = (uint32_t)d;
+    for (uint64_t draw = 0; draw < n_total; ++draw) {
+        hipLaunchKernelGGL(mi::cb_normals, dim3(1), dim3(64), 0, 0, settings->rng_seed_value, 0ull, (uint32_t)draw, (uint32_t)mi::STREAM_NORMAL, dd, m.vec(Z));   // :124
+        hipLaunchKernelGGL(mi::cb_add_scaled, dim3(1), dim3(64), 0, 0, dd, par_scale, m.vec(PREV), m.vec(Z), m.vec(PROP));   // :126, cov_chol = par_scale * I
+        double prop_LP;
+        CB_TRY(m.value_at(PROP, &prop_LP));              // :128
+        if (!std::isfinite(prop_LP)) prop_LP = -INFINITY;   // :130-132
+        const double x = prop_LP - prev_LP;
+        const double comp_val = (x < 0.0) ? x : 0.0;     // std::min(0.0, x) :136
+        double z;
+        hipLaunchKernelGGL(mi::cb_uniform, dim3(1), dim3(1), 0, 0, settings->rng_seed_value, 0ull, (uint32_t)draw, 0u, m.scal.as<double>());
+        CB_TRY(m.fetch(1, &z));                          // :137
+        if (z < mi::det_exp(comp_val)) {                 // :139
+            CB_TRY(m.copy(PREV, PROP));
+            prev_LP = prop_LP;
+            if (draw >= n_burnin) ++n_acc;
+        }
+        if (draw >= n_burnin) {                          // :148-150
+            HIP_TRY(hipMemcpy(row.data(), m.vec(PREV), d * 8, hipMemcpyDeviceToHost));
+            for (uint64_t j = 0; j < d; ++j) draws_out[(draw - n_burnin) + j * n_keep] = row[j];
+        }
+    }
+    if (n_accept_draws) *n_accept_draws = n_acc;
+    return MI_OK;
+}
+
 int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb cb, void* target_data,
                               const mi_settings* settings, double* draws_out, uint64_t* n_accept_draws, double* step_size_out)
 {

@@ -69,6 +69,10 @@ def test_example_runs_on_the_gpu(tmp_path):
     assert mm, out.stdout
     assert 0.2 < float(mm.group(1)) <= 1.0 and 1.5 < float(mm.group(2)) < 3.2 and 1.5 < float(mm.group(3)) < 3.2
     assert "refused=1" in out.stdout and "not implemented on the device path" in out.stdout      # a reachable reason, no silent false
+    mm = re.search(r"callback rwmh ok=1 rows=4000 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) value_calls=(\d+)", out.stdout)
+    assert mm, out.stdout                                       # mcmc::rwmh with the host std::function (value only)
+    assert np.abs([float(mm.group(i)) for i in (1, 2, 3)]).max() < 0.3 and 0.2 < float(mm.group(4)) <= 1.0
+    assert int(mm.group(5)) == 4500 + 1                         # one value call per draw + the initial point (src/rwmh.cpp:113,128)
     # mcmc::mala / mcmc::nuts with the host std::function (the reference's own example call pattern)
     mm = re.search(r"callback mala ok=1 rows=1000 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+)", out.stdout)
     assert mm, out.stdout
@@ -100,7 +104,7 @@ def test_host_callback_route_matches_oracle_and_fused_kernel_bitwise():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,d", [("iso", 3), ("dense", 9), ("diag", 17)])
-def test_mala_and_nuts_host_callback_routes_match_oracle_and_device_kernels_bitwise(kind, d):
+def test_mala_rwmh_and_nuts_host_callback_routes_match_oracle_and_device_kernels_bitwise(kind, d):
     """mcmc::mala / mcmc::nuts with a host callback (ref: mala.hpp:66-73, nuts.hpp:65-72): the oracle's own target function is
     the callback; draws, accept counts and the callback pattern of the reference (mala: 3 gradient + 1 value per draw) agree
     with the oracle and with the fused device kernels."""
@@ -118,6 +122,16 @@ def test_mala_and_nuts_host_callback_routes_match_oracle_and_device_kernels_bitw
     assert np.array_equal(np.asarray(draws_cb), o_draws) and nacc_cb == o["n_accept"] and 0 < nacc_cb
     assert tgt.c.n_grad_calls == t2.c.n_grad_calls == 3 * 80 and tgt.c.n_value_calls == t2.c.n_value_calls == 81
     f_draws, f = mcmc_amd.mala(kg, x0[None, :], st, prec=prec)
+    assert np.array_equal(f_draws[:, :, 0], o_draws)
+    # rwmh (value callbacks only)
+    st = mcmc_amd.default_settings(rng_seed_value=41, n_burnin_draws=20, n_keep_draws=60, step_size=0.25)
+    tgt = orc.TargetSpec(ko, d, prec=prec, W=4)
+    draws_cb, nacc_cb = mcmc_amd.rwmh_callback(x0, cb, st, target_data=C.addressof(tgt.c))
+    t2 = orc.TargetSpec(ko, d, prec=prec, W=4)
+    o_draws, o = orc.run_chain(orc.ALGO_RWMH, t2, x0, orc.make_settings(seed=41, n_burnin=20, n_keep=60, step=0.25, W=4))
+    assert np.array_equal(np.asarray(draws_cb), o_draws) and nacc_cb == o["n_accept"] and 0 < nacc_cb
+    assert tgt.c.n_grad_calls == t2.c.n_grad_calls == 0 and tgt.c.n_value_calls == t2.c.n_value_calls == 81
+    f_draws, f = mcmc_amd.rwmh(kg, x0[None, :], st, prec=prec)
     assert np.array_equal(f_draws[:, :, 0], o_draws)
     # nuts, dual averaging on
     st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=15, n_keep_draws=25, n_adapt_draws=15, max_tree_depth=6)
