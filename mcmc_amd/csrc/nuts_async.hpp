@@ -402,10 +402,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         }
     };
 
+#ifdef MI_NUTS_ASYNC_PROF     // phase clocks of block 0, wave 0 (tools/nuts_prof.py; a variant build, never the shipped library)
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ticks = 0, n_active = 0, n_refresh = 0, n_finblk = 0;
     unsigned long long tmark = clock64();
 #define MI_PROF(k) { const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
+#define MI_PROF_COUNT(stmt) stmt
+#else
+#define MI_PROF(k)
+#define MI_PROF_COUNT(stmt)
+#endif
 #pragma unroll 1
     while (__ballot(state != NS_DONE) != 0ull) {
         asm volatile("" : "+v"(lane_b));
@@ -414,7 +420,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         const unsigned n_wait = __popcll(__ballot(state == NS_NEED_DRAW)) / 4;
         const unsigned n_run = __popcll(__ballot(state == NS_TREE)) / 4;
         if (n_wait >= refresh_batch || (n_run == 0 && n_wait > 0)) {
-            n_refresh++;
+            MI_PROF_COUNT(n_refresh++;)
             finish_draw(state == NS_NEED_DRAW && fin_pending, fin_depth);   // epilogue of the draws that just ended
             const bool p = state == NS_NEED_DRAW;
             double kq = 0.0;
@@ -497,7 +503,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 }
             }
             MI_PROF(1)
-            n_ticks++; n_active += __popcll(__ballot(run)) / 4;
+            MI_PROF_COUNT(n_ticks++; n_active += __popcll(__ballot(run)) / 4;)
             // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
             double xl[GENERAL ? NS : 1];
             auto kick_l = [&]() __attribute__((always_inline)) {
@@ -677,7 +683,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         }
         MI_PROF(5)
         if (__ballot(fin) != 0ull) {
-            n_finblk++;
+            MI_PROF_COUNT(n_finblk++;)
             if (fin) { alpha_val = ca; n_alpha_val = cna; n_val = n_val + cn; }   // :246,255 ; :283
             bool s_ok = false;
             if (__ballot(complete) != 0ull) {
@@ -708,11 +714,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
         if (run && !fin) li = li + 1;
         MI_PROF(6)
     }
+#ifdef MI_NUTS_ASYNC_PROF
     if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0)
     {
         for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
         prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_refresh; prm.prof[11] = n_finblk;
     }
+#endif
 
     if (live) {
         double tmp[NS];

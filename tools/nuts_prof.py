@@ -1,3 +1,5 @@
+"""Phase clocks of the NUTS kernels (one wave of workgroup 0): `make -C mcmc_amd/csrc prof`, then on the GPU box
+   MI_MCMC_LIB=mcmc_amd/libmi_mcmc_prof.so MI_NUTS_PROF=1 [MI_NUTS_HINT=9 for the tick-local kernel] python tools/nuts_prof.py"""
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch, mcmc_amd
