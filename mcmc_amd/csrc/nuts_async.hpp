@@ -25,7 +25,7 @@
 // chunk sizes of the two places where several vectors are in flight per chunk (a chunk that does not fit the 256 arch VGPRs
 // is spilled to scratch, and a scratch reload waits behind every store of the tick: vmcnt is in order)
 #ifndef MI_NUTS_CHF
-#define MI_NUTS_CHF 8      // end-of-doubling U-turn dots: 4 vectors
+#define MI_NUTS_CHF 32     // end-of-doubling U-turn dots: 4 vectors, one round trip (the tick-local state is dead there)
 #endif
 #ifndef MI_NUTS_CHC
 #define MI_NUTS_CHC 16     // proposal copies: 2 vectors
