@@ -76,6 +76,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // bit s: slice s (dims 4s .. 4s+3) has a bounded dimension (wave-uniform).  The log-Jacobian sum of box_log_kernel
+    // (log_jacobian.hpp:36-57, a scalar loop over i ascending = 4 shuffles per slice) runs over those slices only, and not at all
+    // without vals_bound (nuts.cpp:84-95 adds the term only then)
+    uint32_t bslices = 0;
+    if constexpr (GENERAL) {
+        if (prm.vals_bound)
+            for (int s_ = 0; s_ < 4 * NT; ++s_) {
+                const bool any = lds_bt[4 * s_] != 1 || lds_bt[4 * s_ + 1] != 1 || lds_bt[4 * s_ + 2] != 1 || lds_bt[4 * s_ + 3] != 1;
+                bslices |= (any ? 1u : 0u) << s_;
+            }
+        bslices = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslices);
+    }
     const int j4 = lane >> 4;
     const int cw = wave * 16 + (lane & 15);
     const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
@@ -210,6 +222,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             double lj = 0.0;                             // log_jacobian.hpp:36-57: scalar loop, i ascending
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
+                if (((bslices >> s) & 1u) == 0u) continue;
                 const int i0 = 4 * s;
                 const double term = box_log_jacobian_term(th[s], lds_bt[i0 + j4], lds_lb[i0 + j4], lds_ub[i0 + j4]);
 #pragma unroll
@@ -555,6 +568,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 double lj = 0.0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
+                    if (((bslices >> s) & 1u) == 0u) continue;
                     const int i0 = 4 * s;
                     const double term = box_log_jacobian_term(th[s], lds_bt[i0 + j4], lds_lb[i0 + j4], lds_ub[i0 + j4]);
 #pragma unroll
