@@ -306,6 +306,20 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
+    // bit s: slice s (dims 4s .. 4s+3) has a bounded dimension (wave-uniform).  The transforms of a slice without one are the
+    // identity (J = 1, no log-Jacobian term), and the branch around them is uniform -- what matters is the code that is NOT
+    // fetched: the d = 128 general kernel is 1 MB of instructions (four transcendental-laden cases per slice and use), far beyond
+    // the 64 KB instruction cache, and ran 2.9 times slower than the plain kernel with a diagonal precond_mat alone.
+    uint32_t bslices = 0;
+    if constexpr (BOUNDED) {
+        if (prm.vals_bound)
+            for (int s_ = 0; s_ < 4 * NT; ++s_) {
+                const bool any = lds_bt[4 * s_] != 1 || lds_bt[4 * s_ + 1] != 1 || lds_bt[4 * s_ + 2] != 1 || lds_bt[4 * s_ + 3] != 1;
+                bslices |= (any ? 1u : 0u) << s_;
+            }
+        bslices = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslices);
+    }
+    auto slice_bounded = [&](int s) -> bool { return ((bslices >> s) & 1u) != 0u; };
     const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
     const bool live = cl < prm.C;
     const uint64_t cld = live ? cl : prm.C - 1;       // clamped index for loads
@@ -322,7 +336,6 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     // The last accepted (theta, P*theta) lives in HBM (prm.theta / prm.wsave): written on accept,
     // re-read on reject, so a rejection costs 2 KiB of traffic per chain instead of 128 VGPRs.
     double th[NS], pm[NS], w[NS];
-    double kw[BOUNDED ? NS : 1];   // BOUNDED: inv_jacobian * (P x), what the momentum kick uses (hmc.cpp:122)
     double xs[BOUNDED ? NS : 1];   // BOUNDED: x = inv_transform(theta), where the target is evaluated (hmc.cpp:108)
     // addresses = wave-uniform row base (SGPR) + one per-lane element offset (VGPR)
     const size_t lane_off = (size_t)j * C + cld;
@@ -346,21 +359,27 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = 4 * s + j;
-                xs[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                if (slice_bounded(s)) xs[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                else xs[s] = ((uint32_t)i < d) ? th[s] : 0.0;
             }
             matvec_mfma<NT>(afrag, xs, w);
         } else {
             matvec_mfma<NT>(afrag, th, w);
         }
     };
-    auto refresh_kw = [&]() __attribute__((always_inline)) {
+    // BOUNDED: t = (eps * ([J] grad)) / 2 at the current (theta, w), grad = -w (hmc.cpp:122: jacob_matrix * grad_obj, a dense product).
+    // A transient of the kick: nothing of it lives across the mat-vec.
+    auto kick_terms = [&](double (&t)[BOUNDED ? NS : 1]) __attribute__((always_inline)) {
         if constexpr (BOUNDED) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = 4 * s + j;
-                kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];   // J_ii * grad_i (gemv with a diagonal J)
+                if (slice_bounded(s)) t[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];   // J_ii * grad_i (gemv with a diagonal J)
+                else t[s] = 1.0 * w[s];
             }
-            if (prm.vals_bound) dense_product_poison<NS>(w, kw, j, d);   // jacob_matrix * grad_obj is a dense product (:122)
+            if (prm.vals_bound) dense_product_poison<NS>(w, t, j, d);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) t[s] = (eps * t[s]) / 2.0;
         }
     };
     // K = p . (Minv p) / 2 (hmc.cpp:160,184)
@@ -391,6 +410,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             double lj = 0.0;                             // log_jacobian.hpp:36-57: scalar loop, i ascending
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
+                if (!slice_bounded(s)) continue;
                 const int i0 = 4 * s;
                 const int bt = lds_bt[4 * s + j];
                 const double term = box_log_jacobian_term(th[s], bt, lds_lb[4 * s + j], lds_ub[4 * s + j]);
@@ -477,7 +497,6 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         }
 #endif
         const double prev_K = kinetic();                // hmc.cpp:160
-        refresh_kw();
 
         if constexpr (!BOUNDED) {
             // hmc.cpp:164-176, grad = -w.  The second half-step of step k and the first half-step of step k+1 use the same
@@ -512,29 +531,48 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                 }
             }
         } else {
-#pragma unroll 1
-        for (uint32_t k = 0; k < prm.n_leap_steps; ++k) {   // hmc.cpp:164-176, grad = -w
-            if ((prm.ablate & 3u) != 1u) {
+            // The same loop shape for the general variant: the second half-step of step k and the first of step k+1 are at the
+            // same (theta, w), so (eps * [J] grad) / 2 is formed once and subtracted twice (the reference's two roundings), and
+            // neither it nor Minv p lives across the mat-vec (as loop-carried arrays they spilled: 290 ms for configs[1]'s shape).
+            const uint32_t L = prm.n_leap_steps;
+            auto drift_step = [&]() __attribute__((always_inline)) {           // theta += eps * Minv p (:171)
                 double mp[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;   // first half-step (:122)
                 if constexpr (DENSE_M) {
-                    matvec_m2<NT>(afrag_minv, pm, mp);                    // inv_precond_matrix * new_mntm (:171)
+                    matvec_m2<NT>(afrag_minv, pm, mp);                    // inv_precond_matrix * new_mntm
                 } else {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j] * pm[s];
-                    dense_product_poison<NS>(pm, mp, j, d);                 // inv_precond_matrix * new_mntm (:171)
+                    dense_product_poison<NS>(pm, mp, j, d);
                 }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * mp[s];  // theta += eps * Minv p (:171)
-            }
-            if ((prm.ablate & 3u) != 2u) gradient();
-            refresh_kw();
-            if ((prm.ablate & 3u) != 1u) {
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * mp[s];
+            };
+            if (L > 0) {
+                double t[NS];
+                kick_terms(t);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (eps * kw[BOUNDED ? s : 0]) / 2.0;   // second half-step (:175)
+                for (int s = 0; s < NS; ++s) pm[s] = pm[s] - t[s];          // first half-step of step 0 (:122,167)
+                drift_step();
             }
-        }
+#pragma unroll 1
+            for (uint32_t k = 0; k + 1 < L; ++k) {
+                gradient();
+                double t[NS];
+                kick_terms(t);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    pm[s] = pm[s] - t[s];                                   // second half-step of step k (:175)
+                    pm[s] = pm[s] - t[s];                                   // first half-step of step k+1 (:167)
+                }
+                drift_step();
+            }
+            if (L > 0) {
+                gradient();
+                double t[NS];
+                kick_terms(t);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) pm[s] = pm[s] - t[s];          // second half-step of the last step
+            }
         }
         if constexpr (BOUNDED) { if (prm.n_leap_steps == 0) gradient(); }   // xs must match theta for the energy
 
@@ -564,7 +602,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                     const uint32_t dim = 4 * s + j;
                     // bounded runs store inv_transform(row) (the reference does it in the epilogue, :211-218)
                     if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] =
-                        BOUNDED ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
+                        (BOUNDED && slice_bounded(s)) ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
                 }
             }
         }
@@ -575,7 +613,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;
             if (dim < d) prm.theta[(size_t)dim * C + cl] =
-                BOUNDED ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
+                (BOUNDED && slice_bounded(s)) ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
         }
     }
     if (live && j == 0) {
