@@ -170,7 +170,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = 4 * s + j4;
-                xs_[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                if ((bslices >> s) & 1u) xs_[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                else xs_[s] = ((uint32_t)i < d) ? th[s] : 0.0;      // (uniform branch: the transform code of an unbounded slice is never fetched)
             }
             matvec_mfma<NT>(afrag, xs_, w);
         }
@@ -181,7 +182,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int i = 4 * s + j4;
-                kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                if ((bslices >> s) & 1u) kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                else kw[s] = 1.0 * w[s];
             }
             if (prm.vals_bound) dense_product_poison<NS>(w, kw, j4, d);   // jacob_matrix * grad_obj is a dense product
 #pragma unroll
@@ -525,7 +527,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const int i = 4 * s + j4;
-                        kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                        if ((bslices >> s) & 1u) kw[s] = box_inv_jacobian(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) * w[s];
+                        else kw[s] = 1.0 * w[s];
                     }
                     if (prm.vals_bound) dense_product_poison<NS>(w, kw, j4, d);
 #pragma unroll
@@ -555,7 +558,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int i = 4 * s + j4;
-                    xl[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                    if ((bslices >> s) & 1u) xl[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
+                    else xl[s] = ((uint32_t)i < d) ? th[s] : 0.0;
                 }
                 matvec_mfma<NT>(afrag, xl, w);
             } else {
