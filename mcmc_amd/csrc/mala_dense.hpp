@@ -208,7 +208,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
             qa = dfma(xa, sinv * xa, qa);                                 // :39
             const double xb = tp[s] - mean_prev;
             qb = dfma(xb, sinv * xb, qb);
-            if constexpr (GENERAL) ld_term[s] = 2.0 * det_log(__builtin_sqrt(sig_p));   // LOG_DET via CHOL_LOWER, term i
+            if constexpr (GENERAL) { if (vb) ld_term[s] = 2.0 * det_log(__builtin_sqrt(sig_p)); }   // LOG_DET via CHOL_LOWER, term i (Sigma is the host's constant otherwise)
         }
         qa = qa + __shfl_xor(qa, 32); qa = qa + __shfl_xor(qa, 16);
         qb = qb + __shfl_xor(qb, 32); qb = qb + __shfl_xor(qb, 16);
