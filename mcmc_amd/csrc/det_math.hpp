@@ -238,6 +238,9 @@ MI_HD double rng_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t 
 }
 
 // Box-Muller pair of one slot: z0 = r cos(2 pi u2), z1 = r sin(2 pi u2), r = sqrt(-2 log u1)
+#ifdef MI_RNG_NOINLINE
+__attribute__((noinline))
+#endif
 MI_HD void rng_normal_pair(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, uint32_t stream,
                            double& z0, double& z1)
 {
