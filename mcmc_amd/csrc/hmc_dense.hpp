@@ -170,6 +170,16 @@ __device__ __forceinline__ void matvec_mfma_g(const double* __restrict__ gfrag, 
 {
     constexpr int NS = 4 * NT;
     constexpr int PD = 3;
+    // Addressing: wave-uniform base (SGPR pair, taken from lane 0: gfrag = base + lane, every lane is active here) + the lane's 8
+    // bytes as a 32-bit offset + an immediate.  With the per-lane 64-bit pointer the compiler kept one address pair per fragment
+    // row -- 256 per matrix -- as loop invariants of the sampler's loops, spilled them (1 074 spilled VGPRs, 4.3 KB of scratch in the
+    // d = 128 dense-precond HMC kernel) and reloaded one in front of every load.  The base is pinned per call (asm) for the same reason.
+    uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)gfrag);
+    uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)gfrag >> 32));
+    asm volatile("" : "+s"(b_lo), "+s"(b_hi));
+    const double* const gbase = reinterpret_cast<const double*>(((uintptr_t)b_hi << 32) | (uintptr_t)b_lo);
+    const uint32_t lane_ = (uint32_t)(threadIdx.x & 63);
+    auto frag = [&](int t, int s_) -> double { return gbase[(uint32_t)((t * NS + s_) * 64) + lane_]; };
     double4_t acc[NT];
     double a[PD + 1][NT];
 #pragma unroll
@@ -177,12 +187,12 @@ __device__ __forceinline__ void matvec_mfma_g(const double* __restrict__ gfrag, 
 #pragma unroll
     for (int p = 0; p < PD && p < NS; ++p)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[p][t] = gfrag[(size_t)(t * NS + p) * 64];
+        for (int t = 0; t < NT; ++t) a[p][t] = frag(t, p);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (s + PD < NS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[(s + PD) % (PD + 1)][t] = gfrag[(size_t)(t * NS + s + PD) * 64];
+            for (int t = 0; t < NT; ++t) a[(s + PD) % (PD + 1)][t] = frag(t, s + PD);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
