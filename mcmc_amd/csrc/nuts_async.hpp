@@ -102,6 +102,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     [[maybe_unused]] const double* afrag_l = (DENSE_M && dense_m_from_global<NT>()) ? prm.Lchol + lane : lds_L + lane;
     const size_t lane_off = (size_t)j4 * C + cld;
 
+    // 1 / m of this lane's dimension of slice s.  The lane's part of the index is opaque where the table is read: the 4 * NT values are
+    // loop invariants of the tick loop otherwise, registers the general kernel does not have
+    auto mi_tab = [&]() __attribute__((always_inline)) -> const double* {
+        int jo = (int)((threadIdx.x & 63) >> 4);
+        asm volatile("" : "+v"(jo));
+        return lds_mi + jo;
+    };
     auto lvl = [&](int l, int f) -> double& { return lds_lvl[(l * 4 + f) * 64 + cw]; };
     // workspace layout [wave][vec][slice][lane]: a vector of a wave's 16 chains is 16 KiB contiguous (one 512-B
     // coalesced access per slice, 4 pages per vector) instead of 128 fragments 4*C*8 bytes apart
@@ -199,8 +206,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             if constexpr (DENSE_M) {
                 matvec_m2<NT>(afrag_minv, pm, mp);
             } else {
+const double* const mi_t = mi_tab();
 #pragma unroll
-                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                for (int s = 0; s < NS; ++s) mp[s] = mi_t[4 * s] * pm[s];
                 dense_product_poison<NS>(pm, mp, j4, d);
             }
 #pragma unroll
@@ -249,8 +257,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
             if constexpr (DENSE_M) {
                 matvec_m2<NT>(afrag_minv, pm, mp);
             } else {
+const double* const mi_t = mi_tab();
 #pragma unroll
-                for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                for (int s = 0; s < NS; ++s) mp[s] = mi_t[4 * s] * pm[s];
                 dense_product_poison<NS>(pm, mp, j4, d);
             }
             double q = 0.0;
@@ -544,8 +553,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 if constexpr (DENSE_M) {
                     matvec_m2<NT>(afrag_minv, pm, mp);
                 } else {
+const double* const mi_t = mi_tab();
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                    for (int s = 0; s < NS; ++s) mp[s] = mi_t[4 * s] * pm[s];
                     dense_product_poison<NS>(pm, mp, j4, d);
                 }
 #pragma unroll
@@ -586,8 +596,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 if constexpr (DENSE_M) {
                     matvec_m2<NT>(afrag_minv, pm, mp);
                 } else {
+const double* const mi_t = mi_tab();
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) mp[s] = lds_mi[4 * s + j4] * pm[s];
+                    for (int s = 0; s < NS; ++s) mp[s] = mi_t[4 * s] * pm[s];
                     dense_product_poison<NS>(pm, mp, j4, d);
                 }
                 double q = 0.0;
