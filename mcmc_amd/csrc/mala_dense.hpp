@@ -93,10 +93,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
     double xp[GENERAL ? NS : 1]; // GENERAL: x(theta') = inv_transform(theta')
     const bool vb = GENERAL && prm.vals_bound != 0;
 
+    int tab_o = 0;                 // (an opaque zero, renewed at the top of every draw: see there)
     // mala_mean_fn (mala.cpp:97-125) for one dimension; jm_out = eps^2 (J M) when bounded (= Sigma_ii with J = J(v))
     auto mean_of = [&](double v, double pw, int dim, double& jm_out) __attribute__((always_inline)) -> double {
         if constexpr (GENERAL) {
-            const double M = lds_m[dim];
+            const double M = lds_m[dim + tab_o];
             if (vb) {
                 const double J = box_inv_jacobian(v, lds_bt[dim], lds_lb[dim], lds_ub[dim]);   // :113
                 const double JM = s2 * (J * M);                                                // :115-117
@@ -155,6 +156,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
+        // (the per-dimension tables are read at an index that is opaque per draw: s2 * M, 1 / (s2 * M), sqrt(m) of every slice are
+        //  loop invariants otherwise -- 3 x NS values the kernel has no registers for; they were spilled and reloaded from scratch)
+        tab_o = 0;
+        asm volatile("" : "+v"(tab_o));
         // proposal: mala_mean_fn(prev) + eps * L z   (mala.cpp:150-159)
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
@@ -166,7 +171,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
             const double ma = mean_of(th[2 * b], w[2 * b], 8 * b + j, jma);
             const double mb = mean_of(th[2 * b + 1], w[2 * b + 1], 8 * b + 4 + j, jmb);
             if constexpr (GENERAL) {
-                const double sa = lds_ms[8 * b + j], sb = lds_ms[8 * b + 4 + j];
+                const double sa = lds_ms[8 * b + j + tab_o], sb = lds_ms[8 * b + 4 + j + tab_o];
                 if (vb) {                                // CHOL_LOWER(J) * sqrt_precond, scaled by eps (mala.cpp:155-157)
                     const double Ja = box_inv_jacobian(th[2 * b], lds_bt[8 * b + j], lds_lb[8 * b + j], lds_ub[8 * b + j]);
                     const double Jb = box_inv_jacobian(th[2 * b + 1], lds_bt[8 * b + 4 + j], lds_lb[8 * b + 4 + j], lds_ub[8 * b + 4 + j]);
