@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pm[r] = pm[r] - (eps * w[r]) / 2.0;                    // first half-step of step 0
             }
-            for (uint32_t k = 0; k + 1 < L; ++k) {
+            // the step counter lives in a scalar register (a vector counter is 2 of the 30 VALU instructions of this VALU-bound loop)
+            for (uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)((L > 0) ? L - 1 : 0u)); kk != 0u; kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kk - 1u))) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
