@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the many-chain sampling hot path on MI355X, one JSON line per run.
 
-Default workload = BASELINE.json configs[1] (SURVEY.md 8(d) "C2"): mcmc::hmc on a d=128 correlated Gaussian
+Headline workload = BASELINE.json configs[1] (SURVEY.md 8(d) "C2"): mcmc::hmc on a d=128 correlated Gaussian
 (P = A A^T / d + I, analytic gradient), 65 536 chains, fp64, step_size 0.05, n_leap_steps 16, 100 burn-in + 100 kept
-draws.  `--config 3|4|5` selects the other single-GPU BASELINE configs (MALA d=512 logistic regression, 262 144 chains;
+draws.  `--config 2|3|4|5` runs ONE of the single-GPU BASELINE configs (MALA d=512 logistic regression, 262 144 chains;
 NUTS d=128, 65 536 chains, depth 10; one GPU's 131 072-chain shard of the d=1024 ill-conditioned HMC run), each with its
 own roofline object.  One "step" = one mi_mcmc_<algo>_run call = that whole sampling run for every chain of the rank, with
 target, initial states and output buffers already resident in HBM.
@@ -14,9 +14,11 @@ fixed and every rank takes its shard ("scaling": "strong"); `--scaling weak` kee
 `--collate` additionally times the one exchange the path has (RCCL all-gather of the kept draws, HBM to HBM).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel against the resource that bounds it: algorithmic flops per launch
-                  / HIP-event duration measured here on the launch stream; `traffic` = HBM bytes per launch from the
-                  committed rocprofv3 PMC passes of this exact workload (profiles/r2_c<N>_pmc.json), else null
+  roofline     -- the dominant kernel (named by the engine: mi_mcmc_last_kernel) against the resource that bounds it: algorithmic
+                  flops per launch / HIP-event duration measured here on the launch stream; `traffic` = HBM bytes per
+                  launch, measured by two rocprofv3 --pmc child runs of this workload when rocprofv3 is on the box (--traffic),
+                  else from the committed passes of this exact workload (profiles/r*_c<N>_pmc.json), else null
+  other_configs-- (default run, one GPU) BASELINE configs 3, 4, 5 under the same clock at --other-steps steps, each with its roofline
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores on a
                   bounded sample of the same workload: Mode A (reference-faithful work profile) and Mode B
                   (optimised CPU: same bits, gradient reuse, no identity mat-vecs, SIMD mat-vec), built with the
@@ -141,53 +143,67 @@ def cpu_baseline(cfg_id, cfg):
 
 def profiled_traffic(cfg_id, key):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes, if they are of this workload."""
-    p = os.path.join(ROOT, "profiles", f"r2_c{cfg_id}_pmc.json")
+    for tag in ("r3", "r2"):
+        p = os.path.join(ROOT, "profiles", f"{tag}_c{cfg_id}_pmc.json")
+        try:
+            j = json.load(open(p))
+            if j.get("workload_key") == list(key):
+                return j["derived"]["hbm_bytes_per_launch"], f"profiles/{tag}_c{cfg_id}_pmc.json"
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
+
+
+def measured_traffic(cfg_id, kernel, chains_arg):
+    """HBM bytes per launch of `kernel`, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE: they do not fit one pass,
+    /opt/skills/guides/MI355X_MICROARCH.md) of one step of this workload in a child process.  Units and gfx950 corrections as the
+    guide prescribes: both counters are KiB; FETCH_SIZE is doubled for kernels whose reads are 16-byte-per-lane streams (the NUTS
+    record rows), taken as reported otherwise; WRITE_SIZE as reported.  Returns (bytes, detail) or (None, reason)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="mi_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    base = kernel.split("<")[0]
+    per = {}
     try:
-        j = json.load(open(p))
-        if j.get("workload_key") == list(key):
-            return j["derived"]["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--config", str(cfg_id), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                   "--traffic", "none", "--no-ess"] + (["--chains", str(chains_arg)] if chains_arg else [])
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            tot, disp = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f, newline="")):
+                    name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+                    if base in name and r.get("Counter_Name") == counter:
+                        tot += float(r["Counter_Value"]); disp.add(r.get("Dispatch_Id"))
+            if not disp:
+                return None, f"{counter}: kernel {base} not in the counter output"
+            per[counter] = tot / len(disp) * 1024.0
+        factor = 2.0 if base.startswith("nuts_gauss_") else 1.0
+        return per["FETCH_SIZE"] * factor + per["WRITE_SIZE"], {"read_bytes": per["FETCH_SIZE"] * factor, "write_bytes": per["WRITE_SIZE"],
+                                                                   "fetch_factor": factor, "source": "rocprofv3 --pmc, this run"}
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        return None, f"rocprofv3 pass failed: {type(e).__name__}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE config (2 = the headline)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="default: strong when WORLD_SIZE > 1 (north_star), n/a at one GPU")
-    ap.add_argument("--chains", type=int, default=None, help="chains: total (strong) / per GPU (weak)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--collate", action="store_true",
-                    help="also time the RCCL all-gather of the kept draws (not part of `value`)")
-    args = ap.parse_args()
+class Ctx:
+    pass
 
+
+def measure(cfg_id, steps, warmup, args, ctx, headline):
+    """Times `steps` steps of one BASELINE config on this rank's GPU (barrier + synchronize on both sides, max over ranks).
+    Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     import mcmc_amd
     from mcmc_amd import dist as mdist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    # BENCH_TEST_SHARE_GPU=1 (test only): gloo backend and LOCAL_RANK folded onto the visible devices, to exercise the N>1 path on a 1-GPU box
-    share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
-    dev = mdist.bind_device(None if share else int(os.environ.get("LOCAL_RANK", "0")))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-
-    cfg = dict(WORKLOADS[args.config])
+    world, rank, dev, dist, share = ctx.world, ctx.rank, ctx.dev, ctx.dist, ctx.share
+    cfg = dict(WORKLOADS[cfg_id])
     d, algo = cfg["d"], cfg["algo"]
     scaling = args.scaling or ("strong" if world > 1 else "weak")
     if scaling == "weak":
@@ -234,14 +250,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     barrier()
     t0 = time.perf_counter()
-    events = [one_step() for _ in range(args.steps)]
+    events = [one_step() for _ in range(steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_name = mcmc_amd.last_kernel() if C > 0 else cfg["kernel"]   # what the engine actually launched (mi_mcmc_last_kernel)
 
     # units of this rank per step: executed leapfrog steps x dims (hmc, nuts) or draws x dims (mala)
     if algo == "mala":
@@ -259,7 +276,7 @@ def main():
         elapsed, units_all = float(tmax[0].item()), float(t[1].item())
 
     collate_ms = None
-    if args.collate and dist is not None and not share:
+    if headline and args.collate and dist is not None and not share:
         c_max = mdist.shard_bounds(total, world, 0)[1] if scaling == "strong" else C
         send = torch.zeros((n_keep, d, c_max), dtype=torch.float64, device=dev)
         send[:, :, :C] = draws[:, :, :C]
@@ -273,24 +290,39 @@ def main():
         del gathered, send
 
     # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, autocovariances pooled
-    # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region
-    ess_total_rank, rhat_max = 0.0, float("nan")
-    if C > 0 and rank == 0:
+    # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region, its own
+    # time reported next to it
+    ess_total_rank, rhat_max, reducer_ms = 0.0, float("nan"), None
+    if C > 0 and rank == 0 and not args.no_ess:
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
         stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+        torch.cuda.synchronize()
+        reducer_ms = (time.perf_counter() - tr) * 1e3
         ess_total_rank = float(stats["ess"].min()) * C
         rhat_max = float(stats["rhat"].max())
     acc_rate = float(n_accept[:C].double().mean().item()) / n_keep if C else float("nan")
-    value = units_all * args.steps / elapsed
+    value = units_all * steps / elapsed
 
+    out = None
     if rank == 0:
         fpu = flop_per_unit(cfg)
         k_ms = float(np.mean(kernel_ms))
         achieved = units_rank * fpu / (k_ms * 1e-3) / 1e12
-        key = (args.config, C, d, n_tot)
+        key = (cfg_id, C, d, n_tot)
+        traffic, traffic_src = None, None
+        want_pmc = args.traffic == "all" or (args.traffic == "headline" and headline)
+        if want_pmc and world == 1:
+            traffic, traffic_src = measured_traffic(cfg_id, kernel_name, args.chains)
+        if traffic is None:
+            why = traffic_src
+            traffic, traffic_src = profiled_traffic(cfg_id, key)
+            if traffic is None and want_pmc:
+                traffic_src = why
         out = {
             "metric": cfg["metric"], "value": value, "unit": cfg["unit"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "chains_per_gpu": C, "chains_total": total, "d": d,
                        "n_burnin_draws": cfg["n_burnin_draws"], "n_keep_draws": n_keep,
@@ -298,11 +330,11 @@ def main():
                        "accept_rate": acc_rate},
             "roofline": {"bound": cfg["bound"], "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": profiled_traffic(args.config, key),
-                         "kernel": cfg["kernel"], "kernel_ms": k_ms, "flop_per_unit": fpu},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name, "kernel_ms": k_ms, "flop_per_unit": fpu},
         }
-        if out["roofline"]["traffic"] is not None:      # HBM side of the same launch, from the committed PMC passes
-            out["roofline"]["hbm_TBps"] = out["roofline"]["traffic"] / (k_ms * 1e-3) / 1e12
+        if traffic is not None:      # HBM side of the same launch
+            out["roofline"]["hbm_TBps"] = traffic / (k_ms * 1e-3) / 1e12
             out["roofline"]["hbm_frac_of_8TBps"] = out["roofline"]["hbm_TBps"] / 8.0
         for k in ("n_leap_steps", "step_size", "n_adapt_draws", "max_tree_depth", "n_rows"):
             if k in cfg:
@@ -311,11 +343,15 @@ def main():
             out["config"]["leapfrogs_per_chain_mean"] = units_rank / d / C
         if algo == "nuts":
             out["config"]["adapted_step_size_mean"] = float(eps_out[:C].mean().item())
-        out["ess_per_sec"] = ess_total_rank * world / (elapsed / args.steps)
-        out["ess_note"] = (f"min-over-dims Geyer-IPS ESS of the {n_keep} kept draws (autocovariance pooled over all chains of rank 0 on "
-                           "the device), x chains x ranks, / seconds per step")
-        out["rhat_max"] = rhat_max
-        if args.config == 5 and C > 1:
+        if reducer_ms is not None:
+            step_s = elapsed / steps
+            out["ess_per_sec"] = ess_total_rank * world / step_s
+            out["ess_per_sec_incl_reducer"] = ess_total_rank * world / (step_s + reducer_ms * 1e-3)
+            out["ess_reducer_ms"] = reducer_ms
+            out["ess_note"] = (f"min-over-dims Geyer-IPS ESS of the {n_keep} kept draws (autocovariance pooled over all chains of rank 0 on "
+                               "the device), x chains x ranks, / seconds per step; _incl_reducer adds the time of mi_mcmc_draw_stats itself")
+            out["rhat_max"] = rhat_max
+        if headline and cfg_id == 5 and C > 1 and not args.no_ess:
             # the second half of BASELINE.json's metric on this target is decided by the mass matrix, not by the kernel:
             # the same workload through mi_mcmc_hmc_run_mass_adapted (NOT a reference mode), outside the timed region
             theta.copy_(theta0)
@@ -333,12 +369,78 @@ def main():
         if collate_ms is not None:
             out["collate_allgather_ms"] = collate_ms
             out["collate_bytes_per_rank"] = n_keep * d * C * 8
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.config, cfg)
-            out["gpu_over_cpu"] = {k: value / out["cpu_baseline"][k]["value"] for k in ("mode_a", "mode_b") if k in out["cpu_baseline"]}
+    del draws, theta, theta0, n_accept, n_leap, eps_out, kw_dev, target, chains
+    mcmc_amd.release_workspace()
+    torch.cuda.empty_cache()
+    return out, cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(WORKLOADS),
+                    help="one BASELINE config only; default: the headline (2) with --steps/--warmup, then configs 3, 4, 5 at "
+                         "--other-steps (one GPU only), attached as other_configs")
+    ap.add_argument("--other-steps", type=int, default=2)
+    ap.add_argument("--other-warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when WORLD_SIZE > 1 (north_star), n/a at one GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains: total (strong) / per GPU (weak)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--traffic", choices=["headline", "all", "none"], default="headline",
+                    help="measure roofline.traffic with two rocprofv3 --pmc child runs (one GPU only); else the committed profiles/")
+    ap.add_argument("--collate", action="store_true",
+                    help="also time the RCCL all-gather of the kept draws (not part of `value`)")
+    args = ap.parse_args()
+
+    import torch
+    import mcmc_amd
+    from mcmc_amd import dist as mdist
+
+    ctx = Ctx()
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # BENCH_TEST_SHARE_GPU=1 (test only): gloo backend and LOCAL_RANK folded onto the visible devices, to exercise the N>1 path on a 1-GPU box
+    ctx.share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
+    ctx.dev = mdist.bind_device(None if ctx.share else int(os.environ.get("LOCAL_RANK", "0")))
+    ctx.dist = None
+    if ctx.world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ctx.share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=ctx.dev)
+        ctx.dist = dist
+    if args.gpus != ctx.world and ctx.rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={ctx.world}; using WORLD_SIZE", file=sys.stderr)
+
+    head_id = args.config or 2
+    out, cfg = measure(head_id, args.steps, args.warmup, args, ctx, headline=True)
+    if args.config is None and ctx.world == 1 and args.chains is None:
+        # the other single-GPU BASELINE configs under the same clock, at a reduced step count
+        others = []
+        for cid in (3, 4, 5):
+            o, _ = measure(cid, args.other_steps, args.other_warmup, args, ctx, headline=False)
+            others.append({"config_id": cid, "workload": o["config"]["workload"], "metric": o["metric"], "unit": o["unit"],
+                           "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                           "chains": o["config"]["chains_per_gpu"], "accept_rate": o["config"]["accept_rate"],
+                           "roofline": o["roofline"],
+                           **({"ess_per_sec": o["ess_per_sec"], "ess_per_sec_incl_reducer": o["ess_per_sec_incl_reducer"],
+                               "ess_reducer_ms": o["ess_reducer_ms"]} if "ess_per_sec" in o else {})})
+        out["other_configs"] = others
+    if ctx.rank == 0:
+        if not args.no_cpu_baseline and ctx.world == 1:
+            out["cpu_baseline"] = cpu_baseline(head_id, cfg)
+            out["gpu_over_cpu"] = {k: out["value"] / out["cpu_baseline"][k]["value"] for k in ("mode_a", "mode_b") if k in out["cpu_baseline"]}
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

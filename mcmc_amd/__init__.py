@@ -60,7 +60,7 @@ class MiMcmcError(RuntimeError):
 _lib = None
 
 EXPORTS = [
-    "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
+    "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
@@ -102,6 +102,7 @@ def lib():
         _one_hip_runtime()
         _lib = C.CDLL(path)
         _lib.mi_mcmc_last_error.restype = C.c_char_p
+        _lib.mi_mcmc_last_kernel.restype = C.c_char_p
     return _lib
 
 
@@ -175,6 +176,11 @@ def hmc_mass_adapted(target, settings, chains, n_windows=3, stream=None):
     _check(lib().mi_mcmc_hmc_run_mass_adapted(C.byref(target), C.byref(settings), C.byref(chains), C.c_uint32(n_windows),
                                               C.c_void_p(mass.ctypes.data), C.c_void_p(stream or 0)))
     return mass
+
+
+def last_kernel():
+    """mi_mcmc_last_kernel: the kernel this thread's last run spent its time in, as rocprofv3 names it."""
+    return lib().mi_mcmc_last_kernel().decode()
 
 
 def release_workspace(stream=None, all_streams=True):

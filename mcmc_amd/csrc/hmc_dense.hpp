@@ -62,6 +62,8 @@ struct HmcParams {
     const double* m_inv;    // diag of INV(precond) (hmc.cpp:58)
     uint32_t ablate;        // profiling only: 1 = skip kick/drift, 2 = skip mat-vec (results meaningless)
     uint32_t stagger;       // start delay of the second wave of each SIMD, in s_sleep(127) units
+    uint32_t* nf_flag;      // plain kernels: [C + 1] or nullptr.  A chain whose energies went non-finite is flagged (nf_flag[c] = 1,
+                            // nf_flag[C] = 1) and its theta / n_accept / n_leap are left untouched: literal.hpp replays it
 };
 
 template <int NS>
@@ -456,6 +458,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     double prev_U = potential();                        // -box_log_kernel(first_draw), hmc.cpp:140
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    // Non-finite regime: the reference's `inv_precond_matrix * mntm` is a dense product, in which one
+    // non-finite momentum entry turns every other row into NaN.  The plain kernel applies the identity element-wise; what it
+    // does is DETECT the regime -- a non-finite entry of p or theta makes prop_U or prop_K non-finite, and stays -- and hand the
+    // chain to the literal replay (literal.hpp) through prm.nf_flag.
+    [[maybe_unused]] bool nf_seen = false;
 
     // Two waves share each SIMD's matrix pipe.  Started together they stay in lock-step and their
     // VALU phases (RNG, accept, kick/drift) coincide; a one-off start offset is self-preserving under
@@ -592,8 +599,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         if constexpr (BOUNDED) { if (prm.n_leap_steps == 0) gradient(); }   // xs must match theta for the energy
 
         double prop_U = potential();                    // -box_log_kernel(new_draw), hmc.cpp:178
-        if (!is_finite(prop_U)) prop_U = INF;           // :180-182
+        const bool u_nf = !is_finite(prop_U);
+        if (u_nf) prop_U = INF;                         // :180-182
         const double prop_K = kinetic();                // :184
+        if constexpr (!BOUNDED) nf_seen |= u_nf | !is_finite(prop_K);
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;  // std::min(0.01, x), :188
         const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);   // :189
@@ -623,7 +632,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         }
     }
 
-    if (live) {
+    bool replay = false;                                 // the literal kernel owns this chain's outputs
+    if constexpr (!BOUNDED) replay = nf_seen && prm.nf_flag != nullptr;
+    if (live && replay && j == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+    if (live && !replay) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;
@@ -631,7 +643,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                 (BOUNDED && slice_bounded(s)) ? box_inv_transform(th[s], lds_bt[dim], lds_lb[dim], lds_ub[dim]) : th[s];
         }
     }
-    if (live && j == 0) {
+    if (live && !replay && j == 0) {
         if (prm.n_accept) prm.n_accept[cl] = n_acc;                            // hmc.cpp:220-222
         if (prm.n_leap) prm.n_leap[cl] = (prm.ablate & 32u) ? (uint64_t)(clock64() - t_loop0)      // profiling: shader cycles of the draw loop
                                                             : (uint64_t)n_total * prm.n_leap_steps;

@@ -43,6 +43,7 @@ struct HmcDiagParams {
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     const double* m_sqrt;   // PRECOND: diagonal of CHOL_LOWER(precond_mat) (device, d values)
     const double* m_inv;    // PRECOND: diagonal of INV(precond_mat)
+    uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
 };
 
 constexpr int HMC_DIAG_CHAINS_PER_BLOCK = 64;     // 4 waves x 16 chains
@@ -56,8 +57,9 @@ __device__ __forceinline__ double diag_combine(double q)
 }
 
 // PRECOND: a diagonal precond_mat M (hmc.cpp:57-59,158-160,171,184): p = sqrt(M) z, theta += eps (Minv p), K = p.(Minv p)/2 --
-// still one independent trajectory per dimension.  (The NaN poisoning of the reference's dense products, DESIGN.md section 3,
-// is not reproduced by this kernel, with or without M.)
+// still one independent trajectory per dimension.  The NaN poisoning of the reference's dense `inv_precond_matrix * mntm`
+//  couples the dimensions: these kernels detect the regime (a non-finite energy is its necessary
+// consequence), flag the chain in prm.nf_flag and leave theta / n_accept untouched; literal.hpp replays the chain.
 template <bool PRECOND>
 __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
 {
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     uint32_t pp = 0;                                    // ping-pong index of the next free scratch slab
+    bool nf_seen = false;
 
     for (uint32_t draw = 0; draw < n_total; ++draw) {
         const bool kept = draw >= prm.n_burnin;
@@ -154,8 +157,10 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
         }
         const double prev_K = diag_combine(qk0) / 2.0;                    // hmc.cpp:160
         double prop_U = 0.5 * diag_combine(qu1);                          // :178
-        if (!is_finite(prop_U)) prop_U = INF;
+        const bool u_nf = !is_finite(prop_U);
+        if (u_nf) prop_U = INF;
         const double prop_K = diag_combine(qk1) / 2.0;                    // :184
+        nf_seen |= u_nf | !is_finite(prop_K);
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;
         const double zu = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
         if (kept) n_acc += accept ? 1u : 0u;
     }
     if (!live) return;
+    if (nf_seen && prm.nf_flag != nullptr) {             // literal.hpp replays this chain from its untouched initial values
+        if (j == 0) { prm.nf_flag[c] = 1u; prm.nf_flag[C] = 1u; }
+        return;
+    }
     double* out = prm.theta + c;
     if (cur != out)
         for (uint32_t i = j; i < d; i += 4) out[(size_t)i * C] = cur[(size_t)i * C];
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     uint32_t pp = 0;                                    // ping-pong index of the next free scratch slab
+    bool nf_seen = false;
 
     for (uint32_t draw = 0; draw < n_total; ++draw) {
         const bool kept = draw >= prm.n_burnin;
@@ -273,8 +283,10 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
         }
         const double prev_K = ((qk0[0] + qk0[2]) + (qk0[1] + qk0[3])) / 2.0;   // hmc.cpp:160
         double prop_U = 0.5 * ((qu1[0] + qu1[2]) + (qu1[1] + qu1[3]));         // :178
-        if (!is_finite(prop_U)) prop_U = INF;
+        const bool u_nf = !is_finite(prop_U);
+        if (u_nf) prop_U = INF;
         const double prop_K = ((qk1[0] + qk1[2]) + (qk1[1] + qk1[3])) / 2.0;   // :184
+        nf_seen |= u_nf | !is_finite(prop_K);
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;
         const double zu = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
@@ -289,6 +301,7 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
         }
         if (kept) n_acc += accept ? 1u : 0u;
     }
+    if (nf_seen && prm.nf_flag != nullptr) { prm.nf_flag[c] = 1u; prm.nf_flag[C] = 1u; return; }   // replayed by literal.hpp
     double* out = prm.theta + c;
     if (cur != out)
         for (uint32_t i = 0; i < d; ++i) out[(size_t)i * C] = cur[(size_t)i * C];

@@ -148,6 +148,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     const uint32_t L = prm.n_leap_steps;
+    bool nf_seen = false;                               // non-finite regime: detect, flag, replay (hmc_dense.hpp; the energies are tile-uniform)
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
@@ -187,8 +188,10 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
             for (int k = 0; k < NSO; ++k) pm[k] = pm[k] - (eps * w[k]) / 2.0;
         }
         double prop_U = potential();                    // hmc.cpp:178
-        if (!is_finite(prop_U)) prop_U = INF;           // :180-182
+        const bool u_nf = !is_finite(prop_U);
+        if (u_nf) prop_U = INF;                         // :180-182
         const double prop_K = kinetic();                // :184
+        nf_seen |= u_nf | !is_finite(prop_K);
         const double x = -(prop_U + prop_K) + (prev_U + prev_K);
         const double comp_val = (x < 0.01) ? x : 0.01;  // :188
         const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);   // :189
@@ -216,14 +219,16 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
         }
     }
 
-    if (live) {
+    const bool replay = nf_seen && prm.nf_flag != nullptr;
+    if (live && replay && j == 0 && h == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+    if (live && !replay) {
 #pragma unroll
         for (int k = 0; k < NSO; ++k) {
             const uint32_t dim = 4 * (s0 + k) + j;
             if (dim < d) prm.theta[(size_t)dim * C + cl] = full[s0 + k];
         }
     }
-    if (live && j == 0 && h == 0) {
+    if (live && !replay && j == 0 && h == 0) {
         if (prm.n_accept) prm.n_accept[cl] = n_acc;                            // hmc.cpp:220-222
         if (prm.n_leap) prm.n_leap[cl] = (uint64_t)n_total * prm.n_leap_steps;
     }

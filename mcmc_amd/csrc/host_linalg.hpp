@@ -1,0 +1,57 @@
+// host_linalg.hpp -- host-side INV / CHOL_LOWER in the operation order the oracle states for the reference's BMO_MATOPS_INV /
+// BMO_MATOPS_CHOL_LOWER, shared by the C ABI (mi_mcmc.hip), the literal replay preparation (literal_host.hpp) and its host test shim.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <utility>
+#include <vector>
+
+namespace {
+
+// INV and CHOL_LOWER of a dense precond_mat on the host, with the operation order the oracle states for the reference's
+// BMO_MATOPS_INV / BMO_MATOPS_CHOL_LOWER (Gauss-Jordan with partial pivoting; column Cholesky).  Compiled with
+// -ffp-contract=off like everything else, so the bits are the oracle's.
+inline void host_inverse(const double* A, size_t d, std::vector<double>& Ainv)
+{
+    std::vector<double> a(A, A + d * d);
+    Ainv.assign(d * d, 0.0);
+    for (size_t i = 0; i < d; ++i) Ainv[i * d + i] = 1.0;
+    for (size_t c = 0; c < d; ++c) {
+        size_t piv = c;
+        double best = std::fabs(a[c * d + c]);
+        for (size_t r = c + 1; r < d; ++r)
+            if (std::fabs(a[r * d + c]) > best) { best = std::fabs(a[r * d + c]); piv = r; }
+        if (piv != c)
+            for (size_t j = 0; j < d; ++j) { std::swap(a[c * d + j], a[piv * d + j]); std::swap(Ainv[c * d + j], Ainv[piv * d + j]); }
+        const double pv = a[c * d + c];
+        for (size_t j = 0; j < d; ++j) { a[c * d + j] = a[c * d + j] / pv; Ainv[c * d + j] = Ainv[c * d + j] / pv; }
+        for (size_t r = 0; r < d; ++r) {
+            if (r == c) continue;
+            const double f = a[r * d + c];
+            if (f == 0.0) continue;
+            for (size_t j = 0; j < d; ++j) {
+                a[r * d + j] = a[r * d + j] - f * a[c * d + j];
+                Ainv[r * d + j] = Ainv[r * d + j] - f * Ainv[c * d + j];
+            }
+        }
+    }
+}
+
+inline void host_cholesky_lower(const double* A, size_t d, std::vector<double>& L)
+{
+    L.assign(d * d, 0.0);
+    for (size_t j = 0; j < d; ++j) {
+        double sum = A[j * d + j];
+        for (size_t k = 0; k < j; ++k) sum = sum - L[j * d + k] * L[j * d + k];
+        const double ljj = std::sqrt(sum);
+        L[j * d + j] = ljj;
+        for (size_t i = j + 1; i < d; ++i) {
+            double t = A[i * d + j];
+            for (size_t k = 0; k < j; ++k) t = t - L[i * d + k] * L[j * d + k];
+            L[i * d + j] = t / ljj;
+        }
+    }
+}
+
+}  // namespace

@@ -14,6 +14,7 @@ struct MalaParams;
 struct NutsParams;
 struct RwmhParams;
 struct SmallParams;
+namespace lit { struct LitParams; }
 
 // nt = ceil(d / 16) in {1, 2, 3..4, 5..8}; general: bounds and / or diagonal precond; dense_m: dense precond (nt <= 4)
 int launch_hmc_gauss(const HmcParams& prm, int nt, bool general, bool dense_m, hipStream_t st);
@@ -37,5 +38,9 @@ int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st);
 
 // the same engine on LogisticSmallModel<d> (small_targets.hpp), d = 1..8; algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh
 int launch_small_logistic(int algo, int d, const SmallParams& prm, const double* X_dev, const double* y_dev, uint32_t n_rows, hipStream_t st);
+
+
+// literal replay of flagged chains (literal.hpp; algo 0 hmc, 1 mala), n_wg workgroups of 256 threads
+int launch_literal(int algo, const lit::LitParams& prm, unsigned n_wg, hipStream_t st);
 
 }  // namespace mi

@@ -1,0 +1,675 @@
+// literal.hpp -- mcmc::hmc / mcmc::mala stated literally, one workgroup per chain: the replay path of the non-finite regime.
+//
+// The reference forms `inv_precond_matrix * mntm` (/root/reference/src/hmc.cpp:160,171,184), `jacob_matrix * grad_obj` (:122),
+// `precond_matrix * grad_obj` (src/mala.cpp:123), `inv_jacob * precond_matrix` (:115), CHOL_LOWER(J) * sqrt_precond (:155-157),
+// INV / LOG_DET of eps^2 J M (include/stats/dmvnorm.hpp:39-41 through include/mcmc/mala.ipp:52-64) as DENSE operations, also when
+// the matrices are the identity or diagonal.  As long as every value is finite that is the element-wise arithmetic the
+// throughput kernels (hmc_dense.hpp, hmc_diag.hpp, hmc_split.hpp, mala_dense.hpp, logistic_lds.hpp) run.  Once ONE entry of a
+// vector is +-inf or NaN, 0 * inf = NaN reaches every other row of a dense product, Gauss-Jordan pivots on NaN, and the
+// reference's chain becomes something no element-wise kernel computes.  Those kernels therefore only DETECT the regime (a
+// non-finite energy / proposal density is its necessary consequence), flag the chain, leave its outputs untouched, and the
+// kernels below replay the flagged chains from their initial values with the reference's operations as written: every
+// matrix product an fma chain over all columns (k ascending), BMO_MATOPS_INV as Gauss-Jordan with partial pivoting,
+// BMO_MATOPS_CHOL_LOWER as column Cholesky, in the operation order DESIGN.md section 3 states -- so the replayed chain is the
+// reference's chain bit for bit, NaN patterns included.  A chain costs O(d^2) per leapfrog step (hmc) or O(d^3) per draw
+// (bounded mala) here; that is what the reference itself spends.
+//
+// The same kernel, run on ALL chains, is the device path of the one configuration the MFMA kernels do not implement: bounded
+// mala with a dense precond_mat (INV(eps^2 J(theta') M) per draw, mala.ipp:52-53).
+//
+// Everything below is __host__ __device__: tests/lit_host.hip compiles the host instantiation, and the CPU test suite holds it
+// against the oracle on non-finite cases -- the GPU then only has to agree with itself.
+#pragma once
+
+#include "det_math.hpp"
+
+namespace mi {
+namespace lit {
+
+constexpr double LIT_EPS_DBL = 2.220446049250313e-16;    // mcmc_options.hpp:103
+constexpr double LIT_LOG_2PI = 1.83787706640934548356;   // stats/mcmc_stats.hpp:28-30
+
+enum { LIT_ISO = 0, LIT_DIAG = 1, LIT_DENSE = 2, LIT_LOGISTIC = 3 };
+
+struct LitTarget {
+    int kind;
+    uint32_t d, n_rows;
+    const double* prec;      // LIT_DIAG: d precisions, prec[i * prec_stride]; LIT_DENSE: d*d row-major
+    uint32_t prec_stride;    // LIT_DIAG: 1, or d + 1 when prec is the diagonal of a dense d*d matrix
+    const double* X;         // LIT_LOGISTIC: n_rows*d row-major
+    const double* y;
+    int W;                   // strided fma chains of a dot product (4: the layout of the MFMA kernels)
+    int nblk;                // > 1: dimension-blocked reductions, block size bs (the logistic kernels: 4 blocks of 16 NTQ)
+    uint32_t bs;
+    int eta_chains;          // LIT_LOGISTIC: sub-chains of eta inside a dimension block
+};
+
+struct LitParams {
+    LitTarget t;
+    uint64_t C, chain0;
+    double* theta;           // [d][C] in/out
+    double* draws;           // [n_keep][d][C] or nullptr
+    uint64_t* n_accept;
+    uint64_t* n_leap;
+    uint64_t seed;
+    uint32_t n_burnin, n_keep, n_leap_steps, draw0;
+    double eps;              // step_size
+    int vals_bound;
+    const int* btype;        // [d] 1 none, 2 lower, 3 upper, 4 both (determine_bounds_type.hpp:27-57); vals_bound only
+    const double* lb;
+    const double* ub;
+    int precond;             // 0 identity; 1 diagonal: m / m_sqrt / m_inv [d]; 2 dense: Mfull / Lchol / Minv, d*d row-major
+    const double* m;
+    const double* m_sqrt;
+    const double* m_inv;
+    const double* Mfull;
+    const double* Lchol;
+    const double* Minv;
+    // mala, unbounded: INV / LOG_DET of Sigma = eps^2 M are constants of the run, from the host (the oracle's operation order)
+    const double* sinv_diag; // precond 0 / 1: [d] 1 / (eps^2 m_i) (nullptr: all equal rs)
+    const double* Sinv;      // precond 2: d*d row-major
+    double rs, log_det, cons_term;
+    const uint32_t* flag;    // [C]: replay only the chains whose entry is non-zero; nullptr: every chain
+    const uint32_t* any;     // nullptr, or one word: zero = nothing was flagged, the launch returns at once
+    double* work;            // workspace, work_stride doubles per workgroup
+    size_t work_stride;
+};
+
+// workspace doubles per workgroup
+MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded)
+{
+    const size_t dv = (size_t)d + 8;
+    return 16 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0);
+}
+
+struct Par {
+    int tid, nth;
+    MI_HD void sync() const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();
+#endif
+    }
+};
+
+#define LIT_PFOR(i, n) for (uint32_t i = (uint32_t)par.tid; i < (uint32_t)(n); i += (uint32_t)par.nth)
+
+MI_HD double lit_nan() { return __builtin_nan(""); }
+
+// ---- BMO shim, stated.  Scalar reductions are computed redundantly by every thread: same bits everywhere.
+MI_HD double dot_w(const double* x, const double* y, uint32_t n, int W)      // BMO_MATOPS_DOT_PROD
+{
+    if (W <= 1) {
+        double q = 0.0;
+        for (uint32_t i = 0; i < n; ++i) q = dfma(x[i], y[i], q);
+        return q;
+    }
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (W > 8) W = 8;
+    for (uint32_t i = 0; i < n; ++i) q[i % (uint32_t)W] = dfma(x[i], y[i], q[i % (uint32_t)W]);
+    for (int h = W / 2; h >= 1; h /= 2)
+        for (int c = 0; c < h; ++c) q[c] = q[c] + q[c + h];
+    return q[0];
+}
+MI_HD double dot_b(const LitTarget& t, const double* x, const double* y)
+{
+    const uint32_t d = t.d;
+    if (t.nblk <= 1 || t.bs == 0) return dot_w(x, y, d, t.W);
+    double r = 0.0;
+    for (int k = 0; k < t.nblk; ++k) {
+        const uint32_t lo = (uint32_t)k * t.bs;
+        const uint32_t len = (lo < d) ? ((d - lo < t.bs) ? d - lo : t.bs) : 0u;
+        const double bk = dot_w(x + (len ? lo : 0u), y + (len ? lo : 0u), len, t.W);
+        r = (k == 0) ? bk : r + bk;
+    }
+    return r;
+}
+MI_HD double sum_w(const double* x, uint32_t n, int W)
+{
+    if (W <= 1) {
+        double q = 0.0;
+        for (uint32_t i = 0; i < n; ++i) q = q + x[i];
+        return q;
+    }
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (W > 8) W = 8;
+    for (uint32_t i = 0; i < n; ++i) q[i % (uint32_t)W] = q[i % (uint32_t)W] + x[i];
+    for (int h = W / 2; h >= 1; h /= 2)
+        for (int c = 0; c < h; ++c) q[c] = q[c] + q[c + h];
+    return q[0];
+}
+MI_HD uint32_t count_nonfinite(const double* x, uint32_t n)
+{
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < n; ++i) c += is_finite(x[i]) ? 0u : 1u;
+    return c;
+}
+// y = A x, A dense row-major: every row one fma chain, k ascending.  y must not alias x.
+MI_HD void gemv(const Par& par, const double* A, const double* x, uint32_t d, double* y)
+{
+    LIT_PFOR(i, d) {
+        double acc = 0.0;
+        const double* a = A + (size_t)i * d;
+        for (uint32_t k = 0; k < d; ++k) acc = dfma(a[k], x[k], acc);
+        y[i] = acc;
+    }
+    par.sync();
+}
+// y = D x for a matrix D whose off-diagonal entries are exact zeros (the identity when dg == nullptr), as the dense fma chain
+// it is in the reference: acc = +0; fma(0, x_k, acc) leaves acc alone for a finite x_k and makes it NaN otherwise; the
+// diagonal term is fma(D_ii, x_i, +0).  y must not alias x.
+MI_HD void diag_gemv(const Par& par, const double* dg, const double* x, uint32_t d, double* y)
+{
+    const uint32_t n = count_nonfinite(x, d);
+    LIT_PFOR(i, d) {
+        const uint32_t others = n - (is_finite(x[i]) ? 0u : 1u);
+        y[i] = (others > 0u) ? lit_nan() : dfma(dg ? dg[i] : 1.0, x[i], 0.0);
+    }
+    par.sync();
+}
+// C = A B (d x d): every entry one fma chain, k ascending
+MI_HD void matmul(const Par& par, const double* A, const double* B, uint32_t d, double* Cm)
+{
+    LIT_PFOR(e, d * d) {
+        const uint32_t i = e / d, j = e % d;
+        double acc = 0.0;
+        for (uint32_t k = 0; k < d; ++k) acc = dfma(A[(size_t)i * d + k], B[(size_t)k * d + j], acc);
+        Cm[e] = acc;
+    }
+    par.sync();
+}
+MI_HD void scale_mat(const Par& par, double s, double* A, uint32_t d)
+{
+    LIT_PFOR(e, d * d) A[e] = s * A[e];
+    par.sync();
+}
+// BMO_MATOPS_INV: Gauss-Jordan with partial pivoting (first strictly larger |a|, NaN never larger).  a: d*d scratch.
+MI_HD void inverse(const Par& par, const double* A, uint32_t d, double* a, double* Ainv)
+{
+    LIT_PFOR(e, d * d) { a[e] = A[e]; Ainv[e] = (e / d == e % d) ? 1.0 : 0.0; }
+    par.sync();
+    for (uint32_t c = 0; c < d; ++c) {
+        uint32_t piv = c;                                   // every thread runs the same scan
+        double best = __builtin_fabs(a[(size_t)c * d + c]);
+        for (uint32_t r = c + 1; r < d; ++r) {
+            const double v = __builtin_fabs(a[(size_t)r * d + c]);
+            if (v > best) { best = v; piv = r; }
+        }
+        par.sync();                                         // the scan has read column c of every row
+        if (piv != c) {
+            LIT_PFOR(j, d) {
+                double t = a[(size_t)c * d + j]; a[(size_t)c * d + j] = a[(size_t)piv * d + j]; a[(size_t)piv * d + j] = t;
+                t = Ainv[(size_t)c * d + j]; Ainv[(size_t)c * d + j] = Ainv[(size_t)piv * d + j]; Ainv[(size_t)piv * d + j] = t;
+            }
+            par.sync();
+        }
+        const double pv = a[(size_t)c * d + c];
+        par.sync();                                         // everybody holds pv before the row changes
+        LIT_PFOR(j, d) { a[(size_t)c * d + j] = a[(size_t)c * d + j] / pv; Ainv[(size_t)c * d + j] = Ainv[(size_t)c * d + j] / pv; }
+        par.sync();
+        // rows r != c: a[r][:] -= f a[c][:], Ainv[r][:] -= f Ainv[c][:] with f = a[r][c] as it is BEFORE the row changes: column c
+        // (which holds every row's f) is updated in a second phase, behind a barrier
+        LIT_PFOR(e, d * d) {
+            const uint32_t r = e / d, j = e % d;
+            if (r == c || j == c) continue;
+            const double f = a[(size_t)r * d + c];
+            if (f == 0.0) continue;
+            a[e] = a[e] - f * a[(size_t)c * d + j];
+        }
+        LIT_PFOR(e, d * d) {
+            const uint32_t r = e / d, j = e % d;
+            if (r == c) continue;
+            const double f = a[(size_t)r * d + c];
+            if (f == 0.0) continue;
+            Ainv[e] = Ainv[e] - f * Ainv[(size_t)c * d + j];
+        }
+        par.sync();
+        LIT_PFOR(r, d) {                                    // column c itself last: a[r][c] -= f a[c][c]
+            if (r == c) continue;
+            const double f = a[(size_t)r * d + c];
+            if (f == 0.0) continue;
+            a[(size_t)r * d + c] = f - f * a[(size_t)c * d + c];
+        }
+        par.sync();
+    }
+}
+// BMO_MATOPS_CHOL_LOWER: column Cholesky
+MI_HD void chol_lower(const Par& par, const double* A, uint32_t d, double* L)
+{
+    LIT_PFOR(e, d * d) L[e] = 0.0;
+    par.sync();
+    for (uint32_t j = 0; j < d; ++j) {
+        double sum = A[(size_t)j * d + j];
+        for (uint32_t k = 0; k < j; ++k) sum = sum - L[(size_t)j * d + k] * L[(size_t)j * d + k];
+        const double ljj = __builtin_sqrt(sum);
+        par.sync();                                         // row j (columns < j) has been read by everybody
+        LIT_PFOR(i, d) {
+            if (i < j) continue;
+            if (i == j) { L[(size_t)j * d + j] = ljj; continue; }
+            double t = A[(size_t)i * d + j];
+            for (uint32_t k = 0; k < j; ++k) t = t - L[(size_t)i * d + k] * L[(size_t)j * d + k];
+            L[(size_t)i * d + j] = t / ljj;
+        }
+        par.sync();
+    }
+}
+MI_HD double log_det_from_chol(const double* L, uint32_t d)
+{
+    double ld = 0.0;
+    for (uint32_t i = 0; i < d; ++i) ld = ld + 2.0 * det_log(L[(size_t)i * d + i]);
+    return ld;
+}
+
+// ---- box constraints (transform_vals.hpp:25-119, log_jacobian.hpp:25-58, inv_jacobian_adjust.hpp:25-56)
+MI_HD double lit_transform(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return det_log(v - lb + LIT_EPS_DBL);
+    case 3: return -det_log(ub - v + LIT_EPS_DBL);
+    case 4: return det_log(v - lb + LIT_EPS_DBL) - det_log(ub - v + LIT_EPS_DBL);
+    default: return v;
+    }
+}
+MI_HD double lit_inv_transform(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return !is_finite(v) ? lb + LIT_EPS_DBL : lb + LIT_EPS_DBL + det_exp(v);
+    case 3: return !is_finite(v) ? ub - LIT_EPS_DBL : ub - LIT_EPS_DBL - det_exp(-v);
+    case 4: {
+        if (!is_finite(v)) {
+            if (v != v) return (ub - lb) / 2;
+            return (v < 0.0) ? lb + LIT_EPS_DBL : ub - LIT_EPS_DBL;
+        }
+        const double e = det_exp(v);
+        const double r = (lb - LIT_EPS_DBL + (ub + LIT_EPS_DBL) * e) / (1.0 + e);
+        return is_finite(r) ? r : ub - LIT_EPS_DBL;
+    }
+    default: return v;
+    }
+}
+MI_HD double lit_inv_jacobian(double v, int bt, double lb, double ub)
+{
+    switch (bt) {
+    case 2: return det_exp(-v);
+    case 3: return det_exp(v);
+    case 4: { const double e = det_exp(v); return ((e + 1) * (e + 1)) / (e * (ub - lb)); }
+    default: return 1.0;
+    }
+}
+MI_HD double lit_log_jacobian(const LitParams& p, const double* v)
+{
+    double ret = 0.0;
+    for (uint32_t i = 0; i < p.t.d; ++i) {
+        switch (p.btype[i]) {
+        case 2: ret += v[i]; break;
+        case 3: ret += -v[i]; break;
+        case 4: {
+            const double e = det_exp(v[i]);
+            if (is_finite(e)) ret += det_log(p.ub[i] - p.lb[i]) + v[i] - 2 * det_log(1 + e);
+            else ret += det_log(p.ub[i] - p.lb[i]) - v[i];
+            break; }
+        default: break;
+        }
+    }
+    return ret;
+}
+
+// ---- the target: value (returned, same bits in every thread) and, when grad != nullptr, the gradient of the log kernel.
+// w: d doubles of scratch; rows: 2 n_rows doubles of scratch (logistic).  x / grad / w / rows distinct.
+MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, double* grad, double* w, double* rows)
+{
+    const uint32_t d = t.d;
+    switch (t.kind) {
+    case LIT_ISO: {
+        if (grad) { LIT_PFOR(i, d) grad[i] = -x[i]; par.sync(); }
+        const double r = -0.5 * dot_b(t, x, x);
+        par.sync();                                         // x may be overwritten by the caller's next phase
+        return r;
+    }
+    case LIT_DIAG: {
+        LIT_PFOR(i, d) w[i] = t.prec[(size_t)i * t.prec_stride] * x[i];
+        par.sync();
+        if (grad) { LIT_PFOR(i, d) grad[i] = -w[i]; par.sync(); }
+        const double r = -0.5 * dot_b(t, x, w);
+        par.sync();                                         // w may be overwritten by the next call
+        return r;
+    }
+    case LIT_DENSE: {
+        gemv(par, t.prec, x, d, w);
+        if (grad) { LIT_PFOR(i, d) grad[i] = -w[i]; par.sync(); }
+        const double r = -0.5 * dot_b(t, x, w);
+        par.sync();
+        return r;
+    }
+    default: {   // LIT_LOGISTIC: log K = sum_r [y_r eta_r - log(1 + e^eta_r)] - |beta|^2 / 2, grad = X^T (y - sigmoid(eta)) - beta
+        const uint32_t n = t.n_rows;
+        double* eta = rows;
+        double* term = rows + n;
+        LIT_PFOR(r, n) {
+            double acc = 0.0;
+            const double* xr = t.X + (size_t)r * d;
+            if (t.nblk <= 1 || t.bs == 0) {
+                for (uint32_t j = 0; j < d; ++j) acc = dfma(xr[j], x[j], acc);
+            } else {
+                const int nch = t.eta_chains > 1 ? t.eta_chains : 1;
+                const uint32_t sub = t.bs / (uint32_t)nch;
+                for (int k = 0; k < t.nblk; ++k) {
+                    double e = 0.0;
+                    for (int c = 0; c < nch; ++c) {
+                        const uint32_t lo = (uint32_t)k * t.bs + (uint32_t)c * sub;
+                        const uint32_t hi = (c == nch - 1) ? (uint32_t)(k + 1) * t.bs : lo + sub;
+                        double h = 0.0;
+                        for (uint32_t j = lo; j < d && j < hi; ++j) h = dfma(xr[j], x[j], h);
+                        e = (c == 0) ? h : e + h;
+                    }
+                    acc = (k == 0) ? e : acc + e;
+                }
+            }
+            eta[r] = acc;
+            term[r] = t.y[r] * acc - softplus(acc);
+        }
+        par.sync();
+        const double ll = sum_w(term, n, t.W);
+        const double ret = ll - 0.5 * dot_b(t, x, x);
+        par.sync();
+        if (grad) {
+            LIT_PFOR(r, n) term[r] = t.y[r] - sigmoid(eta[r]);
+            par.sync();
+            LIT_PFOR(j, d) {
+                double acc = 0.0;
+                for (uint32_t r = 0; r < n; ++r) acc = dfma(t.X[(size_t)r * d + j], term[r], acc);
+                grad[j] = acc - x[j];
+            }
+            par.sync();
+        }
+        return ret;
+    }
+    }
+}
+
+// vectors of one chain
+struct Vecs {
+    double *prev, *cur, *mntm, *z, *mp, *grad, *vi, *jd, *jg, *w, *mean, *t, *pmean, *qmean, *xc, *tt, *rows;
+    double *J, *JM, *CJ, *T, *Sigma, *ga, *Sinv, *L, *Pm, *SPm;      // d*d each (bounded mala)
+};
+MI_HD Vecs carve(double* wk, uint32_t d, uint32_t n_rows, bool mats)
+{
+    Vecs v;
+    const size_t dv = (size_t)d + 8;
+    double* p = wk;
+    v.prev = p; p += dv; v.cur = p; p += dv; v.mntm = p; p += dv; v.z = p; p += dv; v.mp = p; p += dv; v.grad = p; p += dv;
+    v.vi = p; p += dv; v.jd = p; p += dv; v.jg = p; p += dv; v.w = p; p += dv; v.mean = p; p += dv; v.t = p; p += dv;
+    v.pmean = p; p += dv; v.qmean = p; p += dv; v.xc = p; p += dv; v.tt = p; p += dv;
+    v.rows = p; p += 2 * ((size_t)n_rows + 8);
+    const size_t dd = (size_t)d * d;
+    v.J = v.JM = v.CJ = v.T = v.Sigma = v.ga = v.Sinv = v.L = v.Pm = v.SPm = nullptr;
+    if (mats) { v.J = p; p += dd; v.JM = p; p += dd; v.CJ = p; p += dd; v.T = p; p += dd; v.Sigma = p; p += dd; v.ga = p; p += dd;
+                v.Sinv = p; p += dd; v.L = p; p += dd; v.Pm = p; p += dd; v.SPm = p; p += dd; }
+    return v;
+}
+
+// rnorm_vec_inplace (hmc.cpp:156, mala.cpp:150): dimension i = 8b + 4h + j takes component h of Philox slot 4b + j
+MI_HD void normal_vec(const Par& par, const LitParams& p, uint64_t chain, uint32_t draw, double* z)
+{
+    const uint32_t d = p.t.d, n_slots = (d + 7) / 8 * 4;
+    LIT_PFOR(s, n_slots) {
+        double z0, z1;
+        rng_normal_pair(p.seed, chain, draw, s, STREAM_NORMAL, z0, z1);
+        const uint32_t i0 = 8 * (s / 4) + (s % 4), i1 = i0 + 4;
+        if (i0 < d) z[i0] = z0;
+        if (i1 < d) z[i1] = z1;
+    }
+    par.sync();
+}
+
+// box_log_kernel (hmc.cpp:84-95, mala.cpp:84-95)
+MI_HD double box_log_kernel(const Par& par, const LitParams& p, const Vecs& v, const double* vals)
+{
+    const uint32_t d = p.t.d;
+    if (p.vals_bound) {
+        LIT_PFOR(i, d) v.vi[i] = lit_inv_transform(vals[i], p.btype[i], p.lb[i], p.ub[i]);
+        par.sync();
+        const double k = target_eval(par, p.t, v.vi, nullptr, v.w, v.rows);
+        const double r = k + lit_log_jacobian(p, vals);
+        par.sync();
+        return r;
+    }
+    return target_eval(par, p.t, vals, nullptr, v.w, v.rows);
+}
+
+// y = INV(precond) x, y = CHOL_LOWER(precond) x, y = precond x
+MI_HD void times_minv(const Par& par, const LitParams& p, const double* x, double* y)
+{
+    if (p.precond == 2) gemv(par, p.Minv, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_inv : nullptr, x, p.t.d, y);
+}
+MI_HD void times_lchol(const Par& par, const LitParams& p, const double* x, double* y)
+{
+    if (p.precond == 2) gemv(par, p.Lchol, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_sqrt : nullptr, x, p.t.d, y);
+}
+MI_HD void times_m(const Par& par, const LitParams& p, const double* x, double* y)
+{
+    if (p.precond == 2) gemv(par, p.Mfull, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m : nullptr, x, p.t.d, y);
+}
+
+MI_HD void copy_vec(const Par& par, const double* a, double* b, uint32_t d) { LIT_PFOR(i, d) b[i] = a[i]; par.sync(); }
+
+MI_HD void store_outputs(const Par& par, const LitParams& p, uint64_t c, const Vecs& v, uint64_t n_acc, uint64_t n_leap)
+{
+    const uint32_t d = p.t.d;
+    LIT_PFOR(i, d)
+        p.theta[(size_t)i * p.C + c] = p.vals_bound ? lit_inv_transform(v.prev[i], p.btype[i], p.lb[i], p.ub[i]) : v.prev[i];
+    if (par.tid == 0) {
+        if (p.n_accept) p.n_accept[c] = n_acc;
+        if (p.n_leap) p.n_leap[c] = n_leap;
+    }
+    par.sync();
+}
+MI_HD void store_row(const Par& par, const LitParams& p, uint64_t c, uint32_t row, const double* x)
+{
+    if (!p.draws) return;
+    const uint32_t d = p.t.d;
+    double* out = p.draws + (size_t)row * d * p.C + c;      // hmc.cpp:211-218 / mala.cpp:193-200: rows reported through inv_transform
+    LIT_PFOR(i, d) out[(size_t)i * p.C] = p.vals_bound ? lit_inv_transform(x[i], p.btype[i], p.lb[i], p.ub[i]) : x[i];
+    par.sync();
+}
+
+// ---- mcmc::internal::hmc_impl (hmc.cpp:30-227) for local chain c
+MI_HD void hmc_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+{
+    const uint32_t d = p.t.d;
+    const Vecs v = carve(wk, d, p.t.n_rows, false);
+    const uint64_t chain = p.chain0 + c;
+    const double step = p.eps;
+    LIT_PFOR(i, d) {
+        const double x = p.theta[(size_t)i * p.C + c];
+        v.prev[i] = p.vals_bound ? lit_transform(x, p.btype[i], p.lb[i], p.ub[i]) : x;       // :134-136
+    }
+    par.sync();
+    // mntm_update_fn (:99-128): mntm += step [J] grad / 2 at pos
+    auto mntm_update = [&](const double* pos) {
+        if (p.vals_bound) {
+            LIT_PFOR(i, d) {
+                v.vi[i] = lit_inv_transform(pos[i], p.btype[i], p.lb[i], p.ub[i]);           // :108
+                v.jd[i] = lit_inv_jacobian(pos[i], p.btype[i], p.lb[i], p.ub[i]);            // :114
+            }
+            par.sync();
+            (void)target_eval(par, p.t, v.vi, v.grad, v.w, v.rows);                          // :110
+            diag_gemv(par, v.jd, v.grad, d, v.jg);                                           // jacob_matrix * grad_obj (:122)
+            LIT_PFOR(i, d) v.mntm[i] = v.mntm[i] + (step * v.jg[i]) / 2.0;
+        } else {
+            (void)target_eval(par, p.t, pos, v.grad, v.w, v.rows);                           // :124
+            LIT_PFOR(i, d) v.mntm[i] = v.mntm[i] + (step * v.grad[i]) / 2.0;                 // :126
+        }
+        par.sync();
+    };
+    auto kinetic = [&]() -> double {                        // p . (Minv p) / 2 (:160,184)
+        times_minv(par, p, v.mntm, v.mp);
+        const double k = dot_b(p.t, v.mntm, v.mp) / 2.0;
+        par.sync();
+        return k;
+    };
+    double prev_U = -box_log_kernel(par, p, v, v.prev);     // :140
+    uint64_t n_acc = 0;
+    const uint32_t n_total = p.n_burnin + p.n_keep;
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        normal_vec(par, p, chain, draw + p.draw0, v.z);     // :156
+        times_lchol(par, p, v.z, v.mntm);                   // :158
+        const double prev_K = kinetic();                    // :160
+        copy_vec(par, v.prev, v.cur, d);                    // :162
+        for (uint32_t k = 0; k < p.n_leap_steps; ++k) {     // :164-176
+            mntm_update(v.cur);
+            times_minv(par, p, v.mntm, v.mp);
+            LIT_PFOR(i, d) v.cur[i] = v.cur[i] + step * v.mp[i];                             // :171
+            par.sync();
+            mntm_update(v.cur);
+        }
+        double prop_U = -box_log_kernel(par, p, v, v.cur);  // :178
+        if (!is_finite(prop_U)) prop_U = INF;               // :180-182
+        const double prop_K = kinetic();                    // :184
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;      // std::min(0.01, x), :188
+        const double u = rng_uniform(p.seed, chain, draw + p.draw0, 0u);                     // :189
+        const bool accept = u < det_exp(comp_val);          // :191
+        if (accept) {
+            copy_vec(par, v.cur, v.prev, d);
+            prev_U = prop_U;
+        }
+        if (draw >= p.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            store_row(par, p, c, draw - p.n_burnin, v.prev);
+        }
+    }
+    store_outputs(par, p, c, v, n_acc, (uint64_t)n_total * p.n_leap_steps);
+}
+
+// ---- mcmc::internal::mala_impl (mala.cpp:30-208) with mala_prop_adjustment (mala.ipp:30-70) and dmvnorm (dmvnorm.hpp:28-54)
+MI_HD void mala_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+{
+    const uint32_t d = p.t.d;
+    const bool vb = p.vals_bound != 0;
+    const Vecs v = carve(wk, d, p.t.n_rows, vb);
+    const uint64_t chain = p.chain0 + c;
+    const double step = p.eps, s2 = step * step;            // mala.ipp:41
+    const size_t dd = (size_t)d * d;
+    if (vb) {                                               // precond_matrix / sqrt_precond_matrix as the dense matrices they are (mala.cpp:57-58)
+        LIT_PFOR(e, dd) {
+            const uint32_t i = (uint32_t)(e / d), j = (uint32_t)(e % d);
+            v.Pm[e] = p.precond == 2 ? p.Mfull[e] : (i == j ? (p.precond == 1 ? p.m[i] : 1.0) : 0.0);
+            v.SPm[e] = p.precond == 2 ? p.Lchol[e] : (i == j ? (p.precond == 1 ? p.m_sqrt[i] : 1.0) : 0.0);
+        }
+        par.sync();
+    }
+    LIT_PFOR(i, d) {
+        const double x = p.theta[(size_t)i * p.C + c];
+        v.prev[i] = vb ? lit_transform(x, p.btype[i], p.lb[i], p.ub[i]) : x;                 // :132-134
+    }
+    par.sync();
+    // mala_mean_fn (mala.cpp:97-125): out = vals + step^2 [J] M grad / 2; J_out (d*d) receives inv_jacobian_adjust(vals) when bounded
+    auto mean_fn = [&](const double* vals, double* J_out, double* out) {
+        if (vb) {
+            LIT_PFOR(i, d) v.vi[i] = lit_inv_transform(vals[i], p.btype[i], p.lb[i], p.ub[i]);
+            par.sync();
+            (void)target_eval(par, p.t, v.vi, v.grad, v.w, v.rows);                          // :109
+            LIT_PFOR(e, dd) {
+                const uint32_t i = (uint32_t)(e / d), j = (uint32_t)(e % d);
+                J_out[e] = (i == j) ? lit_inv_jacobian(vals[i], p.btype[i], p.lb[i], p.ub[i]) : 0.0;   // :113
+            }
+            par.sync();
+            matmul(par, J_out, v.Pm, d, v.JM);
+            scale_mat(par, s2, v.JM, d);
+            gemv(par, v.JM, v.grad, d, v.t);
+            LIT_PFOR(i, d) out[i] = vals[i] + v.t[i] / 2.0;                                  // :121
+        } else {
+            (void)target_eval(par, p.t, vals, v.grad, v.w, v.rows);                          // :123
+            times_m(par, p, v.grad, v.t);
+            LIT_PFOR(i, d) out[i] = vals[i] + (s2 * v.t[i]) / 2.0;
+        }
+        par.sync();
+    };
+    // dmvnorm(x | mu, Sigma) with INV(Sigma) as `sinv` (dense, or nullptr: the diagonal p.sinv_diag / p.rs) and LOG_DET(Sigma)
+    auto dmvnorm = [&](const double* x, const double* mu, const double* sinv, double log_det) -> double {
+        LIT_PFOR(i, d) v.xc[i] = x[i] - mu[i];                                               // dmvnorm.hpp:37
+        par.sync();
+        if (sinv) gemv(par, sinv, v.xc, d, v.tt);
+        else if (p.sinv_diag) diag_gemv(par, p.sinv_diag, v.xc, d, v.tt);
+        else {                                              // INV(eps^2 I) = diag(rs)
+            const uint32_t n = count_nonfinite(v.xc, d);
+            LIT_PFOR(i, d) v.tt[i] = (n - (is_finite(v.xc[i]) ? 0u : 1u) > 0u) ? lit_nan() : dfma(p.rs, v.xc[i], 0.0);
+            par.sync();
+        }
+        const double quad = dot_b(p.t, v.xc, v.tt);                                          // :39
+        par.sync();
+        return p.cons_term - 0.5 * (log_det + quad);                                         // :41
+    };
+    double prev_LP = box_log_kernel(par, p, v, v.prev);     // :138
+    uint64_t n_acc = 0;
+    const uint32_t n_total = p.n_burnin + p.n_keep;
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        normal_vec(par, p, chain, draw + p.draw0, v.z);     // :150
+        if (vb) {                                           // :152-157
+            mean_fn(v.prev, v.J, v.mean);
+            chol_lower(par, v.J, d, v.CJ);
+            matmul(par, v.CJ, v.SPm, d, v.T);
+            scale_mat(par, step, v.T, d);
+            gemv(par, v.T, v.z, d, v.tt);
+            LIT_PFOR(i, d) v.cur[i] = v.mean[i] + v.tt[i];
+        } else {                                            // :159
+            mean_fn(v.prev, nullptr, v.mean);
+            times_lchol(par, p, v.z, v.tt);
+            LIT_PFOR(i, d) v.cur[i] = v.mean[i] + step * v.tt[i];
+        }
+        par.sync();
+        double prop_LP = box_log_kernel(par, p, v, v.cur);  // :162
+        if (!is_finite(prop_LP)) prop_LP = -INF;            // :164-166
+        double adj;                                         // mala_prop_adjustment
+        if (vb) {
+            mean_fn(v.cur, v.CJ, v.pmean);                  // :49  (CJ now holds prop_inv_jacob)
+            mean_fn(v.prev, v.J, v.qmean);                  // :50
+            matmul(par, v.CJ, v.Pm, d, v.Sigma);            // :52-53: prop_inv_jacob in BOTH terms
+            scale_mat(par, s2, v.Sigma, d);
+            inverse(par, v.Sigma, d, v.ga, v.Sinv);
+            chol_lower(par, v.Sigma, d, v.L);
+            const double ld = log_det_from_chol(v.L, d);
+            const double a = dmvnorm(v.prev, v.pmean, v.Sinv, ld);
+            const double b = dmvnorm(v.cur, v.qmean, v.Sinv, ld);
+            adj = a - b;
+        } else {
+            mean_fn(v.cur, nullptr, v.pmean);               // :60
+            mean_fn(v.prev, nullptr, v.qmean);              // :61
+            const double a = dmvnorm(v.prev, v.pmean, p.precond == 2 ? p.Sinv : nullptr, p.log_det);
+            const double b = dmvnorm(v.cur, v.qmean, p.precond == 2 ? p.Sinv : nullptr, p.log_det);
+            adj = a - b;
+        }
+        const double x = prop_LP - prev_LP + adj;
+        const double comp_val = (x < 0.01) ? x : 0.01;      // mala.cpp:170
+        const double u = rng_uniform(p.seed, chain, draw + p.draw0, 0u);                     // :171
+        const bool accept = u < det_exp(comp_val);          // :173
+        if (accept) {
+            copy_vec(par, v.cur, v.prev, d);
+            prev_LP = prop_LP;
+        }
+        if (draw >= p.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            store_row(par, p, c, draw - p.n_burnin, v.prev);
+        }
+    }
+    store_outputs(par, p, c, v, n_acc, 0);
+}
+
+#if defined(__HIPCC__)
+template <int ALGO>     // 0 hmc, 1 mala
+__global__ __launch_bounds__(256) void literal_kernel(const LitParams prm)
+{
+    if (prm.any != nullptr && *prm.any == 0u) return;
+    const Par par{(int)threadIdx.x, (int)blockDim.x};
+    double* wk = prm.work + (size_t)blockIdx.x * prm.work_stride;
+    for (uint64_t c = blockIdx.x; c < prm.C; c += gridDim.x) {
+        if (prm.flag != nullptr && prm.flag[c] == 0u) continue;
+        if (ALGO == 0) hmc_chain(par, prm, c, wk); else mala_chain(par, prm, c, wk);
+        __syncthreads();
+    }
+}
+#endif
+
+}  // namespace lit
+}  // namespace mi

@@ -1,0 +1,17 @@
+// literal_launch.hip -- translation unit of the literal replay kernels (literal.hpp): mcmc::hmc / mcmc::mala, one workgroup per
+// chain, the reference's dense operations as written.  Launched behind every throughput kernel of the plain paths (it returns at
+// once unless a chain was flagged) and, on all chains, for bounded mala with a dense precond_mat.
+#include "literal.hpp"
+#include "launchers.hpp"
+
+namespace mi {
+
+int launch_literal(int algo, const lit::LitParams& prm, unsigned n_wg, hipStream_t st)
+{
+    if (n_wg == 0) return 0;
+    if (algo == 0) hipLaunchKernelGGL(lit::literal_kernel<0>, dim3(n_wg), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(lit::literal_kernel<1>, dim3(n_wg), dim3(256), 0, st, prm);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi

@@ -22,6 +22,7 @@ struct LogitParams {
     uint32_t n_burnin, n_keep, n_leap;
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     double eps, s2, rs, cons_term, log_det;
+    uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
 };
 
 enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2 };   // RWMH: eps carries par_scale (identity cov_mat)

@@ -2,6 +2,7 @@
 #define MI_KC_MODE 2
 #define MI_RNG_NOINLINE 1      // the Philox + Box-Muller pair as an out-of-line leaf function: smaller per-draw code, fewer spills (config 3: 61.2 -> 56.2 ms per 20 draws)
 #include "logistic_lds.hpp"
+#include "launch_common.hpp"
 
 namespace mi {
 namespace {
@@ -24,6 +25,7 @@ int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* wor
     prm.Xp = xp;
     hipLaunchKernelGGL(pack_logit_lds_kernel<NTQ>, dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
     auto kern = logit_lds_kernel<NTQ, ALGO>;
+    note_kernel("logit_lds_kernel<%d, %d>", NTQ, ALGO);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);

@@ -328,6 +328,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    // non-finite regime: detected through the proposal densities (mala) / energies (hmc), the same bits in
+    // the four waves of a chain tile; the chain is flagged and replayed by literal.hpp instead of finished here
+    [[maybe_unused]] bool nf_seen = false;
 
     constexpr int SB = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);   // slices per batch of workspace loads
     auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
@@ -434,6 +437,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             if (!is_finite(pl)) pl = -INF;               // mala.cpp:164-166
             const double da = prm.cons_term - 0.5 * (prm.log_det + qv[0]);       // dmvnorm.hpp:41
             const double db = prm.cons_term - 0.5 * (prm.log_det + qv[1]);
+            nf_seen = nf_seen || !is_finite(da) || !is_finite(db);
             const double x = pl - prev_LP + (da - db);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
             const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :171
@@ -525,7 +529,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             }
             const double prop_K = kinetic();
             double prop_U = -lp;                         // :178 (n_leap = 0: the value at the unchanged position)
-            if (!is_finite(prop_U)) prop_U = INF;        // :180-182
+            const bool u_nf = !is_finite(prop_U);
+            if (u_nf) prop_U = INF;                      // :180-182
+            nf_seen |= u_nf | !is_finite(prop_K);
             const double x = -(prop_U + prop_K) + (prev_U + prev_K);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // :188
             const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :189
@@ -548,7 +554,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         if (blockIdx.x == 0 && threadIdx.x == 0 && prm.n_accept) { prm.n_accept[0] = clock64() - t0_clk; prm.n_accept[1] = wall_clock64() - t0_wall; }
         return;
     }
-    if (live) {
+    const bool replay = nf_seen && prm.nf_flag != nullptr;
+    if (live && replay && q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+    if (live && !replay) {
 #pragma unroll
         for (int s = 0; s < NSQ; ++s) {
             const uint32_t dim = dim_of(s);

@@ -51,6 +51,7 @@ struct MalaParams {
     const double* Mfull;    // precond_mat
     const double* Lchol;    // CHOL_LOWER(precond_mat)
     const double* Sinv;     // INV(eps^2 precond_mat)
+    uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
 };
 
 template <int NT, bool GENERAL = false>
@@ -153,6 +154,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
     double prev_LP = log_kernel(th, xp, w);             // box_log_kernel(first_draw), mala.cpp:138
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    // Non-finite regime: `precond_matrix * grad_obj`, INV(Sigma) * (x - mu), and, bounded, `inv_jacob *
+    // precond_matrix`, CHOL_LOWER(J), INV / LOG_DET of eps^2 J M are dense operations in the reference; with every matrix diagonal
+    // they are the element-wise arithmetic below only while every value is finite.  A non-finite entry of theta, theta', either
+    // gradient or either Jacobian makes one of the two proposal densities non-finite: the chain is then flagged and replayed
+    // literally (literal.hpp) instead of finished here.
+    bool nf_seen = false;
 
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
@@ -233,6 +240,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
         }
         const double da = prm.cons_term - 0.5 * (log_det + qa);          // :41
         const double db = prm.cons_term - 0.5 * (log_det + qb);
+        nf_seen = nf_seen || !is_finite(da) || !is_finite(db);
         const double x = prop_LP - prev_LP + (da - db);
         const double comp_val = (x < 0.01) ? x : 0.01;   // std::min(0.01, x), mala.cpp:170
         const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);          // :171
@@ -256,7 +264,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_mfma_kernel(
             }
         }
     }
-    if (live) {
+    const bool replay = nf_seen && prm.nf_flag != nullptr;
+    if (live && replay && j == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+    if (live && !replay) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;

@@ -11,6 +11,7 @@ int gauss(const MalaParams& prm, hipStream_t st)
 {
     const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     auto kern = mala_gauss_mfma_kernel<NT, GENERAL>;
+    note_kernel("mala_gauss_mfma_kernel<%d, %s>", NT, GENERAL ? "true" : "false");
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();
@@ -21,6 +22,7 @@ int dense_m(const MalaParams& prm, hipStream_t st)
 {
     const size_t lds = (size_t)(NT <= 4 ? 4 : 1) * NT * 4 * NT * 64 * sizeof(double);
     auto kern = mala_gauss_dense_m_kernel<NT>;
+    note_kernel("mala_gauss_dense_m_kernel<%d>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();

@@ -19,6 +19,7 @@
 
 #include "../../include/mi_mcmc.h"
 #include "host_common.hpp"
+#include "host_linalg.hpp"
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
@@ -29,6 +30,7 @@
 #include "logistic_launch.hpp"
 #include "launchers.hpp"
 #include "small_samplers.hpp"
+#include "literal_host.hpp"
 
 // round time of the few-chain launch shapes of the plain HMC kernel relative to the default (two waves per SIMD), d = 128
 #ifndef MI_HMC_COST_1WAVE
@@ -41,7 +43,17 @@
 namespace mi {
 namespace host {
 std::string& last_error() { thread_local std::string e; return e; }
+std::string& last_kernel() { thread_local std::string k; return k; }
 }  // namespace host
+void note_kernel(const char* fmt, ...)
+{
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    host::last_kernel() = buf;
+}
 }  // namespace mi
 
 namespace {
@@ -107,6 +119,103 @@ int ws_release(hipStream_t st, bool all_streams, uint64_t* freed)
         w->p = nullptr; w->cap = 0;
     }
     if (freed) *freed = total;
+    return MI_OK;
+}
+
+// ---- literal replay of the non-finite regime (literal.hpp).  The plain throughput kernels flag the chains whose energies /
+// proposal densities went non-finite (nf_flag[c] = 1, nf_flag[C] = 1) and leave their outputs alone; the literal kernel, enqueued
+// right behind them on the same stream, replays exactly those chains from their initial values (it returns at once when nothing
+// was flagged: one scalar load per workgroup).  Flags and the replay's workspace ride behind the caller's own workspace in the
+// per-stream cache.
+struct ReplayWs {
+    uint32_t* flag = nullptr;     // [C + 1]
+    double* work = nullptr;
+    size_t stride = 0;            // doubles per workgroup
+    unsigned n_wg = 0;
+    size_t own_bytes = 0;         // the caller's part, rounded up
+    size_t total_bytes = 0;
+};
+ReplayWs replay_layout(size_t own_bytes, uint64_t C, uint32_t d, uint32_t n_rows, bool mala_bounded)
+{
+    ReplayWs r;
+    r.own_bytes = (own_bytes + 255) & ~(size_t)255;
+    r.stride = mi::lit::lit_work_doubles(d, n_rows, mala_bounded);
+    r.n_wg = (unsigned)std::min<uint64_t>(C, mala_bounded ? 128u : 512u);
+    const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    r.total_bytes = r.own_bytes + flag_bytes + (size_t)r.n_wg * r.stride * sizeof(double);
+    return r;
+}
+int replay_bind(ReplayWs& r, void* base, uint64_t C, hipStream_t st)
+{
+    char* b = static_cast<char*>(base);
+    r.flag = reinterpret_cast<uint32_t*>(b + r.own_bytes);
+    const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    r.work = reinterpret_cast<double*>(b + r.own_bytes + flag_bytes);
+    HIP_TRY(hipMemsetAsync(r.flag, 0, (C + 1) * sizeof(uint32_t), st));
+    return MI_OK;
+}
+// the Gaussian kinds as the literal kernels read them: ISO / DIAG are ELEMENT-WISE targets in the oracle (prec_i * theta_i), DENSE a
+// mat-vec.  P_dense: the d*d device matrix of the MFMA path (diagonal for ISO / DIAG), or nullptr with prec_vec (d values / nullptr)
+void lit_gauss_target(mi::lit::LitTarget& t, int kind, uint32_t d, const double* P_dense, const double* prec_vec)
+{
+    t = mi::lit::LitTarget{};
+    t.d = d;
+    if (kind == MI_TARGET_GAUSS_DENSE) { t.kind = mi::lit::LIT_DENSE; t.prec = P_dense; }
+    else if (kind == MI_TARGET_GAUSS_DIAG) {
+        t.kind = mi::lit::LIT_DIAG;
+        if (P_dense) { t.prec = P_dense; t.prec_stride = d + 1; } else { t.prec = prec_vec; t.prec_stride = 1; }
+    } else t.kind = mi::lit::LIT_ISO;
+    mi::lit::lit_orders(t);
+}
+void lit_common(mi::lit::LitParams& p, const mi_settings* s, const mi_chains* dev_chains, const ReplayWs& r, bool all_chains)
+{
+    p.C = dev_chains->n_chains; p.chain0 = dev_chains->chain0;
+    p.theta = dev_chains->theta; p.draws = dev_chains->draws; p.n_accept = dev_chains->n_accept; p.n_leap = dev_chains->n_leapfrogs;
+    p.seed = s->rng_seed_value;
+    p.n_burnin = (uint32_t)s->n_burnin_draws; p.n_keep = (uint32_t)s->n_keep_draws; p.n_leap_steps = (uint32_t)s->n_leap_steps;
+    p.draw0 = (uint32_t)dev_chains->draw0; p.eps = s->step_size;
+    p.flag = all_chains ? nullptr : r.flag;
+    p.any = all_chains ? nullptr : r.flag + p.C;
+    p.work = r.work; p.work_stride = r.stride;
+}
+
+// device copies of a LitPrep (literal_host.hpp) and the LitParams pointers into them.  The buffers die with the LitDev, so a caller
+// that uploaded anything synchronises the stream before it returns.
+struct LitDev {
+    DevBuf bt, lb, ub, m, ms, mi, Mfull, Lchol, Minv, sinv_diag, Sinv;
+    bool any = false;
+};
+int lit_upload(const mi::lit::LitPrep& pr, uint32_t d, bool want_bounds, LitDev& dv, mi::lit::LitParams& p)
+{
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        HIP_TRY(b.alloc(bytes));
+        HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        dv.any = true;
+        return MI_OK;
+    };
+    int rc;
+    p.precond = pr.precond;
+    p.rs = pr.rs; p.log_det = pr.log_det; p.cons_term = pr.cons_term;
+    if (want_bounds) {
+        if ((rc = up(dv.bt, pr.bt.data(), d * sizeof(int)))) return rc;
+        if ((rc = up(dv.lb, pr.lb.data(), d * 8))) return rc;
+        if ((rc = up(dv.ub, pr.ub.data(), d * 8))) return rc;
+        p.vals_bound = 1; p.btype = dv.bt.as<int>(); p.lb = dv.lb.as<double>(); p.ub = dv.ub.as<double>();
+    }
+    if (pr.precond == 1) {
+        if ((rc = up(dv.m, pr.m.data(), d * 8))) return rc;
+        if ((rc = up(dv.ms, pr.m_sqrt.data(), d * 8))) return rc;
+        if ((rc = up(dv.mi, pr.m_inv.data(), d * 8))) return rc;
+        p.m = dv.m.as<double>(); p.m_sqrt = dv.ms.as<double>(); p.m_inv = dv.mi.as<double>();
+    } else if (pr.precond == 2) {
+        const size_t mb = (size_t)d * d * 8;
+        if ((rc = up(dv.Mfull, pr.Mfull.data(), mb))) return rc;
+        if ((rc = up(dv.Lchol, pr.Lchol.data(), mb))) return rc;
+        if ((rc = up(dv.Minv, pr.Minv.data(), mb))) return rc;
+        p.Mfull = dv.Mfull.as<double>(); p.Lchol = dv.Lchol.as<double>(); p.Minv = dv.Minv.as<double>();
+    }
+    if (!pr.sinv_diag.empty()) { if ((rc = up(dv.sinv_diag, pr.sinv_diag.data(), d * 8))) return rc; p.sinv_diag = dv.sinv_diag.as<double>(); }
+    if (!pr.Sinv.empty()) { if ((rc = up(dv.Sinv, pr.Sinv.data(), (size_t)d * d * 8))) return rc; p.Sinv = dv.Sinv.as<double>(); }
     return MI_OK;
 }
 
@@ -219,61 +328,31 @@ int fill_n_leap(uint64_t* dev_ptr, uint64_t n, uint64_t v, hipStream_t st)
 }
 
 // LDS-staged logistic kernels (logistic_lds.hip): workspace from the per-stream cache, launch in their own translation unit
-int launch_logit(int algo, const mi::LogitParams& prm, const double* X_dev, const double* y_dev, hipStream_t st)
+int launched(const char* what, int hip_err);
+int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const double* y_dev, hipStream_t st,
+                 const mi_settings* settings, const mi_chains* dev_chains)
 {
     WsLease base;
-    int rcw = ws_get(st, mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), base);
+    const bool replay = algo != mi::LOGIT_RWMH;          // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
+    ReplayWs rp = replay_layout(mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), prm.C, prm.d, prm.n_rows, false);
+    int rcw = ws_get(st, replay ? rp.total_bytes : rp.own_bytes, base);
     if (rcw) return rcw;
+    if (replay) {
+        rcw = replay_bind(rp, base.p, prm.C, st);
+        if (rcw) return rcw;
+        prm.nf_flag = rp.flag;
+    }
     const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st);
     if (e != 0) return fail(MI_ERR_HIP, "logistic kernel launch: %s", hipGetErrorString((hipError_t)e));
+    if (replay) {                                       // chains that reached the non-finite regime: replayed literally (literal.hpp)
+        mi::lit::LitParams lp{};
+        lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = prm.d; lp.t.n_rows = prm.n_rows; lp.t.X = X_dev; lp.t.y = y_dev;
+        mi::lit::lit_orders(lp.t);
+        lit_common(lp, settings, dev_chains, rp, false);
+        lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
+        return launched("logistic (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
+    }
     return MI_OK;
-}
-
-
-
-// INV and CHOL_LOWER of a dense precond_mat on the host, with the operation order the oracle states for the reference's
-// BMO_MATOPS_INV / BMO_MATOPS_CHOL_LOWER (Gauss-Jordan with partial pivoting; column Cholesky).  Compiled with
-// -ffp-contract=off like everything else, so the bits are the oracle's.
-void host_inverse(const double* A, size_t d, std::vector<double>& Ainv)
-{
-    std::vector<double> a(A, A + d * d);
-    Ainv.assign(d * d, 0.0);
-    for (size_t i = 0; i < d; ++i) Ainv[i * d + i] = 1.0;
-    for (size_t c = 0; c < d; ++c) {
-        size_t piv = c;
-        double best = std::fabs(a[c * d + c]);
-        for (size_t r = c + 1; r < d; ++r)
-            if (std::fabs(a[r * d + c]) > best) { best = std::fabs(a[r * d + c]); piv = r; }
-        if (piv != c)
-            for (size_t j = 0; j < d; ++j) { std::swap(a[c * d + j], a[piv * d + j]); std::swap(Ainv[c * d + j], Ainv[piv * d + j]); }
-        const double pv = a[c * d + c];
-        for (size_t j = 0; j < d; ++j) { a[c * d + j] = a[c * d + j] / pv; Ainv[c * d + j] = Ainv[c * d + j] / pv; }
-        for (size_t r = 0; r < d; ++r) {
-            if (r == c) continue;
-            const double f = a[r * d + c];
-            if (f == 0.0) continue;
-            for (size_t j = 0; j < d; ++j) {
-                a[r * d + j] = a[r * d + j] - f * a[c * d + j];
-                Ainv[r * d + j] = Ainv[r * d + j] - f * Ainv[c * d + j];
-            }
-        }
-    }
-}
-
-void host_cholesky_lower(const double* A, size_t d, std::vector<double>& L)
-{
-    L.assign(d * d, 0.0);
-    for (size_t j = 0; j < d; ++j) {
-        double sum = A[j * d + j];
-        for (size_t k = 0; k < j; ++k) sum = sum - L[j * d + k] * L[j * d + k];
-        const double ljj = std::sqrt(sum);
-        L[j * d + j] = ljj;
-        for (size_t i = j + 1; i < d; ++i) {
-            double t = A[i * d + j];
-            for (size_t k = 0; k < j; ++k) t = t - L[i * d + k] * L[j * d + k];
-            L[i * d + j] = t / ljj;
-        }
-    }
 }
 
 // d x d row-major -> MFMA A-fragment order [t][s][lane] = M[16 t + (lane & 15)][4 s + (lane >> 4)], zero padded to 16 nt
@@ -398,7 +477,7 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.n_leap = (uint32_t)settings->n_leap_steps;
     q.eps = settings->step_size;
     q.draw0 = (uint32_t)chains->draw0;
-    rc = launch_logit(algo, q, X_dev, y_dev, st);
+    rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
                      algo == mi::LOGIT_HMC ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
@@ -543,6 +622,7 @@ void mi_settings_default(mi_settings* s)
 }
 
 const char* mi_mcmc_last_error(void) { return mi::host::last_error().c_str(); }
+const char* mi_mcmc_last_kernel(void) { return mi::host::last_kernel().c_str(); }
 int mi_mcmc_version(void) { return MI_MCMC_VERSION; }
 int mi_mcmc_device_count(void)
 {
@@ -645,9 +725,13 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
         q.draw0 = (uint32_t)chains->draw0;
         WsLease scratch;
-        rc = ws_get(st, 2 * d * chains->n_chains * sizeof(double), scratch);
+        ReplayWs rp = replay_layout(2 * d * chains->n_chains * sizeof(double), chains->n_chains, (uint32_t)d, 0, false);
+        rc = ws_get(st, rp.total_bytes, scratch);
         if (rc) return rc;
         q.scratch = scratch.as<double>();
+        rc = replay_bind(rp, scratch.p, chains->n_chains, st);
+        if (rc) return rc;
+        q.nf_flag = rp.flag;
         int diag_lanes = mi::hmc_diag_pick_lanes(q.C);          // lanes per chain (hmc_diag.hpp)
         if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_1LANE) diag_lanes = 1;
         if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_4LANE) diag_lanes = 4;
@@ -657,14 +741,24 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             HIP_TRY(hipMemcpy(ms_d.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(mi_d.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
             q.m_sqrt = ms_d.as<double>(); q.m_inv = mi_d.as<double>();
+            mi::note_kernel("hmc_diag%d_kernel<true>", diag_lanes == 4 ? 4 : 1);
             if (diag_lanes == 4) hipLaunchKernelGGL(mi::hmc_diag4_kernel<true>, dim3((unsigned)((q.C + 63) / 64)), dim3(256), 0, st, q);
             else hipLaunchKernelGGL(mi::hmc_diag1_kernel<true>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
-        } else
+        } else {
+        mi::note_kernel("hmc_diag%d_kernel<false>", diag_lanes == 4 ? 4 : 1);
         if (diag_lanes == 4) hipLaunchKernelGGL(mi::hmc_diag4_kernel<false>, dim3((unsigned)((q.C + 63) / 64)), dim3(256), 0, st, q);
         else hipLaunchKernelGGL(mi::hmc_diag1_kernel<false>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+        }
         HIP_TRY(hipGetLastError());
+        {   // chains that reached the non-finite regime: replayed literally (literal.hpp)
+            mi::lit::LitParams lp{};
+            lit_gauss_target(lp.t, target->kind, (uint32_t)d, nullptr, prec_dev);
+            lit_common(lp, settings, &sc.dev, rp, false);
+            if (diag_precond_elementwise) { lp.precond = 1; lp.m_sqrt = ms_d.as<double>(); lp.m_inv = mi_d.as<double>(); }
+            rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
+            if (rc) return rc;
+        }
+        if (diag_precond_elementwise) HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
         if (prec_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -688,9 +782,15 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // stream-ordered workspace: P * theta of the last accepted state, [d][C]
     WsLease wsave;
     const size_t d_pad_h = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, 3 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), wsave);
+    ReplayWs rp = replay_layout(3 * d_pad_h * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), chains->n_chains, (uint32_t)d, 0, false);
+    rc = ws_get(st, rp.total_bytes, wsave);
     if (rc) return rc;
     prm.wsave = wsave.as<double>();
+    if (!bounded) {                                     // the general variants reproduce the dense products themselves
+        rc = replay_bind(rp, wsave.p, chains->n_chains, st);
+        if (rc) return rc;
+        prm.nf_flag = rp.flag;
+    }
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -768,6 +868,11 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         }
         rc = shape == 0 ? launched("hmc", mi::launch_hmc_gauss(prm, nt, false, false, st))
                         : launched("hmc", mi::launch_hmc_gauss_few_chains(prm, shape, st));
+        if (rc) return rc;
+        mi::lit::LitParams lp{};                        // chains that reached the non-finite regime: replayed literally (literal.hpp)
+        lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr);
+        lit_common(lp, settings, &sc.dev, rp, false);
+        rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
     }
     if (rc) return rc;
 
@@ -905,7 +1010,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
         q.log_det = log_det_;
         q.draw0 = (uint32_t)chains->draw0;
-        rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st);
+        rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st, settings, &sc.dev);
         if (rc) return rc;
         rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
         if (rc) return rc;
@@ -955,9 +1060,34 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     GeneralTables gt;
     rc = general_tables("mala", settings, d, gt, true, true);
     if (rc) return rc;
-    if (gt.active && gt.dense) {
+    // literal replay (literal.hpp): the chains the element-wise kernels flag as non-finite; bounded mala with a dense precond_mat
+    // (INV(eps^2 J(theta') M) per draw, mala.ipp:52-53) runs there entirely
+    const bool mala_bounded = settings->vals_bound != 0;
+    const bool literal_only = gt.active && gt.dense && mala_bounded;
+    const bool dense_unbounded = gt.active && gt.dense && !mala_bounded;   // real dense products: nothing to replay
+    WsLease lws;
+    ReplayWs rp = replay_layout(0, chains->n_chains, (uint32_t)d, 0, mala_bounded);
+    mi::lit::LitParams lp{};
+    LitDev ldev;
+    if (!dense_unbounded) {
+        rc = ws_get(st, rp.total_bytes, lws);
+        if (rc) return rc;
+        rc = replay_bind(rp, lws.p, chains->n_chains, st);
+        if (rc) return rc;
+        lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr);
+        lit_common(lp, settings, &sc.dev, rp, literal_only);
+        mi::lit::LitPrep prep;
+        mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
+                             settings->upper_bounds, settings->precond_mat, prep);
+        rc = lit_upload(prep, (uint32_t)d, mala_bounded, ldev, lp);
+        if (rc) return rc;
+        prm.nf_flag = rp.flag;
+    }
+    if (literal_only) {
+        rc = launched("mala (literal)", mi::launch_literal(1, lp, rp.n_wg, st));
+    }
+    else if (dense_unbounded) {
         // dense precond_mat, unbounded: Sigma = eps^2 M is constant, so INV / CHOL_LOWER / LOG_DET come from the host once
-        if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "mala: a dense precond_mat together with vals_bound is not implemented (INV of eps^2 J M per draw)");
         std::vector<double> Sigma(d * d), Sinv, Ls;
         for (uint64_t i = 0; i < d * d; ++i) Sigma[i] = prm.s2 * settings->precond_mat[i];
         host_inverse(Sigma.data(), d, Sinv);
@@ -981,10 +1111,14 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m = gt.m_dev.as<double>(); prm.m_sqrt = gt.ms_dev.as<double>();
         rc = launched("mala", mi::launch_mala_gauss(prm, nt, 1, st));
-        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+        if (!rc) rc = launched("mala (literal replay)", mi::launch_literal(1, lp, rp.n_wg, st));
     }
-    else rc = launched("mala", mi::launch_mala_gauss(prm, nt, 0, st));
+    else {
+        rc = launched("mala", mi::launch_mala_gauss(prm, nt, 0, st));
+        if (!rc) rc = launched("mala (literal replay)", mi::launch_literal(1, lp, rp.n_wg, st));
+    }
     if (rc) return rc;
+    if (gt.active || ldev.any) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
     if (rc) return rc;
 

@@ -14,6 +14,7 @@ int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
 {
     const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double);
     auto kern = nuts_gauss_reg_kernel<NT>;
+    note_kernel("nuts_gauss_reg_kernel<%d>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
     return (int)hipGetLastError();
@@ -24,6 +25,7 @@ int lockstep(const NutsParams& prm, hipStream_t st)
 {
     const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double);
     auto kern = nuts_gauss_mfma_kernel<NT>;
+    note_kernel("nuts_gauss_mfma_kernel<%d>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();

@@ -12,6 +12,7 @@ int gauss(const RwmhParams& prm, hipStream_t st)
     const size_t mat = (size_t)NT * 4 * NT * 64 * sizeof(double);
     const size_t lds = mat * ((DENSE_C && NT <= 4) ? 2 : 1) + (GENERAL ? (size_t)16 * NT * (3 * sizeof(double) + sizeof(int)) : 0);
     auto kern = rwmh_gauss_mfma_kernel<NT, GENERAL, DENSE_C>;
+    note_kernel("rwmh_gauss_mfma_kernel<%d, %s, %s>", NT, GENERAL ? "true" : "false", DENSE_C ? "true" : "false");
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();

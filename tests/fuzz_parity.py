@@ -42,6 +42,9 @@ def sweep(n_cases=60, seed=1, verbose=True):
             N = int(rng.choice([1, 15, 16, 40, 100])); X, y = synth.logistic_problem(d, N, seed=rseed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
         scale = float(rng.choice([0.1, 1.0, 3.0]))
         init = synth.initial_states(C, d, seed=rseed % 1013) * scale
+        if algo in ("hmc", "mala") and rng.random() < 0.15:      # the non-finite regime: chains that blow up or start non-finite
+            eps = float(rng.choice([30.0, 1.0e5, 1.0e160]))
+            if rng.random() < 0.5: init[int(rng.integers(0, C)), int(rng.integers(0, d))] = float(rng.choice([np.inf, -np.inf, np.nan]))
         if general:
             if rng.random() < 0.7:
                 lb, ub = bounds(d); kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
@@ -67,17 +70,6 @@ def sweep(n_cases=60, seed=1, verbose=True):
         o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=chain0)
         ok = np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
         if algo == "nuts": ok = ok and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
-        if not ok and algo == "mala" and (kw.get("vals_bound") or np.isnan(o_draws).any()):
-            # the reference's dense `inv_precond * mntm` / `J * grad` products turn 0 * inf into NaN for every other dimension;
-            # the device keeps dimensions separate ("non-finite regime").  Such a chain's oracle rows are the
-            # image of NaN: NaN (no bound), lb+eps / ub-eps (one bound), (ub-lb)/2 (two bounds).
-            lbv = kw.get("lower_bounds", np.full(d, -np.inf)); ubv = kw.get("upper_bounds", np.full(d, np.inf))
-            fl, fu = np.isfinite(lbv), np.isfinite(ubv)
-            img = np.where(fl & fu, (ubv - lbv) / 2, np.where(fl, lbv + 2.220446049250313e-16, np.where(fu, ubv - 2.220446049250313e-16, np.nan)))
-            badc = sorted(set(np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))[:, 2].tolist()))
-            poisoned = len(badc) > 0 and all(np.array_equal(o_draws[-1, :, c], img, equal_nan=True) for c in badc)
-            if poisoned:
-                say("NONFINITE-REGIME", desc, "chains", badc); continue
         if not ok:
             fails += 1
             bad = np.argwhere(~np.isclose(g_draws, o_draws, rtol=0, atol=0, equal_nan=True))

@@ -1,0 +1,33 @@
+// tests/lit_host.hip -- TEST INFRASTRUCTURE: the HOST instantiation of the literal replay (mcmc_amd/csrc/literal.hpp: the same
+// __host__ __device__ functions the GPU runs, one "thread" per chain here) behind a C entry point, so that the CPU test suite can
+// hold the product's replay logic against the oracle on non-finite cases without a GPU.  Built by tests/lit_host.py with
+//   hipcc -O2 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -shared
+#include "../mcmc_amd/csrc/literal_host.hpp"
+
+extern "C" int lit_host_run(int algo, int kind, uint32_t d, uint32_t n_rows, const double* prec, const double* X, const double* y,
+                            uint64_t C, uint64_t chain0, double* theta, double* draws, uint64_t* n_accept, uint64_t* n_leap,
+                            uint64_t seed, uint32_t n_burnin, uint32_t n_keep, uint32_t n_leap_steps, uint32_t draw0, double eps,
+                            int vals_bound, const double* lower, const double* upper, const double* precond_mat)
+{
+    using namespace mi::lit;
+    LitPrep pr;
+    lit_prepare(algo, d, eps, vals_bound, lower, upper, precond_mat, pr);
+    LitParams p{};
+    p.t.kind = kind; p.t.d = d; p.t.n_rows = n_rows; p.t.prec = prec; p.t.prec_stride = 1; p.t.X = X; p.t.y = y;
+    lit_orders(p.t);
+    p.C = C; p.chain0 = chain0; p.theta = theta; p.draws = draws; p.n_accept = n_accept; p.n_leap = n_leap;
+    p.seed = seed; p.n_burnin = n_burnin; p.n_keep = n_keep; p.n_leap_steps = n_leap_steps; p.draw0 = draw0; p.eps = eps;
+    p.vals_bound = vals_bound; p.btype = pr.bt.data(); p.lb = pr.lb.data(); p.ub = pr.ub.data();
+    p.precond = pr.precond;
+    p.m = pr.m.data(); p.m_sqrt = pr.m_sqrt.data(); p.m_inv = pr.m_inv.data();
+    p.Mfull = pr.Mfull.data(); p.Lchol = pr.Lchol.data(); p.Minv = pr.Minv.data();
+    p.sinv_diag = pr.sinv_diag.empty() ? nullptr : pr.sinv_diag.data();
+    p.Sinv = pr.Sinv.empty() ? nullptr : pr.Sinv.data();
+    p.rs = pr.rs; p.log_det = pr.log_det; p.cons_term = pr.cons_term;
+    std::vector<double> work(lit_work_doubles(d, n_rows, algo == 1 && vals_bound != 0));
+    const Par par{0, 1};
+    for (uint64_t c = 0; c < C; ++c) {
+        if (algo == 0) hmc_chain(par, p, c, work.data()); else mala_chain(par, p, c, work.data());
+    }
+    return 0;
+}

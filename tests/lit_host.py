@@ -1,0 +1,57 @@
+"""ctypes binding of tests/lit_host.hip: the HOST instantiation of the product's literal replay (mcmc_amd/csrc/literal.hpp).
+Test infrastructure: built on first use with hipcc (which cross-compiles without a GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_SO = os.path.join(HERE, "_lit_host.so")
+_SRC = [os.path.join(HERE, "lit_host.hip")] + [os.path.join(ROOT, "mcmc_amd", "csrc", f)
+                                                for f in ("literal.hpp", "literal_host.hpp", "host_linalg.hpp", "det_math.hpp")]
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+KIND = {"iso": 0, "diag": 1, "dense": 2, "logit": 3}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRC):
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared",
+                                   "-o", _SO, _SRC[0]])
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None, y=None, chain0=0, draw0=0,
+        lower=None, upper=None, precond=None):
+    """algo 'hmc' | 'mala'; init [C, d].  Returns (draws [n_keep, d, C], dict(n_accept, n_leap, theta [C, d]))."""
+    init = _f(init)
+    Cn, d = init.shape
+    theta = np.ascontiguousarray(init.T.copy())              # [d][C]
+    draws = np.zeros((n_keep, d, Cn))
+    nacc = np.zeros(Cn, dtype=np.uint64)
+    nleap = np.zeros(Cn, dtype=np.uint64)
+    prec, X, y, lower, upper, precond = _f(prec), _f(X), _f(y), _f(lower), _f(upper), _f(precond)
+    n_rows = 0 if X is None else X.shape[0]
+    u64p = C.POINTER(C.c_uint64)
+    rc = lib().lit_host_run(C.c_int(0 if algo == "hmc" else 1), C.c_int(KIND[kind]), C.c_uint32(d), C.c_uint32(n_rows),
+                            _p(prec), _p(X), _p(y), C.c_uint64(Cn), C.c_uint64(chain0), _p(theta), _p(draws),
+                            nacc.ctypes.data_as(u64p), nleap.ctypes.data_as(u64p), C.c_uint64(seed), C.c_uint32(n_burnin),
+                            C.c_uint32(n_keep), C.c_uint32(n_leap), C.c_uint32(draw0), C.c_double(eps),
+                            C.c_int(0 if lower is None else 1), _p(lower), _p(upper), _p(precond))
+    assert rc == 0
+    return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy())

@@ -17,19 +17,37 @@ def _line(out):
 
 
 def test_single_gpu_line():
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--chains", "8192", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--chains", "8192", "--no-cpu-baseline", "--traffic", "none"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
     assert KEYS <= set(j) and j["n_gpus"] == 1 and j["steps"] == 2 and j["vs_baseline"] is None and j["dtype"] == "f64"
     assert j["roofline"]["bound"] == "mfma" and 0.0 < j["roofline"]["frac"] < 1.0 and "workload" in j["config"]
+    # the kernel label is what the engine launched (mi_mcmc_last_kernel), not a static table: 8 192 chains take a split-tile shape
+    assert j["roofline"]["kernel"].startswith("hmc_gauss_split_kernel<8, 4,"), j["roofline"]["kernel"]
+    assert "ess_per_sec" in j and j["ess_per_sec_incl_reducer"] < j["ess_per_sec"]
+
+
+def test_traffic_is_measured_by_rocprofv3_child_runs():
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    out = subprocess.run([sys.executable, "bench.py", "--config", "5", "--steps", "1", "--warmup", "0", "--chains", "4096",
+                          "--no-cpu-baseline", "--no-ess", "--traffic", "all"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = _line(out.stdout)["roofline"]
+    assert r["kernel"].startswith("hmc_diag4_kernel")
+    assert isinstance(r["traffic_source"], dict) and r["traffic_source"]["source"].startswith("rocprofv3"), r["traffic_source"]
+    # 4096 chains x 1024 dims x 8 B: every draw reads the state and writes the proposal once -- 28 draws, between 1x and 4x of that
+    algorithmic = 28 * 2 * 4096 * 1024 * 8
+    assert 0.5 * algorithmic < r["traffic"] < 4.0 * algorithmic, (r["traffic"], algorithmic)
 
 
 def test_two_rank_code_path():
     env = dict(os.environ, BENCH_TEST_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29531", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "8193",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--traffic", "none"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
@@ -41,7 +59,7 @@ def test_two_rank_code_path():
 @pytest.mark.parametrize("config,bound", [(3, "mfma"), (4, "mfma"), (5, "valu-fp64")])
 def test_other_baseline_configs_print_their_own_roofline(config, bound):
     out = subprocess.run([sys.executable, "bench.py", "--config", str(config), "--steps", "1", "--warmup", "0", "--chains", "2048",
-                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--traffic", "none"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
     assert KEYS <= set(j) and j["roofline"]["bound"] == bound and 0.0 < j["roofline"]["frac"] < 1.0

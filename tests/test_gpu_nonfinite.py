@@ -1,0 +1,164 @@
+"""GPU: the non-finite regime.  The reference multiplies by its identity / diagonal matrices as DENSE products
+(ref: src/hmc.cpp:160,171,184; src/mala.cpp:115-123,155-157; include/mcmc/mala.ipp:52-64), so ONE non-finite entry of a momentum /
+gradient / Jacobian turns every other dimension of the chain into NaN, and std::min(0.01, NaN) accepts the result.  The throughput
+kernels detect such chains and the literal kernels (mcmc_amd/csrc/literal.hpp) replay them; these tests drive chains non-finite on
+every plain path and compare with the oracle bit for bit -- next to healthy chains in the same launch, which must stay untouched."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(g_draws, g, o_draws, o):
+    assert np.array_equal(g["n_accept"], o["n_accept"]), "accept counts differ"
+    bad = np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))
+    assert bad.size == 0, f"draws differ, first at [keep, dim, chain] = {bad[0].tolist()}"
+
+
+def _poisoned_chains(o_draws):
+    """chains whose last kept row holds a non-finite value"""
+    return np.flatnonzero((~np.isfinite(o_draws[-1])).any(axis=0))
+
+
+@pytest.mark.parametrize("hint", [mcmc_amd.KERNEL_ELEMENTWISE_4LANE, mcmc_amd.KERNEL_ELEMENTWISE_1LANE])
+@pytest.mark.parametrize("precond", [False, True])
+def test_elementwise_hmc_d300_chain_driven_non_finite(hint, precond):
+    """hmc_diag{1,4}_kernel (any d): a step size beyond the stability limit of the stiff dimensions lets them overflow inside a
+    trajectory; the reference then poisons the STABLE dimensions too.  Chains 0..5 start huge, the rest stay finite."""
+    d, C = 300, 70
+    prec = synth.ill_conditioned_diag(d, 1.0e4)
+    init = synth.initial_states(C, d, seed=5)
+    init[:6] *= 1.0e300
+    init[7, 11] = np.inf
+    kw, okw = {}, {}
+    if precond:
+        if hint == mcmc_amd.KERNEL_ELEMENTWISE_1LANE: pytest.skip("one case of the preconditioned elementwise kernel is enough")
+        M = np.diag(np.random.default_rng(3).uniform(0.5, 2.0, d)); kw["precond_mat"] = M; okw["precond"] = M
+    st = mcmc_amd.default_settings(rng_seed_value=11, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=6, step_size=0.5, **kw)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec, kernel_hint=hint if not precond else mcmc_amd.KERNEL_AUTO)
+    t = orc.TargetSpec(orc.TARGET_DIAG, d, prec=prec, W=4)
+    s = orc.make_settings(seed=11, n_burnin=2, n_keep=4, n_leap=6, step=0.5, W=4, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    pc = _poisoned_chains(o_draws)
+    assert len(pc) >= 6 and len(pc) < C, f"the case is meant to mix poisoned and healthy chains ({len(pc)} poisoned)"
+    _same(g_draws, g, o_draws, o)
+
+
+@pytest.mark.parametrize("hint", [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_HMC_ONE_WAVE_PER_SIMD, mcmc_amd.KERNEL_HMC_SPLIT2,
+                                  mcmc_amd.KERNEL_HMC_SPLIT4_TWO_WAVES, mcmc_amd.KERNEL_HMC_SPLIT4])
+def test_plain_mfma_hmc_d128_chain_driven_non_finite(hint):
+    """hmc_gauss_mfma_kernel<8, ., false> and the split-tile shapes: chains that start at 1e300 overflow in the first mat-vec."""
+    d, C = 128, 70
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=9)
+    init[3] *= 1.0e300
+    init[20, 5] = -np.inf
+    init[40, 127] = np.nan
+    init[64] *= 1.0e160       # finite gradient, overflow in the energy only
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=1, n_keep_draws=4, n_leap_steps=3, step_size=0.1)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=hint)
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=4, n_burnin=1, n_keep=4, n_leap=3, step=0.1, W=4)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    assert len(_poisoned_chains(o_draws)) >= 2
+    _same(g_draws, g, o_draws, o)
+
+
+@pytest.mark.parametrize("kind", ["iso", "diag"])
+def test_plain_mfma_hmc_on_separable_targets_non_finite(kind):
+    """ISO / DIAG targets on the MFMA kernel (d <= 128): the oracle's target is element-wise there, the kernel's a mat-vec over a
+    diagonal matrix -- they differ only once a value is non-finite, which is when the chain is replayed."""
+    d, C = 100, 33
+    prec = synth.ill_conditioned_diag(d, 1.0e3) if kind == "diag" else None
+    init = synth.initial_states(C, d, seed=2)
+    init[1, 0] = np.inf
+    init[17] *= 1.0e300
+    st = mcmc_amd.default_settings(rng_seed_value=8, n_burnin_draws=0, n_keep_draws=3, n_leap_steps=4, step_size=0.7)
+    kg, ko = (mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG) if kind == "diag" else (mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)
+    g_draws, g = mcmc_amd.hmc(kg, init, st, prec=prec)
+    s = orc.make_settings(seed=8, n_burnin=0, n_keep=3, n_leap=4, step=0.7, W=4)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(ko, d, prec=prec, W=4), init, s)
+    assert len(_poisoned_chains(o_draws)) >= 1
+    _same(g_draws, g, o_draws, o)
+
+
+@pytest.mark.parametrize("variant", ["plain", "diag_precond", "bounded", "bounded_diag_precond"])
+def test_mala_gauss_chain_driven_non_finite(variant):
+    """mala_gauss_mfma_kernel plain and general: a huge step size throws the proposal far out -- gradients overflow, and in a bounded
+    run inv_jacobian_adjust overflows, Gauss-Jordan then pivots on inf / NaN (mala.ipp:52-64)."""
+    d, C = 100, 40
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = np.clip(synth.initial_states(C, d, seed=12), -1.0, 1.5)
+    kw, okw = {}, {}
+    if "bounded" in variant:
+        kind = np.random.default_rng(1).integers(1, 5, d)
+        lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf); ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    else:
+        init[2] *= 1.0e300; init[5, 9] = np.inf
+    if "precond" in variant:
+        M = np.diag(np.random.default_rng(2).uniform(0.3, 3.0, d)); kw["precond_mat"] = M; okw["precond"] = M
+    eps = 1.0e3 if "bounded" in variant else 0.3
+    st = mcmc_amd.default_settings(rng_seed_value=21, n_burnin_draws=1, n_keep_draws=4, step_size=eps, **kw)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    s = orc.make_settings(seed=21, n_burnin=1, n_keep=4, step=eps, W=4, hoist=1, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
+    _same(g_draws, g, o_draws, o)
+
+
+@pytest.mark.parametrize("d,C", [(20, 33), (100, 8)])
+def test_bounded_mala_with_a_dense_preconditioner_runs_on_the_literal_kernel(d, C):
+    """ref: src/mala.cpp:152-157, include/mcmc/mala.ipp:45-55 -- INV(eps^2 J(theta') M) per draw: every chain on literal.hpp"""
+    prec = synth.dense_gaussian_precision(d, seed=3)
+    init = np.clip(synth.initial_states(C, d, seed=4), -1.0, 1.5)
+    rng = np.random.default_rng(9)
+    kind = rng.integers(1, 5, d)
+    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf); ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+    A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + np.diag(rng.uniform(0.3, 3.0, d))
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=2, n_keep_draws=5, step_size=0.15, vals_bound=1,
+                                   lower_bounds=lb, upper_bounds=ub, precond_mat=M)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    s = orc.make_settings(seed=5, n_burnin=2, n_keep=5, step=0.15, W=4, hoist=1, lower=lb, upper=ub, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
+    assert 0 < o["n_accept"].sum() < 5 * C, "the case is meant to both accept and reject"
+    _same(g_draws, g, o_draws, o)
+
+
+@pytest.mark.parametrize("algo", ["mala", "hmc"])
+@pytest.mark.parametrize("d,N", [(70, 33), (300, 40)])
+def test_logistic_chain_driven_non_finite(algo, d, N):
+    """logit_lds_kernel<., MALA | HMC>: an infinite coefficient makes eta +-inf / NaN and one gradient entry infinite; the
+    reference's `precond_matrix * grad_obj` / `inv_precond_matrix * mntm` then poison every coefficient."""
+    C = 40
+    X, y = synth.logistic_problem(d, N, seed=7)
+    init = synth.initial_states(C, d, seed=13) * 0.3
+    init[0, 3] = np.inf
+    init[33, d - 1] = -np.inf
+    init[9] *= 1.0e200
+    dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    st = mcmc_amd.default_settings(rng_seed_value=17, n_burnin_draws=1, n_keep_draws=3, n_leap_steps=2, step_size=0.05)
+    g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=dq, eta_chains=2)
+    s = orc.make_settings(seed=17, n_burnin=1, n_keep=3, n_leap=2, step=0.05, W=4, hoist=1, blocks=4, block_size=dq)
+    o_draws, o = orc.run_many(orc.ALGO_MALA if algo == "mala" else orc.ALGO_HMC, t, init, s)
+    assert len(_poisoned_chains(o_draws)) >= 2
+    _same(g_draws, g, o_draws, o)
+
+
+def test_device_resident_run_replays_without_a_host_round_trip():
+    """MI_MEM_DEVICE: flags, replay workspace and the literal launch ride the caller's stream"""
+    import torch
+    d, C = 128, 48
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=1)
+    init[10] *= 1.0e300
+    st = mcmc_amd.default_settings(rng_seed_value=2, n_burnin_draws=1, n_keep_draws=3, n_leap_steps=2, step_size=0.1)
+    draws, info = mcmc_amd.sample_device("hmc", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    torch.cuda.synchronize()
+    s = orc.make_settings(seed=2, n_burnin=1, n_keep=3, n_leap=2, step=0.1, W=4)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
+    _same(draws.cpu().numpy(), dict(n_accept=info["n_accept"].cpu().numpy().astype(np.uint64)), o_draws, o)

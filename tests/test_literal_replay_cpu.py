@@ -1,0 +1,74 @@
+"""The product's literal replay (mcmc_amd/csrc/literal.hpp), compiled for the HOST, against the oracle -- bit for bit, with the
+emphasis on the non-finite regime: step sizes that blow a chain up, initial values that are already
++-inf / NaN, bounds whose Jacobian overflows, every preconditioner form.  The throughput kernels hand exactly such chains to
+this code on the GPU (tests/test_gpu_nonfinite.py checks that hand-over); here the replay itself is pinned without a GPU."""
+import numpy as np
+import pytest
+
+import lit_host
+import orc
+from mcmc_amd import synth
+
+
+def _case(rng, algo, tgt, force_nonfinite):
+    d = int(rng.choice([1, 2, 3, 5, 8, 12, 17])) if tgt != "logit" else int(rng.choice([3, 9, 17, 40, 70]))
+    C = int(rng.choice([1, 2, 5]))
+    seed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
+    burn, keep = int(rng.integers(0, 3)), int(rng.integers(1, 6))
+    L = int(rng.integers(0, 5))
+    eps = float(rng.choice([0.05, 0.3, 1.5, 40.0, 1e6, 1e160] if force_nonfinite else [0.01, 0.1, 0.5]))
+    prec = X = y = None
+    if tgt == "dense": prec, ko = synth.dense_gaussian_precision(d, seed=seed % 97), orc.TARGET_DENSE
+    elif tgt == "diag": prec, ko = synth.ill_conditioned_diag(d, 50.0), orc.TARGET_DIAG
+    elif tgt == "iso": ko = orc.TARGET_ISO
+    else:
+        N = int(rng.choice([1, 7, 16, 33])); X, y = synth.logistic_problem(d, N, seed=seed % 89); ko = orc.TARGET_LOGISTIC
+    init = synth.initial_states(C, d, seed=seed % 1013) * float(rng.choice([0.1, 1.0, 1e3, 1e200] if force_nonfinite else [0.1, 1.0]))
+    if force_nonfinite and rng.random() < 0.4:
+        bad = rng.choice([np.inf, -np.inf, np.nan])
+        init[rng.integers(0, C), rng.integers(0, d)] = bad
+    kw, okw = {}, {}
+    if tgt != "logit" and rng.random() < 0.6:
+        if rng.random() < 0.6:
+            kind = rng.integers(1, 5, d)
+            lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf); ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+            kw.update(lower=lb, upper=ub); okw.update(lower=lb, upper=ub)
+            fin = np.isfinite(init)
+            init = np.where(fin, np.clip(init, -1.0, 1.5), init)
+        if rng.random() < 0.6:
+            M = np.diag(rng.uniform(0.3, 3.0, d))
+            if rng.random() < 0.5:
+                A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
+            kw.update(precond=M); okw.update(precond=M)
+    tkw = {}
+    if tgt == "logit":
+        dq = 16 if d <= 64 else 32
+        tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
+    t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
+    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_HMC if algo == "hmc" else orc.ALGO_MALA, t, init, s, chain0=chain0)
+    l_draws, l = lit_host.run(algo, tgt, init, seed, burn, keep, L, eps, prec=prec, X=X, y=y, chain0=chain0, **kw)
+    desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} opts={sorted(kw)}"
+    ok = np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"])
+    return ok, desc, bool(np.isnan(o_draws).any() or np.isinf(o_draws).any())
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
+def test_literal_replay_equals_the_oracle_in_the_finite_regime(algo, tgt):
+    rng = np.random.default_rng([11, len(algo), len(tgt)])
+    for _ in range(12):
+        ok, desc, _nf = _case(rng, algo, tgt, force_nonfinite=False)
+        assert ok, desc
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
+def test_literal_replay_equals_the_oracle_in_the_non_finite_regime(algo, tgt):
+    rng = np.random.default_rng([12, len(algo), len(tgt)])
+    n_nonfinite = 0
+    for _ in range(40):
+        ok, desc, nf = _case(rng, algo, tgt, force_nonfinite=True)
+        assert ok, desc
+        n_nonfinite += int(nf)
+    assert n_nonfinite >= 8, f"the sweep is meant to reach the non-finite regime ({n_nonfinite} of 40 cases did)"
