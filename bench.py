@@ -296,7 +296,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
     if C > 0 and rank == 0 and not args.no_ess:
         torch.cuda.synchronize()
         tr = time.perf_counter()
-        stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+        stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream, want_acov=False)
         torch.cuda.synchronize()
         reducer_ms = (time.perf_counter() - tr) * 1e3
         ess_total_rank = float(stats["ess"].min()) * C
@@ -361,7 +361,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
             mass = mcmc_amd.hmc_mass_adapted(target, s_ad, chains, n_windows=3, stream=stream)
             torch.cuda.synchronize()
             t_ad = time.perf_counter() - ta
-            st_ad = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream)
+            st_ad = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream, want_acov=False)
             out["mass_adapted"] = {"what": "mi_mcmc_hmc_run_mass_adapted, pooled diagonal mass, 3 windows, step_size 0.12 (non-reference mode)",
                                    "ms": t_ad * 1e3, "ess_per_sec": float(st_ad["ess"].min()) * C * world / t_ad,
                                    "accept_rate": float(n_accept[:C].double().mean().item()) / n_keep,

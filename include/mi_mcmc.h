@@ -240,6 +240,11 @@ int mi_mcmc_merge_shards(const double* rank_major, uint32_t world_size, uint64_t
  * src/hmc.cpp:138,197). Host memory. */
 int mi_mcmc_draws_to_chain_major(const double* draws_kdc, uint64_t n_keep, uint64_t d, uint64_t n_chains,
                                  double* out_c_colmajor /* [C][d][n_keep] */);
+/* The same for slabs in HBM: both pointers are device memory, the transpose runs as a kernel on `stream` (LDS-tiled, coalesced
+ * on both sides) and the call returns after enqueueing it. */
+int mi_mcmc_draws_to_chain_major_device(const double* draws_kdc_dev, uint64_t n_keep, uint64_t d, uint64_t n_chains,
+                                        double* out_c_colmajor_dev /* [C][d][n_keep] */, void* stream);
+
 
 /* Reducers over a draws_out slab [n_keep][d][C] (in `mem`), on the device (the reference has no ESS / R-hat
  * code, definitions as in mcmc_amd/ess.py).  Outputs are HOST arrays, any of them may be NULL:
@@ -248,8 +253,10 @@ int mi_mcmc_draws_to_chain_major(const double* draws_kdc, uint64_t n_keep, uint6
  *   rhat [d]          Gelman-Rubin potential scale reduction over the C chains
  *   ess  [d]          per-chain effective sample size (Geyer's initial positive sequence on acov); the many-chain ESS is
  *                     C times it.
- * Every lag is computed for n_keep <= 160; for longer series (the reference's default is 1 000 kept draws) lags 0..127 are, the
- * acov rows beyond hold NaN and Geyer's sum runs over the computed lags.  Blocking. */
+ * With acov == NULL only as many lags are computed as Geyer's sum needs (blocks of 16, then 32 lags straight from HBM; a slowly
+ * mixing series falls through to the full computation).  With acov: every lag for n_keep <= 160; for longer series (the
+ * reference's default is 1 000 kept draws) lags 0..127, the acov rows beyond hold NaN and Geyer's sum runs over the computed
+ * lags.  Blocking. */
 int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
                        double* mean, double* acov, double* rhat, double* ess, void* stream);
 

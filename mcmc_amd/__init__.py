@@ -62,7 +62,7 @@ _lib = None
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
-    "mi_mcmc_draws_to_chain_major", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
+    "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
 
@@ -360,15 +360,23 @@ def probe_mfma_cycles(waves_per_simd, use_lds, iters=20000):
     return cyc.value, tf.value
 
 
-def draw_stats(draws, n_keep=None, d=None, n_chains=None, mem=MEM_HOST, stream=None):
+def draw_stats(draws, n_keep=None, d=None, n_chains=None, mem=MEM_HOST, stream=None, want_acov=True):
     """mi_mcmc_draw_stats: pooled mean [d], autocovariance [n_keep, d], R-hat [d] and per-chain ESS [d] of a draws slab
-    [n_keep, d, C] (numpy array, or a device tensor / pointer with mem=MEM_DEVICE and explicit shape)."""
+    [n_keep, d, C] (numpy array, or a device tensor / pointer with mem=MEM_DEVICE and explicit shape).  want_acov=False: ESS and
+    R-hat only -- as many lags as Geyer's sum needs, straight from HBM (acov is None in the result)."""
     if mem == MEM_HOST:
         draws = np.ascontiguousarray(draws, dtype=np.float64)
         n_keep, d, n_chains = draws.shape
-    mean, acov = np.zeros(d), np.zeros((n_keep, d))
+    mean = np.zeros(d)
+    acov = np.zeros((n_keep, d)) if want_acov else None
     rhat, ess = np.zeros(d), np.zeros(d)
     _check(lib().mi_mcmc_draw_stats(C.c_void_p(_ptr(draws)), C.c_int32(mem), C.c_uint64(n_keep), C.c_uint64(d), C.c_uint64(n_chains),
-                                    C.c_void_p(mean.ctypes.data), C.c_void_p(acov.ctypes.data), C.c_void_p(rhat.ctypes.data),
+                                    C.c_void_p(mean.ctypes.data), C.c_void_p(acov.ctypes.data if want_acov else 0), C.c_void_p(rhat.ctypes.data),
                                     C.c_void_p(ess.ctypes.data), C.c_void_p(stream or 0)))
     return dict(mean=mean, acov=acov, rhat=rhat, ess=ess)
+
+
+def draws_to_chain_major_device(draws, n_keep, d, n_chains, out, stream=None):
+    """mi_mcmc_draws_to_chain_major_device: slab [n_keep][d][C] in HBM -> [C][d][n_keep] in HBM (device tensors / pointers)."""
+    _check(lib().mi_mcmc_draws_to_chain_major_device(C.c_void_p(_ptr(draws)), C.c_uint64(n_keep), C.c_uint64(d), C.c_uint64(n_chains),
+                                                     C.c_void_p(_ptr(out)), C.c_void_p(stream or 0)))

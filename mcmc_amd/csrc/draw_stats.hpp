@@ -122,4 +122,94 @@ __global__ __launch_bounds__(64) void stats_acov_tiled_kernel(const double* __re
     if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
 }
 
+// ---- the fast path of ESS / R-hat (no full autocovariance requested): lags 0 .. L-1 only, straight from HBM.
+// Geyer's initial positive sequence stops at the first non-positive pair of autocorrelations -- a handful of lags for a sampler
+// that mixes -- so computing all n lags (n^2 / 2 LDS-fed fmas per series, one wave per CU: the kernels above) is wasted work, and
+// measured slower than the sampler whose draws it summarises.  Here a lane streams its chain's series through a window of L
+// registers (a circular buffer with compile-time indices): one coalesced 512-byte load per time step and wave, L fmas per value,
+// no LDS; many waves per SIMD.  out[g][j][0..L): sum over the group's chains of sum_t v[t] v[t-k]; out2 as above, with the chain
+// variance from sum v^2 - n m_c^2 (v is centred by the pooled mean, so nothing cancels).  The host checks whether Geyer's sum
+// ended inside the L lags and asks for more (2 L, then every lag with the kernels above) if not.
+template <int L>
+__global__ __launch_bounds__(64) void stats_window_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
+                                                          uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                          double* __restrict__ out, double* __restrict__ out2)
+{
+    const uint32_t j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const uint64_t per = (C + G - 1) / G;
+    const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
+    const double mj = mean[j];
+    const size_t row = (size_t)d * C;                   // doubles between consecutive draws of one (dimension, chain)
+    double acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = 0.0;
+    double sm = 0.0, sm2 = 0.0, sv = 0.0;
+    for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
+        const uint64_t c = c0 + lane;
+        const bool on = c < c_hi;
+        const double* p = draws + (size_t)j * C + (on ? c : c_hi - 1);
+        double win[L];
+#pragma unroll
+        for (int u = 0; u < L; ++u) win[u] = 0.0;
+        double s1 = 0.0, q0 = 0.0;
+        for (uint32_t t0 = 0; t0 < n; t0 += L) {
+            double x[L];
+#pragma unroll
+            for (int u = 0; u < L; ++u) {               // L loads in flight per lane
+                const uint32_t t = t0 + (uint32_t)u;
+                x[u] = p[(size_t)(t < n ? t : n - 1) * row];
+            }
+#pragma unroll
+            for (int u = 0; u < L; ++u) {
+                const double v = (on && t0 + (uint32_t)u < n) ? x[u] - mj : 0.0;
+                win[u] = v;
+                s1 += v;
+                q0 = __builtin_fma(v, v, q0);
+#pragma unroll
+                for (int k = 0; k < L; ++k) acc[k] = __builtin_fma(v, win[(u - k + L) % L], acc[k]);
+            }
+        }
+        const double mc = s1 / (double)n;
+        if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? (q0 - (double)n * mc * mc) / (double)(n - 1) : 0.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        double s_ = acc[k];
+        for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m);
+        if (lane == 0) out[((size_t)g * d + j) * L + k] = s_;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
+    if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+}
+
+// draws_out slab [n][d][C] -> per chain the column-major n x d matrix Eigen would hold: out[c][j][k] (SURVEY 8 f-3 "layout
+// converters").  One workgroup per (dimension j, tile of 64 chains): rows of 64 chains in (512-byte coalesced), through an LDS tile,
+// out as runs of n consecutive doubles per chain.
+constexpr int TRANSPOSE_KB = 128;                      // draws per LDS tile
+__global__ __launch_bounds__(256) void draws_to_chain_major_slice_kernel(const double* __restrict__ in, uint32_t n, uint32_t d, uint64_t C_all,
+                                                                        uint64_t c_first, uint64_t c_cnt, double* __restrict__ out)
+{
+    __shared__ double tile[TRANSPOSE_KB * 65];
+    const uint32_t j = blockIdx.x;
+    const uint64_t c0 = c_first + (uint64_t)blockIdx.y * 64;
+    const uint64_t C = c_first + c_cnt;                 // one past the last chain of this launch; rows keep the stride C_all
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t kb = 0; kb < n; kb += TRANSPOSE_KB) {
+        const uint32_t rows = (n - kb < (uint32_t)TRANSPOSE_KB) ? n - kb : (uint32_t)TRANSPOSE_KB;
+        for (uint32_t k = wv; k < rows; k += 4) {
+            const uint64_t c = c0 + lane;
+            tile[(size_t)k * 65 + lane] = (c < C) ? in[((size_t)(kb + k) * d + j) * C_all + c] : 0.0;
+        }
+        __syncthreads();
+        for (uint32_t cc = wv; cc < 64; cc += 4) {
+            const uint64_t c = c0 + cc;
+            if (c < C) {
+                double* o = out + ((size_t)c * d + j) * n + kb;
+                for (uint32_t k = lane; k < rows; k += 64) o[k] = tile[(size_t)k * 65 + cc];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace mi

@@ -15,6 +15,7 @@ namespace mi {
 namespace host {
 
 std::string& last_error();                         // thread-local, defined in mi_mcmc.hip
+std::string& last_kernel();                        // thread-local: what mi_mcmc_last_kernel() returns
 
 inline int fail(int code, const char* fmt, ...)
 {

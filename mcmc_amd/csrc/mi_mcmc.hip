@@ -319,6 +319,14 @@ __global__ void fill_u64_kernel(uint64_t* out, uint64_t n, uint64_t v)
     if (i < n) out[i] = v;
 }
 
+// identity tables of the general kernel variants (no bounds, unit mass) in stream-ordered workspace memory: what a replay of the
+// plain case through a general variant reads (no host buffer has to outlive the call)
+__global__ void fill_identity_tables_kernel(int* bt, double* lb, double* ub, double* ms, double* mi, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bt[i] = 1; lb[i] = 0.0; ub[i] = 0.0; ms[i] = 1.0; mi[i] = 1.0; }
+}
+
 int fill_n_leap(uint64_t* dev_ptr, uint64_t n, uint64_t v, hipStream_t st)
 {
     if (!dev_ptr) return MI_OK;
@@ -1227,9 +1235,14 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.theta = sc.dev.theta;
     WsLease ws;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    rc = ws_get(st, (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), ws);
+    const size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
+    const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
+    const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double), ws);   // + non-finite flags + identity tables of the replay
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
+    uint32_t* const nf_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ws_own_r);
+    double* const id_tab = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ws_own_r + flag_bytes);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -1285,7 +1298,24 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
     else if (lockstep || tick_local) rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));
-    else rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
+    else {
+        // the plain case: nuts_gauss_reg_kernel; chains that reach the non-finite regime are flagged there and
+        // replayed by the general variant, which reproduces the reference's dense products, with identity tables
+        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
+        prm.nf_flag = nf_flag;
+        rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
+        if (rc) return rc;
+        const std::string reg_name = mi::host::last_kernel();
+        int* bt_i = reinterpret_cast<int*>(id_tab);
+        hipLaunchKernelGGL(fill_identity_tables_kernel, dim3(1), dim3(128), 0, st, bt_i, id_tab + 128, id_tab + 256, id_tab + 384, id_tab + 512, 128u);
+        HIP_TRY(hipGetLastError());
+        mi::NutsParams rp = prm;
+        rp.nf_flag = nullptr; rp.replay_flag = nf_flag;
+        rp.btype = bt_i; rp.lb = id_tab + 128; rp.ub = id_tab + 256; rp.m_sqrt = id_tab + 384; rp.m_inv = id_tab + 512;
+        rp.vals_bound = 0;
+        rc = launched("nuts (replay)", mi::launch_nuts_gauss(rp, nt, true, false, false, nuts_batch, st));
+        mi::host::last_kernel() = reg_name;
+    }
     if (rc) return rc;
 
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);

@@ -47,6 +47,7 @@ template <int NT, bool GENERAL = false, bool DENSE_M = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     static_assert(!DENSE_M || GENERAL, "the dense preconditioner rides the general variant");
+    if (prm.replay_flag != nullptr && prm.replay_flag[prm.C] == 0u) return;    // a replay launch with nothing flagged
     constexpr int NS = 4 * NT;
     constexpr int WS_NVEC = NUTS_NVEC_ASYNC;
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
@@ -91,8 +92,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     const int j4 = lane >> 4;
     const int cw = wave * 16 + (lane & 15);
     const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
-    const bool live = cl < prm.C;
-    const uint64_t cld = live ? cl : prm.C - 1;
+    // replay of the chains nuts_gauss_reg_kernel flagged (non-finite regime): the others are not `live` -- they compute along from
+    // whatever theta holds and store nothing -- and a wave without a flagged chain leaves (no barrier follows)
+    const bool live = cl < prm.C && (prm.replay_flag == nullptr || prm.replay_flag[cl] != 0u);
+    if (prm.replay_flag != nullptr && __ballot(live) == 0ull) return;
+    const uint64_t cld = cl < prm.C ? cl : prm.C - 1;
     const uint64_t chain = prm.chain0 + cl;
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
@@ -339,6 +343,7 @@ const double* const mi_t = mi_tab();
         double dH = -(potential() + kinetic()) + (U0 + K0);
         int a_val = 2 * (dH > log_half ? 1 : 0) - 1;
         bool cond = dH > neg_log2;
+        if (prm.replay_flag != nullptr && !live) cond = false;
         while (__ballot(cond) != 0ull) {
             const double e_new = eps * ((a_val == 1) ? 2.0 : 0.5);
             if (cond) { eps = e_new; n_leap++; }
@@ -361,7 +366,7 @@ const double* const mi_t = mi_tab();
     const uint32_t max_depth = prm.max_depth;
 
     // ---------------------------------------------------------------- per-chain state
-    int state = (n_total > 0) ? NS_NEED_DRAW : NS_DONE;
+    int state = (n_total > 0 && (live || prm.replay_flag == nullptr)) ? NS_NEED_DRAW : NS_DONE;   // replay: only the flagged chains run
     uint32_t draw = 0;           // this chain's draw index
     uint32_t jd = 0;             // depth of the doubling in progress
     uint32_t li = 0;             // next leaf of that doubling

@@ -60,6 +60,10 @@ struct NutsParams {
     const double* m_inv;    // diagonal of INV(precond_mat)
     const double* Minv;     // DENSE_M: INV(precond_mat), d*d row-major (device)
     const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), d*d row-major (device)
+    uint32_t* nf_flag;      // nuts_gauss_reg_kernel: [C + 1] or nullptr.  A chain that saw a non-finite energy is flagged (nf_flag[c] = 1,
+                            // nf_flag[C] = 1) and its outputs are left untouched: the general variant, which reproduces the reference's
+                            // dense products in the non-finite regime, replays it
+    const uint32_t* replay_flag;   // nuts_gauss_async_kernel as that replay: only the chains with a non-zero entry run (and write)
 };
 
 enum : int {

@@ -48,6 +48,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
+    double* lds_nf = lds_lvl + NUTS_LVLS * 4 * 64;       // [64]: non-zero = the chain saw a non-finite energy (see below)
     stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,6 +106,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     matvec_mfma<NT>(afrag, th, w);
     if (live) { st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w); }
     double prev_U = 0.5 * dot4<NS>(th, w);               // nuts.cpp:181 (no finiteness guard there)
+    // Non-finite regime: `inv_precond_matrix * mntm` is a dense product in the reference (nuts.cpp:139-154 with
+    // hmc.cpp's leap_frog_fn); this kernel applies the identity element-wise, which is the same arithmetic only while every value is
+    // finite.  A non-finite theta / p makes the leaf's energy non-finite: the chain is flagged and replayed by the general variant.
+    // (The flag lives in LDS, written under a wave-uniform branch that is all but never taken: as a loop-carried register it cost the
+    // d = 128 kernel, which uses all 512 registers, 140 spilled VGPRs.)
+    lds_nf[cw] = is_finite(prev_U) ? 0.0 : 1.0;
+    auto note_nonfinite = [&](bool bad) __attribute__((always_inline)) { if (__ballot(bad) != 0ull) { if (bad) lds_nf[cw] = 1.0; } };
 
     uint64_t n_leap = 0;
     double eps;
@@ -139,6 +147,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         leapfrog(eps);
         n_leap++;
         double dH = -energy() + (U0 + K0);
+        note_nonfinite(!is_finite(dH));
         int a_val = 2 * (dH > log_half ? 1 : 0) - 1;
         bool cond = dH > neg_log2;
         while (__ballot(cond) != 0ull) {
@@ -146,6 +155,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             if (cond) { eps = e_new; n_leap++; }
             leapfrog(eps);
             const double dH2 = -energy() + (U0 + K0);
+            note_nonfinite(cond && !is_finite(dH2));
             if (cond) {
                 a_val = 2 * (dH2 > log_half ? 1 : 0) - 1;
                 cond = dH2 > neg_log2;
@@ -401,6 +411,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
         const bool cs = log_u < 1000.0 - pU - pK;        // :147
         const double dH = -(pU + pK) + H0;
+        note_nonfinite(run && !is_finite(dH));           // pU (replaced by +inf above), pK or the draw's H0 non-finite
         double ca = det_exp((dH < 0.0) ? dH : 0.0);      // :157
         double cna = 1.0;
         double cU = pU;
@@ -528,7 +539,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     }
 #endif
 
-    if (live) {
+    const bool replay = lds_nf[cw] != 0.0 && prm.nf_flag != nullptr;
+    if (live && replay && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+    if (live && !replay) {
 #pragma unroll
         for (int c0 = 0; c0 < NS; c0 += CHC) {
             double tmp[CHC];

@@ -49,6 +49,68 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
     if (mean) std::memcpy(mean, mean_h.data(), d * 8);
     if (!acov && !rhat && !ess) return MI_OK;
     HIP_TRY(hipMemcpyAsync(mean_dev.p, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
+    auto rhat_from = [&](const std::vector<double>& mp) {
+        for (size_t j = 0; j < d; ++j) {
+            double sm = 0.0, sm2 = 0.0, sv = 0.0;
+            for (uint32_t g = 0; g < G; ++g) { const double* o = &mp[((size_t)g * d + j) * 3]; sm += o[0]; sm2 += o[1]; sv += o[2]; }
+            const double W = sv / (double)C;                                                  // mean within-chain variance
+            const double mbar = sm / (double)C;
+            const double B_over_n = (C > 1) ? (sm2 - (double)C * mbar * mbar) / (double)(C - 1) : 0.0;   // variance of the chain means
+            const double var_plus = ((double)(n - 1) / (double)n) * W + B_over_n;
+            rhat[j] = (W > 0.0) ? std::sqrt(var_plus / W) : 1.0;
+        }
+    };
+    // Geyer's initial positive sequence over the lags [0, nlag) of ac[k * d + j]; *ended: the sum met its first non-positive pair
+    // (or ran through all n lags), i.e. more lags would not change it
+    auto geyer = [&](const std::vector<double>& ac, size_t nlag, size_t j, bool* ended) -> double {
+        if (n < 4) { *ended = true; return (double)n; }
+        const double a0 = ac[j];
+        const double den = (a0 > 0.0) ? a0 : 1.0;
+        double tau = -1.0;
+        size_t t = 0;
+        *ended = false;
+        while (t + 1 < nlag) {
+            const double pair = ac[t * d + j] / den + ac[(t + 1) * d + j] / den;
+            if (pair <= 0.0) { *ended = true; break; }
+            tau += 2.0 * pair;
+            t += 2;
+        }
+        if (nlag >= n) *ended = true;
+        const double e = (tau > 0.0) ? (double)n / std::max(tau, 1.0 / (double)n) : (double)n;
+        return std::min(e, (double)n * 10.0);
+    };
+    if (!acov) {
+        // ESS / R-hat only: lags in blocks straight from HBM (stats_window_kernel), until Geyer's sum has ended in every dimension
+        for (int L : {16, 32}) {
+            if ((size_t)L >= n && L != 16) break;
+            DevBuf a_dev;
+            HIP_TRY(a_dev.alloc((size_t)G * d * L * 8));
+            if (L == 16) hipLaunchKernelGGL(mi::stats_window_kernel<16>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
+            else hipLaunchKernelGGL(mi::stats_window_kernel<32>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
+            HIP_TRY(hipGetLastError());
+            std::vector<double> ap((size_t)G * d * L), mp((size_t)G * d * 3);
+            HIP_TRY(hipMemcpyAsync(ap.data(), a_dev.p, ap.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const size_t nlag = std::min<size_t>((size_t)L, n);
+            std::vector<double> ac(nlag * d);
+            for (size_t j = 0; j < d; ++j)
+                for (size_t k = 0; k < nlag; ++k) {
+                    double s_ = 0.0;
+                    for (uint32_t g = 0; g < G; ++g) s_ += ap[((size_t)g * d + j) * L + k];
+                    ac[k * d + j] = s_ / (double)C / (double)(n - k);
+                }
+            bool all_ended = true;
+            std::vector<double> e(d);
+            for (size_t j = 0; j < d; ++j) { bool en; e[j] = geyer(ac, nlag, j, &en); all_ended = all_ended && en; }
+            if (all_ended || !ess) {
+                if (rhat) rhat_from(mp);
+                if (ess) std::memcpy(ess, e.data(), d * 8);
+                return MI_OK;
+            }
+        }
+        // a slowly mixing series: every lag (n <= 160) or 128 of them, with the LDS-resident kernels below
+    }
     // every lag for series of up to STATS_MAX_N draws; beyond, lags below STATS_TILED_LAGS from the streamed kernel
     const bool tiled = n > (size_t)mi::STATS_MAX_N;
     const size_t nlag = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
@@ -203,10 +265,34 @@ int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const dou
 int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
 {
     if (!kdc || !out) return fail(MI_ERR_BAD_ARG, "null buffer");
-    for (uint64_t c = 0; c < C; ++c)
+    // host arrays: blocked over chains so that both sides stay in cache (the device form below is the one for slabs in HBM)
+    constexpr uint64_t CB = 64;
+    for (uint64_t c0 = 0; c0 < C; c0 += CB)
         for (uint64_t j = 0; j < d; ++j)
-            for (uint64_t i = 0; i < n_keep; ++i)
-                out[(c * d + j) * n_keep + i] = kdc[(i * d + j) * C + c];
+            for (uint64_t i = 0; i < n_keep; ++i) {
+                const double* src = kdc + (i * d + j) * C;
+                const uint64_t c1 = std::min(C, c0 + CB);
+                for (uint64_t c = c0; c < c1; ++c) out[(c * d + j) * n_keep + i] = src[c];
+            }
+    return MI_OK;
+}
+
+int mi_mcmc_draws_to_chain_major_device(const double* kdc_dev, uint64_t n_keep, uint64_t d, uint64_t C, double* out_dev, void* stream)
+{
+    if (!kdc_dev || !out_dev) return fail(MI_ERR_BAD_ARG, "null buffer");
+    if (n_keep == 0 || d == 0 || C == 0) return MI_OK;
+    if (n_keep > 0xffffffffULL || d > 0x7fffffffULL || (C + 63) / 64 > 65535ULL * 64ULL) return fail(MI_ERR_BAD_ARG, "draws_to_chain_major: shape out of range");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    // grid.y is limited to 65 535: chains in slices of 65 535 tiles
+    const uint64_t tiles = (C + 63) / 64;
+    for (uint64_t t0 = 0; t0 < tiles; t0 += 65535) {
+        const uint64_t nt = std::min<uint64_t>(65535, tiles - t0);
+        const uint64_t c_first = t0 * 64, c_cnt = std::min<uint64_t>(C - c_first, nt * 64);
+        // a slice [c_first, c_first + c_cnt) of the slab has the same row stride C: pass the full C and offset pointers
+        hipLaunchKernelGGL(mi::draws_to_chain_major_slice_kernel, dim3((unsigned)d, (unsigned)nt), dim3(256), 0, st, kdc_dev, (uint32_t)n_keep, (uint32_t)d, C, c_first, c_cnt, out_dev);
+    }
+    HIP_TRY(hipGetLastError());
     return MI_OK;
 }
 

@@ -42,7 +42,7 @@ def sweep(n_cases=60, seed=1, verbose=True):
             N = int(rng.choice([1, 15, 16, 40, 100])); X, y = synth.logistic_problem(d, N, seed=rseed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
         scale = float(rng.choice([0.1, 1.0, 3.0]))
         init = synth.initial_states(C, d, seed=rseed % 1013) * scale
-        if algo in ("hmc", "mala") and rng.random() < 0.15:      # the non-finite regime: chains that blow up or start non-finite
+        if algo in ("hmc", "mala", "nuts") and rng.random() < 0.15:      # the non-finite regime: chains that blow up or start non-finite
             eps = float(rng.choice([30.0, 1.0e5, 1.0e160]))
             if rng.random() < 0.5: init[int(rng.integers(0, C)), int(rng.integers(0, d))] = float(rng.choice([np.inf, -np.inf, np.nan]))
         if general:

@@ -58,3 +58,38 @@ def test_long_series_are_streamed_and_truncated_at_128_lags(n, d, C, phi):
         assert np.allclose(s["ess"], ess_per_chain(x), rtol=1e-8)
     else:                                   # the sum may still be positive at lag 127: the device reports the truncated sum
         assert np.all(s["ess"] >= ess_per_chain(x) * (1 - 1e-8)) and np.all(s["ess"] < n)
+
+
+@pytest.mark.parametrize("n,d,C,phi", [(100, 5, 700, 0.6), (40, 3, 64, 0.0), (160, 2, 1000, 0.9), (7, 4, 130, 0.3), (1000, 3, 200, 0.7),
+                                       (100, 2, 300, 0.97), (20, 130, 70, 0.5)])
+def test_ess_and_rhat_without_the_full_autocovariance(n, d, C, phi):
+    """acov == NULL: lags in blocks of 16, then 32, straight from HBM (stats_window_kernel), until Geyer's sum has ended in every
+    dimension; phi = 0.97 does not end within 32 lags and falls through to the full computation.  Same numbers as ess.py."""
+    x = _ar1(n, d, C, phi, seed=n + C)
+    s = mcmc_amd.draw_stats(x, want_acov=False)
+    assert s["acov"] is None
+    assert np.allclose(s["mean"], x.mean(axis=(0, 2)), rtol=1e-12, atol=1e-12)
+    if n <= 160:
+        assert np.allclose(s["ess"], ess_per_chain(x), rtol=1e-8)
+    else:
+        full = mcmc_amd.draw_stats(x)["ess"]
+        assert np.allclose(s["ess"], full, rtol=1e-8)
+    m = x.mean(axis=0); W = x.var(axis=0, ddof=1).mean(axis=1); B_n = m.var(axis=1, ddof=1)
+    assert np.allclose(s["rhat"], np.sqrt(((n - 1) / n * W + B_n) / W), rtol=1e-10)
+
+
+def test_device_transpose_to_chain_major():
+    import torch
+    n, d, C = 37, 5, 1000
+    x = np.random.default_rng(0).standard_normal((n, d, C))
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((C, d, n), dtype=torch.float64, device="cuda")
+    mcmc_amd.draws_to_chain_major_device(xd, n, d, C, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.ascontiguousarray(x.transpose(2, 1, 0)))
+    n, d, C = 300, 2, 130                                   # more draws than one LDS tile holds
+    x = np.random.default_rng(1).standard_normal((n, d, C))
+    out = torch.empty((C, d, n), dtype=torch.float64, device="cuda")
+    mcmc_amd.draws_to_chain_major_device(torch.from_numpy(x).cuda(), n, d, C, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.ascontiguousarray(x.transpose(2, 1, 0)))
