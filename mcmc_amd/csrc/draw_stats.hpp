@@ -34,27 +34,36 @@ __global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict_
     if (threadIdx.x == 0) out[(size_t)g * d + j] = s;
 }
 
-// out[g][j][0..n): sum over the group's chains of sum_t v[t] v[t+k];  out2[g][j][0..3): sum_c m_c, sum_c m_c^2, sum_c var_c
-// (m_c = chain mean of the centred series, var_c = its unbiased variance) for R-hat
+// out[g][j][0..nlag): sum over the group's chains of sum_t v[t] v[t-k];  out2[g][j][0..3): sum_c m_c, sum_c m_c^2, sum_c var_c
+// (m_c = chain mean of the centred series, var_c = its unbiased variance) for R-hat.  n <= STATS_MAX_N.
+// One wave per (dimension, chain group); per tile of 64 chains the centred series sit in LDS as [t][lane] (conflict-free columns,
+// n x 512 bytes: three waves per CU at n = 100) and the lags are formed 16 at a time in registers: the lane walks t once per block
+// with a 16-deep window of v[t - k0 - i] (a circular buffer with compile-time indices), two LDS reads and 16 fmas per step.  The 64
+// lanes of a lag are summed by a fixed butterfly and lane 0 adds the tile's sum to that lag's LDS accumulator: the result does not
+// depend on scheduling.  (The first version held an [n][64] accumulator array next to the series -- one wave per CU -- and every lane
+// formed all n lags from LDS operands: 124 ms for the 6.7 GB of configs[1]'s kept draws, more than the sampler took to produce them.)
 __global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
-                                                        uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                        uint32_t n, uint32_t d, uint64_t C, uint32_t G, uint32_t nlag,
                                                         double* __restrict__ out, double* __restrict__ out2)
 {
+    constexpr int LB = 16;
     extern __shared__ double lds[];
     double* v = lds;                       // [n][64]
-    double* acc = lds + (size_t)n * 64;    // [n][64]
+    double* accl = lds + (size_t)n * 64;   // [nlag rounded up to LB]
     const uint32_t j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
     const uint64_t per = (C + G - 1) / G;
     const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
     const double mj = mean[j];
-    for (uint32_t k = 0; k < n; ++k) acc[(size_t)k * 64 + lane] = 0.0;
+    const uint32_t nblk = (nlag + LB - 1) / LB;
+    for (uint32_t k = lane; k < nblk * LB; k += 64) accl[k] = 0.0;
     double sm = 0.0, sm2 = 0.0, sv = 0.0;
     for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
         const uint64_t c = c0 + lane;
         const bool on = c < c_hi;
+        const double* p = draws + (size_t)j * C + (on ? c : c_hi - 1);
         double s1 = 0.0;
         for (uint32_t t = 0; t < n; ++t) {
-            const double x = on ? draws[((size_t)t * d + j) * C + c] - mj : 0.0;
+            const double x = on ? p[(size_t)t * d * C] - mj : 0.0;
             v[(size_t)t * 64 + lane] = x;
             s1 += x;
         }
@@ -62,17 +71,34 @@ __global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict
         double ss = 0.0;
         for (uint32_t t = 0; t < n; ++t) { const double e = v[(size_t)t * 64 + lane] - mc; ss = __builtin_fma(e, e, ss); }
         if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? ss / (double)(n - 1) : 0.0; }
-        for (uint32_t k = 0; k < n; ++k) {
-            double s = 0.0;
-            for (uint32_t t = 0; t + k < n; ++t) s = __builtin_fma(v[(size_t)t * 64 + lane], v[(size_t)(t + k) * 64 + lane], s);
-            acc[(size_t)k * 64 + lane] += s;   // lanes beyond the group hold zeros
+        for (uint32_t b = 0; b < nblk; ++b) {
+            const uint32_t k0 = b * LB;
+            double acc[LB], win[LB];
+#pragma unroll
+            for (int i = 0; i < LB; ++i) { acc[i] = 0.0; win[i] = 0.0; }
+            // t runs from k0 (the first time step whose lag-k0 partner exists) in chunks of LB: slot u of the window receives
+            // v[t - k0], and lag k0 + i pairs v[t] with slot (u - i) mod LB = v[t - k0 - i] (zero while that is before the series)
+            for (uint32_t tc = k0; tc < n; tc += LB) {
+#pragma unroll
+                for (int u = 0; u < LB; ++u) {
+                    const uint32_t t = tc + (uint32_t)u;
+                    const bool in = t < n;
+                    const double a = in ? v[(size_t)t * 64 + lane] : 0.0;
+                    win[u] = in ? v[(size_t)(t - k0) * 64 + lane] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < LB; ++i) acc[i] = __builtin_fma(a, win[(u - i + LB) % LB], acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                double s_ = acc[i];
+                for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m);
+                if (lane == 0) accl[k0 + i] += s_;
+            }
         }
     }
-    for (uint32_t k = 0; k < n; ++k) {
-        double s = acc[(size_t)k * 64 + lane];
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) out[((size_t)g * d + j) * n + k] = s;
-    }
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t k = lane; k < nlag; k += 64) out[((size_t)g * d + j) * nlag + k] = accl[k];
     for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
     if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
 }

@@ -80,13 +80,11 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
         return std::min(e, (double)n * 10.0);
     };
     if (!acov) {
-        // ESS / R-hat only: lags in blocks straight from HBM (stats_window_kernel), until Geyer's sum has ended in every dimension
-        for (int L : {16, 32}) {
-            if ((size_t)L >= n && L != 16) break;
+        // ESS / R-hat only: the first 16 lags straight from HBM (stats_window_kernel); done if Geyer's sum has ended in every dimension
+        for (int L : {16}) {
             DevBuf a_dev;
             HIP_TRY(a_dev.alloc((size_t)G * d * L * 8));
-            if (L == 16) hipLaunchKernelGGL(mi::stats_window_kernel<16>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
-            else hipLaunchKernelGGL(mi::stats_window_kernel<32>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
+            hipLaunchKernelGGL(mi::stats_window_kernel<16>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
             HIP_TRY(hipGetLastError());
             std::vector<double> ap((size_t)G * d * L), mp((size_t)G * d * 3);
             HIP_TRY(hipMemcpyAsync(ap.data(), a_dev.p, ap.size() * 8, hipMemcpyDeviceToHost, st));
@@ -123,10 +121,10 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
         hipLaunchKernelGGL(mi::stats_acov_tiled_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
                            (uint64_t)C, G, acov_out, mom_dev.as<double>());
     } else {
-        const size_t lds = 2 * n * 64 * sizeof(double);
+        const size_t lds = (n * 64 + ((n + 15) / 16) * 16) * sizeof(double);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
+                           (uint64_t)C, G, (uint32_t)n, acov_out, mom_dev.as<double>());
     }
     HIP_TRY(hipGetLastError());
     std::vector<double> ap((size_t)G * d * nlag), mp((size_t)G * d * 3), ac((size_t)n * d, std::nan(""));

@@ -161,11 +161,17 @@ def test_dense_precond_mala_bit_exact_vs_oracle(d, C, eps):
     assert 0 < g["n_accept"].sum()
 
 
-def test_dense_precond_mala_with_bounds_is_refused_not_approximated():
-    d = 8
+def test_dense_precond_mala_with_bounds_runs_literally():
+    """ref: src/mala.cpp:152-157, include/mcmc/mala.ipp:45-55 -- INV(eps^2 J(theta') M) per draw is O(d^3) in the reference too: the
+    configuration runs on the literal kernel (mcmc_amd/csrc/literal.hpp), every chain, not on an MFMA kernel (round 2 refused it)"""
+    d, C = 8, 20
     M = _spd(d, seed=2)
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M, vals_bound=1,
-                                   lower_bounds=np.full(d, -1.0), upper_bounds=np.full(d, 1.0))
-    with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+    lb, ub = np.full(d, -1.0), np.full(d, 1.0)
+    init = synth.initial_states(C, d, seed=3) * 0.2
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=2, n_keep_draws=6, step_size=0.2, precond_mat=M, vals_bound=1,
+                                   lower_bounds=lb, upper_bounds=ub)
+    g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_ISO, init, st)
+    s = orc.make_settings(seed=4, n_burnin=2, n_keep=6, step=0.2, W=4, precond=M, hoist=1, lower=lb, upper=ub)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, orc.TargetSpec(orc.TARGET_ISO, d, W=4), init, s)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert mcmc_amd.last_kernel() == "literal_kernel<1>"
