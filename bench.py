@@ -294,6 +294,12 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
     # time reported next to it
     ess_total_rank, rhat_max, reducer_ms = 0.0, float("nan"), None
     if C > 0 and rank == 0 and not args.no_ess:
+        if not getattr(ctx, "stats_warm", False):           # untimed warm-up of the reducer's kernels (code-object load) on a tiny slab
+            mcmc_amd.draw_stats(torch.randn((8, 2, 64), dtype=torch.float64, device=dev), 8, 2, 64, mem=mcmc_amd.MEM_DEVICE,
+                                stream=stream, want_acov=False)
+            mcmc_amd.draw_stats(torch.randn((40, 2, 64), dtype=torch.float64, device=dev).cumsum(0), 40, 2, 64, mem=mcmc_amd.MEM_DEVICE,
+                                stream=stream, want_acov=False)
+            ctx.stats_warm = True
         torch.cuda.synchronize()
         tr = time.perf_counter()
         stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream, want_acov=False)

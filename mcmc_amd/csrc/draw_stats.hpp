@@ -34,44 +34,62 @@ __global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict_
     if (threadIdx.x == 0) out[(size_t)g * d + j] = s;
 }
 
-// out[g][j][0..nlag): sum over the group's chains of sum_t v[t] v[t-k];  out2[g][j][0..3): sum_c m_c, sum_c m_c^2, sum_c var_c
-// (m_c = chain mean of the centred series, var_c = its unbiased variance) for R-hat.  n <= STATS_MAX_N.
+// Lags [16 b_lo, 16 b_hi) of the series of the dimensions listed in `dims` (nullptr: all d), n <= STATS_MAX_N:
+//   out[g][jj][0 .. 16 (b_hi - b_lo)): sum over the group's chains of sum_t v[t] v[t-k];  with want_mom also out2[g][jj][0..3):
+//   sum_c m_c, sum_c m_c^2, sum_c var_c (m_c = chain mean of the centred series, var_c = its unbiased variance) for R-hat.
 // One wave per (dimension, chain group); per tile of 64 chains the centred series sit in LDS as [t][lane] (conflict-free columns,
-// n x 512 bytes: three waves per CU at n = 100) and the lags are formed 16 at a time in registers: the lane walks t once per block
-// with a 16-deep window of v[t - k0 - i] (a circular buffer with compile-time indices), two LDS reads and 16 fmas per step.  The 64
-// lanes of a lag are summed by a fixed butterfly and lane 0 adds the tile's sum to that lag's LDS accumulator: the result does not
-// depend on scheduling.  (The first version held an [n][64] accumulator array next to the series -- one wave per CU -- and every lane
-// formed all n lags from LDS operands: 124 ms for the 6.7 GB of configs[1]'s kept draws, more than the sampler took to produce them.)
+// n x 512 bytes) and the lags are formed 16 at a time in registers: the lane walks t once per block with a 16-deep window of
+// v[t - k0 - i] (a circular buffer with compile-time indices), two LDS reads and 16 fmas per step; per-lane sums of the pass's lags
+// accumulate in LDS over the tiles and are summed across the 64 lanes by a fixed butterfly at the end: the result does not depend on
+// scheduling.  The host asks for the lags in passes, and only for the dimensions whose Geyer sum has not ended yet.
+// (The first version held an [n][64] accumulator array next to the series -- one wave per CU -- and every lane formed all n lags
+// from LDS operands: 124 ms for the 6.7 GB of configs[1]'s kept draws, more than the sampler took to produce them.)
+constexpr int STATS_LB = 16;              // lags per register block
+constexpr int STATS_PASS_BLOCKS = 3;      // blocks per launch at most: series + accumulators stay near 75 KB of LDS at n = 100
 __global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
-                                                        uint32_t n, uint32_t d, uint64_t C, uint32_t G, uint32_t nlag,
+                                                        uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                        const uint32_t* __restrict__ dims, uint32_t b_lo, uint32_t b_hi, int want_mom,
                                                         double* __restrict__ out, double* __restrict__ out2)
 {
-    constexpr int LB = 16;
+    constexpr int LB = STATS_LB;
     extern __shared__ double lds[];
     double* v = lds;                       // [n][64]
-    double* accl = lds + (size_t)n * 64;   // [nlag rounded up to LB]
-    const uint32_t j = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    double* accl = lds + (size_t)n * 64;   // [(b_hi - b_lo) * LB][64]
+    const uint32_t jj = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const uint32_t j = dims ? dims[jj] : jj;
+    const uint32_t nd = gridDim.x;
     const uint64_t per = (C + G - 1) / G;
     const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
     const double mj = mean[j];
-    const uint32_t nblk = (nlag + LB - 1) / LB;
-    for (uint32_t k = lane; k < nblk * LB; k += 64) accl[k] = 0.0;
+    const uint32_t npl = (b_hi - b_lo) * LB;            // lags of this pass
+    for (uint32_t k = 0; k < npl; ++k) accl[(size_t)k * 64 + lane] = 0.0;
     double sm = 0.0, sm2 = 0.0, sv = 0.0;
+    const size_t row = (size_t)d * C;
     for (uint64_t c0 = c_lo; c0 < c_hi; c0 += 64) {
         const uint64_t c = c0 + lane;
         const bool on = c < c_hi;
         const double* p = draws + (size_t)j * C + (on ? c : c_hi - 1);
         double s1 = 0.0;
-        for (uint32_t t = 0; t < n; ++t) {
-            const double x = on ? p[(size_t)t * d * C] - mj : 0.0;
-            v[(size_t)t * 64 + lane] = x;
-            s1 += x;
+        for (uint32_t t0 = 0; t0 < n; t0 += LB) {        // LB rows in flight per lane (a row of the wave = one 512-byte segment)
+            double xr[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) xr[u] = p[(size_t)((t0 + u < n) ? t0 + u : n - 1) * row];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                if (t0 + u < n) {
+                    const double x = on ? xr[u] - mj : 0.0;
+                    v[(size_t)(t0 + u) * 64 + lane] = x;
+                    s1 += x;
+                }
+            }
         }
-        const double mc = s1 / (double)n;
-        double ss = 0.0;
-        for (uint32_t t = 0; t < n; ++t) { const double e = v[(size_t)t * 64 + lane] - mc; ss = __builtin_fma(e, e, ss); }
-        if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? ss / (double)(n - 1) : 0.0; }
-        for (uint32_t b = 0; b < nblk; ++b) {
+        if (want_mom) {
+            const double mc = s1 / (double)n;
+            double ss = 0.0;
+            for (uint32_t t = 0; t < n; ++t) { const double e = v[(size_t)t * 64 + lane] - mc; ss = __builtin_fma(e, e, ss); }
+            if (on) { sm += mc; sm2 = __builtin_fma(mc, mc, sm2); sv += (n > 1) ? ss / (double)(n - 1) : 0.0; }
+        }
+        for (uint32_t b = b_lo; b < b_hi; ++b) {
             const uint32_t k0 = b * LB;
             double acc[LB], win[LB];
 #pragma unroll
@@ -83,24 +101,27 @@ __global__ __launch_bounds__(64) void stats_acov_kernel(const double* __restrict
                 for (int u = 0; u < LB; ++u) {
                     const uint32_t t = tc + (uint32_t)u;
                     const bool in = t < n;
-                    const double a = in ? v[(size_t)t * 64 + lane] : 0.0;
-                    win[u] = in ? v[(size_t)(t - k0) * 64 + lane] : 0.0;
+                    const uint32_t tcl = in ? t : n - 1;
+                    const double a = in ? v[(size_t)tcl * 64 + lane] : 0.0;
+                    win[u] = in ? v[(size_t)(tcl - k0) * 64 + lane] : 0.0;
 #pragma unroll
                     for (int i = 0; i < LB; ++i) acc[i] = __builtin_fma(a, win[(u - i + LB) % LB], acc[i]);
                 }
             }
+            double* al = accl + (size_t)(b - b_lo) * LB * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < LB; ++i) {
-                double s_ = acc[i];
-                for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m);
-                if (lane == 0) accl[k0 + i] += s_;
-            }
+            for (int i = 0; i < LB; ++i) al[(size_t)i * 64] += acc[i];
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    for (uint32_t k = lane; k < nlag; k += 64) out[((size_t)g * d + j) * nlag + k] = accl[k];
-    for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
-    if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+    for (uint32_t k = 0; k < npl; ++k) {
+        double s_ = accl[(size_t)k * 64 + lane];
+        for (int m = 32; m >= 1; m >>= 1) s_ += __shfl_xor(s_, m);
+        if (lane == 0) out[((size_t)g * nd + jj) * npl + k] = s_;
+    }
+    if (want_mom) {
+        for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
+        if (lane == 0) { double* o = out2 + ((size_t)g * nd + jj) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+    }
 }
 
 // The same for n > STATS_MAX_N: lags 0 .. STATS_TILED_LAGS - 1, the series streamed through LDS in tiles of STATS_TILE_T steps plus a

@@ -34,12 +34,18 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
         x = staged.as<double>();
     }
     const uint32_t G = (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);      // chain groups (partials are added in order on the host)
-    DevBuf sum_dev, mean_dev, acov_dev, mom_dev;
-    HIP_TRY(sum_dev.alloc((size_t)G * d * 8)); HIP_TRY(mean_dev.alloc(d * 8));
-    HIP_TRY(acov_dev.alloc((size_t)G * d * std::min<size_t>(n, (size_t)mi::STATS_MAX_N) * 8)); HIP_TRY(mom_dev.alloc((size_t)G * d * 3 * 8));
-    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, sum_dev.as<double>());
+    const bool tiled = n > (size_t)mi::STATS_MAX_N;                          // long series: lags below STATS_TILED_LAGS, streamed kernel
+    const size_t nlag_max = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
+    const size_t pass_lags = (size_t)mi::STATS_PASS_BLOCKS * mi::STATS_LB;
+    // one device buffer for everything: [G d] sums, [d] means, [d] dimension list, [G d 3] moments, [G d max(pass, tiled) lags]
+    const size_t part_lags = tiled ? nlag_max : std::max<size_t>(pass_lags, 16);
+    DevBuf buf;
+    const size_t o_sum = 0, o_mean = o_sum + (size_t)G * d, o_dims = o_mean + d, o_mom = o_dims + d, o_part = o_mom + (size_t)G * d * 3;
+    HIP_TRY(buf.alloc((o_part + (size_t)G * d * part_lags) * 8));
+    double* const B = buf.as<double>();
+    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, B + o_sum);
     std::vector<double> part((size_t)G * d), mean_h(d);
-    HIP_TRY(hipMemcpyAsync(part.data(), sum_dev.p, part.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(part.data(), B + o_sum, part.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t j = 0; j < d; ++j) {
         double s = 0.0;
@@ -48,21 +54,23 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
     }
     if (mean) std::memcpy(mean, mean_h.data(), d * 8);
     if (!acov && !rhat && !ess) return MI_OK;
-    HIP_TRY(hipMemcpyAsync(mean_dev.p, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
-    auto rhat_from = [&](const std::vector<double>& mp) {
-        for (size_t j = 0; j < d; ++j) {
-            double sm = 0.0, sm2 = 0.0, sv = 0.0;
-            for (uint32_t g = 0; g < G; ++g) { const double* o = &mp[((size_t)g * d + j) * 3]; sm += o[0]; sm2 += o[1]; sv += o[2]; }
-            const double W = sv / (double)C;                                                  // mean within-chain variance
-            const double mbar = sm / (double)C;
-            const double B_over_n = (C > 1) ? (sm2 - (double)C * mbar * mbar) / (double)(C - 1) : 0.0;   // variance of the chain means
-            const double var_plus = ((double)(n - 1) / (double)n) * W + B_over_n;
-            rhat[j] = (W > 0.0) ? std::sqrt(var_plus / W) : 1.0;
-        }
+    HIP_TRY(hipMemcpyAsync(B + o_mean, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
+
+    std::vector<double> ac((size_t)n * d, std::nan(""));     // ac[k * d + j]: pooled over chains, unbiased per lag
+    std::vector<double> mp;                                   // [G][d][3] moments for R-hat
+    // adds the G partials of lags [k_lo, k_lo + cnt) of the listed dimensions (stride `stride` lags per (group, dimension))
+    auto collect = [&](const std::vector<double>& ap, const std::vector<uint32_t>& dl, size_t stride, size_t k_lo, size_t cnt) {
+        const size_t nd = dl.size();
+        for (size_t jj = 0; jj < nd; ++jj)
+            for (size_t k = 0; k < cnt && k_lo + k < nlag_max; ++k) {
+                double s_ = 0.0;
+                for (uint32_t g = 0; g < G; ++g) s_ += ap[((size_t)g * nd + jj) * stride + k];
+                ac[(k_lo + k) * d + dl[jj]] = s_ / (double)C / (double)(n - (k_lo + k));
+            }
     };
-    // Geyer's initial positive sequence over the lags [0, nlag) of ac[k * d + j]; *ended: the sum met its first non-positive pair
-    // (or ran through all n lags), i.e. more lags would not change it
-    auto geyer = [&](const std::vector<double>& ac, size_t nlag, size_t j, bool* ended) -> double {
+    // Geyer's initial positive sequence over the lags [0, nlag) (mcmc_amd/ess.py); *ended: the sum met its first non-positive pair
+    // or ran through every lag there is, i.e. more lags would not change it
+    auto geyer = [&](size_t nlag, size_t j, bool* ended) -> double {
         if (n < 4) { *ended = true; return (double)n; }
         const double a0 = ac[j];
         const double den = (a0 > 0.0) ? a0 : 1.0;
@@ -75,68 +83,78 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
             tau += 2.0 * pair;
             t += 2;
         }
-        if (nlag >= n) *ended = true;
+        if (nlag >= nlag_max) *ended = true;
         const double e = (tau > 0.0) ? (double)n / std::max(tau, 1.0 / (double)n) : (double)n;
         return std::min(e, (double)n * 10.0);
     };
-    if (!acov) {
-        // ESS / R-hat only: the first 16 lags straight from HBM (stats_window_kernel); done if Geyer's sum has ended in every dimension
-        for (int L : {16}) {
-            DevBuf a_dev;
-            HIP_TRY(a_dev.alloc((size_t)G * d * L * 8));
-            hipLaunchKernelGGL(mi::stats_window_kernel<16>, dim3((unsigned)d, G), dim3(64), 0, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d, (uint64_t)C, G, a_dev.as<double>(), mom_dev.as<double>());
-            HIP_TRY(hipGetLastError());
-            std::vector<double> ap((size_t)G * d * L), mp((size_t)G * d * 3);
-            HIP_TRY(hipMemcpyAsync(ap.data(), a_dev.p, ap.size() * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            const size_t nlag = std::min<size_t>((size_t)L, n);
-            std::vector<double> ac(nlag * d);
-            for (size_t j = 0; j < d; ++j)
-                for (size_t k = 0; k < nlag; ++k) {
-                    double s_ = 0.0;
-                    for (uint32_t g = 0; g < G; ++g) s_ += ap[((size_t)g * d + j) * L + k];
-                    ac[k * d + j] = s_ / (double)C / (double)(n - k);
-                }
-            bool all_ended = true;
-            std::vector<double> e(d);
-            for (size_t j = 0; j < d; ++j) { bool en; e[j] = geyer(ac, nlag, j, &en); all_ended = all_ended && en; }
-            if (all_ended || !ess) {
-                if (rhat) rhat_from(mp);
-                if (ess) std::memcpy(ess, e.data(), d * 8);
-                return MI_OK;
-            }
-        }
-        // a slowly mixing series: every lag (n <= 160) or 128 of them, with the LDS-resident kernels below
-    }
-    // every lag for series of up to STATS_MAX_N draws; beyond, lags below STATS_TILED_LAGS from the streamed kernel
-    const bool tiled = n > (size_t)mi::STATS_MAX_N;
-    const size_t nlag = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
-    DevBuf acov_t;
-    if (tiled) { HIP_TRY(acov_t.alloc((size_t)G * d * nlag * 8)); }
-    double* const acov_out = tiled ? acov_t.as<double>() : acov_dev.as<double>();
+    std::vector<uint32_t> active(d);
+    for (size_t j = 0; j < d; ++j) active[j] = (uint32_t)j;
+    std::vector<double> ess_h(d, (double)n);
+    size_t computed = 0;                                      // lags [0, computed) are known for the active dimensions
+    auto fetch = [&](std::vector<double>& dst, const double* src, size_t cnt) -> int {
+        dst.resize(cnt);
+        HIP_TRY(hipMemcpyAsync(dst.data(), src, cnt * 8, hipMemcpyDeviceToHost, st));
+        return MI_OK;
+    };
+    auto prune = [&]() {                                      // keep the dimensions whose sum has not ended inside [0, computed)
+        std::vector<uint32_t> next;
+        for (uint32_t j : active) { bool en; ess_h[j] = geyer(computed, j, &en); if (!en) next.push_back(j); }
+        active.swap(next);
+    };
+    std::vector<double> ap;
+    int rc;
     if (tiled) {
         const size_t lds = (size_t)(mi::STATS_TILE_T + 2 * mi::STATS_TILED_LAGS) * 64 * sizeof(double);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mi::stats_acov_tiled_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                           (uint64_t)C, G, acov_out, mom_dev.as<double>());
+        hipLaunchKernelGGL(mi::stats_acov_tiled_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, B + o_mean, (uint32_t)n, (uint32_t)d,
+                           (uint64_t)C, G, B + o_part, B + o_mom);
+        HIP_TRY(hipGetLastError());
+        if ((rc = fetch(ap, B + o_part, (size_t)G * d * nlag_max))) return rc;
+        if ((rc = fetch(mp, B + o_mom, (size_t)G * d * 3))) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        collect(ap, active, nlag_max, 0, nlag_max);
+        computed = nlag_max;
+        prune();
     } else {
-        const size_t lds = (n * 64 + ((n + 15) / 16) * 16) * sizeof(double);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)d, G), dim3(64), lds, st, x, mean_dev.as<double>(), (uint32_t)n, (uint32_t)d,
-                           (uint64_t)C, G, (uint32_t)n, acov_out, mom_dev.as<double>());
-    }
-    HIP_TRY(hipGetLastError());
-    std::vector<double> ap((size_t)G * d * nlag), mp((size_t)G * d * 3), ac((size_t)n * d, std::nan(""));
-    HIP_TRY(hipMemcpyAsync(ap.data(), acov_out, ap.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(mp.data(), mom_dev.p, mp.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t j = 0; j < d; ++j)
-        for (size_t k = 0; k < nlag; ++k) {
-            double s = 0.0;
-            for (uint32_t g = 0; g < G; ++g) s += ap[((size_t)g * d + j) * nlag + k];
-            ac[k * d + j] = s / (double)C / (double)(n - k);          // pooled over chains, unbiased per lag
+        if (!acov) {
+            // ESS / R-hat only: the first 16 lags (and the moments) straight from HBM at stream speed; a dimension whose Geyer sum ends
+            // inside them is done
+            hipLaunchKernelGGL(mi::stats_window_kernel<16>, dim3((unsigned)d, G), dim3(64), 0, st, x, B + o_mean, (uint32_t)n, (uint32_t)d,
+                               (uint64_t)C, G, B + o_part, B + o_mom);
+            HIP_TRY(hipGetLastError());
+            if ((rc = fetch(ap, B + o_part, (size_t)G * d * 16))) return rc;
+            if ((rc = fetch(mp, B + o_mom, (size_t)G * d * 3))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            collect(ap, active, 16, 0, 16);
+            computed = std::min<size_t>(16, n);
+            prune();
         }
+        // further lags in passes of up to STATS_PASS_BLOCKS blocks of 16, for the dimensions still open (all of them, every lag, when
+        // the autocovariance itself is asked for)
+        while (!active.empty() && computed < n) {
+            const uint32_t b_lo = (uint32_t)(computed / mi::STATS_LB);
+            const uint32_t b_all = (uint32_t)((n + mi::STATS_LB - 1) / mi::STATS_LB);
+            // (ESS only: the first pass after the 16 streamed lags takes two blocks -- lags 16..47 end most sums of a sampler that mixes)
+            const uint32_t b_hi = std::min<uint32_t>(b_all, b_lo + ((!acov && b_lo == 1) ? 2u : (uint32_t)mi::STATS_PASS_BLOCKS));
+            const size_t npl = (size_t)(b_hi - b_lo) * mi::STATS_LB;
+            const bool all_dims = active.size() == d;
+            const int want_mom = (b_lo == 0) ? 1 : 0;
+            if (!all_dims) HIP_TRY(hipMemcpyAsync(B + o_dims, active.data(), active.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            const size_t lds = (n * 64 + npl * 64) * sizeof(double);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mi::stats_acov_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(mi::stats_acov_kernel, dim3((unsigned)active.size(), G), dim3(64), lds, st, x, B + o_mean, (uint32_t)n, (uint32_t)d,
+                               (uint64_t)C, G, all_dims ? nullptr : reinterpret_cast<const uint32_t*>(B + o_dims), b_lo, b_hi, want_mom,
+                               B + o_part, B + o_mom);
+            HIP_TRY(hipGetLastError());
+            if ((rc = fetch(ap, B + o_part, (size_t)G * active.size() * npl))) return rc;
+            if (want_mom) { if ((rc = fetch(mp, B + o_mom, (size_t)G * d * 3))) return rc; }
+            HIP_TRY(hipStreamSynchronize(st));
+            collect(ap, active, npl, (size_t)b_lo * mi::STATS_LB, npl);
+            computed = std::min<size_t>(n, (size_t)b_hi * mi::STATS_LB);
+            if (!acov) prune();
+        }
+        if (acov) { computed = n; prune(); }
+    }
     if (acov) std::memcpy(acov, ac.data(), ac.size() * 8);
     if (rhat)
         for (size_t j = 0; j < d; ++j) {
@@ -148,22 +166,7 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
             const double var_plus = ((double)(n - 1) / (double)n) * W + B_over_n;
             rhat[j] = (W > 0.0) ? std::sqrt(var_plus / W) : 1.0;
         }
-    if (ess)
-        for (size_t j = 0; j < d; ++j) {                               // Geyer's initial positive sequence (mcmc_amd/ess.py)
-            if (n < 4) { ess[j] = (double)n; continue; }
-            const double a0 = ac[j];
-            const double den = (a0 > 0.0) ? a0 : 1.0;
-            double tau = -1.0;
-            size_t t = 0;
-            while (t + 1 < nlag) {
-                const double pair = ac[t * d + j] / den + ac[(t + 1) * d + j] / den;
-                if (pair <= 0.0) break;
-                tau += 2.0 * pair;
-                t += 2;
-            }
-            double e = (tau > 0.0) ? (double)n / std::max(tau, 1.0 / (double)n) : (double)n;
-            ess[j] = std::min(e, (double)n * 10.0);
-        }
+    if (ess) std::memcpy(ess, ess_h.data(), d * 8);
     return MI_OK;
 }
 
