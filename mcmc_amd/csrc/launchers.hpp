@@ -40,7 +40,7 @@ int launch_small_normal_model(int algo, const SmallParams& prm, hipStream_t st);
 int launch_small_logistic(int algo, int d, const SmallParams& prm, const double* X_dev, const double* y_dev, uint32_t n_rows, hipStream_t st);
 
 
-// literal replay of flagged chains (literal.hpp; algo 0 hmc, 1 mala), n_wg workgroups of 256 threads
+// literal.hpp: replay of flagged chains, or (prm.flag == nullptr) the run itself; algo 0 hmc, 1 mala, 2 nuts, 3 rwmh; n_wg workgroups of 256 threads
 int launch_literal(int algo, const lit::LitParams& prm, unsigned n_wg, hipStream_t st);
 
 }  // namespace mi

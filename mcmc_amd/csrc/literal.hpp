@@ -69,6 +69,11 @@ struct LitParams {
     const double* sinv_diag; // precond 0 / 1: [d] 1 / (eps^2 m_i) (nullptr: all equal rs)
     const double* Sinv;      // precond 2: d*d row-major
     double rs, log_det, cons_term;
+    // nuts (nuts_settings_t, mcmc_structs.hpp:89-97): step_size in `eps` is the initial epsilon_bar
+    uint32_t n_adapt, max_depth;
+    double delta, gamma, t0, kappa;
+    double* step_out;        // [C] or nullptr: in (draw0 > 0: the adapted step sizes of the call before) / out (final step size)
+    uint32_t* depth_trace;   // [n_total][C] or nullptr
     const uint32_t* flag;    // [C]: replay only the chains whose entry is non-zero; nullptr: every chain
     const uint32_t* any;     // nullptr, or one word: zero = nothing was flagged, the launch returns at once
     double* work;            // workspace, work_stride doubles per workgroup
@@ -76,10 +81,14 @@ struct LitParams {
 };
 
 // workspace doubles per workgroup
-MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded)
+constexpr int LIT_NUTS_MAX_DEPTH = 30;   // the reference leaves max_tree_depth a free size_t; a tree of depth 30 is 2^30 leapfrog steps per draw
+constexpr int LIT_NUTS_FRAME_VECS = 6;    // new_draw_p, new_draw_pp, dummy_draw, dummy_mntm, edge_draw, edge_mntm (nuts.ipp:160-208)
+constexpr int LIT_NUTS_TOP_VECS = 12;
+MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded, uint32_t nuts_depth = 0, bool nuts = false)
 {
     const size_t dv = (size_t)d + 8;
-    return 16 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0);
+    return 16 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0)
+         + (nuts ? ((size_t)LIT_NUTS_TOP_VECS + (size_t)LIT_NUTS_FRAME_VECS * (nuts_depth + 1)) * dv : 0);
 }
 
 struct Par {
@@ -656,8 +665,310 @@ MI_HD void mala_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     store_outputs(par, p, c, v, n_acc, 0);
 }
 
+// ---- the dynamics nuts shares with hmc (nuts.cpp:84-154 = hmc.cpp:84-128,164-176) on caller-chosen buffers
+// mntm_update_fn: mntm += step [J] grad / 2 at pos
+MI_HD void dyn_mntm_update(const Par& par, const LitParams& p, const Vecs& v, double step, const double* pos, double* mntm)
+{
+    const uint32_t d = p.t.d;
+    if (p.vals_bound) {
+        LIT_PFOR(i, d) {
+            v.vi[i] = lit_inv_transform(pos[i], p.btype[i], p.lb[i], p.ub[i]);
+            v.jd[i] = lit_inv_jacobian(pos[i], p.btype[i], p.lb[i], p.ub[i]);
+        }
+        par.sync();
+        (void)target_eval(par, p.t, v.vi, v.grad, v.w, v.rows);
+        diag_gemv(par, v.jd, v.grad, d, v.jg);
+        LIT_PFOR(i, d) mntm[i] = mntm[i] + (step * v.jg[i]) / 2.0;
+    } else {
+        (void)target_eval(par, p.t, pos, v.grad, v.w, v.rows);
+        LIT_PFOR(i, d) mntm[i] = mntm[i] + (step * v.grad[i]) / 2.0;
+    }
+    par.sync();
+}
+// leap_frog_fn (nuts.cpp:139-154), one step of signed size `step`
+MI_HD void dyn_leap_frog(const Par& par, const LitParams& p, const Vecs& v, double step, double* draw, double* mntm)
+{
+    const uint32_t d = p.t.d;
+    dyn_mntm_update(par, p, v, step, draw, mntm);
+    times_minv(par, p, mntm, v.mp);
+    LIT_PFOR(i, d) draw[i] = draw[i] + step * v.mp[i];
+    par.sync();
+    dyn_mntm_update(par, p, v, step, draw, mntm);
+}
+MI_HD double dyn_kinetic(const Par& par, const LitParams& p, const Vecs& v, const double* mntm)
+{
+    times_minv(par, p, mntm, v.mp);
+    const double k = dot_b(p.t, mntm, v.mp) / 2.0;
+    par.sync();
+    return k;
+}
+
+// ---- mcmc::internal::rwmh_impl (rwmh.cpp:30-175): eps carries par_scale, the preconditioner slots carry cov_mat
+MI_HD void rwmh_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+{
+    const uint32_t d = p.t.d;
+    const Vecs v = carve(wk, d, p.t.n_rows, false);
+    const uint64_t chain = p.chain0 + c;
+    const double par_scale = p.eps;
+    LIT_PFOR(i, d) {
+        const double x = p.theta[(size_t)i * p.C + c];
+        v.prev[i] = p.vals_bound ? lit_transform(x, p.btype[i], p.lb[i], p.ub[i]) : x;       // :105-107
+    }
+    par.sync();
+    double prev_LP = box_log_kernel(par, p, v, v.prev);     // :113
+    uint64_t n_acc = 0;
+    const uint32_t n_total = p.n_burnin + p.n_keep;
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        normal_vec(par, p, chain, draw + p.draw0, v.z);     // :124
+        // (par_scale * CHOL_LOWER(cov)) * z (:119,126): the scaled matrix times the vector, entry by entry
+        if (p.precond == 2) {
+            LIT_PFOR(i, d) {
+                double acc = 0.0;
+                const double* a = p.Lchol + (size_t)i * d;
+                for (uint32_t k = 0; k < d; ++k) acc = dfma(par_scale * a[k], v.z[k], acc);
+                v.tt[i] = acc;
+            }
+            par.sync();
+        } else {
+            const uint32_t nnf = count_nonfinite(v.z, d);
+            LIT_PFOR(i, d) {
+                const double c_i = par_scale * (p.precond == 1 ? p.m_sqrt[i] : 1.0);
+                v.tt[i] = (nnf - (is_finite(v.z[i]) ? 0u : 1u) > 0u) ? lit_nan() : dfma(c_i, v.z[i], 0.0);
+            }
+            par.sync();
+        }
+        LIT_PFOR(i, d) v.cur[i] = v.prev[i] + v.tt[i];
+        par.sync();
+        double prop_LP = box_log_kernel(par, p, v, v.cur);  // :128
+        if (!is_finite(prop_LP)) prop_LP = -INF;            // :130-132
+        const double x = prop_LP - prev_LP;
+        const double comp_val = (x < 0.0) ? x : 0.0;        // std::min(0.0, x): NaN -> 0 (:136)
+        const double u = rng_uniform(p.seed, chain, draw + p.draw0, 0u);                     // :137
+        const bool accept = u < det_exp(comp_val);          // :139
+        if (accept) { copy_vec(par, v.cur, v.prev, d); prev_LP = prop_LP; }
+        if (draw >= p.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            store_row(par, p, c, draw - p.n_burnin, v.prev);
+        }
+    }
+    store_outputs(par, p, c, v, n_acc, 0);
+}
+
+// ---- mcmc::internal::nuts_impl (nuts.cpp:30-332) with nuts_find_initial_step_size (nuts.ipp:30-93) and the RECURSIVE
+// nuts_build_tree (nuts.ipp:97-241) run as an explicit call / return machine: one frame per tree level, the reference's argument
+// plumbing kept literally (every doubling restarts from (prev_draw, mntm_vec); the second-half calls get the crossed edge outputs
+// of :195 / :207; one runif per completed second half, in post-order).
+struct NutsFrame {
+    int state;                       // 0: call the first half; 1: it returned; 2: the second half returned
+    uint32_t depth;
+    const double *draw_vec, *mntm_vec;
+    double *new_draw, *pos, *neg, *mpos, *mneg;
+    uint64_t n_p, s_p, n_alpha_p;
+    double alpha_p;
+};
+MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+{
+    const uint32_t d = p.t.d;
+    const Vecs v = carve(wk, d, p.t.n_rows, false);
+    const size_t dv = (size_t)d + 8;
+    double* extra = wk + 16 * dv + 2 * ((size_t)p.t.n_rows + 8);
+    double* const new_draw = extra + 0 * dv; double* const draw_pos = extra + 1 * dv; double* const draw_neg = extra + 2 * dv;
+    double* const mntm_pos = extra + 3 * dv; double* const mntm_neg = extra + 4 * dv; double* const dummy_draw = extra + 5 * dv;
+    double* const dummy_mntm = extra + 6 * dv; double* const start_draw = extra + 7 * dv; double* const mntm_vec = extra + 8 * dv;
+    double* const leaf_start = extra + 9 * dv; double* const leaf_mntm = extra + 10 * dv; double* const diff = extra + 11 * dv;
+    double* const frames = extra + (size_t)LIT_NUTS_TOP_VECS * dv;
+    auto fvec = [&](uint32_t level, int k) -> double* { return frames + ((size_t)level * LIT_NUTS_FRAME_VECS + k) * dv; };
+    const uint64_t chain = p.chain0 + c;
+    const uint32_t n_total = p.n_burnin + p.n_keep;
+    const uint32_t n_adapt = (p.draw0 > 0) ? 0u : (p.n_adapt <= n_total ? p.n_adapt : n_total);          // :54
+    uint64_t n_leap = 0;
+
+    LIT_PFOR(i, d) {
+        const double x = p.theta[(size_t)i * p.C + c];
+        v.prev[i] = p.vals_bound ? lit_transform(x, p.btype[i], p.lb[i], p.ub[i]) : x;       // :160-162
+    }
+    par.sync();
+    double step_size;
+    if (p.draw0 == 0) {
+        // rand_vec from the INIT stream, mntm_vec = sqrt_precond * rand_vec (:166-168); nuts_find_initial_step_size (:172)
+        {
+            const uint32_t n_slots = (d + 7) / 8 * 4;
+            LIT_PFOR(sl, n_slots) {
+                double z0, z1;
+                rng_normal_pair(p.seed, chain, 0u, sl, STREAM_INIT, z0, z1);
+                const uint32_t i0 = 8 * (sl / 4) + (sl % 4), i1 = i0 + 4;
+                if (i0 < d) v.z[i0] = z0;
+                if (i1 < d) v.z[i1] = z1;
+            }
+            par.sync();
+        }
+        times_lchol(par, p, v.z, mntm_vec);
+        step_size = 1.0;                                     // nuts.ipp:40
+        double pU = -box_log_kernel(par, p, v, v.prev);      // :44
+        if (!is_finite(pU)) pU = INF;
+        const double pK = dyn_kinetic(par, p, v, mntm_vec);  // :51
+        copy_vec(par, v.prev, v.cur, d);
+        copy_vec(par, mntm_vec, v.mntm, d);
+        dyn_leap_frog(par, p, v, step_size, v.cur, v.mntm); n_leap++;                        // :58
+        double qU = -box_log_kernel(par, p, v, v.cur);
+        if (!is_finite(qU)) qU = INF;
+        double qK = dyn_kinetic(par, p, v, v.mntm);          // :66
+        const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
+        int a_val = 2 * ((-(qU + qK) + (pU + pK)) > log_half ? 1 : 0) - 1;                   // :70
+        bool cond = (-(qU + qK) + (pU + pK)) > neg_log2;     // :71
+        while (cond) {
+            step_size *= (a_val == 1) ? 2.0 : 0.5;           // :74
+            dyn_leap_frog(par, p, v, step_size, v.cur, v.mntm); n_leap++;                    // :76: continues from the moved state
+            qU = -box_log_kernel(par, p, v, v.cur);
+            if (!is_finite(qU)) qU = INF;
+            qK = dyn_kinetic(par, p, v, v.mntm);
+            a_val = 2 * ((-(qU + qK) + (pU + pK)) > log_half ? 1 : 0) - 1;                   // :88
+            cond = (-(qU + qK) + (pU + pK)) > neg_log2;      // :89
+        }
+    } else {
+        step_size = p.step_out ? p.step_out[c] : 1.0;        // continuation after the adaptation window
+    }
+    const double mu_val = det_log(10 * step_size);           // nuts.cpp:174
+    double h_val = 0.0;
+    double epsilon_bar = (p.draw0 == 0) ? p.eps : step_size; // :59
+    double prev_U = -box_log_kernel(par, p, v, v.prev);      // :181 (no finiteness guard there)
+    uint64_t n_acc = 0;
+
+    NutsFrame st[LIT_NUTS_MAX_DEPTH + 2];
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        const uint32_t dabs = draw + p.draw0;
+        uint32_t uslot = 0;
+        normal_vec(par, p, chain, dabs, v.z);                // :200
+        times_lchol(par, p, v.z, mntm_vec);                  // :202
+        const double prev_K = dyn_kinetic(par, p, v, mntm_vec);                              // :204
+        const double log_rand = det_log(rng_uniform(p.seed, chain, dabs, uslot++)) - prev_U - prev_K;   // :206
+        copy_vec(par, v.prev, new_draw, d); copy_vec(par, v.prev, draw_pos, d); copy_vec(par, v.prev, draw_neg, d);   // :210-215
+        copy_vec(par, mntm_vec, mntm_pos, d); copy_vec(par, mntm_vec, mntm_neg, d);
+        uint32_t tree_depth = 0;
+        uint64_t n_val = 1, s_val = 1, n_alpha_val = 0;
+        double alpha_val = 0.0;
+        int good_round = 0;
+        while (s_val == 1 && tree_depth < p.max_depth) {     // :227
+            const double z = rng_uniform(p.seed, chain, dabs, uslot++);                      // :233
+            const int dir = (z <= 0.5) ? -1 : 1;             // :235
+            copy_vec(par, v.prev, start_draw, d);
+            // the reference's top-level call (:241-246 / :251-256): the far side's edges go into dummies
+            if (dir == -1) { copy_vec(par, draw_pos, dummy_draw, d); copy_vec(par, mntm_pos, dummy_mntm, d); }
+            else { copy_vec(par, draw_neg, dummy_draw, d); copy_vec(par, mntm_neg, dummy_mntm, d); }
+            int sp = 0;
+            st[0].state = 0; st[0].depth = tree_depth; st[0].draw_vec = start_draw; st[0].mntm_vec = mntm_vec;
+            st[0].new_draw = new_draw;
+            st[0].pos = (dir == -1) ? dummy_draw : draw_pos; st[0].neg = (dir == -1) ? draw_neg : dummy_draw;
+            st[0].mpos = (dir == -1) ? dummy_mntm : mntm_pos; st[0].mneg = (dir == -1) ? mntm_neg : dummy_mntm;
+            uint64_t r_n = 0, r_s = 0, r_na = 0; double r_a = 0.0;       // return registers of the callee
+            while (sp >= 0) {
+                NutsFrame& f = st[sp];
+                if (f.depth == 0) {                          // nuts.ipp:126-158
+                    copy_vec(par, f.draw_vec, leaf_start, d);
+                    copy_vec(par, f.mntm_vec, leaf_mntm, d); // :128
+                    copy_vec(par, leaf_start, f.new_draw, d);   // :127
+                    dyn_leap_frog(par, p, v, (double)dir * step_size, f.new_draw, leaf_mntm); n_leap++;   // :132
+                    double qU = -box_log_kernel(par, p, v, f.new_draw);   // :134
+                    if (!is_finite(qU)) qU = INF;
+                    const double qK = dyn_kinetic(par, p, v, leaf_mntm);  // :140
+                    r_n = (log_rand <= -qU - qK) ? 1u : 0u;  // :146
+                    r_s = (log_rand < 1000.0 - qU - qK) ? 1u : 0u;       // :147
+                    copy_vec(par, f.new_draw, f.pos, d); copy_vec(par, f.new_draw, f.neg, d);          // :151-155
+                    copy_vec(par, leaf_mntm, f.mpos, d); copy_vec(par, leaf_mntm, f.mneg, d);
+                    const double dd = -(qU + qK) + (prev_U + prev_K);
+                    r_a = det_exp((dd < 0.0) ? dd : 0.0);    // :157
+                    r_na = 1;
+                    --sp;
+                    continue;
+                }
+                double* const draw_p = fvec((uint32_t)sp, 0); double* const draw_pp = fvec((uint32_t)sp, 1);
+                double* const f_dummy_d = fvec((uint32_t)sp, 2); double* const f_dummy_m = fvec((uint32_t)sp, 3);
+                double* const edge_d = fvec((uint32_t)sp, 4); double* const edge_m = fvec((uint32_t)sp, 5);
+                if (f.state == 0) {                          // :166-171
+                    f.state = 1;
+                    NutsFrame& g = st[sp + 1];
+                    g.state = 0; g.depth = f.depth - 1; g.draw_vec = f.draw_vec; g.mntm_vec = f.mntm_vec;
+                    g.new_draw = draw_p; g.pos = f.pos; g.neg = f.neg; g.mpos = f.mpos; g.mneg = f.mneg;
+                    ++sp;
+                    continue;
+                }
+                if (f.state == 1) {
+                    f.n_p = r_n; f.s_p = r_s; f.alpha_p = r_a; f.n_alpha_p = r_na;
+                    if (f.s_p == 1) {
+                        f.state = 2;
+                        NutsFrame& g = st[sp + 1];
+                        g.state = 0; g.depth = f.depth - 1; g.draw_vec = edge_d; g.mntm_vec = edge_m; g.new_draw = draw_pp;
+                        if (dir == -1) {                     // :186-196
+                            copy_vec(par, f.pos, f_dummy_d, d); copy_vec(par, f.mpos, f_dummy_m, d);
+                            copy_vec(par, f.neg, edge_d, d); copy_vec(par, f.mneg, edge_m, d);
+                            g.pos = f.neg; g.neg = f_dummy_d; g.mpos = f.mneg; g.mneg = f_dummy_m;     // crossed (:195)
+                        } else {                             // :198-208
+                            copy_vec(par, f.neg, f_dummy_d, d); copy_vec(par, f.mneg, f_dummy_m, d);
+                            copy_vec(par, f.pos, edge_d, d); copy_vec(par, f.mpos, edge_m, d);
+                            g.pos = f_dummy_d; g.neg = f.pos; g.mpos = f_dummy_m; g.mneg = f.mpos;     // crossed (:207)
+                        }
+                        ++sp;
+                        continue;
+                    }
+                } else {                                     // state 2: :212-229
+                    const uint64_t n_pp = r_n, s_pp = r_s, n_alpha_pp = r_na;
+                    const double alpha_pp = r_a;
+                    const double prob = (double)n_pp / (double)(f.n_p + n_pp);               // :212
+                    const double zz = rng_uniform(p.seed, chain, dabs, uslot++);             // :213
+                    if (zz < prob) copy_vec(par, draw_pp, draw_p, d);                        // :215-217
+                    f.n_p += n_pp; f.alpha_p += alpha_pp; f.n_alpha_p += n_alpha_pp;         // :220-222
+                    LIT_PFOR(i, d) diff[i] = f.pos[i] - f.neg[i];
+                    par.sync();
+                    const bool c1 = dot_b(p.t, diff, f.mneg) >= 0.0;                         // :226
+                    const bool c2 = dot_b(p.t, diff, f.mpos) >= 0.0;                         // :227
+                    par.sync();
+                    f.s_p = s_pp * (c1 ? 1u : 0u) * (c2 ? 1u : 0u);                          // :229
+                }
+                r_n = f.n_p; r_s = f.s_p; r_a = f.alpha_p; r_na = f.n_alpha_p;               // :234-239
+                copy_vec(par, draw_p, f.new_draw, d);
+                --sp;
+            }
+            const uint64_t n_p_val = r_n, s_p_val = r_s;
+            alpha_val = r_a; n_alpha_val = r_na;             // the top-level call writes alpha_val / n_alpha_val directly (:246,255)
+            if (s_p_val == 1) {                              // :260
+                const double z2 = rng_uniform(p.seed, chain, dabs, uslot++);                 // :261
+                if (z2 < (double)n_p_val / (double)n_val) {  // :263
+                    double qU = -box_log_kernel(par, p, v, new_draw);                        // :264
+                    if (!is_finite(qU)) qU = INF;
+                    copy_vec(par, new_draw, v.prev, d);      // :272-273
+                    prev_U = qU;
+                    good_round = 1;                          // :277
+                }
+            }
+            n_val += n_p_val;                                // :283
+            tree_depth += 1;
+            LIT_PFOR(i, d) diff[i] = draw_pos[i] - draw_neg[i];
+            par.sync();
+            const bool c1 = dot_b(p.t, diff, mntm_neg) >= 0.0;                               // :286
+            const bool c2 = dot_b(p.t, diff, mntm_pos) >= 0.0;                               // :287
+            par.sync();
+            s_val = s_p_val * (c1 ? 1u : 0u) * (c2 ? 1u : 0u);                               // :289
+        }
+        if (draw < n_adapt) {                                // :294-302 (this chain's own draw index)
+            const double it = (double)(draw + 1);
+            h_val += (1 / (it + p.t0)) * (p.delta - (alpha_val / (double)n_alpha_val) - h_val);
+            step_size = det_exp(mu_val - h_val * __builtin_sqrt(it) / p.gamma);
+            epsilon_bar *= det_exp(det_pow(it, -p.kappa) * (det_log(step_size) - det_log(epsilon_bar)));
+        } else {
+            step_size = epsilon_bar;
+        }
+        if (p.depth_trace && par.tid == 0) p.depth_trace[(size_t)draw * p.C + c] = tree_depth;
+        if (draw >= p.n_burnin) {                            // :306-309
+            n_acc += (uint64_t)good_round;
+            store_row(par, p, c, draw - p.n_burnin, v.prev);
+        }
+    }
+    if (p.step_out && par.tid == 0) p.step_out[c] = step_size;
+    store_outputs(par, p, c, v, n_acc, n_leap);
+}
+
 #if defined(__HIPCC__)
-template <int ALGO>     // 0 hmc, 1 mala
+template <int ALGO>     // 0 hmc, 1 mala, 2 nuts, 3 rwmh
 __global__ __launch_bounds__(256) void literal_kernel(const LitParams prm)
 {
     if (prm.any != nullptr && *prm.any == 0u) return;
@@ -665,7 +976,8 @@ __global__ __launch_bounds__(256) void literal_kernel(const LitParams prm)
     double* wk = prm.work + (size_t)blockIdx.x * prm.work_stride;
     for (uint64_t c = blockIdx.x; c < prm.C; c += gridDim.x) {
         if (prm.flag != nullptr && prm.flag[c] == 0u) continue;
-        if (ALGO == 0) hmc_chain(par, prm, c, wk); else mala_chain(par, prm, c, wk);
+        if (ALGO == 0) hmc_chain(par, prm, c, wk); else if (ALGO == 1) mala_chain(par, prm, c, wk);
+        else if (ALGO == 2) nuts_chain(par, prm, c, wk); else rwmh_chain(par, prm, c, wk);
         __syncthreads();
     }
 }

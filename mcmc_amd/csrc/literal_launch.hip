@@ -10,9 +10,11 @@ namespace mi {
 int launch_literal(int algo, const lit::LitParams& prm, unsigned n_wg, hipStream_t st)
 {
     if (n_wg == 0) return 0;
-    if (prm.flag == nullptr) note_kernel("literal_kernel<%d>", algo == 0 ? 0 : 1);     // the run itself, not a replay behind another kernel
+    if (prm.flag == nullptr) note_kernel("literal_kernel<%d>", algo);     // the run itself, not a replay behind another kernel
     if (algo == 0) hipLaunchKernelGGL(lit::literal_kernel<0>, dim3(n_wg), dim3(256), 0, st, prm);
-    else hipLaunchKernelGGL(lit::literal_kernel<1>, dim3(n_wg), dim3(256), 0, st, prm);
+    else if (algo == 1) hipLaunchKernelGGL(lit::literal_kernel<1>, dim3(n_wg), dim3(256), 0, st, prm);
+    else if (algo == 2) hipLaunchKernelGGL(lit::literal_kernel<2>, dim3(n_wg), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(lit::literal_kernel<3>, dim3(n_wg), dim3(256), 0, st, prm);
     return (int)hipGetLastError();
 }
 

@@ -219,6 +219,12 @@ int lit_upload(const mi::lit::LitPrep& pr, uint32_t d, bool want_bounds, LitDev&
     return MI_OK;
 }
 
+// ---- the literal kernels as the device path of everything the tiled kernels do not implement: dense-gradient targets with d > 128,
+// the logistic target with bounds / a preconditioner / nuts beyond d = 8 or with d > 512, max_tree_depth > 10.  One workgroup per
+// chain, the reference's operations as written (literal.hpp): O(d^2) per leapfrog step and chain, no MFMA, no shared tiles -- a
+// completeness path, not a throughput path.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh.
+int run_literal(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st);
+
 int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
 {
     if (!t || !s || !c) return fail(MI_ERR_BAD_ARG, "null target / settings / chains");
@@ -455,6 +461,86 @@ int launched(const char* what, int hip_err)
     return MI_OK;
 }
 
+int run_literal(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    const uint64_t d = target->d, C = chains->n_chains;
+    const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (d > 0x7fffffffULL) return fail(MI_ERR_BAD_ARG, "%s: d out of range", who);
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds)) return fail(MI_ERR_BAD_ARG, "%s: vals_bound needs lower_bounds and upper_bounds", who);
+    if (algo == 2 && settings->max_tree_depth > (uint64_t)mi::lit::LIT_NUTS_MAX_DEPTH)
+        return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented (2^%d leapfrog steps per draw)", (int)mi::lit::LIT_NUTS_MAX_DEPTH, (int)mi::lit::LIT_NUTS_MAX_DEPTH);
+    mi::lit::LitParams lp{};
+    DevBuf t_a, t_b;                                     // staged target
+    lp.t.d = (uint32_t)d;
+    auto up = [&](DevBuf& b, const double* src, size_t n_doubles, const double** out) -> int {
+        if (target->mem == MI_MEM_DEVICE) { *out = src; return MI_OK; }
+        HIP_TRY(b.alloc(n_doubles * 8));
+        HIP_TRY(hipMemcpy(b.p, src, n_doubles * 8, hipMemcpyHostToDevice));
+        *out = b.as<double>();
+        return MI_OK;
+    };
+    int rc;
+    switch (target->kind) {
+    case MI_TARGET_GAUSS_ISO: lp.t.kind = mi::lit::LIT_ISO; break;
+    case MI_TARGET_GAUSS_DIAG:
+        if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DIAG needs prec (d)");
+        lp.t.kind = mi::lit::LIT_DIAG; lp.t.prec_stride = 1;
+        if ((rc = up(t_a, target->prec, d, &lp.t.prec))) return rc;
+        break;
+    case MI_TARGET_GAUSS_DENSE:
+        if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
+        lp.t.kind = mi::lit::LIT_DENSE;
+        if ((rc = up(t_a, target->prec, d * d, &lp.t.prec))) return rc;
+        break;
+    case MI_TARGET_LOGISTIC:
+        if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+        lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.n_rows = (uint32_t)target->n_rows;
+        if ((rc = up(t_a, target->X, target->n_rows * d, &lp.t.X))) return rc;
+        if ((rc = up(t_b, target->y, target->n_rows, &lp.t.y))) return rc;
+        break;
+    default: return fail(MI_ERR_UNSUPPORTED, "%s: target kind %d not implemented", who, target->kind);
+    }
+    mi::lit::lit_orders(lp.t);
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+    const bool mala_bounded = algo == 1 && settings->vals_bound != 0;
+    if (mala_bounded && d > 512) return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound with d > 512 is not implemented (ten d x d matrices per workgroup)");
+    ReplayWs rp;
+    rp.stride = mi::lit::lit_work_doubles((uint32_t)d, lp.t.n_rows, mala_bounded, (uint32_t)settings->max_tree_depth, algo == 2);
+    rp.n_wg = (unsigned)std::min<uint64_t>(C, mala_bounded ? 128u : 1024u);
+    WsLease ws;
+    rc = ws_get(st, (size_t)rp.n_wg * rp.stride * sizeof(double), ws);
+    if (rc) return rc;
+    rp.work = ws.as<double>();
+    lit_common(lp, settings, &sc.dev, rp, true);
+    mi::lit::LitPrep prep;
+    mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
+                         settings->upper_bounds, settings->precond_mat, prep);
+    LitDev ldev;
+    rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
+    if (rc) return rc;
+    if (algo == 2) {
+        if (chains->draw0 > 0) {
+            if (chains->draw0 <= settings->n_adapt_draws)
+                return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
+            if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
+        }
+        lp.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+        lp.max_depth = (uint32_t)settings->max_tree_depth;
+        lp.delta = settings->target_accept_rate; lp.gamma = settings->gamma_val; lp.t0 = settings->t0_val; lp.kappa = settings->kappa_val;
+        lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth;
+    }
+    rc = launched(who, mi::launch_literal(algo, lp, rp.n_wg, st));
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+    if (t_a.p || t_b.p || ldev.any || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+
 // hmc / rwmh on the logistic-regression target (identity preconditioner / cov_mat, no bounds): logit_lds_kernel<., HMC | RWMH>;
 // settings->step_size is the leapfrog step resp. par_scale
 int run_logit_plain(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -671,9 +757,11 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC)        // plain: the LDS-staged MFMA kernel (any d <= 512); bounds / precond_mat: one chain per lane (d <= 8)
-        return (settings->vals_bound || settings->precond_mat) ? run_small_logistic("hmc", 0, target, settings, chains, st)
-                                                               : run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
+        if (settings->vals_bound || settings->precond_mat)
+            return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("hmc", 0, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
+        return d <= 512 ? run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
+    }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "hmc: target kind %d not implemented", target->kind);
     // precond_mat (hmc.cpp:57-59): a DIAGONAL matrix is supported (INV and CHOL_LOWER of a diagonal matrix are the
@@ -681,8 +769,6 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     std::vector<double> m_sqrt, m_inv;
     bool dense_m = false;
     if (settings->precond_mat) {
-        if (d > 128 && !(target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG))
-            return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with d > 128 is implemented for the separable Gaussian targets only");
         m_sqrt.resize(d); m_inv.resize(d);
         for (uint64_t i = 0; i < d; ++i)
             for (uint64_t k = 0; k < d; ++k) {
@@ -694,6 +780,10 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         // in fragment order (64 < d <= 128); target must be an MFMA one
         if (dense_m && target->kind == MI_TARGET_LOGISTIC) return fail(MI_ERR_UNSUPPORTED, "hmc: precond_mat with the logistic target is not implemented");
     }
+    // beyond d = 128 the tiled kernels serve separable targets without bounds (identity or diagonal precond_mat: hmc_diag.hpp);
+    // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
+    if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
+        return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
     if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds))
         return fail(MI_ERR_BAD_ARG, "hmc: vals_bound needs lower_bounds and upper_bounds");
@@ -984,7 +1074,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("mala", 1, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat))
-        return run_small_logistic("mala", 1, target, settings, chains, st);
+        return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("mala", 1, target, settings, chains, st) : run_literal("mala", 1, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC && d > 512) return run_literal("mala", 1, target, settings, chains, st);
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
     const double s2_ = settings->step_size * settings->step_size;
@@ -1029,7 +1120,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
-    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "mala: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
+    if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
     const double* P_dev = nullptr;
@@ -1145,12 +1236,14 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC)
-        return (settings->vals_bound || settings->precond_mat) ? run_small_logistic("rwmh", 3, target, settings, chains, st)
-                                                               : run_logit_plain("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC) {
+        if (settings->vals_bound || settings->precond_mat)
+            return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("rwmh", 3, target, settings, chains, st) : run_literal("rwmh", 3, target, settings, chains, st);
+        return d <= 512 ? run_logit_plain("rwmh", mi::LOGIT_RWMH, target, settings, chains, st) : run_literal("rwmh", 3, target, settings, chains, st);
+    }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
-    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "rwmh: d = %llu > 128 not implemented", (unsigned long long)d);
+    if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
     const double* P_dev = nullptr;
@@ -1210,12 +1303,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("nuts", 2, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC) return run_small_logistic("nuts", 2, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC)
+        return (d <= (uint64_t)mi::SMALL_MAX_D && settings->max_tree_depth <= 10) ? run_small_logistic("nuts", 2, target, settings, chains, st)
+                                                                                   : run_literal("nuts", 2, target, settings, chains, st);
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
-    if (d > 128) return fail(MI_ERR_UNSUPPORTED, "nuts: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
-    if (settings->max_tree_depth > (uint64_t)mi::NUTS_MAX_DEPTH)
-        return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented", (int)mi::NUTS_MAX_DEPTH);
+    // the tiled kernels: d <= 128, max_tree_depth <= 10 (per-level records and scalars are sized for that); beyond, literal.hpp
+    if (d > 128 || settings->max_tree_depth > (uint64_t)mi::NUTS_MAX_DEPTH) return run_literal("nuts", 2, target, settings, chains, st);
     const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
     if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
 

@@ -36,9 +36,12 @@ def _f(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
+ALGO = {"hmc": 0, "mala": 1, "nuts": 2, "rwmh": 3}
+
+
 def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None, y=None, chain0=0, draw0=0,
-        lower=None, upper=None, precond=None):
-    """algo 'hmc' | 'mala'; init [C, d].  Returns (draws [n_keep, d, C], dict(n_accept, n_leap, theta [C, d]))."""
+        lower=None, upper=None, precond=None, n_adapt=0, max_depth=10, delta=0.55, gamma=0.05, t0=10.0, kappa=0.75, step_in=None):
+    """algo 'hmc' | 'mala' | 'nuts' | 'rwmh'; init [C, d].  Returns (draws [n_keep, d, C], dict(n_accept, n_leap, theta [C, d], eps, depth))."""
     init = _f(init)
     Cn, d = init.shape
     theta = np.ascontiguousarray(init.T.copy())              # [d][C]
@@ -48,10 +51,14 @@ def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None
     prec, X, y, lower, upper, precond = _f(prec), _f(X), _f(y), _f(lower), _f(upper), _f(precond)
     n_rows = 0 if X is None else X.shape[0]
     u64p = C.POINTER(C.c_uint64)
-    rc = lib().lit_host_run(C.c_int(0 if algo == "hmc" else 1), C.c_int(KIND[kind]), C.c_uint32(d), C.c_uint32(n_rows),
+    step = np.zeros(Cn) if step_in is None else np.array(step_in, dtype=np.float64, copy=True)
+    depth = np.zeros((n_burnin + n_keep, Cn), dtype=np.uint32)
+    rc = lib().lit_host_run(C.c_int(ALGO[algo]), C.c_int(KIND[kind]), C.c_uint32(d), C.c_uint32(n_rows),
                             _p(prec), _p(X), _p(y), C.c_uint64(Cn), C.c_uint64(chain0), _p(theta), _p(draws),
                             nacc.ctypes.data_as(u64p), nleap.ctypes.data_as(u64p), C.c_uint64(seed), C.c_uint32(n_burnin),
                             C.c_uint32(n_keep), C.c_uint32(n_leap), C.c_uint32(draw0), C.c_double(eps),
-                            C.c_int(0 if lower is None else 1), _p(lower), _p(upper), _p(precond))
+                            C.c_int(0 if lower is None else 1), _p(lower), _p(upper), _p(precond),
+                            C.c_uint32(n_adapt), C.c_uint32(max_depth), C.c_double(delta), C.c_double(gamma), C.c_double(t0),
+                            C.c_double(kappa), _p(step), depth.ctypes.data_as(C.POINTER(C.c_uint32)))
     assert rc == 0
-    return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy())
+    return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy(), eps=step, depth=depth)

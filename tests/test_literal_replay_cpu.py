@@ -16,6 +16,7 @@ def _case(rng, algo, tgt, force_nonfinite):
     seed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
     burn, keep = int(rng.integers(0, 3)), int(rng.integers(1, 6))
     L = int(rng.integers(0, 5))
+    depth, adapt = int(rng.integers(0, 6)), int(rng.integers(0, 4))
     eps = float(rng.choice([0.05, 0.3, 1.5, 40.0, 1e6, 1e160] if force_nonfinite else [0.01, 0.1, 0.5]))
     prec = X = y = None
     if tgt == "dense": prec, ko = synth.dense_gaussian_precision(d, seed=seed % 97), orc.TARGET_DENSE
@@ -45,15 +46,17 @@ def _case(rng, algo, tgt, force_nonfinite):
         dq = 16 if d <= 64 else 32
         tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
     t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
-    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, **okw)
-    o_draws, o = orc.run_many(orc.ALGO_HMC if algo == "hmc" else orc.ALGO_MALA, t, init, s, chain0=chain0)
-    l_draws, l = lit_host.run(algo, tgt, init, seed, burn, keep, L, eps, prec=prec, X=X, y=y, chain0=chain0, **kw)
-    desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} opts={sorted(kw)}"
+    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, n_adapt=adapt, max_depth=depth, **okw)
+    o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=chain0)
+    l_draws, l = lit_host.run(algo, tgt, init, seed, burn, keep, L, eps, prec=prec, X=X, y=y, chain0=chain0, n_adapt=adapt, max_depth=depth, **kw)
+    desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} depth={depth} adapt={adapt} opts={sorted(kw)}"
     ok = np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"])
+    if algo == "nuts":
+        ok = ok and np.array_equal(l["n_leap"], o["n_leap"]) and np.array_equal(l["eps"], o["eps"], equal_nan=True)
     return ok, desc, bool(np.isnan(o_draws).any() or np.isinf(o_draws).any())
 
 
-@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh"])
 @pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
 def test_literal_replay_equals_the_oracle_in_the_finite_regime(algo, tgt):
     rng = np.random.default_rng([11, len(algo), len(tgt)])
@@ -62,7 +65,7 @@ def test_literal_replay_equals_the_oracle_in_the_finite_regime(algo, tgt):
         assert ok, desc
 
 
-@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh"])
 @pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
 def test_literal_replay_equals_the_oracle_in_the_non_finite_regime(algo, tgt):
     rng = np.random.default_rng([12, len(algo), len(tgt)])
