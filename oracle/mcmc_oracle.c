@@ -787,6 +787,25 @@ static double mala_prop_adjustment(orc_ctx* c, const double* prop_vals, const do
     return ret;
 }
 
+/* test hook (tests/test_oracle_structure.py): mala_prop_adjustment(prop, prev) of a built-in target under settings s */
+double orc_mala_prop_adjustment_eval(orc_target* t, const orc_settings* s, const double* prop_vals, const double* prev_vals)
+{
+    orc_ctx c;
+    ctx_init(&c, t->d, orc_target_kernel, t, s, 0);
+    mala_fact hoisted; hoisted.Sinv = NULL; hoisted.log_det = 0.0;
+    if (s->hoist_factorizations && !c.vals_bound) {
+        double* Sigma = dvec(t->d * t->d);
+        const double s2 = s->step_size * s->step_size;
+        for (size_t i = 0; i < t->d * t->d; ++i) Sigma[i] = s2 * c.precond[i];
+        mala_factorise(Sigma, t->d, &hoisted);
+        free(Sigma);
+    }
+    const double r = mala_prop_adjustment(&c, prop_vals, prev_vals, s->step_size, hoisted.Sinv ? &hoisted : NULL);
+    free(hoisted.Sinv);
+    ctx_free(&c);
+    return r;
+}
+
 /* ref: src/mala.cpp:30-208 */
 int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st)

@@ -128,6 +128,7 @@ typedef struct orc_stats {
 /* draws_out: n_keep x d, element (i,j) at draws_out[i*d + j] (row per draw). */
 int orc_hmc (const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
+double orc_mala_prop_adjustment_eval(orc_target* t, const orc_settings* s, const double* prop_vals, const double* prev_vals);   /* test hook */
 int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
 int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,

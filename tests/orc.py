@@ -51,6 +51,7 @@ def lib():
         _lib.orc_dmvnorm_log.restype = C.c_double
         _lib.orc_log_jacobian.restype = C.c_double
         _lib.orc_target_kernel.restype = C.c_double
+        _lib.orc_mala_prop_adjustment_eval.restype = C.c_double
     return _lib
 
 
@@ -171,3 +172,9 @@ def uniform(seed, chain, draw, slot):
 def dot(x, y, W):
     x, y = _f64(x), _f64(y)
     return lib().orc_dot(_p(x), _p(y), C.c_size_t(x.size), W)
+
+
+def mala_prop_adjustment(target, settings, prop, prev):
+    """mala_prop_adjustment(prop_vals, prev_vals) (ref: include/mcmc/mala.ipp:30-70) of a built-in target"""
+    prop, prev = _f64(prop), _f64(prev)
+    return lib().orc_mala_prop_adjustment_eval(C.byref(target.c), C.byref(settings), _p(prop), _p(prev))

@@ -150,10 +150,12 @@ def test_full_size_config2_subset_parity_and_statistics():
 
 
 def test_unsupported_requests_fail_loudly():
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
+    """what no device path implements is refused with a status and a reason, never approximated (d = 300 itself now runs, on the
+    literal kernel: tests/test_gpu_literal_paths.py)"""
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, max_tree_depth=40)
     with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, np.zeros((4, 300)), st, prec=np.eye(300))
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+        mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, np.zeros((4, 300)), st, prec=np.eye(300))
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED and "max_tree_depth" in str(e.value)
 
 
 # ---------------------------------------------------------------- elementwise kernel (separable targets, any d)
@@ -308,13 +310,17 @@ def test_dense_precond_hmc_bit_exact_vs_oracle(d, C, L, eps, bounded):
     assert 0 < g["n_accept"].sum()
 
 
-def test_dense_precond_beyond_128_dims_is_refused_not_approximated():
-    d = 130
+def test_dense_precond_beyond_128_dims_runs_literally():
+    """three d x d fragment sets beyond d = 128 fit neither LDS nor the tiled kernels' registers: the literal kernel runs it"""
+    d, C = 130, 6
     M = _spd(d, seed=1)
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=M)
-    with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, d)), st)
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+    init = synth.initial_states(C, d, seed=2)
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=1, n_keep_draws=3, n_leap_steps=2, step_size=0.1, precond_mat=M)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_ISO, init, st)
+    assert mcmc_amd.last_kernel() == "literal_kernel<0>"
+    s = orc.make_settings(seed=3, n_burnin=1, n_keep=3, n_leap=2, step=0.1, W=4, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_ISO, d, W=4), init, s)
+    assert np.array_equal(g_draws, o_draws) and np.array_equal(g["n_accept"], o["n_accept"])
 
 
 # ---------------------------------------------------------------- HMC on the logistic-regression target

@@ -104,10 +104,14 @@ def test_one_lane_engine_and_lds_kernel_give_the_same_bits(algo, step, L, d):
     assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
 
 
-def test_small_logistic_beyond_8_dims_is_refused_with_a_reason():
-    d = 9
+def test_logistic_nuts_beyond_8_dims_runs_on_the_literal_kernel():
+    d, C = 9, 6
     X, y = synth.logistic_problem(d, 30, seed=1)
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
-    with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.nuts(mcmc_amd.TARGET_LOGISTIC, np.zeros((4, d)), st, X=X, y=y)
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED and "d <= 8" in str(e.value)
+    init = synth.initial_states(C, d, seed=2) * 0.3
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=2, n_keep_draws=3, n_adapt_draws=2, max_tree_depth=4)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    assert mcmc_amd.last_kernel() == "literal_kernel<2>"
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=16, eta_chains=2)
+    s = orc.make_settings(seed=4, n_burnin=2, n_keep=3, n_adapt=2, max_depth=4, step=float(st.step_size), W=4, blocks=4, block_size=16)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s)
+    assert np.array_equal(g_draws, o_draws) and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"])
