@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000200
+#define MI_MCMC_VERSION 0x000300
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -155,6 +155,13 @@ int         mi_mcmc_device_count(void);
 typedef int (*mi_small_launch_fn)(int algo, const void* small_params, const void* target_pod, void* stream);
 int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
                             const mi_settings* settings, mi_chains* chains, void* stream);
+/* The same for TILE targets (include/mi_mcmc_tile_target.hpp): value + gradient for 16 chains at once in the MFMA register layout,
+ * d <= 16 nt, hmc (algo 0) and mala (1) with the identity precond_mat and no bounds.  wpb: waves per workgroup the target's kernels
+ * are built for (4 or 8); lds_bytes: what the target stages; header_version: MI_MCMC_VERSION of the headers the target library was
+ * compiled against -- it instantiates engine kernels from them, so a library built against other headers is refused (MI_ERR_BAD_ARG). */
+typedef int (*mi_tile_launch_fn)(int algo, const void* tile_params, const void* target_pod, uint64_t lds_bytes, void* stream);
+int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_bytes, mi_tile_launch_fn launch, const void* target_pod,
+                            uint64_t tile_params_bytes, int header_version, const mi_settings* settings, mi_chains* chains, void* stream);
 
 /* Kernel workspaces are cached per (device, stream) and reused by later calls on that stream (NUTS at BASELINE configs[3]
  * holds 4 GiB).  This frees the cache of the CURRENT device for `stream` (all_streams != 0: for every stream, e.g. before
@@ -226,11 +233,14 @@ int mi_mcmc_rwmh_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
 void mi_mcmc_shard_bounds(uint64_t n_chains_total, uint32_t world_size, uint32_t rank, uint64_t* chain0, uint64_t* n_local);
 /* All-gather of the kept draws over xGMI: every rank contributes its slab local_draws [n_keep][d][n_local] and receives
  * all_draws [n_keep][d][n_chains_total] (both DEVICE memory).  rccl_comm is the caller's ncclComm_t (one rank per GPU; RCCL is
- * loaded on first use, MI_ERR_UNSUPPORTED if librccl.so is absent).  Ragged shards need no padding: one grouped broadcast per
- * rank into a rank-major staging buffer (`scratch`, n_keep * d * n_chains_total doubles on the device), then a merge kernel
- * that interleaves the chain axis.  Enqueued on `stream`; returns after enqueueing. */
+ * loaded on first use, MI_ERR_UNSUPPORTED if librccl.so is absent).  Equal shards (n_chains_total divisible by world_size: every
+ * BASELINE split) are ONE ncclAllGather into a rank-major staging buffer (`scratch`, n_keep * d * n_chains_total doubles on the
+ * device); ragged shards need no padding: one grouped broadcast per rank into the same buffer (_ragged, which the first form
+ * falls back to).  A merge kernel then interleaves the chain axis.  Enqueued on `stream`; returns after enqueueing. */
 int mi_mcmc_allgather_draws(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
                             uint64_t d, uint64_t n_chains_total, double* scratch, double* all_draws, void* stream);
+int mi_mcmc_allgather_draws_ragged(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
+                                   uint64_t d, uint64_t n_chains_total, double* scratch, double* all_draws, void* stream);
 /* the merge step alone: rank-major shards [r][n_keep][d][n_local(r)] (device) -> [n_keep][d][n_chains_total] (device) */
 int mi_mcmc_merge_shards(const double* rank_major, uint32_t world_size, uint64_t n_keep, uint64_t d, uint64_t n_chains_total,
                          double* all_draws, void* stream);

@@ -31,6 +31,7 @@
 #include "launchers.hpp"
 #include "small_samplers.hpp"
 #include "literal_host.hpp"
+#include "tile_samplers.hpp"
 
 // round time of the few-chain launch shapes of the plain HMC kernel relative to the default (two waves per SIMD), d = 128
 #ifndef MI_HMC_COST_1WAVE
@@ -743,6 +744,65 @@ int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, con
     return run_small(names[algo], algo, d, settings, chains, static_cast<hipStream_t>(stream), [&](const mi::SmallParams& p, hipStream_t s_) {
         return launch(algo, &p, target_pod, s_);
     });
+}
+
+int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_bytes, mi_tile_launch_fn launch, const void* target_pod,
+                            uint64_t tile_params_bytes, int header_version, const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    if (!launch || !target_pod || !settings || !chains) return fail(MI_ERR_BAD_ARG, "null launch function / target / settings / chains");
+    if (header_version != MI_MCMC_VERSION)
+        return fail(MI_ERR_BAD_ARG, "the target library was built against engine headers %#x, this library is %#x: rebuild it", header_version, MI_MCMC_VERSION);
+    if (tile_params_bytes != sizeof(mi::TileParams))
+        return fail(MI_ERR_BAD_ARG, "the target library was built against another version of the engine headers (TileParams %llu vs %llu bytes)",
+                    (unsigned long long)tile_params_bytes, (unsigned long long)sizeof(mi::TileParams));
+    if (settings->struct_size != sizeof(mi_settings) || chains->struct_size != sizeof(mi_chains))
+        return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
+    if (algo != 0 && algo != 1) return fail(MI_ERR_UNSUPPORTED, "tile targets: hmc (0) and mala (1) are implemented");
+    if (!(nt == 1 || nt == 2 || nt == 4 || nt == 8) || d == 0 || d > (uint64_t)16 * nt) return fail(MI_ERR_BAD_ARG, "tile targets: 1 <= d <= 16 NT, NT in {1, 2, 4, 8}");
+    if (wpb != 4 && wpb != 8) return fail(MI_ERR_BAD_ARG, "tile targets: WPB is 4 or 8");
+    if (settings->vals_bound || settings->precond_mat)
+        return fail(MI_ERR_UNSUPPORTED, "tile targets: vals_bound / precond_mat are not implemented on this route (one-lane targets, include/mi_mcmc_target.hpp, take both)");
+    if (chains->n_chains == 0 || !chains->theta) return fail(MI_ERR_BAD_ARG, "chains.theta and n_chains are required");
+    const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (chains->draw0 + n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw0 + draws exceeds the 32-bit draw counter");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    (void)hipGetLastError();
+    int dev = 0, lds_max = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: the target asks for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StagedChains sc;
+    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    mi::TileParams p{};
+    p.d = (uint32_t)d; p.C = chains->n_chains; p.chain0 = chains->chain0;
+    p.theta = sc.dev.theta; p.draws = sc.dev.draws; p.n_accept = sc.dev.n_accept; p.n_leap = sc.dev.n_leapfrogs;
+    p.seed = settings->rng_seed_value;
+    p.n_burnin = (uint32_t)settings->n_burnin_draws; p.n_keep = (uint32_t)settings->n_keep_draws;
+    p.n_leap_steps = (uint32_t)settings->n_leap_steps; p.draw0 = (uint32_t)chains->draw0;
+    p.eps = settings->step_size;
+    p.s2 = settings->step_size * settings->step_size; p.rs = 1.0 / p.s2;
+    p.cons_term = -0.5 * (double)d * 1.83787706640934548356;
+    {
+        const double lii = __builtin_sqrt(p.s2);
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(lii);
+        p.log_det = ld;
+    }
+    WsLease ws;
+    rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
+    if (rc) return rc;
+    p.wsave = ws.as<double>();
+    mi::note_kernel("%s_tile_kernel<user target, %d>", algo == 0 ? "hmc" : "mala", algo == 0 ? wpb : 4);
+    const int e = launch(algo, &p, target_pod, lds_bytes, stream);
+    if (e != 0) return fail(MI_ERR_HIP, "tile target kernel launch: %s", hipGetErrorString((hipError_t)e));
+    if (algo == 1) { rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st); if (rc) return rc; }
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
 }
 
 int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed)

@@ -204,6 +204,7 @@ struct Rccl {
     int (*group_start)() = nullptr;
     int (*group_end)() = nullptr;
     int (*broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*err)(int) = nullptr;
 };
 Rccl* rccl()
@@ -216,9 +217,10 @@ Rccl* rccl()
         r.group_start = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupStart"));
         r.group_end = reinterpret_cast<int (*)()>(dlsym(r.h, "ncclGroupEnd"));
         r.broadcast = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.h, "ncclBroadcast"));
+        r.allgather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.h, "ncclAllGather"));
         r.err = reinterpret_cast<const char* (*)(int)>(dlsym(r.h, "ncclGetErrorString"));
     });
-    return (r.h && r.group_start && r.group_end && r.broadcast) ? &r : nullptr;
+    return (r.h && r.group_start && r.group_end && r.broadcast && r.allgather) ? &r : nullptr;
 }
 
 }  // namespace
@@ -240,8 +242,9 @@ int mi_mcmc_merge_shards(const double* rank_major, uint32_t world, uint64_t n_ke
     return MI_OK;
 }
 
-int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
-                            double* scratch, double* all, void* stream)
+// ragged shards: one broadcast per rank into the rank-major staging buffer, grouped into one RCCL launch
+int mi_mcmc_allgather_draws_ragged(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                                   double* scratch, double* all, void* stream)
 {
     if (!comm || !scratch || !all || world == 0 || rank >= world) return fail(MI_ERR_BAD_ARG, "allgather_draws: bad communicator / buffers / rank");
     Rccl* r = rccl();
@@ -252,14 +255,33 @@ int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const dou
     mi_mcmc_shard_bounds(C, world, rank, &c0, &nl);
     if (nl > 0 && !local) return fail(MI_ERR_BAD_ARG, "allgather_draws: local_draws is required for a non-empty shard");
     int e = r->group_start();
-    for (uint32_t q = 0; q < world && e == 0; ++q) {       // ragged shards: one broadcast per rank, grouped into one launch
+    for (uint32_t q = 0; q < world && e == 0; ++q) {
         uint64_t qc0 = 0, qn = 0;
         mi_mcmc_shard_bounds(C, world, q, &qc0, &qn);
         if (qn == 0) continue;
-        e = r->broadcast(q == rank ? local : nullptr, scratch + rows * qc0, (size_t)(rows * qn), 8 /* ncclDouble */, (int)q, comm, st);
+        // (sendbuff is read on the root only; the other ranks pass their receive slot, a valid device pointer, not NULL)
+        double* slot = scratch + rows * qc0;
+        e = r->broadcast(q == rank ? static_cast<const void*>(local) : static_cast<const void*>(slot), slot, (size_t)(rows * qn), 8 /* ncclDouble */, (int)q, comm, st);
     }
     const int e2 = r->group_end();
     if (e != 0 || e2 != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e ? e : e2) : "error");
+    return mi_mcmc_merge_shards(scratch, world, n_keep, d, C, all, stream);
+}
+
+// north_star: "a single RCCL all-gather over xGMI to collate draws_out".  Equal shards (every BASELINE split: 65 536 / 8, 2^20 / 8) are
+// exactly one ncclAllGather into the rank-major staging buffer, then the merge kernel puts every chain at its global index; ragged
+// shards fall back to the grouped broadcasts above.
+int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                            double* scratch, double* all, void* stream)
+{
+    if (!comm || !scratch || !all || world == 0 || rank >= world) return fail(MI_ERR_BAD_ARG, "allgather_draws: bad communicator / buffers / rank");
+    if (C % world != 0 || C == 0) return mi_mcmc_allgather_draws_ragged(comm, world, rank, local, n_keep, d, C, scratch, all, stream);
+    Rccl* r = rccl();
+    if (!r) return fail(MI_ERR_UNSUPPORTED, "allgather_draws: librccl.so could not be loaded");
+    if (!local) return fail(MI_ERR_BAD_ARG, "allgather_draws: local_draws is required for a non-empty shard");
+    const uint64_t per = n_keep * d * (C / world);
+    const int e = r->allgather(local, scratch, (size_t)per, 8 /* ncclDouble */, comm, static_cast<hipStream_t>(stream));
+    if (e != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e) : "error");
     return mi_mcmc_merge_shards(scratch, world, n_keep, d, C, all, stream);
 }
 

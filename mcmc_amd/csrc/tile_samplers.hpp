@@ -1,0 +1,300 @@
+// tile_samplers.hpp -- mcmc::hmc / mcmc::mala for USER-DEFINED targets on the tiled (MFMA-layout) engine: the draw loops of
+// hmc_dense.hpp / mala_dense.hpp with the gradient behind a compile-time policy instead of the built-in dense mat-vec.
+//
+// The reference takes the target as a callback (ref: include/mcmc/hmc.hpp:42-48: fp_t (const ColVec_t& vals, ColVec_t* grad_out,
+// void* data)).  Its device form at the dimensions this engine is built for is a TILE functor: one call evaluates value and gradient
+// for the 16 chains of a wavefront, whose vectors sit in registers in the MFMA B / D lane layout
+//     lane l, register s  <->  dimension 4 s + (l >> 4) of chain (l & 15),      s = 0 .. NS - 1,  NS = 4 NT,  d <= 16 NT
+// (hmc_dense.hpp: the D layout of a 16 x 16 x 4 fp64 MFMA tile is the B layout of the next product, so a dense mat-vec maps vectors
+// in this layout to vectors in this layout with no cross-lane traffic).  include/mi_mcmc_tile_target.hpp is the user-facing side.
+//
+//   struct T {
+//       static constexpr int NT = 8;                                   // 1, 2, 4 or 8
+//       static constexpr int WPB = 8;                                  // optional: waves per workgroup, 4 (default) or 8
+//       size_t lds_doubles() const;                                    // host: LDS the target wants (its matrices in fragment order)
+//       __device__ void stage(double* lds) const;                      // once per workgroup, every thread; a barrier follows
+//       __device__ void grad_tile(const double* lds, const double (&theta)[4 * NT], double (&grad)[4 * NT], double& value, bool want_value) const;
+//   };
+// grad_tile returns the gradient and, when want_value (a compile-time constant at every call site: the leapfrog loop needs the value
+// only after its last step), the log kernel (the same bits in the four lanes of a chain: reduce with mi::dot4); padding
+// dimensions (>= d) hold zeros on entry and must get a zero gradient.  Arithmetic is the user's statement: a host function with the
+// same operation order, handed to the oracle as the reference's callback, reproduces the device draws bit for bit
+// (examples/user_tile_target.hip, tests/test_user_tile_target.py).
+//
+// The reference's dense `inv_precond_matrix * mntm` / `precond_matrix * grad_obj` (identity here: no precond_mat, no bounds on this
+// route) are applied element-wise with the explicit NaN rule of hmc_dense.hpp (dense_product_poison), so the non-finite regime needs
+// no replay on this route.
+#pragma once
+
+#include <type_traits>
+
+#include "hmc_dense.hpp"
+
+namespace mi {
+
+struct TileParams {
+    uint32_t d;
+    uint64_t C, chain0;
+    double* theta;          // [d][C] in/out
+    double* wsave;          // [n_tiles][3][NS][64]: last accepted theta and gradient
+    double* draws;          // [n_keep][d][C] or nullptr
+    uint64_t* n_accept;
+    uint64_t* n_leap;
+    uint64_t seed;
+    uint32_t n_burnin, n_keep, n_leap_steps, draw0;
+    double eps;             // step_size
+    double s2, rs, cons_term, log_det;      // mala: eps^2, 1 / eps^2, -d log(2 pi) / 2, LOG_DET(eps^2 I) (host, the oracle's order)
+};
+
+template <class T, class = void> struct tile_wpb_of { static constexpr int value = 4; };
+template <class T> struct tile_wpb_of<T, std::void_t<decltype(T::WPB)>> { static constexpr int value = T::WPB; };
+template <class T> constexpr int tile_wpb() { return tile_wpb_of<T>::value; }
+
+// x . (D x) for a diagonal D applied as the dense product it is in the reference (dg == 1: the identity; else the constant dg on
+// the diagonal): the element-wise sum unless an entry of x is non-finite -- then every OTHER row of D x is NaN (0 * inf), and so is
+// the sum whenever the chain has a second dimension.  The rare branch forms the poisoned product literally.
+template <int NS>
+__device__ __forceinline__ double diag_quadratic(const double (&x)[NS], double dg, int j, uint32_t d)
+{
+    double q = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) q = dfma(x[s], dg * x[s], q);
+    q = q + __shfl_xor(q, 32);
+    q = q + __shfl_xor(q, 16);
+    if (__ballot(!is_finite(q)) != 0ull) {
+        double y[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) y[s] = dg * x[s];
+        dense_product_poison<NS>(x, y, j, d);
+        double q2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) q2 = dfma(x[s], y[s], q2);
+        q2 = q2 + __shfl_xor(q2, 32);
+        q2 = q2 + __shfl_xor(q2, 16);
+        q = q2;
+    }
+    return q;
+}
+
+// mcmc::hmc (ref: src/hmc.cpp:155-205), identity preconditioner, no bounds
+template <class T, int WPB>
+__global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_tile_kernel(const TileParams prm, const T tgt)
+{
+    constexpr int NT = T::NT, NS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_t[];
+    tgt.stage(lds_t);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 4;
+    const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
+    const bool live = cl < prm.C;
+    const uint64_t cld = live ? cl : prm.C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps;
+    const size_t lane_off = (size_t)j * C + cld;
+    double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)3 * NS * 64) + lane;
+    auto ws_group = [&](int k) -> double* {             // opaque base per group of 8 slices (hmc_dense.hpp: why)
+        double* b = ws_wave + (size_t)(k & ~7) * 64;
+        asm volatile("" : "+v"(b));
+        return b + (k & 7) * 64;
+    };
+    double th[NS], pm[NS], g[NS];
+    double val;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dim = 4 * s + j;
+        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];
+        th[s] = (dim < d) ? v : 0.0;
+    }
+    tgt.grad_tile(lds_t, th, g, val, true);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { *ws_group(s) = th[s]; *ws_group(NS + s) = g[s]; }
+    }
+    double prev_U = -val;                               // hmc.cpp:140
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const uint32_t L = prm.n_leap_steps;
+    auto kinetic = [&]() __attribute__((always_inline)) -> double {       // p . (I p) / 2 (:160,184)
+        return diag_quadratic<NS>(pm, 1.0, j, d) / 2.0;
+    };
+    auto drift = [&]() __attribute__((always_inline)) {                   // theta += eps * (I p) (:171): theta_i + eps * NaN where poisoned
+#pragma unroll
+        for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * pm[s];
+        dense_product_poison<NS>(pm, th, j, d);
+    };
+#pragma unroll 1
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+        for (int b = 0; b < NS / 2; ++b) {               // :156-158
+            double z0, z1;
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
+            pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
+            pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double prev_K = kinetic();
+        if (L > 0) {                                     // first half-step of step 0 (:167, :126: mntm + step * grad / 2)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (eps * g[s]) / 2.0;
+            drift();
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k + 1 < L; ++k) {
+            double unused;
+            tgt.grad_tile(lds_t, th, g, unused, false);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {               // second half-step of step k and first of step k + 1: the same gradient
+                const double t = (eps * g[s]) / 2.0;
+                pm[s] = pm[s] + t;
+                pm[s] = pm[s] + t;
+            }
+            drift();
+        }
+        if (L > 0) {
+            tgt.grad_tile(lds_t, th, g, val, true);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (eps * g[s]) / 2.0;
+        }
+        double prop_U = -val;                            // :178
+        if (!is_finite(prop_U)) prop_U = INF;            // :180-182
+        const double prop_K = kinetic();                 // :184
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;   // :188
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
+        const bool accept = z < det_exp(comp_val);       // :191
+        if (accept) {
+            prev_U = prop_U;
+            if (live) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { *ws_group(s) = th[s]; *ws_group(NS + s) = g[s]; }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { th[s] = *ws_group(s); g[s] = *ws_group(NS + s); }
+            val = -prev_U;                               // (n_leap_steps = 0: the value at the unchanged position)
+        }
+        if (draw >= prm.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            if (prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t dim = 4 * s + j;
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = th[s];
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t dim = 4 * s + j;
+            if (dim < d) prm.theta[(size_t)dim * C + cl] = th[s];
+        }
+        if (j == 0) {
+            if (prm.n_accept) prm.n_accept[cl] = n_acc;
+            if (prm.n_leap) prm.n_leap[cl] = (uint64_t)n_total * L;
+        }
+    }
+}
+
+// mcmc::mala (ref: src/mala.cpp:149-186, include/mcmc/mala.ipp:59-64, include/stats/dmvnorm.hpp:28-54), identity preconditioner, no
+// bounds: one evaluation per draw (at the proposal), the current gradient cached -- the reference's three gradient calls are
+// deterministic repeats (mala_dense.hpp)
+template <class T>
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_tile_kernel(const TileParams prm, const T tgt)
+{
+    constexpr int WPB = 4;                              // one wave per SIMD: four register-resident vectors per chain tile
+    constexpr int NT = T::NT, NS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_t[];
+    tgt.stage(lds_t);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 4;
+    const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
+    const bool live = cl < prm.C;
+    const uint64_t cld = live ? cl : prm.C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps, s2 = prm.s2, rs = prm.rs;
+    const size_t lane_off = (size_t)j * C + cld;
+    double th[NS], g[NS], tp[NS], gp[NS];
+    double val, valp;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dim = 4 * s + j;
+        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];
+        th[s] = (dim < d) ? v : 0.0;
+    }
+    tgt.grad_tile(lds_t, th, g, val, true);
+    double prev_LP = val;                               // mala.cpp:138
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    // mala_mean_fn (:123): v + eps^2 (I grad) / 2, the identity as the dense product it is
+    auto mean_of = [&](const double (&v)[NS], const double (&gr)[NS], double (&out)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) out[s] = v[s] + (s2 * gr[s]) / 2.0;
+        dense_product_poison<NS>(gr, out, j, d);         // v_i + (eps^2 NaN) / 2 where (I grad)_i is poisoned
+    };
+    // (x - mu)' INV(eps^2 I) (x - mu) (dmvnorm.hpp:37-39)
+    auto quad = [&](const double (&xv)[NS], const double (&mu)[NS]) __attribute__((always_inline)) -> double {
+        double xc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) xc[s] = xv[s] - mu[s];
+        return diag_quadratic<NS>(xc, rs, j, d);
+    };
+#pragma unroll 1
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        double mean_prev[NS];
+        mean_of(th, g, mean_prev);
+#pragma unroll
+        for (int b = 0; b < NS / 2; ++b) {               // proposal = mean + eps * (I z) (:150,159)
+            double z0, z1;
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
+            tp[2 * b] = mean_prev[2 * b] + eps * ((8u * b + j < d) ? z0 : 0.0);
+            tp[2 * b + 1] = mean_prev[2 * b + 1] + eps * ((8u * b + 4 + j < d) ? z1 : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tgt.grad_tile(lds_t, tp, gp, valp, true);
+        double prop_LP = valp;                           // :162
+        if (!is_finite(prop_LP)) prop_LP = -INF;         // :164-166
+        double mean_prop[NS];
+        mean_of(tp, gp, mean_prop);
+        const double da = prm.cons_term - 0.5 * (prm.log_det + quad(th, mean_prop));      // dmvnorm(prev | mu(prop))
+        const double db = prm.cons_term - 0.5 * (prm.log_det + quad(tp, mean_prev));      // dmvnorm(prop | mu(prev))
+        const double x = prop_LP - prev_LP + (da - db);
+        const double comp_val = (x < 0.01) ? x : 0.01;   // :170
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
+        const bool accept = z < det_exp(comp_val);       // :173
+        if (accept) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { th[s] = tp[s]; g[s] = gp[s]; }
+            prev_LP = prop_LP;
+        }
+        if (draw >= prm.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            if (prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t dim = 4 * s + j;
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = th[s];
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t dim = 4 * s + j;
+            if (dim < d) prm.theta[(size_t)(4 * s) * C + lane_off] = th[s];
+        }
+        if (j == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;
+    }
+}
+
+}  // namespace mi

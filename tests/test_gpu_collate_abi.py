@@ -39,7 +39,9 @@ def test_merge_shards_interleaves_ragged_rank_major_slabs(world, n_keep, d, Ct):
 
 
 @pytest.mark.gpu
-def test_allgather_draws_over_an_rccl_communicator_of_one_rank():
+@pytest.mark.parametrize("fn", ["mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged"])
+def test_allgather_draws_over_an_rccl_communicator_of_one_rank(fn):
+    """equal shards: one ncclAllGather; ragged: grouped broadcasts -- both forms, on the communicator a 1-GPU box can build"""
     import torch
     rccl = C.CDLL("librccl.so.1")
     comm = C.c_void_p(0)
@@ -49,9 +51,51 @@ def test_allgather_draws_over_an_rccl_communicator_of_one_rank():
     local = torch.randn((n_keep, d, Ct), dtype=torch.float64, device="cuda")
     scratch = torch.zeros(n_keep * d * Ct, dtype=torch.float64, device="cuda")
     out = torch.zeros((n_keep, d, Ct), dtype=torch.float64, device="cuda")
-    rc = mcmc_amd.lib().mi_mcmc_allgather_draws(comm, C.c_uint32(1), C.c_uint32(0), C.c_void_p(local.data_ptr()), C.c_uint64(n_keep), C.c_uint64(d),
+    rc = getattr(mcmc_amd.lib(), fn)(comm, C.c_uint32(1), C.c_uint32(0), C.c_void_p(local.data_ptr()), C.c_uint64(n_keep), C.c_uint64(d),
                                                C.c_uint64(Ct), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(0))
     assert rc == 0, mcmc_amd.lib().mi_mcmc_last_error().decode()
     torch.cuda.synchronize()
     assert torch.equal(out, local)
     rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
+def test_two_rccl_ranks_on_one_device_is_what_this_box_cannot_do():
+    """The N > 1 form of mi_mcmc_allgather_draws needs two GPUs: RCCL refuses two ranks of one communicator on the same device.  This
+    test records that fact on the box it runs on (so the claim 'never executed with two RCCL ranks' has a reason attached), and runs
+    the collective for real if the box does have two devices."""
+    import subprocess, sys, textwrap, os
+    import torch
+    code = textwrap.dedent("""
+        import os, sys, ctypes as C, torch, torch.distributed as dist
+        sys.path.insert(0, os.environ["MI_ROOT"])
+        import mcmc_amd
+        rank, world = int(os.environ["RANK"]), 2
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(rank % ndev)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", rank % ndev))
+            x = torch.full((4,), float(rank), device="cuda", dtype=torch.float64)
+            out = torch.empty(8, device="cuda", dtype=torch.float64)
+            dist.all_gather_into_tensor(out, x)
+            torch.cuda.synchronize()
+            print("RCCL2 ok", out.tolist())
+        except Exception as e:
+            print("RCCL2 refused:", type(e).__name__, str(e).replace("\n", " ")[:300])
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_ROOT=root, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "-c", code]
+    # torchrun has no -c: write the script next to the test output instead
+    path = "/tmp/mi_rccl2.py"
+    open(path, "w").write(code)
+    cmd[-2:] = [path]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RCCL2")]
+    print("\n".join(lines))
+    assert lines, out.stderr[-1500:]
+    if torch.cuda.device_count() >= 2:
+        assert all(l.startswith("RCCL2 ok") for l in lines)
+    else:
+        assert any("refused" in l for l in lines), "one device, two ranks: RCCL is expected to refuse (duplicate GPU)"
