@@ -155,6 +155,11 @@ int         mi_mcmc_device_count(void);
 typedef int (*mi_small_launch_fn)(int algo, const void* small_params, const void* target_pod, void* stream);
 int mi_mcmc_run_user_target(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
                             const mi_settings* settings, mi_chains* chains, void* stream);
+/* What MI_MCMC_DEFINE_TARGET calls: the same with the MI_MCMC_VERSION of the headers the target library was compiled against.  A
+ * target library instantiates engine kernels from those headers; one built against another version is refused (MI_ERR_BAD_ARG)
+ * instead of running kernels whose parameter struct may mean something else at the same size. */
+int mi_mcmc_run_user_target_v(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
+                              int header_version, const mi_settings* settings, mi_chains* chains, void* stream);
 /* The same for TILE targets (include/mi_mcmc_tile_target.hpp): value + gradient for 16 chains at once in the MFMA register layout,
  * d <= 16 nt, hmc (algo 0) and mala (1) with the identity precond_mat and no bounds.  wpb: waves per workgroup the target's kernels
  * are built for (4 or 8); lds_bytes: what the target stages; header_version: MI_MCMC_VERSION of the headers the target library was
@@ -170,7 +175,11 @@ int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_fre
 
 /* Blocking calls. `stream` is a hipStream_t (NULL = default stream); with mem == MI_MEM_DEVICE the
  * kernels are enqueued on it and the call returns after enqueueing (asynchronous), so inputs can be
- * resident in HBM and timed with events.  With MI_MEM_HOST buffers are staged and the call blocks. */
+ * resident in HBM and timed with events.  With MI_MEM_HOST buffers are staged and the call blocks.
+ * Also blocking with MI_MEM_DEVICE: every configuration that owns temporary device tables for the call -- settings.vals_bound or
+ * settings.precond_mat (bounds / preconditioner tables), a target given in host memory, and the runs that go to the literal kernels
+ * with such tables -- ends in a stream synchronisation before those tables are freed.  The plain configurations (no bounds, no
+ * precond_mat, target in device memory: every BASELINE config) do return after enqueueing. */
 int mi_mcmc_hmc_run (const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream);

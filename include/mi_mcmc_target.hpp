@@ -72,6 +72,6 @@ int user_target_launch(int algo, const void* small_params, const void* target_po
 #define MI_MCMC_DEFINE_TARGET(NAME, TARGET_T)                                                                             \
     extern "C" int NAME##_run(int algo, const TARGET_T* target, const mi_settings* settings, mi_chains* chains, void* stream) \
     {                                                                                                                     \
-        return mi_mcmc_run_user_target(algo, (uint64_t)TARGET_T::D, &mi::user_target_launch<TARGET_T>, target,            \
-                                       (uint64_t)sizeof(mi::SmallParams), settings, chains, stream);                      \
+        return mi_mcmc_run_user_target_v(algo, (uint64_t)TARGET_T::D, &mi::user_target_launch<TARGET_T>, target,          \
+                                         (uint64_t)sizeof(mi::SmallParams), MI_MCMC_VERSION, settings, chains, stream);   \
     }

@@ -805,6 +805,14 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
     return MI_OK;
 }
 
+int mi_mcmc_run_user_target_v(int algo, uint64_t d, mi_small_launch_fn launch, const void* target_pod, uint64_t small_params_bytes,
+                              int header_version, const mi_settings* settings, mi_chains* chains, void* stream)
+{
+    if (header_version != MI_MCMC_VERSION)
+        return fail(MI_ERR_BAD_ARG, "the target library was built against engine headers %#x, this library is %#x: rebuild it", header_version, MI_MCMC_VERSION);
+    return mi_mcmc_run_user_target(algo, d, launch, target_pod, small_params_bytes, settings, chains, stream);
+}
+
 int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed)
 {
     return ws_release(static_cast<hipStream_t>(stream), all_streams != 0, bytes_freed);
@@ -1099,11 +1107,13 @@ int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* set
         return MI_OK;
     };
     const uint64_t n_burnin = settings->n_burnin_draws;
-    const uint32_t n_parts = n_windows + 1;
+    if ((uint64_t)n_windows > settings->n_burnin_draws)
+        return fail(MI_ERR_BAD_ARG, "hmc (mass adapted): n_windows = %u exceeds n_burnin_draws = %llu (each re-estimation window needs a draw)", n_windows, (unsigned long long)settings->n_burnin_draws);
+    const uint64_t n_parts = (uint64_t)n_windows + 1;
     uint64_t done = 0;
     rc = estimate();                                     // from the spread of initial_vals
     if (rc) return rc;
-    for (uint32_t part = 0; part < n_parts; ++part) {
+    for (uint64_t part = 0; part < n_parts; ++part) {
         const bool last = part + 1 == n_parts;
         const uint64_t upto = last ? n_burnin : (n_burnin * (part + 1)) / n_parts;
         mi_settings s_ = *settings;
@@ -1120,6 +1130,11 @@ int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* set
         }
         done = upto;
         if (!last) { rc = estimate(); if (rc) return rc; }
+    }
+    if (chains->n_leapfrogs) {                           // every part's call reported its own count: the run's total is what the caller gets
+        const uint64_t total = (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps;
+        if (chains->mem == MI_MEM_DEVICE) { rc = fill_n_leap(chains->n_leapfrogs, C, total, st); if (rc) return rc; }
+        else for (uint64_t c = 0; c < C; ++c) chains->n_leapfrogs[c] = total;
     }
     if (mass_diag_out) std::memcpy(mass_diag_out, mass.data(), d * 8);
     return MI_OK;
@@ -1402,7 +1417,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_leap = sc.dev.n_leapfrogs;
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
-    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP;      // the first-generation kernel, same bits
+    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0;      // the first-generation kernel, same bits
     const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
 #ifdef MI_PROFILING
     DevBuf prof_buf;
@@ -1418,7 +1433,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         if (chains->draw0 <= settings->n_adapt_draws)
             return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
         if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
-        if (lockstep) return fail(MI_ERR_UNSUPPORTED, "nuts: the lock-step kernel does not continue runs");
+        // (the lock-step hint cannot be honoured for a continuation -- that kernel keeps no per-chain step size: as mi_mcmc.h promises for a
+        //  hint the request cannot take, it is ignored and the default kernel runs)
         prm.n_adapt = 0;
     }
     prm.max_depth = (uint32_t)settings->max_tree_depth;

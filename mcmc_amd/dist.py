@@ -84,7 +84,10 @@ def run_sharded(algo, kind, init_fn, n_chains_total, settings, runner=None, coll
         draws = None if draws is None else torch.from_numpy(np.ascontiguousarray(draws))
         n_accept = None if n_accept is None else torch.from_numpy(np.asarray(n_accept).astype(np.int64))
     if not collate or world == 1:
-        return (draws, n_accept) if engine else (draws.numpy(), n_accept.numpy())
+        if engine:
+            return draws, n_accept
+        # an empty shard (world_size > n_chains_total) hands back nothing rather than tripping over None
+        return (None if draws is None else draws.numpy()), (None if n_accept is None else n_accept.numpy())
 
     nccl = dist.get_backend(group) == "nccl"
     comm_dev = dev if (nccl and dev is not None) else torch.device("cpu")
@@ -95,6 +98,10 @@ def run_sharded(algo, kind, init_fn, n_chains_total, settings, runner=None, coll
     if draws is None:
         draws = torch.zeros((n_keep, d, 0), dtype=torch.float64, device=comm_dev)
         n_accept = torch.zeros(0, dtype=torch.int64, device=comm_dev)
+    if n_keep == 0:                     # nothing was kept: there is no slab to gather, only the accept counts
+        all_acc = _gather_ragged(n_accept, c_local, n_chains_total, world, group, comm_dev)
+        empty = torch.zeros((0, d, n_chains_total), dtype=torch.float64, device=comm_dev)
+        return (empty.to(dev), all_acc.to(dev)) if engine else (empty.numpy(), all_acc.numpy())
     all_draws = _gather_ragged(draws, c_local, n_chains_total, world, group, comm_dev)
     all_acc = _gather_ragged(n_accept, c_local, n_chains_total, world, group, comm_dev)
     if engine:
