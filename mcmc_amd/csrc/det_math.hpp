@@ -238,6 +238,17 @@ MI_HD double rng_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t 
 }
 
 // Box-Muller pair of one slot: z0 = r cos(2 pi u2), z1 = r sin(2 pi u2), r = sqrt(-2 log u1)
+MI_HD void rng_normal_pair_core(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, uint32_t stream, double& z0, double& z1)
+{
+    const u32x4 w = rng_block(seed, chain, draw, slot, stream);
+    const double u1 = u01(w.x, w.y);
+    const double u2 = u01(w.z, w.w);
+    const double r = __builtin_sqrt(-2.0 * det_log(u1));
+    double s, c;
+    det_sincos2pi(u2, s, c);
+    z0 = r * c;
+    z1 = r * s;
+}
 #ifdef MI_RNG_NOINLINE
 __attribute__((noinline))
 #endif
@@ -249,14 +260,35 @@ MI_HD void rng_normal_pair(uint64_t seed, uint64_t chain, uint32_t draw, uint32_
     // Philox round of every slot out of the draw loop (3 registers per slot), spills it, and reloads it from scratch per draw
     asm volatile("" : "+v"(slot));
 #endif
-    const u32x4 w = rng_block(seed, chain, draw, slot, stream);
-    const double u1 = u01(w.x, w.y);
-    const double u2 = u01(w.z, w.w);
-    const double r = __builtin_sqrt(-2.0 * det_log(u1));
-    double s, c;
-    det_sincos2pi(u2, s, c);
-    z0 = r * c;
-    z1 = r * s;
+    rng_normal_pair_core(seed, chain, draw, slot, stream, z0, z1);
+}
+
+// Two slots in one out-of-line call, results by value (four registers): the two Philox / log / sincos chains are independent, so
+// the scheduler interleaves them -- a Box-Muller pair is ~250 dependent operations, and a wave that walks them one chain at a time
+// waits out every result latency (the logistic kernels: 16 pairs per lane and draw with the matrix pipe idle).
+typedef double rng_double4 __attribute__((ext_vector_type(4)));
+__device__ __attribute__((noinline)) inline rng_double4 rng_normal_two_pairs(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot_a,
+                                                                             uint32_t slot_b, uint32_t stream)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(slot_a), "+v"(slot_b));
+#endif
+    double a0, a1, b0, b1;
+    rng_normal_pair_core(seed, chain, draw, slot_a, stream, a0, a1);
+    rng_normal_pair_core(seed, chain, draw, slot_b, stream, b0, b1);
+    return rng_double4{a0, a1, b0, b1};
+}
+typedef double rng_double8 __attribute__((ext_vector_type(8)));
+__device__ __attribute__((noinline)) inline rng_double8 rng_normal_four_pairs(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot_a,
+                                                                              uint32_t slot_step, uint32_t stream)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(slot_a));
+#endif
+    double z[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rng_normal_pair_core(seed, chain, draw, slot_a + (uint32_t)k * slot_step, stream, z[2 * k], z[2 * k + 1]);
+    return rng_double8{z[0], z[1], z[2], z[3], z[4], z[5], z[6], z[7]};
 }
 
 // The same with slot = base + j, j the lane's part of the slot (lane-varying, fixed for the whole kernel) made opaque BEFORE the

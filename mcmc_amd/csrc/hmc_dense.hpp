@@ -30,6 +30,10 @@
 #define MI_HMC_RNG_STAGED 0
 #endif
 
+#ifndef MI_HMC_RNG_PAIRS
+#define MI_HMC_RNG_PAIRS 1   // (2 measured: no difference, 100.8 ms both) Philox / Box-Muller chains the scheduler may interleave in the plain kernel's momentum draw
+#endif
+
 #ifndef MI_HMC_WPB
 #define MI_HMC_WPB 8     // waves per workgroup of the plain kernel (two per SIMD)
 #endif
@@ -509,7 +513,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                 pm[2 * b] = lds_ms[8 * b + j] * pm[2 * b];
                 pm[2 * b + 1] = lds_ms[8 * b + 4 + j] * pm[2 * b + 1];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (BOUNDED || MI_HMC_RNG_PAIRS == 1 || (b & 1)) __builtin_amdgcn_sched_barrier(0);   // plain kernel: two independent Philox / Box-Muller chains interleave
         }
         if constexpr (DENSE_M) {                        // p = L z (:158)
             double zz[NS];

@@ -329,8 +329,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     // non-finite regime: detected through the proposal densities (mala) / energies (hmc), the same bits in
-    // the four waves of a chain tile; the chain is flagged and replayed by literal.hpp instead of finished here
-    [[maybe_unused]] bool nf_seen = false;
+    // the four waves of a chain tile; the chain is flagged and replayed by literal.hpp instead of finished here.  The flag is bit 63
+    // of the accept counter: this kernel has no register to spare for a second loop-carried value (as a bool of its own it cost the
+    // d = 512 mala instantiation nine more spilled VGPRs).
+    constexpr uint64_t NF_BIT = 1ull << 63;
 
     constexpr int SB = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);   // slices per batch of workspace loads
     auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
@@ -380,16 +382,34 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                         for (int i = 0; i < SB; ++i) { be_n[i] = *st(0, s0 + SB + i); gr_n[i] = *st(1, s0 + SB + i); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#ifndef MI_LOGIT_RNG_GROUP
+#define MI_LOGIT_RNG_GROUP 2
+#endif
+                    constexpr int RG = (MI_LOGIT_RNG_GROUP < SB / 2) ? MI_LOGIT_RNG_GROUP : ((SB / 2 >= 4) ? 4 : 2);   // Philox slots per out-of-line call (det_math.hpp): independent chains the scheduler interleaves
+                    static_assert((RG == 2 || RG == 4) && (SB / 2) % RG == 0, "pairs are drawn RG at a time");
 #pragma unroll
-                    for (int m = 0; m < SB / 2; ++m) {
+                    for (int m = 0; m < SB / 2; m += RG) {
                         const int mm = s0 / 2 + m;
-                        double z0, z1;
+                        double zz[2 * RG];
                         const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * mm + j4);
-                        if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
-                        const double za = (dim_of(2 * mm) < d) ? z0 : 0.0;
-                        const double zb = (dim_of(2 * mm + 1) < d) ? z1 : 0.0;
-                        bp[2 * mm] = (be_c[2 * m] + (s2 * gr_c[2 * m]) / 2.0) + eps * za;           // :123, :159
-                        bp[2 * mm + 1] = (be_c[2 * m + 1] + (s2 * gr_c[2 * m + 1]) / 2.0) + eps * zb;
+                        if constexpr ((ablate & 64u) != 0) {
+#pragma unroll
+                            for (int h = 0; h < 2 * RG; ++h) zz[h] = (h & 1) ? -0.5 : 0.5;
+                        } else if constexpr (RG == 2) {
+                            const rng_double4 t4 = rng_normal_two_pairs(prm.seed, chain, draw + prm.draw0, slot, slot + 4u, STREAM_NORMAL);
+                            zz[0] = t4[0]; zz[1] = t4[1]; zz[2] = t4[2]; zz[3] = t4[3];
+                        } else {
+                            const rng_double8 t8 = rng_normal_four_pairs(prm.seed, chain, draw + prm.draw0, slot, 4u, STREAM_NORMAL);
+#pragma unroll
+                            for (int h = 0; h < 8; ++h) zz[h] = t8[h];
+                        }
+#pragma unroll
+                        for (int h = 0; h < RG; ++h) {
+                            const double za = (dim_of(2 * (mm + h)) < d) ? zz[2 * h] : 0.0;
+                            const double zb = (dim_of(2 * (mm + h) + 1) < d) ? zz[2 * h + 1] : 0.0;
+                            bp[2 * (mm + h)] = (be_c[2 * (m + h)] + (s2 * gr_c[2 * (m + h)]) / 2.0) + eps * za;           // :123, :159
+                            bp[2 * (mm + h) + 1] = (be_c[2 * (m + h) + 1] + (s2 * gr_c[2 * (m + h) + 1]) / 2.0) + eps * zb;
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -437,7 +457,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             if (!is_finite(pl)) pl = -INF;               // mala.cpp:164-166
             const double da = prm.cons_term - 0.5 * (prm.log_det + qv[0]);       // dmvnorm.hpp:41
             const double db = prm.cons_term - 0.5 * (prm.log_det + qv[1]);
-            nf_seen = nf_seen || !is_finite(da) || !is_finite(db);
+            if (!is_finite(da) || !is_finite(db)) n_acc |= NF_BIT;
             const double x = pl - prev_LP + (da - db);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
             const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :171
@@ -531,7 +551,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             double prop_U = -lp;                         // :178 (n_leap = 0: the value at the unchanged position)
             const bool u_nf = !is_finite(prop_U);
             if (u_nf) prop_U = INF;                      // :180-182
-            nf_seen |= u_nf | !is_finite(prop_K);
+            if (u_nf || !is_finite(prop_K)) n_acc |= NF_BIT;
             const double x = -(prop_U + prop_K) + (prev_U + prev_K);
             const double comp_val = (x < 0.01) ? x : 0.01;                       // :188
             const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :189
@@ -554,7 +574,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         if (blockIdx.x == 0 && threadIdx.x == 0 && prm.n_accept) { prm.n_accept[0] = clock64() - t0_clk; prm.n_accept[1] = wall_clock64() - t0_wall; }
         return;
     }
-    const bool replay = nf_seen && prm.nf_flag != nullptr;
+    const bool replay = (n_acc & NF_BIT) != 0 && prm.nf_flag != nullptr;
+    n_acc &= ~NF_BIT;
     if (live && replay && q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
     if (live && !replay) {
 #pragma unroll

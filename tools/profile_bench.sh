@@ -10,7 +10,7 @@ TAG=${1:-r2}; CFG=${2:-2}; shift 2 || true
 OUT=gpurun_out/prof_${TAG}_c$CFG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline $*"
+CMD="python bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --traffic none $*"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
