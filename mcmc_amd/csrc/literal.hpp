@@ -34,9 +34,12 @@ enum { LIT_ISO = 0, LIT_DIAG = 1, LIT_DENSE = 2, LIT_LOGISTIC = 3 };
 struct LitTarget {
     int kind;
     uint32_t d, n_rows;
-    const double* prec;      // LIT_DIAG: d precisions, prec[i * prec_stride]; LIT_DENSE: d*d row-major
+    const double* prec;      // LIT_DIAG: d precisions, prec[i * prec_stride]; LIT_DENSE: the precision TRANSPOSED, prec[k * d + i] = P[i][k]
+                             // (a workgroup forms row i in thread i: consecutive threads then read consecutive addresses; the fma
+                             // chain of a row still runs over k ascending)
     uint32_t prec_stride;    // LIT_DIAG: 1, or d + 1 when prec is the diagonal of a dense d*d matrix
-    const double* X;         // LIT_LOGISTIC: n_rows*d row-major
+    const double* X;         // LIT_LOGISTIC: n_rows*d row-major (X^T r: thread j walks the rows)
+    const double* Xt;        // LIT_LOGISTIC: the same matrix transposed, Xt[j * n_rows + r] (eta = X beta: thread r walks the columns)
     const double* y;
     int W;                   // strided fma chains of a dot product (4: the layout of the MFMA kernels)
     int nblk;                // > 1: dimension-blocked reductions, block size bs (the logistic kernels: 4 blocks of 16 NTQ)
@@ -58,7 +61,7 @@ struct LitParams {
     const int* btype;        // [d] 1 none, 2 lower, 3 upper, 4 both (determine_bounds_type.hpp:27-57); vals_bound only
     const double* lb;
     const double* ub;
-    int precond;             // 0 identity; 1 diagonal: m / m_sqrt / m_inv [d]; 2 dense: Mfull / Lchol / Minv, d*d row-major
+    int precond;             // 0 identity; 1 diagonal: m / m_sqrt / m_inv [d]; 2 dense: Mfull / Lchol / Minv, d*d TRANSPOSED (M_t[k * d + i] = M[i][k])
     const double* m;
     const double* m_sqrt;
     const double* m_inv;
@@ -67,7 +70,7 @@ struct LitParams {
     const double* Minv;
     // mala, unbounded: INV / LOG_DET of Sigma = eps^2 M are constants of the run, from the host (the oracle's operation order)
     const double* sinv_diag; // precond 0 / 1: [d] 1 / (eps^2 m_i) (nullptr: all equal rs)
-    const double* Sinv;      // precond 2: d*d row-major
+    const double* Sinv;      // precond 2: d*d TRANSPOSED
     double rs, log_det, cons_term;
     // nuts (nuts_settings_t, mcmc_structs.hpp:89-97): step_size in `eps` is the initial epsilon_bar
     uint32_t n_adapt, max_depth;
@@ -160,6 +163,16 @@ MI_HD void gemv(const Par& par, const double* A, const double* x, uint32_t d, do
         double acc = 0.0;
         const double* a = A + (size_t)i * d;
         for (uint32_t k = 0; k < d; ++k) acc = dfma(a[k], x[k], acc);
+        y[i] = acc;
+    }
+    par.sync();
+}
+// the same product from the TRANSPOSED matrix At[k * d + i] = A[i][k]: per row the identical k-ascending fma chain, coalesced reads
+MI_HD void gemv_t(const Par& par, const double* At, const double* x, uint32_t d, double* y)
+{
+    LIT_PFOR(i, d) {
+        double acc = 0.0;
+        for (uint32_t k = 0; k < d; ++k) acc = dfma(At[(size_t)k * d + i], x[k], acc);
         y[i] = acc;
     }
     par.sync();
@@ -344,7 +357,7 @@ MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, do
         return r;
     }
     case LIT_DENSE: {
-        gemv(par, t.prec, x, d, w);
+        gemv_t(par, t.prec, x, d, w);
         if (grad) { LIT_PFOR(i, d) grad[i] = -w[i]; par.sync(); }
         const double r = -0.5 * dot_b(t, x, w);
         par.sync();
@@ -356,9 +369,9 @@ MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, do
         double* term = rows + n;
         LIT_PFOR(r, n) {
             double acc = 0.0;
-            const double* xr = t.X + (size_t)r * d;
+            const double* xr = t.Xt + r;                 // X[r][j] = xr[j * n]
             if (t.nblk <= 1 || t.bs == 0) {
-                for (uint32_t j = 0; j < d; ++j) acc = dfma(xr[j], x[j], acc);
+                for (uint32_t j = 0; j < d; ++j) acc = dfma(xr[(size_t)j * n], x[j], acc);
             } else {
                 const int nch = t.eta_chains > 1 ? t.eta_chains : 1;
                 const uint32_t sub = t.bs / (uint32_t)nch;
@@ -368,7 +381,7 @@ MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, do
                         const uint32_t lo = (uint32_t)k * t.bs + (uint32_t)c * sub;
                         const uint32_t hi = (c == nch - 1) ? (uint32_t)(k + 1) * t.bs : lo + sub;
                         double h = 0.0;
-                        for (uint32_t j = lo; j < d && j < hi; ++j) h = dfma(xr[j], x[j], h);
+                        for (uint32_t j = lo; j < d && j < hi; ++j) h = dfma(xr[(size_t)j * n], x[j], h);
                         e = (c == 0) ? h : e + h;
                     }
                     acc = (k == 0) ? e : acc + e;
@@ -449,15 +462,15 @@ MI_HD double box_log_kernel(const Par& par, const LitParams& p, const Vecs& v, c
 // y = INV(precond) x, y = CHOL_LOWER(precond) x, y = precond x
 MI_HD void times_minv(const Par& par, const LitParams& p, const double* x, double* y)
 {
-    if (p.precond == 2) gemv(par, p.Minv, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_inv : nullptr, x, p.t.d, y);
+    if (p.precond == 2) gemv_t(par, p.Minv, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_inv : nullptr, x, p.t.d, y);
 }
 MI_HD void times_lchol(const Par& par, const LitParams& p, const double* x, double* y)
 {
-    if (p.precond == 2) gemv(par, p.Lchol, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_sqrt : nullptr, x, p.t.d, y);
+    if (p.precond == 2) gemv_t(par, p.Lchol, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m_sqrt : nullptr, x, p.t.d, y);
 }
 MI_HD void times_m(const Par& par, const LitParams& p, const double* x, double* y)
 {
-    if (p.precond == 2) gemv(par, p.Mfull, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m : nullptr, x, p.t.d, y);
+    if (p.precond == 2) gemv_t(par, p.Mfull, x, p.t.d, y); else diag_gemv(par, p.precond == 1 ? p.m : nullptr, x, p.t.d, y);
 }
 
 MI_HD void copy_vec(const Par& par, const double* a, double* b, uint32_t d) { LIT_PFOR(i, d) b[i] = a[i]; par.sync(); }
@@ -563,8 +576,8 @@ MI_HD void mala_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     if (vb) {                                               // precond_matrix / sqrt_precond_matrix as the dense matrices they are (mala.cpp:57-58)
         LIT_PFOR(e, dd) {
             const uint32_t i = (uint32_t)(e / d), j = (uint32_t)(e % d);
-            v.Pm[e] = p.precond == 2 ? p.Mfull[e] : (i == j ? (p.precond == 1 ? p.m[i] : 1.0) : 0.0);
-            v.SPm[e] = p.precond == 2 ? p.Lchol[e] : (i == j ? (p.precond == 1 ? p.m_sqrt[i] : 1.0) : 0.0);
+            v.Pm[e] = p.precond == 2 ? p.Mfull[(size_t)j * d + i] : (i == j ? (p.precond == 1 ? p.m[i] : 1.0) : 0.0);
+            v.SPm[e] = p.precond == 2 ? p.Lchol[(size_t)j * d + i] : (i == j ? (p.precond == 1 ? p.m_sqrt[i] : 1.0) : 0.0);
         }
         par.sync();
     }
@@ -599,7 +612,8 @@ MI_HD void mala_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     auto dmvnorm = [&](const double* x, const double* mu, const double* sinv, double log_det) -> double {
         LIT_PFOR(i, d) v.xc[i] = x[i] - mu[i];                                               // dmvnorm.hpp:37
         par.sync();
-        if (sinv) gemv(par, sinv, v.xc, d, v.tt);
+        if (sinv == v.Sinv && vb) gemv(par, sinv, v.xc, d, v.tt);                            // built this draw: row-major
+        else if (sinv) gemv_t(par, sinv, v.xc, d, v.tt);                                     // the host's constant INV(eps^2 M), transposed
         else if (p.sinv_diag) diag_gemv(par, p.sinv_diag, v.xc, d, v.tt);
         else {                                              // INV(eps^2 I) = diag(rs)
             const uint32_t n = count_nonfinite(v.xc, d);
@@ -724,8 +738,7 @@ MI_HD void rwmh_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
         if (p.precond == 2) {
             LIT_PFOR(i, d) {
                 double acc = 0.0;
-                const double* a = p.Lchol + (size_t)i * d;
-                for (uint32_t k = 0; k < d; ++k) acc = dfma(par_scale * a[k], v.z[k], acc);
+                for (uint32_t k = 0; k < d; ++k) acc = dfma(par_scale * p.Lchol[(size_t)k * d + i], v.z[k], acc);
                 v.tt[i] = acc;
             }
             par.sync();

@@ -19,10 +19,18 @@ struct LitPrep {
     std::vector<int> bt;
     std::vector<double> lb, ub;
     std::vector<double> m, m_sqrt, m_inv;     // precond 1
-    std::vector<double> Mfull, Lchol, Minv;   // precond 2 (row-major d*d)
+    std::vector<double> Mfull, Lchol, Minv;   // precond 2: d*d TRANSPOSED (what literal.hpp's gemv_t reads)
     std::vector<double> sinv_diag, Sinv;      // mala, unbounded
     double rs = 0.0, log_det = 0.0, cons_term = 0.0;
 };
+
+// out[c * rows + r] = in[r * cols + c]
+inline void lit_transpose(const double* in, size_t rows, size_t cols, std::vector<double>& out)
+{
+    out.resize(rows * cols);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) out[c * rows + r] = in[r * cols + c];
+}
 
 // algo: 0 hmc, 1 mala.  precond_mat: d*d row-major or nullptr.
 inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const double* lower, const double* upper,
@@ -48,9 +56,12 @@ inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const 
                 o.m[i] = v; o.m_sqrt[i] = __builtin_sqrt(v); o.m_inv[i] = 1.0 / v;
             }
         } else {
-            o.Mfull.assign(precond_mat, precond_mat + (size_t)d * d);
-            host_inverse(precond_mat, d, o.Minv);
-            host_cholesky_lower(precond_mat, d, o.Lchol);
+            std::vector<double> Minv, Lc;
+            host_inverse(precond_mat, d, Minv);
+            host_cholesky_lower(precond_mat, d, Lc);
+            lit_transpose(precond_mat, d, d, o.Mfull);
+            lit_transpose(Minv.data(), d, d, o.Minv);
+            lit_transpose(Lc.data(), d, d, o.Lchol);
         }
     }
     if (algo == 1) {
@@ -71,7 +82,9 @@ inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const 
         } else {
             std::vector<double> Sigma((size_t)d * d), Ls;
             for (size_t i = 0; i < (size_t)d * d; ++i) Sigma[i] = s2 * precond_mat[i];
-            host_inverse(Sigma.data(), d, o.Sinv);
+            std::vector<double> Sinv;
+            host_inverse(Sigma.data(), d, Sinv);
+            lit_transpose(Sinv.data(), d, d, o.Sinv);
             host_cholesky_lower(Sigma.data(), d, Ls);
             for (uint32_t i = 0; i < d; ++i) ld = ld + 2.0 * det_log(Ls[(size_t)i * d + i]);
         }

@@ -130,6 +130,8 @@ int ws_release(hipStream_t st, bool all_streams, uint64_t* freed)
 // per-stream cache.
 struct ReplayWs {
     uint32_t* flag = nullptr;     // [C + 1]
+    double* tbuf = nullptr;       // t_doubles: the target's matrix transposed (literal.hpp reads matrices column-major: coalesced)
+    size_t t_doubles = 0;
     double* work = nullptr;
     size_t stride = 0;            // doubles per workgroup
     unsigned n_wg = 0;
@@ -139,11 +141,12 @@ struct ReplayWs {
 ReplayWs replay_layout(size_t own_bytes, uint64_t C, uint32_t d, uint32_t n_rows, bool mala_bounded)
 {
     ReplayWs r;
+    r.t_doubles = ((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31;
     r.own_bytes = (own_bytes + 255) & ~(size_t)255;
     r.stride = mi::lit::lit_work_doubles(d, n_rows, mala_bounded);
     r.n_wg = (unsigned)std::min<uint64_t>(C, mala_bounded ? 128u : 512u);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
-    r.total_bytes = r.own_bytes + flag_bytes + (size_t)r.n_wg * r.stride * sizeof(double);
+    r.total_bytes = r.own_bytes + flag_bytes + (r.t_doubles + (size_t)r.n_wg * r.stride) * sizeof(double);
     return r;
 }
 int replay_bind(ReplayWs& r, void* base, uint64_t C, hipStream_t st)
@@ -151,22 +154,45 @@ int replay_bind(ReplayWs& r, void* base, uint64_t C, hipStream_t st)
     char* b = static_cast<char*>(base);
     r.flag = reinterpret_cast<uint32_t*>(b + r.own_bytes);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
-    r.work = reinterpret_cast<double*>(b + r.own_bytes + flag_bytes);
+    r.tbuf = reinterpret_cast<double*>(b + r.own_bytes + flag_bytes);
+    r.work = r.tbuf + r.t_doubles;
     HIP_TRY(hipMemsetAsync(r.flag, 0, (C + 1) * sizeof(uint32_t), st));
     return MI_OK;
 }
+// out[c * rows + r] = in[r * cols + c] on the device (small matrices: the d x d precision, the n x d design matrix)
+__global__ void transpose_small_kernel(const double* __restrict__ in, double* __restrict__ out, uint32_t rows, uint32_t cols)
+{
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = e / rows, r = e % rows;        // consecutive threads write consecutive addresses
+        out[e] = in[r * cols + c];
+    }
+}
+int transpose_on_device(const double* in, double* out, uint32_t rows, uint32_t cols, hipStream_t st)
+{
+    const size_t n = (size_t)rows * cols;
+    hipLaunchKernelGGL(transpose_small_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, st, in, out, rows, cols);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+
 // the Gaussian kinds as the literal kernels read them: ISO / DIAG are ELEMENT-WISE targets in the oracle (prec_i * theta_i), DENSE a
 // mat-vec.  P_dense: the d*d device matrix of the MFMA path (diagonal for ISO / DIAG), or nullptr with prec_vec (d values / nullptr)
-void lit_gauss_target(mi::lit::LitTarget& t, int kind, uint32_t d, const double* P_dense, const double* prec_vec)
+int lit_gauss_target(mi::lit::LitTarget& t, int kind, uint32_t d, const double* P_dense, const double* prec_vec, double* tbuf, hipStream_t st)
 {
     t = mi::lit::LitTarget{};
     t.d = d;
-    if (kind == MI_TARGET_GAUSS_DENSE) { t.kind = mi::lit::LIT_DENSE; t.prec = P_dense; }
+    if (kind == MI_TARGET_GAUSS_DENSE) {                 // the literal kernels read the precision transposed
+        t.kind = mi::lit::LIT_DENSE; t.prec = tbuf;
+        const int rc = transpose_on_device(P_dense, tbuf, d, d, st);
+        if (rc) return rc;
+    }
     else if (kind == MI_TARGET_GAUSS_DIAG) {
         t.kind = mi::lit::LIT_DIAG;
         if (P_dense) { t.prec = P_dense; t.prec_stride = d + 1; } else { t.prec = prec_vec; t.prec_stride = 1; }
     } else t.kind = mi::lit::LIT_ISO;
     mi::lit::lit_orders(t);
+    return MI_OK;
 }
 void lit_common(mi::lit::LitParams& p, const mi_settings* s, const mi_chains* dev_chains, const ReplayWs& r, bool all_chains)
 {
@@ -362,6 +388,9 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
     if (replay) {                                       // chains that reached the non-finite regime: replayed literally (literal.hpp)
         mi::lit::LitParams lp{};
         lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = prm.d; lp.t.n_rows = prm.n_rows; lp.t.X = X_dev; lp.t.y = y_dev;
+        rcw = transpose_on_device(X_dev, rp.tbuf, prm.n_rows, prm.d, st);      // eta = X beta reads X transposed (literal.hpp)
+        if (rcw) return rcw;
+        lp.t.Xt = rp.tbuf;
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
@@ -472,7 +501,7 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     if (algo == 2 && settings->max_tree_depth > (uint64_t)mi::lit::LIT_NUTS_MAX_DEPTH)
         return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented (2^%d leapfrog steps per draw)", (int)mi::lit::LIT_NUTS_MAX_DEPTH, (int)mi::lit::LIT_NUTS_MAX_DEPTH);
     mi::lit::LitParams lp{};
-    DevBuf t_a, t_b;                                     // staged target
+    DevBuf t_a, t_b, t_t;                                // staged target (and its transposed matrix)
     lp.t.d = (uint32_t)d;
     auto up = [&](DevBuf& b, const double* src, size_t n_doubles, const double** out) -> int {
         if (target->mem == MI_MEM_DEVICE) { *out = src; return MI_OK; }
@@ -493,12 +522,18 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
         if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
         lp.t.kind = mi::lit::LIT_DENSE;
         if ((rc = up(t_a, target->prec, d * d, &lp.t.prec))) return rc;
+        HIP_TRY(t_t.alloc(d * d * 8));                     // ... read transposed by the literal kernels
+        if ((rc = transpose_on_device(lp.t.prec, t_t.as<double>(), (uint32_t)d, (uint32_t)d, st))) return rc;
+        lp.t.prec = t_t.as<double>();
         break;
     case MI_TARGET_LOGISTIC:
         if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
         lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.n_rows = (uint32_t)target->n_rows;
         if ((rc = up(t_a, target->X, target->n_rows * d, &lp.t.X))) return rc;
         if ((rc = up(t_b, target->y, target->n_rows, &lp.t.y))) return rc;
+        HIP_TRY(t_t.alloc(target->n_rows * d * 8));
+        if ((rc = transpose_on_device(lp.t.X, t_t.as<double>(), (uint32_t)target->n_rows, (uint32_t)d, st))) return rc;
+        lp.t.Xt = t_t.as<double>();
         break;
     default: return fail(MI_ERR_UNSUPPORTED, "%s: target kind %d not implemented", who, target->kind);
     }
@@ -537,7 +572,7 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (t_a.p || t_b.p || ldev.any || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (t_a.p || t_b.p || t_t.p || ldev.any || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -918,7 +953,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         HIP_TRY(hipGetLastError());
         {   // chains that reached the non-finite regime: replayed literally (literal.hpp)
             mi::lit::LitParams lp{};
-            lit_gauss_target(lp.t, target->kind, (uint32_t)d, nullptr, prec_dev);
+            rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, nullptr, prec_dev, rp.tbuf, st);
+            if (rc) return rc;
             lit_common(lp, settings, &sc.dev, rp, false);
             if (diag_precond_elementwise) { lp.precond = 1; lp.m_sqrt = ms_d.as<double>(); lp.m_inv = mi_d.as<double>(); }
             rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
@@ -1036,7 +1072,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
                         : launched("hmc", mi::launch_hmc_gauss_few_chains(prm, shape, st));
         if (rc) return rc;
         mi::lit::LitParams lp{};                        // chains that reached the non-finite regime: replayed literally (literal.hpp)
-        lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr);
+        rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr, rp.tbuf, st);
+        if (rc) return rc;
         lit_common(lp, settings, &sc.dev, rp, false);
         rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
     }
@@ -1248,7 +1285,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         if (rc) return rc;
         rc = replay_bind(rp, lws.p, chains->n_chains, st);
         if (rc) return rc;
-        lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr);
+        rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr, rp.tbuf, st);
+        if (rc) return rc;
         lit_common(lp, settings, &sc.dev, rp, literal_only);
         mi::lit::LitPrep prep;
         mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,

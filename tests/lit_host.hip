@@ -16,7 +16,11 @@ extern "C" int lit_host_run(int algo, int kind, uint32_t d, uint32_t n_rows, con
     if (algo == 2 && max_depth > (uint32_t)LIT_NUTS_MAX_DEPTH) return 1;
     lit_prepare(algo, d, eps, vals_bound, lower, upper, precond_mat, pr);
     LitParams p{};
-    p.t.kind = kind; p.t.d = d; p.t.n_rows = n_rows; p.t.prec = prec; p.t.prec_stride = 1; p.t.X = X; p.t.y = y;
+    std::vector<double> prec_t, Xt;
+    if (kind == LIT_DENSE) lit_transpose(prec, d, d, prec_t);
+    if (kind == LIT_LOGISTIC) lit_transpose(X, n_rows, d, Xt);
+    p.t.kind = kind; p.t.d = d; p.t.n_rows = n_rows; p.t.prec = kind == LIT_DENSE ? prec_t.data() : prec; p.t.prec_stride = 1;
+    p.t.X = X; p.t.Xt = Xt.empty() ? nullptr : Xt.data(); p.t.y = y;
     lit_orders(p.t);
     p.C = C; p.chain0 = chain0; p.theta = theta; p.draws = draws; p.n_accept = n_accept; p.n_leap = n_leap;
     p.seed = seed; p.n_burnin = n_burnin; p.n_keep = n_keep; p.n_leap_steps = n_leap_steps; p.draw0 = draw0; p.eps = eps;
