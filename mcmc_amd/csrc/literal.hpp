@@ -75,6 +75,7 @@ struct LitParams {
     // nuts (nuts_settings_t, mcmc_structs.hpp:89-97): step_size in `eps` is the initial epsilon_bar
     uint32_t n_adapt, max_depth;
     double delta, gamma, t0, kappa;
+    uint32_t n_fp_steps;     // rmhmc (rmhmc_settings_t::n_fp_steps, mcmc_structs.hpp:105-119)
     double* step_out;        // [C] or nullptr: in (draw0 > 0: the adapted step sizes of the call before) / out (final step size)
     uint32_t* depth_trace;   // [n_total][C] or nullptr
     const uint32_t* flag;    // [C]: replay only the chains whose entry is non-zero; nullptr: every chain
@@ -87,11 +88,15 @@ struct LitParams {
 constexpr int LIT_NUTS_MAX_DEPTH = 30;   // the reference leaves max_tree_depth a free size_t; a tree of depth 30 is 2^30 leapfrog steps per draw
 constexpr int LIT_NUTS_FRAME_VECS = 6;    // new_draw_p, new_draw_pp, dummy_draw, dummy_mntm, edge_draw, edge_mntm (nuts.ipp:160-208)
 constexpr int LIT_NUTS_TOP_VECS = 12;
-MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded, uint32_t nuts_depth = 0, bool nuts = false)
+constexpr int LIT_RMHMC_MAX_D = 64;      // two d x d x d derivative cubes per workgroup
+constexpr int LIT_RMHMC_VECS = 10;
+constexpr int LIT_RMHMC_MATS = 10;
+MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded, uint32_t nuts_depth = 0, bool nuts = false, bool rmhmc = false)
 {
     const size_t dv = (size_t)d + 8;
     return 16 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0)
-         + (nuts ? ((size_t)LIT_NUTS_TOP_VECS + (size_t)LIT_NUTS_FRAME_VECS * (nuts_depth + 1)) * dv : 0);
+         + (nuts ? ((size_t)LIT_NUTS_TOP_VECS + (size_t)LIT_NUTS_FRAME_VECS * (nuts_depth + 1)) * dv : 0)
+         + (rmhmc ? (size_t)LIT_RMHMC_VECS * dv + 3 * ((size_t)n_rows + 8) + (size_t)LIT_RMHMC_MATS * d * d + 2 * (size_t)d * d * d : 0);
 }
 
 struct Par {
@@ -980,8 +985,199 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     store_outputs(par, p, c, v, n_acc, n_leap);
 }
 
+// ---- mcmc::internal::rmhmc_impl (rmhmc.cpp:30-287) with the built-in metric tensors (the oracle's orc_target_tensor): the constant
+// precision for the Gaussian kinds (zero derivative), the Fisher information X' Lambda X + I for the logistic target.
+// G: d*d row-major; dG (may be nullptr): d matrices dG/dvals_i.  lam: 3 n_rows doubles of scratch.
+MI_HD void target_tensor(const Par& par, const LitTarget& t, const double* x, double* G, double* dG, double* lam)
+{
+    const uint32_t d = t.d;
+    const size_t dd = (size_t)d * d;
+    if (t.kind != LIT_LOGISTIC) {
+        LIT_PFOR(e, dd) {
+            const uint32_t i = (uint32_t)(e / d), j = (uint32_t)(e % d);
+            G[e] = t.kind == LIT_DENSE ? t.prec[(size_t)j * d + i] : (i == j ? (t.kind == LIT_DIAG ? t.prec[(size_t)i * t.prec_stride] : 1.0) : 0.0);
+        }
+        if (dG) { for (size_t e = (size_t)par.tid; e < dd * d; e += (size_t)par.nth) dG[e] = 0.0; }
+        par.sync();
+        return;
+    }
+    // rows k ascending, one fma per row and entry; eta as ONE sequential chain over the dimensions (orc_target_tensor)
+    const uint32_t n = t.n_rows;
+    double* lm = lam; double* dl = lam + n;
+    LIT_PFOR(k, n) {
+        double eta = 0.0;
+        for (uint32_t j = 0; j < d; ++j) eta = dfma(t.Xt[(size_t)j * n + k], x[j], eta);
+        const double sg = sigmoid(eta);
+        const double l_ = sg * (1.0 - sg);
+        lm[k] = l_;
+        dl[k] = l_ * (1.0 - 2.0 * sg);
+    }
+    par.sync();
+    LIT_PFOR(e, dd) {
+        const uint32_t r = (uint32_t)(e / d), c = (uint32_t)(e % d);
+        double acc = 0.0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const double xx = t.X[(size_t)k * d + r] * t.X[(size_t)k * d + c];
+            acc = dfma(xx, lm[k], acc);
+        }
+        G[e] = (r == c) ? acc + 1.0 : acc;
+    }
+    if (dG) {
+        for (size_t e = (size_t)par.tid; e < dd * d; e += (size_t)par.nth) {
+            const uint32_t i = (uint32_t)(e / dd), r = (uint32_t)((e % dd) / d), c = (uint32_t)(e % d);
+            double acc = 0.0;
+            for (uint32_t k = 0; k < n; ++k) {
+                const double xx = t.X[(size_t)k * d + r] * t.X[(size_t)k * d + c];
+                acc = dfma(xx, dl[k] * t.X[(size_t)k * d + i], acc);
+            }
+            dG[e] = acc;
+        }
+    }
+    par.sync();
+}
+
+MI_HD void rmhmc_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+{
+    const uint32_t d = p.t.d;
+    const size_t dd = (size_t)d * d, dv = (size_t)d + 8;
+    const Vecs v = carve(wk, d, p.t.n_rows, false);
+    double* q = wk + 16 * dv + 2 * ((size_t)p.t.n_rows + 8);
+    double* const new_mntm = q; q += dv; double* const prop_mntm = q; q += dv; double* const prop_draw = q; q += dv; double* const incr = q; q += dv;
+    double* const tmpv = q; q += dv; double* const gobj = q; q += dv; double* const av = q; q += dv; double* const bv = q; q += dv;
+    double* const jd = q; q += dv; double* const jg = q; q += dv;
+    double* const lam = q; q += 3 * ((size_t)p.t.n_rows + 8);
+    double* const new_tensor = q; q += dd; double* const prev_tensor = q; q += dd; double* const inv_new = q; q += dd; double* const inv_prev = q; q += dd;
+    double* const L = q; q += dd; double* const S = q; q += dd; double* const Tn = q; q += dd; double* const T = q; q += dd; double* const ga = q; q += dd;
+    q += dd;
+    double* const new_deriv = q; q += dd * d; double* const prev_deriv = q;
+    const uint64_t chain = p.chain0 + c;
+    const double step = p.eps;
+    const bool vb = p.vals_bound != 0;
+    auto copy_n = [&](const double* a, double* b, size_t n) { for (size_t e = (size_t)par.tid; e < n; e += (size_t)par.nth) b[e] = a[e]; par.sync(); };
+    // box_tensor_fn (rmhmc.cpp:152-164)
+    auto box_tensor = [&](const double* vals, double* G, double* dG) {
+        if (vb) {
+            LIT_PFOR(i, d) v.vi[i] = lit_inv_transform(vals[i], p.btype[i], p.lb[i], p.ub[i]);
+            par.sync();
+            target_tensor(par, p.t, v.vi, G, dG, lam);
+        } else target_tensor(par, p.t, vals, G, dG, lam);
+    };
+    // mntm_update_fn (rmhmc.cpp:99-150): out = step [J] grad_obj / 2,
+    //   grad_obj(i) = -grad(i) + 0.5 (trace(T_i) - dot(T_i' p, Ginv p)),  T_i = Ginv dG_i
+    auto mntm_increment = [&](const double* pos, const double* mntm, const double* Ginv, const double* dG, double* out) {
+        if (vb) {
+            LIT_PFOR(i, d) v.vi[i] = lit_inv_transform(pos[i], p.btype[i], p.lb[i], p.ub[i]);      // :107
+            par.sync();
+            (void)target_eval(par, p.t, v.vi, v.grad, v.w, v.rows);                                // :108
+        } else (void)target_eval(par, p.t, pos, v.grad, v.w, v.rows);                               // :131
+        gemv(par, Ginv, mntm, d, bv);                                                              // b = Ginv p
+        for (uint32_t i = 0; i < d; ++i) {
+            matmul(par, Ginv, dG + (size_t)i * dd, d, T);
+            LIT_PFOR(j, d) {                                                                       // a = T' p
+                double acc = 0.0;
+                for (uint32_t k = 0; k < d; ++k) acc = dfma(T[(size_t)k * d + j], mntm[k], acc);
+                av[j] = acc;
+            }
+            par.sync();
+            double tr = 0.0, dp = 0.0;
+            for (uint32_t j = 0; j < d; ++j) tr = tr + T[(size_t)j * d + j];
+            for (uint32_t j = 0; j < d; ++j) dp = dfma(av[j], bv[j], dp);
+            par.sync();
+            if (par.tid == 0) gobj[i] = -v.grad[i] + 0.5 * (tr - dp);
+        }
+        par.sync();
+        if (vb) {
+            LIT_PFOR(i, d) jd[i] = lit_inv_jacobian(pos[i], p.btype[i], p.lb[i], p.ub[i]);         // :121
+            par.sync();
+            diag_gemv(par, jd, gobj, d, jg);
+            LIT_PFOR(i, d) out[i] = (step * jg[i]) / 2.0;                                          // :129
+        } else {
+            LIT_PFOR(i, d) out[i] = (step * gobj[i]) / 2.0;                                        // :145
+        }
+        par.sync();
+    };
+    auto quad_half = [&](const double* Ginv, const double* mntm) -> double {                       // p' Ginv p / 2 (:211,253)
+        gemv(par, Ginv, mntm, d, tmpv);
+        double k = 0.0;
+        for (uint32_t i = 0; i < d; ++i) k = dfma(mntm[i], tmpv[i], k);
+        par.sync();
+        return k / 2.0;
+    };
+    LIT_PFOR(i, d) {
+        const double x = p.theta[(size_t)i * p.C + c];
+        v.prev[i] = vb ? lit_transform(x, p.btype[i], p.lb[i], p.ub[i]) : x;                      // :170-172
+    }
+    par.sync();
+    copy_vec(par, v.prev, v.cur, d);
+    box_tensor(v.cur, new_tensor, new_deriv);                                                      // :187
+    copy_n(new_tensor, prev_tensor, dd);
+    inverse(par, new_tensor, d, ga, inv_new);                                                      // :190
+    copy_n(inv_new, inv_prev, dd);
+    copy_n(new_deriv, prev_deriv, dd * d);
+    const double cons_term = 0.5 * (double)d * LIT_LOG_2PI;                                        // :195
+    chol_lower(par, new_tensor, d, L);
+    double prev_U = cons_term - box_log_kernel(par, p, v, v.prev) + 0.5 * log_det_from_chol(L, d); // :197
+    par.sync();
+    uint64_t n_acc = 0, n_leap = 0;
+    const uint32_t n_total = p.n_burnin + p.n_keep;
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+        normal_vec(par, p, chain, draw + p.draw0, v.z);                                            // :207
+        chol_lower(par, prev_tensor, d, L);
+        gemv(par, L, v.z, d, new_mntm);                                                            // :209
+        const double prev_K = quad_half(inv_prev, new_mntm);                                       // :211
+        copy_vec(par, v.prev, v.cur, d);                                                           // :213
+        for (uint32_t k = 0; k < p.n_leap_steps; ++k) {
+            copy_vec(par, new_mntm, prop_mntm, d);
+            for (uint32_t kk = 0; kk < p.n_fp_steps; ++kk) {                                       // :220-222
+                mntm_increment(v.cur, prop_mntm, inv_prev, prev_deriv, incr);
+                LIT_PFOR(i, d) prop_mntm[i] = new_mntm[i] + incr[i];
+                par.sync();
+            }
+            copy_vec(par, prop_mntm, new_mntm, d);                                                 // :224
+            copy_vec(par, v.cur, prop_draw, d);                                                    // :228
+            for (uint32_t kk = 0; kk < p.n_fp_steps; ++kk) {                                       // :231-235
+                box_tensor(prop_draw, Tn, nullptr);
+                inverse(par, Tn, d, ga, inv_new);
+                LIT_PFOR(e, dd) S[e] = inv_prev[e] + inv_new[e];
+                par.sync();
+                gemv(par, S, new_mntm, d, tmpv);
+                LIT_PFOR(i, d) prop_draw[i] = v.cur[i] + (0.5 * step) * tmpv[i];
+                par.sync();
+            }
+            copy_vec(par, prop_draw, v.cur, d);                                                    // :237
+            box_tensor(v.cur, new_tensor, new_deriv);                                              // :239
+            inverse(par, new_tensor, d, ga, inv_new);                                              // :240
+            mntm_increment(v.cur, new_mntm, inv_new, new_deriv, incr);                             // :244
+            LIT_PFOR(i, d) new_mntm[i] = new_mntm[i] + incr[i];
+            par.sync();
+            n_leap++;
+        }
+        chol_lower(par, new_tensor, d, L);
+        double prop_U = cons_term - box_log_kernel(par, p, v, v.cur) + 0.5 * log_det_from_chol(L, d);   // :247
+        par.sync();
+        if (!is_finite(prop_U)) prop_U = INF;                                                      // :249-251
+        const double prop_K = quad_half(inv_new, new_mntm);                                        // :253
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;                                             // :257
+        const double u = rng_uniform(p.seed, chain, draw + p.draw0, 0u);                           // :258
+        const bool accept = u < det_exp(comp_val);                                                 // :260
+        if (accept) {
+            copy_vec(par, v.cur, v.prev, d);
+            prev_U = prop_U;
+            copy_n(new_tensor, prev_tensor, dd);
+            copy_n(inv_new, inv_prev, dd);
+            copy_n(new_deriv, prev_deriv, dd * d);
+        }
+        if (draw >= p.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            store_row(par, p, c, draw - p.n_burnin, v.prev);
+        }
+    }
+    store_outputs(par, p, c, v, n_acc, n_leap);
+}
+
 #if defined(__HIPCC__)
-template <int ALGO>     // 0 hmc, 1 mala, 2 nuts, 3 rwmh
+template <int ALGO>     // 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc
 __global__ __launch_bounds__(256) void literal_kernel(const LitParams prm)
 {
     if (prm.any != nullptr && *prm.any == 0u) return;
@@ -990,7 +1186,7 @@ __global__ __launch_bounds__(256) void literal_kernel(const LitParams prm)
     for (uint64_t c = blockIdx.x; c < prm.C; c += gridDim.x) {
         if (prm.flag != nullptr && prm.flag[c] == 0u) continue;
         if (ALGO == 0) hmc_chain(par, prm, c, wk); else if (ALGO == 1) mala_chain(par, prm, c, wk);
-        else if (ALGO == 2) nuts_chain(par, prm, c, wk); else rwmh_chain(par, prm, c, wk);
+        else if (ALGO == 2) nuts_chain(par, prm, c, wk); else if (ALGO == 3) rwmh_chain(par, prm, c, wk); else rmhmc_chain(par, prm, c, wk);
         __syncthreads();
     }
 }

@@ -14,7 +14,8 @@ int launch_literal(int algo, const lit::LitParams& prm, unsigned n_wg, hipStream
     if (algo == 0) hipLaunchKernelGGL(lit::literal_kernel<0>, dim3(n_wg), dim3(256), 0, st, prm);
     else if (algo == 1) hipLaunchKernelGGL(lit::literal_kernel<1>, dim3(n_wg), dim3(256), 0, st, prm);
     else if (algo == 2) hipLaunchKernelGGL(lit::literal_kernel<2>, dim3(n_wg), dim3(256), 0, st, prm);
-    else hipLaunchKernelGGL(lit::literal_kernel<3>, dim3(n_wg), dim3(256), 0, st, prm);
+    else if (algo == 3) hipLaunchKernelGGL(lit::literal_kernel<3>, dim3(n_wg), dim3(256), 0, st, prm);
+    else hipLaunchKernelGGL(lit::literal_kernel<4>, dim3(n_wg), dim3(256), 0, st, prm);
     return (int)hipGetLastError();
 }
 

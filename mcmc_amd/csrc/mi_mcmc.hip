@@ -541,11 +541,14 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     StagedChains sc;
     rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
+    if (algo == 4 && d > (uint64_t)mi::lit::LIT_RMHMC_MAX_D)
+        return fail(MI_ERR_UNSUPPORTED, "rmhmc: d = %llu > %d is not implemented (two d x d x d derivative cubes per chain; O(d^4) per fixed-point step)",
+                    (unsigned long long)d, (int)mi::lit::LIT_RMHMC_MAX_D);
     const bool mala_bounded = algo == 1 && settings->vals_bound != 0;
     if (mala_bounded && d > 512) return fail(MI_ERR_UNSUPPORTED, "mala: vals_bound with d > 512 is not implemented (ten d x d matrices per workgroup)");
     ReplayWs rp;
-    rp.stride = mi::lit::lit_work_doubles((uint32_t)d, lp.t.n_rows, mala_bounded, (uint32_t)settings->max_tree_depth, algo == 2);
-    rp.n_wg = (unsigned)std::min<uint64_t>(C, mala_bounded ? 128u : 1024u);
+    rp.stride = mi::lit::lit_work_doubles((uint32_t)d, lp.t.n_rows, mala_bounded, (uint32_t)settings->max_tree_depth, algo == 2, algo == 4);
+    rp.n_wg = (unsigned)std::min<uint64_t>(C, (mala_bounded || algo == 4) ? 128u : 1024u);
     WsLease ws;
     rc = ws_get(st, (size_t)rp.n_wg * rp.stride * sizeof(double), ws);
     if (rc) return rc;
@@ -553,7 +556,8 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     lit_common(lp, settings, &sc.dev, rp, true);
     mi::lit::LitPrep prep;
     mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
-                         settings->upper_bounds, settings->precond_mat, prep);
+                         settings->upper_bounds, algo == 4 ? nullptr : settings->precond_mat, prep);     // (rmhmc has no precond_mat)
+    lp.n_fp_steps = (uint32_t)settings->n_fp_steps;
     LitDev ldev;
     rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
     if (rc) return rc;
@@ -1550,9 +1554,13 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     if (target->kind == MI_TARGET_LOGISTIC) {           // Fisher information + prior precision (small_targets.hpp), d <= 4
-        if (target->d > 4) return fail(MI_ERR_UNSUPPORTED, "rmhmc: the logistic target's Fisher metric is implemented for d <= 4 (d x d x d derivative cubes per lane)");
+        if (target->d > 4)                                // beyond the one-lane engine's d x d x d cubes per lane: one workgroup per chain (literal.hpp)
+            return run_literal("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
         return run_small_logistic("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
     }
+    // the Gaussian kinds: their (constant) precision is the metric, its derivative zero -- the oracle's orc_target_tensor; literal.hpp
+    if (target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG || target->kind == MI_TARGET_GAUSS_DENSE)
+        return run_literal("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));
     if (target->kind != MI_TARGET_NORMAL_MODEL)
         return fail(MI_ERR_UNSUPPORTED, "rmhmc: target kind %d has no built-in metric tensor on the device path (user targets: include/mi_mcmc_target.hpp)", target->kind);
     return run_small_normal_model("rmhmc", 4, target, settings, chains, static_cast<hipStream_t>(stream));

@@ -9,12 +9,12 @@ extern "C" int lit_host_run(int algo, int kind, uint32_t d, uint32_t n_rows, con
                             uint64_t seed, uint32_t n_burnin, uint32_t n_keep, uint32_t n_leap_steps, uint32_t draw0, double eps,
                             int vals_bound, const double* lower, const double* upper, const double* precond_mat,
                             uint32_t n_adapt, uint32_t max_depth, double delta, double gamma, double t0, double kappa,
-                            double* step_out, uint32_t* depth_trace)
+                            double* step_out, uint32_t* depth_trace, uint32_t n_fp_steps)
 {
     using namespace mi::lit;
     LitPrep pr;
     if (algo == 2 && max_depth > (uint32_t)LIT_NUTS_MAX_DEPTH) return 1;
-    lit_prepare(algo, d, eps, vals_bound, lower, upper, precond_mat, pr);
+    lit_prepare(algo, d, eps, vals_bound, lower, upper, algo == 4 ? nullptr : precond_mat, pr);
     LitParams p{};
     std::vector<double> prec_t, Xt;
     if (kind == LIT_DENSE) lit_transpose(prec, d, d, prec_t);
@@ -32,12 +32,14 @@ extern "C" int lit_host_run(int algo, int kind, uint32_t d, uint32_t n_rows, con
     p.Sinv = pr.Sinv.empty() ? nullptr : pr.Sinv.data();
     p.rs = pr.rs; p.log_det = pr.log_det; p.cons_term = pr.cons_term;
     p.n_adapt = n_adapt; p.max_depth = max_depth; p.delta = delta; p.gamma = gamma; p.t0 = t0; p.kappa = kappa;
-    p.step_out = step_out; p.depth_trace = depth_trace;
-    std::vector<double> work(lit_work_doubles(d, n_rows, algo == 1 && vals_bound != 0, max_depth, algo == 2));
+    p.step_out = step_out; p.depth_trace = depth_trace; p.n_fp_steps = n_fp_steps;
+    if (algo == 4 && d > (uint32_t)LIT_RMHMC_MAX_D) return 1;
+    std::vector<double> work(lit_work_doubles(d, n_rows, algo == 1 && vals_bound != 0, max_depth, algo == 2, algo == 4));
     const Par par{0, 1};
     for (uint64_t c = 0; c < C; ++c) {
         if (algo == 0) hmc_chain(par, p, c, work.data()); else if (algo == 1) mala_chain(par, p, c, work.data());
-        else if (algo == 2) nuts_chain(par, p, c, work.data()); else rwmh_chain(par, p, c, work.data());
+        else if (algo == 2) nuts_chain(par, p, c, work.data()); else if (algo == 3) rwmh_chain(par, p, c, work.data());
+        else rmhmc_chain(par, p, c, work.data());
     }
     return 0;
 }

@@ -36,11 +36,11 @@ def _f(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
 
 
-ALGO = {"hmc": 0, "mala": 1, "nuts": 2, "rwmh": 3}
+ALGO = {"hmc": 0, "mala": 1, "nuts": 2, "rwmh": 3, "rmhmc": 4}
 
 
 def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None, y=None, chain0=0, draw0=0,
-        lower=None, upper=None, precond=None, n_adapt=0, max_depth=10, delta=0.55, gamma=0.05, t0=10.0, kappa=0.75, step_in=None):
+        lower=None, upper=None, precond=None, n_adapt=0, max_depth=10, delta=0.55, gamma=0.05, t0=10.0, kappa=0.75, step_in=None, n_fp=5):
     """algo 'hmc' | 'mala' | 'nuts' | 'rwmh'; init [C, d].  Returns (draws [n_keep, d, C], dict(n_accept, n_leap, theta [C, d], eps, depth))."""
     init = _f(init)
     Cn, d = init.shape
@@ -59,6 +59,6 @@ def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None
                             C.c_uint32(n_keep), C.c_uint32(n_leap), C.c_uint32(draw0), C.c_double(eps),
                             C.c_int(0 if lower is None else 1), _p(lower), _p(upper), _p(precond),
                             C.c_uint32(n_adapt), C.c_uint32(max_depth), C.c_double(delta), C.c_double(gamma), C.c_double(t0),
-                            C.c_double(kappa), _p(step), depth.ctypes.data_as(C.POINTER(C.c_uint32)))
+                            C.c_double(kappa), _p(step), depth.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(n_fp))
     assert rc == 0
     return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy(), eps=step, depth=depth)

@@ -72,9 +72,31 @@ def test_rmhmc_resume_is_bit_identical_to_one_run():
 
 def test_rmhmc_rejects_what_it_does_not_implement():
     st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
-    with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.rmhmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, 3)), st)
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+    with pytest.raises(mcmc_amd.MiMcmcError) as e:        # two d x d x d cubes per chain: d <= 64 on the literal kernel
+        mcmc_amd.rmhmc(mcmc_amd.TARGET_GAUSS_ISO, np.zeros((4, 70)), st)
+    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED and "d x d x d" in str(e.value)
+
+
+@pytest.mark.parametrize("kind,d,bounded", [("dense", 6, False), ("iso", 5, True), ("diag", 9, False), ("dense", 20, False)])
+def test_rmhmc_gaussian_targets_with_their_constant_metric_run_on_the_literal_kernel(kind, d, bounded):
+    """ref: src/rmhmc.cpp:30-287 with G = the precision, dG = 0 (the oracle's orc_target_tensor for the Gaussian kinds): round 2 had no
+    metric for them on the device path; literal.hpp runs the sampler as written, one workgroup per chain"""
+    from mcmc_amd import synth
+    C = 9
+    prec = synth.dense_gaussian_precision(d, seed=3) if kind == "dense" else synth.ill_conditioned_diag(d, 30.0) if kind == "diag" else None
+    kg, ko = {"dense": (mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE), "diag": (mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG),
+              "iso": (mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)}[kind]
+    init = synth.initial_states(C, d, seed=7) * 0.4
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = np.full(d, -2.0), np.full(d, 2.5)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=11, n_burnin_draws=2, n_keep_draws=6, step_size=0.1, n_leap_steps=2, n_fp_steps=3, **kw)
+    g_draws, g = mcmc_amd.rmhmc(kg, init, st, prec=prec, chain0=2)
+    assert mcmc_amd.last_kernel() == "literal_kernel<4>"
+    s = orc.make_settings(seed=11, n_burnin=2, n_keep=6, n_leap=2, step=0.1, n_fp=3, W=4, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_RMHMC, orc.TargetSpec(ko, d, prec=prec, W=4), init, s, chain0=2)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws) and np.array_equal(g["n_leap"], o["n_leap"])
 
 
 # ---------------------------------------------------------------- beyond d = 2: Bayesian logistic regression, Fisher metric
@@ -101,10 +123,22 @@ def test_rmhmc_logistic_fisher_metric_bit_exact_vs_oracle(d, N, C, eps, n_leap, 
     assert 0 < int(g["n_accept"].sum())
 
 
-def test_rmhmc_logistic_beyond_4_dims_is_refused():
+@pytest.mark.parametrize("d,N,bounded", [(5, 30, False), (12, 40, False), (7, 25, True)])
+def test_rmhmc_logistic_beyond_4_dims_runs_on_the_literal_kernel(d, N, bounded):
+    """the Fisher metric X' Lambda X + I with its d x d x d derivative beyond the one-lane engine's d <= 4"""
     from mcmc_amd import synth
-    X, y = synth.logistic_problem(5, 30, seed=8)
-    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)
-    with pytest.raises(mcmc_amd.MiMcmcError) as e:
-        mcmc_amd.rmhmc(mcmc_amd.TARGET_LOGISTIC, np.zeros((4, 5)), st, X=X, y=y)
-    assert e.value.code == mcmc_amd.MI_ERR_UNSUPPORTED
+    C = 7
+    X, y = synth.logistic_problem(d, N, seed=8)
+    init = synth.initial_states(C, d, seed=7) * 0.3
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = np.full(d, -2.0), np.full(d, 2.5)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    st = mcmc_amd.default_settings(rng_seed_value=43, n_burnin_draws=2, n_keep_draws=6, step_size=0.05, n_leap_steps=2, n_fp_steps=3, **kw)
+    g_draws, g = mcmc_amd.rmhmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
+    assert mcmc_amd.last_kernel() == "literal_kernel<4>"
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=16, eta_chains=2)
+    s = orc.make_settings(seed=43, n_burnin=2, n_keep=6, n_leap=2, step=0.05, n_fp=3, W=4, blocks=4, block_size=16, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_RMHMC, t, init, s, chain0=5)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws)
+    assert 0 < int(g["n_accept"].sum())

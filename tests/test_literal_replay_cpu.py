@@ -12,11 +12,14 @@ from mcmc_amd import synth
 
 def _case(rng, algo, tgt, force_nonfinite):
     d = int(rng.choice([1, 2, 3, 5, 8, 12, 17])) if tgt != "logit" else int(rng.choice([3, 9, 17, 40, 70]))
+    if algo == "rmhmc": d = min(d, 9)                        # O(d^4) per fixed-point step
     C = int(rng.choice([1, 2, 5]))
     seed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
     burn, keep = int(rng.integers(0, 3)), int(rng.integers(1, 6))
     L = int(rng.integers(0, 5))
     depth, adapt = int(rng.integers(0, 6)), int(rng.integers(0, 4))
+    n_fp = int(rng.integers(0, 4))
+    if algo == "rmhmc": L = min(L, 2)
     eps = float(rng.choice([0.05, 0.3, 1.5, 40.0, 1e6, 1e160] if force_nonfinite else [0.01, 0.1, 0.5]))
     prec = X = y = None
     if tgt == "dense": prec, ko = synth.dense_gaussian_precision(d, seed=seed % 97), orc.TARGET_DENSE
@@ -36,7 +39,7 @@ def _case(rng, algo, tgt, force_nonfinite):
             kw.update(lower=lb, upper=ub); okw.update(lower=lb, upper=ub)
             fin = np.isfinite(init)
             init = np.where(fin, np.clip(init, -1.0, 1.5), init)
-        if rng.random() < 0.6:
+        if rng.random() < 0.6 and algo != "rmhmc":           # rmhmc has no precond_mat
             M = np.diag(rng.uniform(0.3, 3.0, d))
             if rng.random() < 0.5:
                 A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
@@ -46,17 +49,19 @@ def _case(rng, algo, tgt, force_nonfinite):
         dq = 16 if d <= 64 else 32
         tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
     t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
-    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, n_adapt=adapt, max_depth=depth, **okw)
-    o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=chain0)
-    l_draws, l = lit_host.run(algo, tgt, init, seed, burn, keep, L, eps, prec=prec, X=X, y=y, chain0=chain0, n_adapt=adapt, max_depth=depth, **kw)
+    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, n_adapt=adapt, max_depth=depth, n_fp=n_fp, **okw)
+    o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH, "rmhmc": orc.ALGO_RMHMC}[algo], t, init, s, chain0=chain0)
+    l_draws, l = lit_host.run(algo, tgt, init, seed, burn, keep, L, eps, prec=prec, X=X, y=y, chain0=chain0, n_adapt=adapt, max_depth=depth, n_fp=n_fp, **kw)
     desc = f"{algo} {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} depth={depth} adapt={adapt} opts={sorted(kw)}"
     ok = np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"])
+    if algo in ("hmc", "rmhmc"):
+        ok = ok and np.array_equal(l["n_leap"], o["n_leap"])
     if algo == "nuts":
         ok = ok and np.array_equal(l["n_leap"], o["n_leap"]) and np.array_equal(l["eps"], o["eps"], equal_nan=True)
     return ok, desc, bool(np.isnan(o_draws).any() or np.isinf(o_draws).any())
 
 
-@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh"])
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh", "rmhmc"])
 @pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
 def test_literal_replay_equals_the_oracle_in_the_finite_regime(algo, tgt):
     rng = np.random.default_rng([11, len(algo), len(tgt)])
@@ -65,7 +70,7 @@ def test_literal_replay_equals_the_oracle_in_the_finite_regime(algo, tgt):
         assert ok, desc
 
 
-@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh"])
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh", "rmhmc"])
 @pytest.mark.parametrize("tgt", ["dense", "iso", "diag", "logit"])
 def test_literal_replay_equals_the_oracle_in_the_non_finite_regime(algo, tgt):
     rng = np.random.default_rng([12, len(algo), len(tgt)])
