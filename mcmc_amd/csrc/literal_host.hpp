@@ -101,6 +101,12 @@ inline void lit_orders(LitTarget& t)
         t.nblk = 4; t.eta_chains = 2;
         t.bs = (t.d <= 64) ? 16u : (t.d <= 128) ? 32u : (t.d <= 256) ? 64u : 128u;
     }
+    // dense Gaussians with 128 < d <= 512 run on the LDS-streamed kernel too (logistic_lds.hpp, LOGIT_TARGET_DENSE): rows of P theta as
+    // one ascending fma chain (what every dense kernel does), dot products over its four dimension quarters
+    if (t.kind == LIT_DENSE && t.d > 128 && t.d <= 512) {
+        t.nblk = 4;
+        t.bs = (t.d <= 256) ? 64u : 128u;
+    }
 }
 
 }  // namespace lit

@@ -23,13 +23,18 @@ struct LogitParams {
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     double eps, s2, rs, cons_term, log_det;
     uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
+    double* xexch;          // dense Gaussian target only: [chain tile][4 NSQ][64] the position of an evaluation, shared by the tile's four waves
 };
 
 enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2 };   // RWMH: eps carries par_scale (identity cov_mat)
+// The target the streamed matrix belongs to.  DENSE: the Gaussian log K = -1/2 x'Px with 128 < d <= 512 -- "X" is P (n_rows = d,
+// X_dev = P row-major, y_dev = nullptr), the block images hold P transposed and the evaluation is the X^T r phase alone with r = x.
+enum { LOGIT_TARGET_LOGISTIC = 0, LOGIT_TARGET_DENSE = 1 };
 
 // bytes of device workspace a launch needs (block images of X, accepted state of every chain)
-size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C);
+size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC);
 // packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)
-int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st);
+int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st,
+                     int target = LOGIT_TARGET_LOGISTIC);
 
 }  // namespace mi

@@ -8,24 +8,26 @@ namespace mi {
 namespace {
 
 template <int NTQ>
-size_t ws_doubles(uint32_t NB, uint64_t C)
+size_t ws_doubles(uint32_t NB, uint64_t C, int target)
 {
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (C + 31) / 32;
-    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64;
+    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0);
 }
 
-template <int NTQ, int ALGO>
+template <int NTQ, int ALGO, int TARGET>
 int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (prm.C + 31) / 32;
     double* xp = static_cast<double*>(workspace);
     prm.state = xp + (size_t)prm.NB * G::XBUF_PAD;
+    prm.xexch = (TARGET == LOGIT_TARGET_DENSE) ? prm.state + n_wg * 8 * 2 * G::NSQ * 64 : nullptr;
     prm.Xp = xp;
-    hipLaunchKernelGGL(pack_logit_lds_kernel<NTQ>, dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
-    auto kern = logit_lds_kernel<NTQ, ALGO>;
-    note_kernel("logit_lds_kernel<%d, %d>", NTQ, ALGO);
+    hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, TARGET == LOGIT_TARGET_DENSE>), dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
+    auto kern = logit_lds_kernel<NTQ, ALGO, TARGET>;
+    if (TARGET == LOGIT_TARGET_DENSE) note_kernel("logit_lds_kernel<%d, %d, dense>", NTQ, ALGO);
+    else note_kernel("logit_lds_kernel<%d, %d>", NTQ, ALGO);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);
@@ -33,27 +35,32 @@ int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* wor
 }
 
 template <int ALGO>
-int launch_any(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
+int launch_any(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)
 {
-    if (prm.d <= 64) return launch<1, ALGO>(prm, X_dev, y_dev, workspace, st);
-    if (prm.d <= 128) return launch<2, ALGO>(prm, X_dev, y_dev, workspace, st);
-    if (prm.d <= 256) return launch<4, ALGO>(prm, X_dev, y_dev, workspace, st);
-    return launch<8, ALGO>(prm, X_dev, y_dev, workspace, st);
+    if (target == LOGIT_TARGET_DENSE) {                 // 128 < d <= 512 (smaller d: hmc_dense.hpp keeps P resident in LDS)
+        if (prm.d <= 256) return launch<4, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
+        return launch<8, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
+    }
+    if (prm.d <= 64) return launch<1, ALGO, LOGIT_TARGET_LOGISTIC>(prm, X_dev, y_dev, workspace, st);
+    if (prm.d <= 128) return launch<2, ALGO, LOGIT_TARGET_LOGISTIC>(prm, X_dev, y_dev, workspace, st);
+    if (prm.d <= 256) return launch<4, ALGO, LOGIT_TARGET_LOGISTIC>(prm, X_dev, y_dev, workspace, st);
+    return launch<8, ALGO, LOGIT_TARGET_LOGISTIC>(prm, X_dev, y_dev, workspace, st);
 }
 
 }  // namespace
 
-size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C)
+size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target)
 {
-    const size_t n = (d <= 64) ? ws_doubles<1>(NB, C) : (d <= 128) ? ws_doubles<2>(NB, C) : (d <= 256) ? ws_doubles<4>(NB, C) : ws_doubles<8>(NB, C);
+    const size_t n = (d <= 64) ? ws_doubles<1>(NB, C, target) : (d <= 128) ? ws_doubles<2>(NB, C, target)
+                   : (d <= 256) ? ws_doubles<4>(NB, C, target) : ws_doubles<8>(NB, C, target);
     return n * sizeof(double);
 }
 
-int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
+int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)
 {
-    return algo == LOGIT_HMC  ? launch_any<LOGIT_HMC>(prm, X_dev, y_dev, workspace, st)
-         : algo == LOGIT_RWMH ? launch_any<LOGIT_RWMH>(prm, X_dev, y_dev, workspace, st)
-                              : launch_any<LOGIT_MALA>(prm, X_dev, y_dev, workspace, st);
+    return algo == LOGIT_HMC  ? launch_any<LOGIT_HMC>(prm, X_dev, y_dev, workspace, st, target)
+         : algo == LOGIT_RWMH ? launch_any<LOGIT_RWMH>(prm, X_dev, y_dev, workspace, st, target)
+                              : launch_any<LOGIT_MALA>(prm, X_dev, y_dev, workspace, st, target);
 }
 
 }  // namespace mi

@@ -50,8 +50,9 @@ struct LogitGeo {
     __host__ __device__ static constexpr int xaddr(int row, int dim) { return (row >> 1) * RSP + (row & 1) * (DP + 16) + dim; }
 };
 
-// pack X (row-major n_rows x d) into per-block LDS images; zero padding outside
-template <int NTQ>
+// pack X (row-major n_rows x d) into per-block LDS images; zero padding outside.  TRANSPOSED (dense Gaussian, X = P, n_rows = d):
+// image row r holds column r of P, so that the X^T r phase with r = x yields P x; no labels.
+template <int NTQ, bool TRANSPOSED>
 __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double* __restrict__ y, uint32_t d, uint32_t n_rows,
                                       double* Xp)
 {
@@ -63,15 +64,15 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
     for (int i = threadIdx.x; i < 16 * G::DP; i += blockDim.x) {
         const int r = i / G::DP, j = i % G::DP;
         const uint32_t row = 16 * b + r;
-        if (row < n_rows && (uint32_t)j < d) img[G::xaddr(r, j)] = X[(size_t)row * d + j];
+        if (row < n_rows && (uint32_t)j < d) img[G::xaddr(r, j)] = TRANSPOSED ? X[(size_t)j * d + row] : X[(size_t)row * d + j];
     }
-    if (threadIdx.x < 16) {
+    if (!TRANSPOSED && threadIdx.x < 16) {
         const uint32_t row = 16 * b + threadIdx.x;
         img[G::XBUF + threadIdx.x] = row < n_rows ? y[row] : 0.0;        // labels in the image's tail padding
     }
 }
 
-template <int NTQ, int ALGO>
+template <int NTQ, int ALGO, int TARGET>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
 {
     using G = LogitGeo<NTQ>;
@@ -184,7 +185,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         if constexpr ((ablate & 2048u) != 0) { const uint64_t t = clock64(); prof[i] += t - tp; tp = t; }
     };
     uint32_t xbuf0 = 0;                 // buffer that holds block 0 when an evaluation starts
-    auto evaluate = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+    auto evaluate_logit = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
         double4_t gacc[NTQ];
         double llq = 0.0;
 #pragma unroll
@@ -311,6 +312,79 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         }
         lp = llq - 0.5 * v[0];
         lap(te, 9);
+    };
+
+
+    // Dense Gaussian (LOGIT_TARGET_DENSE): w = P x by the X^T r machinery alone.  The block images hold P transposed, so block b
+    // carries columns 16 b .. 16 b + 15 of P, its "row terms" are x on those dimensions -- slice 4 (b mod NTQ) + sp of wave b / NTQ --
+    // and every wave accumulates w on its own dimensions in registers across all blocks: element i of w is ONE fma chain over the
+    // columns in ascending order (what gauss_dense_grad of hmc_dense.hpp and the oracle's orc_gemv do).  x travels between the four
+    // waves of a tile through xexch (64 KiB per tile at d = 512: LDS is full of P), written once per evaluation; one barrier per
+    // block (the double buffer), none for an eta phase or an exchange of partial sums.  lp = -1/2 x.w, gout = -w.
+    auto evaluate_dense = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+        double4_t gacc[NTQ];
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        double* xq = prm.xexch + ((size_t)blockIdx.x * 2 + g) * ((size_t)4 * NSQ * 64) + lane;
+        asm volatile("" : "+v"(xq));
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) xq[(size_t)(q * NSQ + s) * 64] = x[s];
+        __syncthreads();                                 // x is visible to the tile's four waves; nobody still reads the exchange area
+        double r_cur[4], r_nxt[4];
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) r_cur[sp] = xq[(size_t)sp * 64];
+        constexpr bool prefetch = !(ablate & 8u);
+#pragma unroll 1
+        for (uint32_t b = 0; b < NB; ++b) {
+            const double* xb = Xs + ((xbuf0 + b) & 1u) * G::XBUF_PAD;
+            const uint32_t nblk = (b + 1 < NB) ? b + 1 : 0u;
+            const int nbuf = (int)((xbuf0 + b + 1) & 1u);
+            const uint32_t bn = (b + 1 < NB) ? b + 1 : b;
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) r_nxt[sp] = xq[(size_t)(4 * bn + sp) * 64];
+            const double* xg = xb + grad_off;
+            double g_cur[4], g_nxt[4];
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) g_cur[sp] = xg[2 * sp * RSP];
+#pragma unroll
+            for (int t = 0; t < NTQ; ++t) {
+                if (t + 1 < NTQ) {
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) g_nxt[sp] = xg[2 * sp * RSP + 16 * (t + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (prefetch) {
+#pragma unroll
+                    for (int i = (t * NP) / NTQ; i < ((t + 1) * NP) / NTQ; ++i) issue_piece(nblk, nbuf, i);
+                }
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[sp], r_cur[sp], gacc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp) g_cur[sp] = g_nxt[sp];
+            }
+            wait_loads();                           // block b+1 landed (this wave's pieces; r_nxt too) ...
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) r_cur[sp] = r_nxt[sp];
+            blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2
+        }
+        xbuf0 = (xbuf0 + NB) & 1u;
+        double v[2];
+        {
+            double a = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) a = dfma(x[s], gacc[s >> 2][s & 3], a);
+            a = a + __shfl_xor(a, 32);
+            a = a + __shfl_xor(a, 16);
+            v[0] = a; v[1] = 0.0;
+        }
+        exchange(v);
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) gout[s] = -gacc[s >> 2][s & 3];
+        lp = -0.5 * v[0];
+    };
+    auto evaluate = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+        if constexpr (TARGET == LOGIT_TARGET_DENSE) evaluate_dense(x, gout, lp); else evaluate_logit(x, gout, lp);
     };
 
     double bp[NSQ], gp[NSQ];            // position / proposal and its gradient (this wave's dims)

@@ -371,11 +371,11 @@ int fill_n_leap(uint64_t* dev_ptr, uint64_t n, uint64_t v, hipStream_t st)
 // LDS-staged logistic kernels (logistic_lds.hip): workspace from the per-stream cache, launch in their own translation unit
 int launched(const char* what, int hip_err);
 int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const double* y_dev, hipStream_t st,
-                 const mi_settings* settings, const mi_chains* dev_chains)
+                 const mi_settings* settings, const mi_chains* dev_chains, int lds_target = mi::LOGIT_TARGET_LOGISTIC)
 {
     WsLease base;
     const bool replay = algo != mi::LOGIT_RWMH;          // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
-    ReplayWs rp = replay_layout(mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C), prm.C, prm.d, prm.n_rows, false);
+    ReplayWs rp = replay_layout(mi::logit_lds_workspace_bytes(prm.d, prm.NB, prm.C, lds_target), prm.C, prm.d, prm.n_rows, false);
     int rcw = ws_get(st, replay ? rp.total_bytes : rp.own_bytes, base);
     if (rcw) return rcw;
     if (replay) {
@@ -383,18 +383,22 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         if (rcw) return rcw;
         prm.nf_flag = rp.flag;
     }
-    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st);
-    if (e != 0) return fail(MI_ERR_HIP, "logistic kernel launch: %s", hipGetErrorString((hipError_t)e));
+    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st, lds_target);
+    if (e != 0) return fail(MI_ERR_HIP, "LDS-streamed kernel launch: %s", hipGetErrorString((hipError_t)e));
     if (replay) {                                       // chains that reached the non-finite regime: replayed literally (literal.hpp)
         mi::lit::LitParams lp{};
-        lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = prm.d; lp.t.n_rows = prm.n_rows; lp.t.X = X_dev; lp.t.y = y_dev;
-        rcw = transpose_on_device(X_dev, rp.tbuf, prm.n_rows, prm.d, st);      // eta = X beta reads X transposed (literal.hpp)
+        rcw = transpose_on_device(X_dev, rp.tbuf, prm.n_rows, prm.d, st);      // eta = X beta resp. P x read the matrix transposed (literal.hpp)
         if (rcw) return rcw;
-        lp.t.Xt = rp.tbuf;
+        if (lds_target == mi::LOGIT_TARGET_DENSE) {
+            lp.t.kind = mi::lit::LIT_DENSE; lp.t.d = prm.d; lp.t.prec = rp.tbuf;
+        } else {
+            lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = prm.d; lp.t.n_rows = prm.n_rows; lp.t.X = X_dev; lp.t.y = y_dev;
+            lp.t.Xt = rp.tbuf;
+        }
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
-        return launched("logistic (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
+        return launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
     }
     return MI_OK;
 }
@@ -619,6 +623,50 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
     if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+// hmc / mala / rwmh on a dense Gaussian with 128 < d <= 512 (identity preconditioner / cov_mat, no bounds): P no longer fits into LDS
+// (hmc_dense.hpp), so it is streamed through LDS block by block like the design matrix of the logistic target --
+// logit_lds_kernel<., ., LOGIT_TARGET_DENSE> (logistic_lds.hpp).  settings->step_size is the leapfrog step resp. par_scale.
+int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    int rc;
+    const uint64_t d = target->d;
+    if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    mi::LogitParams q{};
+    q.d = (uint32_t)d; q.n_rows = (uint32_t)d; q.NB = (uint32_t)((d + 15) / 16);
+    q.C = chains->n_chains; q.chain0 = chains->chain0;
+    q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
+    q.seed = settings->rng_seed_value;
+    q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+    q.n_leap = (uint32_t)settings->n_leap_steps;
+    q.eps = settings->step_size;
+    q.draw0 = (uint32_t)chains->draw0;
+    if (algo == mi::LOGIT_MALA) {                        // dmvnorm's constants for Sigma = eps^2 I, as the oracle states them
+        const double s2 = settings->step_size * settings->step_size;
+        double log_det = 0.0;
+        const double lii = __builtin_sqrt(s2);
+        for (uint64_t i = 0; i < d; ++i) log_det = log_det + 2.0 * mi::det_log(lii);
+        q.s2 = s2; q.rs = 1.0 / s2; q.log_det = log_det;
+        q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
+    }
+    rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE);
+    if (rc) return rc;
+    rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
+                     algo == mi::LOGIT_HMC ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -889,6 +937,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     }
     // beyond d = 128 the tiled kernels serve separable targets without bounds (identity or diagonal precond_mat: hmc_diag.hpp);
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
+        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp)
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -1236,7 +1286,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
-    if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no tiled kernel beyond d = 128: literal.hpp
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
+        return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
+    if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
     const double* P_dev = nullptr;
@@ -1360,7 +1412,9 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
-    if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no tiled kernel beyond d = 128: literal.hpp
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
+        return run_dense_lds("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
+    if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
     const double* P_dev = nullptr;

@@ -312,6 +312,27 @@ static inline double orc_sigmoid(double eta)
     return e / (1.0 + e);
 }
 
+/* one row of a blocked mat-vec: ((e0 + e1) + e2) + ... with e_k the dot over dimension block k (block size bs), inside a block nch
+ * contiguous fma sub-chains summed left to right (the reduction order of logit_lds_kernel's eta, logistic_lds.hpp) */
+static double orc_row_dot_blocked(const double* x, const double* th, size_t d, int nblk, size_t bs, int eta_chains)
+{
+    const int nch = eta_chains > 1 ? eta_chains : 1;
+    const size_t sub = bs / (size_t)nch;
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        double e = 0.0;
+        for (int c = 0; c < nch; ++c) {
+            const size_t lo = (size_t)k * bs + (size_t)c * sub;
+            const size_t hi = (c == nch - 1) ? (size_t)(k + 1) * bs : lo + sub;
+            double h = 0.0;
+            for (size_t j = lo; j < d && j < hi; ++j) h = fma(x[j], th[j], h);
+            e = (c == 0) ? h : e + h;
+        }
+        acc = (k == 0) ? e : acc + e;
+    }
+    return acc;
+}
+
 double orc_target_kernel(const double* th, double* grad_out, void* data)
 {
     orc_target* t = (orc_target*)data;
@@ -352,22 +373,7 @@ double orc_target_kernel(const double* th, double* grad_out, void* data)
             const double* x = t->X + r * d;
             if (nblk <= 1 || bs == 0) {
                 for (size_t j = 0; j < d; ++j) acc = fma(x[j], th[j], acc);
-            } else {                     /* ((e0 + e1) + e2) + ...: e_k the eta of dimension block k; inside a block
-                                          * eta_chains contiguous fma sub-chains summed left to right */
-                const int nch = t->eta_chains > 1 ? t->eta_chains : 1;
-                const size_t sub = bs / (size_t)nch;
-                for (int k = 0; k < nblk; ++k) {
-                    double e = 0.0;
-                    for (int c = 0; c < nch; ++c) {
-                        const size_t lo = (size_t)k * bs + (size_t)c * sub;
-                        const size_t hi = (c == nch - 1) ? (size_t)(k + 1) * bs : lo + sub;
-                        double h = 0.0;
-                        for (size_t j = lo; j < d && j < hi; ++j) h = fma(x[j], th[j], h);
-                        e = (c == 0) ? h : e + h;
-                    }
-                    acc = (k == 0) ? e : acc + e;
-                }
-            }
+            } else acc = orc_row_dot_blocked(x, th, d, nblk, bs, t->eta_chains);
             eta[r] = acc;
             term[r] = t->y[r] * acc - orc_softplus(acc);
         }

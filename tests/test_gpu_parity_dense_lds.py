@@ -1,0 +1,70 @@
+"""GPU: dense Gaussian targets with 128 < d <= 512 (ref: src/hmc.cpp:155-205, src/mala.cpp:149-186, src/rwmh.cpp:123-151 --
+n_vals is unrestricted).  P does not fit into LDS beyond d = 128, so hmc / mala / rwmh stream it through LDS block by block on the matrix
+cores (mcmc_amd/csrc/logistic_lds.hpp, LOGIT_TARGET_DENSE).  Bit for bit against the oracle: rows of P x as one ascending fma chain,
+dot products over the kernel's four dimension quarters; chains that reach the non-finite regime are replayed literally."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+ALGO = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "rwmh": orc.ALGO_RWMH}
+
+
+def _blk(d):
+    return dict(blocks=4, block_size=64 if d <= 256 else 128)
+
+
+def _run(algo, d, C, eps, init, seed=3, burn=2, keep=5, L=4, chain0=0, draw0=0):
+    prec = synth.dense_gaussian_precision(d, seed=d % 89)
+    st = mcmc_amd.default_settings(rng_seed_value=seed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps)
+    g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=chain0)
+    kern = mcmc_amd.last_kernel()
+    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, **_blk(d))
+    o_draws, o = orc.run_many(ALGO[algo], orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)), init, s, chain0=chain0)
+    return g_draws, g, o_draws, o, kern
+
+
+@pytest.mark.parametrize("algo,eps", [("hmc", 0.04), ("mala", 0.06), ("rwmh", 0.03)])
+@pytest.mark.parametrize("d", [129, 192, 256, 257, 300, 512])
+def test_dense_gaussian_streamed_through_lds_equals_the_oracle(algo, eps, d):
+    C = 45                                              # one full workgroup of 32 chains + a ragged one
+    init = synth.initial_states(C, d, seed=d + 1) * 0.5
+    g_draws, g, o_draws, o, kern = _run(algo, d, C, eps, init, chain0=11)
+    assert kern.startswith("logit_lds_kernel<") and "dense" in kern, kern
+    assert 0 < o["n_accept"].sum()
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert np.array_equal(g["theta"], o_draws[-1])
+    if algo == "hmc":
+        assert np.array_equal(g["n_leap"], o["n_leap"])
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("d", [160, 512])
+def test_dense_gaussian_beyond_d128_in_the_non_finite_regime(algo, d):
+    """step sizes that blow chains up and initial values that are +-inf / NaN already: flagged by the streamed kernel, replayed literally"""
+    C = 40
+    init = synth.initial_states(C, d, seed=d) * 0.5
+    init[3] *= 1e200; init[7, 5] = np.inf; init[20, d - 1] = np.nan; init[33] *= 1e160
+    for eps in (0.05, 1e6):
+        g_draws, g, o_draws, o, kern = _run(algo, d, C, eps, init, keep=3, L=3)
+        assert np.array_equal(g["n_accept"], o["n_accept"]), eps
+        assert np.array_equal(g_draws, o_draws, equal_nan=True), eps
+        assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True), eps
+
+
+def test_dense_gaussian_beyond_d128_recovers_the_covariance():
+    """statistical check at d = 192: per-dimension variances of 4096 hmc chains against diag(P^-1)"""
+    d, C = 192, 4096
+    prec = synth.dense_gaussian_precision(d, seed=5)
+    cov = np.linalg.inv(prec)
+    rng = np.random.default_rng(1)
+    init = rng.multivariate_normal(np.zeros(d), cov, size=C)
+    st = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=30, n_keep_draws=1, n_leap_steps=8, step_size=0.15)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    v = g_draws[0].var(axis=1)                         # [d] over chains
+    assert np.all(np.abs(v / np.diag(cov) - 1.0) < 0.15)
+    assert g["n_accept"].mean() > 0.5

@@ -80,3 +80,20 @@ def test_literal_replay_equals_the_oracle_in_the_non_finite_regime(algo, tgt):
         assert ok, desc
         n_nonfinite += int(nf)
     assert n_nonfinite >= 8, f"the sweep is meant to reach the non-finite regime ({n_nonfinite} of 40 cases did)"
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala", "rwmh", "nuts"])
+@pytest.mark.parametrize("d", [129, 200, 256, 300, 512])
+def test_literal_dense_gaussian_uses_the_blocked_dot_order_between_128_and_512(algo, d):
+    """128 < d <= 512: the dense Gaussian runs on the LDS-streamed kernel (logistic_lds.hpp); its energies are summed over four dimension
+    quarters, and the literal replay of its flagged chains has to use that order."""
+    rng = np.random.default_rng([13, len(algo), d])
+    prec = synth.dense_gaussian_precision(d, seed=d % 97)
+    bs = 64 if d <= 256 else 128
+    for eps, scale in ((0.05, 1.0), (1e6, 1e3)):
+        init = synth.initial_states(2, d, seed=d) * scale
+        t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, blocks=4, block_size=bs)
+        s = orc.make_settings(seed=77, n_burnin=1, n_keep=3, n_leap=3, step=eps, W=4, hoist=1, n_adapt=2, max_depth=3, blocks=4, block_size=bs)
+        o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=5)
+        l_draws, l = lit_host.run(algo, "dense", init, 77, 1, 3, 3, eps, prec=prec, chain0=5, n_adapt=2, max_depth=3)
+        assert np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"]), (algo, d, eps)
