@@ -105,7 +105,7 @@ inline void lit_orders(LitTarget& t)
     // one ascending fma chain (what every dense kernel does), dot products over its four dimension quarters
     if (t.kind == LIT_DENSE && t.d > 128 && t.d <= 512) {
         t.nblk = 4;
-        t.bs = (t.d <= 256) ? 64u : 128u;
+        t.bs = (t.d <= 192) ? 48u : (t.d <= 256) ? 64u : (t.d <= 384) ? 96u : 128u;     // 16 NTQ of the instantiation (logistic_lds.hip)
     }
 }
 

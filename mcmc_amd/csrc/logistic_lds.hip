@@ -38,7 +38,9 @@ template <int ALGO>
 int launch_any(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)
 {
     if (target == LOGIT_TARGET_DENSE) {                 // 128 < d <= 512 (smaller d: hmc_dense.hpp keeps P resident in LDS)
+        if (prm.d <= 192) return launch<3, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
         if (prm.d <= 256) return launch<4, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
+        if (prm.d <= 384) return launch<6, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
         return launch<8, ALGO, LOGIT_TARGET_DENSE>(prm, X_dev, y_dev, workspace, st);
     }
     if (prm.d <= 64) return launch<1, ALGO, LOGIT_TARGET_LOGISTIC>(prm, X_dev, y_dev, workspace, st);
@@ -51,7 +53,10 @@ int launch_any(LogitParams& prm, const double* X_dev, const double* y_dev, void*
 
 size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target)
 {
-    const size_t n = (d <= 64) ? ws_doubles<1>(NB, C, target) : (d <= 128) ? ws_doubles<2>(NB, C, target)
+    const size_t n = (target == LOGIT_TARGET_DENSE)
+                         ? ((d <= 192) ? ws_doubles<3>(NB, C, target) : (d <= 256) ? ws_doubles<4>(NB, C, target)
+                            : (d <= 384) ? ws_doubles<6>(NB, C, target) : ws_doubles<8>(NB, C, target))
+                   : (d <= 64) ? ws_doubles<1>(NB, C, target) : (d <= 128) ? ws_doubles<2>(NB, C, target)
                    : (d <= 256) ? ws_doubles<4>(NB, C, target) : ws_doubles<8>(NB, C, target);
     return n * sizeof(double);
 }

@@ -343,25 +343,40 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) r_nxt[sp] = xq[(size_t)(4 * bn + sp) * 64];
             const double* xg = xb + grad_off;
-            double g_cur[4], g_nxt[4];
+#ifndef MI_DENSE_TT
+#define MI_DENSE_TT 1      // measured: 2 and 4 tiles interleaved are 3 % and 9 % slower (registers), two waves per SIMD hide the chain already
+#endif
+            // TT dimension tiles at a time: the four MFMAs of one tile form a dependent chain (one fma chain per element of w), and
+            // back-to-back dependent MFMAs leave the matrix pipe half idle; interleaved with the chain of the next tile they do not.
+            constexpr int TT = (NTQ % MI_DENSE_TT == 0) ? MI_DENSE_TT : 1;
+            double g_cur[TT][4], g_nxt[TT][4];
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) g_cur[sp] = xg[2 * sp * RSP];
+            for (int u = 0; u < TT; ++u)
 #pragma unroll
-            for (int t = 0; t < NTQ; ++t) {
-                if (t + 1 < NTQ) {
+                for (int sp = 0; sp < 4; ++sp) g_cur[u][sp] = xg[2 * sp * RSP + 16 * u];
 #pragma unroll
-                    for (int sp = 0; sp < 4; ++sp) g_nxt[sp] = xg[2 * sp * RSP + 16 * (t + 1)];
+            for (int t = 0; t < NTQ; t += TT) {
+                if (t + TT < NTQ) {
+#pragma unroll
+                    for (int u = 0; u < TT; ++u)
+#pragma unroll
+                        for (int sp = 0; sp < 4; ++sp) g_nxt[u][sp] = xg[2 * sp * RSP + 16 * (t + TT + u)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (prefetch) {
 #pragma unroll
-                    for (int i = (t * NP) / NTQ; i < ((t + 1) * NP) / NTQ; ++i) issue_piece(nblk, nbuf, i);
+                    for (int i = (t * NP) / NTQ; i < ((t + TT) * NP) / NTQ; ++i) issue_piece(nblk, nbuf, i);
                 }
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) gacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[sp], r_cur[sp], gacc[t], 0, 0, 0);
+                for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+                    for (int u = 0; u < TT; ++u)
+                        gacc[t + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[u][sp], r_cur[sp], gacc[t + u], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) g_cur[sp] = g_nxt[sp];
+                for (int u = 0; u < TT; ++u)
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) g_cur[u][sp] = g_nxt[u][sp];
             }
             wait_loads();                           // block b+1 landed (this wave's pieces; r_nxt too) ...
 #pragma unroll
@@ -408,7 +423,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     // d = 512 mala instantiation nine more spilled VGPRs).
     constexpr uint64_t NF_BIT = 1ull << 63;
 
-    constexpr int SB = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);   // slices per batch of workspace loads
+    constexpr int SB0 = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);
+    constexpr int SB = (NSQ % SB0 == 0) ? SB0 : 4;      // slices per batch of workspace loads (NTQ = 3: NSQ = 12)
     auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
         if (draw >= prm.n_burnin) {
             n_acc += accept ? 1u : 0u;

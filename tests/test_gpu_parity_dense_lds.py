@@ -14,7 +14,7 @@ ALGO = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "rwmh": orc.ALGO_RWMH}
 
 
 def _blk(d):
-    return dict(blocks=4, block_size=64 if d <= 256 else 128)
+    return dict(blocks=4, block_size=48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128)     # 16 dims x tiles per wave
 
 
 def _run(algo, d, C, eps, init, seed=3, burn=2, keep=5, L=4, chain0=0, draw0=0):
@@ -28,7 +28,7 @@ def _run(algo, d, C, eps, init, seed=3, burn=2, keep=5, L=4, chain0=0, draw0=0):
 
 
 @pytest.mark.parametrize("algo,eps", [("hmc", 0.04), ("mala", 0.06), ("rwmh", 0.03)])
-@pytest.mark.parametrize("d", [129, 192, 256, 257, 300, 512])
+@pytest.mark.parametrize("d", [129, 192, 193, 256, 257, 300, 384, 400, 512])
 def test_dense_gaussian_streamed_through_lds_equals_the_oracle(algo, eps, d):
     C = 45                                              # one full workgroup of 32 chains + a ragged one
     init = synth.initial_states(C, d, seed=d + 1) * 0.5

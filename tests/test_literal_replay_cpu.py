@@ -89,7 +89,7 @@ def test_literal_dense_gaussian_uses_the_blocked_dot_order_between_128_and_512(a
     quarters, and the literal replay of its flagged chains has to use that order."""
     rng = np.random.default_rng([13, len(algo), d])
     prec = synth.dense_gaussian_precision(d, seed=d % 97)
-    bs = 64 if d <= 256 else 128
+    bs = 48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128
     for eps, scale in ((0.05, 1.0), (1e6, 1e3)):
         init = synth.initial_states(2, d, seed=d) * scale
         t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, blocks=4, block_size=bs)
