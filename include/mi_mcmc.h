@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000300
+#define MI_MCMC_VERSION 0x000301
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -136,6 +136,11 @@ typedef struct mi_chains {
                                * the adapted step sizes back in through step_size; n_adapt_draws must be the same in every
                                * call of one run, and a run whose first call is shorter than its adaptation window cannot
                                * be continued (the dual-averaging state is not exported). */
+    const double* mass_diag;  /* hmc only, may be NULL: PER-CHAIN diagonal mass matrices [d][C] (same memory space as theta) -- NOT a
+                               * reference mode (the reference has one precond_mat per call, i.e. per chain: this is C calls of
+                               * mcmc::hmc with precond_mat = diag(mass_diag[:, c]) in one launch).  settings.precond_mat must be
+                               * NULL.  Separable Gaussian targets without bounds run on the elementwise kernels (any d), everything
+                               * else on the literal kernels.  See mi_mcmc_hmc_run_mass_adapted_per_chain. */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);
@@ -205,6 +210,22 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
  * must be NULL; a dimension whose pooled variance is 0 or not finite keeps mass 1. */
 int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
                                  double* mass_diag_out, void* stream);
+/* The per-chain form SURVEY 8 f-2 words ("per-chain diagonal mass adaptation"; what Stan does for each of its chains): every chain
+ * estimates ITS OWN diagonal mass from ITS OWN draws.  The burn-in is cut into n_windows + 1 equal parts; part 0 runs with M = I;
+ * the draws of part k are kept in a scratch slab and give, per chain and dimension, the variance over the part's draws (two passes,
+ * draws ascending), regularised as Stan does, var' = (n var + 5e-3) / (n + 5), mass = 1 / var' (1 where that is not finite or
+ * not positive); part k + 1 and finally the kept draws run with those masses.  Each part is an ordinary mi_mcmc_hmc_run with
+ * mi_chains.mass_diag, chained through draw0: given the masses, chain c is bit-identical to mcmc::hmc with
+ * precond_mat = diag(mass[:, c]) (tests/test_gpu_mass_adapt.py).  mass_diag_out: [d][C] in the memory space of `chains`, may be
+ * NULL.  settings.step_size is in the preconditioned metric (every dimension near unit scale) and drives every part that has
+ * masses; part 0 (M = I on the raw target) runs with first_step_size (0: settings.step_size) -- the reference's hmc has no step-size
+ * adaptation, so the two scales are the caller's to give.  chains.mass_diag and settings.precond_mat must be NULL; n_windows >= 1;
+ * every part needs at least 3 draws.  With >= 10^3
+ * chains on one target the pooled estimate above is the better one (each chain sees few draws); this form is for chains that do
+ * not share a scale (different data per chain are not expressible through mi_target, so: for parity with per-chain adaptation
+ * elsewhere). */
+int mi_mcmc_hmc_run_mass_adapted_per_chain(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
+                                           double first_step_size, double* mass_diag_out, void* stream);
 
 /* Host-callback form of mcmc::hmc for ONE chain: the reference's own target contract
  * (std::function<fp_t(const ColVec_t& vals_inp, ColVec_t* grad_out, void* target_data)>, hmc.hpp:42-48)

@@ -48,7 +48,7 @@ class mi_chains(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mem", C.c_int32), ("n_chains", C.c_uint64),
                 ("chain0", C.c_uint64), ("theta", C.c_void_p), ("draws", C.c_void_p),
                 ("n_accept", C.c_void_p), ("step_size", C.c_void_p), ("n_leapfrogs", C.c_void_p),
-                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64)]
+                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64), ("mass_diag", C.c_void_p)]
 
 
 class MiMcmcError(RuntimeError):
@@ -61,7 +61,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target", "mi_mcmc_run_user_target_v", "mi_mcmc_run_tile_target",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -155,13 +155,14 @@ def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST, kernel_hint=KE
 
 
 def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=None, n_leapfrogs=None,
-                nuts_depth=None, mem=MEM_HOST, draw0=0):
+                nuts_depth=None, mem=MEM_HOST, draw0=0, mass_diag=None):
     c = mi_chains()
     c.struct_size = C.sizeof(mi_chains)
     c.mem, c.n_chains, c.chain0, c.draw0 = mem, int(n_chains), int(chain0), int(draw0)
     c.theta, c.draws, c.n_accept = _ptr(theta), _ptr(draws), _ptr(n_accept)
     c.step_size, c.n_leapfrogs, c.nuts_depth = _ptr(step_size), _ptr(n_leapfrogs), _ptr(nuts_depth)
-    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth]
+    c.mass_diag = _ptr(mass_diag)                         # hmc only: per-chain diagonal masses [d][C]
+    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth, mass_diag]
     return c
 
 
@@ -176,6 +177,15 @@ def hmc_mass_adapted(target, settings, chains, n_windows=3, stream=None):
     _check(lib().mi_mcmc_hmc_run_mass_adapted(C.byref(target), C.byref(settings), C.byref(chains), C.c_uint32(n_windows),
                                               C.c_void_p(mass.ctypes.data), C.c_void_p(stream or 0)))
     return mass
+
+
+def hmc_mass_adapted_per_chain(target, settings, chains, n_windows=3, mass_out=None, first_step_size=0.0, stream=None):
+    """mi_mcmc_hmc_run_mass_adapted_per_chain (NOT a reference mode): every chain adapts its own diagonal mass from its own burn-in
+    draws.  mass_out: [d][C] in the memory space of `chains` (numpy array or torch tensor) or None; first_step_size: the step of
+    part 0 (M = I on the raw target; 0 = settings.step_size, which is in the preconditioned metric)."""
+    _check(lib().mi_mcmc_hmc_run_mass_adapted_per_chain(C.byref(target), C.byref(settings), C.byref(chains), C.c_uint32(n_windows),
+                                                        C.c_double(first_step_size), C.c_void_p(_ptr(mass_out)), C.c_void_p(stream or 0)))
+    return mass_out
 
 
 def last_kernel():

@@ -43,6 +43,7 @@ struct HmcDiagParams {
     uint32_t draw0;         // index of this call's first draw in the chains' random streams (mi_chains.draw0)
     const double* m_sqrt;   // PRECOND: diagonal of CHOL_LOWER(precond_mat) (device, d values)
     const double* m_inv;    // PRECOND: diagonal of INV(precond_mat)
+    uint32_t m_per_chain;   // PRECOND: 0 = one mass for all chains (m_sqrt / m_inv are [d]); 1 = per-chain masses (mi_chains.mass_diag): [d][C]
     uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
 };
 
@@ -76,6 +77,11 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
     const double* prec = prm.prec;
     const uint32_t L = prm.n_leap_steps;
     const size_t slab = (size_t)d * C;
+
+    // PRECOND tables: element i of this chain's mass is at [i * mstr] behind msq / miv (one shared table, or the chain's column of [d][C])
+    [[maybe_unused]] const size_t mstr = (PRECOND && prm.m_per_chain) ? (size_t)C : (size_t)1;
+    [[maybe_unused]] const double* const msq = PRECOND ? prm.m_sqrt + ((prm.m_per_chain) ? c : 0) : nullptr;
+    [[maybe_unused]] const double* const miv = PRECOND ? prm.m_inv + ((prm.m_per_chain) ? c : 0) : nullptr;
 
     const double* cur = prm.theta + c;                  // this chain's column of the slab holding prev_draw
     // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
                 const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
                 th[r] = cur[(size_t)ic * C];
                 lam[r] = prec ? prec[ic] : 1.0;
-                if constexpr (PRECOND) { pm[r] = prm.m_sqrt[ic] * z[r]; mi_[r] = prm.m_inv[ic]; }   // p = L z (hmc.cpp:158)
+                if constexpr (PRECOND) { pm[r] = msq[(size_t)ic * mstr] * z[r]; mi_[r] = miv[(size_t)ic * mstr]; }   // p = L z (hmc.cpp:158)
                 else pm[r] = z[r];                                        // L = I
                 w[r] = lam[r] * th[r];
             }
@@ -206,6 +212,10 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
     const uint32_t L = prm.n_leap_steps;
     const size_t slab = (size_t)d * C;
 
+    [[maybe_unused]] const size_t mstr = (PRECOND && prm.m_per_chain) ? (size_t)C : (size_t)1;
+    [[maybe_unused]] const double* const msq = PRECOND ? prm.m_sqrt + ((prm.m_per_chain) ? c : 0) : nullptr;
+    [[maybe_unused]] const double* const miv = PRECOND ? prm.m_inv + ((prm.m_per_chain) ? c : 0) : nullptr;
+
     const double* cur = prm.theta + c;                  // this chain's column of the slab holding prev_draw
     // prev_U = -box_log_kernel(first_draw)  (hmc.cpp:140)
     double prev_U;
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256) void hmc_diag1_kernel(const HmcDiagParams prm)
                 const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
                 th[r] = cur[(size_t)ic * C];
                 lam[r] = prec ? prec[ic] : 1.0;
-                if constexpr (PRECOND) { pm[r] = prm.m_sqrt[ic] * z[r]; mi_[r] = prm.m_inv[ic]; }   // p = L z (hmc.cpp:158)
+                if constexpr (PRECOND) { pm[r] = msq[(size_t)ic * mstr] * z[r]; mi_[r] = miv[(size_t)ic * mstr]; }   // p = L z (hmc.cpp:158)
                 else pm[r] = z[r];                                        // L = I
                 w[r] = lam[r] * th[r];
             }

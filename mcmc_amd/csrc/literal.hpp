@@ -65,6 +65,7 @@ struct LitParams {
     const double* m;
     const double* m_sqrt;
     const double* m_inv;
+    uint64_t m_chain_stride; // precond 1, hmc: 0 = one mass for all chains; C = per-chain masses (mi_chains.mass_diag): element i of chain c at [i * C + c]
     const double* Mfull;
     const double* Lchol;
     const double* Minv;
@@ -94,7 +95,7 @@ constexpr int LIT_RMHMC_MATS = 10;
 MI_HD size_t lit_work_doubles(uint32_t d, uint32_t n_rows, bool mala_bounded, uint32_t nuts_depth = 0, bool nuts = false, bool rmhmc = false)
 {
     const size_t dv = (size_t)d + 8;
-    return 16 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0)
+    return 19 * dv + 2 * ((size_t)n_rows + 8) + (mala_bounded ? 10 * (size_t)d * d : 0)
          + (nuts ? ((size_t)LIT_NUTS_TOP_VECS + (size_t)LIT_NUTS_FRAME_VECS * (nuts_depth + 1)) * dv : 0)
          + (rmhmc ? (size_t)LIT_RMHMC_VECS * dv + 3 * ((size_t)n_rows + 8) + (size_t)LIT_RMHMC_MATS * d * d + 2 * (size_t)d * d * d : 0);
 }
@@ -417,6 +418,7 @@ MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, do
 // vectors of one chain
 struct Vecs {
     double *prev, *cur, *mntm, *z, *mp, *grad, *vi, *jd, *jg, *w, *mean, *t, *pmean, *qmean, *xc, *tt, *rows;
+    double *mc, *msc, *mic;                                          // this chain's column of per-chain mass tables (m, sqrt, inverse)
     double *J, *JM, *CJ, *T, *Sigma, *ga, *Sinv, *L, *Pm, *SPm;      // d*d each (bounded mala)
 };
 MI_HD Vecs carve(double* wk, uint32_t d, uint32_t n_rows, bool mats)
@@ -427,6 +429,7 @@ MI_HD Vecs carve(double* wk, uint32_t d, uint32_t n_rows, bool mats)
     v.prev = p; p += dv; v.cur = p; p += dv; v.mntm = p; p += dv; v.z = p; p += dv; v.mp = p; p += dv; v.grad = p; p += dv;
     v.vi = p; p += dv; v.jd = p; p += dv; v.jg = p; p += dv; v.w = p; p += dv; v.mean = p; p += dv; v.t = p; p += dv;
     v.pmean = p; p += dv; v.qmean = p; p += dv; v.xc = p; p += dv; v.tt = p; p += dv;
+    v.mc = p; p += dv; v.msc = p; p += dv; v.mic = p; p += dv;
     v.rows = p; p += 2 * ((size_t)n_rows + 8);
     const size_t dd = (size_t)d * d;
     v.J = v.JM = v.CJ = v.T = v.Sigma = v.ga = v.Sinv = v.L = v.Pm = v.SPm = nullptr;
@@ -501,10 +504,20 @@ MI_HD void store_row(const Par& par, const LitParams& p, uint64_t c, uint32_t ro
 }
 
 // ---- mcmc::internal::hmc_impl (hmc.cpp:30-227) for local chain c
-MI_HD void hmc_chain(const Par& par, const LitParams& p, uint64_t c, double* wk)
+MI_HD void hmc_chain(const Par& par, const LitParams& p_in, uint64_t c, double* wk)
 {
-    const uint32_t d = p.t.d;
-    const Vecs v = carve(wk, d, p.t.n_rows, false);
+    const uint32_t d = p_in.t.d;
+    const Vecs v = carve(wk, d, p_in.t.n_rows, false);
+    LitParams p = p_in;
+    if (p.precond == 1 && p.m_chain_stride != 0) {          // per-chain diagonal mass: this chain's column becomes the [d] tables
+        LIT_PFOR(i, d) {
+            const size_t e = (size_t)i * p_in.m_chain_stride + c;
+            v.msc[i] = p_in.m_sqrt[e]; v.mic[i] = p_in.m_inv[e];
+            if (p_in.m) v.mc[i] = p_in.m[e];
+        }
+        par.sync();
+        p.m_sqrt = v.msc; p.m_inv = v.mic; p.m = p_in.m ? v.mc : nullptr;
+    }
     const uint64_t chain = p.chain0 + c;
     const double step = p.eps;
     LIT_PFOR(i, d) {
@@ -789,7 +802,7 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     const uint32_t d = p.t.d;
     const Vecs v = carve(wk, d, p.t.n_rows, false);
     const size_t dv = (size_t)d + 8;
-    double* extra = wk + 16 * dv + 2 * ((size_t)p.t.n_rows + 8);
+    double* extra = v.rows + 2 * ((size_t)p.t.n_rows + 8);
     double* const new_draw = extra + 0 * dv; double* const draw_pos = extra + 1 * dv; double* const draw_neg = extra + 2 * dv;
     double* const mntm_pos = extra + 3 * dv; double* const mntm_neg = extra + 4 * dv; double* const dummy_draw = extra + 5 * dv;
     double* const dummy_mntm = extra + 6 * dv; double* const start_draw = extra + 7 * dv; double* const mntm_vec = extra + 8 * dv;
@@ -1041,7 +1054,7 @@ MI_HD void rmhmc_chain(const Par& par, const LitParams& p, uint64_t c, double* w
     const uint32_t d = p.t.d;
     const size_t dd = (size_t)d * d, dv = (size_t)d + 8;
     const Vecs v = carve(wk, d, p.t.n_rows, false);
-    double* q = wk + 16 * dv + 2 * ((size_t)p.t.n_rows + 8);
+    double* q = v.rows + 2 * ((size_t)p.t.n_rows + 8);
     double* const new_mntm = q; q += dv; double* const prop_mntm = q; q += dv; double* const prop_draw = q; q += dv; double* const incr = q; q += dv;
     double* const tmpv = q; q += dv; double* const gobj = q; q += dv; double* const av = q; q += dv; double* const bv = q; q += dv;
     double* const jd = q; q += dv; double* const jg = q; q += dv;

@@ -252,7 +252,7 @@ int lit_upload(const mi::lit::LitPrep& pr, uint32_t d, bool want_bounds, LitDev&
 // completeness path, not a throughput path.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh.
 int run_literal(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st);
 
-int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
+int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c, bool mass_allowed = false)
 {
     if (!t || !s || !c) return fail(MI_ERR_BAD_ARG, "null target / settings / chains");
     if (t->struct_size != sizeof(mi_target) || s->struct_size != sizeof(mi_settings) ||
@@ -260,6 +260,8 @@ int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c)
         return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
     if (t->d == 0 || c->n_chains == 0) return fail(MI_ERR_BAD_ARG, "d and n_chains must be positive");
     if (!c->theta) return fail(MI_ERR_BAD_ARG, "chains.theta is required");
+    if (c->mass_diag && !mass_allowed) return fail(MI_ERR_UNSUPPORTED, "chains.mass_diag (per-chain diagonal masses) is implemented for mi_mcmc_hmc_run only");
+    if (c->mass_diag && s->precond_mat) return fail(MI_ERR_BAD_ARG, "chains.mass_diag and settings.precond_mat are two mass matrices: one of them must be NULL");
     if (c->draw0 + s->n_burnin_draws + s->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw0 + draws exceeds the 32-bit draw counter");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -301,7 +303,7 @@ int dense_precision_on_device(const mi_target* t, DevBuf& owned, const double** 
 
 // host <-> device staging of one mi_chains shard
 struct StagedChains {
-    DevBuf theta, draws, n_accept, step, n_leap, depth;
+    DevBuf theta, draws, n_accept, step, n_leap, depth, mass;
     mi_chains dev;   // device-pointer view
 };
 
@@ -326,6 +328,10 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
         HIP_TRY(hipMemsetAsync(sc.n_leap.p, 0, C * sizeof(uint64_t), st));    // samplers without leapfrog steps (mala, rwmh) report 0
     }
     if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
+    if (c->mass_diag) {
+        HIP_TRY(sc.mass.alloc(d * C * sizeof(double))); sc.dev.mass_diag = sc.mass.as<double>();
+        HIP_TRY(hipMemcpyAsync(sc.mass.p, c->mass_diag, d * C * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     sc.dev.mem = MI_MEM_DEVICE;
     return MI_OK;
 }
@@ -495,6 +501,27 @@ int launched(const char* what, int hip_err)
     return MI_OK;
 }
 
+// per-chain diagonal masses (mi_chains.mass_diag, [d][C]): CHOL_LOWER and INV of a diagonal matrix are the element-wise sqrt(m) and
+// 1 / m (what the oracle's Cholesky / Gauss-Jordan give for diag(m)), formed on the device next to the masses
+__global__ void chain_mass_tables_kernel(const double* __restrict__ mass, uint64_t n, double* __restrict__ m_sqrt, double* __restrict__ m_inv)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) { const double m = mass[e]; m_sqrt[e] = __builtin_sqrt(m); m_inv[e] = 1.0 / m; }
+}
+struct ChainMass { DevBuf ms, mi; };
+int chain_mass_tables(const double* mass_dev, uint64_t d, uint64_t C, ChainMass& t, hipStream_t st)
+{
+    const uint64_t n = d * C;
+    HIP_TRY(t.ms.alloc(n * 8)); HIP_TRY(t.mi.alloc(n * 8));
+    hipLaunchKernelGGL(chain_mass_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mass_dev, n, t.ms.as<double>(), t.mi.as<double>());
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
+}
+void lit_set_chain_mass(mi::lit::LitParams& lp, const double* mass_dev, const ChainMass& t, uint64_t C)
+{
+    lp.precond = 1; lp.m = mass_dev; lp.m_sqrt = t.ms.as<double>(); lp.m_inv = t.mi.as<double>(); lp.m_chain_stride = C;
+}
+
 int run_literal(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
 {
     const uint64_t d = target->d, C = chains->n_chains;
@@ -565,6 +592,11 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     LitDev ldev;
     rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
     if (rc) return rc;
+    ChainMass cm;
+    if (sc.dev.mass_diag) {                              // hmc with per-chain diagonal masses (checked by the caller)
+        if ((rc = chain_mass_tables(sc.dev.mass_diag, d, C, cm, st))) return rc;
+        lit_set_chain_mass(lp, sc.dev.mass_diag, cm, C);
+    }
     if (algo == 2) {
         if (chains->draw0 > 0) {
             if (chains->draw0 <= settings->n_adapt_draws)
@@ -580,7 +612,7 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (t_a.p || t_b.p || t_t.p || ldev.any || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (t_a.p || t_b.p || t_t.p || ldev.any || cm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -907,10 +939,18 @@ int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_fre
 
 int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
-    int rc = check_common(target, settings, chains);
+    int rc = check_common(target, settings, chains, true);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
+    if (chains->mass_diag) {
+        // per-chain diagonal masses: separable Gaussians without bounds on the elementwise kernels (below), everything else literally
+        const bool sep = target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG;
+        if (!sep || settings->vals_bound) {
+            if (target->kind == MI_TARGET_NORMAL_MODEL) return fail(MI_ERR_UNSUPPORTED, "hmc: chains.mass_diag with the normal-model target is not implemented");
+            return run_literal("hmc", 0, target, settings, chains, st);
+        }
+    }
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
         if (settings->vals_bound || settings->precond_mat)
@@ -955,7 +995,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     const bool force_diag = !bounded && (target->kernel_hint == MI_KERNEL_ELEMENTWISE_1LANE || target->kernel_hint == MI_KERNEL_ELEMENTWISE_4LANE);
     if (d > 128 && !separable)
         return fail(MI_ERR_UNSUPPORTED, "hmc: d = %llu > 128 not implemented for dense-gradient targets", (unsigned long long)d);
-    if (separable && (d > 128 || force_diag)) {
+    if (separable && (d > 128 || force_diag || chains->mass_diag)) {
         if (dense_m) return fail(MI_ERR_UNSUPPORTED, "hmc: a dense precond_mat is implemented for d <= 128");
         // no contraction: the elementwise (lane-per-chain) kernel
         DevBuf prec_owned;
@@ -991,7 +1031,14 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_1LANE) diag_lanes = 1;
         if (target->kernel_hint == MI_KERNEL_ELEMENTWISE_4LANE) diag_lanes = 4;
         DevBuf ms_d, mi_d;
-        if (diag_precond_elementwise) {
+        ChainMass cm;
+        if (sc.dev.mass_diag) {                          // per-chain tables [d][C]
+            if ((rc = chain_mass_tables(sc.dev.mass_diag, d, q.C, cm, st))) return rc;
+            q.m_sqrt = cm.ms.as<double>(); q.m_inv = cm.mi.as<double>(); q.m_per_chain = 1;
+            mi::note_kernel("hmc_diag%d_kernel<true>", diag_lanes == 4 ? 4 : 1);
+            if (diag_lanes == 4) hipLaunchKernelGGL(mi::hmc_diag4_kernel<true>, dim3((unsigned)((q.C + 63) / 64)), dim3(256), 0, st, q);
+            else hipLaunchKernelGGL(mi::hmc_diag1_kernel<true>, dim3((unsigned)((q.C + 255) / 256)), dim3(256), 0, st, q);
+        } else if (diag_precond_elementwise) {
             HIP_TRY(ms_d.alloc(d * 8)); HIP_TRY(mi_d.alloc(d * 8));
             HIP_TRY(hipMemcpy(ms_d.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(mi_d.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
@@ -1010,11 +1057,12 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, nullptr, prec_dev, rp.tbuf, st);
             if (rc) return rc;
             lit_common(lp, settings, &sc.dev, rp, false);
-            if (diag_precond_elementwise) { lp.precond = 1; lp.m_sqrt = ms_d.as<double>(); lp.m_inv = mi_d.as<double>(); }
+            if (sc.dev.mass_diag) lit_set_chain_mass(lp, sc.dev.mass_diag, cm, q.C);
+            else if (diag_precond_elementwise) { lp.precond = 1; lp.m_sqrt = ms_d.as<double>(); lp.m_inv = mi_d.as<double>(); }
             rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
             if (rc) return rc;
         }
-        if (diag_precond_elementwise) HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
+        if (diag_precond_elementwise || sc.dev.mass_diag) HIP_TRY(hipStreamSynchronize(st));          // the tables are ours
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
         if (prec_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -1228,6 +1276,90 @@ int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* set
         else for (uint64_t c = 0; c < C; ++c) chains->n_leapfrogs[c] = total;
     }
     if (mass_diag_out) std::memcpy(mass_diag_out, mass.data(), d * 8);
+    return MI_OK;
+}
+
+// per chain and dimension: variance of the chain's own draws of one burn-in part (slab [n][d][C]; two passes, draws ascending),
+// regularised as Stan regularises its windows, and inverted: mass [d][C]
+namespace {
+__global__ __launch_bounds__(256) void chain_mass_estimate_kernel(const double* __restrict__ slab, uint32_t n, uint64_t dC, double* __restrict__ mass)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // e = i * C + c: coalesced over the chains
+    if (e >= dC) return;
+    double s = 0.0;
+    for (uint32_t t = 0; t < n; ++t) s = s + slab[(size_t)t * dC + e];
+    const double mean = s / (double)n;
+    double q = 0.0;
+    for (uint32_t t = 0; t < n; ++t) { const double x = slab[(size_t)t * dC + e] - mean; q = __builtin_fma(x, x, q); }
+    const double var = q / (double)(n - 1);
+    const double reg = ((double)n * var + 5.0e-3) / ((double)n + 5.0);
+    const double m = 1.0 / reg;
+    mass[e] = (mi::is_finite(m) && m > 0.0) ? m : 1.0;
+}
+}  // namespace
+
+int mi_mcmc_hmc_run_mass_adapted_per_chain(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
+                                           double first_step_size, double* mass_diag_out, void* stream)
+{
+    int rc = check_common(target, settings, chains);
+    if (rc) return rc;
+    if (settings->precond_mat) return fail(MI_ERR_BAD_ARG, "hmc (per-chain mass): settings.precond_mat must be NULL, the mass matrices are estimated");
+    if (n_windows == 0) return fail(MI_ERR_BAD_ARG, "hmc (per-chain mass): n_windows must be at least 1");
+    const uint64_t d = target->d, C = chains->n_chains, n_burnin = settings->n_burnin_draws;
+    const uint64_t n_parts = (uint64_t)n_windows + 1;
+    if (n_burnin / n_parts < 3)
+        return fail(MI_ERR_BAD_ARG, "hmc (per-chain mass): n_burnin_draws = %llu leaves fewer than 3 draws for each of the %llu parts (a chain estimates its variances from the draws of one part)",
+                    (unsigned long long)n_burnin, (unsigned long long)n_parts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // everything runs in device memory; a caller with host buffers gets them staged once, not once per part
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    DevBuf mass, slab;
+    HIP_TRY(mass.alloc(d * C * 8));
+    uint64_t max_part = 0;
+    for (uint64_t part = 0; part + 1 < n_parts; ++part) {
+        const uint64_t len = (n_burnin * (part + 1)) / n_parts - (n_burnin * part) / n_parts;
+        max_part = len > max_part ? len : max_part;
+    }
+    if (hipMalloc(&slab.p, max_part * d * C * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MI_ERR_HIP, "hmc (per-chain mass): no memory for the draws of one burn-in part (%llu x d x C doubles): use more windows",
+                    (unsigned long long)max_part);
+    }
+    uint64_t done = 0;
+    for (uint64_t part = 0; part < n_parts; ++part) {
+        const bool last = part + 1 == n_parts;
+        const uint64_t upto = last ? n_burnin : (n_burnin * (part + 1)) / n_parts;
+        mi_settings s_ = *settings;
+        mi_chains c_ = sc.dev;
+        c_.draw0 = chains->draw0 + done;
+        c_.mass_diag = part == 0 ? nullptr : mass.as<double>();       // part 0: M = I, on the raw target's scale
+        if (part == 0 && first_step_size != 0.0) s_.step_size = first_step_size;
+        if (last) {
+            s_.n_burnin_draws = upto - done; s_.n_keep_draws = settings->n_keep_draws;
+        } else {                                                     // the part's draws are what the chain learns from
+            s_.n_burnin_draws = 0; s_.n_keep_draws = upto - done;
+            c_.draws = slab.as<double>(); c_.n_accept = nullptr;
+        }
+        if (s_.n_burnin_draws + s_.n_keep_draws > 0) {
+            rc = mi_mcmc_hmc_run(target, &s_, &c_, stream);
+            if (rc) return rc;
+        }
+        if (!last) {
+            const uint64_t n = upto - done, dC = d * C;
+            hipLaunchKernelGGL(chain_mass_estimate_kernel, dim3((unsigned)((dC + 255) / 256)), dim3(256), 0, st, slab.as<double>(), (uint32_t)n, dC, mass.as<double>());
+            HIP_TRY(hipGetLastError());
+        }
+        done = upto;
+    }
+    rc = fill_n_leap(sc.dev.n_leapfrogs, C, (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps, st);
+    if (rc) return rc;
+    if (mass_diag_out)
+        HIP_TRY(hipMemcpyAsync(mass_diag_out, mass.p, d * C * 8, chains->mem == MI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));                   // mass / slab are ours
     return MI_OK;
 }
 
