@@ -295,10 +295,15 @@ __device__ MI_BOX_INLINE double box_log_jacobian_term(double v, int bt, double l
 // host with the oracle's Gauss-Jordan / Cholesky and staged into LDS as two more sets of MFMA A-fragments: p = L z,
 // theta += eps (Minv p) and K = p.(Minv p)/2 are mat-vecs with the same fma order as the oracle's dense products (so the
 // NaN poisoning of section 3 of DESIGN.md happens by itself).  d <= 64: three matrices have to share the LDS.
-template <int NT, int WPB, bool BOUNDED = false, bool DENSE_M = false>
+// DIAGM (without BOUNDED): a DIAGONAL precond_mat and no bounds -- the plain kernel with p = sqrt(m) z, theta += eps (p / m) and
+// K = p.(p / m) / 2 applied element-wise from two LDS tables; two waves per SIMD like the plain kernel (the general variant holds a
+// fourth vector and runs one).  The NaN poisoning of the reference's dense `inv_precond_matrix * mntm` is handled as in the plain
+// kernel: detected through the energies, flagged, replayed by literal.hpp (precond = 1).
+template <int NT, int WPB, bool BOUNDED = false, bool DENSE_M = false, bool DIAGM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
     static_assert(!DENSE_M || BOUNDED, "the dense preconditioner rides the general variant");
+    static_assert(!DIAGM || !BOUNDED, "DIAGM is the plain kernel with a diagonal mass; bounds take the general variant");
     constexpr int NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
     stage_precision<NT>(prm.P, prm.d, lds_P);
@@ -324,6 +329,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         }
         __syncthreads();
     }
+    if (DIAGM) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+            lds_mi[i] = in ? prm.m_inv[i] : 1.0;
+        }
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
@@ -341,6 +354,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         bslices = (uint32_t)__builtin_amdgcn_readfirstlane((int)bslices);
     }
     auto slice_bounded = [&](int s) -> bool { return ((bslices >> s) & 1u) != 0u; };
+    // DIAGM: this lane's column of the 1 / m table, re-derived where it is used -- as a loop invariant the compiler would keep all NS
+    // entries in registers across the leapfrog loop (108 more spilled VGPRs at d = 128)
+    [[maybe_unused]] auto mi_col = [&]() __attribute__((always_inline)) -> const double* {
+        const double* p = lds_mi + (lane >> 4);
+        asm volatile("" : "+v"(p));
+        return p;
+    };
     const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
     const bool live = cl < prm.C;
     const uint64_t cld = live ? cl : prm.C - 1;       // clamped index for loads
@@ -420,6 +440,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             q = q + __shfl_xor(q, 32);
             q = q + __shfl_xor(q, 16);
             return q / 2.0;
+        } else if constexpr (DIAGM) {
+            double q = 0.0;
+            const double* mic = mi_col();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], mic[4 * s] * pm[s], q);
+            q = q + __shfl_xor(q, 32);
+            q = q + __shfl_xor(q, 16);
+            return q / 2.0;
         } else {
             return dot4<NS>(pm, pm) / 2.0;
         }
@@ -496,7 +524,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
 #pragma unroll
             for (int s = 0; s < NS; ++s) zz[s] = pm[s];
             matvec_m2<NT>(afrag_l, zz, pm);
-        } else if constexpr (BOUNDED) {                 // p = L z with a diagonal L (:158)
+        } else if constexpr (BOUNDED || DIAGM) {        // p = L z with a diagonal L (:158)
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = lds_ms[4 * s + j] * pm[s];
         }
@@ -509,7 +537,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             else rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
-            if constexpr (BOUNDED && !DENSE_M) {        // p = L z with a diagonal L (:158)
+            if constexpr (DIAGM) {                      // p = L z with a diagonal L (:158); the table entry is read where it is used
+                const double* msc = lds_ms + (lane >> 4);
+                asm volatile("" : "+v"(msc));
+                pm[2 * b] = msc[8 * b] * pm[2 * b];
+                pm[2 * b + 1] = msc[8 * b + 4] * pm[2 * b + 1];
+            } else if constexpr (BOUNDED && !DENSE_M) { // p = L z with a diagonal L (:158)
                 pm[2 * b] = lds_ms[8 * b + j] * pm[2 * b];
                 pm[2 * b + 1] = lds_ms[8 * b + 4 + j] * pm[2 * b + 1];
             }
@@ -530,22 +563,26 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             // statements), 6 instead of 8 VALU operations per element and step.
             const uint32_t L = prm.n_leap_steps;
             if (L > 0 && (prm.ablate & 3u) != 1u) {
+                [[maybe_unused]] const double* mic = DIAGM ? mi_col() : nullptr;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     pm[s] = pm[s] - (eps * w[s]) / 2.0;                     // first half-step of step 0 (:167,126)
-                    th[s] = th[s] + eps * pm[s];                            // (:171)
+                    if constexpr (DIAGM) th[s] = th[s] + eps * (mic[4 * s] * pm[s]);   // (:171) theta += eps Minv p
+                    else th[s] = th[s] + eps * pm[s];                       // (:171)
                 }
             }
 #pragma unroll 1
             for (uint32_t k = 0; k + 1 < L; ++k) {
                 if ((prm.ablate & 3u) != 2u) gradient();
                 if ((prm.ablate & 3u) != 1u) {
+                    [[maybe_unused]] const double* mic = DIAGM ? mi_col() : nullptr;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const double t = (eps * w[s]) / 2.0;
                         pm[s] = pm[s] - t;                                  // second half-step of step k (:175)
                         pm[s] = pm[s] - t;                                  // first half-step of step k+1 (:167)
-                        th[s] = th[s] + eps * pm[s];                        // (:171)
+                        if constexpr (DIAGM) th[s] = th[s] + eps * (mic[4 * s] * pm[s]);
+                        else th[s] = th[s] + eps * pm[s];                   // (:171)
                     }
                 }
             }

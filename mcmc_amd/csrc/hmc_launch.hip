@@ -20,6 +20,20 @@ int plain(const HmcParams& prm, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+// diagonal precond_mat, no bounds: the plain kernel's shape with the two mass tables next to P in LDS
+template <int NT>
+int plain_diagm(const HmcParams& prm, hipStream_t st)
+{
+    constexpr int WPB = MI_HMC_WPB;
+    const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
+    auto kern = hmc_gauss_mfma_kernel<NT, WPB, false, false, true>;
+    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
+    note_kernel("hmc_gauss_mfma_kernel<%d, %d, false, false, true>", NT, WPB);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
+    return (int)hipGetLastError();
+}
+
 // one wave per SIMD (WPB = 4): when the chains do not fill the chip at two waves per SIMD
 template <int NT>
 int plain4(const HmcParams& prm, hipStream_t st)
@@ -56,6 +70,11 @@ int launch_hmc_gauss(const HmcParams& prm, int nt, bool gen, bool dense_m, hipSt
     if (dense_m) return launch_hmc_gauss_dense_m(prm, nt, st);      // hmc_dense_launch.hip
     if (gen) return launch_hmc_gauss_general(prm, nt, st);         // hmc_general_launch.hip
     return MI_DISPATCH_NT(nt, plain<1>(prm, st), plain<2>(prm, st), plain<4>(prm, st), plain<8>(prm, st));
+}
+
+int launch_hmc_gauss_diagm(const HmcParams& prm, int nt, hipStream_t st)
+{
+    return MI_DISPATCH_NT(nt, plain_diagm<1>(prm, st), plain_diagm<2>(prm, st), plain_diagm<4>(prm, st), plain_diagm<8>(prm, st));
 }
 
 // plain case, 64 < d <= 128 (nt = 8), few chains: shape 1 = one wave per SIMD, one tile per wave; 2 = two waves per tile, one

@@ -24,6 +24,7 @@ int launch_hmc_gauss_dense_m(const HmcParams& prm, int nt, hipStream_t st);     
 // shape 1 = one wave per SIMD (hmc_gauss_mfma_kernel<8, 4>); hmc_split.hpp: 2 = two waves per 16-chain tile, 3 = four waves per
 // tile at two waves per SIMD, 4 = four waves per tile at one wave per SIMD
 int launch_hmc_gauss_few_chains(const HmcParams& prm, int shape, hipStream_t st);
+int launch_hmc_gauss_diagm(const HmcParams& prm, int nt, hipStream_t st);        // diagonal precond_mat, no bounds: the plain kernel's shape
 // variant: 0 plain, 1 general (bounds / diagonal precond), 2 dense precond (unbounded, nt <= 4)
 int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st);
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel

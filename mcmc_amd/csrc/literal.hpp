@@ -162,6 +162,16 @@ MI_HD uint32_t count_nonfinite(const double* x, uint32_t n)
     for (uint32_t i = 0; i < n; ++i) c += is_finite(x[i]) ? 0u : 1u;
     return c;
 }
+// A state that is NaN in EVERY dimension is absorbing for hmc and mala: every entry of the next proposal has prev_i as a summand, so the
+// proposal is all NaN again; its energies / densities are NaN, the acceptance exponent is std::min(0.01, NaN) = 0.01 (hmc.cpp:188,
+// mala.cpp:170: the comparison with NaN is false), exp(0.01) > 1 > u, so it is accepted -- whatever the random numbers.  The literal kernels
+// use that to fast-forward such a chain (a chain that starts outside its bounds is NaN from the transform on: without this, each of its
+// draws would still pay the O(d^3) of bounded mala).  Rows are stored through the same store_row as always.
+MI_HD bool all_nan(const double* x, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; ++i) if (x[i] == x[i]) return false;
+    return true;
+}
 // y = A x, A dense row-major: every row one fma chain, k ascending.  y must not alias x.
 MI_HD void gemv(const Par& par, const double* A, const double* x, uint32_t d, double* y)
 {
@@ -552,6 +562,11 @@ MI_HD void hmc_chain(const Par& par, const LitParams& p_in, uint64_t c, double* 
     uint64_t n_acc = 0;
     const uint32_t n_total = p.n_burnin + p.n_keep;
     for (uint32_t draw = 0; draw < n_total; ++draw) {
+        if (all_nan(v.prev, d)) {                           // absorbing (see all_nan): every remaining draw is this state, accepted
+            for (uint32_t r = draw; r < n_total; ++r)
+                if (r >= p.n_burnin) { n_acc += 1u; store_row(par, p, c, r - p.n_burnin, v.prev); }
+            break;
+        }
         normal_vec(par, p, chain, draw + p.draw0, v.z);     // :156
         times_lchol(par, p, v.z, v.mntm);                   // :158
         const double prev_K = kinetic();                    // :160
@@ -646,6 +661,11 @@ MI_HD void mala_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     uint64_t n_acc = 0;
     const uint32_t n_total = p.n_burnin + p.n_keep;
     for (uint32_t draw = 0; draw < n_total; ++draw) {
+        if (all_nan(v.prev, d)) {                           // absorbing (see all_nan): every remaining draw is this state, accepted
+            for (uint32_t r = draw; r < n_total; ++r)
+                if (r >= p.n_burnin) { n_acc += 1u; store_row(par, p, c, r - p.n_burnin, v.prev); }
+            break;
+        }
         normal_vec(par, p, chain, draw + p.draw0, v.z);     // :150
         if (vb) {                                           // :152-157
             mean_fn(v.prev, v.J, v.mean);

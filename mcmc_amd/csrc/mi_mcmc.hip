@@ -1090,7 +1090,10 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     rc = ws_get(st, rp.total_bytes, wsave);
     if (rc) return rc;
     prm.wsave = wsave.as<double>();
-    if (!bounded) {                                     // the general variants reproduce the dense products themselves
+    // a diagonal precond_mat alone (no bounds): the plain kernel's shape with two mass tables (hmc_dense.hpp, DIAGM), replay as the plain kernel
+    const bool diag_only = settings->precond_mat != nullptr && !dense_m && !settings->vals_bound;
+    const bool general = bounded && !diag_only;
+    if (!general) {                                     // the general variants reproduce the dense products themselves
         rc = replay_bind(rp, wsave.p, chains->n_chains, st);
         if (rc) return rc;
         prm.nf_flag = rp.flag;
@@ -1112,7 +1115,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
 
     const int nt = (int)((d + 15) / 16);
     DevBuf bt_dev, lb_dev, ub_dev;
-    if (bounded) {
+    if (general) {
         // determine_bounds_type (determine_bounds_type.hpp:27-57): 1 none, 2 lower, 3 upper, 4 both
         std::vector<int> bt(d, 1);
         std::vector<double> lbv(d, 0.0), ubv(d, 0.0);
@@ -1170,6 +1173,14 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             default: break;
             }
         }
+        DevBuf ms_dev, mi_dev;
+        if (diag_only) {
+            HIP_TRY(ms_dev.alloc(d * 8)); HIP_TRY(mi_dev.alloc(d * 8));
+            HIP_TRY(hipMemcpy(ms_dev.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(mi_dev.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
+            prm.m_sqrt = ms_dev.as<double>(); prm.m_inv = mi_dev.as<double>();
+            rc = launched("hmc", mi::launch_hmc_gauss_diagm(prm, nt, st));
+        } else
         rc = shape == 0 ? launched("hmc", mi::launch_hmc_gauss(prm, nt, false, false, st))
                         : launched("hmc", mi::launch_hmc_gauss_few_chains(prm, shape, st));
         if (rc) return rc;
@@ -1177,7 +1188,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr, rp.tbuf, st);
         if (rc) return rc;
         lit_common(lp, settings, &sc.dev, rp, false);
+        if (diag_only) { lp.precond = 1; lp.m_sqrt = ms_dev.as<double>(); lp.m_inv = mi_dev.as<double>(); }
         rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
+        if (!rc && diag_only) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
     if (rc) return rc;
 

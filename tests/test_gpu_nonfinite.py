@@ -68,6 +68,27 @@ def test_plain_mfma_hmc_d128_chain_driven_non_finite(hint):
     _same(g_draws, g, o_draws, o)
 
 
+@pytest.mark.parametrize("d,kind", [(128, "dense"), (40, "dense"), (100, "diag")])
+def test_mfma_hmc_with_a_diagonal_precond_mat_alone_non_finite(d, kind):
+    """hmc_gauss_mfma_kernel<., 8, false, false, true> (a diagonal precond_mat without bounds runs in the plain kernel's shape):
+    the reference's dense `inv_precond_matrix * mntm` poisons every dimension once one is non-finite -- detected through the energies,
+    replayed by the literal kernel with the same diagonal matrix."""
+    C = 70
+    prec = synth.dense_gaussian_precision(d) if kind == "dense" else synth.ill_conditioned_diag(d, 50.0)
+    M = np.diag(np.random.default_rng(5).uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=9)
+    init[3] *= 1.0e300; init[20, 5] = -np.inf; init[40, d - 1] = np.nan; init[64] *= 1.0e160
+    kg, ko = (mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE) if kind == "dense" else (mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG)
+    for eps in (0.1, 1.0e6):
+        st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=1, n_keep_draws=4, n_leap_steps=3, step_size=eps, precond_mat=M)
+        g_draws, g = mcmc_amd.hmc(kg, init, st, prec=prec)
+        assert mcmc_amd.last_kernel().endswith("false, false, true>"), mcmc_amd.last_kernel()
+        s = orc.make_settings(seed=4, n_burnin=1, n_keep=4, n_leap=3, step=eps, W=4, precond=M)
+        o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(ko, d, prec=prec, W=4), init, s)
+        assert len(_poisoned_chains(o_draws)) >= 2
+        _same(g_draws, g, o_draws, o)
+
+
 @pytest.mark.parametrize("kind", ["iso", "diag"])
 def test_plain_mfma_hmc_on_separable_targets_non_finite(kind):
     """ISO / DIAG targets on the MFMA kernel (d <= 128): the oracle's target is element-wise there, the kernel's a mat-vec over a
