@@ -325,14 +325,21 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         double4_t gacc[NTQ];
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-        double* xq = prm.xexch + ((size_t)blockIdx.x * 2 + g) * ((size_t)4 * NSQ * 64) + lane;
-        asm volatile("" : "+v"(xq));
+        // wave-uniform base (SGPR pair, known to be global memory) + the lane's byte offset, opaque so that the NSQ addresses are not
+        // hoisted: a laundered POINTER would lose its address space and turn these into flat loads, behind which every LDS wait of
+        // the block loop becomes lgkmcnt(0) + vmcnt(0) -- i.e. a wait for the block's own DMA pieces
+        double* const xq_base = prm.xexch + ((size_t)blockIdx.x * 2 + g) * ((size_t)4 * NSQ * 64);
+        uint32_t xq_off = (uint32_t)lane * 8u;
+        asm volatile("" : "+v"(xq_off));
+        auto xq_at = [&](uint32_t slot) __attribute__((always_inline)) -> double* {
+            return reinterpret_cast<double*>(reinterpret_cast<char*>(xq_base) + ((size_t)slot * 512u + xq_off));
+        };
 #pragma unroll
-        for (int s = 0; s < NSQ; ++s) xq[(size_t)(q * NSQ + s) * 64] = x[s];
+        for (int s = 0; s < NSQ; ++s) *xq_at((uint32_t)(q * NSQ + s)) = x[s];
         __syncthreads();                                 // x is visible to the tile's four waves; nobody still reads the exchange area
         double r_cur[4], r_nxt[4];
 #pragma unroll
-        for (int sp = 0; sp < 4; ++sp) r_cur[sp] = xq[(size_t)sp * 64];
+        for (int sp = 0; sp < 4; ++sp) r_cur[sp] = *xq_at((uint32_t)sp);
         constexpr bool prefetch = !(ablate & 8u);
 #pragma unroll 1
         for (uint32_t b = 0; b < NB; ++b) {
@@ -341,7 +348,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             const int nbuf = (int)((xbuf0 + b + 1) & 1u);
             const uint32_t bn = (b + 1 < NB) ? b + 1 : b;
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) r_nxt[sp] = xq[(size_t)(4 * bn + sp) * 64];
+            for (int sp = 0; sp < 4; ++sp) r_nxt[sp] = *xq_at(4u * bn + (uint32_t)sp);
             const double* xg = xb + grad_off;
 #ifndef MI_DENSE_TT
 #define MI_DENSE_TT 1      // measured: 2 and 4 tiles interleaved are 3 % and 9 % slower (registers), two waves per SIMD hide the chain already
@@ -353,32 +360,38 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
 #pragma unroll
             for (int u = 0; u < TT; ++u)
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) g_cur[u][sp] = xg[2 * sp * RSP + 16 * u];
+                for (int sp = 0; sp < 4; ++sp) g_cur[u][sp] = (ablate & 32u) ? 1.0 : xg[2 * sp * RSP + 16 * u];
 #pragma unroll
             for (int t = 0; t < NTQ; t += TT) {
                 if (t + TT < NTQ) {
 #pragma unroll
                     for (int u = 0; u < TT; ++u)
 #pragma unroll
-                        for (int sp = 0; sp < 4; ++sp) g_nxt[u][sp] = xg[2 * sp * RSP + 16 * (t + TT + u)];
+                        for (int sp = 0; sp < 4; ++sp) g_nxt[u][sp] = (ablate & 32u) ? 1.0 : xg[2 * sp * RSP + 16 * (t + TT + u)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef MI_DENSE_DMA_TILES
+#define MI_DENSE_DMA_TILES 0       // tiles of a block over which the wave spreads its DMA pieces of the next block (0: all NTQ)
+#endif
                 if constexpr (prefetch) {
+                    constexpr int DT = (MI_DENSE_DMA_TILES > 0 && MI_DENSE_DMA_TILES < NTQ) ? MI_DENSE_DMA_TILES : NTQ;
+                    if (t < DT) {
 #pragma unroll
-                    for (int i = (t * NP) / NTQ; i < ((t + TT) * NP) / NTQ; ++i) issue_piece(nblk, nbuf, i);
+                        for (int i = (t * NP) / DT; i < ((t + TT) * NP) / DT && i < NP; ++i) issue_piece(nblk, nbuf, i);
+                    }
                 }
 #pragma unroll
                 for (int sp = 0; sp < 4; ++sp)
 #pragma unroll
                     for (int u = 0; u < TT; ++u)
-                        gacc[t + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[u][sp], r_cur[sp], gacc[t + u], 0, 0, 0);
+                    { if constexpr (!(ablate & 4u)) gacc[t + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(g_cur[u][sp], r_cur[sp], gacc[t + u], 0, 0, 0); else gacc[t + u][0] += g_cur[u][sp] * r_cur[sp]; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < TT; ++u)
 #pragma unroll
                     for (int sp = 0; sp < 4; ++sp) g_cur[u][sp] = g_nxt[u][sp];
             }
-            wait_loads();                           // block b+1 landed (this wave's pieces; r_nxt too) ...
+            if constexpr (!(ablate & 128u)) wait_loads();   // block b+1 landed (this wave's pieces; r_nxt too) ...
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) r_cur[sp] = r_nxt[sp];
             blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2

@@ -4,8 +4,10 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, mcmc_amd
 from mcmc_amd import synth
-for algo, d, Cn, L, nd in [("hmc", 512, 65536, 16, 10), ("hmc", 256, 65536, 16, 20), ("hmc", 192, 65536, 16, 20), ("mala", 512, 65536, 0, 100), ("rwmh", 512, 65536, 0, 100),
-                           ("hmc", 512, 8192, 16, 10)]:
+import os
+CASES = [("hmc", 512, 65536, 16, 10), ("hmc", 256, 65536, 16, 20)] if os.environ.get("DENSE_LDS_SHORT") else [("hmc", 512, 65536, 16, 10), ("hmc", 256, 65536, 16, 20), ("hmc", 192, 65536, 16, 20), ("mala", 512, 65536, 0, 100), ("rwmh", 512, 65536, 0, 100),
+                           ("hmc", 512, 8192, 16, 10)]
+for algo, d, Cn, L, nd in CASES:
     P = torch.from_numpy(synth.dense_gaussian_precision(d)).cuda()
     theta = torch.from_numpy(np.ascontiguousarray(synth.initial_states(Cn, d, seed=3).T)).cuda()
     st = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=nd // 2, n_keep_draws=nd - nd // 2, n_leap_steps=max(L, 1), step_size=0.03)
