@@ -30,7 +30,7 @@ int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
 // the plain case (unbounded, identity precond_mat) with register-carried leaf state (nuts_reg.hpp): the default NUTS kernel
-int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);
+int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m = false);
 int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
 int launch_nuts_gauss_dense_m(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_dense_launch.hip
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);

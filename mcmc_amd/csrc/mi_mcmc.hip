@@ -1701,6 +1701,23 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, true, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
+    else if (gt.active && !settings->vals_bound && !lockstep && !tick_local) {
+        // a diagonal precond_mat alone: the register-carried kernel with two mass tables (nuts_reg.hpp, DIAGM); flagged chains are replayed
+        // by the general variant with the same tables
+        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
+        prm.nf_flag = nf_flag;
+        prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
+        rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st, true));
+        if (rc) return rc;
+        const std::string reg_name = mi::host::last_kernel();
+        mi::NutsParams rp = prm;
+        rp.nf_flag = nullptr; rp.replay_flag = nf_flag;
+        rp.btype = gt.bt.as<int>(); rp.lb = gt.lb.as<double>(); rp.ub = gt.ub.as<double>();
+        rp.vals_bound = 0;
+        rc = launched("nuts (replay)", mi::launch_nuts_gauss(rp, nt, true, false, false, nuts_batch, st));
+        mi::host::last_kernel() = reg_name;
+        if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
+    }
     else if (gt.active) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();

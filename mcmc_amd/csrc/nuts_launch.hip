@@ -9,12 +9,12 @@ namespace mi {
 namespace {
 
 // the plain case with register-carried leaf state (nuts_reg.hpp): the default kernel
-template <int NT>
+template <int NT, bool DIAGM>
 int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64) * sizeof(double);
-    auto kern = nuts_gauss_reg_kernel<NT>;
-    note_kernel("nuts_gauss_reg_kernel<%d>", NT);
+    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64 + (DIAGM ? 32 * NT : 0)) * sizeof(double);
+    auto kern = nuts_gauss_reg_kernel<NT, DIAGM>;
+    if (DIAGM) note_kernel("nuts_gauss_reg_kernel<%d, true>", NT); else note_kernel("nuts_gauss_reg_kernel<%d>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
     return (int)hipGetLastError();
@@ -42,10 +42,11 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, boo
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));
 }
 
-int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st)
+int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m)
 {
     if (batch < 1) batch = 1;
-    return MI_DISPATCH_NT(nt, reg<1>(prm, batch, st), reg<2>(prm, batch, st), reg<4>(prm, batch, st), reg<8>(prm, batch, st));
+    if (diag_m) return MI_DISPATCH_NT(nt, (reg<1, true>(prm, batch, st)), (reg<2, true>(prm, batch, st)), (reg<4, true>(prm, batch, st)), (reg<8, true>(prm, batch, st)));
+    return MI_DISPATCH_NT(nt, (reg<1, false>(prm, batch, st)), (reg<2, false>(prm, batch, st)), (reg<4, false>(prm, batch, st)), (reg<8, false>(prm, batch, st)));
 }
 
 }  // namespace mi

@@ -39,7 +39,10 @@ namespace mi {
 // vector and the second (prev_draw, P * prev_draw) pair
 enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
 
-template <int NT>
+// DIAGM: a DIAGONAL precond_mat without bounds (nuts.cpp:139-154 with hmc.cpp's leap_frog_fn: p = sqrt(m) z, theta += e (p / m),
+// K = p.(p / m) / 2; the U-turn tests take the momenta as they are): two tables in LDS, read where they are used.  The non-finite regime
+// is detected and replayed as in the plain case -- the general variant gets the same tables.
+template <int NT, bool DIAGM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(const NutsParams prm, const uint32_t refresh_batch)
 {
     constexpr int NS = 4 * NT;
@@ -49,6 +52,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
     double* lds_nf = lds_lvl + NUTS_LVLS * 4 * 64;       // [64]: non-zero = the chain saw a non-finite energy (see below)
+    [[maybe_unused]] double* lds_ms = lds_nf + 64;       // DIAGM: [16 NT] sqrt(m), [16 NT] 1 / m
+    [[maybe_unused]] double* lds_mi = lds_ms + 16 * NT;
+    if (DIAGM) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+            lds_mi[i] = in ? prm.m_inv[i] : 1.0;
+        }
+    }
     stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -91,6 +103,27 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
     };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
+    // DIAGM: this lane's column of a mass table (entry of slice s at [4 s]), re-derived opaquely where it is used: as loop
+    // invariants the compiler would keep the entries in registers this kernel does not have
+    [[maybe_unused]] auto mcol = [&](const double* tab) __attribute__((always_inline)) -> const double* {
+        const double* p = tab + (lane >> 4);
+        asm volatile("" : "+v"(p));
+        return p;
+    };
+    // K = p . (Minv p) / 2 (nuts.cpp leap_frog_fn / nuts.ipp:51,66,140)
+    auto kinetic_of = [&](const double (&p)[NS]) __attribute__((always_inline)) -> double {
+        if constexpr (DIAGM) {
+            const double* mic = mcol(lds_mi);
+            double q = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) q = dfma(p[s], mic[4 * s] * p[s], q);
+            q = q + __shfl_xor(q, 32);
+            q = q + __shfl_xor(q, 16);
+            return q / 2.0;
+        } else {
+            return dot4<NS>(p, p) / 2.0;
+        }
+    };
 
     constexpr int CHC = (NS < MI_NUTS_R_CHC) ? NS : MI_NUTS_R_CHC;
     // the chain's last leaf: position, momentum, P * position (MFMA B / D layout).  Loop-carried: see the header.
@@ -120,8 +153,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         auto leapfrog = [&](double e) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
+            if constexpr (DIAGM) {
+                const double* mic = mcol(lds_mi);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + e * (mic[4 * s] * pm[s]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
+            }
             matvec_mfma<NT>(afrag, th, w);
 #pragma unroll
             for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e * w[s]) / 2.0;
@@ -129,7 +168,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         auto energy = [&]() __attribute__((always_inline)) -> double {
             double u = 0.5 * dot4<NS>(th, w);
             if (!is_finite(u)) u = INF;
-            return u + dot4<NS>(pm, pm) / 2.0;
+            return u + kinetic_of(pm);
         };
 #pragma unroll
         for (int b = 0; b < NS / 2; ++b) {
@@ -137,11 +176,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
             pm[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+            if constexpr (DIAGM) {                       // mntm_vec = sqrt_precond_matrix * rand_vec (nuts.cpp:168)
+                const double* msc = mcol(lds_ms);
+                pm[2 * b] = msc[8 * b] * pm[2 * b];
+                pm[2 * b + 1] = msc[8 * b + 4] * pm[2 * b + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         double U0 = prev_U;
         if (!is_finite(U0)) U0 = INF;
-        const double K0 = dot4<NS>(pm, pm) / 2.0;
+        const double K0 = kinetic_of(pm);
         const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
         eps = 1.0;
         leapfrog(eps);
@@ -303,10 +347,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
                 rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
-                const double pa = (8u * b + j4 < d) ? z0 : 0.0;
-                const double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                kq = dfma(pa, pa, kq);
-                kq = dfma(pb_, pb_, kq);
+                double pa = (8u * b + j4 < d) ? z0 : 0.0;
+                double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                if constexpr (DIAGM) {                       // :202 and :204 with the diagonal matrices
+                    const double* msc = lds_ms + 8 * b + j4;
+                    const double* mic = lds_mi + 8 * b + j4;
+                    pa = msc[0] * pa; pb_ = msc[4] * pb_;
+                    kq = dfma(pa, mic[0] * pa, kq);
+                    kq = dfma(pb_, mic[4] * pb_, kq);
+                } else {
+                    kq = dfma(pa, pa, kq);
+                    kq = dfma(pb_, pb_, kq);
+                }
                 if (gen && live) st_pair(mvn, 2 * b, pa, pb_);
             }
             kq = kq + __shfl_xor(kq, 32);
@@ -361,11 +413,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
         double dd[NS];           // d; on an eager lane it first receives theta(b) (after the loop that writes d on every lane: a lane is
         double Lp[NS];           // either odd or eager, and the load may not be pending when the VALU writes the register); p(b)
         double q1 = 0.0, q2 = 0.0;
+        [[maybe_unused]] const double* mic_d = DIAGM ? mcol(lds_mi) : nullptr;
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             const double p0 = pm[s_], t0 = th[s_];
             pm[s_] = p0 - (e_signed * w[s_]) / 2.0;
-            th[s_] = t0 + e_signed * pm[s_];
+            if constexpr (DIAGM) th[s_] = t0 + e_signed * (mic_d[4 * s_] * pm[s_]);
+            else th[s_] = t0 + e_signed * pm[s_];
             dd[s_] = (vdir > 0) ? (th[s_] - t0) : (t0 - th[s_]);
             q1 = dfma(dd[s_], p0, q1);
         }
@@ -391,7 +445,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             q2 = dfma(dd[s], pm[s], q2);
         }
         double pU = 0.5 * dot4<NS>(th, w);               // nuts.ipp:134-138
-        const double pK = dot4<NS>(pm, pm) / 2.0;        // :140
+        const double pK = kinetic_of(pm);                // :140
         if (!is_finite(pU)) pU = INF;
         q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
         q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);

@@ -190,6 +190,29 @@ def test_plain_nuts_d128_chain_driven_non_finite(adapt):
     assert np.array_equal(g["eps"], o["eps"], equal_nan=True)
 
 
+@pytest.mark.parametrize("d,adapt", [(128, 6), (128, 0), (48, 4)])
+def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt):
+    """nuts_gauss_reg_kernel<., true>: the register-carried kernel with two mass tables; chains that leave the finite regime are replayed
+    by the general variant with the same tables (ref: src/nuts.cpp:139-154,168,202,204 with the diagonal matrices)."""
+    C = 40
+    prec = synth.dense_gaussian_precision(d)
+    M = np.diag(np.random.default_rng(8).uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=19)
+    init[2] *= 1.0e300
+    init[17, 3] = np.inf
+    init[33, d - 5] = np.nan
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=adapt, max_tree_depth=6, step_size=0.1,
+                                   precond_mat=M)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_reg_kernel<") and mcmc_amd.last_kernel().endswith("true>"), mcmc_amd.last_kernel()
+    s = orc.make_settings(seed=6, n_burnin=6, n_keep=5, n_adapt=adapt, max_depth=6, step=0.1, W=4, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
+    assert len(_poisoned_chains(o_draws)) >= 2 and o["n_accept"].sum() > 0
+    _same(g_draws, g, o_draws, o)
+    assert np.array_equal(g["n_leap"], o["n_leap"])
+    assert np.array_equal(g["eps"], o["eps"], equal_nan=True)
+
+
 def test_device_resident_run_replays_without_a_host_round_trip():
     """MI_MEM_DEVICE: flags, replay workspace and the literal launch ride the caller's stream"""
     import torch
