@@ -8,7 +8,9 @@
 #define MCMC_ENABLE_EIGEN_WRAPPERS
 #include "mcmc.hpp"
 
+#include <cmath>
 #include <cstdio>
+#include <limits>
 #include <vector>
 
 struct iso_data_t { int n_calls_grad = 0, n_calls_value = 0; };
@@ -27,6 +29,39 @@ static double log_target_dens(const mcmc::ColVec_t& vals_inp, mcmc::ColVec_t* gr
         dta->n_calls_value++;
     }
     return -0.5 * ss;
+}
+
+// the model of the reference's rmhmc example as HOST callbacks: log-likelihood of N(mu, sigma^2) data with its gradient, and the Fisher
+// information diag(n / sigma^2, 2 n / sigma^2) with its derivatives (user code: runs on the host)
+struct norm_data_t { const double* x; size_t n; int n_grad, n_value, n_tensor; };
+static double normal_ll(const mcmc::ColVec_t& v, mcmc::ColVec_t* grad_out, void* data)
+{
+    norm_data_t* dta = reinterpret_cast<norm_data_t*>(data);
+    const double mu = v(0), sigma = v(1), n = double(dta->n);
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t i = 0; i < dta->n; ++i) { const double e = dta->x[i] - mu; s1 += e; s2 += e * e; }
+    if (grad_out) {
+        grad_out->resize(2, 1);
+        (*grad_out)(0, 0) = s1 / (sigma * sigma);
+        (*grad_out)(1, 0) = -n / sigma + s2 / (sigma * sigma * sigma);
+        dta->n_grad++;
+    } else dta->n_value++;
+    return -0.5 * n * std::log(2.0 * 3.14159265358979323846) - n * std::log(sigma) - s2 / (2.0 * sigma * sigma);
+}
+static mcmc::Mat_t normal_tensor(const mcmc::ColVec_t& v, mcmc::Cube_t* deriv_out, void* data)
+{
+    norm_data_t* dta = reinterpret_cast<norm_data_t*>(data);
+    const double sigma = v(1), n = double(dta->n);
+    dta->n_tensor++;
+    mcmc::Mat_t G(2, 2);
+    G.setZero();
+    G(0, 0) = n / (sigma * sigma); G(1, 1) = 2.0 * n / (sigma * sigma);
+    if (deriv_out) {
+        deriv_out->setZero(2, 2, 2);                                   // mat(0) = dG/dmu = 0
+        deriv_out->mat(1)(0, 0) = -2.0 * n / (sigma * sigma * sigma);
+        deriv_out->mat(1)(1, 1) = -4.0 * n / (sigma * sigma * sigma);
+    }
+    return G;
 }
 
 static double col_mean(const mcmc::Mat_t& m, size_t j)
@@ -143,10 +178,24 @@ int main()
                 okw ? col_mean(drw, 0) : 0.0, okw ? col_mean(drw, 1) : 0.0, okw ? col_mean(drw, 2) : 0.0,
                 double(s5.rwmh_settings.n_accept_draws) / 4000.0, dw.n_calls_value);
 
-    // what the device path does not implement is refused with a reason, never run on the CPU: mcmc::rmhmc with host callbacks
+    // mcmc::rmhmc with HOST std::function callbacks, the flow of the reference's examples/eigen/rmhmc_normal.cpp: (mu, sigma) of normal
+    // data, the Fisher information as metric tensor, sigma bounded below.  The sampler runs on the device and asks for every evaluation.
+    norm_data_t nd{x_obs.data(), x_obs.size(), 0, 0, 0};
+    mcmc::algo_settings_t s6;
+    s6.rng_seed_value = 11;
+    s6.vals_bound = true;
+    s6.lower_bounds = mcmc::ColVec_t(2); s6.upper_bounds = mcmc::ColVec_t(2);
+    s6.lower_bounds(0) = -std::numeric_limits<double>::infinity(); s6.lower_bounds(1) = 0.01;
+    s6.upper_bounds(0) = std::numeric_limits<double>::infinity(); s6.upper_bounds(1) = std::numeric_limits<double>::infinity();
+    s6.rmhmc_settings.step_size = 0.02;                  // (n_leap_steps = 1, n_fp_steps = 5: the struct's defaults, as in the device run above)
+    s6.rmhmc_settings.n_burnin_draws = 100; s6.rmhmc_settings.n_keep_draws = 200;
     mcmc::Mat_t drm;
-    const bool refused = !mcmc::rmhmc(initial_val, log_target_dens, [](const mcmc::ColVec_t&, mcmc::Cube_t*, void*) { return mcmc::Mat_t(); },
-                                      drm, &dn, nullptr, s5);
-    std::printf("rmhmc with host callbacks refused=%d reason=\"%s\"\n", int(refused), mcmc::mi355x::last_error().c_str());
-    return (ok && ok2 && okm && okn && okw && refused) ? 0 : 1;
+    const bool okr = mcmc::rmhmc(init2, normal_ll, normal_tensor, drm, &nd, &nd, s6);
+    std::printf("callback rmhmc ok=%d rows=%zu cols=%zu mean_mu=%.4f mean_sigma=%.4f acc=%.3f grad_calls=%d value_calls=%d tensor_calls=%d reason=\"%s\"\n",
+                int(okr), size_t(drm.rows()), size_t(drm.cols()), okr ? col_mean(drm, 0) : 0.0, okr ? col_mean(drm, 1) : 0.0,
+                double(s6.rmhmc_settings.n_accept_draws) / 200.0, nd.n_grad, nd.n_value, nd.n_tensor, okr ? "" : mcmc::mi355x::last_error().c_str());
+    // mixing the routes (a device target with a host tensor) is refused with a reason, never run on the CPU
+    const bool refused = !mcmc::rmhmc(init2, mcmc::mi355x::device_kernel, normal_tensor, drm, &nm, &nd, s6);
+    std::printf("rmhmc with mixed routes refused=%d reason=\"%s\"\n", int(refused), mcmc::mi355x::last_error().c_str());
+    return (ok && ok2 && okm && okn && okw && okr && refused) ? 0 : 1;
 }

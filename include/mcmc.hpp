@@ -509,6 +509,26 @@ rwmh_impl(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals
     return ok;
 }
 
+struct tensor_callback_ctx { const tensor_fn_t* fn; void* user; size_t d; };
+
+// tensor_fn(vals_inp, tensor_deriv_out, tensor_data) -> d*d row-major tensor and, when asked for, the d matrices dG/dvals_i
+inline void tensor_callback_trampoline(const double* vals, double* tensor_out, double* deriv_out, void* p)
+{
+    tensor_callback_ctx* ctx = static_cast<tensor_callback_ctx*>(p);
+    const size_t d = ctx->d;
+    ColVec_t v(d);
+    for (size_t i = 0; i < d; ++i) v(i) = vals[i];
+    Cube_t cube;
+    if (deriv_out) cube.setZero(d, d, d);                              // pre-sized like src/rmhmc.cpp:187
+    const Mat_t G = (*ctx->fn)(v, deriv_out ? &cube : nullptr, ctx->user);
+    for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < d; ++j) tensor_out[i * d + j] = G(i, j);
+    if (deriv_out)
+        for (size_t k = 0; k < d; ++k)
+            for (size_t i = 0; i < d; ++i)
+                for (size_t j = 0; j < d; ++j) deriv_out[(k * d + i) * d + j] = cube.mat(k)(i, j);
+}
+
 inline bool
 rmhmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,
            void* target_data, void* tensor_data, algo_settings_t* settings_inp)
@@ -516,11 +536,30 @@ rmhmc_impl(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tens
     // ref: src/rmhmc.cpp:30-287
     algo_settings_t settings;
     if (settings_inp) settings = *settings_inp;
-    (void)tensor_data;
-    if (!mi355x::is_device_route(target_log_kernel) || !mi355x::is_device_route(tensor_fn)) {
-        mi355x::last_error() = "mcmc::rmhmc: host std::function target / tensor callbacks are not implemented on the device path; pass "
-                               "mcmc::mi355x::device_kernel and device_tensor with a mi355x::target_t (no CPU fallback)";
+    if (mi355x::is_device_route(target_log_kernel) != mi355x::is_device_route(tensor_fn)) {
+        mi355x::last_error() = "mcmc::rmhmc: target_log_kernel and tensor_fn must both be host callbacks or both the device route "
+                               "(mcmc::mi355x::device_kernel and device_tensor with a mi355x::target_t)";
         return false;
+    }
+    if (!mi355x::is_device_route(target_log_kernel)) {
+        // host std::function callbacks (the reference's own contract): the sampler runs on the device and asks the host for every
+        // evaluation (mi_mcmc_rmhmc_run_callback)
+        const size_t d = size_t(initial_vals.size());
+        mi_settings m = flatten_common(settings);
+        m.n_burnin_draws = settings.rmhmc_settings.n_burnin_draws;
+        m.n_keep_draws = settings.rmhmc_settings.n_keep_draws;
+        m.n_leap_steps = settings.rmhmc_settings.n_leap_steps;
+        m.step_size = settings.rmhmc_settings.step_size;
+        m.n_fp_steps = settings.rmhmc_settings.n_fp_steps;
+        callback_ctx kctx{&target_log_kernel, target_data, d};
+        tensor_callback_ctx tctx{&tensor_fn, tensor_data, d};
+        draws_out.resize(m.n_keep_draws, d);
+        uint64_t nacc = 0;
+        const bool okc = mi_mcmc_rmhmc_run_callback(initial_vals.data(), d, &callback_trampoline, &kctx, &tensor_callback_trampoline, &tctx, &m,
+                                                    draws_out.data(), &nacc) == MI_OK;
+        if (!okc) mi355x::last_error() = mi_mcmc_last_error();
+        if (okc && settings_inp) settings_inp->rmhmc_settings.n_accept_draws = size_t(nacc);
+        return okc;
     }
     mi355x::target_t& tgt = *static_cast<mi355x::target_t*>(target_data);
     mi_settings m = flatten_common(settings);

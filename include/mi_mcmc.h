@@ -256,6 +256,18 @@ int mi_mcmc_rwmh_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
                               void* target_data, const mi_settings* settings, double* draws_out,
                               uint64_t* n_accept_draws);
 
+/* mcmc::rmhmc with HOST callbacks (ref: include/mcmc/rmhmc.hpp:44-63, src/rmhmc.cpp:30-287): target_log_kernel as above and the metric
+ * tensor tensor_fn(vals_inp, tensor_deriv_out, tensor_data) flattened: tensor_out is d*d row-major, tensor_deriv_out (NULL when not asked
+ * for) holds the d matrices dG/dvals_i at + i*d*d.  One chain (global chain id 0), d <= 64, bounds as in settings.  The sampler runs in ONE
+ * device kernel (the literal rmhmc of mi_mcmc_rmhmc_run); each callback is a request the kernel posts to a mailbox in pinned memory and
+ * this call serves on the calling thread until the kernel ends -- the callbacks are called exactly where the reference calls them
+ * (per fixed-point step: 1 gradient; per position fixed-point step: 1 tensor; per leapfrog step 1 tensor + derivative and 1 gradient more;
+ * 1 value per draw).  A request the host does not answer within 60 s makes the kernel give up (MI_ERR_HIP), never hang. */
+typedef void (*mi_tensor_cb)(const double* vals_inp, double* tensor_out, double* tensor_deriv_out /* NULL = tensor only */, void* tensor_data);
+int mi_mcmc_rmhmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel, void* target_data,
+                               mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
+                               uint64_t* n_accept_draws);
+
 /* ---- multi-GPU: one process per GPU.  Chains are independent (the reference runs one per call), so the path shards with no
  * data-path collective: rank r of world_size runs the global chains [chain0, chain0 + n_local) in its own mi_mcmc_*_run call
  * (mi_chains.chain0 = chain0; the Philox counter uses the global id, so the union of the shards is bit-identical to one call).

@@ -61,7 +61,7 @@ _lib = None
 
 EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target", "mi_mcmc_run_user_target_v", "mi_mcmc_run_tile_target",
-    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback",
+    "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback", "mi_mcmc_rmhmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
@@ -186,6 +186,22 @@ def hmc_mass_adapted_per_chain(target, settings, chains, n_windows=3, mass_out=N
     _check(lib().mi_mcmc_hmc_run_mass_adapted_per_chain(C.byref(target), C.byref(settings), C.byref(chains), C.c_uint32(n_windows),
                                                         C.c_double(first_step_size), C.c_void_p(_ptr(mass_out)), C.c_void_p(stream or 0)))
     return mass_out
+
+
+def rmhmc_callback(initial_vals, kernel_fn, kernel_data, tensor_fn, tensor_data, settings):
+    """mi_mcmc_rmhmc_run_callback: mcmc::rmhmc for one chain with HOST callbacks.  kernel_fn / tensor_fn: C function pointers (ctypes
+    function objects or raw addresses) with the signatures of mi_log_kernel_cb / mi_tensor_cb; *_data: addresses handed through.
+    Returns (draws [n_keep, d], n_accept)."""
+    x0 = np.ascontiguousarray(initial_vals, dtype=np.float64)
+    d, n_keep = int(x0.shape[0]), int(settings.n_keep_draws)
+    out = np.zeros((d, n_keep))                           # column-major n_keep x d
+    nacc = C.c_uint64(0)
+    def addr(f):
+        return f if isinstance(f, int) or f is None else C.cast(f, C.c_void_p).value
+    _check(lib().mi_mcmc_rmhmc_run_callback(C.c_void_p(x0.ctypes.data), C.c_uint64(d), C.c_void_p(addr(kernel_fn)), C.c_void_p(addr(kernel_data)),
+                                            C.c_void_p(addr(tensor_fn)), C.c_void_p(addr(tensor_data)), C.byref(settings),
+                                            C.c_void_p(out.ctypes.data), C.byref(nacc)))
+    return out.T.copy(), int(nacc.value)
 
 
 def last_kernel():

@@ -242,6 +242,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_sp
     static_assert(WPB == 4 || WPB == 8, "one or two waves per SIMD");
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
     stage_precision<NT>(prm.P, prm.d, lds_P);
+    // The waves of a workgroup run DIFFERENT instantiations of the body (their role h is a compile-time constant: register arrays
+    // indexed by it stay registers), each with its own __syncthreads() calls.  What makes that sound on gfx950: a workgroup barrier
+    // is the hardware's s_barrier, which counts arriving WAVES -- not program counters -- and every instantiation executes exactly the
+    // same sequence of barriers (exchange / chain_dot are called from wave-uniform, role-independent control flow: the draw loop, the
+    // leapfrog loop and the accept branch are uniform across the workgroup's waves by construction, all of them running n_total draws of
+    // n_leap_steps steps).  Within a wave every barrier is reached by all 64 lanes.  In the HIP model a barrier reached through
+    // block-divergent control flow is undefined, so this is an architecture assumption, not a language guarantee: it is pinned
+    // by the parity tests of every split shape (tests/test_gpu_parity_hmc.py, test_gpu_nonfinite.py: bit-exact against the oracle, and a
+    // mismatched barrier count hangs rather than passes), which run on every toolchain the library is built with.
     const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) % SPLIT);
     if constexpr (SPLIT == 2) {
         if (h == 0) hmc_split_body<NT, 2, WPB, 0>(prm, lds_P); else hmc_split_body<NT, 2, WPB, 1>(prm, lds_P);

@@ -29,7 +29,31 @@ namespace lit {
 constexpr double LIT_EPS_DBL = 2.220446049250313e-16;    // mcmc_options.hpp:103
 constexpr double LIT_LOG_2PI = 1.83787706640934548356;   // stats/mcmc_stats.hpp:28-30
 
-enum { LIT_ISO = 0, LIT_DIAG = 1, LIT_DENSE = 2, LIT_LOGISTIC = 3 };
+enum { LIT_ISO = 0, LIT_DIAG = 1, LIT_DENSE = 2, LIT_LOGISTIC = 3,
+       LIT_CALLBACK = 4 };   // the user's HOST callbacks (the reference's std::function contract): see LitMailbox
+
+// LIT_CALLBACK.  The target (and, for rmhmc, the metric tensor) is a function that can only run on the host, while the sampler's own
+// arithmetic runs here.  The kernel therefore ASKS: the workgroup writes the evaluation point into a mailbox in host-pinned, fine-grained
+// memory, thread 0 publishes a request number (release, system scope) and waits for the host's acknowledgement (acquire, system scope),
+// and the workgroup reads the value / gradient / tensor back.  The host side is a loop that serves requests while the kernel runs
+// (mi_mcmc.hip: serve_callbacks).  One chain, one workgroup.  A wait is bounded (timeout_ticks of the 100 MHz wall clock): after a
+// timeout the abort word is set, nothing is waited for any more, values become NaN, the kernel runs out and the host reports the error --
+// a host that died cannot hang the GPU.  In the HOST instantiation of this file (tests/lit_host.hip) the callbacks are simply called.
+typedef double (*lit_kernel_cb)(const double* vals, double* grad_out /* nullptr: value only */, void* data);
+typedef void (*lit_tensor_cb)(const double* vals, double* tensor_out /* d*d row-major */, double* deriv_out /* d*d*d: dG/dvals_i at + i*d*d, or nullptr */, void* data);
+enum { LIT_MB_REQ = 0, LIT_MB_ACK = 1, LIT_MB_KIND = 2, LIT_MB_WANT = 3, LIT_MB_ABORT = 4, LIT_MB_WORDS = 16 };
+enum { LIT_REQ_KERNEL = 1, LIT_REQ_TENSOR = 2 };
+struct LitMailbox {
+    uint32_t* ctl;           // [LIT_MB_WORDS] pinned: request number (device), acknowledged number (host), kind, want (gradient / derivative), abort
+    double* value;           // [1] pinned: the log kernel's value
+    double* x;               // [d] pinned: the evaluation point
+    double* out;             // [d] gradient, or [d*d] tensor followed by [d*d*d] derivative
+    uint64_t timeout_ticks;  // of the 100 MHz wall clock
+    lit_kernel_cb kernel;    // host instantiation only
+    lit_tensor_cb tensor;
+    void* kernel_data;
+    void* tensor_data;
+};
 
 struct LitTarget {
     int kind;
@@ -45,6 +69,7 @@ struct LitTarget {
     int nblk;                // > 1: dimension-blocked reductions, block size bs (the logistic kernels: 4 blocks of 16 NTQ)
     uint32_t bs;
     int eta_chains;          // LIT_LOGISTIC: sub-chains of eta inside a dimension block
+    LitMailbox mb;           // LIT_CALLBACK
 };
 
 struct LitParams {
@@ -354,10 +379,51 @@ MI_HD double lit_log_jacobian(const LitParams& p, const double* v)
 
 // ---- the target: value (returned, same bits in every thread) and, when grad != nullptr, the gradient of the log kernel.
 // w: d doubles of scratch; rows: 2 n_rows doubles of scratch (logistic).  x / grad / w / rows distinct.
+// one request to the host (LIT_CALLBACK): the point goes out, the answer comes back; see LitMailbox.  Returns false after an abort.
+MI_HD bool mailbox_call(const Par& par, const LitTarget& t, const double* x, uint32_t kind, bool want)
+{
+    const uint32_t d = t.d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    LIT_PFOR(i, d) t.mb.x[i] = x[i];
+    __threadfence_system();
+    par.sync();
+    if (par.tid == 0) {
+        const uint32_t seq = t.mb.ctl[LIT_MB_REQ] + 1u;      // (only this thread ever writes the request word)
+        t.mb.ctl[LIT_MB_KIND] = kind; t.mb.ctl[LIT_MB_WANT] = want ? 1u : 0u;
+        if (t.mb.ctl[LIT_MB_ABORT] == 0u) {
+            __hip_atomic_store(&t.mb.ctl[LIT_MB_REQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint64_t t0 = wall_clock64();
+            bool ok = false;
+            while (true) {
+                if (__hip_atomic_load(&t.mb.ctl[LIT_MB_ACK], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) { ok = true; break; }
+                if (wall_clock64() - t0 > t.mb.timeout_ticks) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (!ok) __hip_atomic_store(&t.mb.ctl[LIT_MB_ABORT], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    par.sync();
+    return __hip_atomic_load(&t.mb.ctl[LIT_MB_ABORT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u;
+#else
+    for (uint32_t i = 0; i < d; ++i) t.mb.x[i] = x[i];
+    if (kind == LIT_REQ_KERNEL) *t.mb.value = t.mb.kernel(t.mb.x, want ? t.mb.out : nullptr, t.mb.kernel_data);
+    else t.mb.tensor(t.mb.x, t.mb.out, want ? t.mb.out + (size_t)d * d : nullptr, t.mb.tensor_data);
+    (void)par;
+    return true;
+#endif
+}
+
 MI_HD double target_eval(const Par& par, const LitTarget& t, const double* x, double* grad, double* w, double* rows)
 {
     const uint32_t d = t.d;
     switch (t.kind) {
+    case LIT_CALLBACK: {                                    // the reference's target_log_kernel(vals_inp, grad_out, target_data), on the host
+        const bool ok = mailbox_call(par, t, x, LIT_REQ_KERNEL, grad != nullptr);
+        if (grad) { LIT_PFOR(i, d) grad[i] = ok ? t.mb.out[i] : lit_nan(); }
+        const double r = ok ? *t.mb.value : lit_nan();
+        par.sync();                                         // the mailbox may be reused by the caller's next request
+        return r;
+    }
     case LIT_ISO: {
         if (grad) { LIT_PFOR(i, d) grad[i] = -x[i]; par.sync(); }
         const double r = -0.5 * dot_b(t, x, x);
@@ -1025,6 +1091,13 @@ MI_HD void target_tensor(const Par& par, const LitTarget& t, const double* x, do
 {
     const uint32_t d = t.d;
     const size_t dd = (size_t)d * d;
+    if (t.kind == LIT_CALLBACK) {                           // the reference's tensor_fn(vals_inp, tensor_deriv_out, tensor_data), on the host
+        const bool ok = mailbox_call(par, t, x, LIT_REQ_TENSOR, dG != nullptr);
+        for (size_t e = (size_t)par.tid; e < dd; e += (size_t)par.nth) G[e] = ok ? t.mb.out[e] : lit_nan();
+        if (dG) { for (size_t e = (size_t)par.tid; e < dd * d; e += (size_t)par.nth) dG[e] = ok ? t.mb.out[dd + e] : lit_nan(); }
+        par.sync();
+        return;
+    }
     if (t.kind != LIT_LOGISTIC) {
         LIT_PFOR(e, dd) {
             const uint32_t i = (uint32_t)(e / d), j = (uint32_t)(e % d);

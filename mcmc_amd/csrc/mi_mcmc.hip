@@ -617,6 +617,42 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
 }
 
 
+// ---- mcmc::rmhmc with HOST callbacks (ref: include/mcmc/rmhmc.hpp: target_log_kernel and tensor_fn as std::function): one chain on
+// literal_kernel<4> with the LIT_CALLBACK target -- the kernel asks for every evaluation through a mailbox in pinned memory
+// (literal.hpp: LitMailbox), this thread serves the requests while the kernel runs.  Everything that is the sampler's own arithmetic
+// (fixed-point iterations, INV / CHOL_LOWER / LOG_DET of the metric, the d matrix products of mntm_update_fn, energies, the Metropolis
+// test) is on the device; what runs on the host is the user's code, as in the reference.
+namespace {
+struct PinnedBuf {
+    void* p = nullptr;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocCoherent); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+// serve the kernel's requests until the stream is idle; returns the number of requests served
+uint64_t serve_callbacks(const mi::lit::LitMailbox& mb, uint32_t d, mi_log_kernel_cb kcb, void* kdata, mi_tensor_cb tcb, void* tdata, hipStream_t st)
+{
+    uint32_t served = 0;
+    uint64_t n = 0;
+    unsigned idle = 0;
+    for (;;) {
+        const uint32_t req = __atomic_load_n(&mb.ctl[mi::lit::LIT_MB_REQ], __ATOMIC_ACQUIRE);
+        if (req != served) {
+            const bool want = mb.ctl[mi::lit::LIT_MB_WANT] != 0u;
+            if (mb.ctl[mi::lit::LIT_MB_KIND] == (uint32_t)mi::lit::LIT_REQ_KERNEL) *mb.value = kcb(mb.x, want ? mb.out : nullptr, kdata);
+            else tcb(mb.x, mb.out, want ? mb.out + (size_t)d * d : nullptr, tdata);
+            __atomic_store_n(&mb.ctl[mi::lit::LIT_MB_ACK], req, __ATOMIC_RELEASE);
+            served = req; ++n; idle = 0;
+            continue;
+        }
+        if ((++idle & 0xffu) == 0u && hipStreamQuery(st) != hipErrorNotReady) {     // the kernel has ended (or failed): one last look, then out
+            if (__atomic_load_n(&mb.ctl[mi::lit::LIT_MB_REQ], __ATOMIC_ACQUIRE) == served) break;
+        }
+    }
+    return n;
+}
+}  // namespace
+
 // hmc / rwmh on the logistic-regression target (identity preconditioner / cov_mat, no bounds): logit_lds_kernel<., HMC | RWMH>;
 // settings->step_size is the leapfrog step resp. par_scale
 int run_logit_plain(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -1373,6 +1409,65 @@ int mi_mcmc_hmc_run_mass_adapted_per_chain(const mi_target* target, const mi_set
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));                   // mass / slab are ours
+    return MI_OK;
+}
+
+int mi_mcmc_rmhmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel, void* target_data,
+                               mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
+                               uint64_t* n_accept_draws)
+{
+    if (!initial_vals || !target_log_kernel || !tensor_fn || !settings) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): null initial_vals / callbacks / settings");
+    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
+    if (d == 0 || d > (uint64_t)mi::lit::LIT_RMHMC_MAX_D)
+        return fail(MI_ERR_UNSUPPORTED, "rmhmc (callback): d = %llu outside 1 .. %d (two d x d x d derivative cubes per chain)", (unsigned long long)d, (int)mi::lit::LIT_RMHMC_MAX_D);
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds)) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): vals_bound needs lower_bounds and upper_bounds");
+    const uint64_t n_keep = settings->n_keep_draws, n_total = settings->n_burnin_draws + n_keep;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (n_keep > 0 && !draws_out) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): draws_out is required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    (void)hipGetLastError();
+    const size_t dd = (size_t)d * d;
+    PinnedBuf ctl, val, xb, outb;
+    HIP_TRY(ctl.alloc(mi::lit::LIT_MB_WORDS * sizeof(uint32_t))); HIP_TRY(val.alloc(8)); HIP_TRY(xb.alloc(d * 8)); HIP_TRY(outb.alloc((dd + dd * d) * 8));
+    std::memset(ctl.p, 0, mi::lit::LIT_MB_WORDS * sizeof(uint32_t));
+    mi::lit::LitParams lp{};
+    lp.t.kind = mi::lit::LIT_CALLBACK; lp.t.d = (uint32_t)d;
+    mi::lit::lit_orders(lp.t);
+    lp.t.mb.ctl = ctl.as<uint32_t>(); lp.t.mb.value = val.as<double>(); lp.t.mb.x = xb.as<double>(); lp.t.mb.out = outb.as<double>();
+    lp.t.mb.timeout_ticks = 60ull * 100000000ull;          // 60 s of the 100 MHz wall clock per request
+    DevBuf theta, draws, nacc, work;
+    HIP_TRY(theta.alloc(d * 8)); HIP_TRY(draws.alloc(n_keep * d * 8)); HIP_TRY(nacc.alloc(8));
+    const size_t stride = mi::lit::lit_work_doubles((uint32_t)d, 0, false, 0, false, true);
+    HIP_TRY(work.alloc(stride * 8));
+    HIP_TRY(hipMemcpy(theta.p, initial_vals, d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(nacc.p, 0, 8));
+    lp.C = 1; lp.chain0 = 0; lp.theta = theta.as<double>(); lp.draws = n_keep ? draws.as<double>() : nullptr; lp.n_accept = nacc.as<uint64_t>();
+    lp.seed = settings->rng_seed_value;
+    lp.n_burnin = (uint32_t)settings->n_burnin_draws; lp.n_keep = (uint32_t)n_keep; lp.n_leap_steps = (uint32_t)settings->n_leap_steps;
+    lp.eps = settings->step_size; lp.n_fp_steps = (uint32_t)settings->n_fp_steps;
+    lp.work = work.as<double>(); lp.work_stride = stride;
+    mi::lit::LitPrep prep;
+    mi::lit::lit_prepare(0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds, settings->upper_bounds, nullptr, prep);
+    LitDev ldev;
+    int rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    rc = launched("rmhmc (callback)", mi::launch_literal(4, lp, 1, st));
+    if (!rc) {
+        (void)serve_callbacks(lp.t.mb, (uint32_t)d, target_log_kernel, target_data, tensor_fn, tensor_data, st);
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(MI_ERR_HIP, "rmhmc (callback): %s", hipGetErrorString(e));
+        else if (ctl.as<uint32_t>()[mi::lit::LIT_MB_ABORT] != 0u) rc = fail(MI_ERR_HIP, "rmhmc (callback): the kernel gave up waiting for a callback (60 s)");
+    }
+    (void)hipStreamDestroy(st);
+    if (rc) return rc;
+    std::vector<double> rows(n_keep * d);
+    if (n_keep) HIP_TRY(hipMemcpy(rows.data(), draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_keep; ++i)
+        for (uint64_t j = 0; j < d; ++j) draws_out[i + j * n_keep] = rows[i * d + j];       // column-major n_keep x d, as Eigen's Mat_t stores draws_out
+    if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -68,7 +68,14 @@ def test_example_runs_on_the_gpu(tmp_path):
     mm = re.search(r"device rmhmc ok=1 rows=200 cols=128 acc0=(\S+) mu0=(\S+) sigma0=(\S+)", out.stdout)
     assert mm, out.stdout
     assert 0.2 < float(mm.group(1)) <= 1.0 and 1.5 < float(mm.group(2)) < 3.2 and 1.5 < float(mm.group(3)) < 3.2
-    assert "refused=1" in out.stdout and "not implemented on the device path" in out.stdout      # a reachable reason, no silent false
+    # mcmc::rmhmc with host std::function callbacks (examples/eigen/rmhmc_normal.cpp's flow): the data are N(2, 2^2)
+    mm = re.search(r"callback rmhmc ok=1 rows=200 cols=2 mean_mu=(\S+) mean_sigma=(\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+) tensor_calls=(\d+)", out.stdout)
+    assert mm, out.stdout
+    assert 1.5 < float(mm.group(1)) < 3.2 and 1.5 < float(mm.group(2)) < 3.2 and 0.2 < float(mm.group(3)) <= 1.0     # (as the device run above)
+    # the reference's callback pattern (src/rmhmc.cpp:199-272): per leapfrog step n_fp + 1 gradients and n_fp + 1 tensors; 1 value per
+    # draw; at setup 1 tensor and 1 value
+    assert int(mm.group(4)) == 300 * 1 * (5 + 1) and int(mm.group(5)) == 300 + 1 and int(mm.group(6)) == 300 * 1 * (5 + 1) + 1
+    assert "refused=1" in out.stdout and "must both be host callbacks or both the device route" in out.stdout   # a reachable reason, no silent false
     mm = re.search(r"callback rwmh ok=1 rows=4000 cols=3 mean=(\S+) (\S+) (\S+) acc=(\S+) value_calls=(\d+)", out.stdout)
     assert mm, out.stdout                                       # mcmc::rwmh with the host std::function (value only)
     assert np.abs([float(mm.group(i)) for i in (1, 2, 3)]).max() < 0.3 and 0.2 < float(mm.group(4)) <= 1.0
