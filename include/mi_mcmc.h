@@ -232,7 +232,7 @@ int mi_mcmc_hmc_run_mass_adapted_per_chain(const mi_target* target, const mi_set
  * flattened to a C function pointer. The callback runs on the host, called exactly where the
  * reference calls it (2 gradient calls per leapfrog step, 1 value call per draw, 1 at setup);
  * everything else of the draw loop runs on the GPU. draws_out: n_keep x d column-major
- * (element (i,j) at i + j*n_keep, as Eigen's Mat_t stores draws_out). Identity precond, unbounded. */
+ * (element (i,j) at i + j*n_keep, as Eigen's Mat_t stores draws_out). */
 typedef double (*mi_log_kernel_cb)(const double* vals_inp, double* grad_out /* NULL = value only */, void* target_data);
 int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
                              void* target_data, const mi_settings* settings, double* draws_out,
@@ -241,8 +241,9 @@ int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kern
 /* The same for mcmc::mala (mala.hpp:66-73: 3 gradient + 1 value callback per draw, src/mala.cpp:149-186 with
  * include/mcmc/mala.ipp:58-64) and mcmc::nuts (nuts.hpp:65-72: two gradient callbacks per leaf of the recursive
  * nuts_build_tree, one value callback per leaf and per accepted proposal; dual averaging; step_size_out = final step size,
- * may be NULL).  One chain (global chain id 0), identity precond_mat, unbounded; bit-identical to the device kernels run
- * on the same target. */
+ * may be NULL).  One chain (global chain id 0); bit-identical to the device kernels run on the same target.  With settings.vals_bound
+ * and / or settings.precond_mat these calls (and mi_mcmc_hmc_run_callback, mi_mcmc_rwmh_run_callback) run the literal kernel of the sampler
+ * with the callback as its target: one device kernel that asks the host for every evaluation (see mi_mcmc_rmhmc_run_callback). */
 int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel,
                               void* target_data, const mi_settings* settings, double* draws_out,
                               uint64_t* n_accept_draws);

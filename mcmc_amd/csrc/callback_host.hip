@@ -22,8 +22,9 @@ int mi_mcmc_hmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kern
 {
     if (!initial_vals || !cb || !settings || d == 0) return fail(MI_ERR_BAD_ARG, "null / empty argument");
     if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): vals_bound not implemented on the device path yet");
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "hmc(callback): precond_mat not implemented on the device path yet");
+    // bounds / precond_mat: the literal kernel with the callback as its target (the kernel asks the host; literal.hpp LIT_CALLBACK)
+    if (settings->vals_bound || settings->precond_mat)
+        return mi::host::literal_run_callback("hmc", 0, initial_vals, d, cb, target_data, nullptr, nullptr, settings, draws_out, n_accept_draws, nullptr);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
@@ -129,8 +130,6 @@ int callback_common_checks(const char* who, const double* initial_vals, uint64_t
 {
     if (!initial_vals || !cb || !settings || d == 0) return fail(MI_ERR_BAD_ARG, "%s(callback): null / empty argument", who);
     if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
-    if (settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "%s(callback): vals_bound is implemented for the device targets only", who);
-    if (settings->precond_mat) return fail(MI_ERR_UNSUPPORTED, "%s(callback): precond_mat is implemented for the device targets only", who);
     if (settings->n_keep_draws && !draws_out) return fail(MI_ERR_BAD_ARG, "draws_out is required");
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     int ndev = 0;
@@ -241,6 +240,8 @@ int mi_mcmc_mala_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
 {
     int rc = callback_common_checks("mala", initial_vals, d, cb, settings, draws_out);
     if (rc) return rc;
+    if (settings->vals_bound || settings->precond_mat)     // the literal kernel with the callback as its target (literal.hpp LIT_CALLBACK)
+        return mi::host::literal_run_callback("mala", 1, initial_vals, d, cb, target_data, nullptr, nullptr, settings, draws_out, n_accept_draws, nullptr);
     const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
     const double eps = settings->step_size, s2 = eps * eps, rs = 1.0 / s2;
     double log_det = 0.0;                                // LOG_DET(eps^2 I) = sum_i 2 log sqrt(s2), i ascending (oracle: orc_log_det_from_chol)
@@ -302,6 +303,8 @@ int mi_mcmc_rwmh_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
 {
     int rc = callback_common_checks("rwmh", initial_vals, d, cb, settings, draws_out);
     if (rc) return rc;
+    if (settings->vals_bound || settings->precond_mat)     // bounds / cov_mat: the literal kernel with the callback as its target
+        return mi::host::literal_run_callback("rwmh", 3, initial_vals, d, cb, target_data, nullptr, nullptr, settings, draws_out, n_accept_draws, nullptr);
     const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
     const double par_scale = settings->step_size;
     enum { PREV = 0, PROP, Z, NVEC };
@@ -344,6 +347,8 @@ int mi_mcmc_nuts_run_callback(const double* initial_vals, uint64_t d, mi_log_ker
 {
     int rc = callback_common_checks("nuts", initial_vals, d, cb, settings, draws_out);
     if (rc) return rc;
+    if (settings->vals_bound || settings->precond_mat)     // the literal kernel with the callback as its target (literal.hpp LIT_CALLBACK)
+        return mi::host::literal_run_callback("nuts", 2, initial_vals, d, cb, target_data, nullptr, nullptr, settings, draws_out, n_accept_draws, step_size_out);
     const uint64_t n_burnin = settings->n_burnin_draws, n_keep = settings->n_keep_draws, n_total = n_burnin + n_keep;
     const uint64_t n_adapt = settings->n_adapt_draws <= n_total ? settings->n_adapt_draws : n_total;      // nuts.cpp:54
     const uint64_t max_depth = settings->max_tree_depth;

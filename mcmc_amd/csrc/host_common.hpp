@@ -36,6 +36,12 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// One chain of `algo` (0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc) on the literal kernel with HOST callbacks as target (mi_mcmc.hip; the
+// kernel asks the host through a pinned mailbox): bounds, precond_mat / cov_mat, any max_tree_depth <= 30.  tensor_fn: rmhmc only.
+int literal_run_callback(const char* who, int algo, const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel, void* target_data,
+                         mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
+                         uint64_t* n_accept_draws, double* step_size_out);
+
 }  // namespace host
 }  // namespace mi
 

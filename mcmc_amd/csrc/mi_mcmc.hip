@@ -850,6 +850,88 @@ int run_small_logistic(const char* who, int algo, const mi_target* target, const
 
 }  // namespace
 
+namespace mi {
+namespace host {
+
+// One chain of `algo` (0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc) on the literal kernel with the HOST callbacks as target (LIT_CALLBACK,
+// literal.hpp): what mi_mcmc_rmhmc_run_callback is, and what the callback routes of the other samplers use for everything their
+// host-driven form does not implement (bounds, precond_mat / cov_mat, max_tree_depth > 10).  This thread serves the kernel's requests.
+int literal_run_callback(const char* who, int algo, const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel, void* target_data,
+                         mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
+                         uint64_t* n_accept_draws, double* step_size_out)
+{
+    if (!initial_vals || !target_log_kernel || !settings) return fail(MI_ERR_BAD_ARG, "%s (callback): null initial_vals / callback / settings", who);
+    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
+    if (d == 0 || d > 0x7fffffffULL) return fail(MI_ERR_BAD_ARG, "%s (callback): d out of range", who);
+    if (algo == 4 && d > (uint64_t)mi::lit::LIT_RMHMC_MAX_D)
+        return fail(MI_ERR_UNSUPPORTED, "rmhmc (callback): d = %llu outside 1 .. %d (two d x d x d derivative cubes per chain)", (unsigned long long)d, (int)mi::lit::LIT_RMHMC_MAX_D);
+    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds)) return fail(MI_ERR_BAD_ARG, "%s (callback): vals_bound needs lower_bounds and upper_bounds", who);
+    const bool mala_bounded = algo == 1 && settings->vals_bound != 0;
+    if (mala_bounded && d > 512) return fail(MI_ERR_UNSUPPORTED, "mala (callback): vals_bound with d > 512 is not implemented (ten d x d matrices per workgroup)");
+    if (algo == 2 && settings->max_tree_depth > (uint64_t)mi::lit::LIT_NUTS_MAX_DEPTH)
+        return fail(MI_ERR_UNSUPPORTED, "nuts (callback): max_tree_depth > %d not implemented", (int)mi::lit::LIT_NUTS_MAX_DEPTH);
+    const uint64_t n_keep = settings->n_keep_draws, n_total = settings->n_burnin_draws + n_keep;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (n_keep > 0 && !draws_out) return fail(MI_ERR_BAD_ARG, "%s (callback): draws_out is required", who);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
+    (void)hipGetLastError();
+    const size_t dd = (size_t)d * d;
+    PinnedBuf ctl, val, xb, outb;
+    HIP_TRY(ctl.alloc(mi::lit::LIT_MB_WORDS * sizeof(uint32_t))); HIP_TRY(val.alloc(8)); HIP_TRY(xb.alloc(d * 8));
+    HIP_TRY(outb.alloc((algo == 4 ? dd + dd * d : d) * 8));
+    std::memset(ctl.p, 0, mi::lit::LIT_MB_WORDS * sizeof(uint32_t));
+    mi::lit::LitParams lp{};
+    lp.t.kind = mi::lit::LIT_CALLBACK; lp.t.d = (uint32_t)d;
+    mi::lit::lit_orders(lp.t);
+    lp.t.mb.ctl = ctl.as<uint32_t>(); lp.t.mb.value = val.as<double>(); lp.t.mb.x = xb.as<double>(); lp.t.mb.out = outb.as<double>();
+    lp.t.mb.timeout_ticks = 60ull * 100000000ull;          // 60 s of the 100 MHz wall clock per request
+    DevBuf theta, draws, nacc, work, step;
+    HIP_TRY(theta.alloc(d * 8)); HIP_TRY(draws.alloc(n_keep * d * 8)); HIP_TRY(nacc.alloc(8)); HIP_TRY(step.alloc(8));
+    const size_t stride = mi::lit::lit_work_doubles((uint32_t)d, 0, mala_bounded, (uint32_t)settings->max_tree_depth, algo == 2, algo == 4);
+    HIP_TRY(work.alloc(stride * 8));
+    HIP_TRY(hipMemcpy(theta.p, initial_vals, d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(nacc.p, 0, 8)); HIP_TRY(hipMemset(step.p, 0, 8));
+    lp.C = 1; lp.chain0 = 0; lp.theta = theta.as<double>(); lp.draws = n_keep ? draws.as<double>() : nullptr; lp.n_accept = nacc.as<uint64_t>();
+    lp.seed = settings->rng_seed_value;
+    lp.n_burnin = (uint32_t)settings->n_burnin_draws; lp.n_keep = (uint32_t)n_keep; lp.n_leap_steps = (uint32_t)settings->n_leap_steps;
+    lp.eps = settings->step_size; lp.n_fp_steps = (uint32_t)settings->n_fp_steps;
+    lp.work = work.as<double>(); lp.work_stride = stride;
+    if (algo == 2) {
+        lp.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+        lp.max_depth = (uint32_t)settings->max_tree_depth;
+        lp.delta = settings->target_accept_rate; lp.gamma = settings->gamma_val; lp.t0 = settings->t0_val; lp.kappa = settings->kappa_val;
+        lp.step_out = step.as<double>();
+    }
+    mi::lit::LitPrep prep;
+    mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds, settings->upper_bounds,
+                         algo == 4 ? nullptr : settings->precond_mat, prep);
+    LitDev ldev;
+    int rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    rc = launched(who, mi::launch_literal(algo, lp, 1, st));
+    if (!rc) {
+        (void)serve_callbacks(lp.t.mb, (uint32_t)d, target_log_kernel, target_data, tensor_fn, tensor_data, st);
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(MI_ERR_HIP, "%s (callback): %s", who, hipGetErrorString(e));
+        else if (ctl.as<uint32_t>()[mi::lit::LIT_MB_ABORT] != 0u) rc = fail(MI_ERR_HIP, "%s (callback): the kernel gave up waiting for a callback (60 s)", who);
+    }
+    (void)hipStreamDestroy(st);
+    if (rc) return rc;
+    std::vector<double> rows(n_keep * d);
+    if (n_keep) HIP_TRY(hipMemcpy(rows.data(), draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_keep; ++i)
+        for (uint64_t j = 0; j < d; ++j) draws_out[i + j * n_keep] = rows[i * d + j];       // column-major n_keep x d, as Eigen's Mat_t stores draws_out
+    if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
+    if (step_size_out && algo == 2) HIP_TRY(hipMemcpy(step_size_out, step.p, 8, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+}  // namespace host
+}  // namespace mi
+
 extern "C" {
 
 void mi_settings_default(mi_settings* s)
@@ -1416,59 +1498,9 @@ int mi_mcmc_rmhmc_run_callback(const double* initial_vals, uint64_t d, mi_log_ke
                                mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
                                uint64_t* n_accept_draws)
 {
-    if (!initial_vals || !target_log_kernel || !tensor_fn || !settings) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): null initial_vals / callbacks / settings");
-    if (settings->struct_size != sizeof(mi_settings)) return fail(MI_ERR_BAD_ARG, "struct_size mismatch");
-    if (d == 0 || d > (uint64_t)mi::lit::LIT_RMHMC_MAX_D)
-        return fail(MI_ERR_UNSUPPORTED, "rmhmc (callback): d = %llu outside 1 .. %d (two d x d x d derivative cubes per chain)", (unsigned long long)d, (int)mi::lit::LIT_RMHMC_MAX_D);
-    if (settings->vals_bound && (!settings->lower_bounds || !settings->upper_bounds)) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): vals_bound needs lower_bounds and upper_bounds");
-    const uint64_t n_keep = settings->n_keep_draws, n_total = settings->n_burnin_draws + n_keep;
-    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
-    if (n_keep > 0 && !draws_out) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): draws_out is required");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU path");
-    (void)hipGetLastError();
-    const size_t dd = (size_t)d * d;
-    PinnedBuf ctl, val, xb, outb;
-    HIP_TRY(ctl.alloc(mi::lit::LIT_MB_WORDS * sizeof(uint32_t))); HIP_TRY(val.alloc(8)); HIP_TRY(xb.alloc(d * 8)); HIP_TRY(outb.alloc((dd + dd * d) * 8));
-    std::memset(ctl.p, 0, mi::lit::LIT_MB_WORDS * sizeof(uint32_t));
-    mi::lit::LitParams lp{};
-    lp.t.kind = mi::lit::LIT_CALLBACK; lp.t.d = (uint32_t)d;
-    mi::lit::lit_orders(lp.t);
-    lp.t.mb.ctl = ctl.as<uint32_t>(); lp.t.mb.value = val.as<double>(); lp.t.mb.x = xb.as<double>(); lp.t.mb.out = outb.as<double>();
-    lp.t.mb.timeout_ticks = 60ull * 100000000ull;          // 60 s of the 100 MHz wall clock per request
-    DevBuf theta, draws, nacc, work;
-    HIP_TRY(theta.alloc(d * 8)); HIP_TRY(draws.alloc(n_keep * d * 8)); HIP_TRY(nacc.alloc(8));
-    const size_t stride = mi::lit::lit_work_doubles((uint32_t)d, 0, false, 0, false, true);
-    HIP_TRY(work.alloc(stride * 8));
-    HIP_TRY(hipMemcpy(theta.p, initial_vals, d * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(nacc.p, 0, 8));
-    lp.C = 1; lp.chain0 = 0; lp.theta = theta.as<double>(); lp.draws = n_keep ? draws.as<double>() : nullptr; lp.n_accept = nacc.as<uint64_t>();
-    lp.seed = settings->rng_seed_value;
-    lp.n_burnin = (uint32_t)settings->n_burnin_draws; lp.n_keep = (uint32_t)n_keep; lp.n_leap_steps = (uint32_t)settings->n_leap_steps;
-    lp.eps = settings->step_size; lp.n_fp_steps = (uint32_t)settings->n_fp_steps;
-    lp.work = work.as<double>(); lp.work_stride = stride;
-    mi::lit::LitPrep prep;
-    mi::lit::lit_prepare(0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds, settings->upper_bounds, nullptr, prep);
-    LitDev ldev;
-    int rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
-    if (rc) return rc;
-    hipStream_t st = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    rc = launched("rmhmc (callback)", mi::launch_literal(4, lp, 1, st));
-    if (!rc) {
-        (void)serve_callbacks(lp.t.mb, (uint32_t)d, target_log_kernel, target_data, tensor_fn, tensor_data, st);
-        const hipError_t e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = fail(MI_ERR_HIP, "rmhmc (callback): %s", hipGetErrorString(e));
-        else if (ctl.as<uint32_t>()[mi::lit::LIT_MB_ABORT] != 0u) rc = fail(MI_ERR_HIP, "rmhmc (callback): the kernel gave up waiting for a callback (60 s)");
-    }
-    (void)hipStreamDestroy(st);
-    if (rc) return rc;
-    std::vector<double> rows(n_keep * d);
-    if (n_keep) HIP_TRY(hipMemcpy(rows.data(), draws.p, n_keep * d * 8, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n_keep; ++i)
-        for (uint64_t j = 0; j < d; ++j) draws_out[i + j * n_keep] = rows[i * d + j];       // column-major n_keep x d, as Eigen's Mat_t stores draws_out
-    if (n_accept_draws) HIP_TRY(hipMemcpy(n_accept_draws, nacc.p, 8, hipMemcpyDeviceToHost));
-    return MI_OK;
+    if (!tensor_fn) return fail(MI_ERR_BAD_ARG, "rmhmc (callback): null tensor_fn");
+    return mi::host::literal_run_callback("rmhmc", 4, initial_vals, d, target_log_kernel, target_data, tensor_fn, tensor_data, settings, draws_out,
+                                          n_accept_draws, nullptr);
 }
 
 int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)

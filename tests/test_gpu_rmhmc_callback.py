@@ -68,3 +68,33 @@ def test_rmhmc_callback_route_validates_its_arguments():
         mcmc_amd.rmhmc_callback(np.zeros(3), None, None, tens, C.addressof(t.c), st)
     with pytest.raises(mcmc_amd.MiMcmcError):
         mcmc_amd.rmhmc_callback(np.zeros(65), kern, C.addressof(t.c), tens, C.addressof(t.c), st)
+
+
+# ---- the same mailbox under the other samplers: a host callback target together with bounds / precond_mat (cov_mat) runs on the literal
+# kernel with the callback as its target (round 2 refused these combinations; ref: src/hmc.cpp:57-59,84-95,107-122, src/mala.cpp:152-157,
+# src/nuts.cpp:139-154, src/rwmh.cpp:58,119)
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh"])
+@pytest.mark.parametrize("general", ["bounds", "diag_precond", "bounds_dense_precond"])
+def test_host_callback_target_with_bounds_and_preconditioner_equals_the_oracle(algo, general):
+    d = 7
+    X, y = synth.logistic_problem(d, 25, seed=8)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4)
+    rng = np.random.default_rng(3)
+    init = np.clip(synth.initial_states(1, d, seed=6)[0] * 0.3, -1.0, 1.5)
+    kw, okw = {}, {}
+    if "bounds" in general:
+        lb = np.where(np.arange(d) % 3 == 0, -1.5, -np.inf); ub = np.where(np.arange(d) % 4 == 1, 2.0, np.inf)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    if "precond" in general:
+        M = np.diag(rng.uniform(0.5, 2.0, d))
+        if "dense" in general:
+            A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
+        kw.update(precond_mat=M); okw.update(precond=M)
+    st = mcmc_amd.default_settings(rng_seed_value=14, n_burnin_draws=3, n_keep_draws=7, n_leap_steps=4, step_size=0.15, n_adapt_draws=3,
+                                   max_tree_depth=4, **kw)
+    draws, nacc = mcmc_amd.hmc_callback(init, orc.lib().orc_target_kernel, st, target_data=C.addressof(t.c), algo=algo)
+    assert mcmc_amd.last_kernel() == "literal_kernel<%d>" % {"hmc": 0, "mala": 1, "nuts": 2, "rwmh": 3}[algo]
+    s = orc.make_settings(seed=14, n_burnin=3, n_keep=7, n_leap=4, step=0.15, n_adapt=3, max_depth=4, W=4, **okw)
+    o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init[None, :], s)
+    assert np.array_equal(draws, o_draws[:, :, 0]) and nacc == int(o["n_accept"][0])
+    assert nacc > 0 or (algo == "nuts" and np.isfinite(draws).all())      # (a short adapting nuts run may keep its state)
