@@ -44,7 +44,7 @@ WORKLOADS = {
     2: dict(algo="hmc", d=128, chains=65536, n_leap_steps=16, step_size=0.05, n_burnin_draws=100, n_keep_draws=100, seed=2024,
             name="BASELINE configs[1]: mcmc::hmc, d=128 dense-precision Gaussian (P=AA^T/d+I), analytic grad, fp64",
             metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=128 correlated Gaussian, 65536 chains",
-            unit="chain*dim*leapfrog-steps/s", kernel="hmc_gauss_mfma_kernel<8, 8>", bound="mfma"),
+            unit="chain*dim*leapfrog-steps/s", kernel="hmc_gauss_mfma_kernel<8, 8, false, false, false>", bound="mfma"),
     3: dict(algo="mala", d=512, n_rows=1024, chains=262144, step_size=0.02, n_burnin_draws=100, n_keep_draws=100, seed=6,
             name="BASELINE configs[2]: mcmc::mala, d=512 Bayesian logistic regression (N=1024 synthetic rows), fp64",
             metric="MALA draws/sec (chains*dims*draws/s), d=512 logistic regression, 262144 chains",
@@ -52,7 +52,7 @@ WORKLOADS = {
     4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
             name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
             metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",
-            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_reg_kernel<8>", bound="mfma"),
+            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_reg_kernel<8, false>", bound="mfma"),
     5: dict(algo="hmc", d=1024, chains=131072, n_leap_steps=32, step_size=0.005, n_burnin_draws=20, n_keep_draws=8, seed=8,
             name="BASELINE configs[4], one GPU's shard: mcmc::hmc, d=1024 diagonal Gaussian (cond 1e4), 131072 of 2^20 chains, fp64",
             metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=1024 ill-conditioned Gaussian, 131072 chains per GPU",

@@ -146,7 +146,7 @@ typedef struct mi_chains {
 void        mi_settings_default(mi_settings* s);
 const char* mi_mcmc_last_error(void);
 /* Name of the kernel the calling thread's last mi_mcmc_*_run spent its time in, as rocprofv3 prints it (e.g.
- * "hmc_gauss_mfma_kernel<8, 8, false, false>"); "" before the first call.  Kernel choice is automatic (mi_target.kernel_hint
+ * "hmc_gauss_mfma_kernel<8, 8, false, false, false>"); "" before the first call.  Kernel choice is automatic (mi_target.kernel_hint
  * overrides it): this is how a measurement names what actually ran. */
 const char* mi_mcmc_last_kernel(void);
 int         mi_mcmc_version(void);

@@ -16,7 +16,7 @@ int general(const HmcParams& prm, hipStream_t st)
     auto kern = hmc_gauss_mfma_kernel<NT, WPB, true, DENSE_M>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
-    note_kernel("hmc_gauss_mfma_kernel<%d, %d, true, %s>", NT, WPB, DENSE_M ? "true" : "false");
+    note_kernel("hmc_gauss_mfma_kernel<%d, %d, true, %s, false>", NT, WPB, DENSE_M ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
     return (int)hipGetLastError();
 }

@@ -15,7 +15,7 @@ int plain(const HmcParams& prm, hipStream_t st)
     auto kern = hmc_gauss_mfma_kernel<NT, WPB>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
-    note_kernel("hmc_gauss_mfma_kernel<%d, %d, false, false>", NT, WPB);
+    note_kernel("hmc_gauss_mfma_kernel<%d, %d, false, false, false>", NT, WPB);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
     return (int)hipGetLastError();
 }
@@ -41,7 +41,7 @@ int plain4(const HmcParams& prm, hipStream_t st)
     const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double);
     auto kern = hmc_gauss_mfma_kernel<NT, 4>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    note_kernel("hmc_gauss_mfma_kernel<%d, 4, false, false>", NT);
+    note_kernel("hmc_gauss_mfma_kernel<%d, 4, false, false, false>", NT);
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();
 }
