@@ -48,7 +48,7 @@ WORKLOADS = {
     3: dict(algo="mala", d=512, n_rows=1024, chains=262144, step_size=0.02, n_burnin_draws=100, n_keep_draws=100, seed=6,
             name="BASELINE configs[2]: mcmc::mala, d=512 Bayesian logistic regression (N=1024 synthetic rows), fp64",
             metric="MALA draws/sec (chains*dims*draws/s), d=512 logistic regression, 262144 chains",
-            unit="chain*dim*draws/s", kernel="logit_lds_kernel<8, MALA>", bound="mfma"),
+            unit="chain*dim*draws/s", kernel="logit_lds_kernel<8, 0, 0, false>", bound="mfma"),
     4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
             name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
             metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",

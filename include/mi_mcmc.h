@@ -206,7 +206,7 @@ int mi_mcmc_rmhmc_run(const mi_target* target, const mi_settings* settings, mi_c
  * of the burn-in.  Each part is an ordinary mi_mcmc_hmc_run call with that diagonal precond_mat (bit-exact against the oracle
  * given the mass, tests/test_gpu_mass_adapt.py) chained through mi_chains.draw0, so the whole run is reproducible; the kept
  * draws use the last estimate, returned in mass_diag_out[d] (host, may be NULL).  step_size is in the preconditioned metric
- * (every dimension near unit scale).  Gaussian targets (any d for the separable ones, d <= 128 dense); settings->precond_mat
+ * (every dimension near unit scale).  Gaussian targets (any d) and the logistic-regression target; settings->precond_mat
  * must be NULL; a dimension whose pooled variance is 0 or not finite keeps mass 1. */
 int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* settings, mi_chains* chains, uint32_t n_windows,
                                  double* mass_diag_out, void* stream);

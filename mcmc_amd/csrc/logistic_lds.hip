@@ -15,9 +15,12 @@ size_t ws_doubles(uint32_t NB, uint64_t C, int target)
     return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0);
 }
 
-template <int NTQ, int ALGO, int TARGET>
+template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
 int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
+    if constexpr (ALGO == LOGIT_HMC && !DIAGM) {            // a diagonal precond_mat: the same launch with the DIAGM instantiation
+        if (prm.m_sqrt != nullptr) return launch<NTQ, ALGO, TARGET, true>(prm, X_dev, y_dev, workspace, st);
+    }
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (prm.C + 31) / 32;
     double* xp = static_cast<double*>(workspace);
@@ -25,9 +28,8 @@ int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* wor
     prm.xexch = (TARGET == LOGIT_TARGET_DENSE) ? prm.state + n_wg * 8 * 2 * G::NSQ * 64 : nullptr;
     prm.Xp = xp;
     hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, TARGET == LOGIT_TARGET_DENSE>), dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
-    auto kern = logit_lds_kernel<NTQ, ALGO, TARGET>;
-    if (TARGET == LOGIT_TARGET_DENSE) note_kernel("logit_lds_kernel<%d, %d, dense>", NTQ, ALGO);
-    else note_kernel("logit_lds_kernel<%d, %d>", NTQ, ALGO);
+    auto kern = logit_lds_kernel<NTQ, ALGO, TARGET, DIAGM>;
+    note_kernel("logit_lds_kernel<%d, %d, %d, %s>", NTQ, ALGO, TARGET, DIAGM ? "true" : "false");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);

@@ -72,7 +72,10 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
     }
 }
 
-template <int NTQ, int ALGO, int TARGET>
+// DIAGM (hmc): a DIAGONAL precond_mat without bounds (hmc.cpp:57-59,158-160,171,184): p = sqrt(m) z, theta += eps (p / m), K = p.(p / m) / 2,
+// the two tables read from global memory where they are used (LDS is full of X).  The reference's dense `inv_precond_matrix * mntm` is
+// handled like the identity's: the non-finite regime is detected through the energies and replayed by literal.hpp with the same tables.
+template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
 {
     using G = LogitGeo<NTQ>;
@@ -118,6 +121,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         uint32_t j = (uint32_t)j4;
         asm volatile("" : "+v"(j));
         return (uint32_t)(q * DQ + 4 * s) + j;
+    };
+
+    // DIAGM: entry of slice s of a mass table for this lane -- wave-uniform base + an opaque lane offset (re-loaded where it is used: as
+    // loop invariants the 2 NSQ entries would be spilled; global, not flat, loads).  The tables are padded to 64 NTQ entries with ones.
+    [[maybe_unused]] auto mass_at = [&](const double* tab, int s) __attribute__((always_inline)) -> double {
+        uint32_t off = (uint32_t)j4 * 8u;
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab + (q * DQ + 4 * s)) + off);
     };
 
     // per-lane LDS offsets of this wave's fragments inside a block image
@@ -617,7 +628,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             double v[2];
             double a = 0.0;
 #pragma unroll
-            for (int s = 0; s < NSQ; ++s) a = dfma(pm[s], pm[s], a);
+            for (int s = 0; s < NSQ; ++s) {
+                if constexpr (DIAGM) a = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], a);
+                else a = dfma(pm[s], pm[s], a);
+            }
             a = a + __shfl_xor(a, 32);
             a = a + __shfl_xor(a, 16);
             v[0] = a; v[1] = 0.0;
@@ -633,6 +647,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                 if constexpr (!(ablate & 64u)) rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1); else { z0 = 0.5; z1 = -0.5; }
                 pm[2 * m] = (dim_of(2 * m) < d) ? z0 : 0.0;
                 pm[2 * m + 1] = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                if constexpr (DIAGM) {                       // p = L z with a diagonal L (:158)
+                    pm[2 * m] = mass_at(prm.m_sqrt, 2 * m) * pm[2 * m];
+                    pm[2 * m + 1] = mass_at(prm.m_sqrt, 2 * m + 1) * pm[2 * m + 1];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -644,7 +662,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
 #pragma unroll
                 for (int s = 0; s < NSQ; ++s) {
                     pm[s] = pm[s] + (eps * gp[s]) / 2.0; // first half-step (:126)
-                    bp[s] = bp[s] + eps * pm[s];         // (:171)
+                    if constexpr (DIAGM) bp[s] = bp[s] + eps * (mass_at(prm.m_inv, s) * pm[s]);   // (:171) theta += eps Minv p
+                    else bp[s] = bp[s] + eps * pm[s];    // (:171)
                 }
                 evaluate(bp, gp, lp);
 #pragma unroll

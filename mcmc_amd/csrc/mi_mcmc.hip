@@ -404,6 +404,7 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
+        if (prm.m_sqrt != nullptr) { lp.precond = 1; lp.m_sqrt = prm.m_sqrt; lp.m_inv = prm.m_inv; }      // hmc with a diagonal precond_mat
         return launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
     }
     return MI_OK;
@@ -653,6 +654,26 @@ uint64_t serve_callbacks(const mi::lit::LitMailbox& mb, uint32_t d, mi_log_kerne
 }
 }  // namespace
 
+// a diagonal precond_mat for the LDS-streamed hmc kernels: sqrt(m) and 1 / m on the device, padded with ones to 512 entries
+struct DiagMass { DevBuf ms, mi; };
+int diag_mass_upload(const mi_settings* settings, uint64_t d, DiagMass& t)
+{
+    std::vector<double> ms(512, 1.0), mi_(512, 1.0);
+    for (uint64_t i = 0; i < d; ++i) { const double v = settings->precond_mat[i * d + i]; ms[i] = __builtin_sqrt(v); mi_[i] = 1.0 / v; }
+    HIP_TRY(t.ms.alloc(512 * 8)); HIP_TRY(t.mi.alloc(512 * 8));
+    HIP_TRY(hipMemcpy(t.ms.p, ms.data(), 512 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.mi.p, mi_.data(), 512 * 8, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+bool precond_is_diagonal(const mi_settings* settings, uint64_t d)
+{
+    if (!settings->precond_mat) return false;
+    for (uint64_t i = 0; i < d; ++i)
+        for (uint64_t k = 0; k < d; ++k)
+            if (i != k && settings->precond_mat[i * d + k] != 0.0) return false;
+    return true;
+}
+
 // hmc / rwmh on the logistic-regression target (identity preconditioner / cov_mat, no bounds): logit_lds_kernel<., HMC | RWMH>;
 // settings->step_size is the leapfrog step resp. par_scale
 int run_logit_plain(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -683,6 +704,11 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.n_leap = (uint32_t)settings->n_leap_steps;
     q.eps = settings->step_size;
     q.draw0 = (uint32_t)chains->draw0;
+    DiagMass dm;
+    if (algo == mi::LOGIT_HMC && settings->precond_mat) {      // (the caller routed a DIAGONAL matrix without bounds here)
+        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
+        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
+    }
     rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
@@ -690,7 +716,7 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (Xo.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -727,6 +753,11 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
         q.s2 = s2; q.rs = 1.0 / s2; q.log_det = log_det;
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
     }
+    DiagMass dm;
+    if (algo == mi::LOGIT_HMC && settings->precond_mat) {      // (the caller routed a DIAGONAL matrix without bounds here)
+        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
+        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
+    }
     rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
@@ -734,7 +765,7 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (P_owned.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -1071,7 +1102,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     }
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
-        if (settings->vals_bound || settings->precond_mat)
+        // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation: two tables read from global memory)
+        const bool diag_alone = !settings->vals_bound && precond_is_diagonal(settings, d) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+        if ((settings->vals_bound || settings->precond_mat) && !diag_alone)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("hmc", 0, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
         return d <= 512 ? run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
     }
@@ -1095,8 +1128,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     }
     // beyond d = 128 the tiled kernels serve separable targets without bounds (identity or diagonal precond_mat: hmc_diag.hpp);
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
-    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
-        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp)
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && (!settings->precond_mat || !dense_m))
+        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -1350,8 +1383,9 @@ int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* set
     int rc = check_common(target, settings, chains);
     if (rc) return rc;
     if (settings->precond_mat) return fail(MI_ERR_BAD_ARG, "hmc (mass adapted): settings.precond_mat must be NULL, the mass matrix is estimated");
-    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
-        return fail(MI_ERR_UNSUPPORTED, "hmc (mass adapted): implemented for the Gaussian targets (a diagonal precond_mat on the device path)");
+    if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE &&
+        target->kind != MI_TARGET_LOGISTIC)
+        return fail(MI_ERR_UNSUPPORTED, "hmc (mass adapted): implemented for the Gaussian and the logistic-regression targets (a diagonal precond_mat on the device path)");
     if (chains->n_chains < 2) return fail(MI_ERR_BAD_ARG, "hmc (mass adapted): the mass is pooled over the chains, at least 2 are needed");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d, C = chains->n_chains;

@@ -187,3 +187,35 @@ def test_per_chain_adaptation_validates_its_arguments():
             mcmc_amd.hmc_mass_adapted_per_chain(t, mcmc_amd.default_settings(**bad), mcmc_amd.make_chains(th.copy(), C), n_windows=2)
     with pytest.raises(mcmc_amd.MiMcmcError):
         mcmc_amd.hmc_mass_adapted_per_chain(t, mcmc_amd.default_settings(n_burnin_draws=30, n_keep_draws=2), mcmc_amd.make_chains(th.copy(), C), n_windows=0)
+
+
+def test_pooled_mass_adaptation_on_the_logistic_regression_target():
+    """configs[2]'s target family with badly scaled features (column scales 0.1 .. 10: posterior scales differ by two orders of magnitude).
+    hmc with a diagonal precond_mat alone runs on the LDS-staged kernel (its DIAGM instantiation), so the pooled mass adaptation works on
+    this target at its own dimensions; the last part is an ordinary hmc run with the reported mass (bit-exact against the oracle)."""
+    d, N, C, burn, keep, L = 48, 200, 1024, 60, 40, 8
+    X, y = synth.logistic_problem(d, N, seed=5)
+    X = X * np.logspace(-1, 1, d)[None, :] * np.sqrt(d)
+    t = mcmc_amd.make_target(mcmc_amd.TARGET_LOGISTIC, d, X=X, y=y)
+    init = synth.initial_states(C, d, seed=3) * 0.05
+    def run(n_windows, eps):
+        theta = np.ascontiguousarray(init.T.copy()); draws = np.zeros((keep, d, C)); nacc = np.zeros(C, dtype=np.uint64)
+        st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps)
+        mass = mcmc_amd.hmc_mass_adapted(t, st, mcmc_amd.make_chains(theta, C, draws=draws, n_accept=nacc), n_windows=n_windows)
+        return draws, nacc, mass
+    draws, nacc, mass = run(3, 0.25)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().endswith("true>")
+    assert np.isfinite(mass).all() and mass.max() / mass.min() > 50           # it found the scales
+    ess_adapted = ess_per_chain(draws).min()
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=0.02)
+    plain, gp = mcmc_amd.hmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    ess_plain = ess_per_chain(plain).min()
+    print(f"logistic d={d}: min ESS per chain over {keep} draws: identity mass (eps 0.02) {ess_plain:.2f}, pooled diagonal mass (eps 0.25) {ess_adapted:.1f}; "
+          f"accept {nacc.mean() / keep:.2f} / {gp['n_accept'].mean() / keep:.2f}")
+    assert ess_adapted > 3 * ess_plain and nacc.mean() / keep > 0.5
+    # no window: one ordinary run with the mass from the spread of initial_vals -- the oracle reproduces it
+    d0, n0, m0 = run(0, 0.05)
+    bs = 16
+    s = orc.make_settings(seed=5, n_burnin=burn, n_keep=keep, n_leap=L, step=0.05, W=4, hoist=1, precond=np.diag(m0), blocks=4, block_size=bs)
+    o, info = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=bs, eta_chains=2), init[:64], s)
+    assert np.array_equal(d0[:, :, :64], o) and np.array_equal(n0[:64], info["n_accept"])

@@ -33,7 +33,7 @@ def test_dense_gaussian_streamed_through_lds_equals_the_oracle(algo, eps, d):
     C = 45                                              # one full workgroup of 32 chains + a ragged one
     init = synth.initial_states(C, d, seed=d + 1) * 0.5
     g_draws, g, o_draws, o, kern = _run(algo, d, C, eps, init, chain0=11)
-    assert kern.startswith("logit_lds_kernel<") and "dense" in kern, kern
+    assert kern.startswith("logit_lds_kernel<") and kern.split(",")[2].strip() == "1", kern        # TARGET = dense Gaussian
     assert 0 < o["n_accept"].sum()
     assert np.array_equal(g["n_accept"], o["n_accept"])
     assert np.array_equal(g_draws, o_draws)
@@ -68,3 +68,41 @@ def test_dense_gaussian_beyond_d128_recovers_the_covariance():
     v = g_draws[0].var(axis=1)                         # [d] over chains
     assert np.all(np.abs(v / np.diag(cov) - 1.0) < 0.15)
     assert g["n_accept"].mean() > 0.5
+
+
+# ---- hmc with a DIAGONAL precond_mat alone on the LDS-streamed kernels (their DIAGM instantiation; ref: src/hmc.cpp:57-59,158-160,171,184):
+# the dense Gaussian of this file and the logistic-regression target they were written for
+@pytest.mark.parametrize("d", [160, 256, 400, 512])
+def test_dense_gaussian_hmc_with_a_diagonal_precond_mat(d):
+    C = 40
+    prec = synth.dense_gaussian_precision(d, seed=d % 89)
+    M = np.diag(np.random.default_rng(d).uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=d + 1) * 0.5
+    init[5] *= 1e200; init[9, 3] = np.inf                 # two chains leave the finite regime: replayed literally with the same matrix
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=2, n_keep_draws=5, n_leap_steps=4, step_size=0.04, precond_mat=M)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=11)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.endswith("1, true>"), kern
+    s = orc.make_settings(seed=3, n_burnin=2, n_keep=5, n_leap=4, step=0.04, W=4, hoist=1, precond=M, **_blk(d))
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)), init, s, chain0=11)
+    assert o["n_accept"].sum() > 0
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+@pytest.mark.parametrize("d,N", [(9, 20), (40, 33), (130, 64), (512, 100)])
+def test_logistic_hmc_with_a_diagonal_precond_mat(d, N):
+    C = 40
+    X, y = synth.logistic_problem(d, N, seed=5)
+    M = np.diag(np.random.default_rng(d).uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=8) * 0.3
+    init[5] *= 1e200; init[9, 3] = np.inf
+    bs = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    st = mcmc_amd.default_settings(rng_seed_value=12, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=3, step_size=0.1, precond_mat=M)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.endswith("0, true>"), kern
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=bs, eta_chains=2)
+    s = orc.make_settings(seed=12, n_burnin=2, n_keep=4, n_leap=3, step=0.1, W=4, hoist=1, precond=M, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    assert o["n_accept"].sum() > 0
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
