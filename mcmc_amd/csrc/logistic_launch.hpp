@@ -25,6 +25,8 @@ struct LogitParams {
     uint32_t* nf_flag;      // [C + 1] or nullptr: chains that reached the non-finite regime are flagged and left to literal.hpp
     const double* m_sqrt;   // hmc with a DIAGONAL precond_mat (no bounds): diagonal of CHOL_LOWER(M) and of INV(M) on the device, PADDED with ones to 512 entries, or nullptr = identity
     const double* m_inv;
+    const double* m;        // mala with a diagonal precond_mat: its diagonal and the diagonal of INV(eps^2 M) (padded likewise); m_sqrt as above
+    const double* s_inv;
     double* xexch;          // dense Gaussian target only: [chain tile][4 NSQ][64] the position of an evaluation, shared by the tile's four waves
 };
 

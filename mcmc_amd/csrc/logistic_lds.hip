@@ -18,7 +18,7 @@ size_t ws_doubles(uint32_t NB, uint64_t C, int target)
 template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
 int launch(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
-    if constexpr (ALGO == LOGIT_HMC && !DIAGM) {            // a diagonal precond_mat: the same launch with the DIAGM instantiation
+    if constexpr ((ALGO == LOGIT_HMC || ALGO == LOGIT_MALA) && !DIAGM) {    // a diagonal precond_mat: the same launch with the DIAGM instantiation
         if (prm.m_sqrt != nullptr) return launch<NTQ, ALGO, TARGET, true>(prm, X_dev, y_dev, workspace, st);
     }
     using G = LogitGeo<NTQ>;

@@ -72,8 +72,9 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
     }
 }
 
-// DIAGM (hmc): a DIAGONAL precond_mat without bounds (hmc.cpp:57-59,158-160,171,184): p = sqrt(m) z, theta += eps (p / m), K = p.(p / m) / 2,
-// the two tables read from global memory where they are used (LDS is full of X).  The reference's dense `inv_precond_matrix * mntm` is
+// DIAGM (hmc, mala): a DIAGONAL precond_mat without bounds (hmc.cpp:57-59,158-160,171,184: p = sqrt(m) z, theta += eps (p / m),
+// K = p.(p / m) / 2; mala.cpp:57-58,123,159 with mala.ipp:58-64: mean = x + eps^2 (m grad) / 2, noise eps sqrt(m) z, INV(eps^2 M) diagonal),
+// the tables read from global memory where they are used (LDS is full of X).  The reference's dense `inv_precond_matrix * mntm` is
 // handled like the identity's: the non-finite regime is detected through the energies and replayed by literal.hpp with the same tables.
 template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
@@ -521,8 +522,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                         for (int h = 0; h < RG; ++h) {
                             const double za = (dim_of(2 * (mm + h)) < d) ? zz[2 * h] : 0.0;
                             const double zb = (dim_of(2 * (mm + h) + 1) < d) ? zz[2 * h + 1] : 0.0;
+                            if constexpr (DIAGM) {       // mean = x + eps^2 (M grad) / 2 (:123), proposal = mean + eps (sqrt(M) z) (:159), M diagonal
+                                const int sa = 2 * (mm + h), sb = sa + 1;
+                                bp[sa] = (be_c[2 * (m + h)] + (s2 * (mass_at(prm.m, sa) * gr_c[2 * (m + h)])) / 2.0) + eps * (mass_at(prm.m_sqrt, sa) * za);
+                                bp[sb] = (be_c[2 * (m + h) + 1] + (s2 * (mass_at(prm.m, sb) * gr_c[2 * (m + h) + 1])) / 2.0) + eps * (mass_at(prm.m_sqrt, sb) * zb);
+                            } else {
                             bp[2 * (mm + h)] = (be_c[2 * (m + h)] + (s2 * gr_c[2 * (m + h)]) / 2.0) + eps * za;           // :123, :159
                             bp[2 * (mm + h) + 1] = (be_c[2 * (m + h) + 1] + (s2 * gr_c[2 * (m + h) + 1]) / 2.0) + eps * zb;
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -551,12 +558,22 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                     for (int i = 0; i < SB; ++i) {
                         const int s = s0 + i;
                         const double be = be_c[i], gr = gr_c[i];
+                        if constexpr (DIAGM) {           // Sigma = eps^2 M: INV(Sigma)_ii from the host (s_inv), the means with M grad
+                            const double mi_ = mass_at(prm.m, s), si_ = mass_at(prm.s_inv, s);
+                            const double mean_prop = bp[s] + (s2 * (mi_ * gp[s])) / 2.0;
+                            const double xa = be - mean_prop;
+                            qa = dfma(xa, si_ * xa, qa);
+                            const double mean_prev = be + (s2 * (mi_ * gr)) / 2.0;
+                            const double xb = bp[s] - mean_prev;
+                            qb = dfma(xb, si_ * xb, qb);
+                        } else {
                         const double mean_prop = bp[s] + (s2 * gp[s]) / 2.0;
                         const double xa = be - mean_prop;    // dmvnorm.hpp:37
                         qa = dfma(xa, rs * xa, qa);
                         const double mean_prev = be + (s2 * gr) / 2.0;
                         const double xb = bp[s] - mean_prev;
                         qb = dfma(xb, rs * xb, qb);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -404,7 +404,9 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
-        if (prm.m_sqrt != nullptr) { lp.precond = 1; lp.m_sqrt = prm.m_sqrt; lp.m_inv = prm.m_inv; }      // hmc with a diagonal precond_mat
+        if (prm.m_sqrt != nullptr) {                     // a diagonal precond_mat (hmc: m_sqrt, m_inv; mala: m, m_sqrt, s_inv)
+            lp.precond = 1; lp.m = prm.m; lp.m_sqrt = prm.m_sqrt; lp.m_inv = prm.m_inv; lp.sinv_diag = prm.s_inv;
+        }
         return launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
     }
     return MI_OK;
@@ -665,6 +667,23 @@ int diag_mass_upload(const mi_settings* settings, uint64_t d, DiagMass& t)
     HIP_TRY(hipMemcpy(t.mi.p, mi_.data(), 512 * 8, hipMemcpyHostToDevice));
     return MI_OK;
 }
+// mala with a diagonal precond_mat on the LDS-streamed kernels: m, sqrt(m), INV(eps^2 M) (padded to 512) and LOG_DET(eps^2 M), all in the
+// oracle's operation order (literal_host.hpp: lit_prepare)
+struct MalaDiagMass { DevBuf m, ms, sinv; double log_det = 0.0; };
+int mala_diag_mass_upload(const mi_settings* settings, uint64_t d, MalaDiagMass& t, mi::LogitParams& q)
+{
+    mi::lit::LitPrep prep;
+    mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+    std::vector<double> m(512, 1.0), ms(512, 1.0), si(512, 1.0);
+    for (uint64_t i = 0; i < d; ++i) { m[i] = prep.m[i]; ms[i] = prep.m_sqrt[i]; si[i] = prep.sinv_diag[i]; }
+    HIP_TRY(t.m.alloc(512 * 8)); HIP_TRY(t.ms.alloc(512 * 8)); HIP_TRY(t.sinv.alloc(512 * 8));
+    HIP_TRY(hipMemcpy(t.m.p, m.data(), 512 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.ms.p, ms.data(), 512 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.sinv.p, si.data(), 512 * 8, hipMemcpyHostToDevice));
+    q.m = t.m.as<double>(); q.m_sqrt = t.ms.as<double>(); q.s_inv = t.sinv.as<double>();
+    q.log_det = prep.log_det;
+    return MI_OK;
+}
 bool precond_is_diagonal(const mi_settings* settings, uint64_t d)
 {
     if (!settings->precond_mat) return false;
@@ -754,10 +773,12 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
     }
     DiagMass dm;
+    MalaDiagMass mdm;
     if (algo == mi::LOGIT_HMC && settings->precond_mat) {      // (the caller routed a DIAGONAL matrix without bounds here)
         if ((rc = diag_mass_upload(settings, d, dm))) return rc;
         q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
     }
+    if (algo == mi::LOGIT_MALA && settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }
     rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
@@ -765,7 +786,7 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (P_owned.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (P_owned.p || dm.ms.p || mdm.m.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -1545,7 +1566,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     const uint64_t d = target->d;
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("mala", 1, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat))
+    // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation)
+    const bool mala_diag_alone = !settings->vals_bound && precond_is_diagonal(settings, d) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+    if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat) && !mala_diag_alone)
         return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("mala", 1, target, settings, chains, st) : run_literal("mala", 1, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC && d > 512) return run_literal("mala", 1, target, settings, chains, st);
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
@@ -1581,19 +1604,21 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
         q.log_det = log_det_;
         q.draw0 = (uint32_t)chains->draw0;
+        MalaDiagMass mdm;
+        if (settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }     // (diagonal, no bounds: routed above)
         rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st, settings, &sc.dev);
         if (rc) return rc;
         rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
         if (rc) return rc;
         rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
         if (rc) return rc;
-        if (Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+        if (Xo.p || mdm.m.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
         return MI_OK;
     }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
-    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
-        return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && (!settings->precond_mat || precond_is_diagonal(settings, d)))
+        return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat
     if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;

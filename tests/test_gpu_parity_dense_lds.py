@@ -106,3 +106,30 @@ def test_logistic_hmc_with_a_diagonal_precond_mat(d, N):
     o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
     assert o["n_accept"].sum() > 0
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+@pytest.mark.parametrize("target,d", [("dense", 160), ("dense", 512), ("logit", 9), ("logit", 130), ("logit", 512)])
+def test_mala_with_a_diagonal_precond_mat_on_the_streamed_kernels(target, d):
+    """ref: src/mala.cpp:57-58,123,159 with include/mcmc/mala.ipp:58-64: mean = x + eps^2 (M grad) / 2, noise eps sqrt(M) z, dmvnorm with
+    Sigma = eps^2 M (INV and LOG_DET from the host in the oracle's operation order) -- M diagonal, no bounds."""
+    C = 40
+    M = np.diag(np.random.default_rng(d + 1).uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=d + 2) * 0.3
+    init[5] *= 1e200; init[9, 3] = np.inf
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=2, n_keep_draws=6, step_size=0.05, precond_mat=M)
+    if target == "dense":
+        prec = synth.dense_gaussian_precision(d, seed=d % 89)
+        g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+        t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)); blk = _blk(d)
+    else:
+        X, y = synth.logistic_problem(d, 40, seed=5)
+        g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+        bs = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+        blk = dict(blocks=4, block_size=bs)
+        t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, eta_chains=2, **blk)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.endswith("true>"), kern
+    s = orc.make_settings(seed=7, n_burnin=2, n_keep=6, step=0.05, W=4, hoist=1, precond=M, **blk)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s)
+    assert o["n_accept"].sum() > 0
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
