@@ -27,12 +27,14 @@ def sweep(n_cases=60, seed=1, verbose=True):
         algo = ["hmc", "mala", "nuts", "rwmh"][case % 4]
         tgt = rng.choice(["dense", "iso", "diag", "logit"] if algo in ("hmc", "mala", "rwmh") else ["dense", "iso", "diag"])
         d = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 128])) if tgt != "logit" else int(rng.choice([3, 17, 64, 65, 130, 300]))
+        if tgt == "dense" and rng.random() < 0.3: d = int(rng.choice([129, 192, 200, 256, 300, 384, 385, 512]))    # P streamed through LDS (hmc / mala / rwmh), literal (nuts, bounds, dense M)
         C = int(rng.choice([1, 3, 16, 17, 33, 70]))
         rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
         burn, keep = int(rng.integers(0, 4)), int(rng.integers(1, 7))
         eps = float(rng.choice([0.01, 0.05, 0.2, 0.7, 1.5]))
         L = int(rng.integers(0, 6))
-        general = tgt != "logit" and rng.random() < 0.4
+        general = rng.random() < (0.4 if tgt != "logit" else 0.3)
+        if d > 128 and algo == "mala": general = general and rng.random() < 0.5
         kw, okw = {}, {}
         prec = X = y = None
         if tgt == "dense": prec, kg, ko = synth.dense_gaussian_precision(d, seed=rseed % 97), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
@@ -45,8 +47,10 @@ def sweep(n_cases=60, seed=1, verbose=True):
         if algo in ("hmc", "mala", "nuts") and rng.random() < 0.15:      # the non-finite regime: chains that blow up or start non-finite
             eps = float(rng.choice([30.0, 1.0e5, 1.0e160]))
             if rng.random() < 0.5: init[int(rng.integers(0, C)), int(rng.integers(0, d))] = float(rng.choice([np.inf, -np.inf, np.nan]))
+        big = d > 128
+        if big and general: C = min(C, 3)                  # (the literal kernels and the CPU oracle are O(d^2) .. O(d^3) per step and chain)
         if general:
-            if rng.random() < 0.7:
+            if rng.random() < (0.7 if not (big and algo == "mala") and tgt != "logit" else 0.25) and not (big and algo == "mala"):
                 lb, ub = bounds(d); kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
                 init = np.clip(init, -1.0, 1.5)
             if rng.random() < 0.6 or not kw:
@@ -55,6 +59,9 @@ def sweep(n_cases=60, seed=1, verbose=True):
                     A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
                 kw.update(precond_mat=M); okw.update(precond=M)
         tkw = {}
+        if tgt == "dense" and d > 128:                      # dot products over the streamed kernel's four dimension quarters
+            dq = 48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128
+            tkw = dict(blocks=4, block_size=dq); okw.update(blocks=4, block_size=dq)
         if tgt == "logit":
             dq = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
             tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
