@@ -49,6 +49,112 @@ def _gather_ragged(local, c_local, n_chains_total, world, group, comm_dev):
     return torch.cat(parts, dim=-1)
 
 
+def _copy_settings(settings, **fields):
+    """A by-value copy of a ctypes mi_settings (the arrays it points to stay owned by the original)."""
+    c = type(settings).from_buffer_copy(settings)
+    c._keep = getattr(settings, "_keep", None)
+    for k, v in fields.items():
+        setattr(c, k, v)
+    return c
+
+
+def _gather_start(local, c_local, n_chains_total, world, group, comm_dev):
+    """The asynchronous half of _gather_ragged: returns (work, recv, lead, c_max); finish with _gather_finish."""
+    import torch
+    import torch.distributed as dist
+    c_max = shard_bounds(n_chains_total, world, 0)[1]
+    lead = tuple(local.shape[:-1])
+    send = torch.zeros(lead + (c_max,), dtype=local.dtype, device=comm_dev)
+    if c_local:
+        send[..., :c_local] = local.to(comm_dev)
+    recv = torch.empty((world,) + lead + (c_max,), dtype=local.dtype, device=comm_dev)
+    flat = recv.view((world * lead[0],) + lead[1:] + (c_max,)) if lead else recv.view(world * c_max)
+    work = dist.all_gather_into_tensor(flat, send, group=group, async_op=True)
+    return work, recv, send
+
+
+def _gather_finish(started, n_chains_total, world):
+    import torch
+    work, recv, _send = started
+    work.wait()
+    parts = [recv[r][..., :shard_bounds(n_chains_total, world, r)[1]] for r in range(world)]
+    return torch.cat(parts, dim=-1)
+
+
+def run_sharded_overlapped(algo, kind, init_fn, n_chains_total, settings, n_chunks, runner=None, group=None, device=None, **target_kw):
+    """run_sharded with the collation OVERLAPPED with the sampling ("or per kept-draw slab, overlapped with the next
+    trajectory"): the kept draws are produced in n_chunks consecutive calls chained through mi_chains.draw0 (bit-identical to one
+    call: tests/test_gpu_resume.py), and the all-gather of chunk k's slab is issued asynchronously -- RCCL runs it on its own stream --
+    while chunk k + 1 samples.  hmc / mala / rwmh, and nuts when its adaptation window lies inside the burn-in (a nuts continuation must
+    start after it and takes the adapted step sizes back in).  runner: as in run_sharded, and it must accept draw0= (and step_size_in=
+    for nuts) and return info['theta'] = the chains' last state [d, C_r].  Returns (draws [n_keep, d, C], n_accept [C]) on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    n_keep, n_burn = int(settings.n_keep_draws), int(settings.n_burnin_draws)
+    n_chunks = max(1, min(int(n_chunks), n_keep))
+    if algo == "nuts" and int(settings.n_adapt_draws) > n_burn:
+        raise ValueError("run_sharded_overlapped: nuts needs n_adapt_draws <= n_burnin_draws (a continuation starts after the adaptation window)")
+    if algo == "rmhmc":
+        raise ValueError("run_sharded_overlapped: rmhmc is not chained through draw0")
+    engine = runner is None
+    dev = bind_device(device) if engine else None
+    if engine:
+        import mcmc_amd
+        if dev is None:
+            raise mcmc_amd.MiMcmcError(mcmc_amd.MI_ERR_NO_DEVICE, "run_sharded_overlapped: no GPU visible and no runner given (no CPU path)")
+        runner = lambda a, k, init, st, chain0=0, **kw: mcmc_amd.sample_device(a, k, init, st, chain0=chain0, device=dev, **kw)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    chain0, c_local = shard_bounds(n_chains_total, world, rank)
+    nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+    comm_dev = dev if (nccl and dev is not None) else torch.device("cpu")
+    bounds = [(n_keep * i) // n_chunks for i in range(n_chunks + 1)]
+    state = init_fn(chain0, c_local) if c_local > 0 else None
+    eps_in = None
+    acc = None
+    started, locals_ = [], []
+    d = None
+    for i in range(n_chunks):
+        s_i = _copy_settings(settings, n_burnin_draws=(n_burn if i == 0 else 0), n_keep_draws=bounds[i + 1] - bounds[i])
+        kw = dict(target_kw)
+        if i > 0:
+            kw["draw0"] = n_burn + bounds[i]
+            if algo == "nuts":
+                kw["step_size_in"] = eps_in
+        slab = None
+        if c_local > 0:
+            slab, info = runner(algo, kind, state, s_i, chain0=chain0, **kw)
+            th = info["theta"]
+            state = th.t() if hasattr(th, "t") and not isinstance(th, np.ndarray) else np.ascontiguousarray(np.asarray(th).T)
+            eps_in = info.get("eps")
+            a = info["n_accept"]
+            a = a if hasattr(a, "device") and not isinstance(a, np.ndarray) else torch.from_numpy(np.asarray(a).astype(np.int64))
+            acc = a.clone() if acc is None else acc + a
+            slab = slab if hasattr(slab, "device") and not isinstance(slab, np.ndarray) else torch.from_numpy(np.ascontiguousarray(slab))
+            d = slab.shape[1]
+        if world == 1:
+            locals_.append(slab)
+            continue
+        if d is None or i == 0:                       # the slab's chain-independent shape: from rank 0, which always has chains
+            d_t = torch.tensor([d or 0], dtype=torch.int64).to(comm_dev)
+            dist.broadcast(d_t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            d = int(d_t.item())
+        if slab is None:
+            slab = torch.zeros((bounds[i + 1] - bounds[i], d, 0), dtype=torch.float64, device=comm_dev)
+        started.append(_gather_start(slab, c_local, n_chains_total, world, group, comm_dev))    # runs while the next chunk samples
+    if world == 1:
+        draws = torch.cat(locals_, dim=0)
+        return (draws, acc) if engine else (draws.numpy(), acc.numpy())
+    if acc is None:
+        acc = torch.zeros(0, dtype=torch.int64, device=comm_dev)
+    all_draws = torch.cat([_gather_finish(st_, n_chains_total, world) for st_ in started], dim=0)
+    all_acc = _gather_ragged(acc, c_local, n_chains_total, world, group, comm_dev)
+    if engine:
+        return all_draws.to(dev), all_acc.to(dev)
+    return all_draws.numpy(), all_acc.numpy()
+
+
 def run_sharded(algo, kind, init_fn, n_chains_total, settings, runner=None, collate=True, group=None, device=None,
                 **target_kw):
     """Every rank samples its shard; draws are all-gathered when `collate`.

@@ -32,6 +32,25 @@ draws, nacc = mdist.run_sharded("hmc", None, init_fn, C_total, st, runner=runner
 # more ranks than chains: rank 1's shard is empty, it must still join the collectives (and get the full result)
 draws1, nacc1 = mdist.run_sharded("hmc", None, init_fn, 1, st, runner=runner)
 assert draws1.shape == (5, d, 1) and nacc1.shape == (1,)
+# overlapped collation: the kept draws in chunks chained through draw0, chunk k gathered while chunk k + 1 "samples".  The runner is a
+# deterministic map of (global chain id, draw index), so any slip in the chunk bookkeeping (draw0, carried state, shard offsets) shows.
+def fake(algo, kind, init, settings, chain0=0, draw0=0, **kw):
+    x = np.array(init, dtype=np.float64, copy=True)
+    b, k = int(settings.n_burnin_draws), int(settings.n_keep_draws)
+    cid = chain0 + np.arange(x.shape[0])[:, None]
+    rows, nacc_ = np.zeros((k, x.shape[1], x.shape[0])), np.zeros(x.shape[0], dtype=np.int64)
+    for t in range(draw0, draw0 + b + k):
+        x = 0.5 * x + np.sin(0.1 * cid + t + np.arange(x.shape[1])[None, :])
+        if t - draw0 >= b:
+            rows[t - draw0 - b] = x.T
+            nacc_ += ((cid[:, 0] + t) % 3 == 0)
+    return rows, dict(n_accept=nacc_, theta=x.T.copy(), eps=None)
+st2 = orc.make_settings(seed=1, n_burnin=4, n_keep=11, n_leap=1, step=0.1, W=4)
+ov_draws, ov_nacc = mdist.run_sharded_overlapped("hmc", None, init_fn, C_total, st2, 4, runner=fake)
+one_draws, one_info = fake("hmc", None, init_fn(0, C_total), st2)
+assert np.array_equal(ov_draws, one_draws) and np.array_equal(ov_nacc, one_info["n_accept"])
+ov1, ov1n = mdist.run_sharded_overlapped("hmc", None, init_fn, 1, st2, 3, runner=fake)       # rank 1's shard is empty
+assert np.array_equal(ov1, one_draws[:, :, :1]) and ov1n[0] == one_info["n_accept"][0]
 if dist.get_rank() == 0:
     np.savez(sys.argv[2], draws=draws, nacc=nacc, draws1=draws1, nacc1=nacc1)
 if dist.get_rank() == 1:

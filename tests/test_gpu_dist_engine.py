@@ -35,6 +35,16 @@ for name, kind, d, C_total, L, eps, burn, keep, cond in [
     draws, nacc = mdist.run_sharded("hmc", kind, init_fn, C_total, st, prec=prec)
     assert draws.is_cuda and nacc.is_cuda and draws.shape == (keep, d, C_total)
     out[name + "_draws"] = draws.cpu().numpy(); out[name + "_nacc"] = nacc.cpu().numpy()
+# overlapped collation (run_sharded_overlapped): kept draws in chunks chained through draw0, chunk k all-gathered while chunk k + 1 samples
+prec = synth.dense_gaussian_precision(128)
+init_fn = lambda chain0, c: synth.initial_states(c, 128, seed=3, chain0=chain0)
+st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=6, n_keep_draws=10, n_leap_steps=16, step_size=0.05)
+draws, nacc = mdist.run_sharded_overlapped("hmc", mcmc_amd.TARGET_GAUSS_DENSE, init_fn, 4099, st, 3, prec=prec)
+assert draws.is_cuda and draws.shape == (10, 128, 4099)
+out["ov_hmc_draws"] = draws.cpu().numpy(); out["ov_hmc_nacc"] = nacc.cpu().numpy()
+stn = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=8, n_keep_draws=9, n_adapt_draws=8, max_tree_depth=5, step_size=0.1)
+draws, nacc = mdist.run_sharded_overlapped("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init_fn, 333, stn, 4, prec=prec)
+out["ov_nuts_draws"] = draws.cpu().numpy(); out["ov_nuts_nacc"] = nacc.cpu().numpy()
 np.savez(sys.argv[2] + f".rank{dist.get_rank()}.npz", **out)
 dist.barrier()
 dist.destroy_process_group()
@@ -72,3 +82,13 @@ def test_two_rank_engine_shards_collate_to_the_single_call_result_bitwise(tmp_pa
             assert np.array_equal(g[name + "_draws"], want), name
             assert np.array_equal(g[name + "_nacc"], info["n_accept"].astype(np.int64)), name
         assert info["n_accept"].sum() > 0
+
+    # the overlapped, chunked collation gives the same bytes as ONE call over all chains
+    prec = synth.dense_gaussian_precision(128)
+    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=6, n_keep_draws=10, n_leap_steps=16, step_size=0.05)
+    want, info = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, synth.initial_states(4099, 128, seed=3), st, prec=prec)
+    stn = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=8, n_keep_draws=9, n_adapt_draws=8, max_tree_depth=5, step_size=0.1)
+    wantn, infon = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, synth.initial_states(333, 128, seed=3), stn, prec=prec)
+    for k in (0, 1):
+        assert np.array_equal(got[k]["ov_hmc_draws"], want) and np.array_equal(got[k]["ov_hmc_nacc"], info["n_accept"].astype(np.int64))
+        assert np.array_equal(got[k]["ov_nuts_draws"], wantn) and np.array_equal(got[k]["ov_nuts_nacc"], infon["n_accept"].astype(np.int64))
