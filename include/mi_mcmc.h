@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000301
+#define MI_MCMC_VERSION 0x000302
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -131,11 +131,15 @@ typedef struct mi_chains {
     uint64_t  draw0;          /* index of this call's first draw in every chain's random stream: 0 for a fresh run; the
                                * n_burnin+n_keep of the call(s) before to CONTINUE them from their final theta -- the
                                * concatenation is then bit-identical to one long run (checkpoint / resume, chunked output).
-                               * nuts: a continuation must start strictly after the adaptation window (draw0 > n_adapt_draws:
-                               * draw n_adapt_draws itself still uses the last dual-averaging step, not epsilon_bar) and takes
-                               * the adapted step sizes back in through step_size; n_adapt_draws must be the same in every
-                               * call of one run, and a run whose first call is shorter than its adaptation window cannot
-                               * be continued (the dual-averaging state is not exported). */
+                               * nuts: a continuation takes the step sizes back in through step_size; n_adapt_draws must be the
+                               * same in every call of one run (it is the RUN's window); a continuation that starts at
+                               * draw0 <= n_adapt_draws (draw n_adapt_draws itself still uses the last dual-averaging step, not
+                               * epsilon_bar) also needs nuts_adapt_state below. */
+    double*   nuts_adapt_state; /* nuts, may be NULL: the dual-averaging state [3][C] (h, epsilon_bar, mu: src/nuts.cpp:174-176,294-302), written
+                               * at the end of every call.  With it (and step_size) a run can be cut ANYWHERE: a continuation that starts
+                               * inside or at the end of the adaptation window (0 < draw0 <= n_adapt_draws) reads it back and continues the
+                               * adaptation on the run's own schedule (draw indices are global: draw0 + i); the concatenation is
+                               * bit-identical to one long run.  Without it a continuation must start after the window, as before. */
     const double* mass_diag;  /* hmc only, may be NULL: PER-CHAIN diagonal mass matrices [d][C] (same memory space as theta) -- NOT a
                                * reference mode (the reference has one precond_mat per call, i.e. per chain: this is C calls of
                                * mcmc::hmc with precond_mat = diag(mass_diag[:, c]) in one launch).  settings.precond_mat must be

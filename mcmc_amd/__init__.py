@@ -48,7 +48,7 @@ class mi_chains(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mem", C.c_int32), ("n_chains", C.c_uint64),
                 ("chain0", C.c_uint64), ("theta", C.c_void_p), ("draws", C.c_void_p),
                 ("n_accept", C.c_void_p), ("step_size", C.c_void_p), ("n_leapfrogs", C.c_void_p),
-                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64), ("mass_diag", C.c_void_p)]
+                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64), ("nuts_adapt_state", C.c_void_p), ("mass_diag", C.c_void_p)]
 
 
 class MiMcmcError(RuntimeError):
@@ -155,14 +155,15 @@ def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST, kernel_hint=KE
 
 
 def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=None, n_leapfrogs=None,
-                nuts_depth=None, mem=MEM_HOST, draw0=0, mass_diag=None):
+                nuts_depth=None, mem=MEM_HOST, draw0=0, mass_diag=None, nuts_adapt_state=None):
     c = mi_chains()
     c.struct_size = C.sizeof(mi_chains)
     c.mem, c.n_chains, c.chain0, c.draw0 = mem, int(n_chains), int(chain0), int(draw0)
     c.theta, c.draws, c.n_accept = _ptr(theta), _ptr(draws), _ptr(n_accept)
     c.step_size, c.n_leapfrogs, c.nuts_depth = _ptr(step_size), _ptr(n_leapfrogs), _ptr(nuts_depth)
     c.mass_diag = _ptr(mass_diag)                         # hmc only: per-chain diagonal masses [d][C]
-    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth, mass_diag]
+    c.nuts_adapt_state = _ptr(nuts_adapt_state)           # nuts: dual-averaging state [3][C], in (continuation inside the window) / out
+    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth, mass_diag, nuts_adapt_state]
     return c
 
 
@@ -223,7 +224,7 @@ def run(algo, target, settings, chains, stream=None):
 
 
 def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0, step_size_in=None,
-           kernel_hint=KERNEL_AUTO):
+           kernel_hint=KERNEL_AUTO, adapt_state_in=None, want_adapt_state=False):
     """Host-buffer convenience: init is [C, d] (row per chain, like C calls of mcmc::<algo> with
     initial_vals = init[c]).  Returns draws [n_keep, d, C] and a dict of per-chain outputs."""
     init = np.ascontiguousarray(init, dtype=np.float64)
@@ -236,11 +237,14 @@ def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want
     eps = np.zeros(n_chains) if step_size_in is None else np.array(step_size_in, dtype=np.float64, copy=True)
     n_tot = int(settings.n_burnin_draws) + n_keep
     depth = np.zeros((n_tot, n_chains), dtype=np.uint32) if algo == "nuts" else None
+    adapt = None
+    if algo == "nuts" and (want_adapt_state or adapt_state_in is not None):    # the dual-averaging state [3][C]: in (continuation inside the window) / out
+        adapt = np.zeros((3, n_chains)) if adapt_state_in is None else np.array(adapt_state_in, dtype=np.float64, copy=True)
     t = make_target(kind, d, prec=prec, X=X, y=y, kernel_hint=kernel_hint)
     c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept,
-                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0)
+                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0, nuts_adapt_state=adapt)
     run(algo, t, settings, c)
-    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth)
+    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth, adapt_state=adapt)
 
 
 def sample_device(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0,

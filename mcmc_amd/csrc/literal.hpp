@@ -103,6 +103,7 @@ struct LitParams {
     double delta, gamma, t0, kappa;
     uint32_t n_fp_steps;     // rmhmc (rmhmc_settings_t::n_fp_steps, mcmc_structs.hpp:105-119)
     double* step_out;        // [C] or nullptr: in (draw0 > 0: the adapted step sizes of the call before) / out (final step size)
+    double* adapt_state;     // [3][C] or nullptr: nuts dual-averaging state (h, epsilon_bar, mu), out always, in when 0 < draw0 <= n_adapt
     uint32_t* depth_trace;   // [n_total][C] or nullptr
     const uint32_t* flag;    // [C]: replay only the chains whose entry is non-zero; nullptr: every chain
     const uint32_t* any;     // nullptr, or one word: zero = nothing was flagged, the launch returns at once
@@ -897,7 +898,7 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     auto fvec = [&](uint32_t level, int k) -> double* { return frames + ((size_t)level * LIT_NUTS_FRAME_VECS + k) * dv; };
     const uint64_t chain = p.chain0 + c;
     const uint32_t n_total = p.n_burnin + p.n_keep;
-    const uint32_t n_adapt = (p.draw0 > 0) ? 0u : (p.n_adapt <= n_total ? p.n_adapt : n_total);          // :54
+    const uint32_t n_adapt = p.n_adapt;                     // the RUN's adaptation window in global draw indices (the clamp of :54 is immaterial)
     uint64_t n_leap = 0;
 
     LIT_PFOR(i, d) {
@@ -945,9 +946,12 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
     } else {
         step_size = p.step_out ? p.step_out[c] : 1.0;        // continuation after the adaptation window
     }
-    const double mu_val = det_log(10 * step_size);           // nuts.cpp:174
+    double mu_val = det_log(10 * step_size);                 // nuts.cpp:174
     double h_val = 0.0;
     double epsilon_bar = (p.draw0 == 0) ? p.eps : step_size; // :59
+    if (p.draw0 > 0 && p.draw0 <= n_adapt && p.adapt_state != nullptr) {                     // a continuation inside the adaptation window
+        h_val = p.adapt_state[c]; epsilon_bar = p.adapt_state[p.C + c]; mu_val = p.adapt_state[2 * p.C + c];
+    }
     double prev_U = -box_log_kernel(par, p, v, v.prev);      // :181 (no finiteness guard there)
     uint64_t n_acc = 0;
 
@@ -1066,8 +1070,8 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
             par.sync();
             s_val = s_p_val * (c1 ? 1u : 0u) * (c2 ? 1u : 0u);                               // :289
         }
-        if (draw < n_adapt) {                                // :294-302 (this chain's own draw index)
-            const double it = (double)(draw + 1);
+        if (dabs < n_adapt) {                                // :294-302 (the chain's draw index in the RUN)
+            const double it = (double)(dabs + 1);
             h_val += (1 / (it + p.t0)) * (p.delta - (alpha_val / (double)n_alpha_val) - h_val);
             step_size = det_exp(mu_val - h_val * __builtin_sqrt(it) / p.gamma);
             epsilon_bar *= det_exp(det_pow(it, -p.kappa) * (det_log(step_size) - det_log(epsilon_bar)));
@@ -1081,6 +1085,7 @@ MI_HD void nuts_chain(const Par& par, const LitParams& p, uint64_t c, double* wk
         }
     }
     if (p.step_out && par.tid == 0) p.step_out[c] = step_size;
+    if (p.adapt_state && par.tid == 0) { p.adapt_state[c] = h_val; p.adapt_state[p.C + c] = epsilon_bar; p.adapt_state[2 * p.C + c] = mu_val; }
     store_outputs(par, p, c, v, n_acc, n_leap);
 }
 

@@ -252,6 +252,18 @@ int lit_upload(const mi::lit::LitPrep& pr, uint32_t d, bool want_bounds, LitDev&
 // completeness path, not a throughput path.  algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh.
 int run_literal(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st);
 
+// nuts continuation rules (mi_mcmc.h: mi_chains.draw0 / nuts_adapt_state); *n_adapt = the RUN's adaptation window
+int nuts_continuation(const mi_settings* s, const mi_chains* c, uint32_t* n_adapt)
+{
+    *n_adapt = (uint32_t)(s->n_adapt_draws > 0xffffffffULL ? 0xffffffffULL : s->n_adapt_draws);
+    if (c->draw0 > 0) {
+        if (!c->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the step sizes of the previous call)");
+        if (c->draw0 <= s->n_adapt_draws && !c->nuts_adapt_state)
+            return fail(MI_ERR_BAD_ARG, "nuts: a continuation that starts inside or at the end of the adaptation window (draw0 <= n_adapt_draws) needs chains.nuts_adapt_state of the previous call");
+    }
+    return MI_OK;
+}
+
 int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c, bool mass_allowed = false)
 {
     if (!t || !s || !c) return fail(MI_ERR_BAD_ARG, "null target / settings / chains");
@@ -303,7 +315,7 @@ int dense_precision_on_device(const mi_target* t, DevBuf& owned, const double** 
 
 // host <-> device staging of one mi_chains shard
 struct StagedChains {
-    DevBuf theta, draws, n_accept, step, n_leap, depth, mass;
+    DevBuf theta, draws, n_accept, step, n_leap, depth, mass, adapt;
     mi_chains dev;   // device-pointer view
 };
 
@@ -328,6 +340,10 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
         HIP_TRY(hipMemsetAsync(sc.n_leap.p, 0, C * sizeof(uint64_t), st));    // samplers without leapfrog steps (mala, rwmh) report 0
     }
     if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
+    if (c->nuts_adapt_state) {                           // in (a continuation inside the adaptation window) / out
+        HIP_TRY(sc.adapt.alloc(3 * C * sizeof(double))); sc.dev.nuts_adapt_state = sc.adapt.as<double>();
+        HIP_TRY(hipMemcpyAsync(sc.adapt.p, c->nuts_adapt_state, 3 * C * sizeof(double), hipMemcpyHostToDevice, st));
+    }
     if (c->mass_diag) {
         HIP_TRY(sc.mass.alloc(d * C * sizeof(double))); sc.dev.mass_diag = sc.mass.as<double>();
         HIP_TRY(hipMemcpyAsync(sc.mass.p, c->mass_diag, d * C * sizeof(double), hipMemcpyHostToDevice, st));
@@ -346,6 +362,7 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     if (c->step_size) HIP_TRY(hipMemcpyAsync(c->step_size, sc.dev.step_size, C * sizeof(double), hipMemcpyDeviceToHost, st));
     if (c->n_leapfrogs) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs, sc.dev.n_leapfrogs, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (c->nuts_depth) HIP_TRY(hipMemcpyAsync(c->nuts_depth, sc.dev.nuts_depth, n_total * C * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (c->nuts_adapt_state) HIP_TRY(hipMemcpyAsync(c->nuts_adapt_state, sc.dev.nuts_adapt_state, 3 * C * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
@@ -601,15 +618,10 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
         lit_set_chain_mass(lp, sc.dev.mass_diag, cm, C);
     }
     if (algo == 2) {
-        if (chains->draw0 > 0) {
-            if (chains->draw0 <= settings->n_adapt_draws)
-                return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
-            if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
-        }
-        lp.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
+        if ((rc = nuts_continuation(settings, chains, &lp.n_adapt))) return rc;
         lp.max_depth = (uint32_t)settings->max_tree_depth;
         lp.delta = settings->target_accept_rate; lp.gamma = settings->gamma_val; lp.t0 = settings->t0_val; lp.kappa = settings->kappa_val;
-        lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth;
+        lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth; lp.adapt_state = sc.dev.nuts_adapt_state;
     }
     rc = launched(who, mi::launch_literal(algo, lp, rp.n_wg, st));
     if (rc) return rc;
@@ -805,11 +817,6 @@ int run_small(const char* who, int algo, uint64_t d, const mi_settings* settings
     if (algo == 2) {
         if (settings->max_tree_depth > (uint64_t)mi::NUTS_SMALL_MAX_DEPTH)
             return fail(MI_ERR_UNSUPPORTED, "nuts: max_tree_depth > %d not implemented for this target", (int)mi::NUTS_SMALL_MAX_DEPTH);
-        if (chains->draw0 > 0) {          // continuation: as for the other nuts kernels
-            if (chains->draw0 <= settings->n_adapt_draws)
-                return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
-            if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
-        }
     }
     StagedChains sc;
     int rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
@@ -839,11 +846,10 @@ int run_small(const char* who, int algo, uint64_t d, const mi_settings* settings
             prm.btype[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
         }
     if (algo == 2) {
-        prm.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
-        if (chains->draw0 > 0) prm.n_adapt = 0;
+        if ((rc = nuts_continuation(settings, chains, &prm.n_adapt))) return rc;
         prm.max_depth = (uint32_t)settings->max_tree_depth;
         prm.delta = settings->target_accept_rate; prm.gamma = settings->gamma_val; prm.t0 = settings->t0_val; prm.kappa = settings->kappa_val;
-        prm.step_out = sc.dev.step_size; prm.depth_trace = sc.dev.nuts_depth;
+        prm.step_out = sc.dev.step_size; prm.depth_trace = sc.dev.nuts_depth; prm.adapt_state = sc.dev.nuts_adapt_state;
     }
     rc = launched(who, launch(prm, st));
     if (rc) return rc;
@@ -1844,7 +1850,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_leap = sc.dev.n_leapfrogs;
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
-    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0;      // the first-generation kernel, same bits
+    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0 && !chains->nuts_adapt_state;   // the first-generation kernel, same bits (it exports no adaptation state)
     const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
 #ifdef MI_PROFILING
     DevBuf prof_buf;
@@ -1853,17 +1859,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.seed = settings->rng_seed_value;
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
     prm.n_keep = (uint32_t)settings->n_keep_draws;
-    prm.n_adapt = (uint32_t)(settings->n_adapt_draws > n_total ? n_total : settings->n_adapt_draws);
     prm.draw0 = (uint32_t)chains->draw0;
-    if (chains->draw0 > 0) {
-        // continuation (checkpoint / resume): only after the adaptation window, with the adapted step sizes handed back in
-        if (chains->draw0 <= settings->n_adapt_draws)
-            return fail(MI_ERR_UNSUPPORTED, "nuts: a continuation (draw0 > 0) must start after the adaptation window (draw0 > n_adapt_draws)");
-        if (!chains->step_size) return fail(MI_ERR_BAD_ARG, "nuts: a continuation needs chains.step_size (the adapted step sizes of the previous call)");
-        // (the lock-step hint cannot be honoured for a continuation -- that kernel keeps no per-chain step size: as mi_mcmc.h promises for a
-        //  hint the request cannot take, it is ignored and the default kernel runs)
-        prm.n_adapt = 0;
-    }
+    // continuation (checkpoint / resume): the step sizes come back in; inside the adaptation window also the dual-averaging state.
+    // (The lock-step hint cannot be honoured for a continuation -- that kernel keeps no per-chain step size: as mi_mcmc.h promises for a
+    //  hint the request cannot take, it is ignored and the default kernel runs; it also clamps the window to the call, nuts.cpp:54, which is
+    //  the same thing for the single call it serves.)
+    if ((rc = nuts_continuation(settings, chains, &prm.n_adapt))) return rc;
+    prm.adapt_state = sc.dev.nuts_adapt_state;
     prm.max_depth = (uint32_t)settings->max_tree_depth;
     prm.delta = settings->target_accept_rate;
     prm.eps_bar0 = settings->step_size;

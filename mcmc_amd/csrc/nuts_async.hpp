@@ -357,12 +357,16 @@ const double* const mi_t = mi_tab();
     } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
         eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
     }
-    const double mu_val = det_log(10 * eps);             // nuts.cpp:174
+    double mu_val = det_log(10 * eps);                   // nuts.cpp:174
     double h_val = 0.0;
     double eps_bar = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
+    if (prm.draw0 > 0 && prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+        h_val = prm.adapt_state[cld]; eps_bar = prm.adapt_state[C + cld]; mu_val = prm.adapt_state[2 * C + cld];
+    }
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
-    const uint32_t n_adapt = prm.n_adapt <= n_total ? prm.n_adapt : n_total;
+    const uint32_t n_adapt = prm.n_adapt;                // the run's window in GLOBAL draw indices (the clamp of nuts.cpp:54 is immaterial: it only
+                                                         // matters when every draw adapts)
     const uint32_t max_depth = prm.max_depth;
 
     // ---------------------------------------------------------------- per-chain state
@@ -395,8 +399,8 @@ const double* const mi_t = mi_tab();
         if (p && prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
         if (p) fin_pending = false;
         if (p) {
-            if (draw < n_adapt) {
-                const double it = (double)(draw + 1);
+            if (draw + prm.draw0 < n_adapt) {
+                const double it = (double)(draw + prm.draw0 + 1);
                 h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
                 eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
                 eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
@@ -771,6 +775,7 @@ const double* const mi_t = mi_tab();
             if (prm.n_accept) prm.n_accept[cl] = n_acc;
             if (prm.n_leap) prm.n_leap[cl] = n_leap;
             if (prm.step_out) prm.step_out[cl] = eps;
+            if (prm.adapt_state) { prm.adapt_state[cl] = h_val; prm.adapt_state[C + cl] = eps_bar; prm.adapt_state[2 * C + cl] = mu_val; }
         }
     }
 }

@@ -208,12 +208,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
         eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
     }
-    const double mu_val = det_log(10 * eps);             // nuts.cpp:174
+    double mu_val = det_log(10 * eps);                   // nuts.cpp:174
     double h_val = 0.0;
     double eps_bar = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
+    if (prm.draw0 > 0 && prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+        h_val = prm.adapt_state[cld]; eps_bar = prm.adapt_state[C + cld]; mu_val = prm.adapt_state[2 * C + cld];
+    }
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
-    const uint32_t n_adapt = prm.n_adapt <= n_total ? prm.n_adapt : n_total;
+    const uint32_t n_adapt = prm.n_adapt;                // the run's window in GLOBAL draw indices (the clamp of nuts.cpp:54 is immaterial: it only
+                                                         // matters when every draw adapts)
     const uint32_t max_depth = prm.max_depth;
 
     // ---------------------------------------------------------------- per-chain state
@@ -272,15 +276,15 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
     // end of a draw for lanes with `p` (dual averaging nuts.cpp:294-302; the row store :306-309 is left to the next phase)
     auto end_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
         if (p && prm.depth_trace && live && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
-        if (__ballot(p && draw < n_adapt) != 0ull) {
-            if (p && draw < n_adapt) {
-                const double it = (double)(draw + 1);
+        if (__ballot(p && draw + prm.draw0 < n_adapt) != 0ull) {
+            if (p && draw + prm.draw0 < n_adapt) {
+                const double it = (double)(draw + prm.draw0 + 1);
                 h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_() / n_alpha_()) - h_val);
                 eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
                 eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
             }
         }
-        if (p && !(draw < n_adapt)) eps = eps_bar;
+        if (p && !(draw + prm.draw0 < n_adapt)) eps = eps_bar;
         const bool kept = p && draw >= prm.n_burnin;
         if (kept) n_acc += (uint64_t)good_round;
         if (p) {
@@ -608,6 +612,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_reg_kernel(c
             if (prm.n_accept) prm.n_accept[cl] = n_acc;
             if (prm.n_leap) prm.n_leap[cl] = n_leap;
             if (prm.step_out) prm.step_out[cl] = eps;
+            if (prm.adapt_state) { prm.adapt_state[cl] = h_val; prm.adapt_state[C + cl] = eps_bar; prm.adapt_state[2 * C + cl] = mu_val; }
         }
     }
 }

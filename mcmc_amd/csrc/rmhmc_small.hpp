@@ -43,6 +43,7 @@ struct SmallParams {
     uint32_t n_adapt, max_depth;
     double delta, gamma, t0, kappa;
     double* step_out;       // [C] or nullptr: in (continuation, draw0 > 0) / out: step size
+    double* adapt_state;    // [3][C] or nullptr: nuts dual-averaging state (h, epsilon_bar, mu): out always, in when 0 < draw0 <= n_adapt
     uint32_t* depth_trace;  // [n_burnin + n_keep][C] or nullptr
 };
 

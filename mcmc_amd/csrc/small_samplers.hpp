@@ -484,7 +484,11 @@ __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, c
         }
         mu_val = det_log(10 * step_size);                            // nuts.cpp:174
     } else {
-        step_size = prm.step_out[c];                                 // continuation after the adaptation window
+        step_size = prm.step_out[c];                                 // continuation: the step size comes back in ...
+        epsilon_bar = step_size;                                     // (after the window every draw runs at the adapted epsilon_bar)
+        if (prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {   // ... and, inside the adaptation window, the dual-averaging state
+            h_val = prm.adapt_state[c]; epsilon_bar = prm.adapt_state[prm.C + c]; mu_val = prm.adapt_state[2 * prm.C + c];
+        }
     }
     double prev_U = -ch.box_log_kernel(prev_draw);                   // :181
     uint64_t n_acc = 0;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, c
             h_val += (1 / (m + prm.t0)) * (prm.delta - (alpha_val / (double)n_alpha_val) - h_val);
             step_size = det_exp(mu_val - h_val * __builtin_sqrt(m) / prm.gamma);
             epsilon_bar *= det_exp(det_pow(m, -prm.kappa) * (det_log(step_size) - det_log(epsilon_bar)));
-        } else if (prm.draw0 == 0) {
+        } else {
             step_size = epsilon_bar;
         }
         if (prm.depth_trace) prm.depth_trace[(size_t)draw * prm.C + c] = tree_depth;
@@ -619,6 +623,7 @@ __global__ __launch_bounds__(64) void nuts_small_kernel(const SmallParams prm, c
     if (prm.n_accept) prm.n_accept[c] = n_acc;
     if (prm.n_leap) prm.n_leap[c] = n_leap;
     if (prm.step_out) prm.step_out[c] = step_size;
+    if (prm.adapt_state) { prm.adapt_state[c] = h_val; prm.adapt_state[prm.C + c] = epsilon_bar; prm.adapt_state[2 * prm.C + c] = mu_val; }
 }
 
 }  // namespace mi
