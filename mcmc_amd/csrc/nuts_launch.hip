@@ -12,7 +12,7 @@ namespace {
 template <int NT, bool DIAGM>
 int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64 + (DIAGM ? 32 * NT : 0)) * sizeof(double);
+    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64 + 3 * 64 + (DIAGM ? 32 * NT : 0)) * sizeof(double);
     auto kern = nuts_gauss_reg_kernel<NT, DIAGM>;
     note_kernel("nuts_gauss_reg_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
