@@ -53,7 +53,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* lds_P = lds_all;
     double* lds_lvl = lds_all + NT * NS * 64;            // [NUTS_LVLS][4][64]
-    double* const lds_lb = lds_lvl + NUTS_LVLS * 4 * 64;
+    double* const lds_da = lds_lvl + NUTS_LVLS * 4 * 64;  // [3][64]: the dual-averaging state (h, epsilon_bar, mu), touched once per draw
+    double* const lds_lb = lds_da + 3 * 64;
     double* const lds_ub = lds_lb + 16 * NT;
     double* const lds_ms = lds_ub + 16 * NT;
     double* const lds_mi = lds_ms + 16 * NT;
@@ -357,11 +358,17 @@ const double* const mi_t = mi_tab();
     } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
         eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
     }
-    double mu_val = det_log(10 * eps);                   // nuts.cpp:174
-    double h_val = 0.0;
-    double eps_bar = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
+    // (in LDS, not in registers: this kernel's general instantiation at d > 64 has none to spare -- with the three scalars loop-carried
+    //  in VGPRs next to the adaptation-state load and store, hipcc 7.2 produced code that returned the chain index as step size for
+    //  64 < d < 128 with bounds; tests/test_gpu_parity_nuts.py pins those shapes)
+    auto h_val_ = [&]() -> double& { return lds_da[cw]; };
+    auto eps_bar_ = [&]() -> double& { return lds_da[64 + cw]; };
+    auto mu_val_ = [&]() -> double& { return lds_da[128 + cw]; };
+    mu_val_() = det_log(10 * eps);                       // nuts.cpp:174
+    h_val_() = 0.0;
+    eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
     if (prm.draw0 > 0 && prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
-        h_val = prm.adapt_state[cld]; eps_bar = prm.adapt_state[C + cld]; mu_val = prm.adapt_state[2 * C + cld];
+        h_val_() = prm.adapt_state[cld]; eps_bar_() = prm.adapt_state[C + cld]; mu_val_() = prm.adapt_state[2 * C + cld];
     }
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
@@ -401,11 +408,13 @@ const double* const mi_t = mi_tab();
         if (p) {
             if (draw + prm.draw0 < n_adapt) {
                 const double it = (double)(draw + prm.draw0 + 1);
-                h_val = h_val + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val);
-                eps = det_exp(mu_val - h_val * __builtin_sqrt(it) / prm.gamma);
-                eps_bar = eps_bar * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eps_bar)));
+                const double h_new = h_val_() + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_val / n_alpha_val) - h_val_());
+                h_val_() = h_new;
+                eps = det_exp(mu_val_() - h_new * __builtin_sqrt(it) / prm.gamma);
+                const double eb = eps_bar_();
+                eps_bar_() = eb * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eb)));
             } else {
-                eps = eps_bar;
+                eps = eps_bar_();
             }
         }
         const bool kept = p && draw >= prm.n_burnin;
@@ -775,7 +784,7 @@ const double* const mi_t = mi_tab();
             if (prm.n_accept) prm.n_accept[cl] = n_acc;
             if (prm.n_leap) prm.n_leap[cl] = n_leap;
             if (prm.step_out) prm.step_out[cl] = eps;
-            if (prm.adapt_state) { prm.adapt_state[cl] = h_val; prm.adapt_state[C + cl] = eps_bar; prm.adapt_state[2 * C + cl] = mu_val; }
+            if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
         }
     }
 }

@@ -10,7 +10,7 @@ namespace {
 template <int NT, bool GENERAL, bool DENSE_M>
 int async(const NutsParams& prm, uint32_t batch, hipStream_t st)
 {
-    const size_t lds = ((size_t)NT * 4 * NT * 64 * ((DENSE_M && NT <= 4) ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64) * sizeof(double)
+    const size_t lds = ((size_t)NT * 4 * NT * 64 * ((DENSE_M && NT <= 4) ? 3 : 1) + (size_t)NUTS_LVLS * 4 * 64 + 3 * 64) * sizeof(double)
                      + (GENERAL ? (size_t)16 * NT * (4 * sizeof(double) + sizeof(int)) : 0);
     auto kern = nuts_gauss_async_kernel<NT, GENERAL, DENSE_M>;
     note_kernel("nuts_gauss_async_kernel<%d, %s, %s>", NT, GENERAL ? "true" : "false", DENSE_M ? "true" : "false");
