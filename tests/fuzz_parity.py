@@ -139,9 +139,58 @@ def sweep_small(n_cases=60, seed=1, verbose=True):
     return fails
 
 
+def sweep_mass(n_cases=40, seed=1, verbose=True):
+    """hmc with PER-CHAIN diagonal masses (mi_chains.mass_diag): chain c against the oracle run with precond_mat = diag(mass[:, c]) --
+    elementwise kernels (iso / diag targets, any d), literal kernels (dense, logistic, bounds), the non-finite regime.  Returns the mismatches."""
+    rng = np.random.default_rng(seed)
+    fails = 0
+    say = print if verbose else (lambda *a, **k: None)
+    for case in range(n_cases):
+        tgt = rng.choice(["iso", "diag", "dense", "logit"])
+        d = int(rng.choice([1, 2, 5, 17, 64, 129, 300])) if tgt in ("iso", "diag") else int(rng.choice([2, 9, 33, 70]))
+        C = int(rng.choice([1, 3, 17, 70])) if tgt in ("iso", "diag") else int(rng.choice([1, 3, 5]))
+        rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
+        burn, keep, L = int(rng.integers(0, 3)), int(rng.integers(1, 6)), int(rng.integers(0, 5))
+        eps = float(rng.choice([0.02, 0.1, 0.4, 30.0, 1e160]))
+        prec = X = y = None; tkw = {}; okw = {}; kw = {}
+        if tgt == "dense": prec, kg, ko = synth.dense_gaussian_precision(d, seed=rseed % 97), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+        elif tgt == "diag": prec, kg, ko = synth.ill_conditioned_diag(d, 20.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG
+        elif tgt == "iso": kg, ko = mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
+        else:
+            X, y = synth.logistic_problem(d, int(rng.choice([1, 16, 40])), seed=rseed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
+            dq = 16 if d <= 64 else 32
+            tkw = dict(blocks=4, block_size=dq, eta_chains=2); okw.update(blocks=4, block_size=dq)
+        init = synth.initial_states(C, d, seed=rseed % 1013) * float(rng.choice([0.1, 1.0]))
+        if rng.random() < 0.2: init[int(rng.integers(0, C)), int(rng.integers(0, d))] = float(rng.choice([np.inf, np.nan, 1e300]))
+        if tgt != "logit" and rng.random() < 0.3:
+            kind = rng.integers(1, 5, d)
+            lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf); ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+            kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+            init = np.where(np.isfinite(init), np.clip(init, -1.0, 1.5), init)
+        mass = np.ascontiguousarray(rng.uniform(0.2, 5.0, (d, C)))
+        st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps, **kw)
+        t_g = mcmc_amd.make_target(kg, d, prec=prec, X=X, y=y)
+        theta = np.ascontiguousarray(init.T.copy()); draws = np.zeros((keep, d, C)); nacc = np.zeros(C, dtype=np.uint64)
+        mcmc_amd.run("hmc", t_g, st, mcmc_amd.make_chains(theta, C, chain0=chain0, draws=draws, n_accept=nacc, mass_diag=mass))
+        t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
+        ok = True
+        for c in range(C):
+            s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, precond=np.diag(mass[:, c]), **okw)
+            o, info = orc.run_many(orc.ALGO_HMC, t, init[c:c + 1], s, chain0=chain0 + c)
+            ok = ok and np.array_equal(draws[:, :, c], o[:, :, 0], equal_nan=True) and int(nacc[c]) == int(info["n_accept"][0])
+        desc = f"hmc per-chain mass {tgt} d={d} C={C} eps={eps} L={L} burn={burn} keep={keep} general={sorted(kw)} kernel={mcmc_amd.last_kernel()}"
+        if not ok: fails += 1
+        say("ok      " if ok else "MISMATCH", desc)
+    return fails
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "mass":
+        f = sweep_mass(n, sd)
+        print(f"{n} per-chain-mass cases, {f} mismatches")
+        sys.exit(1 if f else 0)
     f = sweep(n, sd) + sweep_small(n, sd)
     print(f"2 x {n} cases, {f} mismatches")
     sys.exit(1 if f else 0)

@@ -28,3 +28,10 @@ def test_plain_nuts_kernel_random_windows_and_depth_caps(seed):
     windows, depth caps 0..10, chain counts around the wave size."""
     import fuzz_nuts
     assert fuzz_nuts.sweep(40, seed, verbose=False) == 0
+
+
+def test_per_chain_mass_sweep_is_bit_exact():
+    """hmc with mi_chains.mass_diag: chain c against the oracle with precond_mat = diag(mass[:, c]), random targets / sizes / bounds /
+    non-finite starts (elementwise and literal kernels)"""
+    import fuzz_parity
+    assert fuzz_parity.sweep_mass(16, 3, verbose=False) == 0
