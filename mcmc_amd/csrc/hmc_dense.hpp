@@ -648,6 +648,25 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         const double comp_val = (x < 0.01) ? x : 0.01;  // std::min(0.01, x), :188
         const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);   // :189
         const bool accept = z < det_exp(comp_val);      // :191
+#ifndef MI_HMC_NO_WSAVE
+#define MI_HMC_NO_WSAVE 0      // 1 (plain kernel only): P*theta of the accepted state is not saved; a wave with a rejecting chain recomputes it
+#endif
+        if constexpr (MI_HMC_NO_WSAVE && !BOUNDED) {
+            if (accept) {
+                prev_U = prop_U;
+                if (live && !(prm.ablate & 8u)) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) *th_mem(s) = th[s];
+                }
+            }
+            if (__ballot(!accept) != 0ull) {            // some chain of the wave keeps prev_draw: its theta comes back, P*theta is recomputed for
+                if (!accept) {                          // the whole tile (the accepted chains get the bits they already hold)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) th[s] = *th_mem(s);
+                }
+                gradient();
+            }
+        } else
         if (accept) {                                   // prev_draw = new_draw (:192-194)
             prev_U = prop_U;
             if (live && !(prm.ablate & 8u)) {
