@@ -178,6 +178,32 @@ int main()
                 okw ? col_mean(drw, 0) : 0.0, okw ? col_mean(drw, 1) : 0.0, okw ? col_mean(drw, 2) : 0.0,
                 double(s5.rwmh_settings.n_accept_draws) / 4000.0, dw.n_calls_value);
 
+    // NOT in the reference: the diagonal mass matrix adapted during burn-in (mcmc::mi355x::hmc_mass_adapted) on an ill-scaled diagonal
+    // Gaussian (precisions 1 .. 1e4), 256 chains started from different points -- pooled over the chains, then per chain
+    {
+        const size_t dd = 32, CC = 256;
+        std::vector<double> lam(dd);
+        for (size_t i = 0; i < dd; ++i) lam[i] = std::pow(10.0, 4.0 * double(i) / double(dd - 1));
+        mcmc::mi355x::target_t td = mcmc::mi355x::gaussian_diag(dd, lam.data());
+        td.n_chains = CC;
+        mcmc::ColVec_t i0(dd * CC);
+        unsigned long long stt = 88172645463325252ULL;
+        for (size_t c = 0; c < CC; ++c)
+            for (size_t i = 0; i < dd; ++i) { stt ^= stt << 13; stt ^= stt >> 7; stt ^= stt << 17; i0(c * dd + i) = (double(stt >> 11) / 9007199254740992.0 - 0.5) * 3.0 / std::sqrt(lam[i]); }
+        mcmc::algo_settings_t sm;
+        sm.rng_seed_value = 3;
+        sm.hmc_settings.step_size = 0.2; sm.hmc_settings.n_leap_steps = 8; sm.hmc_settings.n_burnin_draws = 60; sm.hmc_settings.n_keep_draws = 20;
+        mcmc::Mat_t dmass;
+        std::vector<double> mass;
+        const bool okp = mcmc::mi355x::hmc_mass_adapted(i0, td, dmass, sm, 3, false, 0.0, &mass);
+        std::printf("mass adapted (pooled) ok=%d cols=%zu acc0=%.2f mass0/prec0=%.2f massLast/precLast=%.2f\n", int(okp), size_t(dmass.cols()),
+                    double(sm.hmc_settings.n_accept_draws) / 20.0, okp ? mass[0] / lam[0] : 0.0, okp ? mass[dd - 1] / lam[dd - 1] : 0.0);
+        const bool okc = mcmc::mi355x::hmc_mass_adapted(i0, td, dmass, sm, 2, true, 0.01, &mass);
+        std::printf("mass adapted (per chain) ok=%d cols=%zu acc0=%.2f masses=%zu\n", int(okc), size_t(dmass.cols()),
+                    double(sm.hmc_settings.n_accept_draws) / 20.0, mass.size());
+        if (!okp || !okc) { std::printf("reason=\"%s\"\n", td.last_error.c_str()); return 1; }
+    }
+
     // mcmc::rmhmc with HOST std::function callbacks, the flow of the reference's examples/eigen/rmhmc_normal.cpp: (mu, sigma) of normal
     // data, the Fisher information as metric tensor, sigma bounded below.  The sampler runs on the device and asks for every evaluation.
     norm_data_t nd{x_obs.data(), x_obs.size(), 0, 0, 0};

@@ -319,8 +319,10 @@ inline mi_settings flatten_common(const algo_settings_t& s)
 // precond_mat counts only when it has d*d elements (src/hmc.cpp:57); symmetric, so the storage order is immaterial
 inline const double* precond_or_null(const Mat_t& M, size_t d) { return (size_t(M.size()) == d * d && d > 0) ? M.data() : nullptr; }
 
-// many chains through mi_mcmc_<algo>_run; fills draws_out as n_keep x (d * C)
-inline bool run_device(int algo, const ColVec_t& initial_vals, mi355x::target_t& tgt, Mat_t& draws_out, mi_settings& m)
+// many chains through mi_mcmc_<algo>_run; fills draws_out as n_keep x (d * C).  algo 10 / 11: hmc with the diagonal mass adapted during
+// burn-in, pooled over the chains / per chain (NOT reference modes; mi_mcmc.h: mi_mcmc_hmc_run_mass_adapted[_per_chain])
+inline bool run_device(int algo, const ColVec_t& initial_vals, mi355x::target_t& tgt, Mat_t& draws_out, mi_settings& m,
+                       unsigned n_windows = 0, double first_step_size = 0.0, std::vector<double>* mass_out = nullptr)
 {
     const size_t d = tgt.desc.d, C = tgt.n_chains ? tgt.n_chains : 1, n_keep = m.n_keep_draws;
     const size_t n_init = size_t(initial_vals.size());
@@ -335,7 +337,11 @@ inline bool run_device(int algo, const ColVec_t& initial_vals, mi355x::target_t&
     ch.theta = theta.data(); ch.draws = draws.data(); ch.n_accept = tgt.n_accept_draws.data();
     ch.step_size = tgt.step_size.data();
     tgt.desc.struct_size = sizeof(mi_target);
-    const int rc = (algo == 0) ? mi_mcmc_hmc_run(&tgt.desc, &m, &ch, nullptr)
+    if (mass_out) mass_out->assign(algo == 11 ? d * C : d, 0.0);
+    const int rc = (algo == 10) ? mi_mcmc_hmc_run_mass_adapted(&tgt.desc, &m, &ch, n_windows, mass_out ? mass_out->data() : nullptr, nullptr)
+                 : (algo == 11) ? mi_mcmc_hmc_run_mass_adapted_per_chain(&tgt.desc, &m, &ch, n_windows, first_step_size,
+                                                                         mass_out ? mass_out->data() : nullptr, nullptr)
+                 : (algo == 0) ? mi_mcmc_hmc_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 1) ? mi_mcmc_mala_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 3) ? mi_mcmc_rwmh_run(&tgt.desc, &m, &ch, nullptr)
                  : (algo == 4) ? mi_mcmc_rmhmc_run(&tgt.desc, &m, &ch, nullptr)
@@ -606,6 +612,25 @@ inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_
 inline bool rwmh(const ColVec_t& initial_vals, std::function<fp_t (const ColVec_t& vals_inp, void* target_data)> target_log_kernel,
                  Mat_t& draws_out, void* target_data, algo_settings_t& settings)
 { return internal::rwmh_impl(initial_vals, target_log_kernel, draws_out, target_data, &settings); }
+
+// NOT in the reference: mcmc::hmc on the device route with the DIAGONAL mass matrix adapted during burn-in -- pooled over the chains
+// (one matrix for all, estimated from their spread; mass_out: d values) or per chain (each chain from its own draws, Stan's scheme;
+// mass_out: [d][n_chains]; first_step_size drives the first part, which runs with M = I on the raw target).  settings.hmc_settings as
+// for mcmc::hmc, precond_mat left empty; step_size is in the preconditioned metric.  See include/mi_mcmc.h.
+namespace mi355x {
+inline bool hmc_mass_adapted(const ColVec_t& initial_vals, target_t& tgt, Mat_t& draws_out, algo_settings_t& settings, unsigned n_windows,
+                             bool per_chain = false, double first_step_size = 0.0, std::vector<double>* mass_out = nullptr)
+{
+    mi_settings m = internal::flatten_common(settings);
+    m.n_burnin_draws = settings.hmc_settings.n_burnin_draws;
+    m.n_keep_draws = settings.hmc_settings.n_keep_draws;
+    m.n_leap_steps = settings.hmc_settings.n_leap_steps;
+    m.step_size = settings.hmc_settings.step_size;
+    const bool ok = internal::run_device(per_chain ? 11 : 10, initial_vals, tgt, draws_out, m, n_windows, first_step_size, mass_out);
+    if (ok) settings.hmc_settings.n_accept_draws = size_t(tgt.n_accept_draws[0]);
+    return ok;
+}
+}  // namespace mi355x
 
 // ref: include/mcmc/rmhmc.hpp (both overloads)
 inline bool rmhmc(const ColVec_t& initial_vals, log_kernel_fn_t target_log_kernel, tensor_fn_t tensor_fn, Mat_t& draws_out,

@@ -68,6 +68,12 @@ def test_example_runs_on_the_gpu(tmp_path):
     mm = re.search(r"device rmhmc ok=1 rows=200 cols=128 acc0=(\S+) mu0=(\S+) sigma0=(\S+)", out.stdout)
     assert mm, out.stdout
     assert 0.2 < float(mm.group(1)) <= 1.0 and 1.5 < float(mm.group(2)) < 3.2 and 1.5 < float(mm.group(3)) < 3.2
+    # mcmc::mi355x::hmc_mass_adapted (not a reference mode): pooled masses land on the precisions; the per-chain form returns d x C masses
+    mm = re.search(r"mass adapted \(pooled\) ok=1 cols=8192 acc0=(\S+) mass0/prec0=(\S+) massLast/precLast=(\S+)", out.stdout)
+    assert mm, out.stdout
+    assert float(mm.group(1)) > 0.5 and 0.6 < float(mm.group(2)) < 1.6 and 0.6 < float(mm.group(3)) < 1.6
+    mm = re.search(r"mass adapted \(per chain\) ok=1 cols=8192 acc0=(\S+) masses=8192", out.stdout)
+    assert mm, out.stdout
     # mcmc::rmhmc with host std::function callbacks (examples/eigen/rmhmc_normal.cpp's flow): the data are N(2, 2^2)
     mm = re.search(r"callback rmhmc ok=1 rows=200 cols=2 mean_mu=(\S+) mean_sigma=(\S+) acc=(\S+) grad_calls=(\d+) value_calls=(\d+) tensor_calls=(\d+)", out.stdout)
     assert mm, out.stdout
