@@ -15,6 +15,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi_mcmc.h"
@@ -660,8 +661,11 @@ uint64_t serve_callbacks(const mi::lit::LitMailbox& mb, uint32_t d, mi_log_kerne
             served = req; ++n; idle = 0;
             continue;
         }
-        if ((++idle & 0xffu) == 0u && hipStreamQuery(st) != hipErrorNotReady) {     // the kernel has ended (or failed): one last look, then out
-            if (__atomic_load_n(&mb.ctl[mi::lit::LIT_MB_REQ], __ATOMIC_ACQUIRE) == served) break;
+        if ((++idle & 0xffu) == 0u) {
+            if (hipStreamQuery(st) != hipErrorNotReady) {                            // the kernel has ended (or failed): one last look, then out
+                if (__atomic_load_n(&mb.ctl[mi::lit::LIT_MB_REQ], __ATOMIC_ACQUIRE) == served) break;
+            }
+            std::this_thread::yield();                                              // (between requests the kernel computes: let the core go now and then)
         }
     }
     return n;
