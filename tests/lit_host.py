@@ -14,7 +14,7 @@ _SRC = [os.path.join(HERE, "lit_host.hip")] + [os.path.join(ROOT, "mcmc_amd", "c
 _dp = C.POINTER(C.c_double)
 _lib = None
 
-KIND = {"iso": 0, "diag": 1, "dense": 2, "logit": 3}
+KIND = {"iso": 0, "diag": 1, "dense": 2, "logit": 3, "callback": 4}
 
 
 def lib():
@@ -40,7 +40,8 @@ ALGO = {"hmc": 0, "mala": 1, "nuts": 2, "rwmh": 3, "rmhmc": 4}
 
 
 def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None, y=None, chain0=0, draw0=0,
-        lower=None, upper=None, precond=None, n_adapt=0, max_depth=10, delta=0.55, gamma=0.05, t0=10.0, kappa=0.75, step_in=None, n_fp=5):
+        lower=None, upper=None, precond=None, n_adapt=0, max_depth=10, delta=0.55, gamma=0.05, t0=10.0, kappa=0.75, step_in=None, n_fp=5,
+        mass_diag=None, kernel_cb=None, kernel_data=None, tensor_cb=None, tensor_data=None, adapt_state_in=None):
     """algo 'hmc' | 'mala' | 'nuts' | 'rwmh'; init [C, d].  Returns (draws [n_keep, d, C], dict(n_accept, n_leap, theta [C, d], eps, depth))."""
     init = _f(init)
     Cn, d = init.shape
@@ -53,12 +54,16 @@ def run(algo, kind, init, seed, n_burnin, n_keep, n_leap, eps, prec=None, X=None
     u64p = C.POINTER(C.c_uint64)
     step = np.zeros(Cn) if step_in is None else np.array(step_in, dtype=np.float64, copy=True)
     depth = np.zeros((n_burnin + n_keep, Cn), dtype=np.uint32)
-    rc = lib().lit_host_run(C.c_int(ALGO[algo]), C.c_int(KIND[kind]), C.c_uint32(d), C.c_uint32(n_rows),
+    mass_diag = _f(mass_diag)
+    adapt = np.zeros((3, Cn)) if adapt_state_in is None else np.array(adapt_state_in, dtype=np.float64, copy=True)
+    rc = lib().lit_host_run_ext(C.c_int(ALGO[algo]), C.c_int(KIND[kind]), C.c_uint32(d), C.c_uint32(n_rows),
                             _p(prec), _p(X), _p(y), C.c_uint64(Cn), C.c_uint64(chain0), _p(theta), _p(draws),
                             nacc.ctypes.data_as(u64p), nleap.ctypes.data_as(u64p), C.c_uint64(seed), C.c_uint32(n_burnin),
                             C.c_uint32(n_keep), C.c_uint32(n_leap), C.c_uint32(draw0), C.c_double(eps),
                             C.c_int(0 if lower is None else 1), _p(lower), _p(upper), _p(precond),
                             C.c_uint32(n_adapt), C.c_uint32(max_depth), C.c_double(delta), C.c_double(gamma), C.c_double(t0),
-                            C.c_double(kappa), _p(step), depth.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(n_fp))
+                            C.c_double(kappa), _p(step), depth.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(n_fp),
+                            _p(mass_diag), C.c_void_p(kernel_cb or 0), C.c_void_p(kernel_data or 0), C.c_void_p(tensor_cb or 0),
+                            C.c_void_p(tensor_data or 0), _p(adapt))
     assert rc == 0
-    return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy(), eps=step, depth=depth)
+    return draws, dict(n_accept=nacc, n_leap=nleap, theta=theta.T.copy(), eps=step, depth=depth, adapt_state=adapt)

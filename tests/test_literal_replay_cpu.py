@@ -97,3 +97,63 @@ def test_literal_dense_gaussian_uses_the_blocked_dot_order_between_128_and_512(a
         o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH}[algo], t, init, s, chain0=5)
         l_draws, l = lit_host.run(algo, "dense", init, 77, 1, 3, 3, eps, prec=prec, chain0=5, n_adapt=2, max_depth=3)
         assert np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"]), (algo, d, eps)
+
+
+# ---- the features round 3 added to the literal kernels, pinned on the CPU as well (host instantiation): per-chain diagonal masses, host
+# callbacks as the target (the host branch of the mailbox), the nuts dual-averaging state across a cut
+
+@pytest.mark.parametrize("tgt", ["iso", "dense", "logit"])
+def test_literal_hmc_with_per_chain_masses_equals_the_oracle_chain_by_chain(tgt):
+    rng = np.random.default_rng([21, len(tgt)])
+    d, C = 11, 6
+    prec = X = y = None; tkw, okw = {}, {}
+    if tgt == "dense": prec, ko = synth.dense_gaussian_precision(d, seed=3), orc.TARGET_DENSE
+    elif tgt == "iso": ko = orc.TARGET_ISO
+    else:
+        X, y = synth.logistic_problem(d, 17, seed=3); ko = orc.TARGET_LOGISTIC
+        tkw = dict(blocks=4, block_size=16, eta_chains=2); okw = dict(blocks=4, block_size=16)
+    init = synth.initial_states(C, d, seed=5) * 0.5
+    init[2, 3] = np.inf                                  # one chain in the non-finite regime
+    mass = np.ascontiguousarray(rng.uniform(0.2, 5.0, (d, C)))
+    l_draws, l = lit_host.run("hmc", tgt, init, 31, 2, 5, 4, 0.2, prec=prec, X=X, y=y, chain0=7, mass_diag=mass)
+    t = orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw)
+    for c in range(C):
+        s = orc.make_settings(seed=31, n_burnin=2, n_keep=5, n_leap=4, step=0.2, W=4, hoist=1, precond=np.diag(mass[:, c]), **okw)
+        o, info = orc.run_many(orc.ALGO_HMC, t, init[c:c + 1], s, chain0=7 + c)
+        assert np.array_equal(l_draws[:, :, c], o[:, :, 0], equal_nan=True) and l["n_accept"][c] == info["n_accept"][0], (tgt, c)
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala", "nuts", "rwmh", "rmhmc"])
+def test_literal_samplers_with_host_callbacks_as_target_equal_the_oracle(algo):
+    """kind = LIT_CALLBACK: every target / tensor evaluation goes through the mailbox -- on the host a direct call of the user's function
+    pointers, here the oracle's own target and tensor (so the run must equal the oracle's)."""
+    import ctypes as C
+    d = 5
+    X, y = synth.logistic_problem(d, 20, seed=9)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4)
+    kern = C.cast(orc.lib().orc_target_kernel, C.c_void_p).value
+    tens = C.cast(orc.lib().orc_target_tensor, C.c_void_p).value
+    lb = np.array([-1.5, -np.inf, -np.inf, -2.0, -np.inf]); ub = np.array([2.0, np.inf, 1.8, np.inf, np.inf])
+    M = None if algo == "rmhmc" else np.diag([0.5, 1.0, 2.0, 1.5, 0.8])
+    init = np.clip(synth.initial_states(2, d, seed=4) * 0.3, -1.0, 1.5)
+    l_draws, l = lit_host.run(algo, "callback", init, 17, 2, 6, 3, 0.1, lower=lb, upper=ub, precond=M, n_adapt=2, max_depth=4, n_fp=3,
+                              kernel_cb=kern, kernel_data=C.addressof(t.c), tensor_cb=tens, tensor_data=C.addressof(t.c))
+    okw = dict(lower=lb, upper=ub) if M is None else dict(lower=lb, upper=ub, precond=M)
+    s = orc.make_settings(seed=17, n_burnin=2, n_keep=6, n_leap=3, step=0.1, n_adapt=2, max_depth=4, n_fp=3, W=4, **okw)
+    a = {"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA, "nuts": orc.ALGO_NUTS, "rwmh": orc.ALGO_RWMH, "rmhmc": orc.ALGO_RMHMC}[algo]
+    o_draws, o = orc.run_many(a, t, init, s)
+    assert np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"])
+
+
+@pytest.mark.parametrize("cut", [2, 7, 8, 11])
+def test_literal_nuts_continues_from_a_cut_anywhere_with_its_dual_averaging_state(cut):
+    """n_adapt_draws = 8 of 14 draws: cut inside the window, at its end, after it -- bit-identical to the uncut run (host instantiation)"""
+    d, C, n_tot, n_adapt = 7, 4, 14, 8
+    prec = synth.dense_gaussian_precision(d, seed=2)
+    init = synth.initial_states(C, d, seed=6) * 0.5
+    kw = dict(prec=prec, chain0=3, n_adapt=n_adapt, max_depth=4)
+    w_draws, w = lit_host.run("nuts", "dense", init, 5, 0, n_tot, 0, 0.1, **kw)
+    a_draws, a = lit_host.run("nuts", "dense", init, 5, 0, cut, 0, 0.1, **kw)
+    b_draws, b = lit_host.run("nuts", "dense", a["theta"], 5, 0, n_tot - cut, 0, 0.1, draw0=cut, step_in=a["eps"], adapt_state_in=a["adapt_state"], **kw)
+    assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
+    assert np.array_equal(b["eps"], w["eps"]) and np.array_equal(a["n_leap"] + b["n_leap"], w["n_leap"])
