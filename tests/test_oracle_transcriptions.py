@@ -202,3 +202,121 @@ def test_python_transcription_of_mala_agrees_with_the_oracle(kind, which):
     o_draws, o = orc.run_chain(orc.ALGO_MALA, tgt.spec, init, st, traces=True)
     assert list(o["accept"]) == accepts and 0 < sum(accepts) < len(accepts) + 1
     assert np.allclose(o_draws, rows, rtol=1e-9, atol=1e-11)
+
+
+# ---- mcmc::rmhmc (ref: src/rmhmc.cpp:84-290), with the metric tensors of the built-in targets written from their definitions
+def _logit_tensor(tgt, x, want_deriv):
+    """Fisher information of the logistic likelihood + the N(0, I) prior's precision: G = X' L X + I, L = diag(s (1 - s));
+    dG/dbeta_i = X' diag(s (1 - s)(1 - 2 s) X[:, i]) X"""
+    s = 1.0 / (1.0 + np.exp(-(tgt.X @ x)))
+    lam = s * (1 - s)
+    G = tgt.X.T @ (lam[:, None] * tgt.X) + np.eye(len(x))
+    dG = [tgt.X.T @ ((lam * (1 - 2 * s) * tgt.X[:, i])[:, None] * tgt.X) for i in range(len(x))] if want_deriv else None
+    return G, dG
+
+
+def _py_rmhmc(tgt, tensor, init, seed, n_burnin, n_keep, L, step, n_fp, lb=None, ub=None):
+    d = len(init)
+    vb = lb is not None
+    bt = _bounds_type(lb, ub) if vb else None
+    nat = (lambda v: _inv_transform(v, bt, lb, ub)) if vb else (lambda v: v)
+    def box_log_kernel(v):
+        return tgt(nat(v), False)[0] + (_log_jacobian(v, bt, lb, ub) if vb else 0.0)
+    def mntm_update(pos, mntm, inv_G, dG):                  # :99-150: step [J] grad_obj / 2
+        g = tgt(nat(pos), True)[1]
+        go = np.empty(d)
+        for i in range(d):
+            T = inv_G @ dG[i]
+            go[i] = -g[i] + 0.5 * (np.trace(T) - float((T.T @ mntm) @ (inv_G @ mntm)))
+        return step * ((_inv_jacobian(pos, bt, lb, ub) @ go) if vb else go) / 2
+    box_tensor = lambda v, want: tensor(tgt, nat(v), want)  # :152-164
+    first = _transform(init, bt, lb, ub) if vb else np.array(init, dtype=np.float64)
+    new_tensor, new_deriv = box_tensor(first, True)
+    prev_tensor, inv_new = new_tensor, np.linalg.inv(new_tensor)
+    inv_prev, prev_deriv = inv_new, new_deriv
+    cons = 0.5 * d * math.log(2 * math.pi)
+    prev_U = cons - box_log_kernel(first) + 0.5 * np.linalg.slogdet(new_tensor)[1]       # :197
+    prev_draw, rows, accepts = first.copy(), [], []
+    for draw_ind in range(n_burnin + n_keep):
+        new_mntm = np.linalg.cholesky(prev_tensor) @ orc.normal_vec(seed, 0, draw_ind, 0, d)     # :207-209
+        prev_K = float(new_mntm @ (inv_prev @ new_mntm)) / 2
+        new_draw = prev_draw.copy()
+        for _ in range(L):
+            prop_mntm = new_mntm.copy()
+            for _k in range(n_fp):                          # :220-222
+                prop_mntm = new_mntm + mntm_update(new_draw, prop_mntm, inv_prev, prev_deriv)
+            new_mntm = prop_mntm
+            prop_draw = new_draw.copy()
+            for _k in range(n_fp):                          # :231-235
+                inv_new = np.linalg.inv(box_tensor(prop_draw, False)[0])
+                prop_draw = new_draw + 0.5 * step * ((inv_prev + inv_new) @ new_mntm)
+            new_draw = prop_draw
+            new_tensor, new_deriv = box_tensor(new_draw, True)                           # :239-240
+            inv_new = np.linalg.inv(new_tensor)
+            new_mntm = new_mntm + mntm_update(new_draw, new_mntm, inv_new, new_deriv)    # :244
+        prop_U = cons - box_log_kernel(new_draw) + 0.5 * np.linalg.slogdet(new_tensor)[1]
+        if not math.isfinite(prop_U): prop_U = math.inf
+        prop_K = float(new_mntm @ (inv_new @ new_mntm)) / 2
+        comp_val = min(0.01, -(prop_U + prop_K) + (prev_U + prev_K))
+        acc = orc.uniform(seed, 0, draw_ind, 0) < math.exp(comp_val)
+        if acc:
+            prev_draw, prev_U = new_draw, prop_U
+            prev_tensor, inv_prev, prev_deriv = new_tensor, inv_new, new_deriv
+        accepts.append(int(acc))
+        if draw_ind >= n_burnin: rows.append(prev_draw.copy())
+    rows = np.array(rows)
+    return (np.array([_inv_transform(r, bt, lb, ub) for r in rows]) if vb else rows), accepts
+
+
+@pytest.mark.parametrize("which", ["plain", "bounds"])
+@pytest.mark.parametrize("n_fp,L", [(1, 1), (3, 2), (5, 1)])
+def test_python_transcription_of_rmhmc_agrees_with_the_oracle(which, n_fp, L):
+    d, seed, n_burnin, n_keep, step = 4, 41, 2, 10, 0.1
+    tgt = _Target("logit", d, seed=9)
+    lb, ub, _ = _general(d, which, np.random.default_rng(1))
+    init = np.clip(synth.initial_states(1, d, seed=5)[0] * 0.3, -1.0, 1.5)
+    rows, accepts = _py_rmhmc(tgt, _logit_tensor, init, seed, n_burnin, n_keep, L, step, n_fp, lb, ub)
+    okw = dict(lower=lb, upper=ub) if lb is not None else {}
+    st = orc.make_settings(seed=seed, n_burnin=n_burnin, n_keep=n_keep, n_leap=L, step=step, n_fp=n_fp, W=1, **okw)
+    o_draws, o = orc.run_chain(orc.ALGO_RMHMC, tgt.spec, init, st, traces=True)
+    assert list(o["accept"]) == accepts and 0 < sum(accepts)
+    assert np.allclose(o_draws, rows, rtol=1e-8, atol=1e-10)
+
+
+# ---- mcmc::rwmh (ref: src/rwmh.cpp:84-151): new_draw = prev_draw + par_scale CHOL_LOWER(cov_mat) z, min(0, .) in the accept test
+def _py_rwmh(tgt, init, seed, n_burnin, n_keep, par_scale, lb=None, ub=None, cov=None):
+    d = len(init)
+    vb = lb is not None
+    bt = _bounds_type(lb, ub) if vb else None
+    chol = par_scale * np.linalg.cholesky(np.eye(d) if cov is None else cov)
+    def box_log_kernel(v):
+        return tgt(_inv_transform(v, bt, lb, ub), False)[0] + _log_jacobian(v, bt, lb, ub) if vb else tgt(v, False)[0]
+    first = _transform(init, bt, lb, ub) if vb else np.array(init, dtype=np.float64)
+    prev_LP, prev_draw, rows, accepts = box_log_kernel(first), first.copy(), [], []
+    for draw_ind in range(n_burnin + n_keep):
+        new_draw = prev_draw + chol @ orc.normal_vec(seed, 0, draw_ind, 0, d)
+        prop_LP = box_log_kernel(new_draw)
+        if not math.isfinite(prop_LP): prop_LP = -math.inf
+        acc = orc.uniform(seed, 0, draw_ind, 0) < math.exp(min(0.0, prop_LP - prev_LP))
+        if acc: prev_draw, prev_LP = new_draw, prop_LP
+        accepts.append(int(acc))
+        if draw_ind >= n_burnin: rows.append(prev_draw.copy())
+    rows = np.array(rows)
+    return (np.array([_inv_transform(r, bt, lb, ub) for r in rows]) if vb else rows), accepts
+
+
+@pytest.mark.parametrize("kind", ["dense", "logit"])
+@pytest.mark.parametrize("which", ["plain", "bounds", "dense", "bounds+dense"])
+def test_python_transcription_of_rwmh_agrees_with_the_oracle(kind, which):
+    d, seed, n_burnin, n_keep, scale = 6, 53, 3, 25, 0.25
+    tgt = _Target(kind, d, seed=4)
+    lb, ub, cov = _general(d, which, np.random.default_rng(8))
+    init = np.clip(synth.initial_states(1, d, seed=2)[0] * 0.4, -1.0, 1.5)
+    rows, accepts = _py_rwmh(tgt, init, seed, n_burnin, n_keep, scale, lb, ub, cov)
+    okw = {}
+    if lb is not None: okw.update(lower=lb, upper=ub)
+    if cov is not None: okw.update(precond=cov)
+    st = orc.make_settings(seed=seed, n_burnin=n_burnin, n_keep=n_keep, step=scale, W=1, **okw)
+    o_draws, o = orc.run_chain(orc.ALGO_RWMH, tgt.spec, init, st, traces=True)
+    assert list(o["accept"]) == accepts and 0 < sum(accepts) < len(accepts)
+    assert np.allclose(o_draws, rows, rtol=1e-10, atol=1e-12)
