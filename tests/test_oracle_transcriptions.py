@@ -320,3 +320,32 @@ def test_python_transcription_of_rwmh_agrees_with_the_oracle(kind, which):
     o_draws, o = orc.run_chain(orc.ALGO_RWMH, tgt.spec, init, st, traces=True)
     assert list(o["accept"]) == accepts and 0 < sum(accepts) < len(accepts)
     assert np.allclose(o_draws, rows, rtol=1e-10, atol=1e-12)
+
+
+# ---- the non-finite regime.  The reference multiplies by its identity / diagonal matrices as DENSE products, where one
+# non-finite entry makes 0 * inf = NaN in every other row.  numpy's matmul forms every product as well, so the transcriptions above show the
+# same poisoning without having been told about it: NaN patterns and accept sequences must match the oracle's.
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("which", ["plain", "diag"])
+@pytest.mark.parametrize("bad", ["inf", "huge", "nan"])
+def test_transcriptions_poison_like_the_oracle_in_the_non_finite_regime(algo, which, bad):
+    d, seed = 5, 7
+    tgt = _Target("dense", d, seed=3)
+    _, _, M = _general(d, which, np.random.default_rng(2))
+    init = synth.initial_states(1, d, seed=4)[0]
+    init[2] = {"inf": np.inf, "huge": 1e300, "nan": np.nan}[bad]
+    okw = dict(precond=M) if M is not None else {}
+    with np.errstate(all="ignore"):
+        if algo == "hmc":
+            rows, accepts = _py_hmc(tgt, init, seed, 1, 6, 3, 0.2, M=M)
+            st = orc.make_settings(seed=seed, n_burnin=1, n_keep=6, n_leap=3, step=0.2, W=1, **okw)
+            o_draws, o = orc.run_chain(orc.ALGO_HMC, tgt.spec, init, st, traces=True)
+        else:
+            rows, accepts = _py_mala(tgt, init, seed, 1, 6, 0.2, M=M)
+            st = orc.make_settings(seed=seed, n_burnin=1, n_keep=6, step=0.2, W=1, **okw)
+            o_draws, o = orc.run_chain(orc.ALGO_MALA, tgt.spec, init, st, traces=True)
+    assert list(o["accept"]) == accepts
+    assert np.array_equal(np.isnan(o_draws), np.isnan(rows)) and np.array_equal(np.isinf(o_draws), np.isinf(rows))
+    assert bad == "huge" or np.isnan(o_draws).any()      # inf / nan starts do reach the regime (1e300 stays finite here: an overflow-free giant)
+    fin = np.isfinite(o_draws)
+    assert np.allclose(o_draws[fin], rows[fin], rtol=1e-9)
