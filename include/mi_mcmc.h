@@ -77,9 +77,13 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_HMC_SPLIT2 = 6,              /* two waves share a tile (row halves of the mat-vec, theta exchanged through LDS) */
     MI_KERNEL_HMC_SPLIT4 = 7,              /* four waves share a tile, one wave per SIMD (16 chains per workgroup) */
     MI_KERNEL_HMC_SPLIT4_TWO_WAVES = 8,    /* four waves share a tile, two waves per SIMD (32 chains per workgroup) */
-    MI_KERNEL_NUTS_TICK_LOCAL = 9          /* nuts, unbounded Gaussian targets, identity precond_mat: the asynchronous kernel that reloads
+    MI_KERNEL_NUTS_TICK_LOCAL = 9,         /* nuts, unbounded Gaussian targets, identity precond_mat: the asynchronous kernel that reloads
                                             * every leaf's start record (what the bounded / preconditioned variants run) instead of the
                                             * default one with register-carried leaf state */
+    MI_KERNEL_NUTS_REG = 10,               /* nuts, same case: register-carried leaf state, one wave per 16-chain tile and per SIMD (the default
+                                            * for d <= 64) */
+    MI_KERNEL_NUTS_SPLIT = 11              /* nuts, same case, 64 < d <= 128: every tile split over two waves, two tiles per SIMD, so that one
+                                            * tile's record traffic runs under the other's mat-vec (the default there) */
 } mi_kernel_hint;
 
 typedef struct mi_target {

@@ -97,8 +97,8 @@ inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const 
 inline void lit_orders(LitTarget& t)
 {
     t.W = 4; t.nblk = 1; t.bs = 0; t.eta_chains = 1;
-    if (t.kind == LIT_LOGISTIC) {
-        t.nblk = 4; t.eta_chains = 2;
+    if (t.kind == LIT_LOGISTIC && t.d <= 512) {          // beyond d = 512 there is no LDS kernel to agree with: plain orders (one block, one
+        t.nblk = 4; t.eta_chains = 2;                    // eta chain) -- four blocks of 128 would DROP the dimensions from 512 on
         t.bs = (t.d <= 64) ? 16u : (t.d <= 128) ? 32u : (t.d <= 256) ? 64u : 128u;
     }
     // dense Gaussians with 128 < d <= 512 run on the LDS-streamed kernel too (logistic_lds.hpp, LOGIT_TARGET_DENSE): rows of P theta as
@@ -108,6 +108,8 @@ inline void lit_orders(LitTarget& t)
         t.bs = (t.d <= 192) ? 48u : (t.d <= 256) ? 64u : (t.d <= 384) ? 96u : 128u;     // 16 NTQ of the instantiation (logistic_lds.hip)
     }
 }
+// every blocked reduction must cover every dimension (dot_b and the blocked eta loop of literal.hpp stop at nblk * bs)
+inline bool lit_orders_cover(const LitTarget& t) { return t.nblk <= 1 || t.bs == 0 || (uint64_t)t.nblk * t.bs >= t.d; }
 
 }  // namespace lit
 }  // namespace mi

@@ -1844,11 +1844,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
     const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
-    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double), ws);   // + non-finite flags + identity tables of the replay
+    const size_t pfrag_bytes = (size_t)128 * 128 * sizeof(double);           // the precision in fragment order (nuts_gauss_split_kernel)
+    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + pfrag_bytes, ws);   // + non-finite flags + identity tables of the replay
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
     uint32_t* const nf_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ws_own_r);
     double* const id_tab = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ws_own_r + flag_bytes);
+    double* const pfrag = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ((ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 255) & ~(size_t)255));
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -1923,7 +1925,10 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         // replayed by the general variant, which reproduces the reference's dense products, with identity tables
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
-        rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
+        // 64 < d <= 128: two waves per tile, two tiles per SIMD (nuts_split.hpp); otherwise one wave per tile (nuts_reg.hpp)
+        const bool split = nt > 4 && target->kernel_hint != MI_KERNEL_NUTS_REG;
+        rc = split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, pfrag, st))
+                   : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         int* bt_i = reinterpret_cast<int*>(id_tab);

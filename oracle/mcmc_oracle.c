@@ -46,6 +46,8 @@ double orc_dot(const double* x, const double* y, size_t d, int W)
 double orc_dot_b(const double* x, const double* y, size_t d, int W, int nblk, size_t bs)
 {
     if (nblk <= 1 || bs == 0) return orc_dot(x, y, d, W);
+    if ((size_t)nblk * bs < d) return NAN;      /* a blocking that does not cover every dimension is a mis-configuration, never a
+                                                   silent truncation: poison the result (tests/orc.py refuses it up front) */
     double r = 0.0;
     for (int k = 0; k < nblk; ++k) {
         const size_t lo = (size_t)k * bs;
@@ -318,6 +320,7 @@ static double orc_row_dot_blocked(const double* x, const double* th, size_t d, i
 {
     const int nch = eta_chains > 1 ? eta_chains : 1;
     const size_t sub = bs / (size_t)nch;
+    if ((size_t)nblk * bs < d) return NAN;      /* as orc_dot_b: never truncate */
     double acc = 0.0;
     for (int k = 0; k < nblk; ++k) {
         double e = 0.0;

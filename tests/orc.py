@@ -68,6 +68,8 @@ class TargetSpec:
 
     def __init__(self, kind, d, prec=None, X=None, y=None, W=4, blocks=0, block_size=0, eta_chains=1):
         self.kind, self.d, self.W = kind, int(d), W
+        if blocks > 1 and block_size > 0 and blocks * block_size < int(d):
+            raise ValueError(f"reduction blocking {blocks} x {block_size} does not cover d = {d}: the blocked sums would drop dimensions")
         self.prec, self.X, self.y = _f64(prec), _f64(X), _f64(y)
         n_rows = self.X.shape[0] if self.X is not None else (self.y.shape[0] if self.y is not None else 0)
         self.c = Target(kind, self.d, _p(self.prec), _p(self.X), _p(self.y), n_rows, W, blocks, block_size, eta_chains, 0, 0, None)
@@ -87,6 +89,7 @@ def make_settings(seed=1, n_burnin=0, n_keep=10, n_leap=1, step=1.0, precond=Non
                  n_burnin, n_keep, n_leap, step, _p(keep["precond"]), n_adapt, delta, max_depth,
                  gamma, t0, kappa, n_fp, W, blocks, block_size, hoist, chain_id, work_mode)
     s._keep = keep
+    s._blocking = (blocks, block_size)
     return s
 
 

@@ -86,10 +86,22 @@ def test_logistic_target_beyond_d512_and_plain_nuts_on_it():
     init = synth.initial_states(C, d, seed=3) * 0.1
     st = mcmc_amd.default_settings(rng_seed_value=2, n_burnin_draws=1, n_keep_draws=3, step_size=0.02)
     g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
-    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=128, eta_chains=2)
-    s = orc.make_settings(seed=2, n_burnin=1, n_keep=3, step=0.02, W=4, hoist=1, blocks=4, block_size=128)
+    # beyond d = 512 no LDS kernel exists whose blocked orders the literal kernel would have to share: plain orders (one block, one eta
+    # chain, W = 4).  Round 3 configured BOTH sides with 4 blocks of 128 -- which silently dropped the dimensions from 512 on;
+    # the oracle now poisons and tests/orc.py refuses a blocking that does not cover d.
+    with pytest.raises(ValueError):
+        orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=128, eta_chains=2)
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4)
+    s = orc.make_settings(seed=2, n_burnin=1, n_keep=3, step=0.02, W=4, hoist=1)
     o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s)
     _check("mala", g_draws, g, o_draws, o)
+    # and the density is the whole one: closed form in numpy at the kept draws, against the oracle's value (tolerance, not bits)
+    for c in range(C):
+        beta = g_draws[-1, :, c]
+        eta = X @ beta
+        want = float(np.sum(y * eta - np.logaddexp(0.0, eta)) - 0.5 * beta @ beta)
+        got, _ = t.kernel(beta, want_grad=False)
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want))
     # configs[2]'s own target (d = 512) under nuts: the configuration VERDICT r2 listed as missing
     d = 512
     X, y = synth.logistic_problem(d, N, seed=7)

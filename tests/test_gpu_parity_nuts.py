@@ -40,12 +40,16 @@ CASES = [
     ("dense", 33, 40, 4, 8, 6, 4, 1.0),          # odd d, shallow trees (max_tree_depth cap hit)
     ("diag", 20, 32, 0, 12, 0, 6, 0.05),         # no adaptation: fixed small step -> deep trees
     ("dense", 16, 64, 2, 10, 12, 1, 1.0),        # max_tree_depth = 1
+    ("dense", 100, 150, 3, 5, 5, 10, 1.0),       # three workgroups of the split kernel, the last tile partly live, d short of its row tiles
+    ("dense", 128, 24, 0, 4, 0, 7, 0.02),        # fixed small step at d = 128: trees to the cap, every level of the unwind
+    ("dense", 65, 16, 2, 3, 0, 0, 1.0),          # max_tree_depth = 0: the while-loop of nuts.cpp:227 never entered
 ]
 
 
-# default: the asynchronous kernel with register-carried leaf state (nuts_reg.hpp); the tick-local asynchronous kernel (what the
-# bounded / preconditioned variants run) and the lock-step predecessor must give the same bits
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
+# default: split tiles, two per SIMD, for 64 < d <= 128 (nuts_split.hpp), one wave per tile with register-carried leaf state below
+# (nuts_reg.hpp: KERNEL_NUTS_REG forces it at any d); the tick-local asynchronous kernel (what the bounded / preconditioned variants
+# run) and the lock-step predecessor must give the same bits
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
 
 
 @pytest.mark.parametrize("hint", KERNELS)
@@ -60,6 +64,8 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
                                    n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
     g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
+    if hint == mcmc_amd.KERNEL_AUTO:
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_split_kernel" if d > 64 else "nuts_gauss_reg_kernel")
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
     assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs

@@ -1,5 +1,5 @@
-"""A/B timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events): register-carried leaf state (nuts_reg.hpp)
-vs the tick-local asynchronous kernel, same box, alternating."""
+"""A/B timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events): split tiles, two per SIMD (nuts_split.hpp)
+vs one wave per tile with register-carried leaf state (nuts_reg.hpp), same box, alternating."""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch, mcmc_amd
@@ -16,7 +16,7 @@ n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
 st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn)
 ref = None
 for rep in range(2):
-    for name, hint in (("reg", mcmc_amd.KERNEL_AUTO), ("tick_local", mcmc_amd.KERNEL_NUTS_TICK_LOCAL)):
+    for name, hint in (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)):
         t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
         ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, mem=mcmc_amd.MEM_DEVICE)
         theta.copy_(theta0)
