@@ -33,7 +33,7 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m,
 int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m = false);
 // the plain case at d in (64, 128], every tile split over two waves, two tiles per SIMD (nuts_split.hpp); pfrag: 128 KB of device
 // scratch for the precision in fragment order (packed here, on the stream)
-int launch_nuts_gauss_split(const NutsParams& prm, int nt, double* pfrag, hipStream_t st);         // nuts_split_launch.hip
+int launch_nuts_gauss_split(const NutsParams& prm, int nt, int tiles_per_wg, double* pfrag, hipStream_t st);         // nuts_split_launch.hip
 int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
 int launch_nuts_gauss_dense_m(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_dense_launch.hip
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);

@@ -1860,7 +1860,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
 #ifdef MI_PROFILING
     DevBuf prof_buf;
-    if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(16 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 128)); prm.prof = prof_buf.as<unsigned long long>(); }
+    if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(96 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 96 * 8)); prm.prof = prof_buf.as<unsigned long long>();
+        if (const char* e = getenv("MI_SPLIT_TILES")) { const unsigned long long nt_ = (unsigned long long)atoi(e); HIP_TRY(hipMemcpy(prm.prof + 95, &nt_, 8, hipMemcpyHostToDevice)); } }
 #endif
     prm.seed = settings->rng_seed_value;
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
@@ -1925,9 +1926,16 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         // replayed by the general variant, which reproduces the reference's dense products, with identity tables
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
-        // 64 < d <= 128: two waves per tile, two tiles per SIMD (nuts_split.hpp); otherwise one wave per tile (nuts_reg.hpp)
-        const bool split = nt > 4 && target->kernel_hint != MI_KERNEL_NUTS_REG;
-        rc = split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, pfrag, st))
+        // One wave per tile with register-carried leaf state (nuts_reg.hpp) is the throughput shape.  nuts_split.hpp spreads a tile over
+        // two waves: with FEW chains (no more tiles than the chip has SIMD pairs) that is the shorter tick per tile -- a run then lasts
+        // as long as its slowest tile, not as long as the chip needs for all of them -- and on request at any size.
+        int n_cu = 256;
+        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+        const uint64_t C_ = chains->n_chains;
+        const bool few = C_ <= (uint64_t)32 * (uint64_t)n_cu;
+        const bool split = nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint != MI_KERNEL_NUTS_REG && few));
+        const int tpw = !few ? 4 : (C_ > (uint64_t)16 * (uint64_t)n_cu ? 2 : 1);
+        rc = split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, tpw, pfrag, st))
                    : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
@@ -1946,7 +1954,20 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
 #ifdef MI_PROFILING
-    if (prm.prof) {
+    if (prm.prof && mi::host::last_kernel().rfind("nuts_gauss_split", 0) == 0) {
+        unsigned long long h[96];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));
+        const char* names[12] = {"phase A", "top loads", "kick loop", "gradient (exch+matvec)", "kick2 + relay", "stores", "unwind", "take/pending/copy", "fin block", "loop head", "(await total)", "(ticks)"};
+        for (int wv = 0; wv < 8; ++wv) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 10; ++k) tot += h[wv * 12 + k];
+            fprintf(stderr, "[split prof] wave %d: %llu ticks, %.1f k cycles per tick;", wv, h[wv * 12 + 11], (double)tot / (double)(h[wv * 12 + 11] ? h[wv * 12 + 11] : 1) / 1e3);
+            for (int k = 0; k < 11; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)h[wv * 12 + k] / (double)(tot ? tot : 1));
+            fprintf(stderr, "\n");
+        }
+    }
+    else if (prm.prof) {
         unsigned long long h[12];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));

@@ -31,12 +31,14 @@
 
 namespace mi {
 
-template <int NT>
+// TPW = chain tiles per workgroup (2 TPW waves): 4 = two tiles per SIMD; 2 (1) = one wave per SIMD (on half the SIMDs), the shapes for
+// fewer tiles than the chip has SIMD pairs
+template <int NT, int TPW>
 constexpr size_t nuts_split_lds_bytes()
 {
     constexpr int NS = 4 * NT;
-    // fragments of two row tiles per wave role, exchange buffers of 4 tiles, levels 1..10, per-wave scalars, non-finite flags, counters
-    return ((size_t)(NT / 2) * NS * 64 + (size_t)8 * (NS / 2 + 1) * 64 + (size_t)NUTS_MAX_DEPTH * 4 * 64 + (size_t)8 * 7 * 16 + 32 + 4) * sizeof(double);
+    // fragments of two row tiles per wave role, exchange buffers, levels 1..10, per-wave scalars, non-finite flags, counters
+    return ((size_t)(NT / 2) * NS * 64 + (size_t)2 * TPW * (NS / 2 + 1) * 64 + (size_t)NUTS_MAX_DEPTH * 4 * 16 * TPW + (size_t)2 * TPW * 7 * 16 + 8 * TPW + TPW) * sizeof(double);
 }
 
 // P (d x d row-major) -> MFMA A-fragment order [t][s][lane] = P[16 t + (lane & 15)][4 s + (lane >> 4)], zero padded to 16 NT
@@ -51,9 +53,10 @@ __global__ void pack_precision_fragments_kernel(const double* __restrict__ P, ui
     out[(size_t)f * 64 + lane] = (row < d && col < d) ? P[(size_t)row * d + col] : 0.0;
 }
 
-template <int NT>
-__global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel(const NutsParams prm)
+template <int NT, int TPW>
+__global__ MI_NO_DS_MERGE __launch_bounds__(128 * TPW, 2) void nuts_gauss_split_kernel(const NutsParams prm)
 {
+    static_assert(TPW == 1 || TPW == 2 || TPW == 4, "1, 2 or 4 tiles per workgroup");
     static_assert(NT == 8, "the split kernel is the d = 128 shape (smaller precisions leave LDS for nuts_gauss_reg_kernel's own second workgroup)");
     constexpr int NS = 4 * NT;
     constexpr int NSO = NS / 2;                          // slices a wave owns
@@ -64,11 +67,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
     extern __shared__ __attribute__((aligned(16))) double lds_all[];
     double* const lds_P = lds_all;                                   // [2 roles][NTL][NS][64]
     constexpr int XS = NSO + 1;                                      // exchange slots per wave: its theta slices + one early partial sum
-    double* const lds_x = lds_P + 2 * NTL * NS * 64;                 // [4 tiles][2 roles][XS][64]
-    double* const lds_lvl = lds_x + 8 * XS * 64;                     // [levels 1..10][4][64]
-    double* const lds_pw = lds_lvl + NUTS_MAX_DEPTH * 4 * 64;        // [8 waves][7][16]: per-wave copies of the read-modify-written scalars
-    uint32_t* const lds_nf = reinterpret_cast<uint32_t*>(lds_pw + 8 * 7 * 16);   // [64]
-    uint32_t* const lds_sig = lds_nf + 64;                           // [4 tiles][2 roles] sequence counters
+    double* const lds_x = lds_P + 2 * NTL * NS * 64;                 // [tiles][2 roles][XS][64]
+    constexpr int CW = 16 * TPW;                                     // chains per workgroup
+    double* const lds_lvl = lds_x + 2 * TPW * XS * 64;               // [levels 1..10][4][CW]
+    double* const lds_pw = lds_lvl + NUTS_MAX_DEPTH * 4 * CW;        // [waves][7][16]: per-wave copies of the read-modify-written scalars
+    uint32_t* const lds_nf = reinterpret_cast<uint32_t*>(lds_pw + 2 * TPW * 7 * 16);   // [CW]
+    uint32_t* const lds_sig = lds_nf + CW;                           // [tiles][2 roles] sequence counters
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     {   // stage the LDS-resident fragments from the packed copy (coalesced), zero the counters
@@ -77,16 +81,19 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             const int hh = f / (NTL * NS), r = f % (NTL * NS);       // role, (tt, s)
             lds_P[f * 64 + lane] = prm.Pfrag[((size_t)(hh * NTO) * NS + r) * 64 + lane];
         }
-        if (threadIdx.x < 8) lds_sig[threadIdx.x] = 0u;
+        if (threadIdx.x < 2 * TPW) lds_sig[threadIdx.x] = 0u;
         __syncthreads();                                             // the only workgroup barrier of the kernel
     }
     const int tile = __builtin_amdgcn_readfirstlane(wave >> 1);
     const int h = __builtin_amdgcn_readfirstlane(wave & 1);
     const int j4 = lane >> 4;
     const int ct = tile * 16 + (lane & 15);                          // chain within the workgroup
-    const uint64_t cl = ((uint64_t)blockIdx.x * 4 + tile) * 16 + (lane & 15);
+    const uint64_t cl = ((uint64_t)blockIdx.x * TPW + tile) * 16 + (lane & 15);
     const bool live = cl < prm.C;
     if (__ballot(live) == 0ull) return;                              // (both waves of the tile agree)
+#ifdef MI_NUTS_SPLIT_PROF
+    if (prm.prof != nullptr && prm.prof[95] != 0ull && (unsigned long long)tile >= prm.prof[95]) return;    // experiment: fewer tiles per workgroup (results void)
+#endif
     const uint64_t cld = live ? cl : prm.C - 1;
     const uint64_t chain = prm.chain0 + cl;
     const uint32_t d = prm.d;
@@ -94,7 +101,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
     const int s0 = h * NSO;                                          // first own slice
     const size_t lane_off = (size_t)j4 * C + cld;
 
-    auto lvl = [&](int l, int f) -> double& { return lds_lvl[((l - 1) * 4 + f) * 64 + ct]; };        // l = 1 .. 10
+    auto lvl = [&](int l, int f) -> double& { return lds_lvl[((l - 1) * 4 + f) * CW + ct]; };        // l = 1 .. 10
     auto pw = [&](int k) -> double& { return lds_pw[(wave * 7 + k) * 16 + (lane & 15)]; };
     // exchange buffers of the tile: the own half (written here, read by the partner) and the partner's
     double* const x_own = lds_x + ((size_t)(tile * 2 + h) * XS) * 64 + lane;
@@ -113,19 +120,32 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
     };
     // (A partner that never arrives would hang the GPU: after ~1 s of polling a wave stops waiting for good and runs out on whatever
     //  it reads -- a broken build fails its parity tests instead of the box.  A healthy wait lasts a phase of a tick, microseconds.)
+#ifdef MI_NUTS_SPLIT_PROF   // phase clocks of workgroup 0, every wave (tools/nuts_prof.py; a variant build, never the shipped library)
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = clock64();
+#define MI_SPROF(k) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
+#define MI_SPROF_WAIT0 const unsigned long long tw0_ = clock64();
+#define MI_SPROF_WAIT1 pc[10] += clock64() - tw0_;
+#else
+#define MI_SPROF(k)
+#define MI_SPROF_WAIT0
+#define MI_SPROF_WAIT1
+#endif
     bool sync_lost = false;
     auto await = [&](uint32_t n) __attribute__((always_inline)) {
+        MI_SPROF_WAIT0
         uint32_t spins = 0;
         while (!sync_lost && __hip_atomic_load(sig_par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24)) sync_lost = true;
         }
         asm volatile("" ::: "memory");
+        MI_SPROF_WAIT1
     };
     // workspace: [tile][vector] blocks of NS * 512 bytes, wave-uniform base + one 32-bit byte offset per access; inside a vector
     // [chain][pair of slices][j4] in 16-byte granules (nuts_async.hpp): wave h moves the second / first 512 bytes of a chain's KB
     const int tile_u = tile;
-    char* const ws_tile_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + tile_u) * ((size_t)WS_NVEC * NS * 512);
+    char* const ws_tile_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * TPW + tile_u) * ((size_t)WS_NVEC * NS * 512);
     uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)j4 * 16u + (uint32_t)h * (uint32_t)(NSO * 32);   // redefined (opaquely) at the top of every tick
     auto wsp = [&](int v, int k) -> double* {                // k even: the pair (k, k + 1) of this lane's OWN slices
         return reinterpret_cast<double*>(ws_tile_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)(k >> 1) * 64u));
@@ -192,6 +212,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
 #pragma unroll
         for (int tt = 0; tt < NTL; ++tt) al_cur[tt] = lfr(tt, 0);
         await(n);
+#ifdef MI_NUTS_SPLIT_PROF
+        { const unsigned long long tn_ = clock64(); pc[9] += tn_ - tmark; tmark = tn_; }     // (exchange + wait for the partner, booked under "loop head")
+#endif
         if (early != nullptr && h == 1) { *early = x_par[NSO * 64]; early_body(*early); }
         auto half = [&](auto first_c, auto own_c) __attribute__((always_inline)) {
             constexpr int sb = decltype(first_c)::value ? 0 : NSO;
@@ -453,6 +476,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
 #pragma unroll 1
     while (__ballot(state != NS_DONE) != 0ull) {
         asm volatile("" : "+v"(lane_b));
+        MI_SPROF(9)
         // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
         if (__ballot(state == NS_NEED_DRAW) != 0ull) {
             store_row(row_pend, pvec(pb0), row_draw);
@@ -483,7 +507,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             else { end_draw(p, 0u); if (p) state = NS_NEED_DRAW; }              // while-loop of :227 never entered
         }
         const bool run = state == NS_TREE;
+        MI_SPROF(0)
         if (__ballot(run) == 0ull) continue;
+#ifdef MI_NUTS_SPLIT_PROF
+        pc[11]++;
+#endif
 
         // ------------------------------------------------------------ B. one leaf for every running chain
         auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
@@ -515,6 +543,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             }
             if (__ballot(eager) != 0ull) { if (eager) { ld_row(eb_t, dd); ld_row(eb_p, Lp); } }
         }
+        MI_SPROF(1)
         // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w;  d = theta(b2) - theta(b) (by direction), Lp = p(b).
         // d . p(b) needs nothing of the mat-vec: its chain rides the exchange of theta (wave 0's partial sum travels with its slices,
         // wave 1 finishes it before its MFMAs), so p(b) is dead across the mat-vec -- 32 registers the kernel does not have.
@@ -527,11 +556,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             dd[k] = (vdir > 0) ? (th[k] - tb) : (tb - th[k]);
             Lp[k] = eager ? Lp[k] : p0;
         }
+        MI_SPROF(2)
         double q1c = 0.0;                                // wave 0: its partial chain; wave 1: the finished chain, lane classes not yet added
         gradient(&q1c, [&](double& q_) {
 #pragma unroll
             for (int k = 0; k < NSO; ++k) q_ = dfma(dd[k], Lp[k], q_);
         });
+        MI_SPROF(3)
 #pragma unroll
         for (int k = 0; k < NSO; ++k) pm[k] = pm[k] - (e_signed * w[k]) / 2.0;
         double q4[4];                                    // d.p(b2), theta.P theta, p.p by relay; d.p(b) rides along finished
@@ -547,6 +578,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             }, &q1c);
             q4[0] = q1c; q4[1] = q3[0]; q4[2] = q3[1]; q4[3] = q3[2];
         }
+        MI_SPROF(4)
         double pU = 0.5 * q4[2];                         // nuts.ipp:134-138
         const double pK = q4[3] / 2.0;                   // :140
         if (!is_finite(pU)) pU = INF;
@@ -572,6 +604,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
         bool cref_regs = true;                           // carried proposal: this leaf (registers) ...
         int cref_t = rec_t, cref_w = rec_w;              // ... or a record (theta, P*theta)
         if (run) n_leap++;
+        MI_SPROF(5)
         // ---- unwind (nuts.ipp:212-229), per-chain leaf index
         bool failed = run && !cs;
         bool walking = run;
@@ -604,6 +637,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227
             if (need_ut && !ok) failed = true;                                   // :229
         }
+        MI_SPROF(6)
         // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279)
         const bool keep = run && !failed;
         const bool complete = keep && (li == (1u << jd) - 1u);
@@ -638,6 +672,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
                 }
             }
         }
+        MI_SPROF(7)
         if (__ballot(fin) != 0ull) {
             if (fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
             bool s_ok = false;
@@ -671,7 +706,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, 2) void nuts_gauss_split_kernel
             begin_doubling(more || roll);
         }
         if (run && !fin) li = li + 1;
+        MI_SPROF(8)
     }
+#ifdef MI_NUTS_SPLIT_PROF
+    if (prm.prof && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 12; ++k) prm.prof[wave * 12 + k] = pc[k];
+#endif
 
     if (sync_lost && prm.nf_flag != nullptr && lane == 0) prm.nf_flag[C] = 0xdeadu;      // (the replay then runs over garbage flags: the run is void either way)
     const bool replay = lds_nf[ct] != 0u && prm.nf_flag != nullptr;

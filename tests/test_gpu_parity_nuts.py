@@ -46,10 +46,10 @@ CASES = [
 ]
 
 
-# default: split tiles, two per SIMD, for 64 < d <= 128 (nuts_split.hpp), one wave per tile with register-carried leaf state below
-# (nuts_reg.hpp: KERNEL_NUTS_REG forces it at any d); the tick-local asynchronous kernel (what the bounded / preconditioned variants
-# run) and the lock-step predecessor must give the same bits
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
+# default: one wave per tile with register-carried leaf state (nuts_reg.hpp: KERNEL_NUTS_REG forces it); for 64 < d <= 128 and few chains
+# the tiles split over two waves (nuts_split.hpp: KERNEL_NUTS_SPLIT forces it, with 1, 2 or 4 tiles per workgroup by the number of chains);
+# the tick-local asynchronous kernel (what the bounded / preconditioned variants run) and the lock-step predecessor must give the same bits
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_LOCKSTEP]
 
 
 @pytest.mark.parametrize("hint", KERNELS)
@@ -64,7 +64,7 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
                                    n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
     g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
-    if hint == mcmc_amd.KERNEL_AUTO:
+    if hint in (mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_SPLIT):      # (these cases are few chains: AUTO picks the split shapes too)
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_split_kernel" if d > 64 else "nuts_gauss_reg_kernel")
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
@@ -177,3 +177,22 @@ def test_general_nuts_between_d64_and_d128(d, general, n_adapt):
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
     assert np.array_equal(g["eps"], o["eps"]) and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
     assert np.array_equal(g_draws, o_draws)
+
+
+def test_split_nuts_kernel_every_workgroup_shape_gives_the_bits_of_the_register_carried_kernel():
+    """nuts_gauss_split_kernel<8, 1 | 2 | 4> (tiles per workgroup, picked from the number of chains): 5 000 chains take two tiles per
+    workgroup on a 256-CU part, 9 000 four (forced), 700 one; all equal to nuts_gauss_reg_kernel bit for bit, ragged last tiles included."""
+    d = 128
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    st = mcmc_amd.default_settings(rng_seed_value=11, n_burnin_draws=4, n_keep_draws=3, n_adapt_draws=4, max_tree_depth=5)
+    seen = set()
+    for C in (700, 5000, 9000):
+        init = synth.initial_states(C, d, seed=C)
+        ref, r = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3, kernel_hint=mcmc_amd.KERNEL_NUTS_REG)
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_reg_kernel")
+        got, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3, kernel_hint=mcmc_amd.KERNEL_NUTS_SPLIT)
+        seen.add(mcmc_amd.last_kernel())
+        assert np.array_equal(got, ref)
+        for k in ("n_accept", "n_leap", "eps", "depth"):
+            assert np.array_equal(g[k], r[k]), k
+    assert all(k.startswith("nuts_gauss_split_kernel<8, ") for k in seen) and len(seen) >= 2, seen
