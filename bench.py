@@ -205,7 +205,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
     world, rank, dev, dist, share = ctx.world, ctx.rank, ctx.dev, ctx.dist, ctx.share
     cfg = dict(WORKLOADS[cfg_id])
     d, algo = cfg["d"], cfg["algo"]
-    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    scaling = args.scaling or "strong"     # north_star: the chain total is fixed as N grows (at N = 1 the two coincide)
     if scaling == "weak":
         C = args.chains or cfg["chains"]
         chain0, total = rank * C, (args.chains or cfg["chains"]) * world
@@ -339,6 +339,14 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": k_ms, "flop_per_unit": fpu},
         }
+        # achieved = max(bytes term, flops term), reported with BOTH terms.  The bytes term is the 32 B / unit streaming
+        # model (read theta, p + write theta, p per chain x dim x step) against the 8 TB/s HBM peak; a kernel that keeps the state
+        # register-resident moves less than the model, so its bytes term can exceed 1 -- it is a model, the counter figure below is
+        # what the launch moved.  `frac` stays the term of the bound SURVEY 8(d) assigns the config.
+        units_per_s = units_rank / (k_ms * 1e-3)
+        out["roofline"]["flops_term"] = {"achieved_TFLOPs": achieved, "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac": achieved / FP64_PEAK_TFLOPS}
+        out["roofline"]["bytes_model_term"] = {"bytes_per_unit": 32, "achieved_TBps": units_per_s * 32 / 1e12, "peak_TBps": 8.0,
+                                               "frac": units_per_s * 32 / 8e12}
         if traffic is not None:      # HBM side of the same launch
             out["roofline"]["hbm_TBps"] = traffic / (k_ms * 1e-3) / 1e12
             out["roofline"]["hbm_frac_of_8TBps"] = out["roofline"]["hbm_TBps"] / 8.0
@@ -357,6 +365,11 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
             out["ess_note"] = (f"min-over-dims Geyer-IPS ESS of the {n_keep} kept draws (autocovariance pooled over all chains of rank 0 on "
                                "the device), x chains x ranks, / seconds per step; _incl_reducer adds the time of mi_mcmc_draw_stats itself")
             out["rhat_max"] = rhat_max
+            # a number is not an estimate: few kept draws or chains that have not converged (R-hat far from 1) make ESS meaningless
+            out["ess_is_estimate"] = bool(n_keep >= 20 and rhat_max == rhat_max and rhat_max < 1.1)
+            if not out["ess_is_estimate"]:
+                out["ess_caveat"] = (f"NOT an estimate: n_keep = {n_keep}" + (" < 20" if n_keep < 20 else "") +
+                                     f", rhat_max = {rhat_max:.3g}" + (" (chains not converged)" if not rhat_max < 1.1 else ""))
         if headline and cfg_id == 5 and C > 1 and not args.no_ess:
             # the second half of BASELINE.json's metric on this target is decided by the mass matrix, not by the kernel:
             # the same workload through mi_mcmc_hmc_run_mass_adapted (NOT a reference mode), outside the timed region

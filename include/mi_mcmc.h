@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000302
+#define MI_MCMC_VERSION 0x000400
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -69,7 +69,8 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_AUTO = 0,
     MI_KERNEL_ELEMENTWISE_1LANE = 1,  /* hmc, separable Gaussian targets: one lane per chain (default for d > 128, many chains) */
     MI_KERNEL_ELEMENTWISE_4LANE = 2,  /* hmc, separable Gaussian targets: four lanes per chain */
-    MI_KERNEL_NUTS_LOCKSTEP = 3,      /* nuts, unbounded Gaussian targets: the lock-step predecessor of the asynchronous kernel */
+    MI_KERNEL_NUTS_LOCKSTEP = 3,      /* nuts, unbounded Gaussian targets: the lock-step predecessor of the asynchronous kernel -- compiled into the
+                                       * A/B library (`make prof`) only; the shipped library runs the tick-local kernel for this hint */
     /* hmc, dense-gradient Gaussian target, 64 < d <= 128, unbounded, identity precond_mat: the launch shape.  AUTO picks it from
      * the number of chains and of compute units (the shapes below are what makes 65 536 chains strong-scale over 8 GPUs). */
     MI_KERNEL_HMC_TWO_WAVES_PER_SIMD = 4,  /* 8 waves per workgroup, one 16-chain tile per wave: enough chains to fill the chip */
@@ -321,13 +322,8 @@ int mi_mcmc_draws_to_chain_major_device(const double* draws_kdc_dev, uint64_t n_
 int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, uint64_t d, uint64_t n_chains,
                        double* mean, double* acov, double* rhat, double* ess, void* stream);
 
-/* Diagnostics used by the GPU tests (host pointers, blocking). */
-int mi_probe_mfma_f64(const double* A16x4, const double* B4x16, const double* C16x16, double* D16x16);
-int mi_probe_math(int fn, const double* x, uint64_t n, double* out, double* out2);
-int mi_probe_normals(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t stream, uint64_t d, double* out);
-int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot, double* out);
-int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out);
-int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cycles_per_mfma, double* tflops_out);
+/* (The diagnostics the GPU tests and the measurement tools use -- mi_probe_* -- are not part of this library: they live in
+ * libmi_mcmc_probes.so, declared in mcmc_amd/csrc/mi_mcmc_probes.h.) */
 
 #ifdef __cplusplus
 }

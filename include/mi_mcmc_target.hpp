@@ -33,7 +33,7 @@
 #include <type_traits>
 
 #include "mi_mcmc.h"
-#include "../mcmc_amd/csrc/small_samplers.hpp"
+#include "mi_mcmc_engine/small_samplers.hpp"
 
 namespace mi {
 

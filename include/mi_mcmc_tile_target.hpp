@@ -38,7 +38,7 @@
 #include <type_traits>
 
 #include "mi_mcmc.h"
-#include "../mcmc_amd/csrc/tile_samplers.hpp"
+#include "mi_mcmc_engine/tile_samplers.hpp"
 
 namespace mi {
 namespace tile {

@@ -63,8 +63,9 @@ EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target", "mi_mcmc_run_user_target_v", "mi_mcmc_run_tile_target",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback", "mi_mcmc_rmhmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
-    "mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles",
 ]
+# test / measurement infrastructure: libmi_mcmc_probes.so (mcmc_amd/csrc/mi_mcmc_probes.h), not part of the shipped library
+PROBE_EXPORTS = ["mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles"]
 
 
 def _one_hip_runtime():
@@ -104,6 +105,21 @@ def lib():
         _lib.mi_mcmc_last_error.restype = C.c_char_p
         _lib.mi_mcmc_last_kernel.restype = C.c_char_p
     return _lib
+
+
+_plib = None
+
+
+def probes_lib():
+    """Load libmi_mcmc_probes.so: the diagnostics of the GPU tests and tools/ (linked against the engine, loaded after it)."""
+    global _plib
+    if _plib is None:
+        lib()
+        path = os.path.join(os.path.dirname(LIB_PATH), "libmi_mcmc_probes.so")
+        if not os.path.exists(path):
+            raise MiMcmcError(-1, f"{path} not built: run `make -C mcmc_amd/csrc`")
+        _plib = C.CDLL(path)
+    return _plib
 
 
 def _check(rc):
@@ -351,7 +367,7 @@ def probe_mfma(A, B, Cin):
     B = np.ascontiguousarray(B, dtype=np.float64)
     Cin = np.ascontiguousarray(Cin, dtype=np.float64)
     D = np.zeros((16, 16))
-    _check(lib().mi_probe_mfma_f64(C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data),
+    _check(probes_lib().mi_probe_mfma_f64(C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data),
                                    C.c_void_p(Cin.ctypes.data), C.c_void_p(D.ctypes.data)))
     return D
 
@@ -359,34 +375,34 @@ def probe_mfma(A, B, Cin):
 def probe_math(fn, x):
     x = np.ascontiguousarray(x, dtype=np.float64)
     o1, o2 = np.empty_like(x), np.empty_like(x)
-    _check(lib().mi_probe_math(fn, C.c_void_p(x.ctypes.data), C.c_uint64(x.size),
+    _check(probes_lib().mi_probe_math(fn, C.c_void_p(x.ctypes.data), C.c_uint64(x.size),
                                C.c_void_p(o1.ctypes.data), C.c_void_p(o2.ctypes.data)))
     return o1, o2
 
 
 def probe_normals(seed, chain, draw, stream, d):
     out = np.zeros(d)
-    _check(lib().mi_probe_normals(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
+    _check(probes_lib().mi_probe_normals(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
                                   C.c_uint32(stream), C.c_uint64(d), C.c_void_p(out.ctypes.data)))
     return out
 
 
 def probe_uniform(seed, chain, draw, slot):
     out = np.zeros(1)
-    _check(lib().mi_probe_uniform(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
+    _check(probes_lib().mi_probe_uniform(C.c_uint64(seed), C.c_uint64(chain), C.c_uint32(draw),
                                   C.c_uint32(slot), C.c_void_p(out.ctypes.data)))
     return float(out[0])
 
 
 def probe_fp64_peak(use_mfma, iters=20000):
     out = C.c_double(0.0)
-    _check(lib().mi_probe_fp64_peak(int(use_mfma), int(iters), C.byref(out)))
+    _check(probes_lib().mi_probe_fp64_peak(int(use_mfma), int(iters), C.byref(out)))
     return out.value
 
 
 def probe_mfma_cycles(waves_per_simd, use_lds, iters=20000):
     cyc, tf = C.c_double(0.0), C.c_double(0.0)
-    _check(lib().mi_probe_mfma_cycles(int(waves_per_simd), int(use_lds), int(iters), C.byref(cyc), C.byref(tf)))
+    _check(probes_lib().mi_probe_mfma_cycles(int(waves_per_simd), int(use_lds), int(iters), C.byref(cyc), C.byref(tf)))
     return cyc.value, tf.value
 
 

@@ -26,17 +26,18 @@ constexpr size_t hmc_split_lds_bytes()
     return ((size_t)NT * NS * 64 + (size_t)TILES * NS * 64) * sizeof(double);       // d = 128, SPLIT = 2: exactly the 160 KB of a CU
 }
 
-// The role h of a wave inside its tile is a template parameter: every slice index below is then a compile-time constant (a
-// run-time h would turn the register arrays into scratch memory).  The waves of a workgroup run different instantiations but
-// the same sequence of barriers.
-template <int NT, int SPLIT, int WPB, int H>
-__device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds_P)
+// The role h of a wave inside its tile is a RUN-TIME, wave-uniform value that enters addresses only: the wave keeps its own slices in
+// `own[NSO]` (compile-time indices) and takes every B operand of the mat-vec -- its own slices included -- from the LDS exchange
+// buffer, one read ahead of the MFMAs that use it.  So there is ONE body for all roles and every barrier sits on the common path that
+// all waves of the workgroup execute (round 3 instantiated the body per role, each copy with its own barriers, and relied on
+// s_barrier counting waves rather than program counters).
+template <int NT, int SPLIT, int WPB>
+__device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds_P, const int h)
 {
     constexpr int NS = 4 * NT;
     constexpr int NSO = NS / SPLIT;          // slices this wave owns
     constexpr int NTO = NT / SPLIT;          // row tiles this wave owns
     constexpr int TILES = WPB / SPLIT;       // chain tiles per workgroup (WPB = 4: one wave per SIMD; 8: two, one's exchange / kick / drift under the other's MFMAs)
-    constexpr int h = H;
     double* const lds_x = lds_P + NT * NS * 64;            // [TILES][NS][64]: theta slices of every tile, published by their owners
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,7 +50,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
     const double eps = prm.eps;
-    constexpr int s0 = h * NSO;                            // first own slice
+    const int s0 = h * NSO;                                // first own slice (addresses only: register indices take the role constant)
     double* const xt = lds_x + (size_t)tile * NS * 64 + lane;
     // own A fragments: (t, s) with t = h NTO + tt at ((h NTO + tt) NS + s) * 64 doubles: one per-wave base, immediates below 64 KB
     typedef const double __attribute__((address_space(3)))* lds_cptr;
@@ -57,7 +58,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
     asm volatile("" : "+v"(a_off));
     const lds_cptr afrag = (lds_cptr)(uintptr_t)a_off;
 
-    double full[NS];           // theta of the tile's 16 chains, all slices (MFMA B operands); [s0, s0 + NSO) are this wave's own
+    double own[NSO];           // own slices of theta
     double pm[NSO], w[NSO];    // own slices of the momentum and of P * theta
     const size_t lane_off = (size_t)j * C + cld;
     // last accepted (theta, P*theta), own slices: [tile][2][NS][64 lanes], as hmc_dense.hpp
@@ -65,21 +66,19 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
     auto th_mem = [&](int k) -> double* { return ws_tile + (size_t)(s0 + k) * 64; };
     auto w_mem = [&](int k) -> double* { return ws_tile + (size_t)(NS + s0 + k) * 64; };
 
-    // publish the own slices of theta, fetch everybody else's: the B operands of the next mat-vec
+    // publish the own slices of theta; the B operands of the mat-vec are read back from the buffer (all slices, the own ones too)
     auto exchange = [&]() __attribute__((always_inline)) {
         __syncthreads();                                   // everyone is done reading the previous contents
 #pragma unroll
-        for (int k = 0; k < NSO; ++k) xt[(s0 + k) * 64] = full[s0 + k];
+        for (int k = 0; k < NSO; ++k) xt[(s0 + k) * 64] = own[k];
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (s < s0 || s >= s0 + NSO) full[s] = xt[s * 64];
     };
     // w(own rows) = P(own rows, :) * theta
     auto gradient = [&]() __attribute__((always_inline)) {
         exchange();
         double4_t acc[NTO];
         double a_cur[NTO], a_nxt[NTO];
+        double b_cur = xt[0], b_nxt = 0.0;
 #pragma unroll
         for (int tt = 0; tt < NTO; ++tt) {
             acc[tt] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -90,14 +89,16 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
             if (s + 1 < NS) {
 #pragma unroll
                 for (int tt = 0; tt < NTO; ++tt) a_nxt[tt] = afrag[(tt * NS + s + 1) * 64];
+                b_nxt = xt[(s + 1) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < NTO; ++tt)
-                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[tt], full[s], acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[tt], b_cur, acc[tt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < NTO; ++tt) a_cur[tt] = a_nxt[tt];
+            b_cur = b_nxt;
         }
 #pragma unroll
         for (int tt = 0; tt < NTO; ++tt) {
@@ -128,21 +129,19 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
         return chain_dot([&](int k) { return pm[k]; }, [&](int k) { return pm[k]; }) / 2.0;
     };
     auto potential = [&]() __attribute__((always_inline)) -> double {
-        return 0.5 * chain_dot([&](int k) { return full[s0 + k]; }, [&](int k) { return w[k]; });
+        return 0.5 * chain_dot([&](int k) { return own[k]; }, [&](int k) { return w[k]; });
     };
 
-#pragma unroll
-    for (int s = 0; s < NS; ++s) full[s] = 0.0;
 #pragma unroll
     for (int k = 0; k < NSO; ++k) {
         const uint32_t dim = 4 * (s0 + k) + j;
         const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];   // clamped row: unconditional load
-        full[s0 + k] = (dim < d) ? v : 0.0;
+        own[k] = (dim < d) ? v : 0.0;
     }
     gradient();
     if (live) {
 #pragma unroll
-        for (int k = 0; k < NSO; ++k) { *th_mem(k) = full[s0 + k]; *w_mem(k) = w[k]; }
+        for (int k = 0; k < NSO; ++k) { *th_mem(k) = own[k]; *w_mem(k) = w[k]; }
     }
     double prev_U = potential();                        // -box_log_kernel(first_draw), hmc.cpp:140
     uint64_t n_acc = 0;
@@ -168,7 +167,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
 #pragma unroll
             for (int k = 0; k < NSO; ++k) {
                 pm[k] = pm[k] - (eps * w[k]) / 2.0;
-                full[s0 + k] = full[s0 + k] + eps * pm[k];
+                own[k] = own[k] + eps * pm[k];
             }
         }
 #pragma unroll 1
@@ -179,7 +178,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
                 const double t = (eps * w[k]) / 2.0;
                 pm[k] = pm[k] - t;
                 pm[k] = pm[k] - t;
-                full[s0 + k] = full[s0 + k] + eps * pm[k];
+                own[k] = own[k] + eps * pm[k];
             }
         }
         if (L > 0) {
@@ -200,11 +199,11 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
             prev_U = prop_U;
             if (live) {
 #pragma unroll
-                for (int k = 0; k < NSO; ++k) { *th_mem(k) = full[s0 + k]; *w_mem(k) = w[k]; }
+                for (int k = 0; k < NSO; ++k) { *th_mem(k) = own[k]; *w_mem(k) = w[k]; }
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < NSO; ++k) { full[s0 + k] = *th_mem(k); w[k] = *w_mem(k); }
+            for (int k = 0; k < NSO; ++k) { own[k] = *th_mem(k); w[k] = *w_mem(k); }
         }
         if (draw >= prm.n_burnin) {                     // :196-204
             n_acc += accept ? 1u : 0u;
@@ -213,7 +212,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
 #pragma unroll
                 for (int k = 0; k < NSO; ++k) {
                     const uint32_t dim = 4 * (s0 + k) + j;
-                    if (dim < d) (out + (size_t)(4 * (s0 + k)) * C)[lane_off] = full[s0 + k];
+                    if (dim < d) (out + (size_t)(4 * (s0 + k)) * C)[lane_off] = own[k];
                 }
             }
         }
@@ -225,7 +224,7 @@ __device__ __forceinline__ void hmc_split_body(const HmcParams& prm, double* lds
 #pragma unroll
         for (int k = 0; k < NSO; ++k) {
             const uint32_t dim = 4 * (s0 + k) + j;
-            if (dim < d) prm.theta[(size_t)dim * C + cl] = full[s0 + k];
+            if (dim < d) prm.theta[(size_t)dim * C + cl] = own[k];
         }
     }
     if (live && !replay && j == 0 && h == 0) {
@@ -242,24 +241,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_sp
     static_assert(WPB == 4 || WPB == 8, "one or two waves per SIMD");
     extern __shared__ __attribute__((aligned(16))) double lds_P[];
     stage_precision<NT>(prm.P, prm.d, lds_P);
-    // The waves of a workgroup run DIFFERENT instantiations of the body (their role h is a compile-time constant: register arrays
-    // indexed by it stay registers), each with its own __syncthreads() calls.  What makes that sound on gfx950: a workgroup barrier
-    // is the hardware's s_barrier, which counts arriving WAVES -- not program counters -- and every instantiation executes exactly the
-    // same sequence of barriers (exchange / chain_dot are called from wave-uniform, role-independent control flow: the draw loop, the
-    // leapfrog loop and the accept branch are uniform across the workgroup's waves by construction, all of them running n_total draws of
-    // n_leap_steps steps).  Within a wave every barrier is reached by all 64 lanes.  In the HIP model a barrier reached through
-    // block-divergent control flow is undefined, so this is an architecture assumption, not a language guarantee: it is pinned
-    // by the parity tests of every split shape (tests/test_gpu_parity_hmc.py, test_gpu_nonfinite.py: bit-exact against the oracle, and a
-    // mismatched barrier count hangs rather than passes), which run on every toolchain the library is built with.
+    // one body for every role: h enters addresses only (see hmc_split_body), every barrier is on the common path
     const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) % SPLIT);
-    if constexpr (SPLIT == 2) {
-        if (h == 0) hmc_split_body<NT, 2, WPB, 0>(prm, lds_P); else hmc_split_body<NT, 2, WPB, 1>(prm, lds_P);
-    } else {
-        if (h == 0) hmc_split_body<NT, 4, WPB, 0>(prm, lds_P);
-        else if (h == 1) hmc_split_body<NT, 4, WPB, 1>(prm, lds_P);
-        else if (h == 2) hmc_split_body<NT, 4, WPB, 2>(prm, lds_P);
-        else hmc_split_body<NT, 4, WPB, 3>(prm, lds_P);
-    }
+    hmc_split_body<NT, SPLIT, WPB>(prm, lds_P, h);
 }
 
 }  // namespace mi

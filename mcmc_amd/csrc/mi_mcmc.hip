@@ -139,10 +139,12 @@ struct ReplayWs {
     size_t own_bytes = 0;         // the caller's part, rounded up
     size_t total_bytes = 0;
 };
-ReplayWs replay_layout(size_t own_bytes, uint64_t C, uint32_t d, uint32_t n_rows, bool mala_bounded)
+// needs_matrix: the replay reads a d x max(d, n_rows) matrix transposed (DENSE precision, LOGISTIC design matrix, a dense precond_mat);
+// the separable ISO / DIAG targets of the "any d" elementwise path read none, and their workspace must not grow as d^2
+ReplayWs replay_layout(size_t own_bytes, uint64_t C, uint32_t d, uint32_t n_rows, bool mala_bounded, bool needs_matrix = true)
 {
     ReplayWs r;
-    r.t_doubles = ((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31;
+    r.t_doubles = needs_matrix ? (((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31) : 32;
     r.own_bytes = (own_bytes + 255) & ~(size_t)255;
     r.stride = mi::lit::lit_work_doubles(d, n_rows, mala_bounded);
     r.n_wg = (unsigned)std::min<uint64_t>(C, mala_bounded ? 128u : 512u);
@@ -954,6 +956,7 @@ int literal_run_callback(const char* who, int algo, const double* initial_vals, 
     HIP_TRY(work.alloc(stride * 8));
     HIP_TRY(hipMemcpy(theta.p, initial_vals, d * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(nacc.p, 0, 8)); HIP_TRY(hipMemset(step.p, 0, 8));
+    HIP_TRY(hipDeviceSynchronize());     // the kernel runs on its own NON-BLOCKING stream, which does not order itself behind the null stream's memsets / copies
     lp.C = 1; lp.chain0 = 0; lp.theta = theta.as<double>(); lp.draws = n_keep ? draws.as<double>() : nullptr; lp.n_accept = nacc.as<uint64_t>();
     lp.seed = settings->rng_seed_value;
     lp.n_burnin = (uint32_t)settings->n_burnin_draws; lp.n_keep = (uint32_t)n_keep; lp.n_leap_steps = (uint32_t)settings->n_leap_steps;
@@ -1202,7 +1205,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         q.n_leap_steps = (uint32_t)settings->n_leap_steps; q.eps = settings->step_size;
         q.draw0 = (uint32_t)chains->draw0;
         WsLease scratch;
-        ReplayWs rp = replay_layout(2 * d * chains->n_chains * sizeof(double), chains->n_chains, (uint32_t)d, 0, false);
+        ReplayWs rp = replay_layout(2 * d * chains->n_chains * sizeof(double), chains->n_chains, (uint32_t)d, 0, false, /*needs_matrix=*/false);
         rc = ws_get(st, rp.total_bytes, scratch);
         if (rc) return rc;
         q.scratch = scratch.as<double>();

@@ -20,6 +20,8 @@ int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+#ifdef MI_WITH_LEGACY_KERNELS   // the lock-step first-generation kernel (nuts_dense.hpp: 2.4 KB of scratch per lane at d = 128) ships in the
+                                // A/B library only (`make prof`); the shipped library ignores its hint, as mi_mcmc.h says of a hint it cannot take
 template <int NT>
 int lockstep(const NutsParams& prm, hipStream_t st)
 {
@@ -30,6 +32,7 @@ int lockstep(const NutsParams& prm, hipStream_t st)
     hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm);
     return (int)hipGetLastError();
 }
+#endif
 
 }  // namespace
 
@@ -38,7 +41,11 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, boo
     if (batch < 1) batch = 1;
     if (dense_m) return launch_nuts_gauss_dense_m(prm, nt, batch, st);       // nuts_dense_launch.hip
     if (gen) return launch_nuts_gauss_general(prm, nt, batch, st);          // nuts_general_launch.hip
+#ifdef MI_WITH_LEGACY_KERNELS
     if (ls) return MI_DISPATCH_NT(nt, lockstep<1>(prm, st), lockstep<2>(prm, st), lockstep<4>(prm, st), lockstep<8>(prm, st));
+#else
+    (void)ls;                                             // not in this build: the tick-local asynchronous kernel serves the request, same bits
+#endif
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));
 }
 

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "host_common.hpp"
+#include "mi_mcmc_probes.h"
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 

@@ -59,7 +59,8 @@ def _copy_settings(settings, **fields):
 
 
 def _gather_start(local, c_local, n_chains_total, world, group, comm_dev):
-    """The asynchronous half of _gather_ragged: returns (work, recv, lead, c_max); finish with _gather_finish."""
+    """The asynchronous half of _gather_ragged: returns (work, recv, send) -- the pending collective, its receive buffer [world, ..., c_max]
+    and the send buffer it reads (kept alive until the wait); finish with _gather_finish."""
     import torch
     import torch.distributed as dist
     c_max = shard_bounds(n_chains_total, world, 0)[1]

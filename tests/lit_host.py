@@ -9,8 +9,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 _SO = os.path.join(HERE, "_lit_host.so")
-_SRC = [os.path.join(HERE, "lit_host.hip")] + [os.path.join(ROOT, "mcmc_amd", "csrc", f)
-                                                for f in ("literal.hpp", "literal_host.hpp", "host_linalg.hpp", "det_math.hpp")]
+_ENGINE_INC = os.path.join(ROOT, "include", "mi_mcmc_engine")      # the engine headers that ship with the public ones
+_SRC = ([os.path.join(HERE, "lit_host.hip")] + [os.path.join(ROOT, "mcmc_amd", "csrc", f) for f in ("literal.hpp", "literal_host.hpp", "host_linalg.hpp")]
+        + [os.path.join(_ENGINE_INC, "det_math.hpp")])
 _dp = C.POINTER(C.c_double)
 _lib = None
 
@@ -23,7 +24,7 @@ def lib():
         if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRC):
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-shared",
-                                   "-o", _SO, _SRC[0]])
+                                   f"-I{_ENGINE_INC}", "-o", _SO, _SRC[0]])
         _lib = C.CDLL(_SO)
     return _lib
 

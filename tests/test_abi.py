@@ -32,6 +32,18 @@ def test_library_exports_every_declared_symbol():
     assert sorted(mcmc_amd.EXPORTS) == _declared_functions()
 
 
+def test_probes_live_in_their_own_library_not_in_the_shipped_one():
+    """mi_probe_* are test / measurement infrastructure (mcmc_amd/csrc/mi_mcmc_probes.h, libmi_mcmc_probes.so)."""
+    if not os.path.exists(mcmc_amd.LIB_PATH):
+        pytest.skip("libmi_mcmc.so not built")
+    lib = ctypes.CDLL(mcmc_amd.LIB_PATH)
+    plib = ctypes.CDLL(os.path.join(os.path.dirname(mcmc_amd.LIB_PATH), "libmi_mcmc_probes.so"))
+    hdr = open(os.path.join(ROOT, "mcmc_amd", "csrc", "mi_mcmc_probes.h")).read()
+    for n in mcmc_amd.PROBE_EXPORTS:
+        assert not hasattr(lib, n), f"{n} exported from the shipped library"
+        assert hasattr(plib, n) and n in hdr
+
+
 def test_struct_sizes_and_defaults_match_reference_settings():
     if not os.path.exists(mcmc_amd.LIB_PATH):
         pytest.skip("libmi_mcmc.so not built")
@@ -42,7 +54,7 @@ def test_struct_sizes_and_defaults_match_reference_settings():
     assert (s.n_adapt_draws, s.target_accept_rate, s.max_tree_depth) == (1000, 0.55, 10)
     assert (s.gamma_val, s.t0_val, s.kappa_val) == (0.05, 10.0, 0.75)
     assert s.vals_bound == 0 and not s.precond_mat
-    assert mcmc_amd.lib().mi_mcmc_version() == 0x000302
+    assert mcmc_amd.lib().mi_mcmc_version() == 0x000400
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -1,5 +1,5 @@
 // Timing harness for the LDS-staged logistic kernel (experiments only; not part of the library).
-//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -DMI_RNG_NOINLINE -DMI_LOGIT_ABLATE=<bits> -o lb tools/logit_bench.hip
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -Iinclude/mi_mcmc_engine -DMI_RNG_NOINLINE -DMI_LOGIT_ABLATE=<bits> -o lb tools/logit_bench.hip
 //   ./lb [chains] [draws] [algo 0=mala 1=hmc] [n_leap]
 #ifndef MI_KC_MODE
 #define MI_KC_MODE 2      // as logistic_lds.hip
