@@ -297,6 +297,26 @@ int mi_mcmc_allgather_draws_ragged(void* rccl_comm, uint32_t world_size, uint32_
 int mi_mcmc_merge_shards(const double* rank_major, uint32_t world_size, uint64_t n_keep, uint64_t d, uint64_t n_chains_total,
                          double* all_draws, void* stream);
 
+/* The same collation in SURVEY 8(e)'s own receive layout -- rank-major, all_rank_major [G][n_keep][d][C / G] for equal shards (every
+ * BASELINE split): ONE ncclAllGather straight into the caller's buffer, no staging buffer and no merge kernel (half the memory of the
+ * form above: at configs[4], n_keep = 8, 64 GiB + the 8 GiB local slab per GPU).  Ragged shards arrive packed: shard r at offset
+ * n_keep * d * chain0(r) with its own row length n_local(r) (what mi_mcmc_merge_shards reads), as one grouped broadcast per rank.
+ * mi_mcmc_rank_major_index gives the offset of (kept draw i, dimension j, GLOBAL chain c) in either case (~0 if c is out of range). */
+int mi_mcmc_allgather_draws_rank_major(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
+                                       uint64_t d, uint64_t n_chains_total, double* all_rank_major, void* stream);
+uint64_t mi_mcmc_rank_major_index(uint64_t n_chains_total, uint32_t world_size, uint64_t n_keep, uint64_t d, uint64_t i, uint64_t j, uint64_t c);
+/* Collation OVERLAPPED with sampling ("or per kept-draw slab, overlapped with the next trajectory").  _begin takes the
+ * slab of kept draws [row0, row0 + n_keep) of a run that keeps n_keep_total (local_draws [n_keep][d][n_local], produced on
+ * producer_stream), orders a gather into the run's rank-major buffer behind that stream's work so far, on the library's own
+ * communication stream, and returns at once: the caller goes on to enqueue the next chunk of the run (mi_chains.draw0 continues
+ * it bit-identically) on producer_stream while the slab travels.  _wait makes consumer_stream wait for the gather (block_host != 0:
+ * the calling thread instead) and releases the handle.  Gathers of one communicator must be begun in the same order on every rank. */
+typedef struct mi_collation mi_collation;
+int mi_mcmc_allgather_draws_begin(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
+                                  uint64_t d, uint64_t n_chains_total, uint64_t row0, uint64_t n_keep_total, double* all_rank_major,
+                                  void* producer_stream, mi_collation** handle);
+int mi_mcmc_allgather_draws_wait(mi_collation* handle, void* consumer_stream, int block_host);
+
 /* Layout converters between the engine's [n_keep][d][C] slabs and the reference's per-chain
  * draws_out (n_keep x d, column-major as Eigen stores it: element (i,j) at i + j*n_keep;
  * src/hmc.cpp:138,197). Host memory. */

@@ -44,6 +44,14 @@ struct TileParams {
     uint32_t n_burnin, n_keep, n_leap_steps, draw0;
     double eps;             // step_size
     double s2, rs, cons_term, log_det;      // mala: eps^2, 1 / eps^2, -d log(2 pi) / 2, LOG_DET(eps^2 I) (host, the oracle's order)
+    // nuts (nuts_tile.hpp)
+    double* ws;             // [n_tiles][64 vectors][NS][64 lanes] workspace, tile-local and contiguous
+    double* step_out;       // [C] or nullptr: final step size (in: the adapted step sizes of a continuation, draw0 > 0)
+    uint32_t* depth_trace;  // [n_total][C] or nullptr
+    double* adapt_state;    // [3][C] or nullptr: dual-averaging state (h, epsilon_bar, mu), mi_chains.nuts_adapt_state
+    uint32_t n_adapt, max_depth;
+    double delta, eps_bar0, gamma, t0, kappa;
+    uint32_t lds_user_doubles;              // the target's own LDS (T::lds_doubles()); the sampler's tables follow it
 };
 
 template <class T, class = void> struct tile_wpb_of { static constexpr int value = 4; };

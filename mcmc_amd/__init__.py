@@ -63,6 +63,7 @@ EXPORTS = [
     "mi_settings_default", "mi_mcmc_last_error", "mi_mcmc_last_kernel", "mi_mcmc_version", "mi_mcmc_device_count", "mi_mcmc_release_workspace", "mi_mcmc_run_user_target", "mi_mcmc_run_user_target_v", "mi_mcmc_run_tile_target",
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback", "mi_mcmc_rmhmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
+    "mi_mcmc_allgather_draws_rank_major", "mi_mcmc_rank_major_index", "mi_mcmc_allgather_draws_begin", "mi_mcmc_allgather_draws_wait",
 ]
 # test / measurement infrastructure: libmi_mcmc_probes.so (mcmc_amd/csrc/mi_mcmc_probes.h), not part of the shipped library
 PROBE_EXPORTS = ["mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles"]

@@ -24,6 +24,7 @@
 #include "det_math.hpp"
 #include "hmc_dense.hpp"
 #include "nuts_dense.hpp"
+#include "nuts_tile.hpp"
 #include "nuts_async.hpp"
 #include "mala_dense.hpp"
 #include "rwmh_dense.hpp"
@@ -1059,7 +1060,9 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
                     (unsigned long long)tile_params_bytes, (unsigned long long)sizeof(mi::TileParams));
     if (settings->struct_size != sizeof(mi_settings) || chains->struct_size != sizeof(mi_chains))
         return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
-    if (algo != 0 && algo != 1) return fail(MI_ERR_UNSUPPORTED, "tile targets: hmc (0) and mala (1) are implemented");
+    if (algo != 0 && algo != 1 && algo != 2) return fail(MI_ERR_UNSUPPORTED, "tile targets: hmc (0), mala (1) and nuts (2) are implemented");
+    if (algo == 2 && settings->max_tree_depth > (uint64_t)mi::tile_nuts::NUTS_MAX_DEPTH)
+        return fail(MI_ERR_UNSUPPORTED, "tile targets: nuts with max_tree_depth > %d is not implemented on this route", (int)mi::tile_nuts::NUTS_MAX_DEPTH);
     if (!(nt == 1 || nt == 2 || nt == 4 || nt == 8) || d == 0 || d > (uint64_t)16 * nt) return fail(MI_ERR_BAD_ARG, "tile targets: 1 <= d <= 16 NT, NT in {1, 2, 4, 8}");
     if (wpb != 4 && wpb != 8) return fail(MI_ERR_BAD_ARG, "tile targets: WPB is 4 or 8");
     if (settings->vals_bound || settings->precond_mat)
@@ -1075,8 +1078,10 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
     HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
     if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: the target asks for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (algo == 2) lds_bytes += mi::tile_nuts::lds_doubles() * sizeof(double);     // the sampler's per-level tables behind the target's own LDS
+    if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: target + nuts tables ask for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
     StagedChains sc;
-    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    int rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
     mi::TileParams p{};
     p.d = (uint32_t)d; p.C = chains->n_chains; p.chain0 = chains->chain0;
@@ -1094,14 +1099,26 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         p.log_det = ld;
     }
     WsLease ws;
-    rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
-    if (rc) return rc;
-    p.wsave = ws.as<double>();
-    mi::note_kernel("%s_tile_kernel<user target, %d>", algo == 0 ? "hmc" : "mala", algo == 0 ? wpb : 4);
+    if (algo == 2) {                                       // nuts: 64 workspace vectors per chain (records, pending proposals, edges)
+        p.lds_user_doubles = (uint32_t)((lds_bytes - mi::tile_nuts::lds_doubles() * sizeof(double)) / sizeof(double));
+        if ((rc = nuts_continuation(settings, chains, &p.n_adapt))) return rc;
+        p.max_depth = (uint32_t)settings->max_tree_depth;
+        p.delta = settings->target_accept_rate; p.eps_bar0 = settings->step_size;
+        p.gamma = settings->gamma_val; p.t0 = settings->t0_val; p.kappa = settings->kappa_val;
+        p.step_out = sc.dev.step_size; p.depth_trace = sc.dev.nuts_depth; p.adapt_state = sc.dev.nuts_adapt_state;
+        rc = ws_get(st, (size_t)mi::tile_nuts::NUTS_NVEC * 16 * nt * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), ws);
+        if (rc) return rc;
+        p.ws = ws.as<double>();
+    } else {
+        rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
+        if (rc) return rc;
+        p.wsave = ws.as<double>();
+    }
+    mi::note_kernel("%s_tile_kernel<user target, %d>", algo == 0 ? "hmc" : algo == 1 ? "mala" : "nuts", algo == 0 ? wpb : 4);
     const int e = launch(algo, &p, target_pod, lds_bytes, stream);
     if (e != 0) return fail(MI_ERR_HIP, "tile target kernel launch: %s", hipGetErrorString((hipError_t)e));
     if (algo == 1) { rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st); if (rc) return rc; }
-    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
     if (chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;

@@ -285,6 +285,107 @@ int mi_mcmc_allgather_draws(void* comm, uint32_t world, uint32_t rank, const dou
     return mi_mcmc_merge_shards(scratch, world, n_keep, d, C, all, stream);
 }
 
+// ---- SURVEY 8(e)'s own receive layout: rank-major [G][n_keep][d][C / G], which equal shards fill with ONE ncclAllGather straight into
+// the caller's buffer -- no staging buffer, no merge kernel, half the memory of mi_mcmc_allgather_draws (configs[4], n_keep = 8: 64 GiB
+// + the 8 GiB local slab per GPU instead of 64 + 64 + 8).  Ragged shards: the packed form, shard r at offset rows * chain0(r) with its
+// own row length n_local(r) (what mi_mcmc_merge_shards reads); one grouped broadcast per rank.
+// row0 / n_keep_total: the slab is rows [row0, row0 + n_keep) of a run that keeps n_keep_total draws, gathered INTO the run's one
+// rank-major buffer (per kept-draw slab, overlapped with the next trajectory: mi_mcmc_allgather_draws_begin below).  A partial slab
+// is not contiguous on the receiving side across ranks, so it travels as one grouped broadcast per rank (one RCCL launch).
+namespace {
+int gather_rank_major(Rccl* r, void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                      uint64_t row0, uint64_t n_keep_total, double* all, hipStream_t st)
+{
+    uint64_t c0 = 0, nl = 0;
+    mi_mcmc_shard_bounds(C, world, rank, &c0, &nl);
+    if (nl > 0 && !local) return fail(MI_ERR_BAD_ARG, "allgather_draws: local_draws is required for a non-empty shard");
+    if (C % world == 0 && C > 0 && row0 == 0 && n_keep == n_keep_total) {       // north_star's single all-gather
+        const int e = r->allgather(local, all, (size_t)(n_keep * d * (C / world)), 8 /* ncclDouble */, comm, st);
+        if (e != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e) : "error");
+        return MI_OK;
+    }
+    int e = r->group_start();
+    for (uint32_t q = 0; q < world && e == 0; ++q) {
+        uint64_t qc0 = 0, qn = 0;
+        mi_mcmc_shard_bounds(C, world, q, &qc0, &qn);
+        if (qn == 0 || n_keep == 0) continue;
+        double* slot = all + n_keep_total * d * qc0 + row0 * d * qn;             // shard q's block, its rows [row0, row0 + n_keep)
+        e = r->broadcast(q == rank ? static_cast<const void*>(local) : static_cast<const void*>(slot), slot, (size_t)(n_keep * d * qn), 8, (int)q, comm, st);
+    }
+    const int e2 = r->group_end();
+    if (e != 0 || e2 != 0) return fail(MI_ERR_HIP, "allgather_draws: RCCL: %s", r->err ? r->err(e ? e : e2) : "error");
+    return MI_OK;
+}
+
+// one communication stream per device for the overlapped form: collectives of one communicator must be enqueued in the same order
+// on every rank, which a single stream per device gives by construction
+hipStream_t comm_stream(int dev)
+{
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    std::lock_guard<std::mutex> g(mu);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) streams[dev] = nullptr;
+    return streams[dev];
+}
+}  // namespace
+
+struct mi_collation { hipEvent_t done; };
+
+int mi_mcmc_allgather_draws_rank_major(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                                       double* all_rank_major, void* stream)
+{
+    if (!comm || !all_rank_major || world == 0 || rank >= world) return fail(MI_ERR_BAD_ARG, "allgather_draws: bad communicator / buffers / rank");
+    Rccl* r = rccl();
+    if (!r) return fail(MI_ERR_UNSUPPORTED, "allgather_draws: librccl.so could not be loaded");
+    return gather_rank_major(r, comm, world, rank, local, n_keep, d, C, 0, n_keep, all_rank_major, static_cast<hipStream_t>(stream));
+}
+
+uint64_t mi_mcmc_rank_major_index(uint64_t C, uint32_t world, uint64_t n_keep, uint64_t d, uint64_t i, uint64_t j, uint64_t c)
+{
+    if (world == 0 || c >= C) return ~(uint64_t)0;
+    const uint64_t base = C / world, extra = C % world, cut = extra * (base + 1);
+    const uint64_t r = (c < cut) ? c / (base + 1) : extra + (base ? (c - cut) / base : 0);
+    const uint64_t c0 = r * base + (r < extra ? r : extra), nl = base + (r < extra ? 1 : 0);
+    return n_keep * d * c0 + (i * d + j) * nl + (c - c0);
+}
+
+int mi_mcmc_allgather_draws_begin(void* comm, uint32_t world, uint32_t rank, const double* local, uint64_t n_keep, uint64_t d, uint64_t C,
+                                  uint64_t row0, uint64_t n_keep_total, double* all_rank_major, void* producer_stream, mi_collation** handle)
+{
+    if (!handle) return fail(MI_ERR_BAD_ARG, "allgather_draws_begin: null handle");
+    *handle = nullptr;
+    if (!comm || !all_rank_major || world == 0 || rank >= world || row0 + n_keep > n_keep_total)
+        return fail(MI_ERR_BAD_ARG, "allgather_draws_begin: bad communicator / buffers / rank / row range");
+    Rccl* r = rccl();
+    if (!r) return fail(MI_ERR_UNSUPPORTED, "allgather_draws: librccl.so could not be loaded");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipStream_t cs = comm_stream(dev);
+    if (!cs) return fail(MI_ERR_HIP, "allgather_draws_begin: no communication stream");
+    hipEvent_t ready = nullptr, done = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ready, static_cast<hipStream_t>(producer_stream)));     // the slab is complete when the producer stream gets here
+    HIP_TRY(hipStreamWaitEvent(cs, ready, 0));
+    HIP_TRY(hipEventDestroy(ready));                                               // (released once the wait has consumed it)
+    const int rc = gather_rank_major(r, comm, world, rank, local, n_keep, d, C, row0, n_keep_total, all_rank_major, cs);
+    if (rc) return rc;
+    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(done, cs));
+    *handle = new mi_collation{done};
+    return MI_OK;
+}
+
+int mi_mcmc_allgather_draws_wait(mi_collation* handle, void* consumer_stream, int block_host)
+{
+    if (!handle) return fail(MI_ERR_BAD_ARG, "allgather_draws_wait: null handle");
+    hipError_t e = block_host ? hipEventSynchronize(handle->done) : hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), handle->done, 0);
+    (void)hipEventDestroy(handle->done);
+    delete handle;
+    if (e != hipSuccess) return fail(MI_ERR_HIP, "allgather_draws_wait: %s", hipGetErrorString(e));
+    return MI_OK;
+}
+
 int mi_mcmc_draws_to_chain_major(const double* kdc, uint64_t n_keep, uint64_t d, uint64_t C, double* out)
 {
     if (!kdc || !out) return fail(MI_ERR_BAD_ARG, "null buffer");

@@ -105,3 +105,77 @@ def test_two_rccl_ranks_on_one_device_is_what_this_box_cannot_do():
         assert all(l.startswith("RCCL2 ok") for l in lines)
     else:
         assert any("refused" in l for l in lines), "one device, two ranks: RCCL is expected to refuse (duplicate GPU)"
+
+
+def test_rank_major_index_addresses_every_chain_of_equal_and_ragged_splits():
+    """mi_mcmc_rank_major_index against the layout it documents: shard r packed at n_keep * d * chain0(r) with row length n_local(r)
+    (equal shards: [G][n_keep][d][C / G])."""
+    lib = mcmc_amd.lib()
+    lib.mi_mcmc_rank_major_index.restype = C.c_uint64
+    for Ct, world, n_keep, d in [(16, 4, 3, 2), (13, 4, 2, 3), (5, 8, 2, 2), (9, 1, 2, 2)]:
+        full = np.arange(n_keep * d * Ct, dtype=np.float64).reshape(n_keep, d, Ct)
+        packed = np.concatenate([np.ascontiguousarray(full[:, :, c0:c0 + nl]).ravel() for c0, nl in (shard_bounds(Ct, world, r) for r in range(world))])
+        for i in range(n_keep):
+            for j in range(d):
+                for c in range(Ct):
+                    k = lib.mi_mcmc_rank_major_index(C.c_uint64(Ct), C.c_uint32(world), C.c_uint64(n_keep), C.c_uint64(d), C.c_uint64(i), C.c_uint64(j), C.c_uint64(c))
+                    assert packed[k] == full[i, j, c]
+        assert lib.mi_mcmc_rank_major_index(C.c_uint64(Ct), C.c_uint32(world), C.c_uint64(n_keep), C.c_uint64(d), C.c_uint64(0), C.c_uint64(0), C.c_uint64(Ct)) == 2 ** 64 - 1
+
+
+@pytest.mark.gpu
+def test_rank_major_allgather_and_the_overlapped_begin_wait_form_on_one_rank():
+    """The C route of SURVEY 8(e)'s "per kept-draw slab, overlapped with the next trajectory": an hmc run cut into three chunks through
+    mi_chains.draw0, every chunk's slab handed to mi_mcmc_allgather_draws_begin while the next chunk samples on the producer stream,
+    gathered into ONE rank-major buffer -- equal to the single blocking call over the whole run, bit for bit.  (World size 1: what the
+    box can build; with one rank the rank-major layout IS [n_keep][d][C].)"""
+    import torch
+    lib = mcmc_amd.lib()
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, (C.c_int * 1)(0)) == 0
+    d, Ct, n_burn, n_keep = 24, 96, 3, 9
+    prec = torch.from_numpy(synth_prec(d)).cuda()
+    init = torch.from_numpy(np.ascontiguousarray(np.random.default_rng(1).standard_normal((d, Ct)))).cuda()
+    t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE)
+    st_all = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=n_burn, n_keep_draws=n_keep, n_leap_steps=4, step_size=0.1)
+    stream = torch.cuda.current_stream().cuda_stream
+    # one blocking run + the rank-major all-gather
+    theta = init.clone()
+    draws = torch.zeros((n_keep, d, Ct), dtype=torch.float64, device="cuda")
+    mcmc_amd.run("hmc", t, st_all, mcmc_amd.make_chains(theta, Ct, draws=draws, mem=mcmc_amd.MEM_DEVICE), stream=stream)
+    ref = torch.zeros_like(draws)
+    rc = lib.mi_mcmc_allgather_draws_rank_major(comm, C.c_uint32(1), C.c_uint32(0), C.c_void_p(draws.data_ptr()), C.c_uint64(n_keep), C.c_uint64(d),
+                                                C.c_uint64(Ct), C.c_void_p(ref.data_ptr()), C.c_void_p(stream))
+    assert rc == 0, lib.mi_mcmc_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, draws)
+    # three chunks, each gathered while the next one samples
+    theta = init.clone()
+    out = torch.zeros_like(draws)
+    bounds, handles, slabs = [0, 3, 7, 9], [], []
+    for k in range(3):
+        nk = bounds[k + 1] - bounds[k]
+        s_k = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=n_burn if k == 0 else 0, n_keep_draws=nk, n_leap_steps=4, step_size=0.1)
+        slab = torch.zeros((nk, d, Ct), dtype=torch.float64, device="cuda")
+        slabs.append(slab)
+        mcmc_amd.run("hmc", t, s_k, mcmc_amd.make_chains(theta, Ct, draws=slab, mem=mcmc_amd.MEM_DEVICE, draw0=0 if k == 0 else n_burn + bounds[k]), stream=stream)
+        h = C.c_void_p(0)
+        rc = lib.mi_mcmc_allgather_draws_begin(comm, C.c_uint32(1), C.c_uint32(0), C.c_void_p(slab.data_ptr()), C.c_uint64(nk), C.c_uint64(d), C.c_uint64(Ct),
+                                               C.c_uint64(bounds[k]), C.c_uint64(n_keep), C.c_void_p(out.data_ptr()), C.c_void_p(stream), C.byref(h))
+        assert rc == 0 and h.value, lib.mi_mcmc_last_error().decode()
+        handles.append(h)
+    for k, h in enumerate(handles):
+        assert lib.mi_mcmc_allgather_draws_wait(h, C.c_void_p(stream), C.c_int(k == 2)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, draws)
+    # a row range outside the run is refused, not gathered somewhere
+    h = C.c_void_p(0)
+    assert lib.mi_mcmc_allgather_draws_begin(comm, C.c_uint32(1), C.c_uint32(0), C.c_void_p(draws.data_ptr()), C.c_uint64(4), C.c_uint64(d), C.c_uint64(Ct),
+                                             C.c_uint64(7), C.c_uint64(n_keep), C.c_void_p(out.data_ptr()), C.c_void_p(stream), C.byref(h)) == mcmc_amd.MI_ERR_BAD_ARG
+    rccl.ncclCommDestroy(comm)
+
+
+def synth_prec(d):
+    from mcmc_amd import synth
+    return synth.dense_gaussian_precision(d, seed=4)

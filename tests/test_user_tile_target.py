@@ -3,7 +3,7 @@ library, exactly as a user would, and driven through the generated C entry point
 
 CPU: the example cross-compiles for gfx950; its host callback is a valid target for the oracle.  GPU: (1) the dense Gaussian written
 as a user tile target reproduces the built-in hmc_gauss_mfma_kernel / mala_gauss_mfma_kernel bit for bit; (2) a non-Gaussian d = 64
-target (twisted Gaussian) under hmc and mala is bit-identical to the oracle driven by the same arithmetic as the reference's host
+target (twisted Gaussian) under hmc, mala and nuts is bit-identical to the oracle driven by the same arithmetic as the reference's host
 callback (ref: include/mcmc/hmc.hpp:42-48)."""
 import ctypes as C
 import os
@@ -73,11 +73,13 @@ def _run_tile(lib, fn, algo, target, d, init, st):
     theta = np.ascontiguousarray(init.T.copy())
     n_keep = int(st.n_keep_draws)
     draws = np.zeros((n_keep, d, Cn)); nacc = np.zeros(Cn, dtype=np.uint64); nleap = np.zeros(Cn, dtype=np.uint64)
-    ch = mcmc_amd.make_chains(theta, Cn, draws=draws, n_accept=nacc, n_leapfrogs=nleap)
+    eps = np.zeros(Cn); depth = np.zeros((int(st.n_burnin_draws) + n_keep, Cn), dtype=np.uint32)
+    ch = mcmc_amd.make_chains(theta, Cn, draws=draws, n_accept=nacc, n_leapfrogs=nleap, step_size=eps if algo == 2 else None,
+                              nuts_depth=depth if algo == 2 else None)
     rc = getattr(lib, fn)(C.c_int(algo), C.byref(target), C.c_uint64(d), C.byref(st), C.byref(ch), C.c_void_p(0))
     assert rc == 0, mcmc_amd.lib().mi_mcmc_last_error().decode()
     torch.cuda.synchronize()
-    return draws, dict(n_accept=nacc, n_leap=nleap)
+    return draws, dict(n_accept=nacc, n_leap=nleap, eps=eps, depth=depth)
 
 
 @pytest.mark.gpu
@@ -120,6 +122,50 @@ def test_twisted_gaussian_tile_target_against_the_oracle_with_the_same_callback(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,C_,max_depth", [(128, 150, 6), (100, 33, 10), (70, 16, 3)])
+def test_dense_gaussian_tile_target_under_nuts_reproduces_the_built_in_nuts_kernel(tile_lib, d, C_, max_depth):
+    """mcmc::nuts on the tile route (nuts_tile.hpp): with the built-in dense Gaussian as the user target, p + (e grad) / 2 is
+    p - (e P theta) / 2 to the bit, so trees, step sizes and draws equal nuts_gauss_reg_kernel's."""
+    import torch
+    P = synth.dense_gaussian_precision(d, seed=d)
+    Pd = torch.from_numpy(P).cuda()
+    init = synth.initial_states(C_, d, seed=5)
+    st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=4, n_keep_draws=5, n_adapt_draws=6, max_tree_depth=max_depth)
+    t_draws, t = _run_tile(tile_lib, "gauss_tile_run", 2, GaussTile(Pd.data_ptr(), d), d, init, st)
+    assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<")
+    b_draws, b = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=P, kernel_hint=mcmc_amd.KERNEL_NUTS_REG)
+    assert np.array_equal(t["depth"], b["depth"]) and np.array_equal(t["n_leap"], b["n_leap"])
+    assert np.array_equal(t["eps"], b["eps"]) and np.array_equal(t["n_accept"], b["n_accept"])
+    assert np.array_equal(t_draws, b_draws)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,C_,adapt", [(64, 40, 6), (37, 17, 0), (2, 70, 4)])
+def test_twisted_gaussian_tile_target_under_nuts_against_the_oracle_with_the_same_callback(tile_lib, d, C_, adapt):
+    """a non-Gaussian d = 64 tile target under mcmc::nuts, bit for bit against the oracle driven by the same
+    function as the reference's host callback (ref: include/mcmc/nuts.hpp:65-72): trees, leapfrog counts, adapted step sizes, draws."""
+    import torch
+    P = _twisted_precision(d)
+    Pd = torch.from_numpy(P).cuda()
+    init = synth.initial_states(C_, d, seed=7) * 0.5
+    st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=4, n_keep_draws=8, n_adapt_draws=adapt, max_tree_depth=6,
+                                   step_size=1.0 if adapt else 0.1)
+    g_draws, g = _run_tile(tile_lib, "twisted_tile_run", 2, TwistedTile(Pd.data_ptr(), d, 0.2, 1.5), d, init, st)
+    host = TwistedTile(P.ctypes.data, d, 0.2, 1.5)
+    s = orc.make_settings(seed=4, n_burnin=4, n_keep=8, n_adapt=adapt, max_depth=6, step=1.0 if adapt else 0.1, W=4)
+    o_draws = np.zeros_like(g_draws); o_acc = np.zeros(C_, dtype=np.uint64); o_leap = np.zeros(C_, dtype=np.uint64); o_eps = np.zeros(C_)
+    o_depth = np.zeros_like(g["depth"])
+    for c in range(C_):
+        s.chain_id = c
+        dr, info = orc.run_chain(orc.ALGO_NUTS, None, init[c], s, traces=True, kernel=tile_lib.twisted_host_kernel, data=C.addressof(host), d=d)
+        o_draws[:, :, c] = dr; o_acc[c] = info["n_accept"]; o_leap[c] = info["n_leap"]; o_eps[c] = info["eps"]; o_depth[:, c] = info["depth"]
+    assert np.array_equal(g["depth"], o_depth) and np.array_equal(g["n_leap"], o_leap)
+    assert np.array_equal(g["eps"], o_eps) and np.array_equal(g["n_accept"], o_acc)
+    assert np.array_equal(g_draws, o_draws)
+    assert g["depth"].max() >= 2
+
+
+@pytest.mark.gpu
 def test_tile_route_refuses_what_it_does_not_implement(tile_lib):
     import torch
     d = 64
@@ -129,6 +175,7 @@ def test_tile_route_refuses_what_it_does_not_implement(tile_lib):
     ch = mcmc_amd.make_chains(theta, 4)
     rc = tile_lib.twisted_tile_run(C.c_int(0), C.byref(TwistedTile(Pd.data_ptr(), d, 0.2, 1.5)), C.c_uint64(d), C.byref(st), C.byref(ch), C.c_void_p(0))
     assert rc == mcmc_amd.MI_ERR_UNSUPPORTED
-    rc = tile_lib.twisted_tile_run(C.c_int(2), C.byref(TwistedTile(Pd.data_ptr(), d, 0.2, 1.5)), C.c_uint64(d),
-                                   C.byref(mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1)), C.byref(ch), C.c_void_p(0))
-    assert rc == mcmc_amd.MI_ERR_UNSUPPORTED
+    for algo, kw in ((3, {}), (2, dict(max_tree_depth=11))):          # rwmh is not on this route; nuts trees deeper than its records
+        rc = tile_lib.twisted_tile_run(C.c_int(algo), C.byref(TwistedTile(Pd.data_ptr(), d, 0.2, 1.5)), C.c_uint64(d),
+                                       C.byref(mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, **kw)), C.byref(ch), C.c_void_p(0))
+        assert rc == mcmc_amd.MI_ERR_UNSUPPORTED
