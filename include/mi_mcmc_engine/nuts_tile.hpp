@@ -32,11 +32,13 @@ enum : int {
 };
 enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
 enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
-constexpr size_t lds_doubles() { return (size_t)NUTS_LVLS * 4 * 64 + 3 * 64; }     // behind the target's own LDS
+constexpr size_t lds_doubles() { return (size_t)NUTS_LVLS * 4 * 64 + 3 * 64; }     // behind the target's own LDS (GEN: TileGen's tables follow)
 
 // (the kernel lives in this namespace so that its vector numbering is found before the built-in kernels' mi:: enums, which a
 //  translation unit of the engine sees as well)
-template <class T>
+// GEN: settings.vals_bound and / or a diagonal precond_mat (TileGen, tile_samplers.hpp): the tree lives in the transformed space (the
+// U-turn dots are plain), rows are reported through inv_transform
+template <class T, bool GEN = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const TileParams prm, const T tgt)
 {
     constexpr int NT = T::NT, NS = 4 * NT;
@@ -45,8 +47,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
     double* const lds_t = lds_all;                                   // the target's own LDS (its matrices in fragment order)
     double* const lds_lvl = lds_all + prm.lds_user_doubles;         // [NUTS_LVLS][4][64]
     double* const lds_da = lds_lvl + NUTS_LVLS * 4 * 64;            // [3][64]: the dual-averaging state (h, epsilon_bar, mu)
+    [[maybe_unused]] double* const lds_gen = lds_da + 3 * 64;        // GEN: the bounds / mass tables
     tgt.stage(lds_t);
+    if constexpr (GEN) TileGen<T::NT>::stage(lds_gen, prm);
     __syncthreads();
+    [[maybe_unused]] TileGen<T::NT> tg;
+    if constexpr (GEN) tg.use(lds_gen, prm);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j4 = lane >> 4;
@@ -88,39 +94,78 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
     };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
     // K = p . (I p) / 2 with the identity as the dense product it is in the reference (nuts.cpp leap_frog_fn / nuts.ipp:51,66,140)
-    auto kinetic_of = [&](const double (&p)[NS]) __attribute__((always_inline)) -> double { return diag_quadratic<NS>(p, 1.0, j4, d) / 2.0; };
+    auto kinetic_of = [&](const double (&p)[NS]) __attribute__((always_inline)) -> double {
+        if constexpr (GEN) return tg.kinetic(p);
+        else return diag_quadratic<NS>(p, 1.0, j4, d) / 2.0;
+    };
     double val = 0.0;                                    // log kernel at the register-resident position
     constexpr int CHC = (NS < 16) ? NS : 16;             // record copies: 2 vectors per chunk
     // the chain's last leaf: position, momentum, GRADIENT of the log kernel at the position (MFMA B / D layout).  Loop-carried.
     double th[NS], pm[NS], w[NS];
+    // value and gradient at the register-resident position (GEN: at x = inv_transform(theta), hmc.cpp:108-110)
+    auto eval = [&]() __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            double xs[NS];
+            tg.x_of(th, xs);
+            tgt.grad_tile(lds_t, xs, w, val, true);
+        } else {
+            tgt.grad_tile(lds_t, th, w, val, true);
+        }
+    };
+    auto potential_of = [&]() __attribute__((always_inline)) -> double {       // -box_log_kernel(theta), nuts.cpp:84-95
+        if constexpr (GEN) return tg.potential(val, th);
+        else return -val;
+    };
+    // p += (e [J^-1] grad) / 2 (nuts.cpp:108-135)
+    auto kick = [&](double e) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            double t[NS];
+            tg.kick_terms(th, w, e, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + t[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
+        }
+    };
+    // theta += e (Minv p), a dense product in the reference (nuts.cpp:139-154)
+    auto drift = [&](double e) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            double mp[NS];
+            tg.minv_p(pm, mp);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * mp[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
+            dense_product_poison<NS>(pm, th, j4, d);
+        }
+    };
 
     // ---------------------------------------------------------------- setup (nuts.cpp:156-195), all chains together
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t dimc = dim_ok(s) ? (uint32_t)(4 * s + j4) : 0u;
         const double v = prm.theta[(size_t)dimc * C + cld];
-        th[s] = dim_ok(s) ? v : 0.0;
+        if constexpr (GEN) th[s] = dim_ok(s) ? tg.enter(v, dimc) : 0.0;        // nuts.cpp:160-162
+        else th[s] = dim_ok(s) ? v : 0.0;
     }
-    tgt.grad_tile(lds_t, th, w, val, true);
+    eval();
     if (live) { st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w); }
-    double prev_U = -val;                                // nuts.cpp:181 (no finiteness guard there)
+    double prev_U = potential_of();                      // nuts.cpp:181 (no finiteness guard there)
     // Non-finite regime: the identity `inv_precond_matrix * mntm` is applied element-wise WITH the NaN rule of the dense product
     // (dense_product_poison, diag_quadratic), so this route needs no replay (tile_samplers.hpp)
     uint64_t n_leap = 0;
     double eps;
     if (prm.draw0 == 0) {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, z_init), nuts.cpp:166-172
         auto leapfrog = [&](double e) __attribute__((always_inline)) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
-            dense_product_poison<NS>(pm, th, j4, d);
-            tgt.grad_tile(lds_t, th, w, val, true);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
+            kick(e);
+            drift(e);
+            eval();
+            kick(e);
         };
         auto energy = [&]() __attribute__((always_inline)) -> double {
-            double u = -val;
+            double u = potential_of();
             if (!is_finite(u)) u = INF;
             return u + kinetic_of(pm);
         };
@@ -130,6 +175,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
             rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
             pm[2 * b] = (8u * b + j4 < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+            if constexpr (GEN) {                         // mntm_vec = sqrt_precond_matrix * rand_vec (nuts.cpp:168)
+                pm[2 * b] = tg.msqrt(8 * b + j4) * pm[2 * b];
+                pm[2 * b + 1] = tg.msqrt(8 * b + 4 + j4) * pm[2 * b + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         double U0 = prev_U;
@@ -254,8 +303,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
                 double tmp[CHC];
                 ld_row(vec, c0, tmp);
 #pragma unroll
-                for (int k = 0; k < CHC; ++k)
+                for (int k = 0; k < CHC; ++k) {
+                    if constexpr (GEN) tmp[k] = tg.leave(tmp[k], c0 + k);      // rows are reported in the constrained space
                     if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -293,8 +344,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
                 rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
                 double pa = (8u * b + j4 < d) ? z0 : 0.0;
                 double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                kq = dfma(pa, 1.0 * pa, kq);                 // (finite normals: the identity product needs no NaN rule here)
-                kq = dfma(pb_, 1.0 * pb_, kq);
+                if constexpr (GEN) {                         // :202 and :204 with the diagonal matrices
+                    pa = tg.msqrt(8 * b + j4) * pa; pb_ = tg.msqrt(8 * b + 4 + j4) * pb_;
+                    kq = dfma(pa, tg.mi[8 * b + j4] * pa, kq);
+                    kq = dfma(pb_, tg.mi[8 * b + 4 + j4] * pb_, kq);
+                } else {
+                    kq = dfma(pa, 1.0 * pa, kq);             // (finite normals: the identity product needs no NaN rule here)
+                    kq = dfma(pb_, 1.0 * pb_, kq);
+                }
                 if (gen && live) st_pair(mvn, 2 * b, pa, pb_);
             }
             kq = kq + __shfl_xor(kq, 32);
@@ -347,11 +404,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             Lp[s_] = pm[s_];                             // p(b) of an odd leaf: the start momentum (an eager lane's load overwrites it below)
-            pm[s_] = pm[s_] + (e_signed * w[s_]) / 2.0;
-            dd[s_] = th[s_];                             // t0, until the poisoned drift is known
-            th[s_] = th[s_] + e_signed * pm[s_];
+            dd[s_] = th[s_];                             // t0, until the drift (with its NaN rule) is known
         }
-        dense_product_poison<NS>(pm, th, j4, d);         // theta_i + e * NaN where (I p)_i is poisoned
+        kick(e_signed);
+        drift(e_signed);
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             dd[s_] = (vdir > 0) ? (th[s_] - dd[s_]) : (dd[s_] - th[s_]);
@@ -359,7 +415,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (any_eager) { if (eager) { ld_row(eb_t, 0, dd); ld_row(eb_p, 0, Lp); } }
-        tgt.grad_tile(lds_t, th, w, val, true);
+        eval();
         if (any_eager) {
             if (eager) {
                 double q1e = 0.0;
@@ -371,12 +427,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
                 q1 = q1e;
             }
         }
+        kick(e_signed);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            pm[s] = pm[s] + (e_signed * w[s]) / 2.0;
-            q2 = dfma(dd[s], pm[s], q2);
-        }
-        double pU = -val;                                // nuts.ipp:134-138
+        for (int s = 0; s < NS; ++s) q2 = dfma(dd[s], pm[s], q2);
+        double pU = potential_of();                      // nuts.ipp:134-138
         const double pK = kinetic_of(pm);                // :140
         if (!is_finite(pU)) pU = INF;
         q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
@@ -518,8 +572,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_tile_kernel(const 
             double tmp[CHC];
             ld_row(pvec(pb), c0, tmp);
 #pragma unroll
-            for (int k = 0; k < CHC; ++k)
+            for (int k = 0; k < CHC; ++k) {
+                if constexpr (GEN) tmp[k] = tg.leave(tmp[k], c0 + k);
                 if (dim_ok(c0 + k)) prm.theta[(size_t)(4 * (c0 + k)) * C + lane_off] = tmp[k];
+            }
         }
         if (j4 == 0) {
             if (prm.n_accept) prm.n_accept[cl] = n_acc;

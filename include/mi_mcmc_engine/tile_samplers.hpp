@@ -52,6 +52,118 @@ struct TileParams {
     uint32_t n_adapt, max_depth;
     double delta, eps_bar0, gamma, t0, kappa;
     uint32_t lds_user_doubles;              // the target's own LDS (T::lds_doubles()); the sampler's tables follow it
+    // general runs (hmc, nuts): settings.vals_bound and / or a DIAGONAL precond_mat (TileGen below); all device, d values each
+    int vals_bound;
+    const int* btype;       // determine_bounds_type.hpp:27-57
+    const double* lb;
+    const double* ub;
+    const double* m_sqrt;   // diag of CHOL_LOWER(precond_mat) (ones = identity)
+    const double* m_inv;    // diag of INV(precond_mat)
+};
+
+// ---- settings.vals_bound and / or a diagonal precond_mat on the tile route, with the arithmetic of the general built-in kernels
+// (hmc_dense.hpp; the reference's NUTS shares mntm_update_fn / leap_frog_fn / box_log_kernel with HMC, ref: src/hmc.cpp:84-128,
+// src/nuts.cpp:84-154): the chain lives in the transformed space, the target is evaluated at x = inv_transform(theta), the kick uses
+// [J^-1] grad (a dense product in the reference: NaN rule), the drift Minv p (likewise), K = p.(Minv p) / 2, U = -(K(x) +
+// log_jacobian(theta)) with the log-Jacobian summed over the bounded dimensions in order, p = sqrt(M) z; rows are reported through
+// inv_transform.  Identity tables reproduce the plain kernels' bits.  Tables: 5 x 16 NT doubles + 16 NT ints of LDS.
+template <int NT>
+struct TileGen {
+    static constexpr int NS = 4 * NT;
+    static constexpr size_t lds_doubles() { return (size_t)16 * NT * 4 + 8 * NT; }
+    const double* lb; const double* ub; const double* ms; const double* mi; const int* bt;
+    uint32_t bslices, d;
+    int vals_bound, j, lane;
+
+    // every thread of the workgroup; a barrier must follow before use()
+    __device__ __forceinline__ static void stage(double* tab, const TileParams& prm)
+    {
+        double* l = tab; double* u = l + 16 * NT; double* s_ = u + 16 * NT; double* i_ = s_ + 16 * NT;
+        int* b = reinterpret_cast<int*>(i_ + 16 * NT);
+        for (int k = threadIdx.x; k < 16 * NT; k += blockDim.x) {
+            const bool in = (uint32_t)k < prm.d;
+            l[k] = in ? prm.lb[k] : 0.0; u[k] = in ? prm.ub[k] : 0.0; b[k] = in ? prm.btype[k] : 1;
+            s_[k] = in ? prm.m_sqrt[k] : 1.0; i_[k] = in ? prm.m_inv[k] : 1.0;
+        }
+    }
+    __device__ __forceinline__ void use(double* tab, const TileParams& prm)
+    {
+        lb = tab; ub = lb + 16 * NT; ms = ub + 16 * NT; mi = ms + 16 * NT; bt = reinterpret_cast<const int*>(mi + 16 * NT);
+        d = prm.d; vals_bound = prm.vals_bound; lane = threadIdx.x & 63; j = lane >> 4;
+        uint32_t m = 0;
+        if (vals_bound)
+            for (int s = 0; s < NS; ++s) {
+                const bool any = bt[4 * s] != 1 || bt[4 * s + 1] != 1 || bt[4 * s + 2] != 1 || bt[4 * s + 3] != 1;
+                m |= (any ? 1u : 0u) << s;
+            }
+        bslices = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);     // bit s: slice s holds a bounded dimension (wave-uniform)
+    }
+    __device__ __forceinline__ bool bounded(int s) const { return ((bslices >> s) & 1u) != 0u; }
+    __device__ __forceinline__ double enter(double v, uint32_t dim) const { return box_transform(v, bt[dim], lb[dim], ub[dim]); }       // hmc.cpp:134-136
+    __device__ __forceinline__ double leave(double v, int s) const                                                                    // :211-218
+    {
+        const int dim = 4 * s + j;
+        return bounded(s) ? box_inv_transform(v, bt[dim], lb[dim], ub[dim]) : v;
+    }
+    __device__ __forceinline__ void x_of(const double (&th)[NS], double (&xs)[NS]) const                                                // :108
+    {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = 4 * s + j;
+            if (bounded(s)) xs[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], bt[i], lb[i], ub[i]) : 0.0;
+            else xs[s] = ((uint32_t)i < d) ? th[s] : 0.0;
+        }
+    }
+    // t = (e * ([J^-1] grad)) / 2 at (theta, grad)  (hmc.cpp:122,126)
+    __device__ __forceinline__ void kick_terms(const double (&th)[NS], const double (&g)[NS], double e, double (&t)[NS]) const
+    {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int i = 4 * s + j;
+            if (bounded(s)) t[s] = box_inv_jacobian(th[s], bt[i], lb[i], ub[i]) * g[s];
+            else t[s] = 1.0 * g[s];
+        }
+        if (vals_bound) dense_product_poison<NS>(g, t, j, d);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) t[s] = (e * t[s]) / 2.0;
+    }
+    __device__ __forceinline__ void minv_p(const double (&pm)[NS], double (&mp)[NS]) const                                              // inv_precond_matrix * mntm
+    {
+        const double* mic = mi + j;
+        asm volatile("" : "+v"(mic));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mp[s] = mic[4 * s] * pm[s];
+        dense_product_poison<NS>(pm, mp, j, d);
+    }
+    __device__ __forceinline__ double kinetic(const double (&pm)[NS]) const                                                             // :160,184
+    {
+        double mp[NS];
+        minv_p(pm, mp);
+        double q = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) q = dfma(pm[s], mp[s], q);
+        q = q + __shfl_xor(q, 32);
+        q = q + __shfl_xor(q, 16);
+        return q / 2.0;
+    }
+    // U = -box_log_kernel(theta) given the log kernel `val` at x(theta) (hmc.cpp:84-95; log_jacobian.hpp:36-57: a scalar loop, i ascending)
+    __device__ __forceinline__ double potential(double val, const double (&th)[NS]) const
+    {
+        double lj = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!bounded(s)) continue;
+            const int i0 = 4 * s;
+            const double term = box_log_jacobian_term(th[s], bt[i0 + j], lb[i0 + j], ub[i0 + j]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double tg = __shfl(term, (lane & 15) + 16 * g);
+                if ((uint32_t)(i0 + g) < d && bt[i0 + g] != 1) lj = lj + tg;
+            }
+        }
+        return -(val + lj);
+    }
+    __device__ __forceinline__ double msqrt(int dim) const { return ms[dim]; }
 };
 
 template <class T, class = void> struct tile_wpb_of { static constexpr int value = 4; };
@@ -201,6 +313,141 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_tile_ker
         for (int s = 0; s < NS; ++s) {
             const uint32_t dim = 4 * s + j;
             if (dim < d) prm.theta[(size_t)dim * C + cl] = th[s];
+        }
+        if (j == 0) {
+            if (prm.n_accept) prm.n_accept[cl] = n_acc;
+            if (prm.n_leap) prm.n_leap[cl] = (uint64_t)n_total * L;
+        }
+    }
+}
+
+// mcmc::hmc with settings.vals_bound and / or a diagonal precond_mat (TileGen): the draw loop of the general built-in variant
+// (hmc_dense.hpp, BOUNDED) on the tile functor.  One wave per SIMD (a fourth register-resident vector).
+template <class T>
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void hmc_tile_gen_kernel(const TileParams prm, const T tgt)
+{
+    constexpr int WPB = 4;
+    constexpr int NT = T::NT, NS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_t[];
+    tgt.stage(lds_t);
+    TileGen<NT>::stage(lds_t + prm.lds_user_doubles, prm);
+    __syncthreads();
+    TileGen<NT> gen;
+    gen.use(lds_t + prm.lds_user_doubles, prm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane >> 4;
+    const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
+    const bool live = cl < prm.C;
+    const uint64_t cld = live ? cl : prm.C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const double eps = prm.eps;
+    const size_t lane_off = (size_t)j * C + cld;
+    double* const ws_wave = prm.wsave + ((size_t)blockIdx.x * WPB + wave) * ((size_t)3 * NS * 64) + lane;
+    auto ws_group = [&](int k) -> double* {
+        double* b = ws_wave + (size_t)(k & ~7) * 64;
+        asm volatile("" : "+v"(b));
+        return b + (k & 7) * 64;
+    };
+    double th[NS], pm[NS], g[NS];
+    double val;
+    auto eval = [&]() __attribute__((always_inline)) {   // value and gradient at x = inv_transform(theta) (hmc.cpp:108-110)
+        double xs[NS];
+        gen.x_of(th, xs);
+        tgt.grad_tile(lds_t, xs, g, val, true);
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t dim = 4 * s + j;
+        const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cld];
+        th[s] = (dim < d) ? gen.enter(v, dim) : 0.0;
+    }
+    eval();
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { *ws_group(s) = th[s]; *ws_group(NS + s) = g[s]; }
+    }
+    double prev_U = gen.potential(val, th);              // hmc.cpp:140
+    double val_prev = val;
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const uint32_t L = prm.n_leap_steps;
+    auto drift = [&]() __attribute__((always_inline)) {  // theta += eps * (Minv p) (:171)
+        double mp[NS];
+        gen.minv_p(pm, mp);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) th[s] = th[s] + eps * mp[s];
+    };
+#pragma unroll 1
+    for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+        for (int b = 0; b < NS / 2; ++b) {               // :156-158: p = L z with a diagonal L
+            double z0, z1;
+            rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
+            pm[2 * b] = gen.msqrt(8 * b + j) * ((8u * b + j < d) ? z0 : 0.0);
+            pm[2 * b + 1] = gen.msqrt(8 * b + 4 + j) * ((8u * b + 4 + j < d) ? z1 : 0.0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double prev_K = gen.kinetic(pm);
+        if (L > 0) {
+            double t[NS];
+            gen.kick_terms(th, g, eps, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + t[s];
+            drift();
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k + 1 < L; ++k) {
+            eval();
+            double t[NS];
+            gen.kick_terms(th, g, eps, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { pm[s] = pm[s] + t[s]; pm[s] = pm[s] + t[s]; }
+            drift();
+        }
+        if (L > 0) {
+            eval();
+            double t[NS];
+            gen.kick_terms(th, g, eps, t);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) pm[s] = pm[s] + t[s];
+        }
+        double prop_U = gen.potential(val, th);          // :178
+        if (!is_finite(prop_U)) prop_U = INF;            // :180-182
+        const double prop_K = gen.kinetic(pm);           // :184
+        const double x = -(prop_U + prop_K) + (prev_U + prev_K);
+        const double comp_val = (x < 0.01) ? x : 0.01;   // :188
+        const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);
+        const bool accept = z < det_exp(comp_val);       // :191
+        if (accept) {
+            prev_U = prop_U; val_prev = val;
+            if (live) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { *ws_group(s) = th[s]; *ws_group(NS + s) = g[s]; }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { th[s] = *ws_group(s); g[s] = *ws_group(NS + s); }
+            val = val_prev;
+        }
+        if (draw >= prm.n_burnin) {
+            n_acc += accept ? 1u : 0u;
+            if (prm.draws != nullptr && live) {
+                double* out = prm.draws + (size_t)(draw - prm.n_burnin) * d * C;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t dim = 4 * s + j;
+                    if (dim < d) (out + (size_t)(4 * s) * C)[lane_off] = gen.leave(th[s], s);     // :211-218
+                }
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint32_t dim = 4 * s + j;
+            if (dim < d) prm.theta[(size_t)dim * C + cl] = gen.leave(th[s], s);
         }
         if (j == 0) {
             if (prm.n_accept) prm.n_accept[cl] = n_acc;

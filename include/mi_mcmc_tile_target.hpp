@@ -27,8 +27,8 @@
 //           -L<repo>/mcmc_amd -lmi_mcmc -o libmy_tile.so
 //
 // The macro defines  extern "C" int my_tile_run(int algo, const MyTile* target, uint64_t d, const mi_settings*, mi_chains*, void* stream)
-// with algo 0 = mcmc::hmc, 1 = mcmc::mala, 2 = mcmc::nuts (max_tree_depth <= 10; identity precond_mat, no bounds on this route: anything
-// else returns MI_ERR_UNSUPPORTED),
+// with algo 0 = mcmc::hmc, 1 = mcmc::mala, 2 = mcmc::nuts (max_tree_depth <= 10); hmc and nuts also with settings.vals_bound and / or a
+// DIAGONAL precond_mat (anything else -- mala with either, a dense precond_mat -- returns MI_ERR_UNSUPPORTED with the reason),
 // the settings / chains contract of include/mi_mcmc.h (host or device memory, global chain ids, draw0).  The target above IS the
 // built-in dense Gaussian: it reproduces hmc_gauss_mfma_kernel's draws bit for bit (tests/test_user_tile_target.py), and a
 // non-Gaussian target is checked the way every target is -- the oracle driven by a host function with the same operation order.
@@ -74,7 +74,18 @@ int tile_target_launch(int algo, const void* tile_params, const void* target_pod
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB)));
     hipError_t e;
-    if (algo == 0) {
+    const bool gen = prm.btype != nullptr;               // settings.vals_bound and / or a diagonal precond_mat (TileGen)
+    if (algo == 0 && gen) {
+        auto kern = hmc_tile_gen_kernel<T>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
+    } else if (algo == 2 && gen) {
+        auto kern = nuts_tile_kernel<T, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
+    } else if (algo == 0) {
         auto kern = hmc_tile_kernel<T, WPB>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
@@ -85,7 +96,7 @@ int tile_target_launch(int algo, const void* tile_params, const void* target_pod
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
     } else if (algo == 2) {
-        auto kern = nuts_tile_kernel<T>;                 // one wave per SIMD: register-carried leaf state (nuts_tile.hpp)
+        auto kern = nuts_tile_kernel<T, false>;          // one wave per SIMD: register-carried leaf state (nuts_tile.hpp)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);

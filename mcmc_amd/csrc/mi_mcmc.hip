@@ -1065,8 +1065,14 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         return fail(MI_ERR_UNSUPPORTED, "tile targets: nuts with max_tree_depth > %d is not implemented on this route", (int)mi::tile_nuts::NUTS_MAX_DEPTH);
     if (!(nt == 1 || nt == 2 || nt == 4 || nt == 8) || d == 0 || d > (uint64_t)16 * nt) return fail(MI_ERR_BAD_ARG, "tile targets: 1 <= d <= 16 NT, NT in {1, 2, 4, 8}");
     if (wpb != 4 && wpb != 8) return fail(MI_ERR_BAD_ARG, "tile targets: WPB is 4 or 8");
-    if (settings->vals_bound || settings->precond_mat)
-        return fail(MI_ERR_UNSUPPORTED, "tile targets: vals_bound / precond_mat are not implemented on this route (one-lane targets, include/mi_mcmc_target.hpp, take both)");
+    // vals_bound and / or a DIAGONAL precond_mat: hmc and nuts (TileGen, tile_samplers.hpp).  mala with either and a dense precond_mat stay
+    // with the one-lane targets (include/mi_mcmc_target.hpp), which take every combination: refused here with the reason
+    GeneralTables gt;
+    if (settings->vals_bound || settings->precond_mat) {
+        if (algo == 1) return fail(MI_ERR_UNSUPPORTED, "tile targets: mala with vals_bound / precond_mat is not implemented on this route (one-lane targets, include/mi_mcmc_target.hpp, take both)");
+        const int rcg = general_tables("tile targets", settings, d, gt, false);
+        if (rcg) return rcg;
+    }
     if (chains->n_chains == 0 || !chains->theta) return fail(MI_ERR_BAD_ARG, "chains.theta and n_chains are required");
     const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
     if (chains->draw0 + n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "draw0 + draws exceeds the 32-bit draw counter");
@@ -1078,7 +1084,9 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
     HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
     if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: the target asks for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t lds_user = lds_bytes;
     if (algo == 2) lds_bytes += mi::tile_nuts::lds_doubles() * sizeof(double);     // the sampler's per-level tables behind the target's own LDS
+    if (gt.active) lds_bytes += (uint64_t)(16 * nt * 4 + 8 * nt) * sizeof(double);  // TileGen<NT>::lds_doubles(): bounds / mass tables
     if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: target + nuts tables ask for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
     StagedChains sc;
     int rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
@@ -1098,9 +1106,14 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(lii);
         p.log_det = ld;
     }
+    p.lds_user_doubles = (uint32_t)(lds_user / sizeof(double));
+    if (gt.active) {
+        p.vals_bound = settings->vals_bound ? 1 : 0;
+        p.btype = gt.bt.as<int>(); p.lb = gt.lb.as<double>(); p.ub = gt.ub.as<double>();
+        p.m_sqrt = gt.ms_dev.as<double>(); p.m_inv = gt.mi_dev.as<double>();
+    }
     WsLease ws;
     if (algo == 2) {                                       // nuts: 64 workspace vectors per chain (records, pending proposals, edges)
-        p.lds_user_doubles = (uint32_t)((lds_bytes - mi::tile_nuts::lds_doubles() * sizeof(double)) / sizeof(double));
         if ((rc = nuts_continuation(settings, chains, &p.n_adapt))) return rc;
         p.max_depth = (uint32_t)settings->max_tree_depth;
         p.delta = settings->target_accept_rate; p.eps_bar0 = settings->step_size;
@@ -1114,13 +1127,13 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         if (rc) return rc;
         p.wsave = ws.as<double>();
     }
-    mi::note_kernel("%s_tile_kernel<user target, %d>", algo == 0 ? "hmc" : algo == 1 ? "mala" : "nuts", algo == 0 ? wpb : 4);
+    mi::note_kernel("%s_tile%s_kernel<user target, %d>", algo == 0 ? "hmc" : algo == 1 ? "mala" : "nuts", gt.active ? "_gen" : "", (algo == 0 && !gt.active) ? wpb : 4);
     const int e = launch(algo, &p, target_pod, lds_bytes, stream);
     if (e != 0) return fail(MI_ERR_HIP, "tile target kernel launch: %s", hipGetErrorString((hipError_t)e));
     if (algo == 1) { rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st); if (rc) return rc; }
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (chains->mem == MI_MEM_HOST || gt.active) HIP_TRY(hipStreamSynchronize(st));      // (the tables are ours)
     return MI_OK;
 }
 

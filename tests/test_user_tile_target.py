@@ -165,6 +165,56 @@ def test_twisted_gaussian_tile_target_under_nuts_against_the_oracle_with_the_sam
     assert g["depth"].max() >= 2
 
 
+def _mixed_bounds(d, seed):
+    """A mix of the four bounds types of determine_bounds_type.hpp:27-57."""
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(1, 5, d)
+    lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf)
+    ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+    return lb, ub
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["hmc", "nuts"])
+@pytest.mark.parametrize("d,C_,bounded,precond", [(64, 40, True, False), (37, 17, False, True), (50, 20, True, True)])
+def test_twisted_tile_target_with_bounds_and_a_diagonal_precond_mat_against_the_oracle(tile_lib, algo, d, C_, bounded, precond):
+    """settings.vals_bound and / or a diagonal precond_mat on the tile route (TileGen: hmc_tile_gen_kernel, nuts_tile_kernel<., true>):
+    the non-Gaussian tile target against the oracle driven by the same function as the reference's host callback, bit for bit --
+    draws reported in the constrained space, accept counts, and for nuts trees, leapfrog counts and adapted step sizes."""
+    import torch
+    P = _twisted_precision(d)
+    Pd = torch.from_numpy(P).cuda()
+    init = np.clip(synth.initial_states(C_, d, seed=7) * 0.3, -1.0, 1.5)       # inside every box
+    kw, okw = {}, {}
+    if bounded:
+        lb, ub = _mixed_bounds(d, seed=d)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    if precond:
+        M = np.diag(np.linspace(0.5, 2.0, d))
+        kw.update(precond_mat=M); okw.update(precond=M)
+    if algo == "hmc":
+        st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=3, n_keep_draws=8, n_leap_steps=4, step_size=0.08, **kw)
+        s = orc.make_settings(seed=4, n_burnin=3, n_keep=8, n_leap=4, step=0.08, W=4, hoist=1, **okw)
+    else:
+        st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=4, n_keep_draws=6, n_adapt_draws=5, max_tree_depth=5, **kw)
+        s = orc.make_settings(seed=4, n_burnin=4, n_keep=6, n_adapt=5, max_depth=5, W=4, **okw)
+    g_draws, g = _run_tile(tile_lib, "twisted_tile_run", 0 if algo == "hmc" else 2, TwistedTile(Pd.data_ptr(), d, 0.2, 1.5), d, init, st)
+    assert mcmc_amd.last_kernel().startswith(f"{algo}_tile_gen_kernel<")
+    host = TwistedTile(P.ctypes.data, d, 0.2, 1.5)
+    o_draws = np.zeros_like(g_draws); o_acc = np.zeros(C_, dtype=np.uint64); o_leap = np.zeros(C_, dtype=np.uint64); o_eps = np.zeros(C_)
+    for c in range(C_):
+        s.chain_id = c
+        dr, info = orc.run_chain(orc.ALGO_HMC if algo == "hmc" else orc.ALGO_NUTS, None, init[c], s, kernel=tile_lib.twisted_host_kernel,
+                                 data=C.addressof(host), d=d)
+        o_draws[:, :, c] = dr; o_acc[c] = info["n_accept"]; o_leap[c] = info["n_leap"]; o_eps[c] = info["eps"]
+    assert np.array_equal(g["n_accept"], o_acc)
+    if algo == "nuts":
+        assert np.array_equal(g["n_leap"], o_leap) and np.array_equal(g["eps"], o_eps)
+    assert np.array_equal(g_draws, o_draws)
+    if bounded:
+        assert ((g_draws >= lb[None, :, None]) & (g_draws <= ub[None, :, None])).all()
+
+
 @pytest.mark.gpu
 def test_tile_route_refuses_what_it_does_not_implement(tile_lib):
     import torch
@@ -173,6 +223,10 @@ def test_tile_route_refuses_what_it_does_not_implement(tile_lib):
     st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, vals_bound=1, lower_bounds=np.full(d, -1.0), upper_bounds=np.full(d, 1.0))
     theta = np.zeros((d, 4))
     ch = mcmc_amd.make_chains(theta, 4)
+    rc = tile_lib.twisted_tile_run(C.c_int(1), C.byref(TwistedTile(Pd.data_ptr(), d, 0.2, 1.5)), C.c_uint64(d), C.byref(st), C.byref(ch), C.c_void_p(0))
+    assert rc == mcmc_amd.MI_ERR_UNSUPPORTED                            # mala with bounds: the one-lane route
+    Mfull = _twisted_precision(d)                                       # a dense precond_mat: likewise
+    st = mcmc_amd.default_settings(n_burnin_draws=1, n_keep_draws=1, precond_mat=Mfull)
     rc = tile_lib.twisted_tile_run(C.c_int(0), C.byref(TwistedTile(Pd.data_ptr(), d, 0.2, 1.5)), C.c_uint64(d), C.byref(st), C.byref(ch), C.c_void_p(0))
     assert rc == mcmc_amd.MI_ERR_UNSUPPORTED
     for algo, kw in ((3, {}), (2, dict(max_tree_depth=11))):          # rwmh is not on this route; nuts trees deeper than its records
