@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mi {
 
@@ -227,6 +228,221 @@ __global__ __launch_bounds__(64) void stats_window_kernel(const double* __restri
     }
     for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
     if (lane == 0) { double* o = out2 + ((size_t)g * d + j) * 3; o[0] = sm; o[1] = sm2; o[2] = sv; }
+}
+
+// ---- every lag in ONE pass, on the fp64 matrix cores (round 4; n <= 128).  For a slowly mixing sampler Geyer's sum needs every lag
+// (configs[2]: 107 GB of kept draws, 272 ms through the window + lag-block passes above, 13 times what one read of the slab costs).
+// The autocovariances of a dimension are the diagonal sums of a Gram matrix over the chains,
+//     acov_k = sum_t G[t][t + k] / (C (n - k)),      G[t][s] = sum_c v[t][c] v[s][c],      v = x - pooled mean,
+// and G = V V' is exactly a v_mfma_f64_16x16x4_f64 product contracting over 4 chains per instruction: with the centred series of a
+// tile of 32 chains in LDS as [t][chain] (row stride 34: conflict-free fragment reads), fragment tb of chain group cg -- lane l holds
+// v[16 tb + (l & 15)][4 cg + (l >> 4)] -- is the A operand of row block tb AND the B operand of column block tb.  A wave keeps the
+// NB (NB + 1) / 2 upper blocks of G in its accumulators (NB = n / 16 rounded up: 28 blocks = 224 registers at n = 100) over all its
+// tiles; per 4 chains that is 3.5 KB of draws for 28 MFMAs of 64 cycles: 2 bytes per SIMD cycle, the chip's HBM rate -- the pass
+// is bound by the read of the slab and by the matrix pipe at the same time.  The R-hat moments ride along (per-chain sums as the tile
+// is loaded).  At the end the four waves of a workgroup spill their blocks through LDS one after the other and thread k adds diagonal
+// k in a fixed order; the host adds the G chain groups in order: the result does not depend on scheduling.
+//   out[g][j][0 .. 16 NB): sum over the group's chains of sum_t v[t] v[t + k];  out[g][j][16 NB .. 32 NB): the row sums sum_c v[t][c];
+//   out2[g][j][0..3) as in the kernels above.  v = x - mean[j], where `mean` may be a PROVISIONAL centre (see the host).
+constexpr int STATS_GRAM_MAX_N = 128;
+constexpr int STATS_GRAM_TC = 64;                       // chains per tile
+constexpr int STATS_GRAM_RS = 66;                       // LDS row stride in doubles: (66 i + k) mod 32 = 2 i + k, conflict-free fragment reads
+constexpr size_t stats_gram_lds_bytes(int nb)
+{
+    const size_t tiles = (size_t)2 * 16 * nb * STATS_GRAM_RS + 2 * 8 * 64 * 2, mat = (size_t)16 * nb * (16 * nb + 1);
+    return ((tiles > mat ? tiles : mat) + 32) * sizeof(double);
+}
+// upper-triangle block b of an NB x NB block matrix, row-major: (tb, sb), tb <= sb
+template <int NB> constexpr int gram_tb(int b) { int tb = 0; while (b >= NB - tb) { b -= NB - tb; ++tb; } return tb; }
+template <int NB> constexpr int gram_sb(int b) { int tb = 0; while (b >= NB - tb) { b -= NB - tb; ++tb; } return tb + b; }
+
+typedef double double4_gram __attribute__((ext_vector_type(4)));
+// the blocks b = Q, Q + 4, ... of quarter Q, with (tb, sb) as true compile-time constants (as values of a loop variable the compiler
+// indexed the fragment array dynamically: scratch, and a vmcnt(0) per MFMA that also waited for the next tile's loads)
+template <int NB, int Q, int I = 0>
+__device__ __forceinline__ void gram_run(const double (&f)[NB], double4_gram (&acc)[(NB * (NB + 1) / 2 + 3) / 4])
+{
+    constexpr int b = Q + 4 * I;
+    if constexpr (b < NB * (NB + 1) / 2) {
+        constexpr int tb = gram_tb<NB>(b), sb = gram_sb<NB>(b);
+        acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[tb], f[sb], acc[I], 0, 0, 0);
+        gram_run<NB, Q, I + 1>(f, acc);
+    }
+}
+template <int NB, int Q, int I = 0>
+__device__ __forceinline__ void gram_spill(double* M, int lane, const double4_gram (&acc)[(NB * (NB + 1) / 2 + 3) / 4])
+{
+    constexpr int b = Q + 4 * I, NR = 16 * NB;
+    if constexpr (b < NB * (NB + 1) / 2) {
+        constexpr int tb = gram_tb<NB>(b), sb = gram_sb<NB>(b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[(size_t)(16 * tb + 4 * r + (lane >> 4)) * (NR + 1) + 16 * sb + (lane & 15)] = acc[I][r];
+        gram_spill<NB, Q, I + 1>(M, lane, acc);
+    }
+}
+
+// Workgroup = 8 waves (two per SIMD) sharing ONE tile of 64 chains at a time, double-buffered in LDS: while the waves run the MFMAs
+// of tile i out of one buffer, the rows of tile i + 1 are in flight (14 coalesced 512-byte loads per lane) and land in the other --
+// one barrier per tile.  Wave w = (quarter q = w >> 1, parity w & 1) owns the blocks b = q (mod 4) of G for the chain groups of its
+// parity: 7 accumulator blocks at n = 100 (the first version gave every wave a tile of its own and all 28 blocks: 446 registers, one
+// wave per SIMD, loads and MFMAs taking turns -- 2 TB/s).
+template <int NB>
+__global__ __launch_bounds__(512, 2) void stats_gram_kernel(const double* __restrict__ draws, const double* __restrict__ mean,
+                                                            uint32_t n, uint32_t d, uint64_t C, uint32_t G,
+                                                            double* __restrict__ out, double* __restrict__ out2)
+{
+    typedef double4_gram double4_g;
+    constexpr int NR = 16 * NB, RS = STATS_GRAM_RS, TC = STATS_GRAM_TC, NBLK = NB * (NB + 1) / 2, BPW = (NBLK + 3) / 4;
+    constexpr int RPW = (NR + 7) / 8;                   // rows a wave loads per tile: w, w + 8, ...
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const uint32_t j = blockIdx.x, g = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = __builtin_amdgcn_readfirstlane(wave >> 1), par = __builtin_amdgcn_readfirstlane(wave & 1);
+    double* const buf0 = lds;                           // [2][NR][RS]
+    double* const momb = lds + (size_t)2 * NR * RS;     // [2][8 waves][64][2]: per-chain partial sums of a tile's rows
+    const uint64_t per = (C + G - 1) / G;
+    const uint64_t c_lo = (uint64_t)g * per, c_hi = (c_lo + per < C) ? c_lo + per : C;
+    const double mj = mean[j];
+    const size_t row = (size_t)d * C;
+    for (int i = threadIdx.x; i < 2 * NR * RS; i += 512) buf0[i] = 0.0;     // rows n .. NR - 1 and the padding columns stay zero
+    double4_g acc[BPW];
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) acc[b] = double4_g{0.0, 0.0, 0.0, 0.0};
+    double sm = 0.0, sm2 = 0.0, sv = 0.0;
+    const uint64_t n_tiles = (c_hi > c_lo) ? (c_hi - c_lo + TC - 1) / TC : 0;
+    // Two tiles ahead: the rows of tiles i + 1 and i + 2 are in flight (registers) while tile i runs out of LDS.  One tile ahead kept
+    // 57 KB in flight per CU, 15 MB on the chip: at the ~7 us a 512-byte row segment takes under load that is 2 TB/s (measured);
+    // HBM wants twice as many bytes in flight.  (NB = 8 has no registers for the second set and stays one tile ahead.)
+    constexpr bool DEEP = false;                        // (measured at n = 100: 52.2 ms either way once the barrier stopped draining the loads -- the pass is not latency-bound)
+    // The barrier of the tile loop orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well and drains the GLOBAL
+    // loads in flight (s_waitcnt vmcnt(0)): the prefetched rows would be waited for at every tile, which is what held the first
+    // versions at 2 TB/s however far ahead they requested.
+    auto lds_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    double xrA[RPW], xrB[DEEP ? RPW : 1];
+    // this lane's share of the ROW sums R_t = sum_c v[t][c], rows wave + 8 u: the host needs them to move the centre from the provisional
+    // `mean` the kernel is given to the pooled mean it yields (one pass over the slab instead of a mean pass and this one)
+    double rs[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) rs[u] = 0.0;
+    // rows wave, wave + 8, ... of tile `tile`: requested into registers
+    auto request = [&](uint64_t tile, auto& xr) __attribute__((always_inline)) {
+        const uint64_t c = c_lo + tile * TC + lane;
+        const double* p = draws + (size_t)j * C + ((c < c_hi) ? c : c_hi - 1);
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const uint32_t t = (uint32_t)(wave + 8 * u);
+            xr[u] = p[(size_t)(t < n ? t : n - 1) * row];
+        }
+    };
+    // ... centred, written to buffer `bi`, with this wave's part of the per-chain sums
+    auto deposit = [&](uint64_t tile, int bi, const auto& xr) __attribute__((always_inline)) {
+        const bool on = c_lo + tile * TC + lane < c_hi;
+        double* const V = buf0 + (size_t)bi * NR * RS;
+        double s1 = 0.0, q0 = 0.0;
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            const uint32_t t = (uint32_t)(wave + 8 * u);
+            if (t < n) {
+                const double v = on ? xr[u] - mj : 0.0;
+                V[(size_t)t * RS + lane] = v;
+                s1 += v;
+                q0 = __builtin_fma(v, v, q0);
+                rs[u] += v;
+            }
+        }
+        double* m = momb + (((size_t)bi * 8 + wave) * 64 + lane) * 2;
+        m[0] = s1; m[1] = q0;
+    };
+    // the MFMAs and the R-hat moments of the tile in buffer bi
+    auto compute = [&](uint64_t tile, int bi) __attribute__((always_inline)) {
+        const double* const V = buf0 + (size_t)bi * NR * RS;
+        if ((uint64_t)wave == (tile & 7)) {             // one wave adds the 8 partial per-chain sums, in order
+            double s1 = 0.0, q0 = 0.0;
+            for (int wv = 0; wv < 8; ++wv) { const double* m = momb + (((size_t)bi * 8 + wv) * 64 + lane) * 2; s1 += m[0]; q0 += m[1]; }
+            if (c_lo + tile * TC + lane < c_hi) {
+                const double mc = s1 / (double)n;
+                sm += mc; sm2 = __builtin_fma(mc, mc, sm2);
+                sv += (n > 1) ? (q0 - (double)n * mc * mc) / (double)(n - 1) : 0.0;
+            }
+        }
+        const double* fr = V + (size_t)(lane & 15) * RS + (lane >> 4) + 4 * par;
+#pragma unroll 1
+        for (int cg2 = 0; cg2 < TC / 8; ++cg2) {        // chain groups cg = 2 cg2 + par
+            double f[NB];
+#pragma unroll
+            for (int tb = 0; tb < NB; ++tb) f[tb] = fr[(size_t)(16 * tb) * RS + 8 * cg2];
+            if (q == 0) gram_run<NB, 0>(f, acc);
+            else if (q == 1) gram_run<NB, 1>(f, acc);
+            else if (q == 2) gram_run<NB, 2>(f, acc);
+            else gram_run<NB, 3>(f, acc);
+        }
+    };
+    __syncthreads();                                    // the zeroed buffers
+    if (n_tiles > 0) { request(0, xrA); deposit(0, 0, xrA); }
+    if (n_tiles > 1) request(1, xrA);
+    __syncthreads();
+    if constexpr (DEEP) {
+        // invariant at the top of a step: tile `tile` in buffer bi, tile + 1 in flight in the first register set
+        auto step = [&](uint64_t tile, auto& x_next, auto& x_after) __attribute__((always_inline)) {
+            const int bi = (int)(tile & 1);
+            if (tile + 2 < n_tiles) request(tile + 2, x_after);
+            compute(tile, bi);
+            if (tile + 1 < n_tiles) deposit(tile + 1, 1 - bi, x_next);
+            lds_barrier();                              // tile + 1 is in its buffer, everybody is done with tile
+        };
+        for (uint64_t tile = 0; tile < n_tiles; tile += 2) {
+            step(tile, xrA, xrB);
+            if (tile + 1 < n_tiles) step(tile + 1, xrB, xrA);
+        }
+    } else {
+        for (uint64_t tile = 0; tile < n_tiles; ++tile) {
+            const int bi = (int)(tile & 1);
+            compute(tile, bi);                          // (tile + 1 was requested before this tile's MFMAs began)
+            if (tile + 1 < n_tiles) deposit(tile + 1, 1 - bi, xrA);
+            if (tile + 2 < n_tiles) request(tile + 2, xrA);
+            lds_barrier();
+        }
+    }
+    // ---- diagonal sums: the 8 waves spill their blocks through LDS one after the other, thread k adds diagonal k (fixed order)
+    double* const M = lds;                              // [NR][NR + 1]
+    double* const red = lds + ((size_t)2 * NR * RS + 2 * 8 * 64 * 2 > (size_t)NR * (NR + 1) ? (size_t)2 * NR * RS + 2 * 8 * 64 * 2 : (size_t)NR * (NR + 1));
+    double lag_sum = 0.0;
+    for (int m = 32; m >= 1; m >>= 1) { sm += __shfl_xor(sm, m); sm2 += __shfl_xor(sm2, m); sv += __shfl_xor(sv, m); }
+    if (lane == 0) { red[wave * 3 + 0] = sm; red[wave * 3 + 1] = sm2; red[wave * 3 + 2] = sv; }
+    for (int pr = 0; pr < 2; ++pr) {                    // the four quarters of one parity together fill the whole upper triangle
+        __syncthreads();
+        if (par == pr) {
+            if (q == 0) gram_spill<NB, 0>(M, lane, acc);
+            else if (q == 1) gram_spill<NB, 1>(M, lane, acc);
+            else if (q == 2) gram_spill<NB, 2>(M, lane, acc);
+            else gram_spill<NB, 3>(M, lane, acc);
+        }
+        __syncthreads();
+        const uint32_t k = threadIdx.x;
+        if (k < n) {
+            double s_ = 0.0;
+            for (uint32_t t = 0; t + k < n; ++t) s_ += M[(size_t)t * (NR + 1) + t + k];
+            lag_sum += s_;
+        }
+    }
+    if (threadIdx.x < (uint32_t)NR) out[((size_t)g * d + j) * (2 * NR) + threadIdx.x] = (threadIdx.x < n) ? lag_sum : 0.0;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {                     // row sums: the 64 chains-lanes of the wave that owns the row, fixed butterfly
+        double r_ = rs[u];
+        for (int m = 32; m >= 1; m >>= 1) r_ += __shfl_xor(r_, m);
+        const uint32_t t = (uint32_t)(wave + 8 * u);
+        if (lane == 0 && t < (uint32_t)NR) out[((size_t)g * d + j) * (2 * NR) + NR + t] = (t < n) ? r_ : 0.0;
+    }
+    if (threadIdx.x == 0) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int wv = 0; wv < 8; ++wv) { a0 += red[wv * 3 + 0]; a1 += red[wv * 3 + 1]; a2 += red[wv * 3 + 2]; }
+        double* o = out2 + ((size_t)g * d + j) * 3;
+        o[0] = a0; o[1] = a1; o[2] = a2;
+    }
 }
 
 // draws_out slab [n][d][C] -> per chain the column-major n x d matrix Eigen would hold: out[c][j][k] (SURVEY 8 f-3 "layout

@@ -33,26 +33,38 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
         HIP_TRY(hipMemcpyAsync(staged.p, draws_kdc, n * d * C * 8, hipMemcpyHostToDevice, st));
         x = staged.as<double>();
     }
-    const uint32_t G = (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);      // chain groups (partials are added in order on the host)
+    // chain groups (partials are added in order on the host).  The one-pass Gram kernel (n <= 128) wants few, long workgroups -- its
+    // prologue (first tile) and epilogue (diagonal sums) are per workgroup, and every group is 16 NB x d doubles to fetch --: about 2 048
+    // workgroups in all; the streamed kernels want many short ones.
+    const bool gram = n <= (size_t)mi::STATS_GRAM_MAX_N;
+    const uint32_t G = gram ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(64, (2048 + d - 1) / d), (C + 63) / 64))
+                            : (uint32_t)std::min<uint64_t>(64, (C + 63) / 64);
     const bool tiled = n > (size_t)mi::STATS_MAX_N;                          // long series: lags below STATS_TILED_LAGS, streamed kernel
     const size_t nlag_max = tiled ? (size_t)mi::STATS_TILED_LAGS : n;
     const size_t pass_lags = (size_t)mi::STATS_PASS_BLOCKS * mi::STATS_LB;
     // one device buffer for everything: [G d] sums, [d] means, [d] dimension list, [G d 3] moments, [G d max(pass, tiled) lags]
-    const size_t part_lags = tiled ? nlag_max : std::max<size_t>(pass_lags, 16);
+    const size_t part_lags = tiled ? nlag_max : std::max<size_t>(std::max<size_t>(pass_lags, 16), (n <= (size_t)mi::STATS_GRAM_MAX_N) ? ((n + 15) / 16) * 32 : 0);
     DevBuf buf;
     const size_t o_sum = 0, o_mean = o_sum + (size_t)G * d, o_dims = o_mean + d, o_mom = o_dims + d, o_part = o_mom + (size_t)G * d * 3;
     HIP_TRY(buf.alloc((o_part + (size_t)G * d * part_lags) * 8));
     double* const B = buf.as<double>();
-    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, B + o_sum);
+    // ONE pass over the slab when the Gram kernel serves the request (n <= 128 and more than the mean is asked for): the series are
+    // centred by a PROVISIONAL centre a_j -- the mean of the first kept draw over the chains, 1 / n of the slab -- and the kernel's row
+    // sums R_t = sum_c (x_t - a) move the centre to the pooled mean afterwards (exactly, in the algebra; a_j is within a few standard
+    // errors of the mean, so nothing cancels):  sum_c sum_t (v_t - e)(v_{t+k} - e) = S_k - e (sum_{t < n-k} R_t + sum_{t >= k} R_t) + C (n - k) e^2,
+    // e = pooled mean - a.  (Otherwise: the pooled mean first, one read of the slab, then the lag kernels.)
+    const bool one_pass = gram && (acov || rhat || ess);
+    const uint32_t n_sum = one_pass ? 1u : (uint32_t)n;
+    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, n_sum, (uint32_t)d, (uint64_t)C, G, B + o_sum);
     std::vector<double> part((size_t)G * d), mean_h(d);
     HIP_TRY(hipMemcpyAsync(part.data(), B + o_sum, part.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t j = 0; j < d; ++j) {
         double s = 0.0;
         for (uint32_t g = 0; g < G; ++g) s += part[(size_t)g * d + j];
-        mean_h[j] = s / ((double)n * (double)C);
+        mean_h[j] = s / ((double)n_sum * (double)C);
     }
-    if (mean) std::memcpy(mean, mean_h.data(), d * 8);
+    if (!one_pass && mean) std::memcpy(mean, mean_h.data(), d * 8);
     if (!acov && !rhat && !ess) return MI_OK;
     HIP_TRY(hipMemcpyAsync(B + o_mean, mean_h.data(), d * 8, hipMemcpyHostToDevice, st));
 
@@ -114,6 +126,56 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
         HIP_TRY(hipStreamSynchronize(st));
         collect(ap, active, nlag_max, 0, nlag_max);
         computed = nlag_max;
+        prune();
+    } else if (gram) {
+        // every lag of every dimension in ONE pass over the slab, on the matrix cores (draw_stats.hpp: stats_gram_kernel)
+        const int nb = (int)((n + 15) / 16);
+        const size_t lds = mi::stats_gram_lds_bytes(nb);
+        auto launch = [&](auto kern) -> int {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)d, G), dim3(512), lds, st, x, B + o_mean, (uint32_t)n, (uint32_t)d, (uint64_t)C, G, B + o_part, B + o_mom);
+            HIP_TRY(hipGetLastError());
+            return MI_OK;
+        };
+        switch (nb) {
+        case 1: rc = launch(mi::stats_gram_kernel<1>); break;
+        case 2: rc = launch(mi::stats_gram_kernel<2>); break;
+        case 3: rc = launch(mi::stats_gram_kernel<3>); break;
+        case 4: rc = launch(mi::stats_gram_kernel<4>); break;
+        case 5: rc = launch(mi::stats_gram_kernel<5>); break;
+        case 6: rc = launch(mi::stats_gram_kernel<6>); break;
+        case 7: rc = launch(mi::stats_gram_kernel<7>); break;
+        default: rc = launch(mi::stats_gram_kernel<8>); break;
+        }
+        if (rc) return rc;
+        const size_t nr = (size_t)16 * nb;
+        if ((rc = fetch(ap, B + o_part, (size_t)G * d * 2 * nr))) return rc;
+        if ((rc = fetch(mp, B + o_mom, (size_t)G * d * 3))) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        // move the centre from the provisional a_j (mean_h) to the pooled mean (see above); groups added in order
+        std::vector<double> R(n);
+        for (size_t j = 0; j < d; ++j) {
+            double tot = 0.0;
+            for (size_t t = 0; t < n; ++t) {
+                double r_ = 0.0;
+                for (uint32_t g = 0; g < G; ++g) r_ += ap[((size_t)g * d + j) * 2 * nr + nr + t];
+                R[t] = r_; tot += r_;
+            }
+            const double e = tot / ((double)n * (double)C);
+            double head = tot, tail = tot;                  // sum_{t < n-k} R_t and sum_{t >= k} R_t, k = 0
+            for (size_t k = 0; k < n; ++k) {
+                if (k > 0) { head -= R[n - k]; tail -= R[k - 1]; }
+                double s_ = 0.0;
+                for (uint32_t g = 0; g < G; ++g) s_ += ap[((size_t)g * d + j) * 2 * nr + k];
+                const double cen = s_ - e * (head + tail) + (double)C * (double)(n - k) * e * e;
+                ac[k * d + j] = cen / (double)C / (double)(n - k);
+            }
+            mean_h[j] += e;
+            // (the R-hat moments are sums over chains of the chain mean, its square and the chain variance about the provisional centre:
+            //  the variance of the chain means and the within-chain variances do not depend on the centre)
+        }
+        if (mean) std::memcpy(mean, mean_h.data(), d * 8);
+        computed = n;
         prune();
     } else {
         if (!acov) {
