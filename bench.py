@@ -450,8 +450,8 @@ def main():
                            "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
                            "chains": o["config"]["chains_per_gpu"], "accept_rate": o["config"]["accept_rate"],
                            "roofline": o["roofline"],
-                           **({"ess_per_sec": o["ess_per_sec"], "ess_per_sec_incl_reducer": o["ess_per_sec_incl_reducer"],
-                               "ess_reducer_ms": o["ess_reducer_ms"]} if "ess_per_sec" in o else {})})
+                           **({k: o[k] for k in ("ess_per_sec", "ess_per_sec_incl_reducer", "ess_reducer_ms", "rhat_max", "ess_is_estimate",
+                                                 "ess_caveat") if k in o})})
         out["other_configs"] = others
     if ctx.rank == 0:
         if not args.no_cpu_baseline and ctx.world == 1:

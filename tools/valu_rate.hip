@@ -51,7 +51,7 @@ void run(const char* name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 8}) {
         run<0>("v_fma_f64", w);
         run<1>("v_mul_f64 v,v", w);
         run<2>("v_add_f64 v,v", w);
