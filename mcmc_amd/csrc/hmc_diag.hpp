@@ -61,9 +61,17 @@ __device__ __forceinline__ double diag_combine(double q)
 // still one independent trajectory per dimension.  The NaN poisoning of the reference's dense `inv_precond_matrix * mntm`
 //  couples the dimensions: these kernels detect the regime (a non-finite energy is its necessary
 // consequence), flag the chain in prm.nf_flag and leave theta / n_accept untouched; literal.hpp replays the chain.
+#ifndef MI_DIAG4_TRAJ
+#define MI_DIAG4_TRAJ 4        // trajectories in flight per lane: 4 (two Philox slots per iteration) or 2 (one)
+#endif
+#ifndef MI_DIAG4_MINW
+#define MI_DIAG4_MINW 1        // waves per SIMD the register allocation must allow (launch bound)
+#endif
 template <bool PRECOND>
-__global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
+__global__ __launch_bounds__(256, MI_DIAG4_MINW) void hmc_diag4_kernel(const HmcDiagParams prm)
 {
+    constexpr int TR = MI_DIAG4_TRAJ;
+    static_assert(TR == 2 || TR == 4, "one or two Philox slots per iteration");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t j = (uint32_t)(lane >> 4);
     const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (uint64_t)(lane & 15);
@@ -107,12 +115,12 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
         if (dst == cur) { pp ^= 1u; dst = prm.scratch + (size_t)pp * slab + c; }   // never overwrite prev_draw
         double qk0 = 0.0, qu1 = 0.0, qk1 = 0.0;
         // two blocks of 8 dimensions per iteration: 4 trajectories in flight per lane (dims 8b+j, 8b+4+j, 8b+8+j, 8b+12+j)
-        for (uint32_t b = 0; b * 8 < d; b += 2) {
-            double z[4], th[4], pm[4], lam[4], w[4], mi_[PRECOND ? 4 : 1];
+        for (uint32_t b = 0; b * 8 < d; b += TR / 2) {
+            double z[TR], th[TR], pm[TR], lam[TR], w[TR], mi_[PRECOND ? TR : 1];
             rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * b + j, STREAM_NORMAL, z[0], z[1]);
-            rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * (b + 1) + j, STREAM_NORMAL, z[2], z[3]);
+            if constexpr (TR == 4) rng_normal_pair(prm.seed, chain, draw + prm.draw0, 4 * (b + 1) + j, STREAM_NORMAL, z[TR - 2], z[TR - 1]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < TR; ++r) {
                 const uint32_t i = 8 * b + 4 * (uint32_t)r + j;
                 const uint32_t ic = i < d ? i : d - 1;                    // clamped: unconditional loads
                 th[r] = cur[(size_t)ic * C];
@@ -122,18 +130,18 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
                 w[r] = lam[r] * th[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < TR; ++r)
                 if (8 * b + 4 * (uint32_t)r + j < d) qk0 = dfma(pm[r], PRECOND ? mi_[PRECOND ? r : 0] * pm[r] : pm[r], qk0);
             // hmc.cpp:164-176.  The second half-step of step k and the first of step k+1 see the same gradient, hence the same
             // (eps*w)/2: formed once, subtracted twice (the reference's two roundings) -- 7 instead of 9 operations per step.
             if (L > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pm[r] = pm[r] - (eps * w[r]) / 2.0;                    // first half-step of step 0
+                for (int r = 0; r < TR; ++r) pm[r] = pm[r] - (eps * w[r]) / 2.0;                    // first half-step of step 0
             }
             // the step counter lives in a scalar register (a vector counter is 2 of the 30 VALU instructions of this VALU-bound loop)
             for (uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)((L > 0) ? L - 1 : 0u)); kk != 0u; kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kk - 1u))) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < TR; ++r) {
                     if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);   // :171
                     else th[r] = th[r] + eps * pm[r];
                     w[r] = lam[r] * th[r];
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
             }
             if (L > 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < TR; ++r) {
                     if constexpr (PRECOND) th[r] = th[r] + eps * (mi_[PRECOND ? r : 0] * pm[r]);
                     else th[r] = th[r] + eps * pm[r];
                     w[r] = lam[r] * th[r];
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void hmc_diag4_kernel(const HmcDiagParams prm)
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < TR; ++r) {
                 const uint32_t i = 8 * b + 4 * (uint32_t)r + j;
                 if (i < d) {
                     qu1 = dfma(th[r], w[r], qu1);
