@@ -30,14 +30,16 @@ def sweep(n_cases=40, seed=1, verbose=True):
         st = mcmc_amd.default_settings(rng_seed_value=int(rng.integers(1, 10**6)), n_burnin_draws=burn, n_keep_draws=keep,
                                        n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
         chain0 = int(rng.integers(0, 5000))
-        g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0)
+        # the launch shape: AUTO (few chains at d > 64: the split-tile kernel), or one of the plain-case kernels by name
+        hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL]))
+        g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0, kernel_hint=hint)
         o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0)
         bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
         same = lambda a, b: np.array_equal(bits(a), bits(b)) or np.array_equal(a, b, equal_nan=True)     # (NaN payloads may differ)
         ok = (same(g_draws, o_draws) and np.array_equal(g["depth"], o["depth"]) and np.array_equal(g["n_leap"], o["n_leap"])
               and np.array_equal(g["n_accept"], o["n_accept"]) and same(g["eps"], o["eps"]))
         if verbose or not ok:
-            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, C=C, burn=burn, keep=keep, adapt=adapt, max_depth=max_depth, eps0=eps0, chain0=chain0), flush=True)
+            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, C=C, burn=burn, keep=keep, adapt=adapt, max_depth=max_depth, eps0=eps0, chain0=chain0, hint=hint, kernel=mcmc_amd.last_kernel()), flush=True)
         fails += 0 if ok else 1
     return fails
 

@@ -51,7 +51,7 @@ def test_nuts_resumes_after_its_adaptation_window():
     assert e.value.code == mcmc_amd.MI_ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
+@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
 @pytest.mark.parametrize("cut", [3, 9, 10, 14])
 def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     """checkpoint of (theta, eps, h, Philox counter).  n_adapt_draws = 10 of 12 burn-in + 6 kept draws; the run is cut after
@@ -59,8 +59,8 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     after it (14) -- and continued with step_size + nuts_adapt_state: bit-identical to the uncut run on every nuts kernel."""
     burn, keep, n_adapt, C = 12, 6, 10, 21
     kw, tkw = dict(max_tree_depth=5), {}
-    if route.startswith("reg") or route.startswith("general"):
-        d = 32 if route.startswith("reg") else 20
+    if route.startswith("reg") or route.startswith("general") or route.startswith("split"):
+        d = 32 if route.startswith("reg") else 100 if route.startswith("split") else 20     # (d = 100, few chains: nuts_gauss_split_kernel)
         kind = mcmc_amd.TARGET_GAUSS_DENSE; tkw = dict(prec=synth.dense_gaussian_precision(d, seed=2))
         if "diag_mass" in route: kw["precond_mat"] = np.diag(np.linspace(0.5, 2.0, d))
         if "dense_precond" in route:                          # (the general tick-local kernel; bounds are left out on purpose: a checkpoint holds
@@ -80,6 +80,8 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     a_draws, a = mcmc_amd.sample("nuts", kind, init, S(0, cut), chain0=4, want_adapt_state=True, **tkw)
     b_draws, b = mcmc_amd.sample("nuts", kind, a["theta"].T.copy(), S(0, burn + keep - cut), chain0=4, draw0=cut, step_size_in=a["eps"],
                                  adapt_state_in=a["adapt_state"], **tkw)
+    if route.startswith("split"):
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_split_kernel<8, ")
     assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
     assert np.array_equal(b["eps"], w["eps"])
     if cut <= n_adapt:                                  # (after the window the state is no longer read, hence not carried)
