@@ -275,7 +275,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, units_all = float(tmax[0].item()), float(t[1].item())
 
-    collate_ms = None
+    collate_ms, collate_overlapped_total_ms = None, None
     if headline and args.collate and dist is not None and not share:
         c_max = mdist.shard_bounds(total, world, 0)[1] if scaling == "strong" else C
         send = torch.zeros((n_keep, d, c_max), dtype=torch.float64, device=dev)
@@ -288,6 +288,36 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
         barrier()
         collate_ms = (time.perf_counter() - tc) * 1e3
         del gathered, send
+        # ... and OVERLAPPED with the sampling ("per kept-draw slab, overlapped with the next trajectory"): the same run in
+        # four chunks chained through mi_chains.draw0 (bit-identical to one call), chunk k's slab all-gathered asynchronously -- RCCL's
+        # own stream -- while chunk k + 1 samples.  One timed repetition, barrier on both sides; compare with ms_per_step + the blocking
+        # gather above.  (The C-ABI form of the same thing: mi_mcmc_allgather_draws_begin / _wait.)
+        if algo in ("hmc", "mala") and n_keep >= 4:
+            K = 4
+            bounds = [(n_keep * i) // K for i in range(K + 1)]
+            slabs = [torch.zeros((bounds[i + 1] - bounds[i], d, c_max), dtype=torch.float64, device=dev) for i in range(K)]
+            outs = [torch.empty((world * (bounds[i + 1] - bounds[i]), d, c_max), dtype=torch.float64, device=dev) for i in range(K)]
+            theta.copy_(theta0)
+            barrier()
+            tc = time.perf_counter()
+            works = []
+            for i in range(K):
+                s_i = mcmc_amd.default_settings(**dict(skw, n_burnin_draws=cfg["n_burnin_draws"] if i == 0 else 0, n_keep_draws=bounds[i + 1] - bounds[i]))
+                # (the slab of a chunk has the shard's own chain count as its row length; the padded send buffer is filled by a strided copy)
+                loc = torch.empty((bounds[i + 1] - bounds[i], d, max(C, 1)), dtype=torch.float64, device=dev)
+                ch_i = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=loc, mem=mcmc_amd.MEM_DEVICE,
+                                            draw0=0 if i == 0 else cfg["n_burnin_draws"] + bounds[i])
+                if C > 0:
+                    mcmc_amd.run(algo, target, s_i, ch_i, stream=stream)
+                    slabs[i][:, :, :C] = loc[:, :, :C]
+                works.append(dist.all_gather_into_tensor(outs[i], slabs[i], async_op=True))
+            for w_ in works:
+                w_.wait()
+            barrier()
+            collate_overlapped_total_ms = (time.perf_counter() - tc) * 1e3
+            del slabs, outs
+        else:
+            collate_overlapped_total_ms = None
 
     # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, autocovariances pooled
     # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region, its own
@@ -388,6 +418,10 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
         if collate_ms is not None:
             out["collate_allgather_ms"] = collate_ms
             out["collate_bytes_per_rank"] = n_keep * d * C * 8
+            if collate_overlapped_total_ms is not None:
+                out["collate_overlapped"] = {"chunks": 4, "sampling_plus_gather_ms": collate_overlapped_total_ms,
+                                             "blocking_equivalent_ms": elapsed / steps * 1e3 + collate_ms,
+                                             "note": "one run in 4 chunks through mi_chains.draw0, each chunk's slab all-gathered asynchronously under the next chunk's sampling"}
     del draws, theta, theta0, n_accept, n_leap, eps_out, kw_dev, target, chains
     mcmc_amd.release_workspace()
     torch.cuda.empty_cache()
@@ -428,9 +462,12 @@ def main():
     ctx.share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
     ctx.dev = mdist.bind_device(None if ctx.share else int(os.environ.get("LOCAL_RANK", "0")))
     ctx.dist = None
-    if ctx.world > 1:
+    if ctx.world > 1 or args.collate:          # (--collate at one GPU: a 1-rank RCCL group, so that the collation code runs on the box that has one)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if ctx.share:
             dist.init_process_group(backend="gloo")
         else:

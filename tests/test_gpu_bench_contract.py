@@ -56,6 +56,18 @@ def test_two_rank_code_path():
     assert j["value"] > 0
 
 
+def test_collate_reports_the_blocking_and_the_overlapped_gather():
+    """--collate: the RCCL all-gather of the kept draws, blocking and overlapped with the sampling (four chunks through mi_chains.draw0);
+    on this box a 1-rank group."""
+    out = subprocess.run([sys.executable, "bench.py", "--collate", "--steps", "1", "--warmup", "0", "--chains", "4096", "--no-cpu-baseline",
+                          "--traffic", "none", "--no-ess"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert j["collate_allgather_ms"] > 0 and j["collate_bytes_per_rank"] == 100 * 128 * 4096 * 8
+    ov = j["collate_overlapped"]
+    assert ov["chunks"] == 4 and ov["sampling_plus_gather_ms"] > 0 and ov["blocking_equivalent_ms"] > 0
+
+
 @pytest.mark.parametrize("config,bound", [(3, "mfma"), (4, "mfma"), (5, "valu-fp64")])
 def test_other_baseline_configs_print_their_own_roofline(config, bound):
     out = subprocess.run([sys.executable, "bench.py", "--config", str(config), "--steps", "1", "--warmup", "0", "--chains", "2048",
