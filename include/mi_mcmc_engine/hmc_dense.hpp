@@ -66,6 +66,7 @@ struct HmcParams {
     const double* m_inv;    // diag of INV(precond) (hmc.cpp:58)
     uint32_t ablate;        // profiling only: 1 = skip kick/drift, 2 = skip mat-vec (results meaningless)
     uint32_t stagger;       // start delay of the second wave of each SIMD, in s_sleep(127) units
+    uint32_t m_per_chain;   // DIAGM: 0 = one mass for all chains (m_sqrt / m_inv are [d]); 1 = per-chain masses (mi_chains.mass_diag): [d][C]
     uint32_t* nf_flag;      // plain kernels: [C + 1] or nullptr.  A chain whose energies went non-finite is flagged (nf_flag[c] = 1,
                             // nf_flag[C] = 1) and its theta / n_accept / n_leap are left untouched: literal.hpp replays it
 };
@@ -299,9 +300,13 @@ __device__ MI_BOX_INLINE double box_log_jacobian_term(double v, int bt, double l
 // K = p.(p / m) / 2 applied element-wise from two LDS tables; two waves per SIMD like the plain kernel (the general variant holds a
 // fourth vector and runs one).  The NaN poisoning of the reference's dense `inv_precond_matrix * mntm` is handled as in the plain
 // kernel: detected through the energies, flagged, replayed by literal.hpp (precond = 1).
-template <int NT, int WPB, bool BOUNDED = false, bool DENSE_M = false, bool DIAGM = false>
+// PCM (with DIAGM): PER-CHAIN diagonal masses (mi_chains.mass_diag: chain c runs with precond_mat = diag(mass[:, c])): the two tables are
+// [d][C] in global memory, this lane's entry of slice s at [(4 s + j) C + c], read where it is used (a chain's column is 2 KB at d = 128;
+// the 16 chains of a wave make 128-byte segments).
+template <int NT, int WPB, bool BOUNDED = false, bool DENSE_M = false, bool DIAGM = false, bool PCM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mfma_kernel(const HmcParams prm)
 {
+    static_assert(!PCM || DIAGM, "per-chain masses ride the diagonal-mass variant");
     static_assert(!DENSE_M || BOUNDED, "the dense preconditioner rides the general variant");
     static_assert(!DIAGM || !BOUNDED, "DIAGM is the plain kernel with a diagonal mass; bounds take the general variant");
     constexpr int NS = 4 * NT;
@@ -329,7 +334,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
         }
         __syncthreads();
     }
-    if (DIAGM) {
+    if (DIAGM && !PCM) {
         for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
             const bool in = (uint32_t)i < prm.d;
             lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
@@ -364,6 +369,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
     const uint64_t cl = ((uint64_t)blockIdx.x * WPB + wave) * 16 + (lane & 15);
     const bool live = cl < prm.C;
     const uint64_t cld = live ? cl : prm.C - 1;       // clamped index for loads
+    // PCM: 1 / m and sqrt(m) of (slice s, this lane) from the chain's column; padding dimensions (>= d) read entry 0 and multiply zeros
+    [[maybe_unused]] auto pcm_at = [&](const double* tab, int s) __attribute__((always_inline)) -> double {
+        uint32_t dim = 4u * (uint32_t)s + (uint32_t)(lane >> 4);
+        asm volatile("" : "+v"(dim));                   // (opaque: as loop invariants of the leapfrog loop the NS entries were kept in registers
+                                                        //  the kernel does not have -- 276 spilled VGPRs, 980 B of scratch, 204 ms on configs[1]'s shape)
+        return tab[(size_t)(dim < prm.d ? dim : 0u) * prm.C + cld];
+    };
+    auto minv_at = [&]([[maybe_unused]] const double* mic, int s) __attribute__((always_inline)) -> double {
+        if constexpr (PCM) return pcm_at(prm.m_inv, s); else return mic[4 * s];
+    };
     const uint64_t chain = prm.chain0 + cl;           // global chain id (Philox counter)
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
@@ -442,9 +457,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             return q / 2.0;
         } else if constexpr (DIAGM) {
             double q = 0.0;
-            const double* mic = mi_col();
+            const double* mic = PCM ? nullptr : mi_col();
 #pragma unroll
-            for (int s = 0; s < NS; ++s) q = dfma(pm[s], mic[4 * s] * pm[s], q);
+            for (int s = 0; s < NS; ++s) q = dfma(pm[s], minv_at(mic, s) * pm[s], q);
             q = q + __shfl_xor(q, 32);
             q = q + __shfl_xor(q, 16);
             return q / 2.0;
@@ -537,7 +552,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             else rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
             pm[2 * b] = (8u * b + j < d) ? z0 : 0.0;
             pm[2 * b + 1] = (8u * b + 4 + j < d) ? z1 : 0.0;
-            if constexpr (DIAGM) {                      // p = L z with a diagonal L (:158); the table entry is read where it is used
+            if constexpr (DIAGM && PCM) {               // p = L z, L = diag(sqrt(mass[:, c])) of this chain
+                pm[2 * b] = pcm_at(prm.m_sqrt, 2 * b) * pm[2 * b];
+                pm[2 * b + 1] = pcm_at(prm.m_sqrt, 2 * b + 1) * pm[2 * b + 1];
+            } else if constexpr (DIAGM) {               // p = L z with a diagonal L (:158); the table entry is read where it is used
                 const double* msc = lds_ms + (lane >> 4);
                 asm volatile("" : "+v"(msc));
                 pm[2 * b] = msc[8 * b] * pm[2 * b];
@@ -563,11 +581,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             // statements), 6 instead of 8 VALU operations per element and step.
             const uint32_t L = prm.n_leap_steps;
             if (L > 0 && (prm.ablate & 3u) != 1u) {
-                [[maybe_unused]] const double* mic = DIAGM ? mi_col() : nullptr;
+                [[maybe_unused]] const double* mic = (DIAGM && !PCM) ? mi_col() : nullptr;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     pm[s] = pm[s] - (eps * w[s]) / 2.0;                     // first half-step of step 0 (:167,126)
-                    if constexpr (DIAGM) th[s] = th[s] + eps * (mic[4 * s] * pm[s]);   // (:171) theta += eps Minv p
+                    if constexpr (DIAGM) th[s] = th[s] + eps * (minv_at(mic, s) * pm[s]);   // (:171) theta += eps Minv p
                     else th[s] = th[s] + eps * pm[s];                       // (:171)
                 }
             }
@@ -575,13 +593,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
             for (uint32_t k = 0; k + 1 < L; ++k) {
                 if ((prm.ablate & 3u) != 2u) gradient();
                 if ((prm.ablate & 3u) != 1u) {
-                    [[maybe_unused]] const double* mic = DIAGM ? mi_col() : nullptr;
+                    [[maybe_unused]] const double* mic = (DIAGM && !PCM) ? mi_col() : nullptr;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const double t = (eps * w[s]) / 2.0;
                         pm[s] = pm[s] - t;                                  // second half-step of step k (:175)
                         pm[s] = pm[s] - t;                                  // first half-step of step k+1 (:167)
-                        if constexpr (DIAGM) th[s] = th[s] + eps * (mic[4 * s] * pm[s]);
+                        if constexpr (DIAGM) th[s] = th[s] + eps * (minv_at(mic, s) * pm[s]);
                         else th[s] = th[s] + eps * pm[s];                   // (:171)
                     }
                 }

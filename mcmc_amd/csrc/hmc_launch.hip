@@ -21,15 +21,15 @@ int plain(const HmcParams& prm, hipStream_t st)
 }
 
 // diagonal precond_mat, no bounds: the plain kernel's shape with the two mass tables next to P in LDS
-template <int NT>
+template <int NT, bool PCM = false>
 int plain_diagm(const HmcParams& prm, hipStream_t st)
 {
     constexpr int WPB = MI_HMC_WPB;
     const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + (size_t)16 * NT * (4 * sizeof(double) + sizeof(int));
-    auto kern = hmc_gauss_mfma_kernel<NT, WPB, false, false, true>;
+    auto kern = hmc_gauss_mfma_kernel<NT, WPB, false, false, true, PCM>;
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((prm.C + 16 * WPB - 1) / (16 * WPB));
-    note_kernel("hmc_gauss_mfma_kernel<%d, %d, false, false, true>", NT, WPB);
+    note_kernel("hmc_gauss_mfma_kernel<%d, %d, false, false, true%s>", NT, WPB, PCM ? ", true" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, prm);
     return (int)hipGetLastError();
 }
@@ -74,6 +74,8 @@ int launch_hmc_gauss(const HmcParams& prm, int nt, bool gen, bool dense_m, hipSt
 
 int launch_hmc_gauss_diagm(const HmcParams& prm, int nt, hipStream_t st)
 {
+    if (prm.m_per_chain)      // per-chain masses (mi_chains.mass_diag): the tables are [d][C] in global memory
+        return MI_DISPATCH_NT(nt, (plain_diagm<1, true>(prm, st)), (plain_diagm<2, true>(prm, st)), (plain_diagm<4, true>(prm, st)), (plain_diagm<8, true>(prm, st)));
     return MI_DISPATCH_NT(nt, plain_diagm<1>(prm, st), plain_diagm<2>(prm, st), plain_diagm<4>(prm, st), plain_diagm<8>(prm, st));
 }
 

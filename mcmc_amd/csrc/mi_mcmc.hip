@@ -1159,7 +1159,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (chains->mass_diag) {
         // per-chain diagonal masses: separable Gaussians without bounds on the elementwise kernels (below), everything else literally
         const bool sep = target->kind == MI_TARGET_GAUSS_ISO || target->kind == MI_TARGET_GAUSS_DIAG;
-        if (!sep || settings->vals_bound) {
+        // ... a dense precision with d <= 128, no bounds: the MFMA kernel with per-chain tables (round 4; the literal kernel served it before)
+        const bool dense_mfma = target->kind == MI_TARGET_GAUSS_DENSE && d <= 128 && !settings->vals_bound;
+        if ((!sep && !dense_mfma) || settings->vals_bound) {
             if (target->kind == MI_TARGET_NORMAL_MODEL) return fail(MI_ERR_UNSUPPORTED, "hmc: chains.mass_diag with the normal-model target is not implemented");
             return run_literal("hmc", 0, target, settings, chains, st);
         }
@@ -1305,8 +1307,10 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     rc = ws_get(st, rp.total_bytes, wsave);
     if (rc) return rc;
     prm.wsave = wsave.as<double>();
-    // a diagonal precond_mat alone (no bounds): the plain kernel's shape with two mass tables (hmc_dense.hpp, DIAGM), replay as the plain kernel
-    const bool diag_only = settings->precond_mat != nullptr && !dense_m && !settings->vals_bound;
+    // a diagonal precond_mat alone (no bounds): the plain kernel's shape with two mass tables (hmc_dense.hpp, DIAGM), replay as the plain kernel;
+    // per-chain diagonal masses (mi_chains.mass_diag) ride the same variant with [d][C] tables in global memory (PCM)
+    const bool chain_mass = sc.dev.mass_diag != nullptr;
+    const bool diag_only = (settings->precond_mat != nullptr && !dense_m && !settings->vals_bound) || chain_mass;
     const bool general = bounded && !diag_only;
     if (!general) {                                     // the general variants reproduce the dense products themselves
         rc = replay_bind(rp, wsave.p, chains->n_chains, st);
@@ -1389,7 +1393,12 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
             }
         }
         DevBuf ms_dev, mi_dev;
-        if (diag_only) {
+        ChainMass cm;
+        if (chain_mass) {
+            if ((rc = chain_mass_tables(sc.dev.mass_diag, d, chains->n_chains, cm, st))) return rc;
+            prm.m_sqrt = cm.ms.as<double>(); prm.m_inv = cm.mi.as<double>(); prm.m_per_chain = 1;
+            rc = launched("hmc", mi::launch_hmc_gauss_diagm(prm, nt, st));
+        } else if (diag_only) {
             HIP_TRY(ms_dev.alloc(d * 8)); HIP_TRY(mi_dev.alloc(d * 8));
             HIP_TRY(hipMemcpy(ms_dev.p, m_sqrt.data(), d * 8, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(mi_dev.p, m_inv.data(), d * 8, hipMemcpyHostToDevice));
@@ -1403,7 +1412,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         rc = lit_gauss_target(lp.t, target->kind, (uint32_t)d, P_dev, nullptr, rp.tbuf, st);
         if (rc) return rc;
         lit_common(lp, settings, &sc.dev, rp, false);
-        if (diag_only) { lp.precond = 1; lp.m_sqrt = ms_dev.as<double>(); lp.m_inv = mi_dev.as<double>(); }
+        if (chain_mass) lit_set_chain_mass(lp, sc.dev.mass_diag, cm, chains->n_chains);
+        else if (diag_only) { lp.precond = 1; lp.m_sqrt = ms_dev.as<double>(); lp.m_inv = mi_dev.as<double>(); }
         rc = launched("hmc (literal replay)", mi::launch_literal(0, lp, rp.n_wg, st));
         if (!rc && diag_only) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
