@@ -265,8 +265,40 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
                 const double eta = ((part[(0 * 4 + q) * 64 + lane] + part[(1 * 4 + q) * 64 + lane]) + part[(2 * 4 + q) * 64 + lane])
                                    + part[(3 * 4 + q) * 64 + lane];
                 // softplus / sigmoid share e = exp(-|eta|) (the oracle evaluates it once per function; same bits)
+#ifdef MI_LOGIT_ESTRIN      // EXPERIMENT (timing only: not the oracle's arithmetic): exp / log1p of the row term with Estrin-form polynomials
+                double e, l1p;
+                {
+                    const double x = eta > 0.0 ? -eta : eta;
+                    const double kf = __builtin_rint(x * INV_LN2);
+                    const int k = (int)kf;
+                    double r = dfma(-kf, LN2_HI, x);
+                    r = dfma(-kf, LN2_LO, r);
+                    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+                    const double a0 = dfma(r, 1.0, 1.0), a1 = dfma(r, MI_KC(1.0 / 6.0), 0.5), a2 = dfma(r, MI_KC(1.0 / 120.0), MI_KC(1.0 / 24.0)), a3 = dfma(r, MI_KC(1.0 / 5040.0), MI_KC(1.0 / 720.0));
+                    const double a4 = dfma(r, MI_KC(1.0 / 362880.0), MI_KC(1.0 / 40320.0)), a5 = dfma(r, MI_KC(1.0 / 39916800.0), MI_KC(1.0 / 3628800.0)), a6 = dfma(r, MI_KC(1.0 / 6227020800.0), MI_KC(1.0 / 479001600.0));
+                    const double b0 = dfma(r2, a1, a0), b1 = dfma(r2, a3, a2), b2 = dfma(r2, a5, a4), b3 = dfma(r2, MI_KC(1.0 / 87178291200.0), a6);
+                    const double d0 = dfma(r4, b1, b0), d1 = dfma(r4, b3, b2);
+                    const double pe = dfma(r8, d1, d0);
+                    const int k1 = k / 2, k2 = k - k1;
+                    e = (x < -745.2) ? 0.0 : (pe * pow2i(k1)) * pow2i(k2);
+                    double m = 1.0 + e;
+                    const bool big = m > 0x1.6a09e667f3bcdp+0;
+                    m = big ? m * 0.5 : m;
+                    const double ef = big ? 1.0 : 0.0;
+                    const double f = m - 1.0;
+                    const double sq = f / (2.0 + f);
+                    const double z = sq * sq, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+                    const double c0 = dfma(z, MI_KC(1.0 / 3.0), 1.0), c1 = dfma(z, MI_KC(1.0 / 7.0), MI_KC(1.0 / 5.0)), c2 = dfma(z, MI_KC(1.0 / 11.0), MI_KC(1.0 / 9.0)), c3 = dfma(z, MI_KC(1.0 / 15.0), MI_KC(1.0 / 13.0));
+                    const double c4 = dfma(z, MI_KC(1.0 / 19.0), MI_KC(1.0 / 17.0)), c5 = dfma(z, MI_KC(1.0 / 23.0), MI_KC(1.0 / 21.0));
+                    const double g0 = dfma(z2, c1, c0), g1 = dfma(z2, c3, c2), g2 = dfma(z2, c5, c4);
+                    const double h0 = dfma(z4, g1, g0);
+                    const double pl = dfma(z8, g2, h0);
+                    l1p = dfma(ef, LN2_HI, dfma(ef, LN2_LO, (2.0 * sq) * pl));
+                }
+#else
                 const double e = (ablate & 1u) ? eta * 0.25 : det_exp(eta > 0.0 ? -eta : eta);
                 const double l1p = (ablate & 1u) ? e * 0.5 : det_log(1.0 + e);
+#endif
                 const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
                 const double sg = (eta >= 0.0) ? (1.0 / (1.0 + e)) : (e / (1.0 + e));
                 rt[(q * 2 + 0) * 64 + lane] = valid ? (yv - sg) : 0.0;
