@@ -73,3 +73,22 @@ def test_bad_arguments_are_rejected_without_a_gpu():
         with pytest.raises(mcmc_amd.MiMcmcError) as e:   # no CPU fallback: fails loudly
             mcmc_amd.run("hmc", t, s, c)
         assert e.value.code == mcmc_amd.MI_ERR_NO_DEVICE
+
+
+def test_public_headers_stand_alone():
+    """include/ is all a user-target build needs (the public target headers reached into mcmc_amd/csrc): the example target
+    libraries and the C++ front-end parse and instantiate with a COPY of include/ alone on the include path."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+        for ex in ("user_target.hip", "user_tile_target.hip"):
+            shutil.copy(os.path.join(ROOT, "examples", ex), tmp)
+            subprocess.check_call([hipcc, "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-fsyntax-only", "-Wall", "-Wno-unused-function",
+                                   "-Iinclude", ex], cwd=tmp)
+        shutil.copy(os.path.join(ROOT, "examples", "hmc_plumbing.cpp"), tmp)
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Iinclude", "hmc_plumbing.cpp"], cwd=tmp)
