@@ -83,8 +83,11 @@ typedef enum mi_kernel_hint {
                                             * default one with register-carried leaf state */
     MI_KERNEL_NUTS_REG = 10,               /* nuts, same case: register-carried leaf state, one wave per 16-chain tile and per SIMD (the default
                                             * for d <= 64) */
-    MI_KERNEL_NUTS_SPLIT = 11              /* nuts, same case, 64 < d <= 128: every tile split over two waves, two tiles per SIMD, so that one
+    MI_KERNEL_NUTS_SPLIT = 11,             /* nuts, same case, 64 < d <= 128: every tile split over two waves, two tiles per SIMD, so that one
                                             * tile's record traffic runs under the other's mat-vec (the default there) */
+    MI_KERNEL_LITERAL = 12                 /* nuts on the logistic target (d <= 512) and on dense Gaussians with 128 < d <= 512: the literal kernel
+                                            * (one workgroup per chain) instead of the tiled kernel on the LDS-streamed evaluation -- same bits,
+                                            * for A/B timing */
 } mi_kernel_hint;
 
 typedef struct mi_target {

@@ -28,15 +28,24 @@ struct LogitParams {
     const double* m;        // mala with a diagonal precond_mat: its diagonal and the diagonal of INV(eps^2 M) (padded likewise); m_sqrt as above
     const double* s_inv;
     double* xexch;          // dense Gaussian target only: [chain tile][4 NSQ][64] the position of an evaluation, shared by the tile's four waves
+    // nuts (nuts_lds.hpp): workspace vectors / per-chain scalars of every wave (set by the launcher), outputs and the dual-averaging settings
+    double* nuts_ws;
+    double* nuts_sc;
+    uint64_t* n_leap_out;   // [C] leapfrog steps of every chain, or nullptr
+    double* step_out;       // [C] step sizes: out (and in, for a continuation: draw0 > 0), or nullptr
+    uint32_t* depth_trace;  // [n_total][C] tree depth of every draw, or nullptr
+    double* adapt_state;    // [3][C] dual-averaging state (h, eps_bar, mu): out (and in, for a continuation inside the window), or nullptr
+    uint32_t n_adapt, max_depth;
+    double delta, eps_bar0, gamma, t0, kappa;
 };
 
-enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2 };   // RWMH: eps carries par_scale (identity cov_mat)
+enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2, LOGIT_NUTS = 3 };   // RWMH: eps carries par_scale (identity cov_mat); NUTS: nuts_lds.hpp
 // The target the streamed matrix belongs to.  DENSE: the Gaussian log K = -1/2 x'Px with 128 < d <= 512 -- "X" is P (n_rows = d,
 // X_dev = P row-major, y_dev = nullptr), the block images hold P transposed and the evaluation is the X^T r phase alone with r = x.
 enum { LOGIT_TARGET_LOGISTIC = 0, LOGIT_TARGET_DENSE = 1 };
 
 // bytes of device workspace a launch needs (block images of X, accepted state of every chain)
-size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC);
+size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC, int algo = LOGIT_HMC);
 // packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)
 int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st,
                      int target = LOGIT_TARGET_LOGISTIC);

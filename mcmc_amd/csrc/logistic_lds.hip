@@ -8,11 +8,9 @@ namespace mi {
 namespace {
 
 template <int NTQ>
-size_t ws_doubles(uint32_t NB, uint64_t C, int target)
+size_t ws_doubles(uint32_t NB, uint64_t C, int target, int algo)
 {
-    using G = LogitGeo<NTQ>;
-    const size_t n_wg = (C + 31) / 32;
-    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0);
+    return logit_lds_ws_doubles<NTQ>(NB, C, target, algo);
 }
 
 template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
@@ -53,18 +51,19 @@ int launch_any(LogitParams& prm, const double* X_dev, const double* y_dev, void*
 
 }  // namespace
 
-size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target)
+size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target, int algo)
 {
     const size_t n = (target == LOGIT_TARGET_DENSE)
-                         ? ((d <= 192) ? ws_doubles<3>(NB, C, target) : (d <= 256) ? ws_doubles<4>(NB, C, target)
-                            : (d <= 384) ? ws_doubles<6>(NB, C, target) : ws_doubles<8>(NB, C, target))
-                   : (d <= 64) ? ws_doubles<1>(NB, C, target) : (d <= 128) ? ws_doubles<2>(NB, C, target)
-                   : (d <= 256) ? ws_doubles<4>(NB, C, target) : ws_doubles<8>(NB, C, target);
+                         ? ((d <= 192) ? ws_doubles<3>(NB, C, target, algo) : (d <= 256) ? ws_doubles<4>(NB, C, target, algo)
+                            : (d <= 384) ? ws_doubles<6>(NB, C, target, algo) : ws_doubles<8>(NB, C, target, algo))
+                   : (d <= 64) ? ws_doubles<1>(NB, C, target, algo) : (d <= 128) ? ws_doubles<2>(NB, C, target, algo)
+                   : (d <= 256) ? ws_doubles<4>(NB, C, target, algo) : ws_doubles<8>(NB, C, target, algo);
     return n * sizeof(double);
 }
 
 int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)
 {
+    if (algo == LOGIT_NUTS) return logit_lds_launch_nuts(prm, X_dev, y_dev, workspace, st, target);     // logistic_nuts.hip
     return algo == LOGIT_HMC  ? launch_any<LOGIT_HMC>(prm, X_dev, y_dev, workspace, st, target)
          : algo == LOGIT_RWMH ? launch_any<LOGIT_RWMH>(prm, X_dev, y_dev, workspace, st, target)
                               : launch_any<LOGIT_MALA>(prm, X_dev, y_dev, workspace, st, target);

@@ -24,6 +24,7 @@
 
 #include "hmc_dense.hpp"
 #include "logistic_launch.hpp"
+#include "nuts_lds.hpp"
 
 #ifndef MI_LOGIT_ABLATE
 #define MI_LOGIT_ABLATE 0
@@ -49,6 +50,19 @@ struct LogitGeo {
     static constexpr size_t LDS_BYTES = (size_t)(2 * XBUF_PAD + EXCH) * sizeof(double);
     __host__ __device__ static constexpr int xaddr(int row, int dim) { return (row >> 1) * RSP + (row & 1) * (DP + 16) + dim; }
 };
+
+// doubles of device workspace of a launch: block images | accepted (beta, grad) of every chain | dense: the exchanged positions |
+// nuts: workspace vectors and per-chain scalars of every wave (nuts_lds.hpp)
+template <int NTQ>
+inline size_t logit_lds_ws_doubles(uint32_t NB, uint64_t C, int target, int algo)
+{
+    using G = LogitGeo<NTQ>;
+    const size_t n_wg = (C + 31) / 32;
+    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0)
+           + (algo == LOGIT_NUTS ? n_wg * 8 * (lds_nuts::vec_doubles_per_wave(G::NSQ) + lds_nuts::sc_doubles_per_wave()) : 0);
+}
+// (logistic_nuts.hip: the nuts instantiations are a translation unit of their own)
+int logit_lds_launch_nuts(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target);
 
 // pack X (row-major n_rows x d) into per-block LDS images; zero padding outside.  TRANSPOSED (dense Gaussian, X = P, n_rows = d):
 // image row r holds column r of P, so that the X^T r phase with r = x yields P x; no labels.
@@ -196,13 +210,19 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     auto lap = [&](uint64_t& tp, int i) __attribute__((always_inline)) {
         if constexpr ((ablate & 2048u) != 0) { const uint64_t t = clock64(); prof[i] += t - tp; tp = t; }
     };
-    uint32_t xbuf0 = 0;                 // buffer that holds block 0 when an evaluation starts
+    uint32_t xbuf_next = 0;             // buffer that holds block 0 when an evaluation starts
+    // (nuts: the parity is loop-carried through loops that end on workgroup votes read from LDS, which the compiler takes for divergent;
+    //  the DMA destination must be an SGPR)
+    auto xbuf_parity = [&]() __attribute__((always_inline)) -> uint32_t {
+        if constexpr (ALGO == LOGIT_NUTS) return (uint32_t)__builtin_amdgcn_readfirstlane((int)xbuf_next); else return xbuf_next;
+    };
     auto evaluate_logit = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
         double4_t gacc[NTQ];
         double llq = 0.0;
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         uint64_t te = stamp();
+        const uint32_t xbuf0 = xbuf_parity();
         __syncthreads();                                 // nobody still reads the exchange area
         lap(te, 8);
         // Block 0 is already resident in buffer xbuf0: the last iteration of the previous evaluation fetched it (the
@@ -333,7 +353,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2
             lap(tp, 6);
         }
-        xbuf0 = (xbuf0 + NB) & 1u;
+        xbuf_next = (xbuf0 + NB) & 1u;
         te = stamp();
         llq = llq + __shfl_xor(llq, 32);
         llq = llq + __shfl_xor(llq, 16);
@@ -369,6 +389,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         double4_t gacc[NTQ];
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+        const uint32_t xbuf0 = xbuf_parity();
         // wave-uniform base (SGPR pair, known to be global memory) + the lane's byte offset, opaque so that the NSQ addresses are not
         // hoisted: a laundered POINTER would lose its address space and turn these into flat loads, behind which every LDS wait of
         // the block loop becomes lgkmcnt(0) + vmcnt(0) -- i.e. a wait for the block's own DMA pieces
@@ -440,7 +461,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             for (int sp = 0; sp < 4; ++sp) r_cur[sp] = r_nxt[sp];
             blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2
         }
-        xbuf0 = (xbuf0 + NB) & 1u;
+        xbuf_next = (xbuf0 + NB) & 1u;
         double v[2];
         {
             double a = 0.0;
@@ -667,6 +688,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             }
             keep_draw(draw, accept);
         }
+    } else if constexpr (ALGO == LOGIT_NUTS) {
+        // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp)
+        static_assert(!DIAGM, "nuts on the LDS-streamed evaluation: identity precond_mat");
+        nuts_lds_body<NTQ>(prm, evaluate, part_all, bp, gp, first_lp);
+        return;
     } else {
         // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step
         // k+1 are at the same position -- and the value of the last one is prop_U.

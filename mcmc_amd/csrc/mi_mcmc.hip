@@ -1851,6 +1851,98 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     return MI_OK;
 }
 
+// nuts on the LDS-streamed evaluation (nuts_lds.hpp): the logistic target with 8 < d <= 512 and dense Gaussians with 128 < d <= 512,
+// identity precond_mat, no bounds, 1 <= max_tree_depth <= 10.  Chains that reach the non-finite regime are flagged by the kernel and
+// replayed by literal_kernel<2> right behind it.  lds_target: mi::LOGIT_TARGET_LOGISTIC / mi::LOGIT_TARGET_DENSE.
+int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st, int lds_target)
+{
+    int rc;
+    const uint64_t d = target->d, C = chains->n_chains;
+    const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
+    if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    const bool dense = lds_target == mi::LOGIT_TARGET_DENSE;
+    DevBuf Xo, yo, P_owned;
+    const double *X_dev = nullptr, *y_dev = nullptr;
+    uint64_t n_rows = d;
+    if (dense) {
+        if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
+        rc = dense_precision_on_device(target, P_owned, &X_dev, st);
+        if (rc) return rc;
+    } else {
+        if (!target->X || !target->y || target->n_rows == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+        n_rows = target->n_rows;
+        X_dev = target->X; y_dev = target->y;
+        if (target->mem == MI_MEM_HOST) {
+            HIP_TRY(Xo.alloc(n_rows * d * sizeof(double))); HIP_TRY(yo.alloc(n_rows * sizeof(double)));
+            HIP_TRY(hipMemcpy(Xo.p, target->X, n_rows * d * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(yo.p, target->y, n_rows * sizeof(double), hipMemcpyHostToDevice));
+            X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+        }
+    }
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+    mi::LogitParams q{};
+    q.d = (uint32_t)d; q.n_rows = (uint32_t)n_rows; q.NB = (uint32_t)((n_rows + 15) / 16);
+    q.C = C; q.chain0 = chains->chain0;
+    q.theta = sc.dev.theta; q.draws = sc.dev.draws; q.n_accept = sc.dev.n_accept;
+    q.seed = settings->rng_seed_value;
+    q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
+    q.draw0 = (uint32_t)chains->draw0;
+    q.n_leap_out = sc.dev.n_leapfrogs; q.step_out = sc.dev.step_size; q.depth_trace = sc.dev.nuts_depth;
+    if ((rc = nuts_continuation(settings, chains, &q.n_adapt))) return rc;
+    q.adapt_state = sc.dev.nuts_adapt_state;
+    q.max_depth = (uint32_t)settings->max_tree_depth;
+    q.delta = settings->target_accept_rate; q.eps_bar0 = settings->step_size;
+    q.gamma = settings->gamma_val; q.t0 = settings->t0_val; q.kappa = settings->kappa_val;
+
+    // workspace: the kernel's own | non-finite flags | the matrix transposed and the work areas of the literal replay
+    ReplayWs rp;
+    rp.t_doubles = ((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31;
+    rp.own_bytes = (mi::logit_lds_workspace_bytes(q.d, q.NB, C, lds_target, mi::LOGIT_NUTS) + 255) & ~(size_t)255;
+    rp.stride = mi::lit::lit_work_doubles((uint32_t)d, dense ? 0u : (uint32_t)n_rows, false, q.max_depth, true, false);
+    rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
+    const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    rp.total_bytes = rp.own_bytes + flag_bytes + (rp.t_doubles + (size_t)rp.n_wg * rp.stride) * sizeof(double);
+    WsLease base;
+    rc = ws_get(st, rp.total_bytes, base);
+    if (rc) return rc;
+    rc = replay_bind(rp, base.p, C, st);
+    if (rc) return rc;
+    q.nf_flag = rp.flag;
+    const int e = mi::logit_lds_launch(mi::LOGIT_NUTS, q, X_dev, y_dev, base.p, st, lds_target);
+    if (e != 0) return fail(MI_ERR_HIP, "LDS-streamed nuts kernel launch: %s", hipGetErrorString((hipError_t)e));
+    const std::string lds_name = mi::host::last_kernel();
+    {
+        mi::lit::LitParams lp{};
+        rc = transpose_on_device(X_dev, rp.tbuf, (uint32_t)n_rows, (uint32_t)d, st);
+        if (rc) return rc;
+        if (dense) { lp.t.kind = mi::lit::LIT_DENSE; lp.t.d = (uint32_t)d; lp.t.prec = rp.tbuf; }
+        else {
+            lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = (uint32_t)d; lp.t.n_rows = (uint32_t)n_rows; lp.t.X = X_dev; lp.t.y = y_dev;
+            lp.t.Xt = rp.tbuf;
+        }
+        mi::lit::lit_orders(lp.t);
+        lit_common(lp, settings, &sc.dev, rp, false);
+        lp.n_adapt = q.n_adapt; lp.max_depth = q.max_depth;
+        lp.delta = q.delta; lp.gamma = q.gamma; lp.t0 = q.t0; lp.kappa = q.kappa;
+        lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth; lp.adapt_state = sc.dev.nuts_adapt_state;
+        rc = launched("LDS-streamed nuts kernel (literal replay)", mi::launch_literal(2, lp, rp.n_wg, st));
+        if (rc) return rc;
+        mi::host::last_kernel() = lds_name;
+    }
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
+    if (rc) return rc;
+    if (Xo.p || P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+// the cases nuts_lds.hpp covers (everything else on these targets: literal.hpp)
+bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
+{
+    return target->kernel_hint != MI_KERNEL_LITERAL && !settings->vals_bound && !settings->precond_mat
+           && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
+}
+
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
     int rc = check_common(target, settings, chains);
@@ -1858,12 +1950,16 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("nuts", 2, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC)
-        return (d <= (uint64_t)mi::SMALL_MAX_D && settings->max_tree_depth <= 10) ? run_small_logistic("nuts", 2, target, settings, chains, st)
-                                                                                   : run_literal("nuts", 2, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC) {
+        if (d <= (uint64_t)mi::SMALL_MAX_D && settings->max_tree_depth <= 10) return run_small_logistic("nuts", 2, target, settings, chains, st);
+        if (d <= 512 && lds_nuts_case(target, settings)) return run_lds_nuts(target, settings, chains, st, mi::LOGIT_TARGET_LOGISTIC);
+        return run_literal("nuts", 2, target, settings, chains, st);
+    }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "nuts: target kind %d not implemented", target->kind);
     // the tiled kernels: d <= 128, max_tree_depth <= 10 (per-level records and scalars are sized for that); beyond, literal.hpp
+    if (target->kind == MI_TARGET_GAUSS_DENSE && d > 128 && d <= 512 && lds_nuts_case(target, settings))
+        return run_lds_nuts(target, settings, chains, st, mi::LOGIT_TARGET_DENSE);     // P streamed through LDS (nuts_lds.hpp)
     if (d > 128 || settings->max_tree_depth > (uint64_t)mi::NUTS_MAX_DEPTH) return run_literal("nuts", 2, target, settings, chains, st);
     const uint64_t n_total = settings->n_burnin_draws + settings->n_keep_draws;
     if (n_total > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");

@@ -1,0 +1,555 @@
+// nuts_lds.hpp -- mcmc::nuts on the LDS-streamed evaluation (logistic_lds.hpp): the logistic-regression target with d <= 512 and the
+// dense Gaussian with 128 < d <= 512, where one evaluation of the target is a pass of the whole design / precision matrix through
+// LDS, shared by the 2 chain tiles x 4 dimension quarters of a workgroup.
+//
+// Replaces, for C independent chains, mcmc::internal::nuts_impl with nuts_find_initial_step_size and the recursive nuts_build_tree
+// (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity precond_mat, no bounds.
+//
+// The sampler is the asynchronous per-chain tree state machine of nuts_reg.hpp / include/mi_mcmc_engine/nuts_tile.hpp (iterative
+// leaf-indexed tree: nuts_dense.hpp; eager U-turn tests, momenta generated ahead, draw boundaries without waiting), with two changes
+// that the evaluation forces:
+//   * a chain's vectors are split over the FOUR waves of its tile (wave q: dims [q DQ, (q+1) DQ)), every per-chain scalar is replicated
+//     in the four waves, and every dot product over dimensions is ((S0 + S1) + S2) + S3 of the waves' 4-strided partial dots through
+//     LDS -- the order the hmc / mala kernels of logistic_lds.hpp and the oracle's blocked reductions use (orc_dot_b);
+//   * the evaluation is a WORKGROUP collective (its block stream is shared by both tiles), so a tick -- one leapfrog for every running
+//     chain -- is taken by the 32 chains of a workgroup together and every decision that guards a collective is a workgroup vote.
+//     Chains stay asynchronous inside that: each is at its own leaf of its own tree of its own draw, so no lane waits for a longer tree.
+// Registers hold (theta, p, grad) of the chain's last leaf; the momentum crosses the evaluation through the workspace when the tile is
+// wide (NTQ >= 6: the evaluation's accumulators take its registers).  Records, pending proposals and the per-level scalars live in
+// global memory (LDS is full of matrix): vectors chain-major inside a wave's block so that a chain's row is contiguous whatever
+// record each chain of the wave addresses.
+//
+// Non-finite regime: detected through the energies of every leaf; the chain is flagged and replayed by
+// literal_kernel<2> (the reference's dense products as written), like the hmc / mala kernels of logistic_lds.hpp do.
+#pragma once
+
+#include "logistic_launch.hpp"
+
+namespace mi {
+
+namespace lds_nuts {
+// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp / nuts_reg.hpp / nuts_tile.hpp)
+enum : int {
+    V_PREV = 0, V_WPREV = 1, V_MNTM = 2, V_TPOS_T = 3, V_TPOS_P = 4, V_TNEG_T = 5, V_TNEG_P = 6,
+    V_LEAF0 = 7,             // slot k: theta 7+3k, p 8+3k, grad 9+3k, k = 0..10 (even leaves only: slot 1 is free, see below)
+    V_PP0 = 40,              // pending proposal of level l >= 1 at 40 + l, its gradient at 52 + l
+    V_PPW0 = 52,
+    V_TMPP = 40,             // the momentum across an evaluation (wide tiles)
+    NVEC = 64,
+    MAX_DEPTH = 10,
+    LVLS = 12,
+    SC_PER_CHAIN = 64        // doubles of per-chain scalars: [level][4] + the dual-averaging state at 48..50
+};
+enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
+enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
+// doubles of workspace per workgroup (8 waves): vectors, then scalars
+__host__ __device__ constexpr size_t vec_doubles_per_wave(int NSQ) { return (size_t)NVEC * NSQ * 64; }
+__host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 * SC_PER_CHAIN; }
+}  // namespace lds_nuts
+
+template <int NTQ, class Eval>
+__device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all,
+                                              double (&th)[4 * NTQ], double (&w)[4 * NTQ], const double first_lp)
+{
+    using namespace lds_nuts;
+    constexpr int NS = 4 * NTQ, DQ = 16 * NTQ;
+    constexpr bool PM_MEM = NTQ >= 6;                    // the momentum leaves the registers for the evaluation
+    constexpr int CH = (NS % 8 == 0) ? 8 : 4;            // slices per chunk of a row that passes through temporaries
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = wv >> 2, q = wv & 3;
+    const int j4 = lane >> 4;
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
+    const bool live = cl < C;
+    const uint64_t cld = live ? cl : C - 1;
+    const uint64_t chain = prm.chain0 + cl;
+    double* const part = part_all + g * (4 * 4 * 64);
+
+    // ---- workgroup collectives.  ((S0 + S1) + S2) + S3 of per-wave partial sums (each already butterflied inside the wave), K <= 3 values
+    // at a time, and the OR of a flag word over the workgroup's waves (the four waves of a tile hold the same flags: wave 0 of each tile
+    // speaks).  Every wave of the workgroup calls these in the same order.
+    auto exchange = [&](auto& v, uint32_t flags) __attribute__((always_inline)) -> uint32_t {
+        constexpr int K = (int)(sizeof(v) / sizeof(double));
+        static_assert(K <= 3, "slot 3 of the exchange area carries the flags");
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) part[(k * 4 + q) * 64 + lane] = v[k];
+        if (q == 0 && lane == 0) part[(3 * 4) * 64] = (double)flags;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            v[k] = ((part[(k * 4 + 0) * 64 + lane] + part[(k * 4 + 1) * 64 + lane]) + part[(k * 4 + 2) * 64 + lane])
+                   + part[(k * 4 + 3) * 64 + lane];
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)part_all[(3 * 4) * 64] | (uint32_t)part_all[(4 * 4 * 64) + (3 * 4) * 64]));   // (uniform: the block stream's buffer parity is loop-carried behind these votes)
+    };
+    auto wg_or = [&](uint32_t flags) __attribute__((always_inline)) -> uint32_t {
+        __syncthreads();
+        if (q == 0 && lane == 0) part[(3 * 4) * 64] = (double)flags;
+        __syncthreads();
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)part_all[(3 * 4) * 64] | (uint32_t)part_all[(4 * 4 * 64) + (3 * 4) * 64]));   // (uniform: the block stream's buffer parity is loop-carried behind these votes)
+    };
+    auto any = [&](bool p) -> bool { return __ballot(p) != 0ull; };
+    auto fold = [&](double a) __attribute__((always_inline)) -> double {     // the 4-strided chains of a block: (q0 + q2) + (q1 + q3)
+        a = a + __shfl_xor(a, 32);
+        a = a + __shfl_xor(a, 16);
+        return a;
+    };
+
+    // ---- workspace.  Vectors: [wave][vector] blocks of NS * 512 bytes, inside a vector [chain][pair of slices][j4] in 16-byte granules
+    // (nuts_async.hpp: a chain's row is contiguous, so lanes that address different records still fetch whole lines); wave-uniform
+    // base + one 32-bit byte offset per access.
+    char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.nuts_ws, 256))
+                            + ((size_t)blockIdx.x * 8 + wv) * (vec_doubles_per_wave(NS) * sizeof(double));
+    uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)j4 * 16u;     // redefined (opaquely) at the top of every tick
+    auto wsp = [&](int v, int s) -> double* {            // s even: the pair (s, s + 1) of this lane
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)(s >> 1) * 64u));
+    };
+    auto ld_row = [&](int v, int s0, auto& dst) __attribute__((always_inline)) {      // dst[0..N) <- slices s0.. of vector v
+        constexpr int N = (int)(sizeof(dst) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(wsp(v, s0 + k));
+            dst[k] = t.x; dst[k + 1] = t.y;
+        }
+    };
+    auto st_row = [&](int v, int s0, const auto& src) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(src) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) *reinterpret_cast<double2*>(wsp(v, s0 + k)) = double2{src[k], src[k + 1]};
+    };
+    auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
+        *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
+    };
+    auto cp_row = [&](int src, int dst) __attribute__((always_inline)) {      // a whole row, CH slices at a time
+#pragma unroll
+        for (int c0 = 0; c0 < NS; c0 += CH) { double t[CH]; ld_row(src, c0, t); st_row(dst, c0, t); }
+    };
+    // per-chain scalars: chain-major, one private copy per wave (the four waves of a tile compute the same values)
+    double* const sc_chain = prm.nuts_sc + ((size_t)blockIdx.x * 8 + wv) * sc_doubles_per_wave() + (size_t)(lane & 15) * SC_PER_CHAIN;
+    auto lvl = [&](int l, int f) -> double& { return sc_chain[l * 4 + f]; };
+    auto h_val_ = [&]() -> double& { return sc_chain[48]; };
+    auto eps_bar_ = [&]() -> double& { return sc_chain[49]; };
+    auto mu_val_ = [&]() -> double& { return sc_chain[50]; };
+
+    auto dim_of = [&](int s) -> uint32_t {               // opaque on purpose (logistic_lds.hpp: why)
+        uint32_t j = (uint32_t)j4;
+        asm volatile("" : "+v"(j));
+        return (uint32_t)(q * DQ + 4 * s) + j;
+    };
+
+    double pm[NS];
+    double val = first_lp;
+    bool nf = false;                                     // the chain reached the non-finite regime: flagged, replayed by literal.hpp
+    // one evaluation at the register-resident position; the momentum survives it
+    auto eval = [&]() __attribute__((always_inline)) {
+        if constexpr (PM_MEM) st_row(V_TMPP, 0, pm);
+        evaluate(th, w, val);
+        if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
+    };
+    auto kick = [&](double e) __attribute__((always_inline)) {               // p += (e grad) / 2 (nuts.cpp:108-135)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
+    };
+    auto drift = [&](double e) __attribute__((always_inline)) {              // theta += e (Minv p), Minv = I (nuts.cpp:139-154)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
+    };
+    auto kinetic_partial = [&]() __attribute__((always_inline)) -> double {  // this wave's share of p . (I p)
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a = dfma(pm[s], pm[s], a);
+        return fold(a);
+    };
+
+    // ---------------------------------------------------------------- setup (nuts.cpp:156-195), all chains together
+    st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w);
+    double prev_U = -first_lp;                           // nuts.cpp:181 (no finiteness guard there)
+    if (!is_finite(prev_U)) nf = true;
+    uint64_t n_leap = 0;
+    double eps;
+    if (prm.draw0 == 0) {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, z_init), nuts.cpp:166-172
+#pragma unroll
+        for (int b = 0; b < NS / 2; ++b) {
+            double z0, z1;
+            rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_INIT, z0, z1);
+            pm[2 * b] = (dim_of(2 * b) < d) ? z0 : 0.0;
+            pm[2 * b + 1] = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        double U0 = prev_U;
+        if (!is_finite(U0)) U0 = INF;
+        double K0;
+        { double v1[1] = {kinetic_partial()}; (void)exchange(v1, 0u); K0 = v1[0] / 2.0; }
+        const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
+        eps = 1.0;
+        int a_val = 1;
+        bool cond = live;                                // (lanes beyond the last chain take no part in any vote)
+        bool first = true;
+#pragma unroll 1
+        for (;;) {
+            if (!first) {
+                const double e_new = eps * ((a_val == 1) ? 2.0 : 0.5);
+                if (cond) eps = e_new;
+            }
+            if (cond) n_leap++;
+            kick(eps); drift(eps); eval(); kick(eps);
+            double u = -val;
+            if (!is_finite(u)) { u = INF; if (cond) nf = true; }
+            double v1[1] = {kinetic_partial()};
+            (void)exchange(v1, 0u);
+            const double k_new = v1[0] / 2.0;
+            if (cond && !is_finite(k_new)) nf = true;
+            const double dH = -(u + k_new) + (U0 + K0);
+            if (first) { a_val = 2 * (dH > log_half ? 1 : 0) - 1; cond = cond && (dH > neg_log2); }
+            else if (cond) { a_val = 2 * (dH > log_half ? 1 : 0) - 1; cond = dH > neg_log2; }
+            first = false;
+            if (wg_or(any(cond) ? 1u : 0u) == 0u) break;
+        }
+    } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
+        eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
+    }
+    mu_val_() = det_log(10 * eps);                       // nuts.cpp:174
+    h_val_() = 0.0;
+    eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
+    if (prm.draw0 > 0 && prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+        h_val_() = prm.adapt_state[cld]; eps_bar_() = prm.adapt_state[C + cld]; mu_val_() = prm.adapt_state[2 * C + cld];
+    }
+    uint64_t n_acc = 0;
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const uint32_t n_adapt = prm.n_adapt;
+    const uint32_t max_depth = prm.max_depth;            // 1 .. MAX_DEPTH (the host routes everything else to literal.hpp)
+
+    // ---------------------------------------------------------------- per-chain state (nuts_tile.hpp: the same machine)
+    int state = (n_total > 0 && live) ? NS_NEED_DRAW : NS_DONE;
+    uint32_t draw = 0;           // this chain's draw index
+    uint32_t jd = 0;             // depth of the doubling in progress
+    uint32_t li = 0;             // next leaf of that doubling
+    uint32_t uslot = 0;
+    int vdir = 1;
+    double e_signed = 0.0, H0 = 0.0, log_u = 0.0;
+    auto prev_K_ = [&]() -> double& { return lvl(0, 0); };
+    auto n_val_ = [&]() -> double& { return lvl(0, 1); };
+    auto alpha_ = [&]() -> double& { return lvl(0, 2); };
+    auto n_alpha_ = [&]() -> double& { return lvl(0, 3); };
+    int good_round = 0;
+    uint32_t utpre = 0;          // bit l: the U-turn test of the open level-l node passed
+    int mv = V_MNTM, mvn = V_MNTM2;          // momentum vector of the running draw / of the next one
+    int pb = 0, pb0 = 0;                     // which of the two vectors holds prev_draw now / held it when the draw started
+    bool mom_ready = false;
+    double next_K = 0.0, next_lu = 0.0;
+    bool row_pend = false, row2_pend = false;
+    uint32_t row_draw = 0;
+    bool pos_init = true, neg_init = true;
+    auto pvec = [](int b) -> int { return b ? V_PREVB : V_PREV; };
+    auto wvec = [](int b) -> int { return b ? V_WPREVB : V_WPREV; };
+
+    auto begin_doubling = [&](bool p) __attribute__((always_inline)) {       // direction draw, nuts.cpp:233-235
+        const double zdir = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);
+        if (p) {
+            uslot++;
+            vdir = (zdir <= 0.5) ? -1 : 1;
+            e_signed = (double)vdir * eps;
+            H0 = prev_U + prev_K_();
+            li = 0;
+        }
+    };
+    auto end_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {   // dual averaging nuts.cpp:294-302
+        if (p && prm.depth_trace && q == 0 && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
+        if (any(p && draw + prm.draw0 < n_adapt)) {
+            if (p && draw + prm.draw0 < n_adapt) {
+                const double it = (double)(draw + prm.draw0 + 1);
+                const double h_new = h_val_() + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_() / n_alpha_()) - h_val_());
+                h_val_() = h_new;
+                eps = det_exp(mu_val_() - h_new * __builtin_sqrt(it) / prm.gamma);
+                const double eb = eps_bar_();
+                eps_bar_() = eb * det_exp(det_pow(it, -prm.kappa) * (det_log(eps) - det_log(eb)));
+            }
+        }
+        if (p && !(draw + prm.draw0 < n_adapt)) eps = eps_bar_();
+        const bool kept = p && draw >= prm.n_burnin;
+        if (kept) n_acc += (uint64_t)good_round;
+        if (p) {
+            row2_pend = kept && prm.draws != nullptr;
+            draw++;
+        }
+    };
+    auto store_row = [&](bool p, int vec, uint32_t idx) __attribute__((always_inline)) {   // kept row `idx` (nuts.cpp:306-309)
+        if (!any(p)) return;
+        if (p) {
+            double* out = prm.draws + (size_t)(idx - prm.n_burnin) * d * C + cl;
+#pragma unroll
+            for (int c0 = 0; c0 < NS; c0 += CH) {
+                double tmp[CH];
+                ld_row(vec, c0, tmp);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const uint32_t dim = dim_of(c0 + k);
+                    if (dim < d) out[(size_t)dim * C] = tmp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto roll_state = [&](bool p) __attribute__((always_inline)) {           // enter the next draw (nuts.cpp:200-219)
+        if (p) {
+            const int t_ = mv; mv = mvn; mvn = t_;
+            prev_K_() = next_K;
+            log_u = next_lu - prev_U - next_K;            // :206
+            mom_ready = false;
+            row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
+            pb0 = pb; pos_init = true; neg_init = true;
+            uslot = 1;
+            jd = 0; n_val_() = 1.0; alpha_() = 0.0; n_alpha_() = 0.0; good_round = 0;
+            state = NS_TREE;
+        }
+    };
+
+#pragma unroll 1
+    for (;;) {
+        asm volatile("" : "+v"(lane_b));
+        if (nf) state = NS_DONE;                         // a flagged chain is replayed from its initial state: nothing of it is kept
+        const uint32_t f0 = wg_or((any(state != NS_DONE) ? 1u : 0u) | (any(state == NS_NEED_DRAW) ? 2u : 0u));
+        if ((f0 & 1u) == 0u) break;
+        // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
+        if ((f0 & 2u) != 0u) {
+            store_row(row_pend, pvec(pb0), row_draw);
+            store_row(row2_pend, pvec(pb), draw - 1u);
+            row_pend = false; row2_pend = false;
+            if (state == NS_NEED_DRAW && draw >= n_total) state = NS_DONE;
+            const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
+            const bool gen = state != NS_DONE && !mom_ready && nidx < n_total;
+            double kq = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
+                double z0, z1;
+                rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_NORMAL, z0, z1);
+                const double pa = (dim_of(2 * b) < d) ? z0 : 0.0;
+                const double pb_ = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+                kq = dfma(pa, pa, kq);
+                kq = dfma(pb_, pb_, kq);
+                if (gen) st_pair(mvn, 2 * b, pa, pb_);
+            }
+            double v1[1] = {fold(kq)};
+            (void)exchange(v1, 0u);
+            const double lu = det_log(rng_uniform(prm.seed, chain, nidx + prm.draw0, 0u));
+            if (gen) { next_K = v1[0] / 2.0; next_lu = lu; mom_ready = true; }     // :204
+            const bool p = state == NS_NEED_DRAW;
+            roll_state(p);
+            begin_doubling(p);
+            if (wg_or(any(state == NS_TREE) ? 1u : 0u) == 0u) continue;
+        }
+        const bool run = state == NS_TREE;
+
+        // ------------------------------------------------------------ B. one leaf for every running chain
+        auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
+        const int slot_i = slot_of(li);
+        const int rec_t = V_LEAF0 + 3 * slot_i, rec_p = rec_t + 1, rec_w = rec_t + 2;    // this leaf's record (even leaves only)
+        const bool odd = (li & 1u) != 0u;
+        {   // start state: the registers hold the previous leaf (li odd, or ctz(li) == 1); otherwise a record
+            const int cz = (li == 0) ? 0 : __builtin_ctz(li);
+            const bool need = run && (li == 0 || cz >= 2);
+            if (any(need)) {
+                const int vt = (li == 0) ? pvec(pb) : V_LEAF0 + 3 * cz;                  // leaf li - 2^(cz-1) sits in slot cz
+                const int vp = (li == 0) ? mv : V_LEAF0 + 3 * cz + 1;
+                const int vw = (li == 0) ? wvec(pb) : V_LEAF0 + 3 * cz + 2;
+                if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
+            }
+        }
+        // U-turn tests, evaluated when their second operand appears (nuts_tile.hpp: EAGER).  Leaf li > 0 is the first leaf b2 of the second
+        // half of exactly one node, level l = ctz(li) + 1 (if l <= jd), whose first leaf is b = li - 2^ctz(li) -- an even leaf, so its
+        // (theta, p) are a record (an odd li: the leaf this leapfrog starts from).  Both rows are fetched AFTER the evaluation.
+        const uint32_t cz_i = (li == 0) ? 0u : (uint32_t)__builtin_ctz(li);
+        const bool tst = run && li != 0u && (cz_i + 1u <= jd);
+        const bool any_tst = any(tst);
+        const uint32_t bleaf = li - (1u << cz_i);
+        const int sb = (!tst || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
+        const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;
+        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = w
+        kick(e_signed);
+        drift(e_signed);
+        eval();
+        // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
+        double q1 = 0.0, q2 = 0.0, pk = 0.0;
+#pragma unroll
+        for (int c0 = 0; c0 < NS; c0 += CH) {
+            double tb[CH], pbv[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) { tb[k] = 0.0; pbv[k] = 0.0; }
+            if (any_tst) { if (tst) { ld_row(eb_t, c0, tb); ld_row(eb_p, c0, pbv); } }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int s = c0 + k;
+                pm[s] = pm[s] + (e_signed * w[s]) / 2.0;
+                const double dd = (vdir > 0) ? (th[s] - tb[k]) : (tb[k] - th[s]);
+                q1 = dfma(dd, pbv[k], q1);
+                q2 = dfma(dd, pm[s], q2);
+                pk = dfma(pm[s], pm[s], pk);
+            }
+        }
+        const bool last_leaf = run && (li == (1u << jd) - 1u);               // the doubling may complete in this tick
+        double v3[3] = {fold(q1), fold(q2), fold(pk)};
+        const bool wg_complete = exchange(v3, any(last_leaf) ? 1u : 0u) != 0u;
+        q1 = v3[0]; q2 = v3[1];
+        const double pK = v3[2] / 2.0;                   // nuts.ipp:140
+        double pU = -val;                                // nuts.ipp:134-138
+        if (!is_finite(pU)) { pU = INF; if (run) nf = true; }
+        if (run && !is_finite(pK)) nf = true;
+        const bool ut_now = (q1 >= 0.0) && (q2 >= 0.0);  // the test of level ctz(li) + 1
+        if (tst && !odd) utpre = (utpre & ~(1u << (cz_i + 1u))) | ((ut_now ? 1u : 0u) << (cz_i + 1u));
+        if (run && !odd) {                               // even leaves are the records later leaves and tests read
+            st_row(rec_t, 0, th); st_row(rec_p, 0, pm); st_row(rec_w, 0, w);
+        }
+        // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a successful doubling
+        // leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw, so it is written in place
+        const bool st_edge = run && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
+        if (any(st_edge)) {
+            if (st_edge) {
+                const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+                st_row(et, 0, th); st_row(ep, 0, pm);
+                if (vdir > 0) pos_init = false; else neg_init = false;
+            }
+        }
+        double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
+        const bool cs = log_u < 1000.0 - pU - pK;        // :147
+        const double dH = -(pU + pK) + H0;
+        double ca = det_exp((dH < 0.0) ? dH : 0.0);      // :157
+        double cna = 1.0;
+        double cU = pU;
+        bool cref_regs = true;                           // carried proposal: this leaf (registers) ...
+        int cref_t = rec_t, cref_w = rec_w;              // ... or a record (theta, grad)
+        if (run) n_leap++;
+        // ---- unwind (nuts.ipp:212-229), per-chain leaf index
+        bool failed = run && !cs;
+        bool walking = run;
+        uint32_t pend_level = jd + 1;
+#pragma unroll 1
+        for (uint32_t l = 1; l <= (uint32_t)MAX_DEPTH; ++l) {
+            if (walking && l > jd) walking = false;                      // reached the root of its own tree
+            const bool bit = ((li >> (l - 1)) & 1u) != 0u;
+            if (walking && !failed && !bit) { pend_level = l; walking = false; }   // first half: wait here
+            if (!any(walking)) break;
+            const bool mrg = walking && bit;
+            if (!any(mrg)) continue;
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :213
+            if (mrg) {
+                uslot++;
+                const double p_n = lvl((int)l, 0), p_a = lvl((int)l, 1), p_na = lvl((int)l, 2), p_U = lvl((int)l, 3);
+                const double prob = cn / (p_n + cn);                     // :212
+                if (!(z < prob)) {                                       // keep new_draw_p (:215-217)
+                    const int ps = slot_of(li - 1);                      // level 1: the previous (even) leaf's record
+                    cref_regs = false;
+                    cref_t = (l == 1) ? V_LEAF0 + 3 * ps : V_PP0 + (int)l;
+                    cref_w = (l == 1) ? V_LEAF0 + 3 * ps + 2 : V_PPW0 + (int)l;
+                    cU = p_U;
+                }
+                cn = p_n + cn;                                           // :220-222
+                ca = p_a + ca;
+                cna = p_na + cna;
+            }
+            const bool need_ut = mrg && !failed;
+            const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227
+            if (need_ut && !ok) failed = true;                                   // :229
+        }
+        // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279)
+        const bool keep = run && !failed;
+        const bool complete = keep && (li == (1u << jd) - 1u);
+        const bool fin = run && (failed || complete);
+        bool take = false;
+        if (any(complete)) {
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :261
+            if (complete) {
+                uslot++;
+                take = z < cn / n_val_();                                   // :263
+                if (take) { prev_U = cU; good_round = 1; pb = 1 - pb0; }  // :264-277; the proposal goes to pvec(pb) below
+            }
+        }
+        // ---- pending first half: proposal and its gradient by value, scalars to the level table
+        if (keep && !complete) {
+            lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
+            lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
+        }
+        {
+            // a pending first half at level 1 IS the (even) leaf's record just written (referenced, not copied); deeper levels
+            // and accepted proposals are written to their slot: from the registers when the carried proposal is this leaf,
+            // record -> slot otherwise
+            const bool do_store = keep && (complete ? take : (pend_level > 1u));
+            if (any(do_store)) {
+                const int pl = do_store ? (int)pend_level : 1;
+                const int dst_t = take ? pvec(1 - pb0) : V_PP0 + pl;
+                const int dst_w = take ? wvec(1 - pb0) : V_PPW0 + pl;
+                if (do_store && cref_regs) { st_row(dst_t, 0, th); st_row(dst_w, 0, w); }
+                const bool do_copy = do_store && !cref_regs;
+                if (any(do_copy)) { if (do_copy) { cp_row(cref_t, dst_t); cp_row(cref_w, dst_w); } }
+            }
+        }
+        // ---- the whole tree's U-turn test (:286-289): a dot product over dimensions, so every wave of the workgroup takes part
+        //      whenever some chain of the workgroup was at the last leaf of its doubling
+        bool s_ok = false;
+        if (wg_complete) {
+            double r1 = 0.0, r2 = 0.0;
+            if (any(complete)) {
+                const int en_t = neg_init ? pvec(pb0) : V_TNEG_T, en_p = neg_init ? mv : V_TNEG_P;
+                const int ep_t = pos_init ? pvec(pb0) : V_TPOS_T, ep_p = pos_init ? mv : V_TPOS_P;
+                if (complete) {
+#pragma unroll
+                    for (int c0 = 0; c0 < NS; c0 += CH) {
+                        double tn[CH], pn[CH], tp[CH], pp[CH];
+                        ld_row(en_t, c0, tn); ld_row(en_p, c0, pn); ld_row(ep_t, c0, tp); ld_row(ep_p, c0, pp);
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            const double dd_ = tp[k] - tn[k];
+                            r1 = dfma(dd_, pn[k], r1);
+                            r2 = dfma(dd_, pp[k], r2);
+                        }
+                    }
+                }
+            }
+            double v2[2] = {fold(r1), fold(r2)};
+            (void)exchange(v2, 0u);
+            s_ok = complete && (v2[0] >= 0.0) && (v2[1] >= 0.0);
+        }
+        if (any(fin)) {
+            if (fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
+            const bool more = fin && s_ok && (jd + 1 < max_depth);
+            if (fin) jd = jd + 1;                                        // :284
+            const bool ended = fin && !more;
+            bool roll = false;
+            if (any(ended)) {
+                end_draw(ended, jd);
+                roll = ended && draw < n_total && mom_ready && !row_pend;
+                if (ended && !roll) state = NS_NEED_DRAW;                // the phase: its row, its next momentum, or the end of its run
+                roll_state(roll);
+            }
+            begin_doubling(more || roll);
+        }
+        if (run && !fin) li = li + 1;
+    }
+
+    if (live && nf && prm.nf_flag != nullptr) { if (q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; } }
+    if (live && !(nf && prm.nf_flag != nullptr)) {
+        // rows still owed (the last draw's row is written by the phase that retires the chain: nothing is pending here)
+#pragma unroll
+        for (int c0 = 0; c0 < NS; c0 += CH) {
+            double tmp[CH];
+            ld_row(pvec(pb), c0, tmp);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const uint32_t dim = dim_of(c0 + k);
+                if (dim < d) prm.theta[(size_t)dim * C + cl] = tmp[k];
+            }
+        }
+        if (q == 0 && j4 == 0) {
+            if (prm.n_accept) prm.n_accept[cl] = n_acc;
+            if (prm.n_leap_out) prm.n_leap_out[cl] = n_leap;
+            if (prm.step_out) prm.step_out[cl] = eps;
+            if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
+        }
+    }
+}
+
+}  // namespace mi
