@@ -196,6 +196,45 @@ class Ctx:
     pass
 
 
+def extra_nuts_on_logistic(ctx):
+    """Not a BASELINE config: mcmc::nuts on configs[2]'s OWN target (d = 512 logistic regression, N = 1024), the combination round 3 could
+    only serve on the literal kernel.  One run of 8 192 chains x (4 burn-in + 4 kept) draws with dual averaging on the
+    tiled kernel of mcmc_amd/csrc/nuts_lds.hpp, timed with events on the launch stream; a leapfrog is one fused evaluation (4 N d flop)."""
+    import torch
+    import mcmc_amd
+    from mcmc_amd import synth
+    d, n_rows, C, burn, keep = 512, 1024, 8192, 4, 4
+    X, y = synth.logistic_problem(d, n_rows)
+    dev = ctx.dev
+    theta0 = torch.from_numpy(np.ascontiguousarray((synth.initial_states(C, d, seed=3) * 0.1).T)).to(dev)
+    theta = torch.empty_like(theta0)
+    draws = torch.empty((keep, d, C), dtype=torch.float64, device=dev)
+    n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
+    target = mcmc_amd.make_target(mcmc_amd.TARGET_LOGISTIC, d, mem=mcmc_amd.MEM_DEVICE, X=torch.from_numpy(X).to(dev), y=torch.from_numpy(y).to(dev))
+    settings = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn, max_tree_depth=10, step_size=0.03)
+    chains = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, step_size=torch.zeros(C, dtype=torch.float64, device=dev),
+                                  mem=mcmc_amd.MEM_DEVICE)
+    stream = torch.cuda.current_stream().cuda_stream
+    ms = None
+    for _ in range(2):                          # the first run loads the code object
+        theta.copy_(theta0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        mcmc_amd.run("nuts", target, settings, chains, stream=stream)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+    leaps = float(n_leap.double().sum().item())
+    tflops = leaps * 4.0 * n_rows * d / (ms * 1e-3) / 1e12
+    return {"workload": "mcmc::nuts on configs[2]'s target: d=512 Bayesian logistic regression (N=1024 synthetic rows), max_tree_depth=10, dual averaging, fp64",
+            "chains": C, "draws": burn + keep, "ms": ms, "kernel": mcmc_amd.last_kernel(), "leapfrogs": leaps,
+            "value": leaps * d / (ms * 1e-3), "unit": "chain*dim*leapfrog-steps/s",
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+                         "flop_per_unit": 4 * n_rows},
+            "note": "whole run incl. the step-size search and the literal replay launch; a workgroup of 32 chains lasts as long as its "
+                    "slowest chain (8 draws: the spread of the chains' leapfrog totals is large), see DESIGN.md section 4.14"}
+
+
 def measure(cfg_id, steps, warmup, args, ctx, headline):
     """Times `steps` steps of one BASELINE config on this rank's GPU (barrier + synchronize on both sides, max over ranks).
     Returns the result dict on rank 0 (None elsewhere)."""
@@ -443,6 +482,7 @@ def main():
     ap.add_argument("--chains", type=int, default=None, help="chains: total (strong) / per GPU (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-BASELINE) measurements of the default run")
     ap.add_argument("--traffic", choices=["headline", "all", "none"], default="headline",
                     help="measure roofline.traffic with two rocprofv3 --pmc child runs (one GPU only); else the committed profiles/")
     ap.add_argument("--collate", action="store_true",
@@ -490,6 +530,8 @@ def main():
                            **({k: o[k] for k in ("ess_per_sec", "ess_per_sec_incl_reducer", "ess_reducer_ms", "rhat_max", "ess_is_estimate",
                                                  "ess_caveat") if k in o})})
         out["other_configs"] = others
+        if not args.no_extra:
+            out["extra"] = {"nuts_on_configs2_target": extra_nuts_on_logistic(ctx)}
     if ctx.rank == 0:
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(head_id, cfg)

@@ -690,8 +690,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         }
     } else if constexpr (ALGO == LOGIT_NUTS) {
         // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp)
-        static_assert(!DIAGM, "nuts on the LDS-streamed evaluation: identity precond_mat");
-        nuts_lds_body<NTQ>(prm, evaluate, part_all, bp, gp, first_lp);
+        nuts_lds_body<NTQ, DIAGM>(prm, evaluate, part_all, bp, gp, first_lp);
         return;
     } else {
         // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step

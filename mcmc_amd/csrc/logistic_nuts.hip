@@ -8,9 +8,12 @@
 namespace mi {
 namespace {
 
-template <int NTQ, int TARGET>
+template <int NTQ, int TARGET, bool DIAGM = false>
 int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
+    if constexpr (!DIAGM) {                              // a diagonal precond_mat: the same launch with the DIAGM instantiation
+        if (prm.m_sqrt != nullptr) return launch_nuts<NTQ, TARGET, true>(prm, X_dev, y_dev, workspace, st);
+    }
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (prm.C + 31) / 32;
     double* xp = static_cast<double*>(workspace);
@@ -22,8 +25,8 @@ int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void
     prm.nuts_sc = nxt + n_wg * 8 * lds_nuts::vec_doubles_per_wave(G::NSQ);
     prm.Xp = xp;
     hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, TARGET == LOGIT_TARGET_DENSE>), dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
-    auto kern = logit_lds_kernel<NTQ, LOGIT_NUTS, TARGET, false>;
-    note_kernel("logit_lds_kernel<%d, nuts, %d>", NTQ, TARGET);
+    auto kern = logit_lds_kernel<NTQ, LOGIT_NUTS, TARGET, DIAGM>;
+    note_kernel("logit_lds_kernel<%d, nuts, %d, %s>", NTQ, TARGET, DIAGM ? "true" : "false");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);

@@ -1895,6 +1895,11 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     q.max_depth = (uint32_t)settings->max_tree_depth;
     q.delta = settings->target_accept_rate; q.eps_bar0 = settings->step_size;
     q.gamma = settings->gamma_val; q.t0 = settings->t0_val; q.kappa = settings->kappa_val;
+    DiagMass dm;
+    if (settings->precond_mat) {                         // (the caller routed a DIAGONAL matrix without bounds here)
+        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
+        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
+    }
 
     // workspace: the kernel's own | non-finite flags | the matrix transposed and the work areas of the literal replay
     ReplayWs rp;
@@ -1927,19 +1932,29 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
         lp.n_adapt = q.n_adapt; lp.max_depth = q.max_depth;
         lp.delta = q.delta; lp.gamma = q.gamma; lp.t0 = q.t0; lp.kappa = q.kappa;
         lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth; lp.adapt_state = sc.dev.nuts_adapt_state;
+        DevBuf m_dev;
+        if (q.m_sqrt != nullptr) {                       // the replay's tables: M, sqrt(M), 1 / M element by element (literal_host.hpp)
+            std::vector<double> m(d);
+            for (uint64_t i = 0; i < d; ++i) m[i] = settings->precond_mat[i * d + i];
+            HIP_TRY(m_dev.alloc(d * 8));
+            HIP_TRY(hipMemcpy(m_dev.p, m.data(), d * 8, hipMemcpyHostToDevice));
+            lp.precond = 1; lp.m = m_dev.as<double>(); lp.m_sqrt = q.m_sqrt; lp.m_inv = q.m_inv;
+        }
         rc = launched("LDS-streamed nuts kernel (literal replay)", mi::launch_literal(2, lp, rp.n_wg, st));
+        if (!rc && m_dev.p) HIP_TRY(hipStreamSynchronize(st));
         if (rc) return rc;
         mi::host::last_kernel() = lds_name;
     }
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (Xo.p || P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (Xo.p || P_owned.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 // the cases nuts_lds.hpp covers (everything else on these targets: literal.hpp)
 bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
 {
-    return target->kernel_hint != MI_KERNEL_LITERAL && !settings->vals_bound && !settings->precond_mat
+    return target->kernel_hint != MI_KERNEL_LITERAL && !settings->vals_bound
+           && (!settings->precond_mat || precond_is_diagonal(settings, target->d))
            && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
 }
 

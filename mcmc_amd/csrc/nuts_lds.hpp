@@ -3,7 +3,7 @@
 // LDS, shared by the 2 chain tiles x 4 dimension quarters of a workgroup.
 //
 // Replaces, for C independent chains, mcmc::internal::nuts_impl with nuts_find_initial_step_size and the recursive nuts_build_tree
-// (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity precond_mat, no bounds.
+// (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity or DIAGONAL precond_mat, no bounds.
 //
 // The sampler is the asynchronous per-chain tree state machine of nuts_reg.hpp / include/mi_mcmc_engine/nuts_tile.hpp (iterative
 // leaf-indexed tree: nuts_dense.hpp; eager U-turn tests, momenta generated ahead, draw boundaries without waiting), with two changes
@@ -24,6 +24,14 @@
 #pragma once
 
 #include "logistic_launch.hpp"
+
+// -DMI_NUTS_LDS_PROF: shader-clock totals per section of the tick (workgroup 0, every wave), printed by the kernel when it ends -- timing
+// experiments only (tools/build_variant.sh)
+#ifdef MI_NUTS_LDS_PROF
+#define MI_LPROF(i) do { const unsigned long long t_ = clock64(); prof_[i] += t_ - tp_; tp_ = t_; } while (0)
+#else
+#define MI_LPROF(i) do { } while (0)
+#endif
 
 namespace mi {
 
@@ -47,7 +55,9 @@ __host__ __device__ constexpr size_t vec_doubles_per_wave(int NSQ) { return (siz
 __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 * SC_PER_CHAIN; }
 }  // namespace lds_nuts
 
-template <int NTQ, class Eval>
+// DIAGM: a DIAGONAL precond_mat (nuts.cpp:57-59,168,202-204,139-154: p = sqrt(m) z, K = p.(p / m) / 2, theta += e (p / m); the U-turn dots
+// are plain), tables read from global memory where they are used (prm.m_sqrt, prm.m_inv: padded with ones to 64 NTQ entries).
+template <int NTQ, bool DIAGM, class Eval>
 __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all,
                                               double (&th)[4 * NTQ], double (&w)[4 * NTQ], const double first_lp)
 {
@@ -142,6 +152,13 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         return (uint32_t)(q * DQ + 4 * s) + j;
     };
 
+    // DIAGM: entry of slice s of a mass table for this lane (logistic_lds.hpp: mass_at)
+    [[maybe_unused]] auto mass_at = [&](const double* tab, int s) __attribute__((always_inline)) -> double {
+        uint32_t off = (uint32_t)j4 * 8u;
+        asm volatile("" : "+v"(off));
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab + (q * DQ + 4 * s)) + off);
+    };
+
     double pm[NS];
     double val = first_lp;
     bool nf = false;                                     // the chain reached the non-finite regime: flagged, replayed by literal.hpp
@@ -157,12 +174,18 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     };
     auto drift = [&](double e) __attribute__((always_inline)) {              // theta += e (Minv p), Minv = I (nuts.cpp:139-154)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) th[s] = th[s] + e * pm[s];
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (DIAGM) th[s] = th[s] + e * (mass_at(prm.m_inv, s) * pm[s]);
+            else th[s] = th[s] + e * pm[s];
+        }
     };
     auto kinetic_partial = [&]() __attribute__((always_inline)) -> double {  // this wave's share of p . (I p)
         double a = 0.0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) a = dfma(pm[s], pm[s], a);
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (DIAGM) a = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], a);
+            else a = dfma(pm[s], pm[s], a);
+        }
         return fold(a);
     };
 
@@ -179,6 +202,10 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_INIT, z0, z1);
             pm[2 * b] = (dim_of(2 * b) < d) ? z0 : 0.0;
             pm[2 * b + 1] = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+            if constexpr (DIAGM) {                       // mntm_vec = sqrt_precond_matrix * rand_vec (nuts.cpp:168)
+                pm[2 * b] = mass_at(prm.m_sqrt, 2 * b) * pm[2 * b];
+                pm[2 * b + 1] = mass_at(prm.m_sqrt, 2 * b + 1) * pm[2 * b + 1];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         double U0 = prev_U;
@@ -309,11 +336,15 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         }
     };
 
+#ifdef MI_NUTS_LDS_PROF
+    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), n_ticks_ = 0, n_phase_ = 0, n_top_ = 0;
+#endif
 #pragma unroll 1
     for (;;) {
         asm volatile("" : "+v"(lane_b));
         if (nf) state = NS_DONE;                         // a flagged chain is replayed from its initial state: nothing of it is kept
         const uint32_t f0 = wg_or((any(state != NS_DONE) ? 1u : 0u) | (any(state == NS_NEED_DRAW) ? 2u : 0u));
+        MI_LPROF(0);
         if ((f0 & 1u) == 0u) break;
         // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
         if ((f0 & 2u) != 0u) {
@@ -328,10 +359,16 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
                 rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_NORMAL, z0, z1);
-                const double pa = (dim_of(2 * b) < d) ? z0 : 0.0;
-                const double pb_ = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
-                kq = dfma(pa, pa, kq);
-                kq = dfma(pb_, pb_, kq);
+                double pa = (dim_of(2 * b) < d) ? z0 : 0.0;
+                double pb_ = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+                if constexpr (DIAGM) {                       // :202 and :204 with the diagonal matrices
+                    pa = mass_at(prm.m_sqrt, 2 * b) * pa; pb_ = mass_at(prm.m_sqrt, 2 * b + 1) * pb_;
+                    kq = dfma(pa, mass_at(prm.m_inv, 2 * b) * pa, kq);
+                    kq = dfma(pb_, mass_at(prm.m_inv, 2 * b + 1) * pb_, kq);
+                } else {
+                    kq = dfma(pa, pa, kq);
+                    kq = dfma(pb_, pb_, kq);
+                }
                 if (gen) st_pair(mvn, 2 * b, pa, pb_);
             }
             double v1[1] = {fold(kq)};
@@ -341,9 +378,16 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             const bool p = state == NS_NEED_DRAW;
             roll_state(p);
             begin_doubling(p);
+#ifdef MI_NUTS_LDS_PROF
+            n_phase_++;
+#endif
+            MI_LPROF(1);
             if (wg_or(any(state == NS_TREE) ? 1u : 0u) == 0u) continue;
         }
         const bool run = state == NS_TREE;
+#ifdef MI_NUTS_LDS_PROF
+        n_ticks_++;
+#endif
 
         // ------------------------------------------------------------ B. one leaf for every running chain
         auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
@@ -369,10 +413,13 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         const uint32_t bleaf = li - (1u << cz_i);
         const int sb = (!tst || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
         const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;
+        MI_LPROF(2);
         // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = w
         kick(e_signed);
         drift(e_signed);
+        MI_LPROF(3);
         eval();
+        MI_LPROF(4);
         // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
         double q1 = 0.0, q2 = 0.0, pk = 0.0;
 #pragma unroll
@@ -388,12 +435,15 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 const double dd = (vdir > 0) ? (th[s] - tb[k]) : (tb[k] - th[s]);
                 q1 = dfma(dd, pbv[k], q1);
                 q2 = dfma(dd, pm[s], q2);
-                pk = dfma(pm[s], pm[s], pk);
+                if constexpr (DIAGM) pk = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], pk);
+                else pk = dfma(pm[s], pm[s], pk);
             }
         }
+        MI_LPROF(5);
         const bool last_leaf = run && (li == (1u << jd) - 1u);               // the doubling may complete in this tick
         double v3[3] = {fold(q1), fold(q2), fold(pk)};
         const bool wg_complete = exchange(v3, any(last_leaf) ? 1u : 0u) != 0u;
+        MI_LPROF(6);
         q1 = v3[0]; q2 = v3[1];
         const double pK = v3[2] / 2.0;                   // nuts.ipp:140
         double pU = -val;                                // nuts.ipp:134-138
@@ -414,6 +464,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 if (vdir > 0) pos_init = false; else neg_init = false;
             }
         }
+        MI_LPROF(7);
         double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
         const bool cs = log_u < 1000.0 - pU - pK;        // :147
         const double dH = -(pU + pK) + H0;
@@ -455,6 +506,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227
             if (need_ut && !ok) failed = true;                                   // :229
         }
+        MI_LPROF(8);
         // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279)
         const bool keep = run && !failed;
         const bool complete = keep && (li == (1u << jd) - 1u);
@@ -489,7 +541,11 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         }
         // ---- the whole tree's U-turn test (:286-289): a dot product over dimensions, so every wave of the workgroup takes part
         //      whenever some chain of the workgroup was at the last leaf of its doubling
+        MI_LPROF(9);
         bool s_ok = false;
+#ifdef MI_NUTS_LDS_PROF
+        if (wg_complete) n_top_++;
+#endif
         if (wg_complete) {
             double r1 = 0.0, r2 = 0.0;
             if (any(complete)) {
@@ -513,6 +569,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             (void)exchange(v2, 0u);
             s_ok = complete && (v2[0] >= 0.0) && (v2[1] >= 0.0);
         }
+        MI_LPROF(10);
         if (any(fin)) {
             if (fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
             const bool more = fin && s_ok && (jd + 1 < max_depth);
@@ -528,7 +585,19 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             begin_doubling(more || roll);
         }
         if (run && !fin) li = li + 1;
+        MI_LPROF(11);
     }
+#ifdef MI_NUTS_LDS_PROF
+    if (blockIdx.x == 0 && lane == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += prof_[i];
+        printf("[nuts_lds prof] wave %d: %llu ticks, %llu phases, %llu tree tests, %.1f k cycles per tick | vote %.1f%% phaseA %.1f%% top-loads %.1f%% kick+drift %.1f%% "
+               "eval %.1f%% kick2+dots %.1f%% exchange %.1f%% stores %.1f%% unwind %.1f%% take/pending %.1f%% tree-test %.1f%% fin %.1f%%\n",
+               wv, n_ticks_, n_phase_, n_top_, (double)tot / (double)(n_ticks_ ? n_ticks_ : 1) / 1e3,
+               100.0 * prof_[0] / tot, 100.0 * prof_[1] / tot, 100.0 * prof_[2] / tot, 100.0 * prof_[3] / tot, 100.0 * prof_[4] / tot, 100.0 * prof_[5] / tot,
+               100.0 * prof_[6] / tot, 100.0 * prof_[7] / tot, 100.0 * prof_[8] / tot, 100.0 * prof_[9] / tot, 100.0 * prof_[10] / tot, 100.0 * prof_[11] / tot);
+    }
+#endif
 
     if (live && nf && prm.nf_flag != nullptr) { if (q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; } }
     if (live && !(nf && prm.nf_flag != nullptr)) {

@@ -57,6 +57,26 @@ def test_lds_nuts_matches_the_oracle(kind, d, n_rows, C, depth):
     _same(g_draws, g, o_draws, o, depth=False)
 
 
+@pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 100, 20, 37), ("logistic", 512, 24, 5), ("dense", 160, 0, 5), ("dense", 384, 0, 37)])
+def test_lds_nuts_with_a_diagonal_precond_mat_matches_the_oracle(kind, d, n_rows, C):
+    """ref: src/nuts.cpp:57-59,168,202-204 -- p = sqrt(M) z, K = p.(INV(M) p) / 2, theta += e INV(M) p with a diagonal M"""
+    tk, tkw, spec = _problem(kind, d, n_rows, seed=d + 9)
+    init = synth.initial_states(C, d, seed=d + 3) * (0.1 if kind == "logistic" else 0.5)
+    M = np.diag(np.random.default_rng(d).uniform(0.4, 2.5, d))
+    st = mcmc_amd.default_settings(rng_seed_value=21, n_burnin_draws=3, n_keep_draws=3, n_adapt_draws=4, max_tree_depth=5, step_size=0.05, precond_mat=M)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=2, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().endswith("true>")
+    s = orc.make_settings(seed=21, n_burnin=3, n_keep=3, n_adapt=4, max_depth=5, step=0.05, W=4, blocks=4, block_size=_bs(kind, d), precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=2)
+    assert o["n_leap"].max() > 16
+    _same(g_draws, g, o_draws, o, depth=False)
+    # the non-finite regime with the tables: flagged, replayed literally with the same M
+    init[1] = 1e200
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=2, **tkw)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=2)
+    _same(g_draws, g, o_draws, o, depth=False)
+
+
 @pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 512, 64, 100), ("logistic", 48, 200, 70), ("dense", 512, 0, 70), ("dense", 192, 0, 100)])
 def test_lds_nuts_matches_the_literal_kernel_on_longer_runs(kind, d, n_rows, C):
     """deep trees (up to 2^8 leaves), many draws, the adaptation window inside the run, several workgroups that finish at different times"""
@@ -112,8 +132,10 @@ def test_lds_nuts_refusals_and_fallbacks_are_the_documented_ones():
     d, C = 160, 4
     prec = synth.dense_gaussian_precision(d, seed=1)
     init = synth.initial_states(C, d, seed=1) * 0.5
-    # bounds / a preconditioner / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal
-    for kw in (dict(precond_mat=np.diag(np.linspace(0.5, 2.0, d))), dict(max_tree_depth=11), dict(max_tree_depth=0)):
+    # bounds / a dense preconditioner / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal
+    A = np.random.default_rng(3).standard_normal((d, d)) / np.sqrt(d)
+    for kw in (dict(precond_mat=A @ A.T + np.eye(d)), dict(vals_bound=1, lower_bounds=np.full(d, -5.0), upper_bounds=np.full(d, 5.0)),
+               dict(max_tree_depth=11), dict(max_tree_depth=0)):
         st = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=1, n_keep_draws=1, n_adapt_draws=1, step_size=0.1, **{"max_tree_depth": 3, **kw})
         mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
         assert mcmc_amd.last_kernel().startswith("literal_kernel<")
