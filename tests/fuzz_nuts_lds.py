@@ -1,0 +1,75 @@
+"""Randomised sweep of nuts on the LDS-streamed evaluation (mcmc_amd/csrc/nuts_lds.hpp) against literal_kernel<2> of the same library
+(MI_KERNEL_LITERAL: one workgroup per chain, the reference's recursion as written, itself pinned against the oracle by
+tests/test_gpu_literal_paths.py and the CPU suite) -- both run on the GPU, so the cases can be long: logistic / dense targets of every
+instantiation, ragged workgroups, draw counts and adaptation windows incl. none, depth caps 1..10, step sizes from tiny to absurd, a
+diagonal precond_mat, chains that start in the non-finite regime, runs cut in two.  Bit-exact or report.
+Usage (GPU box): python tests/fuzz_nuts_lds.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import mcmc_amd
+from mcmc_amd import synth
+
+
+def sweep(n_cases=30, seed=1, verbose=True):
+    rng = np.random.default_rng(seed)
+    fails = 0
+    for case in range(n_cases):
+        kind = str(rng.choice(["logistic", "dense"]))
+        if kind == "logistic":
+            d = int(rng.choice([9, 16, 40, 64, 65, 128, 129, 200, 256, 300, 512]))
+            n_rows = int(rng.choice([1, 7, 16, 17, 50, 130]))
+            X, y = synth.logistic_problem(d, n_rows, seed=int(rng.integers(1, 99)))
+            tk, tkw, scale = mcmc_amd.TARGET_LOGISTIC, dict(X=X, y=y), 0.1
+        else:
+            d = int(rng.choice([129, 160, 192, 193, 256, 257, 384, 385, 512]))
+            tk, tkw, scale = mcmc_amd.TARGET_GAUSS_DENSE, dict(prec=synth.dense_gaussian_precision(d, seed=int(rng.integers(1, 99)))), 0.5
+        C = int(rng.choice([1, 5, 16, 17, 32, 33, 70, 130]))
+        burn, keep = int(rng.integers(0, 10)), int(rng.integers(0, 10))
+        if burn + keep == 0: keep = 1
+        adapt = int(rng.integers(0, burn + keep + 3))
+        max_depth = int(rng.choice([1, 2, 3, 5, 7, 10]))
+        eps0 = float(rng.choice([0.005, 0.03, 0.1, 0.5, 2.0]))
+        init = synth.initial_states(C, d, seed=int(rng.integers(1, 1000))) * scale
+        wild = rng.random() < 0.25
+        if wild:                                           # some chains start where energies overflow
+            for c in rng.choice(C, size=min(C, 3), replace=False):
+                init[c] *= float(rng.choice([1e150, 1e300])); 
+                if rng.random() < 0.3: init[c, 0] = np.inf
+        kw = {}
+        if rng.random() < 0.3: kw["precond_mat"] = np.diag(rng.uniform(0.3, 3.0, d))
+        S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=int(sd), n_burnin_draws=b, n_keep_draws=k, n_adapt_draws=adapt,
+                                                   max_tree_depth=max_depth, step_size=eps0, **kw)
+        sd = rng.integers(1, 10**6)
+        chain0 = int(rng.integers(0, 5000))
+        a_draws, a = mcmc_amd.sample("nuts", tk, init, S(burn, keep), chain0=chain0, want_adapt_state=True, **tkw)
+        kernel = mcmc_amd.last_kernel()
+        b_draws, b = mcmc_amd.sample("nuts", tk, init, S(burn, keep), chain0=chain0, want_adapt_state=True, kernel_hint=mcmc_amd.KERNEL_LITERAL, **tkw)
+        bits = lambda v: np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
+        same = lambda u, v: np.array_equal(bits(u), bits(v)) or np.array_equal(u, v, equal_nan=True)     # (NaN payloads may differ)
+        ok = (kernel.startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().startswith("literal_kernel<")
+              and same(a_draws, b_draws) and np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["n_leap"], b["n_leap"])
+              and np.array_equal(a["n_accept"], b["n_accept"]) and same(a["eps"], b["eps"]) and same(a["theta"], b["theta"])
+              and same(a["adapt_state"], b["adapt_state"]))
+        cut = None
+        if ok and not wild and burn == 0 and keep >= 2:   # the same run cut in two on the tiled kernel (all draws kept: rows compare one to one)
+            cut = int(rng.integers(1, keep))
+            p_draws, p = mcmc_amd.sample("nuts", tk, init, S(0, cut), chain0=chain0, want_adapt_state=True, **tkw)
+            q_draws, q = mcmc_amd.sample("nuts", tk, p["theta"].T.copy(), S(0, keep - cut), chain0=chain0, draw0=cut, step_size_in=p["eps"],
+                                         adapt_state_in=p["adapt_state"], **tkw)
+            ok = same(np.concatenate([p_draws, q_draws]), a_draws) and same(q["eps"], a["eps"]) and np.array_equal(p["n_leap"] + q["n_leap"], a["n_leap"])
+        if verbose or not ok:
+            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, n_rows=(n_rows if kind == "logistic" else 0), C=C, burn=burn, keep=keep, adapt=adapt,
+                                                   max_depth=max_depth, eps0=eps0, chain0=chain0, wild=wild, diag="precond_mat" in kw, cut=cut,
+                                                   seed=int(sd), kernel=kernel, leaps=int(a["n_leap"].sum())), flush=True)
+        fails += 0 if ok else 1
+    return fails
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    s = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f = sweep(n, s)
+    print("mismatching cases:", f)
+    sys.exit(1 if f else 0)

@@ -30,6 +30,14 @@ def test_plain_nuts_kernel_random_windows_and_depth_caps(seed):
     assert fuzz_nuts.sweep(40, seed, verbose=False) == 0
 
 
+@pytest.mark.parametrize("seed", [7])
+def test_nuts_on_the_lds_streamed_evaluation_random_cases(seed):
+    """nuts_lds.hpp against literal_kernel<2> of the same library (both on the GPU): random targets of every instantiation, ragged
+    workgroups, windows, depth caps, step sizes, a diagonal precond_mat, non-finite starts, runs cut in two."""
+    import fuzz_nuts_lds
+    assert fuzz_nuts_lds.sweep(16, seed, verbose=False) == 0
+
+
 def test_per_chain_mass_sweep_is_bit_exact():
     """hmc with mi_chains.mass_diag: chain c against the oracle with precond_mat = diag(mass[:, c]), random targets / sizes / bounds /
     non-finite starts (elementwise and literal kernels)"""
