@@ -31,6 +31,7 @@ struct LogitParams {
     // nuts (nuts_lds.hpp): workspace vectors / per-chain scalars of every wave (set by the launcher), outputs and the dual-averaging settings
     double* nuts_ws;
     double* nuts_sc;
+    uint32_t* nuts_next;    // chains handed out beyond the first gridDim.x * 32 (zeroed by the launcher)
     uint64_t* n_leap_out;   // [C] leapfrog steps of every chain, or nullptr
     double* step_out;       // [C] step sizes: out (and in, for a continuation: draw0 > 0), or nullptr
     uint32_t* depth_trace;  // [n_total][C] tree depth of every draw, or nullptr
@@ -46,6 +47,8 @@ enum { LOGIT_TARGET_LOGISTIC = 0, LOGIT_TARGET_DENSE = 1 };
 
 // bytes of device workspace a launch needs (block images of X, accepted state of every chain)
 size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC, int algo = LOGIT_HMC);
+// nuts: workgroups of the persistent grid (32 chain slots each; the workspace is sized by chains = 32 * this)
+uint64_t logit_lds_nuts_workgroups(uint32_t d, uint64_t C, int target);
 // packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)
 int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st,
                      int target = LOGIT_TARGET_LOGISTIC);

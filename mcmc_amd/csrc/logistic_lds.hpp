@@ -59,7 +59,7 @@ inline size_t logit_lds_ws_doubles(uint32_t NB, uint64_t C, int target, int algo
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (C + 31) / 32;
     return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0)
-           + (algo == LOGIT_NUTS ? n_wg * 8 * (lds_nuts::vec_doubles_per_wave(G::NSQ) + lds_nuts::sc_doubles_per_wave()) : 0);
+           + (algo == LOGIT_NUTS ? n_wg * 8 * (lds_nuts::vec_doubles_per_wave(G::NSQ) + lds_nuts::sc_doubles_per_wave()) + 32 : 0);   // (+ the chain counter)
 }
 // (logistic_nuts.hip: the nuts instantiations are a translation unit of their own)
 int logit_lds_launch_nuts(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target);
@@ -489,6 +489,12 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     }
     issue_block(0, 0);
     wait_loads();
+    if constexpr (ALGO == LOGIT_NUTS) {
+        // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp); chains are
+        // handed to the workgroup's 32 slots dynamically, their first evaluation is a state of that machine
+        nuts_lds_body<NTQ, DIAGM>(prm, evaluate, part_all);
+        return;
+    }
     double first_lp;
     evaluate(bp, gp, first_lp);         // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
 #pragma unroll
@@ -689,9 +695,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             keep_draw(draw, accept);
         }
     } else if constexpr (ALGO == LOGIT_NUTS) {
-        // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp)
-        nuts_lds_body<NTQ, DIAGM>(prm, evaluate, part_all, bp, gp, first_lp);
-        return;
+        // (handled above)
     } else {
         // HMC (hmc.cpp:155-205): one evaluation per leapfrog step -- the second half-kick of step k and the first of step
         // k+1 are at the same position -- and the value of the last one is prop_U.

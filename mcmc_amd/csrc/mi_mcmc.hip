@@ -1904,7 +1904,9 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     // workspace: the kernel's own | non-finite flags | the matrix transposed and the work areas of the literal replay
     ReplayWs rp;
     rp.t_doubles = ((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31;
-    rp.own_bytes = (mi::logit_lds_workspace_bytes(q.d, q.NB, C, lds_target, mi::LOGIT_NUTS) + 255) & ~(size_t)255;
+    // (the kernel's workspace is sized by the chain SLOTS of its persistent grid, not by the chains)
+    const uint64_t n_slots = 32 * mi::logit_lds_nuts_workgroups(q.d, C, lds_target);
+    rp.own_bytes = (mi::logit_lds_workspace_bytes(q.d, q.NB, n_slots, lds_target, mi::LOGIT_NUTS) + 255) & ~(size_t)255;
     rp.stride = mi::lit::lit_work_doubles((uint32_t)d, dense ? 0u : (uint32_t)n_rows, false, q.max_depth, true, false);
     rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;

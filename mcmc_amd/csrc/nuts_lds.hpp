@@ -19,6 +19,14 @@
 // global memory (LDS is full of matrix): vectors chain-major inside a wave's block so that a chain's row is contiguous whatever
 // record each chain of the wave addresses.
 //
+// Chains are handed to lanes DYNAMICALLY.  A workgroup has 32 chain slots (2 tiles x 16 lanes); the grid is persistent (as many workgroups as
+// the chip holds at once, or fewer if the chains are few) and a slot whose chain has finished all its draws fetches the next chain index
+// from a global counter at the next vote.  A new chain enters the same tick loop in two more states -- INIT (the evaluation at its initial
+// values: nuts.cpp:181) and SEARCH (one leapfrog of nuts_find_initial_step_size per tick, nuts.ipp:30-93) -- so a workgroup never waits
+// for its slowest chain while there are chains left, and the workspace is sized by the slots, not by the chains.  Results do not depend on
+// the slot a chain runs in: its random numbers are counter-based on the global chain index and its arithmetic never crosses lanes of
+// other chains.
+//
 // Non-finite regime: detected through the energies of every leaf; the chain is flagged and replayed by
 // literal_kernel<2> (the reference's dense products as written), like the hmc / mala kernels of logistic_lds.hpp do.
 #pragma once
@@ -49,7 +57,7 @@ enum : int {
     SC_PER_CHAIN = 64        // doubles of per-chain scalars: [level][4] + the dual-averaging state at 48..50
 };
 enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
-enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2 };
+enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2, NS_INIT = 3, NS_SEARCH = 4 };
 // doubles of workspace per workgroup (8 waves): vectors, then scalars
 __host__ __device__ constexpr size_t vec_doubles_per_wave(int NSQ) { return (size_t)NVEC * NSQ * 64; }
 __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 * SC_PER_CHAIN; }
@@ -58,13 +66,15 @@ __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 *
 // DIAGM: a DIAGONAL precond_mat (nuts.cpp:57-59,168,202-204,139-154: p = sqrt(m) z, K = p.(p / m) / 2, theta += e (p / m); the U-turn dots
 // are plain), tables read from global memory where they are used (prm.m_sqrt, prm.m_inv: padded with ones to 64 NTQ entries).
 template <int NTQ, bool DIAGM, class Eval>
-__device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all,
-                                              double (&th)[4 * NTQ], double (&w)[4 * NTQ], const double first_lp)
+__device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all)
 {
     using namespace lds_nuts;
     constexpr int NS = 4 * NTQ, DQ = 16 * NTQ;
     constexpr bool PM_MEM = NTQ >= 6;                    // the momentum leaves the registers for the evaluation
-    constexpr int CH = (NS % 8 == 0) ? 8 : 4;            // slices per chunk of a row that passes through temporaries
+#ifndef MI_NUTS_LDS_CH_WIDE
+#define MI_NUTS_LDS_CH_WIDE 8      // (timing experiments: chunk size of the wide tiles)
+#endif
+    constexpr int CH = (NTQ >= 6) ? MI_NUTS_LDS_CH_WIDE : ((NS % 8 == 0) ? 8 : 4);   // slices per chunk of a row that passes through temporaries
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -72,34 +82,38 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     const int j4 = lane >> 4;
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
-    const uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
-    const bool live = cl < C;
-    const uint64_t cld = live ? cl : C - 1;
-    const uint64_t chain = prm.chain0 + cl;
+    const uint64_t n_slots = (uint64_t)gridDim.x * 32;   // chains [0, n_slots) start in their own slot; the counter hands out the rest
     double* const part = part_all + g * (4 * 4 * 64);
+    constexpr int FLAG_AT = (3 * 4) * 64;                // slot 3 of a tile's exchange area: the tile's flags, then the 16 chain indices of an assignment
+    // this slot's chain (replicated in the four waves of the tile); cl >= C: none
+    uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
+    bool exhausted = false;                              // the counter has run past the last chain: this slot asks no more
 
     // ---- workgroup collectives.  ((S0 + S1) + S2) + S3 of per-wave partial sums (each already butterflied inside the wave), K <= 3 values
     // at a time, and the OR of a flag word over the workgroup's waves (the four waves of a tile hold the same flags: wave 0 of each tile
     // speaks).  Every wave of the workgroup calls these in the same order.
+    auto read_flags = [&]() __attribute__((always_inline)) -> uint32_t {      // (uniform: the block stream's buffer parity is loop-carried behind these votes)
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)part_all[FLAG_AT] | (uint32_t)part_all[(4 * 4 * 64) + FLAG_AT]));
+    };
     auto exchange = [&](auto& v, uint32_t flags) __attribute__((always_inline)) -> uint32_t {
         constexpr int K = (int)(sizeof(v) / sizeof(double));
         static_assert(K <= 3, "slot 3 of the exchange area carries the flags");
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < K; ++k) part[(k * 4 + q) * 64 + lane] = v[k];
-        if (q == 0 && lane == 0) part[(3 * 4) * 64] = (double)flags;
+        if (q == 0 && lane == 0) part[FLAG_AT] = (double)flags;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < K; ++k)
             v[k] = ((part[(k * 4 + 0) * 64 + lane] + part[(k * 4 + 1) * 64 + lane]) + part[(k * 4 + 2) * 64 + lane])
                    + part[(k * 4 + 3) * 64 + lane];
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)part_all[(3 * 4) * 64] | (uint32_t)part_all[(4 * 4 * 64) + (3 * 4) * 64]));   // (uniform: the block stream's buffer parity is loop-carried behind these votes)
+        return read_flags();
     };
     auto wg_or = [&](uint32_t flags) __attribute__((always_inline)) -> uint32_t {
         __syncthreads();
-        if (q == 0 && lane == 0) part[(3 * 4) * 64] = (double)flags;
+        if (q == 0 && lane == 0) part[FLAG_AT] = (double)flags;
         __syncthreads();
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)part_all[(3 * 4) * 64] | (uint32_t)part_all[(4 * 4 * 64) + (3 * 4) * 64]));   // (uniform: the block stream's buffer parity is loop-carried behind these votes)
+        return read_flags();
     };
     auto any = [&](bool p) -> bool { return __ballot(p) != 0ull; };
     auto fold = [&](double a) __attribute__((always_inline)) -> double {     // the 4-strided chains of a block: (q0 + q2) + (q1 + q3)
@@ -159,106 +173,38 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab + (q * DQ + 4 * s)) + off);
     };
 
-    double pm[NS];
-    double val = first_lp;
+    // the chain's last leaf on this wave's dims: position, momentum, GRADIENT of the log kernel at the position (MFMA B / D layout)
+    double th[NS], pm[NS], w[NS];
+    double val = 0.0;
     bool nf = false;                                     // the chain reached the non-finite regime: flagged, replayed by literal.hpp
-    // one evaluation at the register-resident position; the momentum survives it
-    auto eval = [&]() __attribute__((always_inline)) {
-        if constexpr (PM_MEM) st_row(V_TMPP, 0, pm);
-        evaluate(th, w, val);
-        if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
-    };
     auto kick = [&](double e) __attribute__((always_inline)) {               // p += (e grad) / 2 (nuts.cpp:108-135)
 #pragma unroll
         for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
     };
-    auto drift = [&](double e) __attribute__((always_inline)) {              // theta += e (Minv p), Minv = I (nuts.cpp:139-154)
+    auto drift = [&](double e) __attribute__((always_inline)) {              // theta += e (Minv p), Minv = I or diagonal (nuts.cpp:139-154)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if constexpr (DIAGM) th[s] = th[s] + e * (mass_at(prm.m_inv, s) * pm[s]);
             else th[s] = th[s] + e * pm[s];
         }
     };
-    auto kinetic_partial = [&]() __attribute__((always_inline)) -> double {  // this wave's share of p . (I p)
-        double a = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if constexpr (DIAGM) a = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], a);
-            else a = dfma(pm[s], pm[s], a);
-        }
-        return fold(a);
-    };
 
-    // ---------------------------------------------------------------- setup (nuts.cpp:156-195), all chains together
-    st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w);
-    double prev_U = -first_lp;                           // nuts.cpp:181 (no finiteness guard there)
-    if (!is_finite(prev_U)) nf = true;
-    uint64_t n_leap = 0;
-    double eps;
-    if (prm.draw0 == 0) {   // nuts_find_initial_step_size (nuts.ipp:30-93) from (first_draw, z_init), nuts.cpp:166-172
-#pragma unroll
-        for (int b = 0; b < NS / 2; ++b) {
-            double z0, z1;
-            rng_normal_pair(prm.seed, chain, 0u, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_INIT, z0, z1);
-            pm[2 * b] = (dim_of(2 * b) < d) ? z0 : 0.0;
-            pm[2 * b + 1] = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
-            if constexpr (DIAGM) {                       // mntm_vec = sqrt_precond_matrix * rand_vec (nuts.cpp:168)
-                pm[2 * b] = mass_at(prm.m_sqrt, 2 * b) * pm[2 * b];
-                pm[2 * b + 1] = mass_at(prm.m_sqrt, 2 * b + 1) * pm[2 * b + 1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        double U0 = prev_U;
-        if (!is_finite(U0)) U0 = INF;
-        double K0;
-        { double v1[1] = {kinetic_partial()}; (void)exchange(v1, 0u); K0 = v1[0] / 2.0; }
-        const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
-        eps = 1.0;
-        int a_val = 1;
-        bool cond = live;                                // (lanes beyond the last chain take no part in any vote)
-        bool first = true;
-#pragma unroll 1
-        for (;;) {
-            if (!first) {
-                const double e_new = eps * ((a_val == 1) ? 2.0 : 0.5);
-                if (cond) eps = e_new;
-            }
-            if (cond) n_leap++;
-            kick(eps); drift(eps); eval(); kick(eps);
-            double u = -val;
-            if (!is_finite(u)) { u = INF; if (cond) nf = true; }
-            double v1[1] = {kinetic_partial()};
-            (void)exchange(v1, 0u);
-            const double k_new = v1[0] / 2.0;
-            if (cond && !is_finite(k_new)) nf = true;
-            const double dH = -(u + k_new) + (U0 + K0);
-            if (first) { a_val = 2 * (dH > log_half ? 1 : 0) - 1; cond = cond && (dH > neg_log2); }
-            else if (cond) { a_val = 2 * (dH > log_half ? 1 : 0) - 1; cond = dH > neg_log2; }
-            first = false;
-            if (wg_or(any(cond) ? 1u : 0u) == 0u) break;
-        }
-    } else {                // continuation of an adapted run (mi_chains.draw0 > n_adapt_draws): the step size comes back in
-        eps = (live && prm.step_out) ? prm.step_out[cl] : 1.0;
-    }
-    mu_val_() = det_log(10 * eps);                       // nuts.cpp:174
-    h_val_() = 0.0;
-    eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
-    if (prm.draw0 > 0 && prm.draw0 <= prm.n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
-        h_val_() = prm.adapt_state[cld]; eps_bar_() = prm.adapt_state[C + cld]; mu_val_() = prm.adapt_state[2 * C + cld];
-    }
-    uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
-    const uint32_t n_adapt = prm.n_adapt;
+    const uint32_t n_adapt = prm.n_adapt;                // the run's window in GLOBAL draw indices
     const uint32_t max_depth = prm.max_depth;            // 1 .. MAX_DEPTH (the host routes everything else to literal.hpp)
+    const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
 
-    // ---------------------------------------------------------------- per-chain state (nuts_tile.hpp: the same machine)
-    int state = (n_total > 0 && live) ? NS_NEED_DRAW : NS_DONE;
+    // ---------------------------------------------------------------- per-chain state (nuts_tile.hpp: the same machine, plus INIT / SEARCH)
+    int state = (cl < C) ? NS_INIT : NS_DONE;
+    uint64_t n_leap = 0, n_acc = 0;
+    double eps = 1.0, prev_U = 0.0;
     uint32_t draw = 0;           // this chain's draw index
     uint32_t jd = 0;             // depth of the doubling in progress
     uint32_t li = 0;             // next leaf of that doubling
     uint32_t uslot = 0;
-    int vdir = 1;
-    double e_signed = 0.0, H0 = 0.0, log_u = 0.0;
+    int vdir = 1;                // direction of the doubling; SEARCH: a of nuts.ipp:75
+    bool s_first = true;         // SEARCH: the leapfrog of nuts.ipp:62-72 (before the loop)
+    double e_signed = 0.0, H0 = 0.0, log_u = 0.0;        // H0: energy at the start of the draw; SEARCH: U0 + K0 of the initial state
     auto prev_K_ = [&]() -> double& { return lvl(0, 0); };
     auto n_val_ = [&]() -> double& { return lvl(0, 1); };
     auto alpha_ = [&]() -> double& { return lvl(0, 2); };
@@ -276,7 +222,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     auto wvec = [](int b) -> int { return b ? V_WPREVB : V_WPREV; };
 
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {       // direction draw, nuts.cpp:233-235
-        const double zdir = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);
+        const double zdir = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);
         if (p) {
             uslot++;
             vdir = (zdir <= 0.5) ? -1 : 1;
@@ -335,30 +281,96 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             state = NS_TREE;
         }
     };
+    // a chain leaves its slot: final state, counters, step size and dual-averaging state (nuts.cpp:311-330) -- or, flagged, only its flag
+    auto retire = [&](bool p) __attribute__((always_inline)) {
+        if (!any(p)) return;
+        const bool flagged = p && nf && prm.nf_flag != nullptr;
+        if (flagged && q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+        if (p && !flagged) {
+#pragma unroll
+            for (int c0 = 0; c0 < NS; c0 += CH) {
+                double tmp[CH];
+                ld_row(pvec(pb), c0, tmp);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const uint32_t dim = dim_of(c0 + k);
+                    if (dim < d) prm.theta[(size_t)dim * C + cl] = tmp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q == 0 && j4 == 0) {
+                if (prm.n_accept) prm.n_accept[cl] = n_acc;
+                if (prm.n_leap_out) prm.n_leap_out[cl] = n_leap;
+                if (prm.step_out) prm.step_out[cl] = eps;
+                if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
+            }
+        }
+        if (p) state = NS_DONE;
+    };
+    // SEARCH ends (or is skipped by a continuation): the dual-averaging state of nuts.cpp:174-176, then the chain waits for its first phase
+    auto start_sampling = [&](bool p) __attribute__((always_inline)) {
+        if (!any(p)) return;
+        if (p) {
+            mu_val_() = det_log(10 * eps);                   // nuts.cpp:174
+            h_val_() = 0.0;
+            eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
+            if (prm.draw0 > 0 && prm.draw0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+                h_val_() = prm.adapt_state[cl]; eps_bar_() = prm.adapt_state[C + cl]; mu_val_() = prm.adapt_state[2 * C + cl];
+            }
+            state = NS_NEED_DRAW;
+        }
+    };
 
 #ifdef MI_NUTS_LDS_PROF
-    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), n_ticks_ = 0, n_phase_ = 0, n_top_ = 0;
+    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), n_ticks_ = 0, n_phase_ = 0, n_top_ = 0, n_lane_ticks_ = 0;
 #endif
 #pragma unroll 1
     for (;;) {
         asm volatile("" : "+v"(lane_b));
-        if (nf) state = NS_DONE;                         // a flagged chain is replayed from its initial state: nothing of it is kept
-        const uint32_t f0 = wg_or((any(state != NS_DONE) ? 1u : 0u) | (any(state == NS_NEED_DRAW) ? 2u : 0u));
+        retire(nf && state != NS_DONE);                  // a flagged chain is replayed from its initial state: nothing of it is kept
+        // ------------------------------------------------------------ the vote; free slots take the next chains
+        {
+            const bool want = state == NS_DONE && !exhausted;
+            __syncthreads();
+            if (q == 0) {
+                const uint32_t m = (uint32_t)(__ballot(want) & 0xffffull);          // the tile's 16 slots (lanes 0..15; the j4 copies agree)
+                uint32_t base = 0;
+                if (m != 0u) {
+                    if (lane == 0) base = atomicAdd(prm.nuts_next, (uint32_t)__builtin_popcount(m));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                }
+                const uint64_t nid = n_slots + base + (uint32_t)__builtin_popcount(m & ((1u << (lane & 15)) - 1u));
+                const bool got = want && nid < C;
+                if (lane < 16) part[FLAG_AT + 1 + lane] = got ? (double)nid : -1.0;
+                const uint32_t fl = ((any(state != NS_DONE) || any(got)) ? 1u : 0u) | (any(state == NS_NEED_DRAW) ? 2u : 0u);
+                if (lane == 0) part[FLAG_AT] = (double)fl;
+            }
+            __syncthreads();
+            if (want) {
+                const double nid = part[FLAG_AT + 1 + (lane & 15)];
+                if (nid >= 0.0) {                        // a new chain in this slot: everything per-chain starts over
+                    cl = (uint64_t)nid;
+                    state = NS_INIT; nf = false; n_leap = 0; n_acc = 0; draw = 0; eps = 1.0;
+                    mv = V_MNTM; mvn = V_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false;
+                } else exhausted = true;
+            }
+        }
+        const uint32_t f0 = read_flags();
         MI_LPROF(0);
         if ((f0 & 1u) == 0u) break;
-        // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
+        // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start or leave
         if ((f0 & 2u) != 0u) {
             store_row(row_pend, pvec(pb0), row_draw);
             store_row(row2_pend, pvec(pb), draw - 1u);
             row_pend = false; row2_pend = false;
-            if (state == NS_NEED_DRAW && draw >= n_total) state = NS_DONE;
+            retire(state == NS_NEED_DRAW && draw >= n_total);
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
-            const bool gen = state != NS_DONE && !mom_ready && nidx < n_total;
+            const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
-                rng_normal_pair(prm.seed, chain, nidx + prm.draw0, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_NORMAL, z0, z1);
+                rng_normal_pair(prm.seed, prm.chain0 + cl, nidx + prm.draw0, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_NORMAL, z0, z1);
                 double pa = (dim_of(2 * b) < d) ? z0 : 0.0;
                 double pb_ = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
                 if constexpr (DIAGM) {                       // :202 and :204 with the diagonal matrices
@@ -373,7 +385,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             }
             double v1[1] = {fold(kq)};
             (void)exchange(v1, 0u);
-            const double lu = det_log(rng_uniform(prm.seed, chain, nidx + prm.draw0, 0u));
+            const double lu = det_log(rng_uniform(prm.seed, prm.chain0 + cl, nidx + prm.draw0, 0u));
             if (gen) { next_K = v1[0] / 2.0; next_lu = lu; mom_ready = true; }     // :204
             const bool p = state == NS_NEED_DRAW;
             roll_state(p);
@@ -382,11 +394,12 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             n_phase_++;
 #endif
             MI_LPROF(1);
-            if (wg_or(any(state == NS_TREE) ? 1u : 0u) == 0u) continue;
+            if (wg_or(any(state == NS_TREE || state == NS_INIT || state == NS_SEARCH) ? 1u : 0u) == 0u) continue;
         }
-        const bool run = state == NS_TREE;
+        const bool run = state == NS_TREE, init = state == NS_INIT, srch = state == NS_SEARCH;
 #ifdef MI_NUTS_LDS_PROF
         n_ticks_++;
+        n_lane_ticks_ += (unsigned long long)__builtin_popcountll(__ballot(run || init || srch) & 0xffffull);
 #endif
 
         // ------------------------------------------------------------ B. one leaf for every running chain
@@ -414,11 +427,39 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         const int sb = (!tst || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
         const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;
         MI_LPROF(2);
-        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = w
-        kick(e_signed);
-        drift(e_signed);
+        // SEARCH: the step of this leapfrog (nuts.ipp:62, 80-82)
+        if (srch) {
+            if (!s_first) eps = eps * ((vdir == 1) ? 2.0 : 0.5);
+            n_leap++;
+        }
+        // one leapfrog of size e (nuts.ipp:132 / :64, nuts.cpp:139-154), grad = w.  INIT: e = 0 and the state is set after the (idle) updates
+        const double e_tick = run ? e_signed : (srch ? eps : 0.0);
+        kick(e_tick);
+        drift(e_tick);
+        if (any(init)) {                                 // first_draw and z_init (nuts.cpp:160-168): an evaluation, no leapfrog
+            if (init) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const uint32_t dim = dim_of(s);
+                    const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cl];
+                    th[s] = (dim < d) ? v : 0.0;
+                }
+            }
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {
+                double z0, z1;
+                rng_normal_pair(prm.seed, prm.chain0 + cl, 0u, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_INIT, z0, z1);
+                double pa = (dim_of(2 * b) < d) ? z0 : 0.0;
+                double pb_ = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+                if constexpr (DIAGM) { pa = mass_at(prm.m_sqrt, 2 * b) * pa; pb_ = mass_at(prm.m_sqrt, 2 * b + 1) * pb_; }   // nuts.cpp:168
+                if (init) st_pair(V_TMPP, 2 * b, pa, pb_);
+            }
+            if (init) ld_row(V_TMPP, 0, pm);
+        }
         MI_LPROF(3);
-        eval();
+        if constexpr (PM_MEM) st_row(V_TMPP, 0, pm);
+        evaluate(th, w, val);
+        if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
         MI_LPROF(4);
         // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
         double q1 = 0.0, q2 = 0.0, pk = 0.0;
@@ -431,7 +472,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int s = c0 + k;
-                pm[s] = pm[s] + (e_signed * w[s]) / 2.0;
+                pm[s] = pm[s] + (e_tick * w[s]) / 2.0;
                 const double dd = (vdir > 0) ? (th[s] - tb[k]) : (tb[k] - th[s]);
                 q1 = dfma(dd, pbv[k], q1);
                 q2 = dfma(dd, pm[s], q2);
@@ -445,14 +486,39 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         const bool wg_complete = exchange(v3, any(last_leaf) ? 1u : 0u) != 0u;
         MI_LPROF(6);
         q1 = v3[0]; q2 = v3[1];
-        const double pK = v3[2] / 2.0;                   // nuts.ipp:140
-        double pU = -val;                                // nuts.ipp:134-138
-        if (!is_finite(pU)) { pU = INF; if (run) nf = true; }
+        const double pK = v3[2] / 2.0;                   // nuts.ipp:140 / :51,66
+        double pU = -val;                                // nuts.ipp:134-138 / :50,65
+        const bool u_nf = !is_finite(pU);
+        // ---- INIT: the chain's first state is on record; SEARCH: one step of nuts_find_initial_step_size
+        if (any(init)) {
+            if (init) {
+                st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w);
+                prev_U = pU;                             // nuts.cpp:181 (no finiteness guard there)
+                if (u_nf || !is_finite(pK)) nf = true;
+                H0 = (u_nf ? INF : pU) + pK;             // U0 + K0 (nuts.ipp:50-52)
+                s_first = true;
+            }
+            if (init && prm.draw0 != 0) eps = prm.step_out ? prm.step_out[cl] : 1.0;     // a continuation: the step size comes back in
+            start_sampling(init && prm.draw0 != 0);
+            if (init && prm.draw0 == 0) state = NS_SEARCH;
+        }
+        if (any(srch)) {
+            if (srch) {
+                if (u_nf || !is_finite(pK)) nf = true;
+                const double dH = -((u_nf ? INF : pU) + pK) + H0;            // nuts.ipp:68,86
+                vdir = 2 * (dH > log_half ? 1 : 0) - 1;                      // :75,88
+                s_first = false;
+            }
+            start_sampling(srch && !(-((u_nf ? INF : pU) + pK) + H0 > neg_log2));     // :78,90: the loop ends
+        }
+        if (u_nf) { pU = INF; if (run) nf = true; }
         if (run && !is_finite(pK)) nf = true;
         const bool ut_now = (q1 >= 0.0) && (q2 >= 0.0);  // the test of level ctz(li) + 1
         if (tst && !odd) utpre = (utpre & ~(1u << (cz_i + 1u))) | ((ut_now ? 1u : 0u) << (cz_i + 1u));
-        if (run && !odd) {                               // even leaves are the records later leaves and tests read
-            st_row(rec_t, 0, th); st_row(rec_p, 0, pm); st_row(rec_w, 0, w);
+        if (any(run && !odd)) {
+            if (run && !odd) {                           // even leaves are the records later leaves and tests read
+                st_row(rec_t, 0, th); st_row(rec_p, 0, pm); st_row(rec_w, 0, w);
+            }
         }
         // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a successful doubling
         // leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw, so it is written in place
@@ -486,7 +552,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             if (!any(walking)) break;
             const bool mrg = walking && bit;
             if (!any(mrg)) continue;
-            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :213
+            const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :213
             if (mrg) {
                 uslot++;
                 const double p_n = lvl((int)l, 0), p_a = lvl((int)l, 1), p_na = lvl((int)l, 2), p_U = lvl((int)l, 3);
@@ -513,7 +579,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         const bool fin = run && (failed || complete);
         bool take = false;
         if (any(complete)) {
-            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, uslot);  // :261
+            const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :261
             if (complete) {
                 uslot++;
                 take = z < cn / n_val_();                                   // :263
@@ -539,9 +605,9 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 if (any(do_copy)) { if (do_copy) { cp_row(cref_t, dst_t); cp_row(cref_w, dst_w); } }
             }
         }
+        MI_LPROF(9);
         // ---- the whole tree's U-turn test (:286-289): a dot product over dimensions, so every wave of the workgroup takes part
         //      whenever some chain of the workgroup was at the last leaf of its doubling
-        MI_LPROF(9);
         bool s_ok = false;
 #ifdef MI_NUTS_LDS_PROF
         if (wg_complete) n_top_++;
@@ -591,34 +657,13 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     if (blockIdx.x == 0 && lane == 0) {
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += prof_[i];
-        printf("[nuts_lds prof] wave %d: %llu ticks, %llu phases, %llu tree tests, %.1f k cycles per tick | vote %.1f%% phaseA %.1f%% top-loads %.1f%% kick+drift %.1f%% "
+        printf("[nuts_lds prof] wave %d: %llu ticks (%.1f of 16 slots busy), %llu phases, %llu tree tests, %.1f k cycles per tick | vote %.1f%% phaseA %.1f%% top-loads %.1f%% kick+drift %.1f%% "
                "eval %.1f%% kick2+dots %.1f%% exchange %.1f%% stores %.1f%% unwind %.1f%% take/pending %.1f%% tree-test %.1f%% fin %.1f%%\n",
-               wv, n_ticks_, n_phase_, n_top_, (double)tot / (double)(n_ticks_ ? n_ticks_ : 1) / 1e3,
+               wv, n_ticks_, (double)n_lane_ticks_ / (double)(n_ticks_ ? n_ticks_ : 1), n_phase_, n_top_, (double)tot / (double)(n_ticks_ ? n_ticks_ : 1) / 1e3,
                100.0 * prof_[0] / tot, 100.0 * prof_[1] / tot, 100.0 * prof_[2] / tot, 100.0 * prof_[3] / tot, 100.0 * prof_[4] / tot, 100.0 * prof_[5] / tot,
                100.0 * prof_[6] / tot, 100.0 * prof_[7] / tot, 100.0 * prof_[8] / tot, 100.0 * prof_[9] / tot, 100.0 * prof_[10] / tot, 100.0 * prof_[11] / tot);
     }
 #endif
-
-    if (live && nf && prm.nf_flag != nullptr) { if (q == 0 && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; } }
-    if (live && !(nf && prm.nf_flag != nullptr)) {
-        // rows still owed (the last draw's row is written by the phase that retires the chain: nothing is pending here)
-#pragma unroll
-        for (int c0 = 0; c0 < NS; c0 += CH) {
-            double tmp[CH];
-            ld_row(pvec(pb), c0, tmp);
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const uint32_t dim = dim_of(c0 + k);
-                if (dim < d) prm.theta[(size_t)dim * C + cl] = tmp[k];
-            }
-        }
-        if (q == 0 && j4 == 0) {
-            if (prm.n_accept) prm.n_accept[cl] = n_acc;
-            if (prm.n_leap_out) prm.n_leap_out[cl] = n_leap;
-            if (prm.step_out) prm.step_out[cl] = eps;
-            if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
-        }
-    }
 }
 
 }  // namespace mi
