@@ -37,6 +37,8 @@
 // experiments only (tools/build_variant.sh)
 #ifdef MI_NUTS_LDS_PROF
 #define MI_LPROF(i) do { const unsigned long long t_ = clock64(); prof_[i] += t_ - tp_; tp_ = t_; } while (0)
+#elif defined(MI_NUTS_LDS_SECTIONS)
+#define MI_LPROF(i) __builtin_amdgcn_sched_barrier(0)       // (experiment: the sections of the profile as scheduling regions)
 #else
 #define MI_LPROF(i) do { } while (0)
 #endif
@@ -654,6 +656,13 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         MI_LPROF(11);
     }
 #ifdef MI_NUTS_LDS_PROF
+#if MI_NUTS_LDS_PROF == 2
+    if (wv == 0 && lane == 0) {      // every workgroup: its ticks and cycles (which one is the last to finish?)
+        unsigned long long tot2 = 0;
+        for (int i = 0; i < 12; ++i) tot2 += prof_[i];
+        printf("[nuts_lds wg] %u %llu %llu\n", (unsigned)blockIdx.x, n_ticks_, tot2);
+    }
+#endif
     if (blockIdx.x == 0 && lane == 0) {
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += prof_[i];

@@ -6,7 +6,8 @@ import numpy as np, torch, mcmc_amd
 from mcmc_amd import synth
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-SHAPES = [("dense", 256, 0, 4096, 20), ("dense", 512, 0, 4096, 10), ("logistic", 512, 1024, 4096, 10), ("dense", 256, 0, 16384, 20), ("logistic", 512, 1024, 16384, 10)]
+SHAPES = [("dense", 256, 0, 4096, 20), ("dense", 512, 0, 4096, 10), ("logistic", 512, 1024, 4096, 10), ("dense", 256, 0, 16384, 20), ("logistic", 512, 1024, 16384, 10),
+          ("dense", 256, 0, 65536, 20), ("dense", 512, 0, 32768, 10), ("logistic", 512, 1024, 65536, 10)]
 if quick: SHAPES = SHAPES[:3]
 for kind, d, n_rows, Cn, nd in SHAPES:
     res = {}
