@@ -27,6 +27,9 @@ struct LogitParams {
     const double* m_inv;
     const double* m;        // mala with a diagonal precond_mat: its diagonal and the diagonal of INV(eps^2 M) (padded likewise); m_sqrt as above
     const double* s_inv;
+    const int* btype;       // hmc / nuts with settings.vals_bound (lds_box.hpp): bounds type 1..4, lower / upper bound of every dimension on the device, PADDED to
+    const double* lb;       // 512 entries with type 1 -- or nullptr = unbounded.  With them m_sqrt / m_inv are set too (ones for the identity).
+    const double* ub;
     double* xexch;          // dense Gaussian target only: [chain tile][4 NSQ][64] the position of an evaluation, shared by the tile's four waves
     // nuts (nuts_lds.hpp): workspace vectors / per-chain scalars of every wave (set by the launcher), outputs and the dual-averaging settings
     double* nuts_ws;

@@ -25,6 +25,7 @@
 #include "hmc_dense.hpp"
 #include "logistic_launch.hpp"
 #include "nuts_lds.hpp"
+#include "lds_box.hpp"
 
 #ifndef MI_LOGIT_ABLATE
 #define MI_LOGIT_ABLATE 0
@@ -35,6 +36,8 @@
 
 namespace mi {
 
+
+constexpr int LOGIT_STATE_VECS = 3;      // workspace vectors of a wave: accepted (beta, grad); BOUNDS: theta across an evaluation
 
 template <int NTQ>
 struct LogitGeo {
@@ -58,7 +61,7 @@ inline size_t logit_lds_ws_doubles(uint32_t NB, uint64_t C, int target, int algo
 {
     using G = LogitGeo<NTQ>;
     const size_t n_wg = (C + 31) / 32;
-    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * 2 * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0)
+    return (size_t)NB * G::XBUF_PAD + n_wg * 8 * LOGIT_STATE_VECS * G::NSQ * 64 + (target == LOGIT_TARGET_DENSE ? n_wg * 2 * 4 * G::NSQ * 64 : 0)
            + (algo == LOGIT_NUTS ? n_wg * 8 * (lds_nuts::vec_doubles_per_wave(G::NSQ) + lds_nuts::sc_doubles_per_wave()) + 32 : 0);   // (+ the chain counter)
 }
 // (logistic_nuts.hip: the nuts instantiations are a translation unit of their own)
@@ -90,9 +93,12 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
 // K = p.(p / m) / 2; mala.cpp:57-58,123,159 with mala.ipp:58-64: mean = x + eps^2 (m grad) / 2, noise eps sqrt(m) z, INV(eps^2 M) diagonal),
 // the tables read from global memory where they are used (LDS is full of X).  The reference's dense `inv_precond_matrix * mntm` is
 // handled like the identity's: the non-finite regime is detected through the energies and replayed by literal.hpp with the same tables.
-template <int NTQ, int ALGO, int TARGET, bool DIAGM = false>
+// BOUNDS (hmc, nuts): settings.vals_bound (lds_box.hpp) -- the sampler runs in the transformed space, the evaluation sees x = inv_transform(theta);
+// always together with DIAGM (tables of ones for the identity).
+template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
 {
+    static_assert(!BOUNDS || (DIAGM && (ALGO == LOGIT_HMC || ALGO == LOGIT_NUTS)), "bounds: hmc and nuts, with the mass tables");
     using G = LogitGeo<NTQ>;
     constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
     extern __shared__ double smem[];
@@ -119,7 +125,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
     const uint64_t chain = prm.chain0 + cl;
     double* const part = part_all + g * (4 * 4 * 64);
     double* const rt = rt_all + g * (4 * 2 * 64);
-    double* const ws_wave = prm.state + ((size_t)blockIdx.x * 8 + w) * ((size_t)2 * NSQ * 64) + lane;
+    double* const ws_wave = prm.state + ((size_t)blockIdx.x * 8 + w) * ((size_t)LOGIT_STATE_VECS * NSQ * 64) + lane;
     // Address of slice s of state vector v.  The base of each group of 8 slices is made opaque where it is used: otherwise the
     // compiler hoists all 2*NSQ loop-invariant 64-bit addresses out of the draw loop, spills them, and serialises every
     // workspace access behind a scratch reload of its address (reload, wait, load, wait).  Inside a group the 512-byte
@@ -487,16 +493,35 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
         const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + (live ? cl : C - 1)];
         bp[s] = (dim < d) ? v : 0.0;
     }
+    [[maybe_unused]] LdsBox<NTQ> box;
+    [[maybe_unused]] double* const lj_rel = part + (3 * 4) * 64 + 32;       // BOUNDS: the log-Jacobian relay of the tile (16 doubles)
+    if constexpr (BOUNDS && ALGO == LOGIT_HMC) {
+        box.init(prm.btype, prm.lb, prm.ub, d, q, lane);
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) bp[s] = (dim_of(s) < d) ? box.enter(bp[s], s) : 0.0;       // hmc.cpp:134-136
+    }
+    // BOUNDS: the evaluation at x = inv_transform(theta) (hmc.cpp:108); theta crosses it in the wave's third workspace vector
+    auto evaluate_at = [&](double (&t)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+        if constexpr (BOUNDS) {
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) *st(2, s) = t[s];
+            box.x_inplace(t);
+            evaluate(t, gout, lp);
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) t[s] = *st(2, s);
+        } else evaluate(t, gout, lp);
+    };
     issue_block(0, 0);
     wait_loads();
     if constexpr (ALGO == LOGIT_NUTS) {
         // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp); chains are
         // handed to the workgroup's 32 slots dynamically, their first evaluation is a state of that machine
-        nuts_lds_body<NTQ, DIAGM>(prm, evaluate, part_all);
+        nuts_lds_body<NTQ, DIAGM, BOUNDS>(prm, evaluate, part_all);
         return;
     }
     double first_lp;
-    evaluate(bp, gp, first_lp);         // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
+    evaluate_at(bp, gp, first_lp);      // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
+    if constexpr (BOUNDS) first_lp = first_lp + box.log_jacobian(bp, lj_rel, [&]() { __syncthreads(); });      // hmc.cpp:84-95
 #pragma unroll
     for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(1, s) = gp[s]; }
     uint64_t n_acc = 0;
@@ -523,14 +548,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
 #pragma unroll
                         for (int i = 0; i < SB; ++i) {
                             const uint32_t dim = dim_of(s0 + i);
-                            if (live && dim < d) out[(size_t)dim * C] = accept ? bp[s0 + i] : old[i];
+                            double v = accept ? bp[s0 + i] : old[i];
+                            if constexpr (BOUNDS) v = box.leave(v, s0 + i);      // rows are reported in the constrained space (hmc.cpp:211-218)
+                            if (live && dim < d) out[(size_t)dim * C] = v;
                         }
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < NSQ; ++s) {
                         const uint32_t dim = dim_of(s);
-                        if (live && dim < d) out[(size_t)dim * C] = bp[s];
+                        double v = bp[s];
+                        if constexpr (BOUNDS) v = box.leave(v, s);
+                        if (live && dim < d) out[(size_t)dim * C] = v;
                     }
                 }
             }
@@ -739,15 +768,21 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
             for (uint32_t k = 0; k < n_leap; ++k) {      // :164-176
 #pragma unroll
                 for (int s = 0; s < NSQ; ++s) {
-                    pm[s] = pm[s] + (eps * gp[s]) / 2.0; // first half-step (:126)
+                    if constexpr (BOUNDS) pm[s] = pm[s] + (eps * box.jgrad(bp[s], gp[s], s)) / 2.0;     // (:122,126) with the inverse Jacobian
+                    else pm[s] = pm[s] + (eps * gp[s]) / 2.0; // first half-step (:126)
                     if constexpr (DIAGM) bp[s] = bp[s] + eps * (mass_at(prm.m_inv, s) * pm[s]);   // (:171) theta += eps Minv p
                     else bp[s] = bp[s] + eps * pm[s];    // (:171)
                 }
-                evaluate(bp, gp, lp);
+                evaluate_at(bp, gp, lp);
 #pragma unroll
-                for (int s = 0; s < NSQ; ++s) pm[s] = pm[s] + (eps * gp[s]) / 2.0;     // second half-step (:175)
+                for (int s = 0; s < NSQ; ++s) {
+                    if constexpr (BOUNDS) pm[s] = pm[s] + (eps * box.jgrad(bp[s], gp[s], s)) / 2.0;
+                    else pm[s] = pm[s] + (eps * gp[s]) / 2.0;     // second half-step (:175)
+                }
             }
             const double prop_K = kinetic();
+            // BOUNDS: box_log_kernel adds log_jacobian(theta) (:84-95) -- only the end point's value is used (n_leap = 0: prev_U, exactly)
+            if constexpr (BOUNDS) { const double lj = box.log_jacobian(bp, lj_rel, [&]() { __syncthreads(); }); if (n_leap != 0u) lp = lp + lj; }
             double prop_U = -lp;                         // :178 (n_leap = 0: the value at the unchanged position)
             const bool u_nf = !is_finite(prop_U);
             if (u_nf) prop_U = INF;                      // :180-182
@@ -781,7 +816,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const Log
 #pragma unroll
         for (int s = 0; s < NSQ; ++s) {
             const uint32_t dim = dim_of(s);
-            const double v = *st(0, s);
+            double v = *st(0, s);
+            if constexpr (BOUNDS) v = box.leave(v, s);
             if (dim < d) prm.theta[(size_t)dim * C + cl] = v;
         }
         if (q == 0 && j4 == 0 && prm.n_accept) prm.n_accept[cl] = n_acc;

@@ -397,8 +397,11 @@ int fill_n_leap(uint64_t* dev_ptr, uint64_t n, uint64_t v, hipStream_t st)
 
 // LDS-staged logistic kernels (logistic_lds.hip): workspace from the per-stream cache, launch in their own translation unit
 int launched(const char* what, int hip_err);
+struct LdsTables;
+void lds_tables_replay(const LdsTables& t, const mi::LogitParams& q, mi::lit::LitParams& lp);
+bool lds_tables_active(const LdsTables* t);
 int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const double* y_dev, hipStream_t st,
-                 const mi_settings* settings, const mi_chains* dev_chains, int lds_target = mi::LOGIT_TARGET_LOGISTIC)
+                 const mi_settings* settings, const mi_chains* dev_chains, int lds_target = mi::LOGIT_TARGET_LOGISTIC, const LdsTables* lt = nullptr)
 {
     WsLease base;
     const bool replay = algo != mi::LOGIT_RWMH;          // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
@@ -425,7 +428,8 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
-        if (prm.m_sqrt != nullptr) {                     // a diagonal precond_mat (hmc: m_sqrt, m_inv; mala: m, m_sqrt, s_inv)
+        if (lds_tables_active(lt)) lds_tables_replay(*lt, prm, lp);      // hmc: bounds and / or a diagonal precond_mat
+        else if (prm.m_sqrt != nullptr) {                // a diagonal precond_mat (mala: m, m_sqrt, s_inv)
             lp.precond = 1; lp.m = prm.m; lp.m_sqrt = prm.m_sqrt; lp.m_inv = prm.m_inv; lp.sinv_diag = prm.s_inv;
         }
         return launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
@@ -712,6 +716,51 @@ bool precond_is_diagonal(const mi_settings* settings, uint64_t d)
     return true;
 }
 
+// settings.vals_bound and / or a DIAGONAL precond_mat for hmc / nuts on the LDS-streamed kernels (lds_box.hpp; logistic_lds.hpp DIAGM / BOUNDS):
+// determine_bounds_type (determine_bounds_type.hpp:27-57), the bounds, sqrt(m) and 1 / m -- on the device, padded to 512 entries with type 1 /
+// ones; with bounds the mass tables are always there (ones for the identity)
+struct LdsTables { DevBuf bt, lb, ub, m, ms, mi; bool bounds = false, mass = false; };
+int lds_tables(const char* who, const mi_settings* settings, uint64_t d, LdsTables& t, mi::LogitParams& q)
+{
+    t.bounds = settings->vals_bound != 0; t.mass = settings->precond_mat != nullptr;
+    if (!t.bounds && !t.mass) return MI_OK;
+    if (t.bounds && (!settings->lower_bounds || !settings->upper_bounds)) return fail(MI_ERR_BAD_ARG, "%s: vals_bound needs lower_bounds and upper_bounds", who);
+    std::vector<double> m(512, 1.0), ms(512, 1.0), mi_(512, 1.0), lbv(512, 0.0), ubv(512, 0.0);
+    std::vector<int> bt(512, 1);
+    if (t.mass) for (uint64_t i = 0; i < d; ++i) { const double v = settings->precond_mat[i * d + i]; m[i] = v; ms[i] = __builtin_sqrt(v); mi_[i] = 1.0 / v; }
+    if (t.bounds)
+        for (uint64_t i = 0; i < d; ++i) {
+            lbv[i] = settings->lower_bounds[i]; ubv[i] = settings->upper_bounds[i];
+            const bool fl = std::isfinite(lbv[i]), fu = std::isfinite(ubv[i]);
+            bt[i] = (fl && fu) ? 4 : (fl && !fu) ? 2 : (!fl && fu) ? 3 : 1;
+        }
+    HIP_TRY(t.m.alloc(512 * 8)); HIP_TRY(t.ms.alloc(512 * 8)); HIP_TRY(t.mi.alloc(512 * 8));
+    HIP_TRY(hipMemcpy(t.m.p, m.data(), 512 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.ms.p, ms.data(), 512 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.mi.p, mi_.data(), 512 * 8, hipMemcpyHostToDevice));
+    q.m_sqrt = t.ms.as<double>(); q.m_inv = t.mi.as<double>();
+    if (t.bounds) {
+        HIP_TRY(t.bt.alloc(512 * sizeof(int))); HIP_TRY(t.lb.alloc(512 * 8)); HIP_TRY(t.ub.alloc(512 * 8));
+        HIP_TRY(hipMemcpy(t.bt.p, bt.data(), 512 * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.lb.p, lbv.data(), 512 * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t.ub.p, ubv.data(), 512 * 8, hipMemcpyHostToDevice));
+        q.btype = t.bt.as<int>(); q.lb = t.lb.as<double>(); q.ub = t.ub.as<double>();
+    }
+    return MI_OK;
+}
+// the same tables for the literal replay behind such a launch (precond 1: M, sqrt(M), 1 / M element by element; literal_host.hpp)
+void lds_tables_replay(const LdsTables& t, const mi::LogitParams& q, mi::lit::LitParams& lp)
+{
+    if (t.mass) { lp.precond = 1; lp.m = t.m.as<double>(); lp.m_sqrt = q.m_sqrt; lp.m_inv = q.m_inv; }
+    if (t.bounds) { lp.vals_bound = 1; lp.btype = q.btype; lp.lb = q.lb; lp.ub = q.ub; }
+}
+bool lds_tables_active(const LdsTables* t) { return t != nullptr && (t->bounds || t->mass); }
+// hmc / nuts cases of settings the LDS-streamed kernels cover: no bounds / bounds, identity / diagonal precond_mat
+bool lds_general_ok(const mi_target* target, const mi_settings* settings)
+{
+    return target->kernel_hint != MI_KERNEL_LITERAL && (!settings->precond_mat || precond_is_diagonal(settings, target->d));
+}
+
 // hmc / rwmh on the logistic-regression target (identity preconditioner / cov_mat, no bounds): logit_lds_kernel<., HMC | RWMH>;
 // settings->step_size is the leapfrog step resp. par_scale
 int run_logit_plain(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -742,19 +791,16 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.n_leap = (uint32_t)settings->n_leap_steps;
     q.eps = settings->step_size;
     q.draw0 = (uint32_t)chains->draw0;
-    DiagMass dm;
-    if (algo == mi::LOGIT_HMC && settings->precond_mat) {      // (the caller routed a DIAGONAL matrix without bounds here)
-        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
-        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
-    }
-    rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev);
+    LdsTables lt;
+    if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
+    rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev, mi::LOGIT_TARGET_LOGISTIC, &lt);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
                      algo == mi::LOGIT_HMC ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (Xo.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (Xo.p || lt.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -791,21 +837,18 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
         q.s2 = s2; q.rs = 1.0 / s2; q.log_det = log_det;
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
     }
-    DiagMass dm;
+    LdsTables lt;
     MalaDiagMass mdm;
-    if (algo == mi::LOGIT_HMC && settings->precond_mat) {      // (the caller routed a DIAGONAL matrix without bounds here)
-        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
-        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
-    }
+    if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
     if (algo == mi::LOGIT_MALA && settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }
-    rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE);
+    rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE, &lt);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
                      algo == mi::LOGIT_HMC ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (P_owned.p || dm.ms.p || mdm.m.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (P_owned.p || lt.ms.p || mdm.m.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -1169,7 +1212,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
         // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation: two tables read from global memory)
-        const bool diag_alone = !settings->vals_bound && precond_is_diagonal(settings, d) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+        // ... and so do bounds (its BOUNDS instantiation, lds_box.hpp), with the identity or a diagonal matrix
+        const bool diag_alone = (settings->vals_bound || settings->precond_mat) && lds_general_ok(target, settings) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
         if ((settings->vals_bound || settings->precond_mat) && !diag_alone)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("hmc", 0, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
         return d <= 512 ? run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
@@ -1194,8 +1238,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     }
     // beyond d = 128 the tiled kernels serve separable targets without bounds (identity or diagonal precond_mat: hmc_diag.hpp);
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
-    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && (!settings->precond_mat || !dense_m))
-        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && (!settings->precond_mat || !dense_m) && target->kernel_hint != MI_KERNEL_LITERAL)
+        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat, with or without bounds
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -1895,11 +1939,8 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     q.max_depth = (uint32_t)settings->max_tree_depth;
     q.delta = settings->target_accept_rate; q.eps_bar0 = settings->step_size;
     q.gamma = settings->gamma_val; q.t0 = settings->t0_val; q.kappa = settings->kappa_val;
-    DiagMass dm;
-    if (settings->precond_mat) {                         // (the caller routed a DIAGONAL matrix without bounds here)
-        if ((rc = diag_mass_upload(settings, d, dm))) return rc;
-        q.m_sqrt = dm.ms.as<double>(); q.m_inv = dm.mi.as<double>();
-    }
+    LdsTables lt;
+    if ((rc = lds_tables("nuts", settings, d, lt, q))) return rc;      // (the caller routed bounds / a DIAGONAL matrix here)
 
     // workspace: the kernel's own | non-finite flags | the matrix transposed and the work areas of the literal replay
     ReplayWs rp;
@@ -1934,30 +1975,21 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
         lp.n_adapt = q.n_adapt; lp.max_depth = q.max_depth;
         lp.delta = q.delta; lp.gamma = q.gamma; lp.t0 = q.t0; lp.kappa = q.kappa;
         lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth; lp.adapt_state = sc.dev.nuts_adapt_state;
-        DevBuf m_dev;
-        if (q.m_sqrt != nullptr) {                       // the replay's tables: M, sqrt(M), 1 / M element by element (literal_host.hpp)
-            std::vector<double> m(d);
-            for (uint64_t i = 0; i < d; ++i) m[i] = settings->precond_mat[i * d + i];
-            HIP_TRY(m_dev.alloc(d * 8));
-            HIP_TRY(hipMemcpy(m_dev.p, m.data(), d * 8, hipMemcpyHostToDevice));
-            lp.precond = 1; lp.m = m_dev.as<double>(); lp.m_sqrt = q.m_sqrt; lp.m_inv = q.m_inv;
-        }
+        lds_tables_replay(lt, q, lp);
         rc = launched("LDS-streamed nuts kernel (literal replay)", mi::launch_literal(2, lp, rp.n_wg, st));
-        if (!rc && m_dev.p) HIP_TRY(hipStreamSynchronize(st));
+
         if (rc) return rc;
         mi::host::last_kernel() = lds_name;
     }
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (Xo.p || P_owned.p || dm.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (Xo.p || P_owned.p || lt.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 // the cases nuts_lds.hpp covers (everything else on these targets: literal.hpp)
 bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
 {
-    return target->kernel_hint != MI_KERNEL_LITERAL && !settings->vals_bound
-           && (!settings->precond_mat || precond_is_diagonal(settings, target->d))
-           && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
+    return lds_general_ok(target, settings) && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
 }
 
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)

@@ -32,6 +32,7 @@
 #pragma once
 
 #include "logistic_launch.hpp"
+#include "lds_box.hpp"
 
 // -DMI_NUTS_LDS_PROF: shader-clock totals per section of the tick (workgroup 0, every wave), printed by the kernel when it ends -- timing
 // experiments only (tools/build_variant.sh)
@@ -53,6 +54,7 @@ enum : int {
     V_PP0 = 40,              // pending proposal of level l >= 1 at 40 + l, its gradient at 52 + l
     V_PPW0 = 52,
     V_TMPP = 40,             // the momentum across an evaluation (wide tiles)
+    V_TMPT = 52,             // BOUNDS: theta across an evaluation (the registers hold x = inv_transform(theta) meanwhile)
     NVEC = 64,
     MAX_DEPTH = 10,
     LVLS = 12,
@@ -67,7 +69,10 @@ __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 *
 
 // DIAGM: a DIAGONAL precond_mat (nuts.cpp:57-59,168,202-204,139-154: p = sqrt(m) z, K = p.(p / m) / 2, theta += e (p / m); the U-turn dots
 // are plain), tables read from global memory where they are used (prm.m_sqrt, prm.m_inv: padded with ones to 64 NTQ entries).
-template <int NTQ, bool DIAGM, class Eval>
+// BOUNDS: settings.vals_bound (lds_box.hpp): the tree lives in the transformed space (the U-turn dots are plain), the target is evaluated at
+// x = inv_transform(theta), the kicks carry the inverse Jacobian, the potential the log-Jacobian, rows are reported through inv_transform.
+// Always together with DIAGM (tables of ones for the identity: 1.0 * p is p).
+template <int NTQ, bool DIAGM, bool BOUNDS, class Eval>
 __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all)
 {
     using namespace lds_nuts;
@@ -178,10 +183,17 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     // the chain's last leaf on this wave's dims: position, momentum, GRADIENT of the log kernel at the position (MFMA B / D layout)
     double th[NS], pm[NS], w[NS];
     double val = 0.0;
+    static_assert(!BOUNDS || DIAGM, "the bounded variant reads the mass tables");
+    [[maybe_unused]] LdsBox<NTQ> box;
+    if constexpr (BOUNDS) box.init(prm.btype, prm.lb, prm.ub, d, q, lane);
+    [[maybe_unused]] double* const lj_rel = part + FLAG_AT + 32;             // the log-Jacobian relay of the tile: 16 doubles
     bool nf = false;                                     // the chain reached the non-finite regime: flagged, replayed by literal.hpp
     auto kick = [&](double e) __attribute__((always_inline)) {               // p += (e grad) / 2 (nuts.cpp:108-135)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) pm[s] = pm[s] + (e * w[s]) / 2.0;
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (BOUNDS) pm[s] = pm[s] + (e * box.jgrad(th[s], w[s], s)) / 2.0;     // (hmc.cpp:122,126 / nuts.cpp:108-135)
+            else pm[s] = pm[s] + (e * w[s]) / 2.0;
+        }
     };
     auto drift = [&](double e) __attribute__((always_inline)) {              // theta += e (Minv p), Minv = I or diagonal (nuts.cpp:139-154)
 #pragma unroll
@@ -264,6 +276,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const uint32_t dim = dim_of(c0 + k);
+                    if constexpr (BOUNDS) tmp[k] = box.leave(tmp[k], c0 + k);      // rows are reported in the constrained space
                     if (dim < d) out[(size_t)dim * C] = tmp[k];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -296,6 +309,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const uint32_t dim = dim_of(c0 + k);
+                    if constexpr (BOUNDS) tmp[k] = box.leave(tmp[k], c0 + k);
                     if (dim < d) prm.theta[(size_t)dim * C + cl] = tmp[k];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -444,7 +458,8 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t dim = dim_of(s);
                     const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cl];
-                    th[s] = (dim < d) ? v : 0.0;
+                    if constexpr (BOUNDS) th[s] = (dim < d) ? box.enter(v, s) : 0.0;      // nuts.cpp:160-162
+                    else th[s] = (dim < d) ? v : 0.0;
                 }
             }
 #pragma unroll 1
@@ -460,7 +475,9 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         }
         MI_LPROF(3);
         if constexpr (PM_MEM) st_row(V_TMPP, 0, pm);
+        if constexpr (BOUNDS) { st_row(V_TMPT, 0, th); box.x_inplace(th); }      // the target sees x = inv_transform(theta) (hmc.cpp:108)
         evaluate(th, w, val);
+        if constexpr (BOUNDS) ld_row(V_TMPT, 0, th);
         if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
         MI_LPROF(4);
         // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
@@ -474,7 +491,8 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int s = c0 + k;
-                pm[s] = pm[s] + (e_tick * w[s]) / 2.0;
+                if constexpr (BOUNDS) pm[s] = pm[s] + (e_tick * box.jgrad(th[s], w[s], s)) / 2.0;
+                else pm[s] = pm[s] + (e_tick * w[s]) / 2.0;
                 const double dd = (vdir > 0) ? (th[s] - tb[k]) : (tb[k] - th[s]);
                 q1 = dfma(dd, pbv[k], q1);
                 q2 = dfma(dd, pm[s], q2);
@@ -490,6 +508,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         q1 = v3[0]; q2 = v3[1];
         const double pK = v3[2] / 2.0;                   // nuts.ipp:140 / :51,66
         double pU = -val;                                // nuts.ipp:134-138 / :50,65
+        if constexpr (BOUNDS) pU = -(val + box.log_jacobian(th, lj_rel, [&]() { __syncthreads(); }));     // -box_log_kernel(theta), nuts.cpp:84-95
         const bool u_nf = !is_finite(pU);
         // ---- INIT: the chain's first state is on record; SEARCH: one step of nuts_find_initial_step_size
         if (any(init)) {

@@ -39,9 +39,9 @@ def test_dense_gradient_targets_beyond_d128(algo, d, eps, general):
     st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=3, step_size=eps, n_adapt_draws=3,
                                    max_tree_depth=5, **kw)
     g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=5)
-    # plain hmc / mala / rwmh / nuts up to d = 512: P streamed through LDS (tests/test_gpu_parity_dense_lds.py, test_gpu_parity_nuts_lds.py);
-    # everything else literally
-    assert mcmc_amd.last_kernel().startswith("literal_kernel<" if general else "logit_lds_kernel<")
+    # plain hmc / mala / rwmh / nuts up to d = 512: P streamed through LDS (tests/test_gpu_parity_dense_lds.py, test_gpu_parity_nuts_lds.py),
+    # hmc / nuts also with bounds and a diagonal precond_mat (tests/test_gpu_lds_bounds.py); everything else literally
+    assert mcmc_amd.last_kernel().startswith("literal_kernel<" if general and algo in ("mala", "rwmh") else "logit_lds_kernel<")
     blk = dict(blocks=4, block_size=48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128)   # dot products over the four dimension quarters (128 < d <= 512)
     s = orc.make_settings(seed=3, n_burnin=2, n_keep=4, n_leap=3, step=eps, n_adapt=3, max_depth=5, W=4, hoist=1, **okw, **blk)
     o_draws, o = orc.run_many(ALGO[algo], orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **blk), init, s, chain0=5)

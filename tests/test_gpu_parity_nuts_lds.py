@@ -128,14 +128,32 @@ def test_lds_nuts_non_finite_chains_are_replayed_literally(kind, d, n_rows):
     _same(g_draws, g, o_draws, o, depth=False)
 
 
+@pytest.mark.parametrize("kind,d,n_rows", [("logistic", 300, 24), ("dense", 192, 0)])
+def test_lds_nuts_results_do_not_depend_on_sharding_or_slot(kind, d, n_rows):
+    """chains shard by GLOBAL chain id.  One call over 100 chains against three calls over [0, 37), [37, 69), [69, 100) with
+    chain0 set -- a chain lands in a different slot of a different workgroup each time (nuts_lds.hpp hands chains to slots dynamically);
+    its draws, step size, tree depths and leapfrog count are the same bits."""
+    C = 100
+    tk, tkw, _ = _problem(kind, d, n_rows, seed=31)
+    init = synth.initial_states(C, d, seed=13) * (0.1 if kind == "logistic" else 0.5)
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=5, n_keep_draws=4, n_adapt_draws=5, max_tree_depth=6, step_size=0.05)
+    w_draws, w = mcmc_amd.sample("nuts", tk, init, st, chain0=1000, **tkw)
+    for lo, hi in ((0, 37), (37, 69), (69, 100)):
+        p_draws, p = mcmc_amd.sample("nuts", tk, init[lo:hi], st, chain0=1000 + lo, **tkw)
+        assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
+        assert np.array_equal(p_draws, w_draws[:, :, lo:hi])
+        for k in ("n_accept", "n_leap", "eps"):
+            assert np.array_equal(p[k], w[k][lo:hi])
+        assert np.array_equal(p["depth"], w["depth"][:, lo:hi]) and np.array_equal(p["theta"], w["theta"][:, lo:hi])
+
+
 def test_lds_nuts_refusals_and_fallbacks_are_the_documented_ones():
     d, C = 160, 4
     prec = synth.dense_gaussian_precision(d, seed=1)
     init = synth.initial_states(C, d, seed=1) * 0.5
-    # bounds / a dense preconditioner / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal
+    # a dense preconditioner / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal (bounds: tests/test_gpu_lds_bounds.py)
     A = np.random.default_rng(3).standard_normal((d, d)) / np.sqrt(d)
-    for kw in (dict(precond_mat=A @ A.T + np.eye(d)), dict(vals_bound=1, lower_bounds=np.full(d, -5.0), upper_bounds=np.full(d, 5.0)),
-               dict(max_tree_depth=11), dict(max_tree_depth=0)):
+    for kw in (dict(precond_mat=A @ A.T + np.eye(d)), dict(max_tree_depth=11), dict(max_tree_depth=0)):
         st = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=1, n_keep_draws=1, n_adapt_draws=1, step_size=0.1, **{"max_tree_depth": 3, **kw})
         mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
         assert mcmc_amd.last_kernel().startswith("literal_kernel<")
