@@ -104,13 +104,16 @@ def test_one_lane_engine_and_lds_kernel_give_the_same_bits(algo, step, L, d):
     assert np.array_equal(a, b) and np.array_equal(ga["n_accept"], gb["n_accept"])
 
 
-def test_logistic_nuts_beyond_8_dims_runs_on_the_literal_kernel():
+def test_logistic_nuts_beyond_8_dims_runs_on_the_lds_streamed_kernel_and_on_the_literal_kernel_by_request():
     d, C = 9, 6
     X, y = synth.logistic_problem(d, 30, seed=1)
     init = synth.initial_states(C, d, seed=2) * 0.3
     st = mcmc_amd.default_settings(rng_seed_value=4, n_burnin_draws=2, n_keep_draws=3, n_adapt_draws=2, max_tree_depth=4)
     g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    assert mcmc_amd.last_kernel() == "logit_lds_kernel<1, nuts, 0, false>"     # round 4 (nuts_lds.hpp); round 3: the literal kernel
+    l_draws, l = mcmc_amd.nuts(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, kernel_hint=mcmc_amd.KERNEL_LITERAL)
     assert mcmc_amd.last_kernel() == "literal_kernel<2>"
+    assert np.array_equal(g_draws, l_draws) and np.array_equal(g["n_leap"], l["n_leap"]) and np.array_equal(g["eps"], l["eps"])
     t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=16, eta_chains=2)
     s = orc.make_settings(seed=4, n_burnin=2, n_keep=3, n_adapt=2, max_depth=4, step=float(st.step_size), W=4, blocks=4, block_size=16)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s)
