@@ -48,6 +48,16 @@ def cases():
     yield "mala_normal2", normal2, dict(algo=orc.ALGO_MALA, step=0.15)
     yield "nuts_normal2", normal2, dict(algo=orc.ALGO_NUTS, step=1.0, n_adapt=10)
     yield "rwmh_normal2", normal2, dict(algo=orc.ALGO_RWMH, step=0.15)
+    # round 4: the LDS-streamed evaluation under nuts (nuts_lds.hpp) and with bounds (lds_box.hpp) -- reduction orders over four dimension quarters
+    X40, y40 = synth.logistic_problem(40, 30, seed=6)
+    P160 = synth.dense_gaussian_precision(160, seed=7)
+    logit40 = dict(kind=orc.TARGET_LOGISTIC, d=40, X=X40, y=y40, blocks=4, block_size=16, eta_chains=2, init_scale=0.2)
+    dense160 = dict(kind=orc.TARGET_DENSE, d=160, prec=P160, blocks=4, block_size=48)
+    box = lambda d: dict(lower=np.where(np.arange(d) % 3 == 0, -1.5, -np.inf), upper=np.where(np.arange(d) % 4 == 0, 2.0, np.inf))
+    yield "nuts_logit40", logit40, dict(algo=orc.ALGO_NUTS, step=0.1, n_adapt=10, max_depth=6)
+    yield "nuts_dense160", dense160, dict(algo=orc.ALGO_NUTS, step=0.1, n_adapt=10, max_depth=6)
+    yield "hmc_logit40box", dict(logit40, **box(40)), dict(algo=orc.ALGO_HMC, n_leap=4, step=0.05)
+    yield "nuts_dense160box", dict(dense160, **box(160)), dict(algo=orc.ALGO_NUTS, step=0.05, n_adapt=10, max_depth=5)
 
 
 def run_case(t, a):
@@ -56,12 +66,13 @@ def run_case(t, a):
     W = t.get("W", 4)
     tgt = orc.TargetSpec(t["kind"], d, prec=t.get("prec"), X=t.get("X"), y=t.get("y"), W=W, blocks=blocks, block_size=bs,
                          eta_chains=t.get("eta_chains", 1))
-    init = synth.initial_states(C, d, seed=99) * 0.5 + t.get("init_shift", 0.0)
+    init = synth.initial_states(C, d, seed=99) * t.get("init_scale", 0.5) + t.get("init_shift", 0.0)
+    if "lower" in t: init = np.clip(init, -1.0, 1.5)
     out = dict(draws=[], accept=[], depth=[], eps=[], n_leap=[])
     for c in range(C):
         s = orc.make_settings(seed=SEED, n_burnin=BURN, n_keep=KEEP, n_leap=a.get("n_leap", 1), step=a["step"],
                               n_adapt=a.get("n_adapt", 1000), W=W, hoist=1, blocks=blocks, block_size=bs, chain_id=c,
-                              n_fp=a.get("n_fp", 5))
+                              n_fp=a.get("n_fp", 5), max_depth=a.get("max_depth", 10), lower=t.get("lower"), upper=t.get("upper"))
         dr, info = orc.run_chain(a["algo"], tgt, init[c], s, traces=True)
         out["draws"].append(dr); out["accept"].append(info["accept"]); out["depth"].append(info["depth"])
         out["eps"].append(info["eps"]); out["n_leap"].append(info["n_leap"])

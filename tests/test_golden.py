@@ -43,13 +43,16 @@ def test_engine_reproduces_golden(name):
     algo, tname = name.split("_")
     t, a = {n: (t, a) for n, t, a in G.cases()}[name]
     kind = {"iso3": mcmc_amd.TARGET_GAUSS_ISO, "dense8": mcmc_amd.TARGET_GAUSS_DENSE, "logit5": mcmc_amd.TARGET_LOGISTIC,
-            "normal2": mcmc_amd.TARGET_NORMAL_MODEL}[tname]
+            "normal2": mcmc_amd.TARGET_NORMAL_MODEL, "logit40": mcmc_amd.TARGET_LOGISTIC, "dense160": mcmc_amd.TARGET_GAUSS_DENSE,
+            "logit40box": mcmc_amd.TARGET_LOGISTIC, "dense160box": mcmc_amd.TARGET_GAUSS_DENSE}[tname]
+    bkw = dict(vals_bound=1, lower_bounds=t["lower"], upper_bounds=t["upper"]) if "lower" in t else {}
     st = mcmc_amd.default_settings(rng_seed_value=G.SEED, n_burnin_draws=G.BURN, n_keep_draws=G.KEEP,
                                    n_leap_steps=a.get("n_leap", 1), step_size=a["step"], n_adapt_draws=a.get("n_adapt", 1000),
-                                   n_fp_steps=a.get("n_fp", 5))
+                                   n_fp_steps=a.get("n_fp", 5), max_tree_depth=a.get("max_depth", 10), **bkw)
     draws, g = mcmc_amd.sample(algo, kind, KAT[f"{name}/init"], st, prec=t.get("prec"), X=t.get("X"), y=t.get("y"))
     want = np.transpose(KAT[f"{name}/draws"], (1, 2, 0))            # [C, n_keep, d] -> [n_keep, d, C]
     assert np.array_equal(draws, want)
+    if tname in ("logit40", "dense160", "logit40box", "dense160box"): assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
     assert np.array_equal(g["n_accept"], KAT[f"{name}/accept"][:, G.BURN:].sum(axis=1).astype(np.uint64))
     if algo == "nuts":
         assert np.array_equal(g["depth"], KAT[f"{name}/depth"].T)
