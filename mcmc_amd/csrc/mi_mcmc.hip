@@ -1213,8 +1213,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
         // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation: two tables read from global memory)
         // ... and so do bounds (its BOUNDS instantiation, lds_box.hpp), with the identity or a diagonal matrix
-        const bool diag_alone = (settings->vals_bound || settings->precond_mat) && lds_general_ok(target, settings) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
-        if ((settings->vals_bound || settings->precond_mat) && !diag_alone)
+        const bool lds_general = (settings->vals_bound || settings->precond_mat) && lds_general_ok(target, settings) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+        if ((settings->vals_bound || settings->precond_mat) && !lds_general)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("hmc", 0, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
         return d <= 512 ? run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
     }
