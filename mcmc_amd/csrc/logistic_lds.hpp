@@ -95,8 +95,16 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
 // handled like the identity's: the non-finite regime is detected through the energies and replayed by literal.hpp with the same tables.
 // BOUNDS (hmc, nuts): settings.vals_bound (lds_box.hpp) -- the sampler runs in the transformed space, the evaluation sees x = inv_transform(theta);
 // always together with DIAGM (tables of ones for the identity).
+// waves per SIMD the register allocation is made for: the workgroup's 8 waves are two per SIMD.  (MI_LOGIT_NUTS_W1 = 4 compiles the narrowest
+// nuts instantiation for 128 registers, two workgroups per CU -- at d <= 64 an evaluation is the latency of the row terms, not matrix work.
+// Measured: SLOWER, 421 vs 296 ms at d = 64, N = 1 024, 16 384 chains and 91 vs 77 ms at d = 32, N = 256: 56 spilled registers, and twice
+// the chain slots leave nothing for the dynamic hand-out to balance.)
+#ifndef MI_LOGIT_NUTS_W1
+#define MI_LOGIT_NUTS_W1 2
+#endif
+template <int NTQ, int ALGO> constexpr int logit_waves_per_simd() { return (ALGO == LOGIT_NUTS && NTQ == 1) ? MI_LOGIT_NUTS_W1 : 2; }
 template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false>
-__global__ MI_NO_DS_MERGE __launch_bounds__(512) void logit_lds_kernel(const LogitParams prm)
+__global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO>())) void logit_lds_kernel(const LogitParams prm)
 {
     static_assert(!BOUNDS || (DIAGM && (ALGO == LOGIT_HMC || ALGO == LOGIT_NUTS)), "bounds: hmc and nuts, with the mass tables");
     using G = LogitGeo<NTQ>;
