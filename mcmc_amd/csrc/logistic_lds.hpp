@@ -6,7 +6,8 @@
 // Replaces the draw loops of mcmc::internal::mala_impl (/root/reference/src/mala.cpp:149-186, with mala_mean_fn :97-125,
 // mala_prop_adjustment /root/reference/include/mcmc/mala.ipp:30-70, stats_mcmc::dmvnorm
 // /root/reference/include/stats/dmvnorm.hpp:28-54) and mcmc::internal::hmc_impl (/root/reference/src/hmc.cpp:155-205),
-// identity preconditioner, no bounds.  The fused value+gradient evaluation is the reference's target_log_kernel callback.
+// identity preconditioner, no bounds (DIAGM: a diagonal precond_mat; BOUNDS, hmc: settings.vals_bound, lds_box.hpp; nuts: nuts_lds.hpp).  The fused
+// value+gradient evaluation is the reference's target_log_kernel callback.
 //
 // Why LDS: with X fragments streamed from L2 into registers (the first version of this kernel) every 8-byte operand fed one
 // MFMA of one 16-chain tile: 4 flop per L2 byte, and the kernel sat on the L2/MALL stream (6 TB/s at 25 TFLOP/s).  Here a workgroup of

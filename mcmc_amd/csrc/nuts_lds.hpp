@@ -3,7 +3,8 @@
 // LDS, shared by the 2 chain tiles x 4 dimension quarters of a workgroup.
 //
 // Replaces, for C independent chains, mcmc::internal::nuts_impl with nuts_find_initial_step_size and the recursive nuts_build_tree
-// (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity or DIAGONAL precond_mat, no bounds.
+// (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity or DIAGONAL precond_mat, with or without
+// settings.vals_bound (lds_box.hpp).
 //
 // The sampler is the asynchronous per-chain tree state machine of nuts_reg.hpp / include/mi_mcmc_engine/nuts_tile.hpp (iterative
 // leaf-indexed tree: nuts_dense.hpp; eager U-turn tests, momenta generated ahead, draw boundaries without waiting), with two changes
