@@ -85,9 +85,12 @@ typedef enum mi_kernel_hint {
                                             * for d <= 64) */
     MI_KERNEL_NUTS_SPLIT = 11,             /* nuts, same case, 64 < d <= 128: every tile split over two waves, two tiles per SIMD, so that one
                                             * tile's record traffic runs under the other's mat-vec (the default there) */
-    MI_KERNEL_LITERAL = 12                 /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
+    MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
                                             * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
+    MI_KERNEL_NUTS_DYN = 13                /* nuts, same case as MI_KERNEL_NUTS_REG: its tick with the chains handed to the lanes dynamically (a persistent
+                                            * grid; a lane whose chain is done takes the next one) -- the default when there are more chains than the chip
+                                            * has chain slots */
 } mi_kernel_hint;
 
 typedef struct mi_target {

@@ -31,6 +31,8 @@ int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
 // the plain case (unbounded, identity precond_mat) with register-carried leaf state (nuts_reg.hpp): the default NUTS kernel
 int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m = false);
+// nuts_dyn.hpp: the same tick, chains handed to the lanes dynamically (prm.next_chain: one uint32_t of device memory)
+int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
 // the plain case at d in (64, 128], every tile split over two waves, two tiles per SIMD (nuts_split.hpp); pfrag: 128 KB of device
 // scratch for the precision in fragment order (packed here, on the stream)
 int launch_nuts_gauss_split(const NutsParams& prm, int nt, int tiles_per_wg, double* pfrag, hipStream_t st);         // nuts_split_launch.hip

@@ -1992,6 +1992,17 @@ bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
     return lds_general_ok(target, settings) && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
 }
 
+// nuts_dyn.hpp instead of nuts_reg.hpp: on request, and by default when there are more chains than the chip has chain slots (then a slot
+// gets a second chain when its first one is done; with fewer chains the two kernels do the same thing)
+bool nuts_dynamic(const mi_target* target, uint64_t C)
+{
+    if (target->kernel_hint == MI_KERNEL_NUTS_DYN) return true;
+    if (target->kernel_hint != MI_KERNEL_AUTO) return false;
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
+}
+
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
     int rc = check_common(target, settings, chains);
@@ -2033,12 +2044,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
     const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t pfrag_bytes = (size_t)128 * 128 * sizeof(double);           // the precision in fragment order (nuts_gauss_split_kernel)
-    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + pfrag_bytes, ws);   // + non-finite flags + identity tables of the replay
+    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + pfrag_bytes + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
     uint32_t* const nf_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ws_own_r);
     double* const id_tab = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ws_own_r + flag_bytes);
     double* const pfrag = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ((ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 255) & ~(size_t)255));
+    prm.next_chain = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(pfrag) + pfrag_bytes);
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -2090,7 +2102,8 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
-        rc = launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st, true));
+        rc = nuts_dynamic(target, chains->n_chains) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st, true))
+                                                     : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st, true));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         mi::NutsParams rp = prm;
@@ -2121,10 +2134,12 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
         const uint64_t C_ = chains->n_chains;
         const bool few = C_ <= (uint64_t)32 * (uint64_t)n_cu;
-        const bool split = nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint != MI_KERNEL_NUTS_REG && few));
+        const bool split = nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint == MI_KERNEL_AUTO && few));
         const int tpw = !few ? 4 : (C_ > (uint64_t)16 * (uint64_t)n_cu ? 2 : 1);
+        // Many chains: the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp) -- a wave does not end with its slowest chain
         rc = split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, tpw, pfrag, st))
-                   : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
+           : nuts_dynamic(target, C_) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st))
+                                      : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         int* bt_i = reinterpret_cast<int*>(id_tab);

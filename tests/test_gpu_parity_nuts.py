@@ -50,7 +50,7 @@ CASES = [
 # the tiles split over two waves (nuts_split.hpp: KERNEL_NUTS_SPLIT forces it, with 1, 2 or 4 tiles per workgroup by the number of chains);
 # the tick-local asynchronous kernel (what the bounded / preconditioned variants run) must give the same bits.  (The lock-step
 # first-generation kernel, 2.4 KB of scratch per lane, is no longer in the shipped library: `make prof` keeps it for A/B runs.)
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL]
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN]
 
 
 @pytest.mark.parametrize("hint", KERNELS)

@@ -16,7 +16,7 @@ n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
 st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn)
 ref = None
 for rep in range(2):
-    for name, hint in (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)):
+    for name, hint in (("dyn", mcmc_amd.KERNEL_NUTS_DYN), ("reg", mcmc_amd.KERNEL_NUTS_REG)) if os.environ.get("MI_AB", "dyn") == "dyn" else (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)):
         t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
         ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, mem=mcmc_amd.MEM_DEVICE)
         theta.copy_(theta0)
