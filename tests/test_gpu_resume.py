@@ -51,7 +51,7 @@ def test_nuts_resumes_after_its_adaptation_window():
     assert e.value.code == mcmc_amd.MI_ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
+@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "dyn_d32", "dyn_diag_mass_d100", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
 @pytest.mark.parametrize("cut", [3, 9, 10, 14])
 def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     """checkpoint of (theta, eps, h, Philox counter).  n_adapt_draws = 10 of 12 burn-in + 6 kept draws; the run is cut after
@@ -59,8 +59,10 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     after it (14) -- and continued with step_size + nuts_adapt_state: bit-identical to the uncut run on every nuts kernel."""
     burn, keep, n_adapt, C = 12, 6, 10, 21
     kw, tkw = dict(max_tree_depth=5), {}
-    if route.startswith("reg") or route.startswith("general") or route.startswith("split"):
-        d = 32 if route.startswith("reg") else 100 if route.startswith("split") else 20     # (d = 100, few chains: nuts_gauss_split_kernel)
+    hint = mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_AUTO     # (nuts_dyn.hpp: chains handed to the lanes dynamically)
+    if route.startswith("reg") or route.startswith("general") or route.startswith("split") or route.startswith("dyn"):
+        d = 100 if route.endswith("d100") else 32 if (route.startswith("reg") or route.startswith("dyn")) else 20     # (split_d100, few chains: nuts_gauss_split_kernel)
+        if route.startswith("dyn"): C = 150
         kind = mcmc_amd.TARGET_GAUSS_DENSE; tkw = dict(prec=synth.dense_gaussian_precision(d, seed=2))
         if "diag_mass" in route: kw["precond_mat"] = np.diag(np.linspace(0.5, 2.0, d))
         if "dense_precond" in route:                          # (the general tick-local kernel; bounds are left out on purpose: a checkpoint holds
@@ -76,10 +78,12 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     if route == "small_normal_model": init = np.abs(init) + np.array([1.5, 1.5])
     S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=99, n_burnin_draws=b, n_keep_draws=k, n_adapt_draws=n_adapt, **kw)
     # the uncut run keeps every draw (burn-in included) so that the two halves can be compared row by row
-    w_draws, w = mcmc_amd.sample("nuts", kind, init, S(0, burn + keep), chain0=4, want_adapt_state=True, **tkw)
-    a_draws, a = mcmc_amd.sample("nuts", kind, init, S(0, cut), chain0=4, want_adapt_state=True, **tkw)
+    w_draws, w = mcmc_amd.sample("nuts", kind, init, S(0, burn + keep), chain0=4, want_adapt_state=True, kernel_hint=hint, **tkw)
+    a_draws, a = mcmc_amd.sample("nuts", kind, init, S(0, cut), chain0=4, want_adapt_state=True, kernel_hint=hint, **tkw)
     b_draws, b = mcmc_amd.sample("nuts", kind, a["theta"].T.copy(), S(0, burn + keep - cut), chain0=4, draw0=cut, step_size_in=a["eps"],
-                                 adapt_state_in=a["adapt_state"], **tkw)
+                                 adapt_state_in=a["adapt_state"], kernel_hint=hint, **tkw)
+    if route.startswith("dyn"):
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_dyn_kernel<")
     if route.startswith("split"):
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_split_kernel<8, ")
     assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
