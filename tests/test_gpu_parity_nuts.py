@@ -43,6 +43,8 @@ CASES = [
     ("dense", 100, 150, 3, 5, 5, 10, 1.0),       # three workgroups of the split kernel, the last tile partly live, d short of its row tiles
     ("dense", 128, 24, 0, 4, 0, 7, 0.02),        # fixed small step at d = 128: trees to the cap, every level of the unwind
     ("dense", 65, 16, 2, 3, 0, 0, 1.0),          # max_tree_depth = 0: the while-loop of nuts.cpp:227 never entered
+    ("dense", 128, 200, 10, 14, 12, 8, 1.0),     # four workgroups, the adaptation window ends inside the run (nuts_dyn.hpp: every chain in a slot of its own)
+    ("dense", 32, 300, 12, 20, 16, 10, 1.0),     # five workgroups of narrow tiles
 ]
 
 
