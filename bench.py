@@ -8,7 +8,8 @@ NUTS d=128, 65 536 chains, depth 10; one GPU's 131 072-chain shard of the d=1024
 own roofline object.  One "step" = one mi_mcmc_<algo>_run call = that whole sampling run for every chain of the rank, with
 target, initial states and output buffers already resident in HBM.
 
-Multi-GPU (torchrun, one rank per GPU): chains shard by global chain id (mcmc_amd.dist.shard_bounds) with no data-path
+Multi-GPU (one rank per GPU: under torchrun, or `--gpus N` alone -- bench.py then launches the N ranks itself through
+torch.distributed.run and FAILS if fewer than N GPUs are visible): chains shard by global chain id (mcmc_amd.dist.shard_bounds) with no data-path
 collective.  north_star asks for STRONG scaling at 65 536 chains, so with WORLD_SIZE > 1 the total chain count stays
 fixed and every rank takes its shard ("scaling": "strong"); `--scaling weak` keeps the per-GPU count fixed instead.
 `--collate` additionally times the one exchange the path has (RCCL all-gather of the kept draws, HBM to HBM).
@@ -18,7 +19,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   flops per launch / HIP-event duration measured here on the launch stream; `traffic` = HBM bytes per
                   launch, measured by two rocprofv3 --pmc child runs of this workload when rocprofv3 is on the box (--traffic),
                   else from the committed passes of this exact workload (profiles/r*_c<N>_pmc.json), else null
-  other_configs-- (default run, one GPU) BASELINE configs 3, 4, 5 under the same clock at --other-steps steps, each with its roofline
+  other_configs-- (default run, one GPU) BASELINE configs 3, 4, 5 under the same clock at --other-steps steps, each with its roofline, its own
+                  cpu_baseline and -- where BASELINE's frozen settings do not converge (configs[2], configs[4]) -- a `converged` leg outside the
+                  timed region that makes ESS/sec an estimate (CONVERGED below, frozen in BASELINE.md section 9)
+  scaling_proxy-- (default run, one GPU) the share of one GPU at N = 1, 2, 4, 8 (chains_total / N) of configs[1] and configs[3], timed here:
+                  a one-GPU PROXY of north_star's strong-scaling curve, labelled as such
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) timed on this box's host cores on a
                   bounded sample of the same workload: Mode A (reference-faithful work profile) and Mode B
                   (optimised CPU: same bits, gradient reuse, no identity mat-vecs, SIMD mat-vec), built with the
@@ -52,7 +57,7 @@ WORKLOADS = {
     4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
             name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
             metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",
-            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_reg_kernel<8, false>", bound="mfma"),
+            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_dyn_kernel<8, false>", bound="mfma"),
     5: dict(algo="hmc", d=1024, chains=131072, n_leap_steps=32, step_size=0.005, n_burnin_draws=20, n_keep_draws=8, seed=8,
             name="BASELINE configs[4], one GPU's shard: mcmc::hmc, d=1024 diagonal Gaussian (cond 1e4), 131072 of 2^20 chains, fp64",
             metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=1024 ill-conditioned Gaussian, 131072 chains per GPU",
@@ -141,17 +146,33 @@ def cpu_baseline(cfg_id, cfg):
     return out
 
 
-def profiled_traffic(cfg_id, key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes, if they are of this workload."""
-    for tag in ("r3", "r2"):
-        p = os.path.join(ROOT, "profiles", f"{tag}_c{cfg_id}_pmc.json")
+def profiled_traffic(cfg_id, key, kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r<N>_c<cfg>_pmc.json, newest round first) --
+    only from a profile of THIS workload (workload_key) and of THE KERNEL THAT JUST RAN (mi_mcmc_last_kernel): a figure measured on another
+    kernel is not this kernel's traffic.  Returns (bytes, source) or (None, why)."""
+    import glob
+    import re
+    cands = []
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_c{cfg_id}_pmc.json")):
+        m = re.match(r"r(\d+)_c\d+_pmc\.json$", os.path.basename(p))
+        if m:
+            cands.append((int(m.group(1)), p))
+    why = "no committed profile of this config"
+    for _, p in sorted(cands, reverse=True):
+        rel = os.path.relpath(p, ROOT)
         try:
             j = json.load(open(p))
-            if j.get("workload_key") == list(key):
-                return j["derived"]["hbm_bytes_per_launch"], f"profiles/{tag}_c{cfg_id}_pmc.json"
+            if j.get("workload_key") != list(key):
+                why = f"{rel}: another workload shape {j.get('workload_key')}"
+                continue
+            prof_kernel = j["derived"]["kernel"]
+            if kernel_name.split("(")[0].strip() not in prof_kernel:
+                why = f"{rel} profiled {prof_kernel.split('(')[0].replace('void mi::', '')}, this run launched {kernel_name}: not quoted"
+                continue
+            return j["derived"]["hbm_bytes_per_launch"], rel
         except (OSError, ValueError, KeyError):
-            pass
-    return None, None
+            continue
+    return None, why
 
 
 def measured_traffic(cfg_id, kernel, chains_arg):
@@ -173,7 +194,7 @@ def measured_traffic(cfg_id, kernel, chains_arg):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--config", str(cfg_id), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                    "--traffic", "none", "--no-ess"] + (["--chains", str(chains_arg)] if chains_arg else [])
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             tot, disp = 0.0, set()
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f, newline="")):
@@ -235,7 +256,66 @@ def extra_nuts_on_logistic(ctx):
                     "8 192 chain slots of the persistent grid dynamically, see DESIGN.md section 4.14"}
 
 
-def measure(cfg_id, steps, warmup, args, ctx, headline):
+# ESS/sec legs: BASELINE's frozen settings of configs[2] (step_size 0.02: accept 0.99996, the chains barely move) and
+# configs[4] (8 kept draws at M = I) give draws/sec but no ESS that is an estimate.  These legs run the SAME target and sampler, outside the
+# timed region, at settings under which the chains converge (R-hat < 1.1); the values are frozen in BASELINE.md section 9.
+CONVERGED = {
+    3: dict(chains=65536, step_size=0.46, n_burnin_draws=100, n_keep_draws=400,
+            what="mcmc::mala on configs[2]'s target, step_size 0.46 (accept ~ 0.58, ref: src/mala.cpp:170-173 -- the accept rule -- tuned on the "
+                 "CPU oracle), 100 burn-in + 400 kept draws, 65 536 chains (400 kept draws of 262 144 chains do not fit one GPU's HBM)"),
+    5: dict(chains=131072, step_size=0.12, n_burnin_draws=20, n_keep_draws=50, n_windows=3,
+            what="mi_mcmc_hmc_run_mass_adapted on configs[4]'s shard: pooled diagonal mass, 3 windows, step_size 0.12, 50 kept draws "
+                 "(NOT a reference mode: the reference has no mass adaptation; M = I at cond 1e4 does not mix in any affordable run)"),
+}
+
+
+def converged_leg(cfg_id, ctx):
+    """One run of CONVERGED[cfg_id] on rank 0's GPU, timed host-side around the call (synchronize on both sides); returns the dict that
+    goes under `converged` or None."""
+    import torch
+    import mcmc_amd
+    if cfg_id not in CONVERGED:
+        return None
+    cfg, cv = dict(WORKLOADS[cfg_id]), CONVERGED[cfg_id]
+    d, C, dev = cfg["d"], cv["chains"], ctx.dev
+    n_keep = cv["n_keep_draws"]
+    cfg_in = dict(cfg, chains=C) if cfg_id != 3 else cfg           # (the mala starts are spread by the FULL run's chain ids)
+    kw, init = build_inputs(cfg_in, C, 0)
+    kw_dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in kw.items()}
+    theta = torch.from_numpy(np.ascontiguousarray(init.T)).to(dev)
+    del init
+    draws = torch.empty((n_keep, d, C), dtype=torch.float64, device=dev)
+    n_accept = torch.zeros(C, dtype=torch.int64, device=dev)
+    kind = mcmc_amd.TARGET_LOGISTIC if cfg["algo"] == "mala" else mcmc_amd.TARGET_GAUSS_DIAG
+    target = mcmc_amd.make_target(kind, d, mem=mcmc_amd.MEM_DEVICE, **kw_dev)
+    skw = dict(rng_seed_value=cfg["seed"], n_burnin_draws=cv["n_burnin_draws"], n_keep_draws=n_keep, step_size=cv["step_size"])
+    if "n_leap_steps" in cfg:
+        skw["n_leap_steps"] = cfg["n_leap_steps"]
+    settings = mcmc_amd.default_settings(**skw)
+    chains = mcmc_amd.make_chains(theta, C, draws=draws, n_accept=n_accept, mem=mcmc_amd.MEM_DEVICE)
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if cfg_id == 5:
+        mcmc_amd.hmc_mass_adapted(target, settings, chains, n_windows=cv["n_windows"], stream=stream)
+    else:
+        mcmc_amd.run(cfg["algo"], target, settings, chains, stream=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = mcmc_amd.draw_stats(draws, n_keep, d, C, mem=mcmc_amd.MEM_DEVICE, stream=stream, want_acov=False)
+    rhat = float(stats["rhat"].max())
+    ess_chain = float(stats["ess"].min())
+    out = {"what": cv["what"], "chains": C, "step_size": cv["step_size"], "n_burnin_draws": cv["n_burnin_draws"], "n_keep_draws": n_keep,
+           "ms": dt * 1e3, "accept_rate": float(n_accept.double().mean().item()) / n_keep, "rhat_max": rhat,
+           "ess_per_chain_min_over_dims": ess_chain, "ess_per_sec": ess_chain * C / dt,
+           "ess_is_estimate": bool(n_keep >= 20 and rhat == rhat and rhat < 1.1), "kernel": mcmc_amd.last_kernel()}
+    del draws, theta, n_accept, kw_dev, target, chains
+    mcmc_amd.release_workspace()
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, want_traffic=True):
     """Times `steps` steps of one BASELINE config on this rank's GPU (barrier + synchronize on both sides, max over ranks).
     Returns the result dict on rank 0 (None elsewhere)."""
     import torch
@@ -245,11 +325,12 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
     cfg = dict(WORKLOADS[cfg_id])
     d, algo = cfg["d"], cfg["algo"]
     scaling = args.scaling or "strong"     # north_star: the chain total is fixed as N grows (at N = 1 the two coincide)
+    n_chains_arg = chains_override or args.chains
     if scaling == "weak":
-        C = args.chains or cfg["chains"]
-        chain0, total = rank * C, (args.chains or cfg["chains"]) * world
+        C = n_chains_arg or cfg["chains"]
+        chain0, total = rank * C, (n_chains_arg or cfg["chains"]) * world
     else:
-        total = args.chains or cfg["chains"]
+        total = n_chains_arg or cfg["chains"]
         chain0, C = mdist.shard_bounds(total, world, rank)              # balanced, no chain dropped
     n_keep, n_tot = cfg["n_keep_draws"], cfg["n_burnin_draws"] + cfg["n_keep_draws"]
 
@@ -362,7 +443,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
     # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region, its own
     # time reported next to it
     ess_total_rank, rhat_max, reducer_ms = 0.0, float("nan"), None
-    if C > 0 and rank == 0 and not args.no_ess:
+    if C > 0 and rank == 0 and not args.no_ess and chains_override is None:
         if not getattr(ctx, "stats_warm", False):           # untimed warm-up of the reducer's kernels (code-object load) on a tiny slab
             mcmc_amd.draw_stats(torch.randn((8, 2, 64), dtype=torch.float64, device=dev), 8, 2, 64, mem=mcmc_amd.MEM_DEVICE,
                                 stream=stream, want_acov=False)
@@ -386,14 +467,14 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
         achieved = units_rank * fpu / (k_ms * 1e-3) / 1e12
         key = (cfg_id, C, d, n_tot)
         traffic, traffic_src = None, None
-        want_pmc = args.traffic == "all" or (args.traffic == "headline" and headline)
+        want_pmc = want_traffic and (args.traffic == "all" or (args.traffic == "headline" and headline))
         if want_pmc and world == 1:
-            traffic, traffic_src = measured_traffic(cfg_id, kernel_name, args.chains)
-        if traffic is None:
+            traffic, traffic_src = measured_traffic(cfg_id, kernel_name, n_chains_arg)
+        if traffic is None and want_traffic:
             why = traffic_src
-            traffic, traffic_src = profiled_traffic(cfg_id, key)
+            traffic, traffic_src = profiled_traffic(cfg_id, key, kernel_name)
             if traffic is None and want_pmc:
-                traffic_src = why
+                traffic_src = f"{why}; {traffic_src}"
         out = {
             "metric": cfg["metric"], "value": value, "unit": cfg["unit"],
             "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -414,8 +495,12 @@ def measure(cfg_id, steps, warmup, args, ctx, headline):
         # what the launch moved.  `frac` stays the term of the bound SURVEY 8(d) assigns the config.
         units_per_s = units_rank / (k_ms * 1e-3)
         out["roofline"]["flops_term"] = {"achieved_TFLOPs": achieved, "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac": achieved / FP64_PEAK_TFLOPS}
+        bfrac = units_per_s * 32 / 8e12
         out["roofline"]["bytes_model_term"] = {"bytes_per_unit": 32, "achieved_TBps": units_per_s * 32 / 1e12, "peak_TBps": 8.0,
-                                               "frac": units_per_s * 32 / 8e12}
+                                               "frac": bfrac if bfrac <= 1.0 else None}
+        if bfrac > 1.0:
+            out["roofline"]["bytes_model_term"]["why_null"] = ("n/a: the state is register-resident, nothing streams per unit -- the model's "
+                                                               "32 B / unit are not moved (see hbm_TBps for what the launch moved)")
         if traffic is not None:      # HBM side of the same launch
             out["roofline"]["hbm_TBps"] = traffic / (k_ms * 1e-3) / 1e12
             out["roofline"]["hbm_frac_of_8TBps"] = out["roofline"]["hbm_TBps"] / 8.0
@@ -483,13 +568,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra (non-BASELINE) measurements of the default run")
-    ap.add_argument("--traffic", choices=["headline", "all", "none"], default="headline",
-                    help="measure roofline.traffic with two rocprofv3 --pmc child runs (one GPU only); else the committed profiles/")
+    ap.add_argument("--traffic", choices=["headline", "all", "none"], default="all",
+                    help="measure roofline.traffic with two rocprofv3 --pmc child runs per config (one GPU only); headline: only the headline "
+                         "config that way, the others from the committed profiles/ of the same kernel; none: committed profiles only")
+    ap.add_argument("--proxy-scaling", action="store_true", help="with --config N: also time chains/2, /4, /8 on this GPU (scaling_proxy)")
+    ap.add_argument("--no-proxy", action="store_true", help="skip scaling_proxy in the default run")
     ap.add_argument("--collate", action="store_true",
                     help="also time the RCCL all-gather of the kept draws (not part of `value`)")
     args = ap.parse_args()
 
     import torch
+
+    # --gpus N without a launcher: this process IS the launcher (it used to run ONE rank and print n_gpus 1)
+    share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"        # test only: ranks share the visible GPU(s) over gloo
+    n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if n_vis < args.gpus and not share:
+            print(f"bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) visible: refusing to report an N={args.gpus} line", file=sys.stderr)
+            raise SystemExit(3)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"# bench.py: spawning {args.gpus} ranks (one per GPU): {' '.join(cmd[2:9])} ...", file=sys.stderr)
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
     import mcmc_amd
     from mcmc_amd import dist as mdist
 
@@ -498,10 +603,19 @@ def main():
     ctx.rank = int(os.environ.get("RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.gpus != ctx.world:
+        if ctx.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}: the line would not be the run that was asked for", file=sys.stderr)
+        raise SystemExit(2)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not share and local_rank >= n_vis:
+        print(f"bench.py: LOCAL_RANK {local_rank} but only {n_vis} GPU(s) visible", file=sys.stderr)
+        raise SystemExit(3)
     # BENCH_TEST_SHARE_GPU=1 (test only): gloo backend and LOCAL_RANK folded onto the visible devices, to exercise the N>1 path on a 1-GPU box
-    ctx.share = os.environ.get("BENCH_TEST_SHARE_GPU") == "1"
-    ctx.dev = mdist.bind_device(None if ctx.share else int(os.environ.get("LOCAL_RANK", "0")))
+    ctx.share = share
+    ctx.dev = mdist.bind_device(None if ctx.share else local_rank)
     ctx.dist = None
+    ranks_seen, backend = 1, None
     if ctx.world > 1 or args.collate:          # (--collate at one GPU: a 1-rank RCCL group, so that the collation code runs on the box that has one)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -513,25 +627,71 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=ctx.dev)
         ctx.dist = dist
-    if args.gpus != ctx.world and ctx.rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={ctx.world}; using WORLD_SIZE", file=sys.stderr)
+        ranks_seen, backend = dist.get_world_size(), ("gloo (BENCH_TEST_SHARE_GPU)" if ctx.share else "nccl (RCCL)")
+        # every rank on its own device (unless the test mode folds them): the N-GPU line must be N GPUs
+        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cpu" if ctx.share else ctx.dev)
+        seen = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(seen, mine)
+        n_distinct = len({int(t.item()) for t in seen})
+        if not ctx.share and n_distinct != ctx.world:
+            raise SystemExit(f"bench.py: {ctx.world} ranks on {n_distinct} distinct devices")
 
     head_id = args.config or 2
     out, cfg = measure(head_id, args.steps, args.warmup, args, ctx, headline=True)
-    if args.config is None and ctx.world == 1 and args.chains is None:
+    if ctx.rank == 0:
+        out["ranks"] = {"world_size": ranks_seen, "backend": backend, "devices_visible": n_vis}
+    single = args.config is None and ctx.world == 1 and args.chains is None
+    if single:
         # the other single-GPU BASELINE configs under the same clock, at a reduced step count
         others = []
         for cid in (3, 4, 5):
-            o, _ = measure(cid, args.other_steps, args.other_warmup, args, ctx, headline=False)
-            others.append({"config_id": cid, "workload": o["config"]["workload"], "metric": o["metric"], "unit": o["unit"],
-                           "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
-                           "chains": o["config"]["chains_per_gpu"], "accept_rate": o["config"]["accept_rate"],
-                           "roofline": o["roofline"],
-                           **({k: o[k] for k in ("ess_per_sec", "ess_per_sec_incl_reducer", "ess_reducer_ms", "rhat_max", "ess_is_estimate",
-                                                 "ess_caveat") if k in o})})
+            o, ocfg = measure(cid, args.other_steps, args.other_warmup, args, ctx, headline=False)
+            ent = {"config_id": cid, "workload": o["config"]["workload"], "metric": o["metric"], "unit": o["unit"],
+                   "value": o["value"], "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                   "chains": o["config"]["chains_per_gpu"], "accept_rate": o["config"]["accept_rate"],
+                   "roofline": o["roofline"],
+                   **({k: o[k] for k in ("ess_per_sec", "ess_per_sec_incl_reducer", "ess_reducer_ms", "rhat_max", "ess_is_estimate",
+                                         "ess_caveat", "executed") if k in o})}
+            if not args.no_ess and cid in CONVERGED:
+                # ESS/sec of this config = the converged leg's; the frozen-settings run keeps its (non-)estimate next to it
+                ent["frozen_run_ess"] = {k: ent.pop(k) for k in ("ess_per_sec", "ess_per_sec_incl_reducer", "ess_reducer_ms", "rhat_max",
+                                                                 "ess_is_estimate", "ess_caveat") if k in ent}
+                leg = converged_leg(cid, ctx)
+                ent["converged"] = leg
+                ent["ess_per_sec"], ent["rhat_max"], ent["ess_is_estimate"] = leg["ess_per_sec"], leg["rhat_max"], leg["ess_is_estimate"]
+                ent["ess_source"] = "converged leg (outside the timed region; `value` and ms_per_step are the frozen BASELINE settings)"
+            if not args.no_cpu_baseline:
+                ent["cpu_baseline"] = cpu_baseline(cid, ocfg)
+                ent["gpu_over_cpu"] = {k: ent["value"] / ent["cpu_baseline"][k]["value"] for k in ("mode_a", "mode_b") if k in ent["cpu_baseline"]}
+            others.append(ent)
         out["other_configs"] = others
         if not args.no_extra:
             out["extra"] = {"nuts_on_configs2_target": extra_nuts_on_logistic(ctx)}
+    elif ctx.rank == 0 and ctx.world == 1 and args.chains is None and head_id in CONVERGED and not args.no_ess:
+        out["converged"] = converged_leg(head_id, ctx)
+    if (single and not args.no_proxy) or (args.proxy_scaling and ctx.world == 1):
+        # ONE-GPU PROXY of the strong-scaling curve: the share of one GPU at N = 1, 2, 4, 8 -- total / N chains -- timed here
+        # under the same clock.  It prices the kernel's few-chain launch shapes only: no collation, no launch skew between ranks, no xGMI.
+        proxy = {"note": "ONE GPU: ms of one rank's share (chains_total / N) of the run -- what N GPUs would each spend in the sampling "
+                         "kernel; a proxy, not a multi-GPU measurement (no collation, no rank skew)", "configs": []}
+        for cid in ([2, 4] if single else [head_id]):
+            total = WORKLOADS[cid]["chains"]
+            rows = []
+            for n in (1, 2, 4, 8):
+                if n == 1 and cid == head_id:
+                    ms, kern = out["ms_per_step"], out["roofline"]["kernel"]
+                elif n == 1 and single:
+                    ent = [e for e in out["other_configs"] if e["config_id"] == cid][0]
+                    ms, kern = ent["ms_per_step"], ent["roofline"]["kernel"]
+                else:
+                    o, _ = measure(cid, 3, 1, args, ctx, headline=False, chains_override=total // n, want_traffic=False)
+                    ms, kern = o["ms_per_step"], o["roofline"]["kernel"]
+                rows.append({"n_gpus_modelled": n, "chains_per_gpu": total // n, "ms_per_step": ms, "kernel": kern})
+            for r in rows:
+                r["speedup_vs_1"] = rows[0]["ms_per_step"] / r["ms_per_step"]
+            proxy["configs"].append({"config_id": cid, "chains_total": total, "curve": rows})
+        if ctx.rank == 0:
+            out["scaling_proxy"] = proxy
     if ctx.rank == 0:
         if not args.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(head_id, cfg)

@@ -83,8 +83,10 @@ typedef enum mi_kernel_hint {
                                             * default one with register-carried leaf state */
     MI_KERNEL_NUTS_REG = 10,               /* nuts, same case: register-carried leaf state, one wave per 16-chain tile and per SIMD (the default
                                             * for d <= 64) */
-    MI_KERNEL_NUTS_SPLIT = 11,             /* nuts, same case, 64 < d <= 128: every tile split over two waves, two tiles per SIMD, so that one
-                                            * tile's record traffic runs under the other's mat-vec (the default there) */
+    MI_KERNEL_NUTS_SPLIT = 11,             /* nuts, same case, 64 < d <= 128 only (ignored for d <= 64): every 16-chain tile split over two waves.  Tiles per
+                                            * workgroup by the chain count: 1 up to 16 chains per CU, 2 up to 32 per CU, 4 beyond.  AUTO takes it for FEW
+                                            * chains only (<= 32 per CU: the shorter tick per tile wins there); with more chains AUTO runs
+                                            * MI_KERNEL_NUTS_REG / _DYN / _MEMO, and this hint forces the (slower) four-tile shape */
     MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
                                             * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
@@ -316,7 +318,10 @@ uint64_t mi_mcmc_rank_major_index(uint64_t n_chains_total, uint32_t world_size, 
  * producer_stream), orders a gather into the run's rank-major buffer behind that stream's work so far, on the library's own
  * communication stream, and returns at once: the caller goes on to enqueue the next chunk of the run (mi_chains.draw0 continues
  * it bit-identically) on producer_stream while the slab travels.  _wait makes consumer_stream wait for the gather (block_host != 0:
- * the calling thread instead) and releases the handle.  Gathers of one communicator must be begun in the same order on every rank. */
+ * the calling thread instead) and releases the handle.  Gathers of one communicator must be begun in the same order on every rank.
+ * LIFETIME: between _begin and the completion of _wait the gather READS local_draws and WRITES rows [row0, row0 + n_keep) of
+ * all_rank_major on the library's stream -- the caller must not overwrite local_draws (give every chunk in flight its own slab, or _wait
+ * with block_host before re-using one) nor touch those rows of all_rank_major on any other stream until then.  Nothing enforces it. */
 typedef struct mi_collation mi_collation;
 int mi_mcmc_allgather_draws_begin(void* rccl_comm, uint32_t world_size, uint32_t rank, const double* local_draws, uint64_t n_keep,
                                   uint64_t d, uint64_t n_chains_total, uint64_t row0, uint64_t n_keep_total, double* all_rank_major,

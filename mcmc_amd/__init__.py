@@ -222,6 +222,11 @@ def rmhmc_callback(initial_vals, kernel_fn, kernel_data, tensor_fn, tensor_data,
     return out.T.copy(), int(nacc.value)
 
 
+def test_set_grid_cap(max_workgroups):
+    """mi_mcmc_test_set_grid_cap (TEST HOOK, mi_mcmc_probes.h): cap the persistent grids of the dynamic-hand-out NUTS kernels; 0 = none."""
+    lib().mi_mcmc_test_set_grid_cap(C.c_uint32(int(max_workgroups)))
+
+
 def last_kernel():
     """mi_mcmc_last_kernel: the kernel this thread's last run spent its time in, as rocprofv3 names it."""
     return lib().mi_mcmc_last_kernel().decode()

@@ -22,15 +22,15 @@ constexpr int STATS_MAX_N = 160;          // series length up to which every lag
 constexpr int STATS_TILED_LAGS = 128;     // lags computed for longer series
 constexpr int STATS_TILE_T = 64;          // time steps per tile of the streamed variant: (TILE_T + 2 LAGS) x 64 doubles = 160 KB
 
-// partial sums of x over (t, chains of group g) per dimension: out[g][j]
-__global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict__ draws, uint32_t n, uint32_t d, uint64_t C,
+// partial sums of x over (t = 0, t_step, 2 t_step, ... < n; chains of group g) per dimension: out[g][j]
+__global__ __launch_bounds__(64) void stats_sum_kernel(const double* __restrict__ draws, uint32_t n, uint32_t t_step, uint32_t d, uint64_t C,
                                                        uint32_t G, double* __restrict__ out)
 {
     const uint32_t j = blockIdx.x, g = blockIdx.y;
     const uint64_t c_lo = (uint64_t)g * ((C + G - 1) / G), c_hi = (c_lo + (C + G - 1) / G < C) ? c_lo + (C + G - 1) / G : C;
     double s = 0.0;
     for (uint64_t c = c_lo + threadIdx.x; c < c_hi; c += 64)
-        for (uint32_t t = 0; t < n; ++t) s += draws[((size_t)t * d + j) * C + c];
+        for (uint32_t t = 0; t < n; t += t_step) s += draws[((size_t)t * d + j) * C + c];
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
     if (threadIdx.x == 0) out[(size_t)g * d + j] = s;
 }

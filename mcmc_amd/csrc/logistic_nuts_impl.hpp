@@ -21,7 +21,7 @@ uint64_t grid_of(uint64_t C)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 512, G::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint64_t need = (C + 31) / 32, cap = (uint64_t)n_cu * (uint64_t)per_cu;
-    return need < cap ? need : cap;
+    return cap_grid(need < cap ? need : cap);
 }
 
 template <int NTQ, int TARGET, bool DIAGM = false, bool BOUNDS = false>

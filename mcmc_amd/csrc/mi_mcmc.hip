@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,7 +58,12 @@ void note_kernel(const char* fmt, ...)
     va_end(ap);
     host::last_kernel() = buf;
 }
+namespace { std::atomic<uint64_t> g_test_grid_cap{0}; }
+uint64_t test_grid_cap() { return g_test_grid_cap.load(std::memory_order_relaxed); }
 }  // namespace mi
+
+// test hook, declared in mi_mcmc_probes.h (not in the product header): see launch_common.hpp
+extern "C" void mi_mcmc_test_set_grid_cap(uint32_t max_workgroups) { mi::g_test_grid_cap.store(max_workgroups, std::memory_order_relaxed); }
 
 namespace {
 
@@ -381,6 +387,12 @@ __global__ void fill_u64_kernel(uint64_t* out, uint64_t n, uint64_t v)
 
 // identity tables of the general kernel variants (no bounds, unit mass) in stream-ordered workspace memory: what a replay of the
 // plain case through a general variant reads (no host buffer has to outlive the call)
+// behind a nuts_gauss_split_kernel launch: its status word says a pair-wise LDS wait timed out (nuts_split.hpp) -> abort the queue
+__global__ void trap_if_sync_lost_kernel(const uint32_t* status)
+{
+    if (*status == 0xdeadu) __builtin_trap();
+}
+
 __global__ void fill_identity_tables_kernel(int* bt, double* lb, double* ub, double* ms, double* mi, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2042,7 +2054,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
     const size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
-    const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t flag_bytes = ((chains->n_chains + 2) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any", [C + 1] status (nuts_split.hpp)
     const size_t pfrag_bytes = (size_t)128 * 128 * sizeof(double);           // the precision in fragment order (nuts_gauss_split_kernel)
     rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + pfrag_bytes + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
@@ -2125,7 +2137,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     else {
         // the plain case: nuts_gauss_reg_kernel; chains that reach the non-finite regime are flagged there and
         // replayed by the general variant, which reproduces the reference's dense products, with identity tables
-        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 2) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
         // One wave per tile with register-carried leaf state (nuts_reg.hpp) is the throughput shape.  nuts_split.hpp spreads a tile over
         // two waves: with FEW chains (no more tiles than the chip has SIMD pairs) that is the shorter tick per tile -- a run then lasts
@@ -2141,6 +2153,10 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
            : nuts_dynamic(target, C_) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st))
                                       : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
+        if (split) {     // a lost pair-wise synchronisation must not return MI_OK with garbage: abort the queue, the next sync reports it
+            hipLaunchKernelGGL(trap_if_sync_lost_kernel, dim3(1), dim3(1), 0, st, nf_flag + chains->n_chains + 1);
+            HIP_TRY(hipGetLastError());
+        }
         const std::string reg_name = mi::host::last_kernel();
         int* bt_i = reinterpret_cast<int*>(id_tab);
         hipLaunchKernelGGL(fill_identity_tables_kernel, dim3(1), dim3(128), 0, st, bt_i, id_tab + 128, id_tab + 256, id_tab + 384, id_tab + 512, 128u);

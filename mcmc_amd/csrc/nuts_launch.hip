@@ -36,7 +36,7 @@ int dyn(NutsParams prm, uint32_t batch, hipStream_t st)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint64_t need = (prm.C + 63) / 64, cap = (uint64_t)n_cu * (uint64_t)per_cu;
     MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(need < cap ? need : cap)), dim3(256), lds, st, prm, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)cap_grid(need < cap ? need : cap)), dim3(256), lds, st, prm, batch);
     return (int)hipGetLastError();
 }
 

@@ -713,7 +713,9 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(128 * TPW, 2) void nuts_gauss_split_
         for (int k = 0; k < 12; ++k) prm.prof[wave * 12 + k] = pc[k];
 #endif
 
-    if (sync_lost && prm.nf_flag != nullptr && lane == 0) prm.nf_flag[C] = 0xdeadu;      // (the replay then runs over garbage flags: the run is void either way)
+    // the pair-wise wait timed out (a broken build, never seen): the run is void.  The status word behind the flags makes it LOUD: the host enqueues
+    // trap_if_sync_lost_kernel behind this launch, which aborts the queue -- the caller's next synchronisation fails instead of returning garbage
+    if (sync_lost && prm.nf_flag != nullptr && lane == 0) prm.nf_flag[C + 1] = 0xdeadu;
     const bool replay = lds_nf[ct] != 0u && prm.nf_flag != nullptr;
     if (live && replay && j4 == 0 && h == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
     if (live && !replay) {

@@ -49,13 +49,15 @@ int mi_mcmc_draw_stats(const double* draws_kdc, int32_t mem, uint64_t n_keep, ui
     HIP_TRY(buf.alloc((o_part + (size_t)G * d * part_lags) * 8));
     double* const B = buf.as<double>();
     // ONE pass over the slab when the Gram kernel serves the request (n <= 128 and more than the mean is asked for): the series are
-    // centred by a PROVISIONAL centre a_j -- the mean of the first kept draw over the chains, 1 / n of the slab -- and the kernel's row
-    // sums R_t = sum_c (x_t - a) move the centre to the pooled mean afterwards (exactly, in the algebra; a_j is within a few standard
-    // errors of the mean, so nothing cancels):  sum_c sum_t (v_t - e)(v_{t+k} - e) = S_k - e (sum_{t < n-k} R_t + sum_{t >= k} R_t) + C (n - k) e^2,
+    // centred by a PROVISIONAL centre a_j -- the mean over the chains of the FIRST, MIDDLE and LAST kept draw, 3 / n of the slab (the first
+    // draw alone can sit far from the pooled mean when n_burnin is 0 and the chains share a start far from the mode: with e / sigma large
+    // the recentring below would cancel (e / sigma)^2 ulp of the autocovariances) -- and the kernel's row
+    // sums R_t = sum_c (x_t - a) move the centre to the pooled mean afterwards (exactly, in the algebra):  sum_c sum_t (v_t - e)(v_{t+k} - e) = S_k - e (sum_{t < n-k} R_t + sum_{t >= k} R_t) + C (n - k) e^2,
     // e = pooled mean - a.  (Otherwise: the pooled mean first, one read of the slab, then the lag kernels.)
     const bool one_pass = gram && (acov || rhat || ess);
-    const uint32_t n_sum = one_pass ? 1u : (uint32_t)n;
-    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, n_sum, (uint32_t)d, (uint64_t)C, G, B + o_sum);
+    const uint32_t t_step = one_pass ? (uint32_t)std::max<size_t>(1, (n - 1) / 2) : 1u;      // rows 0, (n-1)/2, 2 ((n-1)/2) [= n-1 or n-2] / every row
+    const uint32_t n_sum = (uint32_t)((n + t_step - 1) / t_step);
+    hipLaunchKernelGGL(mi::stats_sum_kernel, dim3((unsigned)d, G), dim3(64), 0, st, x, (uint32_t)n, t_step, (uint32_t)d, (uint64_t)C, G, B + o_sum);
     std::vector<double> part((size_t)G * d), mean_h(d);
     HIP_TRY(hipMemcpyAsync(part.data(), B + o_sum, part.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -426,14 +428,23 @@ int mi_mcmc_allgather_draws_begin(void* comm, uint32_t world, uint32_t rank, con
     hipStream_t cs = comm_stream(dev);
     if (!cs) return fail(MI_ERR_HIP, "allgather_draws_begin: no communication stream");
     hipEvent_t ready = nullptr, done = nullptr;
-    HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ready, static_cast<hipStream_t>(producer_stream)));     // the slab is complete when the producer stream gets here
-    HIP_TRY(hipStreamWaitEvent(cs, ready, 0));
-    HIP_TRY(hipEventDestroy(ready));                                               // (released once the wait has consumed it)
-    const int rc = gather_rank_major(r, comm, world, rank, local, n_keep, d, C, row0, n_keep_total, all_rank_major, cs);
+    // (every early return below releases what it created: no event outlives a failed call)
+    auto try_hip = [&](hipError_t e, const char* what) -> int {
+        if (e == hipSuccess) return MI_OK;
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+        return fail(MI_ERR_HIP, "allgather_draws_begin: %s: %s", what, hipGetErrorString(e));
+    };
+    int rc;
+    if ((rc = try_hip(hipEventCreateWithFlags(&ready, hipEventDisableTiming), "event"))) return rc;
+    if ((rc = try_hip(hipEventRecord(ready, static_cast<hipStream_t>(producer_stream)), "record"))) return rc;   // the slab is complete when the producer stream gets here
+    if ((rc = try_hip(hipStreamWaitEvent(cs, ready, 0), "wait"))) return rc;
+    (void)hipEventDestroy(ready);                                                  // (released once the wait has consumed it)
+    ready = nullptr;
+    rc = gather_rank_major(r, comm, world, rank, local, n_keep, d, C, row0, n_keep_total, all_rank_major, cs);
     if (rc) return rc;
-    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(done, cs));
+    if ((rc = try_hip(hipEventCreateWithFlags(&done, hipEventDisableTiming), "event"))) return rc;
+    if ((rc = try_hip(hipEventRecord(done, cs), "record"))) return rc;
     *handle = new mi_collation{done};
     return MI_OK;
 }

@@ -56,6 +56,29 @@ def test_two_rank_code_path():
     assert j["value"] > 0
 
 
+def test_gpus_flag_alone_launches_the_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (what a plain driver command would be): bench.py spawns the two ranks itself and the
+    line says n_gpus 2 with the rank count the process group saw (it used to run one rank and print n_gpus 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_TEST_SHARE_GPU"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "8192", "--no-cpu-baseline",
+                          "--traffic", "none"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _line(out.stdout)
+    assert j["n_gpus"] == 2 and j["ranks"]["world_size"] == 2 and j["config"]["chains_per_gpu"] == 4096 and j["scaling"] == "strong"
+
+
+def test_gpus_flag_refuses_more_ranks_than_devices():
+    """Without the test-only sharing switch an N-GPU line needs N visible GPUs: rc != 0, no JSON line."""
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_TEST_SHARE_GPU")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "refusing" in out.stderr
+
+
 def test_collate_reports_the_blocking_and_the_overlapped_gather():
     """--collate: the RCCL all-gather of the kept draws, blocking and overlapped with the sampling (four chunks through mi_chains.draw0);
     on this box a 1-rank group."""

@@ -1,0 +1,123 @@
+"""GPU: the DYNAMIC chain hand-out of the persistent-grid NUTS kernels (nuts_dyn.hpp, nuts_memo.hpp, nuts_lds.hpp) exercised at small sizes
+(ADVICE r4, medium): with the test-only grid cap (mi_mcmc_test_set_grid_cap, mi_mcmc_probes.h) the grid is ONE or TWO workgroups, so a few
+hundred chains run the global counter, slots that take their second ... fifth chain with every per-chain state reset, retire-on-leave and
+INIT / SEARCH in a recycled slot -- what otherwise only runs beyond 16 384 chains.  Bit for bit against the oracle: parity, a chain that goes
+non-finite (retired at once, replayed), and a run cut inside its adaptation window."""
+import numpy as np
+import pytest
+
+import mcmc_amd
+import orc
+from mcmc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DYN_HINTS = [h for h in ("KERNEL_NUTS_DYN", "KERNEL_NUTS_MEMO") if hasattr(mcmc_amd, h)]
+
+
+@pytest.fixture
+def grid_cap():
+    def set_cap(n):
+        mcmc_amd.test_set_grid_cap(n)
+    yield set_cap
+    mcmc_amd.test_set_grid_cap(0)
+
+
+def _oracle(d, init, st, prec, chain0, precond=None):
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=int(st.rng_seed_value), n_burnin=int(st.n_burnin_draws), n_keep=int(st.n_keep_draws), step=float(st.step_size),
+                          n_adapt=int(st.n_adapt_draws), max_depth=int(st.max_tree_depth), W=4, precond=precond)
+    return orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=chain0)
+
+
+@pytest.mark.parametrize("hint", DYN_HINTS)
+@pytest.mark.parametrize("d,C,cap,burn,keep,adapt,depth", [
+    (128, 200, 1, 8, 6, 8, 8),       # 64 slots, 200 chains: every slot takes 3-4 chains; the adaptation window covers the burn-in
+    (128, 333, 2, 3, 4, 4, 10),      # two workgroups racing for the counter; ragged last hand-out (333 - 128 = 205 chains from the counter)
+    (32, 300, 1, 12, 10, 16, 10),    # narrow tiles; the window ends inside the kept draws
+    (100, 70, 1, 0, 5, 0, 7),        # 6 chains from the counter only; no adaptation, fixed small step: deep trees
+])
+def test_recycled_slots_match_the_oracle(hint, d, C, cap, burn, keep, adapt, depth, grid_cap):
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=23)
+    st = mcmc_amd.default_settings(rng_seed_value=31, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=adapt, max_tree_depth=depth,
+                                   step_size=1.0 if adapt else 0.05)
+    grid_cap(cap)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=1000, kernel_hint=getattr(mcmc_amd, hint))
+    assert hint.split("_")[-1].lower() in mcmc_amd.last_kernel()
+    o_draws, o = _oracle(d, init, st, prec, 1000)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"])
+    assert np.array_equal(g_draws, o_draws)
+
+
+@pytest.mark.parametrize("hint", DYN_HINTS)
+def test_recycled_slots_with_a_diagonal_precond_mat(hint, grid_cap):
+    d, C = 100, 180
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=5)
+    M = np.diag(np.linspace(0.5, 2.0, d))
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=5, n_keep_draws=5, n_adapt_draws=5, max_tree_depth=7, precond_mat=M)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=7, kernel_hint=getattr(mcmc_amd, hint))
+    o_draws, o = _oracle(d, init, st, prec, 7, precond=M)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"]) and np.array_equal(g_draws, o_draws)
+
+
+@pytest.mark.parametrize("hint", DYN_HINTS)
+def test_a_flagged_chain_leaves_a_recycled_slot_and_is_replayed(hint, grid_cap):
+    d, C = 128, 200
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=19)
+    init[2] *= 1.0e300            # in its own first slot
+    init[90, 3] = np.inf          # a chain from the counter (second occupant of some slot)
+    init[150, 100] = np.nan       # third occupant
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=6, max_tree_depth=6, step_size=0.1)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=getattr(mcmc_amd, hint))
+    o_draws, o = _oracle(d, init, st, prec, 0)
+    assert np.isnan(o_draws[:, :, [2, 90, 150]]).any()
+    assert np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+
+
+@pytest.mark.parametrize("hint", DYN_HINTS)
+@pytest.mark.parametrize("cut", [4, 10])
+def test_a_run_on_recycled_slots_can_be_cut_inside_the_window(hint, cut, grid_cap):
+    d, C, burn, keep, n_adapt = 64, 150, 12, 6, 10
+    prec = synth.dense_gaussian_precision(d, seed=2)
+    init = synth.initial_states(C, d, seed=8) * 0.5
+    S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=99, n_burnin_draws=b, n_keep_draws=k, n_adapt_draws=n_adapt, max_tree_depth=6)
+    grid_cap(1)
+    kw = dict(prec=prec, kernel_hint=getattr(mcmc_amd, hint))
+    whole, w = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, S(0, burn + keep), want_adapt_state=True, **kw)
+    a_draws, a = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, S(0, cut), want_adapt_state=True, **kw)
+    b_draws, b = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, a["theta"].T, S(0, burn + keep - cut), draw0=cut, step_size_in=a["eps"],
+                                 adapt_state_in=a["adapt_state"], **kw)
+    assert np.array_equal(np.concatenate([a_draws, b_draws], axis=0), whole)
+    assert np.array_equal(a["n_leap"] + b["n_leap"], w["n_leap"]) and np.array_equal(b["eps"], w["eps"])
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 100, 16, 150), ("dense", 160, 0, 100)])
+def test_lds_nuts_on_recycled_slots_matches_the_oracle(kind, d, n_rows, C, grid_cap):
+    """nuts_lds.hpp hands chains out the same way (32 slots per workgroup): one workgroup, 100-150 chains"""
+    bs = (32 if d <= 128 else 64) if kind == "logistic" else 48
+    if kind == "logistic":
+        X, y = synth.logistic_problem(d, n_rows, seed=d)
+        tk, tkw = mcmc_amd.TARGET_LOGISTIC, dict(X=X, y=y)
+        spec = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=bs, eta_chains=2)
+    else:
+        prec = synth.dense_gaussian_precision(d, seed=d)
+        tk, tkw = mcmc_amd.TARGET_GAUSS_DENSE, dict(prec=prec)
+        spec = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, blocks=4, block_size=bs)
+    init = synth.initial_states(C, d, seed=d + 1) * (0.1 if kind == "logistic" else 0.5)
+    init[40] = 1e200                                  # one chain of the second round goes non-finite: flagged, replayed literally
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=3, n_keep_draws=3, n_adapt_draws=4, max_tree_depth=5, step_size=0.05)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=3, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
+    s = orc.make_settings(seed=7, n_burnin=3, n_keep=3, n_adapt=4, max_depth=5, step=0.05, W=4, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
