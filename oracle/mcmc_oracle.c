@@ -15,6 +15,7 @@
 #include "mcmc_oracle.h"
 #include "orc_math.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -1061,10 +1062,133 @@ static void nuts_build_tree(orc_ctx* c, int direction_val, double step_size, dou
     }
 }
 
-/* ref: src/nuts.cpp:30-332 */
+
+/* ------------------------------------------------------------------ NUTS, one doubling evaluated with a MEMOISED trajectory
+ *
+ * Not a second algorithm: the SAME doubling as nuts_build_tree above, evaluated in another order.  From the argument plumbing of
+ * ref: include/mcmc/nuts.ipp:166-209 (the crossed edge outputs of the second-half calls, :195 and :207) leaf i of a doubling (i > 0,
+ * c = ctz(i)) starts from the result of leaf i - 1 (c <= 1) or of leaf i - 2^(c-1) (c >= 2), and every doubling starts from
+ * (prev_draw, mntm_vec) (ref: src/nuts.cpp:241-256).  So the state after leaf i is
+ *        s(i) = LF^{n(i)}(prev_draw, mntm_vec),     n(i) = 1 + sum over the set bits k of i of (k + 1):
+ * all 2^j leaves of a doubling lie on ONE trajectory and visit only 1 + j (j + 1) / 2 distinct points of it (56 of 1024 at j = 10), and
+ * the U-turn test of a level-l node whose first leaf sits at point n1 (ref: nuts.ipp:224-229) compares the points n1 and n1 + l.  A leaf's
+ * n', s', alpha (ref: :146-157) depend on its point only.  Here each point is computed ONCE (one leap_frog + one kernel evaluation), each
+ * distinct test once (when its second point appears), and the tree is then walked leaf by leaf exactly as the recursion walks it -- the
+ * same merges in the same order, the same uniforms from the same slots, the same early exit -- on the memoised scalars.  Same bits as the
+ * recursion by construction; tests/test_oracle_memo.py checks that on random cases (including the non-finite regime and bounds).
+ * This is what mcmc_amd/csrc/nuts_memo.hpp runs on the device; *n_exec counts the leap_frog calls it really makes, c->n_leap keeps the
+ * reference's count (one per leaf walked). */
+#define ORC_MEMO_MAXPTS 57        /* 1 + 10 * 11 / 2 = 56 points at max_tree_depth 10 (deeper trees: the recursion) */
+static int memo_npt(uint32_t i) { int n = 1; for (int k = 0; i >> k; ++k) if ((i >> k) & 1u) n += k + 1; return n; }
+/* is there a level-l node (l >= 1) in a doubling of depth j whose first leaf sits at point n1?  First leaves of level-l nodes are the
+ * multiples of 2^l below 2^j: n1 - 1 must be a sum of distinct integers of {l + 1, ..., j}; the sums of t of these consecutive integers
+ * are exactly the integers between the t smallest and the t largest. */
+static int memo_pair_used(int l, int n1, int j)
+{
+    const int m = n1 - 1;
+    for (int t = 0; t <= j - l; ++t) {
+        const int lo = t * (l + 1) + t * (t - 1) / 2, hi = t * j - t * (t - 1) / 2;
+        if (m >= lo && m <= hi) return 1;
+    }
+    return 0;
+}
+
+static void nuts_doubling_memo(orc_ctx* c, int direction_val, double step_size, double log_rand_val, double prev_U, double prev_K,
+                               const double* draw_vec, const double* mntm_vec, size_t tree_depth,
+                               double* new_draw, double* edge_draw, double* edge_mntm,
+                               size_t* n_val, size_t* s_val, double* alpha_val, size_t* n_alpha_val,
+                               uint32_t draw_ind, uint32_t* uslot, uint64_t* n_exec)
+{
+    const size_t d = c->d, nb = d * sizeof(double);
+    const int jd = (int)tree_depth;
+    const double max_tuning_par = 1000;
+    double* pt_th = dvec((size_t)ORC_MEMO_MAXPTS * d);           /* point n at [n * d] (n = 1 ..) */
+    double* pt_p = dvec((size_t)ORC_MEMO_MAXPTS * d);
+    double pt_a[ORC_MEMO_MAXPTS];
+    uint64_t cnb = 0, csb = 0, okb[12] = {0}, okc[12] = {0};
+    double* cur_th = dvec(d); memcpy(cur_th, draw_vec, nb);
+    double* cur_p = dvec(d);  memcpy(cur_p, mntm_vec, nb);
+    double* diff = dvec(d);
+    int npts = 0;
+    const uint64_t leap_before = c->n_leap;
+    uint64_t leaves = 0;
+    /* pending first halves per level (ref: the frames of the recursion) */
+    double p_n[12], p_a[12], p_na[12]; int p_ref[12];
+    double cn = 0, ca = 0, cna = 0; int cref = 0, complete = 0;
+    for (uint32_t li = 0; li < (1u << jd); ++li) {
+        const int n = memo_npt(li);
+        while (npts < n) {                                          /* a point of the trajectory that no leaf has visited yet */
+            const int m = npts + 1;
+            leap_frog(c, direction_val * step_size, 1, cur_th, cur_p);      /* ref: nuts.ipp:132 */
+            double prop_U = -box_log_kernel(c, cur_th);             /* :134 */
+            if (!isfinite(prop_U)) prop_U = INFINITY;
+            const double prop_K = kinetic(c, cur_p);                /* :140 */
+            memcpy(pt_th + (size_t)m * d, cur_th, nb); memcpy(pt_p + (size_t)m * d, cur_p, nb);
+            if (log_rand_val <= -prop_U - prop_K) cnb |= 1ull << m;                       /* :146 */
+            if (log_rand_val < max_tuning_par - prop_U - prop_K) csb |= 1ull << m;        /* :147 */
+            const double dd = -(prop_U + prop_K) + (prev_U + prev_K);
+            pt_a[m] = orc_exp((dd < 0.0) ? dd : 0.0);               /* :157 */
+            for (int l = 1; l <= jd; ++l) {                         /* the tests whose second point this is (:224-229) */
+                const int n1 = m - l;
+                if (n1 < 1 || !memo_pair_used(l, n1, jd)) continue;
+                const double* ta = pt_th + (size_t)n1 * d; const double* pa = pt_p + (size_t)n1 * d;
+                for (size_t i = 0; i < d; ++i) diff[i] = (direction_val > 0) ? cur_th[i] - ta[i] : ta[i] - cur_th[i];   /* pos - neg */
+                const int c1 = orc_dot_b(diff, pa, d, c->W, c->nblk, c->bs) >= 0.0;
+                const int c2 = orc_dot_b(diff, cur_p, d, c->W, c->nblk, c->bs) >= 0.0;
+                if (c1 && c2) okb[l] |= 1ull << n1;
+                okc[l] |= 1ull << n1;
+            }
+            if (m == 1 + jd) { memcpy(edge_draw, cur_th, nb); memcpy(edge_mntm, cur_p, nb); }   /* the far edge: first leaf of the second half */
+            npts = m;
+        }
+        /* the leaf (:146-158) on the memoised scalars */
+        leaves++;
+        cn = (double)((cnb >> n) & 1ull); ca = pt_a[n]; cna = 1.0; cref = n;
+        int failed = !((csb >> n) & 1ull);
+        int pend_level = jd + 1;
+        for (int l = 1; l <= jd; ++l) {                             /* unwind: the returns of the recursion (:212-239) */
+            const int bit = (int)((li >> (l - 1)) & 1u);
+            if (!failed && !bit) { pend_level = l; break; }         /* a first half with s' = 1: its second half is built next */
+            if (!bit) continue;                                     /* a first half with s' = 0 returns through its parent (:234-239) */
+            const double z = orc_rng_uniform(c->seed, c->chain, draw_ind, (*uslot)++);    /* :213 */
+            const double prob = cn / (p_n[l] + cn);                 /* :212 */
+            if (!(z < prob)) cref = p_ref[l];                       /* :215-217 (0/0 = NaN keeps) */
+            cn = p_n[l] + cn; ca = p_a[l] + ca; cna = p_na[l] + cna;    /* :220-222 */
+            if (!failed) {
+                const int n1 = memo_npt(li + 1u - (1u << l));        /* the node's first leaf */
+                if (!((okc[l] >> n1) & 1ull)) { fprintf(stderr, "orc memo: test (%d, %d) not evaluated\n", l, n1); abort(); }
+                if (!((okb[l] >> n1) & 1ull)) failed = 1;           /* :226-229 */
+            }
+        }
+        if (failed) break;
+        if (li == (1u << jd) - 1u) { complete = 1; break; }
+        p_n[pend_level] = cn; p_a[pend_level] = ca; p_na[pend_level] = cna; p_ref[pend_level] = cref;
+    }
+    *n_val = (size_t)cn; *s_val = (size_t)complete; *alpha_val = ca; *n_alpha_val = (size_t)cna;
+    if (complete) memcpy(new_draw, pt_th + (size_t)cref * d, nb);
+    *n_exec += c->n_leap - leap_before;
+    c->n_leap = leap_before + leaves;                               /* the reference's count: one leapfrog per leaf */
+    free(pt_th); free(pt_p); free(cur_th); free(cur_p); free(diff);
+}
+
+/* ref: src/nuts.cpp:30-332; memo != 0: every doubling through nuts_doubling_memo (same bits, fewer leap_frog calls) */
+static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st, int memo, uint64_t* n_exec_out);
 int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st)
 {
+    return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 0, NULL);
+}
+int orc_nuts_memo(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+                  const orc_settings* s, double* draws_out, orc_stats* st, uint64_t* n_exec_out)
+{
+    if (s->max_tree_depth > 10) return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 0, n_exec_out);
+    return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 1, n_exec_out);
+}
+static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+             const orc_settings* s, double* draws_out, orc_stats* st, int memo, uint64_t* n_exec_out)
+{
+    uint64_t n_exec = 0;
     orc_ctx c;
     ctx_init(&c, d, kernel, data, s, 1);
     const size_t nb = d * sizeof(double);
@@ -1085,6 +1209,7 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
     orc_gemv(c.sqrt_precond, rand_vec, d, mntm_vec);                    /* :168 */
 
     double step_size = nuts_find_initial_step_size(&c, first_draw, mntm_vec);   /* :172 */
+    const uint64_t n_search_leaps = c.n_leap;                           /* (the search's leapfrogs are executed as they are) */
     const double mu_val = orc_log(10 * step_size);                      /* :174 */
     double h_val = 0;
 
@@ -1130,12 +1255,18 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
             if (direction_val == -1) {
                 memcpy(dummy_draw, draw_pos, nb);                       /* :238-239 */
                 memcpy(dummy_mntm, mntm_pos, nb);
+                if (memo) nuts_doubling_memo(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec, tree_depth,
+                                             new_draw, draw_neg, mntm_neg, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec);
+                else
                 nuts_build_tree(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec,
                                 tree_depth, new_draw, dummy_draw, draw_neg, dummy_mntm, mntm_neg,
                                 &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot);   /* :241-246 */
             } else {
                 memcpy(dummy_draw, draw_neg, nb);                       /* :248-249 */
                 memcpy(dummy_mntm, mntm_neg, nb);
+                if (memo) nuts_doubling_memo(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec, tree_depth,
+                                             new_draw, draw_pos, mntm_pos, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec);
+                else
                 nuts_build_tree(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec,
                                 tree_depth, new_draw, draw_pos, dummy_draw, mntm_pos, dummy_mntm,
                                 &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot);   /* :251-256 */
@@ -1179,6 +1310,7 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
     }
     epilogue_inv_transform(&c, draws_out, n_keep);
     if (st) { st->n_accept_draws = n_accept; st->n_leapfrogs = c.n_leap; st->final_step_size = step_size; }
+    if (n_exec_out) *n_exec_out = memo ? n_exec + n_search_leaps : c.n_leap;
     free(first_draw); free(rand_vec); free(mntm_vec); free(prev_draw); free(new_draw);
     free(draw_pos); free(draw_neg); free(mntm_pos); free(mntm_neg);
     free(dummy_draw); free(dummy_mntm); free(start_draw); free(diff);
@@ -1398,6 +1530,7 @@ int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t 
         else if (algo == 1) r = orc_mala(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else if (algo == 3) r = orc_rwmh(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         else if (algo == 4) r = orc_rmhmc(init + (size_t)ci * d, d, orc_target_kernel, orc_target_tensor, &t, &t, &sc, local, &st);
+        else if (algo == 5) r = orc_nuts_memo(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st, NULL);
         else r = orc_nuts(init + (size_t)ci * d, d, orc_target_kernel, &t, &sc, local, &st);
         if (r) rc = r;
         if (draws_out)

@@ -133,6 +133,10 @@ int orc_mala(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
              const orc_settings* s, double* draws_out, orc_stats* st);
 int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
+/* the same run with every doubling evaluated on a memoised trajectory (mcmc_oracle.c: nuts_doubling_memo): identical outputs, the reference's
+ * leapfrog count in st->n_leapfrogs, the leap_frog calls really made in *n_exec_out (may be NULL).  max_tree_depth > 10: the recursion. */
+int orc_nuts_memo(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+                  const orc_settings* s, double* draws_out, orc_stats* st, uint64_t* n_exec_out);
 /* mcmc::rwmh (src/rwmh.cpp:30-175): step_size carries par_scale, precond_mat carries cov_mat */
 int orc_rwmh(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);
@@ -144,7 +148,7 @@ int orc_rmhmc(const double* initial_vals, size_t d, orc_kernel_fn kernel, orc_te
 /* many independent chains of a built-in target, OpenMP over chains (the CPU
  * baseline of BASELINE.md section 3).  init: n_chains x d (row per chain).
  * draws_out: [n_keep][d][n_chains] (the engine's device layout) or NULL.
- * algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc.  Chain c uses chain_id = chain0 + c. */
+ * algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc, 5 nuts through orc_nuts_memo.  Chain c uses chain_id = chain0 + c. */
 int orc_run_many(int algo, const orc_target* tgt, const orc_settings* s, size_t n_chains,
                  uint64_t chain0, const double* init, double* draws_out,
                  uint64_t* n_accept_out, uint64_t* n_leap_out, double* eps_out, int n_threads);
