@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000400
+#define MI_MCMC_VERSION 0x000500
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -90,9 +90,12 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
                                             * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
-    MI_KERNEL_NUTS_DYN = 13                /* nuts, same case as MI_KERNEL_NUTS_REG: its tick with the chains handed to the lanes dynamically (a persistent
-                                            * grid; a lane whose chain is done takes the next one) -- the default when there are more chains than the chip
-                                            * has chain slots */
+    MI_KERNEL_NUTS_DYN = 13,               /* nuts, same case as MI_KERNEL_NUTS_REG: its tick with the chains handed to the lanes dynamically (a persistent
+                                            * grid; a lane whose chain is done takes the next one) */
+    MI_KERNEL_NUTS_MEMO = 14               /* nuts, same case: every doubling on a MEMOISED trajectory (nuts_memo.hpp) -- the 2^j leaves of a doubling visit only
+                                            * 1 + j (j + 1) / 2 distinct states (the reference's crossed edge plumbing, nuts.ipp:195,207), each is computed
+                                            * once, the tree is walked on scalars; same bits, ~40 % fewer leapfrogs executed on BASELINE configs[3]; chains
+                                            * handed out dynamically -- the default beyond 64 chains per CU */
 } mi_kernel_hint;
 
 typedef struct mi_target {
@@ -139,7 +142,8 @@ typedef struct mi_chains {
     double*   draws;          /* out [n_keep][d][C], may be NULL (draws discarded) */
     uint64_t* n_accept;       /* out [C], may be NULL */
     double*   step_size;      /* nuts out [C]: adapted step size per chain (in: see draw0), may be NULL; other samplers leave it unchanged */
-    uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps executed per chain (0 for mala / rwmh), may be NULL */
+    uint64_t* n_leapfrogs;    /* out [C]: leapfrog steps per chain AS THE REFERENCE EXECUTES THEM (0 for mala / rwmh), may be NULL.  nuts: one per leaf of
+                               * every tree (nuts.ipp:132) -- see n_leapfrogs_executed */
     uint32_t* nuts_depth;     /* nuts out [n_burnin+n_keep][C]: tree depth reached per draw, may be NULL */
     uint64_t  draw0;          /* index of this call's first draw in every chain's random stream: 0 for a fresh run; the
                                * n_burnin+n_keep of the call(s) before to CONTINUE them from their final theta -- the
@@ -158,6 +162,8 @@ typedef struct mi_chains {
                                * mcmc::hmc with precond_mat = diag(mass_diag[:, c]) in one launch).  settings.precond_mat must be
                                * NULL.  Separable Gaussian targets without bounds run on the elementwise kernels (any d), everything
                                * else on the literal kernels.  See mi_mcmc_hmc_run_mass_adapted_per_chain. */
+    uint64_t* n_leapfrogs_executed; /* out [C], may be NULL: the leapfrog steps the device really computed.  Equal to n_leapfrogs except for nuts on
+                               * MI_KERNEL_NUTS_MEMO, which computes every distinct state of a doubling once (same draws, fewer steps) */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);

@@ -21,7 +21,7 @@ TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET
 MEM_HOST, MEM_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_ELEMENTWISE_1LANE, KERNEL_ELEMENTWISE_4LANE, KERNEL_NUTS_LOCKSTEP = 0, 1, 2, 3   # mi_kernel_hint
 KERNEL_HMC_TWO_WAVES_PER_SIMD, KERNEL_HMC_ONE_WAVE_PER_SIMD, KERNEL_HMC_SPLIT2, KERNEL_HMC_SPLIT4, KERNEL_HMC_SPLIT4_TWO_WAVES = 4, 5, 6, 7, 8
-KERNEL_NUTS_TICK_LOCAL, KERNEL_NUTS_REG, KERNEL_NUTS_SPLIT, KERNEL_LITERAL, KERNEL_NUTS_DYN = 9, 10, 11, 12, 13
+KERNEL_NUTS_TICK_LOCAL, KERNEL_NUTS_REG, KERNEL_NUTS_SPLIT, KERNEL_LITERAL, KERNEL_NUTS_DYN, KERNEL_NUTS_MEMO = 9, 10, 11, 12, 13, 14
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)
@@ -48,7 +48,8 @@ class mi_chains(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("mem", C.c_int32), ("n_chains", C.c_uint64),
                 ("chain0", C.c_uint64), ("theta", C.c_void_p), ("draws", C.c_void_p),
                 ("n_accept", C.c_void_p), ("step_size", C.c_void_p), ("n_leapfrogs", C.c_void_p),
-                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64), ("nuts_adapt_state", C.c_void_p), ("mass_diag", C.c_void_p)]
+                ("nuts_depth", C.c_void_p), ("draw0", C.c_uint64), ("nuts_adapt_state", C.c_void_p), ("mass_diag", C.c_void_p),
+                ("n_leapfrogs_executed", C.c_void_p)]
 
 
 class MiMcmcError(RuntimeError):
@@ -172,7 +173,7 @@ def make_target(kind, d, prec=None, X=None, y=None, mem=MEM_HOST, kernel_hint=KE
 
 
 def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=None, n_leapfrogs=None,
-                nuts_depth=None, mem=MEM_HOST, draw0=0, mass_diag=None, nuts_adapt_state=None):
+                nuts_depth=None, mem=MEM_HOST, draw0=0, mass_diag=None, nuts_adapt_state=None, n_leapfrogs_executed=None):
     c = mi_chains()
     c.struct_size = C.sizeof(mi_chains)
     c.mem, c.n_chains, c.chain0, c.draw0 = mem, int(n_chains), int(chain0), int(draw0)
@@ -180,7 +181,8 @@ def make_chains(theta, n_chains, chain0=0, draws=None, n_accept=None, step_size=
     c.step_size, c.n_leapfrogs, c.nuts_depth = _ptr(step_size), _ptr(n_leapfrogs), _ptr(nuts_depth)
     c.mass_diag = _ptr(mass_diag)                         # hmc only: per-chain diagonal masses [d][C]
     c.nuts_adapt_state = _ptr(nuts_adapt_state)           # nuts: dual-averaging state [3][C], in (continuation inside the window) / out
-    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth, mass_diag, nuts_adapt_state]
+    c.n_leapfrogs_executed = _ptr(n_leapfrogs_executed)   # out [C]: leapfrogs really computed (nuts on the memoised kernel: fewer than n_leapfrogs)
+    c._keep = [theta, draws, n_accept, step_size, n_leapfrogs, nuts_depth, mass_diag, nuts_adapt_state, n_leapfrogs_executed]
     return c
 
 
@@ -263,10 +265,11 @@ def sample(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want
     if algo == "nuts" and (want_adapt_state or adapt_state_in is not None):    # the dual-averaging state [3][C]: in (continuation inside the window) / out
         adapt = np.zeros((3, n_chains)) if adapt_state_in is None else np.array(adapt_state_in, dtype=np.float64, copy=True)
     t = make_target(kind, d, prec=prec, X=X, y=y, kernel_hint=kernel_hint)
+    n_exec = np.zeros(n_chains, dtype=np.uint64)
     c = make_chains(theta, n_chains, chain0=chain0, draws=draws, n_accept=n_accept,
-                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0, nuts_adapt_state=adapt)
+                    step_size=eps, n_leapfrogs=n_leap, nuts_depth=depth, draw0=draw0, nuts_adapt_state=adapt, n_leapfrogs_executed=n_exec)
     run(algo, t, settings, c)
-    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth, adapt_state=adapt)
+    return draws, dict(n_accept=n_accept, n_leap=n_leap, eps=eps, theta=theta, depth=depth, adapt_state=adapt, n_exec=n_exec)
 
 
 def sample_device(algo, kind, init, settings, prec=None, X=None, y=None, chain0=0, want_draws=True, draw0=0,

@@ -33,6 +33,10 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m,
 int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m = false);
 // nuts_dyn.hpp: the same tick, chains handed to the lanes dynamically (prm.next_chain: one uint32_t of device memory)
 int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
+// nuts_memo.hpp: every doubling on a memoised trajectory, chains handed out dynamically; its workspace is sized by the chain SLOTS of the
+// persistent grid (prm.ws must hold nuts_memo_workspace_bytes)
+int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
+size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);
 // the plain case at d in (64, 128], every tile split over two waves, two tiles per SIMD (nuts_split.hpp); pfrag: 128 KB of device
 // scratch for the precision in fragment order (packed here, on the stream)
 int launch_nuts_gauss_split(const NutsParams& prm, int nt, int tiles_per_wg, double* pfrag, hipStream_t st);         // nuts_split_launch.hip

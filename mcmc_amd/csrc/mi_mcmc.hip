@@ -280,6 +280,7 @@ int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c, b
     if (t->struct_size != sizeof(mi_target) || s->struct_size != sizeof(mi_settings) ||
         c->struct_size != sizeof(mi_chains))
         return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
+    if (c->n_leapfrogs_executed && !c->n_leapfrogs) return fail(MI_ERR_BAD_ARG, "n_leapfrogs_executed needs n_leapfrogs next to it");
     if (t->d == 0 || c->n_chains == 0) return fail(MI_ERR_BAD_ARG, "d and n_chains must be positive");
     if (!c->theta) return fail(MI_ERR_BAD_ARG, "chains.theta is required");
     if (c->mass_diag && !mass_allowed) return fail(MI_ERR_UNSUPPORTED, "chains.mass_diag (per-chain diagonal masses) is implemented for mi_mcmc_hmc_run only");
@@ -325,8 +326,9 @@ int dense_precision_on_device(const mi_target* t, DevBuf& owned, const double** 
 
 // host <-> device staging of one mi_chains shard
 struct StagedChains {
-    DevBuf theta, draws, n_accept, step, n_leap, depth, mass, adapt;
+    DevBuf theta, draws, n_accept, step, n_leap, depth, mass, adapt, n_exec;
     mi_chains dev;   // device-pointer view
+    bool exec_written = false;   // the kernel wrote n_leapfrogs_executed itself (nuts_memo.hpp); otherwise it is a copy of n_leapfrogs
 };
 
 int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st, uint64_t n_total = 0)
@@ -349,6 +351,10 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
         HIP_TRY(sc.n_leap.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs = sc.n_leap.as<uint64_t>();
         HIP_TRY(hipMemsetAsync(sc.n_leap.p, 0, C * sizeof(uint64_t), st));    // samplers without leapfrog steps (mala, rwmh) report 0
     }
+    if (c->n_leapfrogs_executed) {
+        HIP_TRY(sc.n_exec.alloc(C * sizeof(uint64_t))); sc.dev.n_leapfrogs_executed = sc.n_exec.as<uint64_t>();
+        HIP_TRY(hipMemsetAsync(sc.n_exec.p, 0, C * sizeof(uint64_t), st));
+    }
     if (c->nuts_depth) { HIP_TRY(sc.depth.alloc(n_total * C * sizeof(uint32_t))); sc.dev.nuts_depth = sc.depth.as<uint32_t>(); }
     if (c->nuts_adapt_state) {                           // in (a continuation inside the adaptation window) / out
         HIP_TRY(sc.adapt.alloc(3 * C * sizeof(double))); sc.dev.nuts_adapt_state = sc.adapt.as<double>();
@@ -364,6 +370,9 @@ int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, 
 
 int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st, uint64_t n_total = 0)
 {
+    // every kernel but nuts_gauss_memo_kernel executes exactly the leapfrogs it counts
+    if (c->n_leapfrogs_executed && !sc.exec_written)
+        HIP_TRY(hipMemcpyAsync(sc.dev.n_leapfrogs_executed, sc.dev.n_leapfrogs, c->n_chains * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     if (c->mem == MI_MEM_DEVICE) return MI_OK;
     const size_t C = c->n_chains;
     HIP_TRY(hipMemcpyAsync(c->theta, sc.dev.theta, d * C * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -371,6 +380,7 @@ int stage_out(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc,
     if (c->n_accept) HIP_TRY(hipMemcpyAsync(c->n_accept, sc.dev.n_accept, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (c->step_size) HIP_TRY(hipMemcpyAsync(c->step_size, sc.dev.step_size, C * sizeof(double), hipMemcpyDeviceToHost, st));
     if (c->n_leapfrogs) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs, sc.dev.n_leapfrogs, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    if (c->n_leapfrogs_executed) HIP_TRY(hipMemcpyAsync(c->n_leapfrogs_executed, sc.dev.n_leapfrogs_executed, C * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     if (c->nuts_depth) HIP_TRY(hipMemcpyAsync(c->nuts_depth, sc.dev.nuts_depth, n_total * C * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (c->nuts_adapt_state) HIP_TRY(hipMemcpyAsync(c->nuts_adapt_state, sc.dev.nuts_adapt_state, 3 * C * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -391,6 +401,13 @@ __global__ void fill_u64_kernel(uint64_t* out, uint64_t n, uint64_t v)
 __global__ void trap_if_sync_lost_kernel(const uint32_t* status)
 {
     if (*status == 0xdeadu) __builtin_trap();
+}
+
+// nuts_gauss_memo_kernel: a flagged chain was replayed by the general variant, which executes every leapfrog it counts
+__global__ void copy_flagged_counts_kernel(const uint32_t* flag, const uint64_t* n_leap, uint64_t* n_exec, uint64_t C)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C && flag[c] != 0u) n_exec[c] = n_leap[c];
 }
 
 __global__ void fill_identity_tables_kernel(int* bt, double* lb, double* ub, double* ms, double* mi, uint32_t n)
@@ -2015,6 +2032,16 @@ bool nuts_dynamic(const mi_target* target, uint64_t C)
     return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
 }
 
+// nuts_memo.hpp instead of nuts_reg.hpp / nuts_dyn.hpp: on request, and by default where nuts_dyn.hpp was (more chains than chain slots)
+bool nuts_memoised(const mi_target* target, uint64_t C)
+{
+    if (target->kernel_hint == MI_KERNEL_NUTS_MEMO) return true;
+    if (target->kernel_hint != MI_KERNEL_AUTO) return false;
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
+}
+
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
     int rc = check_common(target, settings, chains);
@@ -2050,9 +2077,21 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.C = chains->n_chains;
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;
+    const int nt = (int)((d + 15) / 16);
+    GeneralTables gt;
+    rc = general_tables("nuts", settings, d, gt, true, true);
+    if (rc) return rc;
+    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0 && !chains->nuts_adapt_state;   // the first-generation kernel, same bits (it exports no adaptation state)
+    const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
+    // the plain case and a diagonal precond_mat alone can run on the memoised trajectory (nuts_memo.hpp)
+    const bool memo_case = (!gt.active || (!gt.dense && !settings->vals_bound)) && !lockstep && !tick_local && settings->max_tree_depth >= 1;
+    const bool memo = memo_case && nuts_memoised(target, chains->n_chains);
     WsLease ws;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
-    const size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
+    size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
+    // (the memoised kernel's workspace is sized by the chain slots of its persistent grid; the replay of flagged chains re-uses the same
+    //  bytes in the asynchronous kernel's layout afterwards)
+    if (memo) ws_own = std::max(ws_own, mi::nuts_memo_workspace_bytes(chains->n_chains, nt, gt.active));
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
     const size_t flag_bytes = ((chains->n_chains + 2) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any", [C + 1] status (nuts_split.hpp)
     const size_t pfrag_bytes = (size_t)128 * 128 * sizeof(double);           // the precision in fragment order (nuts_gauss_split_kernel)
@@ -2068,8 +2107,6 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.n_leap = sc.dev.n_leapfrogs;
     prm.step_out = sc.dev.step_size;
     prm.depth_trace = sc.dev.nuts_depth;
-    const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0 && !chains->nuts_adapt_state;   // the first-generation kernel, same bits (it exports no adaptation state)
-    const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
 #ifdef MI_PROFILING
     DevBuf prof_buf;
     if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(96 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 96 * 8)); prm.prof = prof_buf.as<unsigned long long>();
@@ -2092,14 +2129,10 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     prm.t0 = settings->t0_val;
     prm.kappa = settings->kappa_val;
 
-    const int nt = (int)((d + 15) / 16);
-    GeneralTables gt;
     uint32_t nuts_batch = 8;                 // momentum-refresh batch of the asynchronous kernel
 #ifdef MI_PROFILING
     if (const char* e = getenv("MI_NUTS_BATCH")) nuts_batch = (uint32_t)atoi(e);
 #endif
-    rc = general_tables("nuts", settings, d, gt, true, true);
-    if (rc) return rc;
     if (gt.active && gt.dense) {
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
@@ -2114,16 +2147,23 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
-        rc = nuts_dynamic(target, chains->n_chains) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st, true))
+        if (memo) { prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr; }
+        rc = memo ? launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st, true))
+           : nuts_dynamic(target, chains->n_chains) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st, true))
                                                      : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st, true));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         mi::NutsParams rp = prm;
+        rp.n_exec = nullptr;
         rp.nf_flag = nullptr; rp.replay_flag = nf_flag;
         rp.btype = gt.bt.as<int>(); rp.lb = gt.lb.as<double>(); rp.ub = gt.ub.as<double>();
         rp.vals_bound = 0;
         rc = launched("nuts (replay)", mi::launch_nuts_gauss(rp, nt, true, false, false, nuts_batch, st));
         mi::host::last_kernel() = reg_name;
+        if (!rc && prm.n_exec) {
+            hipLaunchKernelGGL(copy_flagged_counts_kernel, dim3((unsigned)((chains->n_chains + 255) / 256)), dim3(256), 0, st, nf_flag, prm.n_leap, prm.n_exec, chains->n_chains);
+            HIP_TRY(hipGetLastError());
+        }
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
     else if (gt.active) {
@@ -2146,10 +2186,12 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
         const uint64_t C_ = chains->n_chains;
         const bool few = C_ <= (uint64_t)32 * (uint64_t)n_cu;
-        const bool split = nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint == MI_KERNEL_AUTO && few));
+        const bool split = !memo && nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint == MI_KERNEL_AUTO && few));
         const int tpw = !few ? 4 : (C_ > (uint64_t)16 * (uint64_t)n_cu ? 2 : 1);
         // Many chains: the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp) -- a wave does not end with its slowest chain
-        rc = split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, tpw, pfrag, st))
+        if (memo) { prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr; }
+        rc = memo ? launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st))
+           : split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, tpw, pfrag, st))
            : nuts_dynamic(target, C_) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st))
                                       : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
@@ -2162,11 +2204,16 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         hipLaunchKernelGGL(fill_identity_tables_kernel, dim3(1), dim3(128), 0, st, bt_i, id_tab + 128, id_tab + 256, id_tab + 384, id_tab + 512, 128u);
         HIP_TRY(hipGetLastError());
         mi::NutsParams rp = prm;
+        rp.n_exec = nullptr;
         rp.nf_flag = nullptr; rp.replay_flag = nf_flag;
         rp.btype = bt_i; rp.lb = id_tab + 128; rp.ub = id_tab + 256; rp.m_sqrt = id_tab + 384; rp.m_inv = id_tab + 512;
         rp.vals_bound = 0;
         rc = launched("nuts (replay)", mi::launch_nuts_gauss(rp, nt, true, false, false, nuts_batch, st));
         mi::host::last_kernel() = reg_name;
+        if (!rc && prm.n_exec) {
+            hipLaunchKernelGGL(copy_flagged_counts_kernel, dim3((unsigned)((C_ + 255) / 256)), dim3(256), 0, st, nf_flag, prm.n_leap, prm.n_exec, C_);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (rc) return rc;
 

@@ -3,6 +3,7 @@
 #include "nuts_async_launch.hpp"
 #include "nuts_reg.hpp"
 #include "nuts_dyn.hpp"
+#include "nuts_memo.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
 
@@ -40,6 +41,39 @@ int dyn(NutsParams prm, uint32_t batch, hipStream_t st)
     return (int)hipGetLastError();
 }
 
+// every doubling on a memoised trajectory (nuts_memo.hpp): the same persistent grid
+template <int NT, bool DIAGM>
+size_t memo_lds()
+{
+    // fragments | 52 per-chain rows of 64 eight-byte columns (nuts_memo.hpp: R_END) | the test table | the mass tables
+    return ((size_t)NT * 4 * NT * 64 + 52 * 64) * sizeof(double) + 10 * 48 * sizeof(uint16_t) + (DIAGM ? 32 * NT : 0) * sizeof(double);
+}
+template <int NT, bool DIAGM>
+uint64_t memo_grid(uint64_t C)
+{
+    const size_t lds = memo_lds<NT, DIAGM>();
+    auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int dev = 0, n_cu = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint64_t need = (C + 63) / 64, cap = (uint64_t)n_cu * (uint64_t)per_cu;
+    return cap_grid(need < cap ? need : cap);
+}
+template <int NT, bool DIAGM>
+int memo(NutsParams prm, hipStream_t st)
+{
+    const size_t lds = memo_lds<NT, DIAGM>();
+    auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
+    note_kernel("nuts_gauss_memo_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
+    const uint64_t grid = memo_grid<NT, DIAGM>(prm.C);       // (sets the kernel's LDS attribute)
+    MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, prm);
+    return (int)hipGetLastError();
+}
+
 #ifdef MI_WITH_LEGACY_KERNELS   // the lock-step first-generation kernel (nuts_dense.hpp: 2.4 KB of scratch per lane at d = 128) ships in the
                                 // A/B library only (`make prof`); the shipped library ignores its hint, as mi_mcmc.h says of a hint it cannot take
 template <int NT>
@@ -74,6 +108,20 @@ int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStre
     if (batch < 1) batch = 1;
     if (diag_m) return MI_DISPATCH_NT(nt, (reg<1, true>(prm, batch, st)), (reg<2, true>(prm, batch, st)), (reg<4, true>(prm, batch, st)), (reg<8, true>(prm, batch, st)));
     return MI_DISPATCH_NT(nt, (reg<1, false>(prm, batch, st)), (reg<2, false>(prm, batch, st)), (reg<4, false>(prm, batch, st)), (reg<8, false>(prm, batch, st)));
+}
+
+int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)
+{
+    if (diag_m) return MI_DISPATCH_NT(nt, (memo<1, true>(prm, st)), (memo<2, true>(prm, st)), (memo<4, true>(prm, st)), (memo<8, true>(prm, st)));
+    return MI_DISPATCH_NT(nt, (memo<1, false>(prm, st)), (memo<2, false>(prm, st)), (memo<4, false>(prm, st)), (memo<8, false>(prm, st)));
+}
+
+size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)
+{
+    const uint64_t grid = diag_m ? MI_DISPATCH_NT(nt, (memo_grid<1, true>(C)), (memo_grid<2, true>(C)), (memo_grid<4, true>(C)), (memo_grid<8, true>(C)))
+                                 : MI_DISPATCH_NT(nt, (memo_grid<1, false>(C)), (memo_grid<2, false>(C)), (memo_grid<4, false>(C)), (memo_grid<8, false>(C)));
+    const int ns = 4 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8);
+    return (size_t)grid * 4 * memo_wave_bytes(ns);
 }
 
 int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)

@@ -1,0 +1,675 @@
+// nuts_memo.hpp -- many-chain NUTS for the plain case (unbounded; identity or DIAGONAL precond_mat; d <= 128, max_tree_depth <= 10) with every
+// doubling evaluated on a MEMOISED TRAJECTORY: same draws, accepts, tree depths, leapfrog counts and step sizes as nuts_reg.hpp / nuts_dyn.hpp,
+// bit for bit, with ~40 % fewer leapfrogs executed on BASELINE configs[3].
+//
+// Replaces what they replace: mcmc::internal::nuts_impl with nuts_find_initial_step_size and nuts_build_tree
+// (/root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241).
+//
+// Why.  The reference's second-half calls cross their edge outputs (nuts.ipp:195,207) and every doubling restarts from (prev_draw, mntm_vec)
+// (src/nuts.cpp:241-256).  nuts_dense.hpp derives from that plumbing that leaf i of a doubling (c = ctz i) starts from the result of leaf
+// i - 1 (c <= 1) or of leaf i - 2^(c-1), i.e. the state after leaf i is
+//        s(i) = LF^{n(i)}(prev_draw, mntm_vec),        n(i) = 1 + sum over the set bits k of i of (k + 1):
+// the 2^j leaves of a doubling lie on ONE trajectory and visit only 1 + j (j + 1) / 2 distinct points of it (46 of 512 at j = 9), and the
+// U-turn test of a level-l node whose first leaf sits at point n1 (nuts.ipp:224-229) compares the points n1 and n1 + l.  A leaf's n', s',
+// alpha (nuts.ipp:146-157) depend on its point only.  The kernels before this one execute every leaf's leapfrog: on configs[3] (65 536
+// chains, 100 adapting + 100 kept draws) 42 % of the executed leapfrogs recompute a state the same doubling has already computed (the
+// burn-in grows depth-8..10 trees while the step size adapts; measured with oracle/mcmc_oracle.c: orc_nuts_memo, which is this algorithm on
+// the CPU and is checked against the recursion bit for bit in tests/test_oracle_memo.py).
+//
+// The tick.  Chains are handed to 16 slots per wave dynamically (nuts_dyn.hpp: persistent grid, global counter, INIT / SEARCH as tick
+// states).  Per tick every chain inside a tree
+//   1. computes the NEXT POINT of its doubling's trajectory -- one leapfrog from the point in registers (the trajectory is sequential: no
+//      start-record loads except the origin at the start of a doubling), P theta on the matrix cores --, its energies and the leaf scalars
+//      (n', s' as bits, alpha and U in a per-chain scalar table), and stores the point's record (theta, p, P theta);
+//   2. evaluates the U-turn tests whose SECOND point this is: for every level l with a node whose first leaf sits at point m - l (a table
+//      in LDS says which), (theta, p)(m - l) from memory against (theta, p)(m) in registers -- the first one is requested before the
+//      mat-vec and lands under it; the results are bits in an LDS table [level][point];
+//   3. WALKS the leaves that this point unblocks: leaf after leaf exactly as the recursion returns through them (nuts.ipp:212-239: the same
+//      merges in the same order, one uniform per merge from the same Philox slot, the same early exit), on the memoised scalars -- no
+//      vector work at all -- until the chain needs a point that does not exist yet, or its doubling ends;
+//   4. ends the doubling as before (top-level accept src/nuts.cpp:260-279 -- the proposal is a point record --, the test :286-289, dual
+//      averaging, next doubling / next draw).
+// n_leapfrogs reports the REFERENCE's count (one per leaf walked: what mcmc::nuts executes); NutsParams::n_exec the leapfrogs really made.
+//
+// Workspace per wave: 10 fixed vectors (prev_draw x 2 with P theta, momentum x 2, the four edge vectors) + 3 vectors per point (46 points at
+// max_tree_depth 10) in the record layout of nuts_async.hpp, then the scalar table [47][64 lanes][alpha, U].  Non-finite regime: detected,
+// flagged, retired and replayed by the general variant exactly as nuts_dyn.hpp does.
+
+#pragma once
+
+#include "nuts_reg.hpp"
+#include "nuts_dyn.hpp"
+
+namespace mi {
+
+enum : int {
+    MV_MNTM2 = 7, MV_PREVB = 8, MV_WPREVB = 9,
+    MV_PT0 = 10,                 // point n (1 ..): theta at MV_PT0 + 3 (n - 1), p at + 1, P theta at + 2
+    MEMO_MAXPTS = 46,            // 1 + 9 * 10 / 2: the deepest doubling of max_tree_depth = 10 has depth 9
+    MEMO_NVEC = MV_PT0 + 3 * MEMO_MAXPTS
+};
+
+// bytes of workspace per wave (16 chain slots): the vectors, then the scalar table
+__host__ __device__ constexpr size_t memo_wave_bytes(int NS) { return (size_t)MEMO_NVEC * NS * 512 + (size_t)(MEMO_MAXPTS + 1) * 64 * 16; }
+
+// point of leaf i: n(i) = 1 + sum_{k : bit k of i} (k + 1) = 1 + popc(i) + sum_b 2^b popc(i & M_b), M_b = the bit positions k with bit b of k set
+__device__ __forceinline__ uint32_t memo_npt(uint32_t i)
+{
+    return 1u + (uint32_t)__builtin_popcount(i) + (uint32_t)__builtin_popcount(i & 0x2AAu) + 2u * (uint32_t)__builtin_popcount(i & 0xCCu)
+         + 4u * (uint32_t)__builtin_popcount(i & 0xF0u) + 8u * (uint32_t)__builtin_popcount(i & 0x300u);
+}
+// is there a level-l node in a doubling of depth j whose first leaf sits at point n1?  (first leaves of level-l nodes: multiples of 2^l; n1 - 1
+// must be a sum of distinct integers of {l + 1 .. j}: the sums of t of these consecutive integers are the integers between the t smallest
+// and the t largest)
+__host__ __device__ inline bool memo_pair_used(int l, int n1, int j)
+{
+    const int m = n1 - 1;
+    for (int t = 0; t <= j - l; ++t) {
+        const int lo = t * (l + 1) + t * (t - 1) / 2, hi = t * j - t * (t - 1) / 2;
+        if (m >= lo && m <= hi) return true;
+    }
+    return false;
+}
+
+template <int NT, bool DIAGM = false>
+__global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(const NutsParams prm)
+{
+    constexpr int NS = 4 * NT;
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    double* lds_P = lds_all;
+    // behind the fragments: per-chain rows of 64 eight-byte columns (column = chain slot of the workgroup), addressed from ONE opaque
+    // per-lane base + an immediate offset (as separate arrays the row addresses are loop invariants of the tick loop -- a dozen VGPRs the
+    // d = 128 instantiation does not have: they were spilled and reloaded from scratch)
+    enum : int {
+        R_LA = 0,        // [11]: alpha' of the pending first half of level l (row 0 unused)
+        R_SC = 11,       // [4]: per-draw scalars: kinetic energy of the draw's momentum, n, alpha, n_alpha
+        R_NF = 15,       // non-zero = the chain saw a non-finite energy
+        R_DA = 16,       // [3]: the dual-averaging state (h, epsilon_bar, mu)
+        R_OKB = 19,      // [12] bit masks over points: row 0: n' of point n; rows 1..10: the U-turn test of the level-l node whose first leaf sits
+                         // at point n1 passed; row 11: s' of point n
+        R_LP = 31,       // [11]: n' | n_alpha' << 11 | proposal point << 22 of the pending first half of level l
+        R_CH = 42,       // [7]: step size, U of prev_draw, H0 and log u of the draw / doubling, the signed step, kinetic energy and log u of the NEXT draw
+        R_CT = 49,       // [3] counters: leapfrogs as the reference counts them, leapfrogs executed, accepted kept draws
+        R_END = 52
+    };
+    char* const lds_rows = reinterpret_cast<char*>(lds_all + NT * NS * 64);
+    uint16_t* lds_pm = reinterpret_cast<uint16_t*>(lds_rows + R_END * 512);   // [10][48]: bit l of [j][m]: point m of a depth-j doubling closes a level-l test
+    [[maybe_unused]] double* lds_ms = reinterpret_cast<double*>(lds_pm + 10 * 48);   // DIAGM: [16 NT] sqrt(m), [16 NT] 1 / m   (10 * 48 * 2 = 960 bytes: 8-aligned)
+    [[maybe_unused]] double* lds_mi = lds_ms + 16 * NT;
+    if (DIAGM) {
+        for (int i = threadIdx.x; i < 16 * NT; i += blockDim.x) {
+            const bool in = (uint32_t)i < prm.d;
+            lds_ms[i] = in ? prm.m_sqrt[i] : 1.0;
+            lds_mi[i] = in ? prm.m_inv[i] : 1.0;
+        }
+    }
+    for (int i = threadIdx.x; i < 10 * 48; i += blockDim.x) {
+        const int j = i / 48, m = i % 48;
+        uint32_t bits = 0;
+        for (int l = 1; l <= j; ++l)
+            if (m - l >= 1 && memo_pair_used(l, m - l, j)) bits |= 1u << l;
+        lds_pm[i] = (uint16_t)bits;
+    }
+    stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j4 = lane >> 4;
+    const int cw = wave * 16 + (lane & 15);
+    const uint32_t d = prm.d;
+    const uint64_t C = prm.C;
+    const uint64_t n_slots = (uint64_t)gridDim.x * 64;   // chains [0, n_slots) start in their own slot; the counter hands out the rest
+    uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);     // this slot's chain (the four lanes of a chain agree); >= C: none
+    bool exhausted = false;
+    const double* afrag = lds_P + lane;
+
+    char* lrow = lds_rows + cw * 8;                      // redefined (opaquely) at the top of every tick
+    auto rd_ = [&](int r) -> double& { return *reinterpret_cast<double*>(lrow + r * 512); };
+    auto ru_ = [&](int r) -> unsigned long long& { return *reinterpret_cast<unsigned long long*>(lrow + r * 512); };
+    auto la_ = [&](int l) -> double& { return rd_(R_LA + l); };
+    auto lp_ = [&](int l) -> unsigned long long& { return ru_(R_LP + l); };
+    auto okb_ = [&](int r) -> unsigned long long& { return ru_(R_OKB + r); };
+    auto nf_ = [&]() -> double& { return rd_(R_NF); };
+    // workspace: [wave] blocks of memo_wave_bytes, wave-uniform base + one 32-bit byte offset per access (nuts_async.hpp)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * memo_wave_bytes(NS);
+    // inside a vector: [chain][pair of slices][j4] in 16-byte granules (nuts_async.hpp: why)
+    uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)j4 * 16u;     // redefined (opaquely) at the top of every tick
+    uint32_t lane_sc = (uint32_t)MEMO_NVEC * (uint32_t)(NS * 512) + (uint32_t)lane * 16u;   // this lane's column of the scalar table
+    auto wsp = [&](int v, int s) -> double* {                // s even: the pair (s, s + 1) of this lane
+        return reinterpret_cast<double*>(ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b + (uint32_t)(s >> 1) * 64u));
+    };
+    auto scp = [&](uint32_t n) -> double2* { return reinterpret_cast<double2*>(ws_wave_u + (lane_sc + n * 1024u)); };   // (alpha, U) of point n
+    auto ld_row = [&](int v, int s0, auto& dst) __attribute__((always_inline)) {      // dst[0..N) <- slices s0.. of vector v
+        constexpr int N = (int)(sizeof(dst) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(wsp(v, s0 + k));
+            dst[k] = t.x; dst[k + 1] = t.y;
+        }
+    };
+    auto st_row = [&](int v, int s0, const auto& src) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(src) / sizeof(double));
+        static_assert(N % 2 == 0, "rows move in pairs of slices");
+#pragma unroll
+        for (int k = 0; k < N; k += 2) *reinterpret_cast<double2*>(wsp(v, s0 + k)) = double2{src[k], src[k + 1]};
+    };
+    auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
+        *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
+    };
+    auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
+    [[maybe_unused]] auto mcol = [&](const double* tab) __attribute__((always_inline)) -> const double* {
+        const double* p = tab + (lane >> 4);
+        asm volatile("" : "+v"(p));
+        return p;
+    };
+    // K = p . (Minv p) / 2 (nuts.cpp leap_frog_fn / nuts.ipp:51,66,140)
+    auto kinetic_of = [&](const double (&p)[NS]) __attribute__((always_inline)) -> double {
+        if constexpr (DIAGM) {
+            const double* mic = mcol(lds_mi);
+            double q = 0.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) q = dfma(p[s], mic[4 * s] * p[s], q);
+            q = q + __shfl_xor(q, 32);
+            q = q + __shfl_xor(q, 16);
+            return q / 2.0;
+        } else {
+            return dot4<NS>(p, p) / 2.0;
+        }
+    };
+
+    constexpr int CHC = (NS < MI_NUTS_R_CHC) ? NS : MI_NUTS_R_CHC;
+    // the LAST POINT of the chain's trajectory (or the doubling's origin): position, momentum, P * position (MFMA B / D layout).  Loop-carried.
+    double th[NS], pm[NS], w[NS];
+
+    auto note_nonfinite = [&](bool bad) __attribute__((always_inline)) { if (__ballot(bad) != 0ull) { if (bad) nf_() = 1.0; } };
+    nf_() = 0.0;
+    auto eps_ = [&]() -> double& { return rd_(R_CH); };
+    auto prev_U_ = [&]() -> double& { return rd_(R_CH + 1); };
+    auto H0_ = [&]() -> double& { return rd_(R_CH + 2); };
+    auto log_u_ = [&]() -> double& { return rd_(R_CH + 3); };
+    auto esg_ = [&]() -> double& { return rd_(R_CH + 4); };
+    auto next_K_ = [&]() -> double& { return rd_(R_CH + 5); };
+    auto next_lu_ = [&]() -> double& { return rd_(R_CH + 6); };
+    auto n_leap_ = [&]() -> unsigned long long& { return ru_(R_CT); };
+    auto n_exec_ = [&]() -> unsigned long long& { return ru_(R_CT + 1); };
+    auto n_acc_ = [&]() -> unsigned long long& { return ru_(R_CT + 2); };
+    n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull;
+    eps_() = 1.0; prev_U_() = 0.0;
+    const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
+    auto h_val_ = [&]() -> double& { return rd_(R_DA); };
+    auto eps_bar_ = [&]() -> double& { return rd_(R_DA + 1); };
+    auto mu_val_ = [&]() -> double& { return rd_(R_DA + 2); };
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    const uint32_t n_adapt = prm.n_adapt;
+    const uint32_t max_depth = prm.max_depth;
+
+    // ---------------------------------------------------------------- per-chain state
+    int state = (cl < C) ? NS_INIT : NS_DONE;
+    bool s_first = true;         // SEARCH: the leapfrog of nuts.ipp:62-72 (before the loop); vdir carries a of nuts.ipp:75, H0 carries U0 + K0
+    uint32_t draw = 0;           // this chain's draw index
+    uint32_t jd = 0;             // depth of the doubling in progress
+    uint32_t li = 0;             // next leaf of that doubling to be walked
+    uint32_t npts = 0;           // points of its trajectory that exist (the registers hold point npts; 0: the origin has to be loaded)
+    uint32_t uslot = 0;
+    int vdir = 1;
+    auto prev_K_ = [&]() -> double& { return rd_(R_SC); };
+    auto n_val_ = [&]() -> double& { return rd_(R_SC + 1); };
+    auto alpha_ = [&]() -> double& { return rd_(R_SC + 2); };
+    auto n_alpha_ = [&]() -> double& { return rd_(R_SC + 3); };
+    int good_round = 0;
+    // Draw boundaries without waiting: as nuts_reg.hpp / nuts_dyn.hpp (momenta generated ahead, prev_draw alternating between two vectors,
+    // the edges are the draw's initial vectors until a doubling has written that side)
+    int mv = V_MNTM, mvn = MV_MNTM2;
+    int pb = 0, pb0 = 0;
+    bool mom_ready = false;
+    bool row_pend = false, row2_pend = false;
+    uint32_t row_draw = 0;
+    bool pos_init = true, neg_init = true;
+    auto pvec = [](int b) -> int { return b ? MV_PREVB : V_PREV; };
+    auto wvec = [](int b) -> int { return b ? MV_WPREVB : V_WPREV; };
+
+    // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
+    auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
+        const double zdir = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);
+        if (p) {
+            uslot++;
+            vdir = (zdir <= 0.5) ? -1 : 1;
+            esg_() = (double)vdir * eps_();
+            H0_() = prev_U_() + prev_K_();
+            li = 0; npts = 0;
+        }
+    };
+    // end of a draw for lanes with `p` (dual averaging nuts.cpp:294-302; the row store :306-309 is left to the next phase)
+    auto end_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {
+        if (p && prm.depth_trace && j4 == 0) prm.depth_trace[(size_t)draw * C + cl] = my_depth;
+        if (__ballot(p && draw + prm.draw0 < n_adapt) != 0ull) {
+            if (p && draw + prm.draw0 < n_adapt) {
+                const double it = (double)(draw + prm.draw0 + 1);
+                const double h_new = h_val_() + (1.0 / (it + prm.t0)) * (prm.delta - (alpha_() / n_alpha_()) - h_val_());
+                h_val_() = h_new;
+                const double e_new = det_exp(mu_val_() - h_new * __builtin_sqrt(it) / prm.gamma);
+                eps_() = e_new;
+                const double eb = eps_bar_();
+                eps_bar_() = eb * det_exp(det_pow(it, -prm.kappa) * (det_log(e_new) - det_log(eb)));
+            }
+        }
+        if (p && !(draw + prm.draw0 < n_adapt)) eps_() = eps_bar_();
+        const bool kept = p && draw >= prm.n_burnin;
+        if (kept) n_acc_() += (unsigned long long)good_round;
+        if (p) {
+            row2_pend = kept && prm.draws != nullptr;
+            draw++;
+        }
+    };
+    // kept row `idx` of lanes with `p` from workspace vector `vec`
+    auto store_row = [&](bool p, int vec, uint32_t idx) __attribute__((always_inline)) {
+        if (__ballot(p) == 0ull) return;
+        if (p) {
+            double* out = prm.draws + (size_t)(idx - prm.n_burnin) * d * C;
+            const size_t lane_off = (size_t)j4 * C + cl;
+#pragma unroll
+            for (int c0 = 0; c0 < NS; c0 += CHC) {
+                double tmp[CHC];
+                ld_row(vec, c0, tmp);
+#pragma unroll
+                for (int k = 0; k < CHC; ++k)
+                    if (dim_ok(c0 + k)) (out + (size_t)(4 * (c0 + k)) * C)[lane_off] = tmp[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // lanes with `p` (next momentum ready, no older row pending) enter their next draw (nuts.cpp:200-219)
+    auto roll_state = [&](bool p) __attribute__((always_inline)) {
+        if (p) {
+            const int t_ = mv; mv = mvn; mvn = t_;
+            const double nk = next_K_();
+            prev_K_() = nk;
+            log_u_() = next_lu_() - prev_U_() - nk;       // :206
+            mom_ready = false;
+            row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
+            pb0 = pb; pos_init = true; neg_init = true;
+            uslot = 1;
+            jd = 0; n_val_() = 1.0; alpha_() = 0.0; n_alpha_() = 0.0; good_round = 0;
+            state = NS_TREE;
+        }
+    };
+    // a chain leaves its slot: final state, counters, step size and dual-averaging state (nuts.cpp:311-330) -- or, flagged, only its flag
+    auto retire = [&](bool p) __attribute__((always_inline)) {
+        if (__ballot(p) == 0ull) return;
+        const bool flagged = p && nf_() != 0.0 && prm.nf_flag != nullptr;
+        if (flagged && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+        if (p && !flagged) {
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {           // (a rolled loop: see INIT)
+                const double2 t = *reinterpret_cast<const double2*>(wsp(pvec(pb), 2 * b));
+                double* dst = prm.theta + ((size_t)(8u * b + j4) * C + cl);
+                if (8u * b + j4 < d) dst[0] = t.x;
+                if (8u * b + 4 + j4 < d) dst[(size_t)4 * C] = t.y;
+            }
+            if (j4 == 0) {
+                if (prm.n_accept) prm.n_accept[cl] = n_acc_();
+                if (prm.n_leap) prm.n_leap[cl] = n_leap_();
+                if (prm.n_exec) prm.n_exec[cl] = n_exec_();
+                if (prm.step_out) prm.step_out[cl] = eps_();
+                if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
+            }
+        }
+        if (p) state = NS_DONE;
+    };
+    // SEARCH ends (or is skipped by a continuation): the dual-averaging state of nuts.cpp:174-176, then the chain waits for its first phase
+    auto start_sampling = [&](bool p) __attribute__((always_inline)) {
+        if (__ballot(p) == 0ull) return;
+        if (p) {
+            mu_val_() = det_log(10 * eps_());                // nuts.cpp:174
+            h_val_() = 0.0;
+            eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps_();
+            if (prm.draw0 > 0 && prm.draw0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+                h_val_() = prm.adapt_state[cl]; eps_bar_() = prm.adapt_state[C + cl]; mu_val_() = prm.adapt_state[2 * C + cl];
+            }
+            state = NS_NEED_DRAW;
+        }
+    };
+
+#pragma unroll 1
+    for (;;) {
+        asm volatile("" : "+v"(lane_b), "+v"(lane_sc), "+v"(lrow));
+        retire(state != NS_DONE && nf_() != 0.0);   // a flagged chain is replayed from its initial state: nothing of it is kept
+        // ------------------------------------------------------------ free slots take the next chains
+        {
+            const bool want = state == NS_DONE && !exhausted;
+            const uint32_t m = (uint32_t)(__ballot(want) & 0xffffull);      // the wave's 16 slots (lanes 0..15; the j4 copies agree)
+            if (m != 0u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(prm.next_chain, (uint32_t)__builtin_popcount(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint64_t nid = n_slots + base + (uint32_t)__builtin_popcount(m & ((1u << (lane & 15)) - 1u));
+                if (want) {
+                    if (nid < C) {                       // a new chain in this slot: everything per-chain starts over
+                        cl = nid;
+                        state = NS_INIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
+                        mv = V_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false;
+                    } else exhausted = true;
+                }
+            }
+        }
+        if (__ballot(state != NS_DONE) == 0ull) break;
+        // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
+        if (__ballot(state == NS_NEED_DRAW) != 0ull) {
+            store_row(row_pend, pvec(pb0), row_draw);
+            store_row(row2_pend, pvec(pb), draw - 1u);
+            row_pend = false; row2_pend = false;
+            retire(state == NS_NEED_DRAW && draw >= n_total);
+            const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
+            const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
+            double kq = 0.0;
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
+                double z0, z1;
+                rng_normal_pair(prm.seed, prm.chain0 + cl, nidx + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+                double pa = (8u * b + j4 < d) ? z0 : 0.0;
+                double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                if constexpr (DIAGM) {                       // :202 and :204 with the diagonal matrices
+                    const double* msc = lds_ms + 8 * b + j4;
+                    const double* mic = lds_mi + 8 * b + j4;
+                    pa = msc[0] * pa; pb_ = msc[4] * pb_;
+                    kq = dfma(pa, mic[0] * pa, kq);
+                    kq = dfma(pb_, mic[4] * pb_, kq);
+                } else {
+                    kq = dfma(pa, pa, kq);
+                    kq = dfma(pb_, pb_, kq);
+                }
+                if (gen) st_pair(mvn, 2 * b, pa, pb_);
+            }
+            kq = kq + __shfl_xor(kq, 32);
+            kq = kq + __shfl_xor(kq, 16);
+            const double lu = det_log(rng_uniform(prm.seed, prm.chain0 + cl, nidx + prm.draw0, 0u));
+            if (gen) { next_K_() = kq / 2.0; next_lu_() = lu; mom_ready = true; }     // :204
+            const bool p = state == NS_NEED_DRAW;             // (all of them have a momentum now and no row pending)
+            roll_state(p);
+            if (max_depth > 0) begin_doubling(p);
+            else { end_draw(p, 0u); if (p) state = NS_NEED_DRAW; }              // while-loop of :227 never entered
+        }
+        const bool run = state == NS_TREE, init = state == NS_INIT, srch = state == NS_SEARCH;
+        if (__ballot(run || init || srch) == 0ull) continue;
+
+        // INIT: first_draw and z_init (nuts.cpp:160-168) are staged in the workspace -- theta in V_PREV, the momentum in mv -- and enter the
+        // registers through the origin load below; the tick is P theta with e = 0 (nuts_dyn.hpp: why rolled loops, and why here)
+        if (__ballot(init) != 0ull) {
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {
+                const bool in0 = 8u * b + j4 < d, in1 = 8u * b + 4 + j4 < d;
+                const double* src = prm.theta + ((size_t)(in0 ? 8u * b + j4 : 0u) * C + cl);
+                double t0 = 0.0, t1 = 0.0;
+                if (init) { t0 = src[0]; t1 = src[in1 ? (size_t)4 * C : 0]; }
+                if (init) st_pair(V_PREV, 2 * b, in0 ? t0 : 0.0, in1 ? t1 : 0.0);
+            }
+#pragma unroll 1
+            for (int b = 0; b < NS / 2; ++b) {
+                double z0, z1;
+                rng_normal_pair(prm.seed, prm.chain0 + cl, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
+                double pa = (8u * b + j4 < d) ? z0 : 0.0;
+                double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                if constexpr (DIAGM) { pa = lds_ms[8 * b + j4] * pa; pb_ = lds_ms[8 * b + 4 + j4] * pb_; }      // nuts.cpp:168
+                if (init) st_pair(mv, 2 * b, pa, pb_);
+            }
+        }
+        // ------------------------------------------------------------ B. the next point of every running chain's trajectory
+        {   // the origin of a doubling (prev_draw, mntm_vec, P prev_draw: src/nuts.cpp:241-256); every later point continues from the registers
+            const bool need = (run && npts == 0u) || init;
+            if (__ballot(need) != 0ull) {
+                const int vt = pvec(pb), vp = mv, vw = init ? pvec(pb) : wvec(pb);      // INIT: first_draw (pb = 0), any finite row as P theta (e = 0)
+                if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
+            }
+        }
+        const uint32_t mpt = npts + 1u;                  // the point this tick computes (run lanes)
+        // the tests this point closes: level l against point mpt - l (lds_pm), lowest level first
+        uint32_t pmask = run ? (uint32_t)lds_pm[jd * 48u + mpt] : 0u;
+        double dd[NS];           // theta of the other point of a test, then d = theta(mpt) - theta(mpt - l) (by direction)
+        double Lp[NS];           // p of the other point
+        [[maybe_unused]] const double* mic_d = DIAGM ? mcol(lds_mi) : nullptr;
+        // SEARCH: the step of this leapfrog (nuts.ipp:62, 80-82).  INIT: e = 0, and the state is set after the (idle) updates
+        if (srch) {
+            if (!s_first) eps_() = eps_() * ((vdir == 1) ? 2.0 : 0.5);
+            n_leap_() += 1ull; n_exec_() += 1ull;
+        }
+        const double e_tick = run ? esg_() : (srch ? eps_() : 0.0);
+        // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            pm[s_] = pm[s_] - (e_tick * w[s_]) / 2.0;
+            if constexpr (DIAGM) th[s_] = th[s_] + e_tick * (mic_d[4 * s_] * pm[s_]);
+            else th[s_] = th[s_] + e_tick * pm[s_];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the first test's rows are requested here and used AFTER the mat-vec (8.6 us of matrix-pipe time in which the wave has nothing else
+        // in flight): their latency costs nothing
+#ifndef MI_MEMO_NO_PREFETCH
+        {
+            const bool t1 = pmask != 0u;
+            if (__ballot(t1) != 0ull) {
+                const int l1 = t1 ? __builtin_ctz(pmask) : 1;
+                const int vq = MV_PT0 + 3 * ((int)mpt - l1 - 1);
+                if (t1) { ld_row(vq, 0, dd); ld_row(vq + 1, 0, Lp); }
+            }
+        }
+#endif
+        matvec_mfma<NT>(afrag, th, w);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_tick * w[s]) / 2.0;
+        double pU = 0.5 * dot4<NS>(th, w);               // nuts.ipp:134-138 / :50,65
+        const double pK = kinetic_of(pm);                // :140 / :51,66
+        // ---- INIT: the chain's first state is on record; SEARCH: one step of nuts_find_initial_step_size
+        if (__ballot(init) != 0ull) {
+            if (init) {
+                st_row(V_PREV, 0, th); st_row(V_WPREV, 0, w);
+                prev_U_() = pU;                          // nuts.cpp:181 (no finiteness guard there)
+                if (!is_finite(pU)) nf_() = 1.0;
+                H0_() = (is_finite(pU) ? pU : INF) + pK; // U0 + K0 (nuts.ipp:50-52)
+                s_first = true;
+            }
+            if (init && prm.draw0 != 0) eps_() = prm.step_out ? prm.step_out[cl] : 1.0;  // a continuation: the step size comes back in
+            start_sampling(init && prm.draw0 != 0);
+            if (init && prm.draw0 == 0) state = NS_SEARCH;
+        }
+        if (!is_finite(pU)) pU = INF;
+        if (__ballot(srch) != 0ull) {
+            const double dHs = -(pU + pK) + H0_();       // nuts.ipp:68,86
+            note_nonfinite(srch && !is_finite(dHs));
+            if (srch) { vdir = 2 * (dHs > log_half ? 1 : 0) - 1; s_first = false; }      // :75,88
+            start_sampling(srch && !(dHs > neg_log2));   // :78,90: the loop ends
+        }
+        if (__ballot(run) == 0ull) continue;
+        // ---- the point's record and scalars (nuts.ipp:146-157)
+        const double dH = -(pU + pK) + H0_();
+        note_nonfinite(run && !is_finite(dH));           // pU (replaced by +inf above), pK or the draw's H0 non-finite
+        double ca = det_exp((dH < 0.0) ? dH : 0.0);      // :157
+        if (run) {
+            const int vr = MV_PT0 + 3 * ((int)mpt - 1);
+            st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
+            *scp(mpt) = double2{ca, pU};
+            const unsigned long long bit = 1ull << mpt;
+            const double lu_ = log_u_();
+            const bool cn_b = lu_ <= -pU - pK;           // :146
+            const bool cs_b = lu_ < 1000.0 - pU - pK;    // :147
+            okb_(0) = (okb_(0) & ~bit) | (cn_b ? bit : 0ull);
+            okb_(11) = (okb_(11) & ~bit) | (cs_b ? bit : 0ull);
+            n_exec_() += 1ull;
+        }
+        // the tree's far edge (= the first leaf of its second half, point 1 + jd; the leaf itself at depth 0) is what a successful doubling leaves
+        // in draw_pos / draw_neg (src/nuts.cpp:241-256); a doubling that fails before that leaf ends the draw, so writing it early is harmless
+        const bool st_edge = run && mpt == 1u + jd;
+        if (st_edge) {
+            const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+            st_row(et, 0, th); st_row(ep, 0, pm);
+            if (vdir > 0) pos_init = false; else neg_init = false;
+        }
+        // ---- the tests whose second point this is: [ d . p(n1) >= 0 ] * [ d . p(mpt) >= 0 ], d = theta(mpt) - theta(n1) by direction (:224-229)
+        {
+#ifndef MI_MEMO_NO_PREFETCH
+            bool first = true;
+#else
+            bool first = false;
+#endif
+#ifdef MI_MEMO_X_NOPAIR
+            pmask = 0;
+#endif
+#pragma unroll 1
+            while (__ballot(pmask != 0u) != 0ull) {
+                const bool t = pmask != 0u;
+                const int l = t ? __builtin_ctz(pmask) : 1;
+                const int n1 = (int)mpt - l;
+                if (!first) {
+                    const int vq = MV_PT0 + 3 * (n1 - 1);
+                    if (t) { ld_row(vq, 0, dd); ld_row(vq + 1, 0, Lp); }
+                }
+                first = false;
+                // (two passes: d . p(n1) with theta, d, p(n1) as operands, then d . p(mpt) with d, p -- four vectors as VALU operands of one loop
+                //  are the whole architectural register file, and the allocator spills instead of streaming them from the AGPRs)
+                double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) {
+                    dd[s_] = (vdir > 0) ? (th[s_] - dd[s_]) : (dd[s_] - th[s_]);
+                    q1 = dfma(dd[s_], Lp[s_], q1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) q2 = dfma(dd[s_], pm[s_], q2);
+                q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
+                q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
+                if (t) {
+                    const unsigned long long bit = 1ull << n1;
+                    const bool ok = (q1 >= 0.0) && (q2 >= 0.0);
+                    okb_(l) = (okb_(l) & ~bit) | (ok ? bit : 0ull);
+                    pmask &= pmask - 1u;
+                }
+            }
+        }
+        if (run) npts = mpt;
+        // ------------------------------------------------------------ C. walk the leaves this point unblocks (nuts.ipp:146-158, 212-239)
+        bool wl = run;                                   // (the leaf the chain was waiting at sits on the new point)
+        bool at_fin = false, complete = false;
+        uint32_t cn_i = 0, cna_i = 0, cref = 0;
+        double ca_nx = 0.0;
+#ifdef MI_MEMO_X_NOWALK
+        wl = false; at_fin = run; complete = run;
+#endif
+#pragma unroll 1
+        while (__ballot(wl) != 0ull) {
+            const uint32_t n = memo_npt(li);
+            // the next leaf's alpha, in case the chain gets that far (it is on record if its point exists)
+            {
+                const uint32_t nn = memo_npt(li + 1u);
+                if (wl && nn <= npts) ca_nx = scp(nn)->x;
+            }
+            const unsigned long long nbit = 1ull << n;
+            if (wl) {
+                cn_i = (okb_(0) & nbit) ? 1u : 0u;
+                cna_i = 1u; cref = n;
+                n_leap_() += 1ull;
+            }
+            bool failed = wl && !(okb_(11) & nbit);
+            bool walking = wl;
+            uint32_t pend_level = jd + 1;
+#pragma unroll 1
+            for (uint32_t l = 1; l <= (uint32_t)NUTS_MAX_DEPTH; ++l) {
+                if (walking && l > jd) walking = false;                      // reached the root of its own tree
+                const bool bit = ((li >> (l - 1)) & 1u) != 0u;
+                if (walking && !failed && !bit) { pend_level = l; walking = false; }   // first half: wait here
+                if (__ballot(walking) == 0ull) break;
+                const bool mrg = walking && bit;
+                if (__ballot(mrg) == 0ull) continue;
+#ifdef MI_MEMO_X_NORNG
+                const double z = 0.25;
+#else
+                const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :213
+#endif
+                if (mrg) {
+                    uslot++;
+                    const uint32_t pk = (uint32_t)lp_((int)l);
+                    const uint32_t p_n = pk & 0x7ffu, p_na = (pk >> 11) & 0x7ffu, p_ref = pk >> 22;
+                    const double prob = (double)cn_i / (double)(p_n + cn_i);     // :212
+                    if (!(z < prob)) cref = p_ref;                               // keep new_draw_p (:215-217; 0 / 0 = NaN keeps)
+                    cn_i = p_n + cn_i;                                           // :220-222
+                    ca = la_((int)l) + ca;
+                    cna_i = p_na + cna_i;
+                    if (!failed) {                                               // :226-229, evaluated when its second point appeared
+                        const uint32_t n1 = n - l * (l + 1u) / 2u;               // the node's first leaf: li with its l low (set) bits cleared
+                        if (!((okb_((int)l) >> n1) & 1ull)) failed = true;
+                    }
+                }
+            }
+            if (wl) {
+                const bool keep = !failed;
+                complete = keep && (li == (1u << jd) - 1u);
+                if (keep && !complete) {                 // a pending first half: scalars to LDS, the proposal by reference (its point)
+                    la_((int)pend_level) = ca;
+                    lp_((int)pend_level) = (unsigned long long)(cn_i | (cna_i << 11) | (cref << 22));
+                    li = li + 1u;
+                    ca = ca_nx;
+                    wl = memo_npt(li) <= npts;
+                } else {
+                    at_fin = true; wl = false;
+                }
+            }
+        }
+        // ------------------------------------------------------------ D. end of a doubling (src/nuts.cpp:260-289)
+#ifdef MI_MEMO_X_NOFIN
+        at_fin = false; if (run) { li = 0; npts = 0; }
+#endif
+        if (__ballot(at_fin) != 0ull) {
+            bool take = false;
+            if (__ballot(complete) != 0ull) {
+                const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :261
+                if (complete) {
+                    uslot++;
+                    take = z < (double)cn_i / n_val_();                         // :263
+                    if (take) { good_round = 1; pb = 1 - pb0; }                 // :264-277
+                }
+            }
+            if (__ballot(take) != 0ull) {
+                if (take) {      // the proposal is a point of the trajectory: its record goes to prev_draw (both rows in ONE round trip)
+                    const int vq = MV_PT0 + 3 * ((int)cref - 1);
+                    ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
+                    prev_U_() = scp(cref)->y;
+                    st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
+                }
+            }
+            if (at_fin) { alpha_() = ca; n_alpha_() = (double)cna_i; n_val_() = n_val_() + (double)cn_i; }   // :246,255 ; :283
+            bool s_ok = false;
+            if (__ballot(complete) != 0ull) {
+                const int en_t = neg_init ? pvec(pb0) : V_TNEG_T, en_p = neg_init ? mv : V_TNEG_P;
+                const int ep_t = pos_init ? pvec(pb0) : V_TPOS_T, ep_p = pos_init ? mv : V_TPOS_P;
+                // [ (pos - neg) . p_neg >= 0 ] * [ (pos - neg) . p_pos >= 0 ] (:286-289).  The trajectory of a chain whose doubling is complete is
+                // dead (the next doubling starts from prev_draw), so its registers take the four operands in ONE round trip
+                double (&x4)[NS] = Lp;                   // (dead since the proposal copy)
+                double q1 = 0.0, q2 = 0.0;
+                if (complete) {
+                    ld_row(en_t, 0, th); ld_row(en_p, 0, pm); ld_row(ep_t, 0, w); ld_row(ep_p, 0, x4);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const double dd_ = w[k] - th[k];
+                        q1 = dfma(dd_, pm[k], q1);
+                        q2 = dfma(dd_, x4[k], q2);
+                    }
+                }
+                q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
+                q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
+                s_ok = complete && (q1 >= 0.0) && (q2 >= 0.0);
+            }
+            const bool more = at_fin && s_ok && (jd + 1 < max_depth);
+            if (at_fin) jd = jd + 1;                                     // :284
+            const bool ended = at_fin && !more;
+            bool roll = false;
+            if (__ballot(ended) != 0ull) {
+                end_draw(ended, jd);
+                roll = ended && draw < n_total && mom_ready && !row_pend;
+                if (ended && !roll) state = NS_NEED_DRAW;                // the phase: its row, its next momentum, or the end of its run
+                roll_state(roll);
+            }
+            begin_doubling(more || roll);
+        }
+    }
+}
+
+}  // namespace mi

@@ -170,7 +170,7 @@ def test_logistic_chain_driven_non_finite(algo, d, N):
     _same(g_draws, g, o_draws, o)
 
 
-@pytest.mark.parametrize("hint", ["reg", "dyn"])
+@pytest.mark.parametrize("hint", ["reg", "dyn", "memo"])
 @pytest.mark.parametrize("adapt", [0, 6])
 def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
     """nuts_gauss_reg_kernel / nuts_gauss_dyn_kernel (the latter retires a flagged chain at once and hands its lane the next one): flagged chains are replayed by the general variant (identity tables), which forms the reference's dense
@@ -183,7 +183,7 @@ def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
     init[33, 100] = np.nan
     st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=adapt, max_tree_depth=6, step_size=0.1)
     g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec,
-                               kernel_hint=mcmc_amd.KERNEL_NUTS_DYN if hint == "dyn" else mcmc_amd.KERNEL_NUTS_REG)
+                               kernel_hint={"dyn": mcmc_amd.KERNEL_NUTS_DYN, "memo": mcmc_amd.KERNEL_NUTS_MEMO, "reg": mcmc_amd.KERNEL_NUTS_REG}[hint])
     assert mcmc_amd.last_kernel().startswith("nuts_gauss_%s_kernel<" % hint)
     s = orc.make_settings(seed=6, n_burnin=6, n_keep=5, n_adapt=adapt, max_depth=6, step=0.1, W=4)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)

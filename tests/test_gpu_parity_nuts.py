@@ -52,7 +52,9 @@ CASES = [
 # the tiles split over two waves (nuts_split.hpp: KERNEL_NUTS_SPLIT forces it, with 1, 2 or 4 tiles per workgroup by the number of chains);
 # the tick-local asynchronous kernel (what the bounded / preconditioned variants run) must give the same bits.  (The lock-step
 # first-generation kernel, 2.4 KB of scratch per lane, is no longer in the shipped library: `make prof` keeps it for A/B runs.)
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN]
+# ... and nuts_memo.hpp (KERNEL_NUTS_MEMO: every doubling on a memoised trajectory -- the default beyond 64 chains per CU) with fewer leapfrogs executed
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN,
+           mcmc_amd.KERNEL_NUTS_MEMO]
 
 
 @pytest.mark.parametrize("hint", KERNELS)
@@ -76,6 +78,18 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     assert np.array_equal(g["eps"], o["eps"])                # same dual-averaging trajectory
     assert np.array_equal(g_draws, o_draws)
     assert np.linalg.norm(g_draws - o_draws) <= 1e-9 * np.linalg.norm(o_draws)
+    if hint == mcmc_amd.KERNEL_NUTS_MEMO and max_depth >= 1:
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel")
+        # the leapfrogs it really made: what the memoised oracle makes (one per distinct point of a doubling + the step-size search)
+        n_exec = []
+        for c in range(C):
+            t = orc.TargetSpec(k_orc, d, prec=prec, W=4)
+            s = orc.make_settings(seed=77, n_burnin=burn, n_keep=keep, step=eps0, n_adapt=adapt, max_depth=max_depth, W=4, chain_id=500 + c)
+            n_exec.append(orc.run_chain(orc.ALGO_NUTS_MEMO, t, init[c], s)[1]["n_exec"])
+        assert np.array_equal(g["n_exec"], np.array(n_exec, dtype=np.uint64))
+        assert (g["n_exec"] <= g["n_leap"]).all()
+    else:
+        assert np.array_equal(g["n_exec"], g["n_leap"])     # every other kernel executes what it counts
 
 
 def test_nuts_sharding_independence_and_statistics():

@@ -51,7 +51,7 @@ def test_nuts_resumes_after_its_adaptation_window():
     assert e.value.code == mcmc_amd.MI_ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "dyn_d32", "dyn_diag_mass_d100", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
+@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "dyn_d32", "dyn_diag_mass_d100", "memo_d32", "memo_diag_mass_d100", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
 @pytest.mark.parametrize("cut", [3, 9, 10, 14])
 def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     """checkpoint of (theta, eps, h, Philox counter).  n_adapt_draws = 10 of 12 burn-in + 6 kept draws; the run is cut after
@@ -59,10 +59,10 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     after it (14) -- and continued with step_size + nuts_adapt_state: bit-identical to the uncut run on every nuts kernel."""
     burn, keep, n_adapt, C = 12, 6, 10, 21
     kw, tkw = dict(max_tree_depth=5), {}
-    hint = mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_AUTO     # (nuts_dyn.hpp: chains handed to the lanes dynamically)
-    if route.startswith("reg") or route.startswith("general") or route.startswith("split") or route.startswith("dyn"):
-        d = 100 if route.endswith("d100") else 32 if (route.startswith("reg") or route.startswith("dyn")) else 20     # (split_d100, few chains: nuts_gauss_split_kernel)
-        if route.startswith("dyn"): C = 150
+    hint = mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_NUTS_MEMO if route.startswith("memo") else mcmc_amd.KERNEL_AUTO     # (nuts_dyn.hpp / nuts_memo.hpp: chains handed to the lanes dynamically)
+    if route.startswith("reg") or route.startswith("general") or route.startswith("split") or route.startswith("dyn") or route.startswith("memo"):
+        d = 100 if route.endswith("d100") else 32 if (route.startswith("reg") or route.startswith("dyn") or route.startswith("memo")) else 20     # (split_d100, few chains: nuts_gauss_split_kernel)
+        if route.startswith("dyn") or route.startswith("memo"): C = 150
         kind = mcmc_amd.TARGET_GAUSS_DENSE; tkw = dict(prec=synth.dense_gaussian_precision(d, seed=2))
         if "diag_mass" in route: kw["precond_mat"] = np.diag(np.linspace(0.5, 2.0, d))
         if "dense_precond" in route:                          # (the general tick-local kernel; bounds are left out on purpose: a checkpoint holds

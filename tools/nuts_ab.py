@@ -13,20 +13,27 @@ theta0 = torch.from_numpy(np.ascontiguousarray(synth.initial_states(C, d, seed=3
 theta = torch.empty_like(theta0)
 draws = torch.empty((keep, d, C), dtype=torch.float64, device=dev)
 n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
+n_exec = torch.zeros(C, dtype=torch.int64, device=dev)
 st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn)
 ref = None
 for rep in range(2):
-    for name, hint in (("dyn", mcmc_amd.KERNEL_NUTS_DYN), ("reg", mcmc_amd.KERNEL_NUTS_REG)) if os.environ.get("MI_AB", "dyn") == "dyn" else (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)):
+    AB = {"dyn": (("dyn", mcmc_amd.KERNEL_NUTS_DYN), ("reg", mcmc_amd.KERNEL_NUTS_REG)),
+          "memo": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("dyn", mcmc_amd.KERNEL_NUTS_DYN)),
+          "memo_only": (("memo", mcmc_amd.KERNEL_NUTS_MEMO),),
+          "memo_split": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)),
+          "split": (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG))}[os.environ.get("MI_AB", "dyn")]
+    for name, hint in AB:
         t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
-        ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, mem=mcmc_amd.MEM_DEVICE)
+        ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, n_leapfrogs_executed=n_exec, mem=mcmc_amd.MEM_DEVICE)
         theta.copy_(theta0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); mcmc_amd.run("nuts", t, st, ch, stream=torch.cuda.current_stream().cuda_stream); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         leaps = float(n_leap.double().sum().item())
+        execd = float(n_exec.double().sum().item())
         chk = float(draws[-1].double().sum().item())
         if ref is None:
             ref = draws.clone()
         same = bool(torch.equal(ref, draws))
-        print(json.dumps({"kernel": name, "chains": C, "ms": ms, "leapfrogs": leaps, "units_per_s": leaps * d / (ms * 1e-3),
+        print(json.dumps({"kernel": name, "chains": C, "ms": ms, "leapfrogs": leaps, "executed": execd, "lib_kernel": mcmc_amd.last_kernel(), "units_per_s": leaps * d / (ms * 1e-3),
                           "TFLOPs": leaps * d * 264 / (ms * 1e-3) / 1e12, "same_bits_as_first": same, "checksum": chk}))
