@@ -57,7 +57,7 @@ WORKLOADS = {
     4: dict(algo="nuts", d=128, chains=65536, n_burnin_draws=100, n_keep_draws=100, n_adapt_draws=100, max_tree_depth=10, seed=2024,
             name="BASELINE configs[3]: mcmc::nuts, d=128 dense-precision Gaussian, max_tree_depth=10, dual averaging, fp64",
             metric="leapfrog-steps/sec (chains*dims*executed steps/s), NUTS d=128 Gaussian, 65536 chains",
-            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_dyn_kernel<8, false>", bound="mfma"),
+            unit="chain*dim*leapfrog-steps/s", kernel="nuts_gauss_memo_kernel<8, false>", bound="mfma"),
     5: dict(algo="hmc", d=1024, chains=131072, n_leap_steps=32, step_size=0.005, n_burnin_draws=20, n_keep_draws=8, seed=8,
             name="BASELINE configs[4], one GPU's shard: mcmc::hmc, d=1024 diagonal Gaussian (cond 1e4), 131072 of 2^20 chains, fp64",
             metric="leapfrog-steps/sec (chains*dims*steps/s), HMC d=1024 ill-conditioned Gaussian, 131072 chains per GPU",
@@ -204,7 +204,7 @@ def measured_traffic(cfg_id, kernel, chains_arg):
             if not disp:
                 return None, f"{counter}: kernel {base} not in the counter output"
             per[counter] = tot / len(disp) * 1024.0
-        factor = 2.0 if base.startswith("nuts_gauss_") else 1.0
+        factor = 2.0 if base.startswith("nuts_gauss_") else 1.0       # (every nuts_gauss_* kernel reads its records 16 bytes per lane)
         return per["FETCH_SIZE"] * factor + per["WRITE_SIZE"], {"read_bytes": per["FETCH_SIZE"] * factor, "write_bytes": per["WRITE_SIZE"],
                                                                    "fetch_factor": factor, "source": "rocprofv3 --pmc, this run"}
     except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
@@ -341,6 +341,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
     draws = torch.empty((n_keep, d, max(C, 1)), dtype=torch.float64, device=dev)
     n_accept = torch.zeros(max(C, 1), dtype=torch.int64, device=dev)
     n_leap = torch.zeros(max(C, 1), dtype=torch.int64, device=dev)
+    n_exec = torch.zeros(max(C, 1), dtype=torch.int64, device=dev)
     eps_out = torch.zeros(max(C, 1), dtype=torch.float64, device=dev)
 
     kind = {"hmc": mcmc_amd.TARGET_GAUSS_DENSE if d <= 128 else mcmc_amd.TARGET_GAUSS_DIAG,
@@ -352,7 +353,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
             skw[k] = cfg[k]
     settings = mcmc_amd.default_settings(**skw)
     chains = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=draws, n_accept=n_accept, n_leapfrogs=n_leap,
-                                  step_size=eps_out, mem=mcmc_amd.MEM_DEVICE)
+                                  n_leapfrogs_executed=n_exec, step_size=eps_out, mem=mcmc_amd.MEM_DEVICE)
     stream = torch.cuda.current_stream().cuda_stream
 
     def one_step():
@@ -380,13 +381,17 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_name = mcmc_amd.last_kernel() if C > 0 else cfg["kernel"]   # what the engine actually launched (mi_mcmc_last_kernel)
 
-    # units of this rank per step: executed leapfrog steps x dims (hmc, nuts) or draws x dims (mala)
+    # units of this rank per step: EXECUTED leapfrog steps x dims (hmc, nuts) or draws x dims (mala).  nuts on the memoised kernel
+    # (nuts_memo.hpp) computes every distinct state of a doubling once: it executes fewer leapfrogs than mcmc::nuts does for the same draws --
+    # `value` counts only what the device really computed (mi_chains.n_leapfrogs_executed); the reference's own count is reported next to it
+    units_ref_rank = None
     if algo == "mala":
         units_rank = float(C) * d * n_tot
     else:
-        units_rank = float(n_leap[:C].double().sum().item()) * d if C else 0.0
+        units_rank = float(n_exec[:C].double().sum().item()) * d if C else 0.0
+        units_ref_rank = float(n_leap[:C].double().sum().item()) * d if C else 0.0
         if algo == "hmc" and C:
-            assert int(n_leap[0].item()) == n_tot * cfg["n_leap_steps"]
+            assert int(n_leap[0].item()) == n_tot * cfg["n_leap_steps"] == int(n_exec[0].item())
     units_all = units_rank
     if dist is not None:
         t = torch.tensor([elapsed, units_rank], dtype=torch.float64, device=dev if not share else "cpu")
@@ -509,6 +514,14 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
                 out["config"][k] = cfg[k]
         if algo != "mala" and C:
             out["config"]["leapfrogs_per_chain_mean"] = units_rank / d / C
+        if algo == "nuts" and C and world == 1:
+            out["executed"] = {"leapfrogs_executed_per_chain_mean": units_rank / d / C,
+                               "leapfrogs_reference_per_chain_mean": units_ref_rank / d / C,
+                               "executed_over_reference": units_rank / units_ref_rank if units_ref_rank else None,
+                               "reference_equivalent_value": units_ref_rank * steps / elapsed,
+                               "note": "`value` and the roofline count EXECUTED leapfrogs only.  The memoised kernel (nuts_memo.hpp) produces the draws "
+                                       "mcmc::nuts produces -- bit for bit -- while computing each distinct state of a doubling once; "
+                                       "reference_equivalent_value = the leapfrogs mcmc::nuts executes for these draws x dims / the same seconds"}
         if algo == "nuts":
             out["config"]["adapted_step_size_mean"] = float(eps_out[:C].mean().item())
         if reducer_ms is not None:
@@ -546,7 +559,7 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
                 out["collate_overlapped"] = {"chunks": 4, "sampling_plus_gather_ms": collate_overlapped_total_ms,
                                              "blocking_equivalent_ms": elapsed / steps * 1e3 + collate_ms,
                                              "note": "one run in 4 chunks through mi_chains.draw0, each chunk's slab all-gathered asynchronously under the next chunk's sampling"}
-    del draws, theta, theta0, n_accept, n_leap, eps_out, kw_dev, target, chains
+    del draws, theta, theta0, n_accept, n_leap, n_exec, eps_out, kw_dev, target, chains
     mcmc_amd.release_workspace()
     torch.cuda.empty_cache()
     return out, cfg

@@ -2032,14 +2032,13 @@ bool nuts_dynamic(const mi_target* target, uint64_t C)
     return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
 }
 
-// nuts_memo.hpp instead of nuts_reg.hpp / nuts_dyn.hpp: on request, and by default where nuts_dyn.hpp was (more chains than chain slots)
-bool nuts_memoised(const mi_target* target, uint64_t C)
+// nuts_memo.hpp instead of nuts_reg.hpp / nuts_dyn.hpp / nuts_split.hpp: on request, and by default for d > 16 at every chain count (measured, same
+// box, alternating, configs[3]'s settings: d = 128: 563 ms against 699 at 65 536 chains, 154 / 212 at 16 384, 139 / 156 at 8 192, 126 / 135 at 2 048;
+// d = 64: 209 / 208 and 48 / 54 at 4 096; d = 32: 71 / 72 and 26.5 / 27.6; d = 16: 37 / 33 -- there a leapfrog is too cheap for the walk to pay)
+bool nuts_memoised(const mi_target* target, uint64_t)
 {
     if (target->kernel_hint == MI_KERNEL_NUTS_MEMO) return true;
-    if (target->kernel_hint != MI_KERNEL_AUTO) return false;
-    int dev = 0, n_cu = 256;
-    (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
+    return target->kernel_hint == MI_KERNEL_AUTO && target->d > 16;
 }
 
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)

@@ -37,6 +37,11 @@
 
 #pragma once
 
+#ifndef MI_MEMO_WALK_CAP
+#define MI_MEMO_WALK_CAP 8       // at most that many leaves per chain and tick (a chain with leaves left computes no point in the next tick: the other
+                                 // 15 chains of its wave do not wait for a 32-leaf walk).  0 = no limit.  Measured on configs[3]: 0: 578 ms, 6: 569, 8: 563, 12: 568
+#endif
+
 #include "nuts_reg.hpp"
 #include "nuts_dyn.hpp"
 
@@ -122,13 +127,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
     bool exhausted = false;
     const double* afrag = lds_P + lane;
 
-    char* lrow = lds_rows + cw * 8;                      // redefined (opaquely) at the top of every tick
-    auto rd_ = [&](int r) -> double& { return *reinterpret_cast<double*>(lrow + r * 512); };
-    auto ru_ = [&](int r) -> unsigned long long& { return *reinterpret_cast<unsigned long long*>(lrow + r * 512); };
-    auto la_ = [&](int l) -> double& { return rd_(R_LA + l); };
-    auto lp_ = [&](int l) -> unsigned long long& { return ru_(R_LP + l); };
-    auto okb_ = [&](int r) -> unsigned long long& { return ru_(R_OKB + r); };
-    auto nf_ = [&]() -> double& { return rd_(R_NF); };
+    // (a 32-bit LDS byte address, re-materialised as address-space-3 pointers: through a generic char* the accesses become FLAT instructions,
+    //  which queue in order with the wave's global memory operations)
+    typedef double __attribute__((address_space(3)))* lds_dptr;
+    typedef unsigned long long __attribute__((address_space(3)))* lds_uptr;
+    typedef char __attribute__((address_space(3)))* lds_bptr;
+    uint32_t lrow = (uint32_t)(uintptr_t)(lds_bptr)lds_rows + (uint32_t)cw * 8u;    // redefined (opaquely) at the top of every tick
+#define MI_RD(r) (*(lds_dptr)(uintptr_t)(lrow + (uint32_t)(r) * 512u))
+#define MI_RU(r) (*(lds_uptr)(uintptr_t)(lrow + (uint32_t)(r) * 512u))
+#define la_(l) MI_RD(R_LA + (l))
+#define lp_(l) MI_RU(R_LP + (l))
+#define okb_(r) MI_RU(R_OKB + (r))
+#define nf_() MI_RD(R_NF)
     // workspace: [wave] blocks of memo_wave_bytes, wave-uniform base + one 32-bit byte offset per access (nuts_async.hpp)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * memo_wave_bytes(NS);
@@ -184,22 +194,22 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
 
     auto note_nonfinite = [&](bool bad) __attribute__((always_inline)) { if (__ballot(bad) != 0ull) { if (bad) nf_() = 1.0; } };
     nf_() = 0.0;
-    auto eps_ = [&]() -> double& { return rd_(R_CH); };
-    auto prev_U_ = [&]() -> double& { return rd_(R_CH + 1); };
-    auto H0_ = [&]() -> double& { return rd_(R_CH + 2); };
-    auto log_u_ = [&]() -> double& { return rd_(R_CH + 3); };
-    auto esg_ = [&]() -> double& { return rd_(R_CH + 4); };
-    auto next_K_ = [&]() -> double& { return rd_(R_CH + 5); };
-    auto next_lu_ = [&]() -> double& { return rd_(R_CH + 6); };
-    auto n_leap_ = [&]() -> unsigned long long& { return ru_(R_CT); };
-    auto n_exec_ = [&]() -> unsigned long long& { return ru_(R_CT + 1); };
-    auto n_acc_ = [&]() -> unsigned long long& { return ru_(R_CT + 2); };
+#define eps_() MI_RD(R_CH)
+#define prev_U_() MI_RD(R_CH + 1)
+#define H0_() MI_RD(R_CH + 2)
+#define log_u_() MI_RD(R_CH + 3)
+#define esg_() MI_RD(R_CH + 4)
+#define next_K_() MI_RD(R_CH + 5)
+#define next_lu_() MI_RD(R_CH + 6)
+#define n_leap_() MI_RU(R_CT)
+#define n_exec_() MI_RU(R_CT + 1)
+#define n_acc_() MI_RU(R_CT + 2)
     n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull;
     eps_() = 1.0; prev_U_() = 0.0;
     const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
-    auto h_val_ = [&]() -> double& { return rd_(R_DA); };
-    auto eps_bar_ = [&]() -> double& { return rd_(R_DA + 1); };
-    auto mu_val_ = [&]() -> double& { return rd_(R_DA + 2); };
+#define h_val_() MI_RD(R_DA)
+#define eps_bar_() MI_RD(R_DA + 1)
+#define mu_val_() MI_RD(R_DA + 2)
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
     const uint32_t n_adapt = prm.n_adapt;
     const uint32_t max_depth = prm.max_depth;
@@ -213,11 +223,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
     uint32_t npts = 0;           // points of its trajectory that exist (the registers hold point npts; 0: the origin has to be loaded)
     uint32_t uslot = 0;
     int vdir = 1;
-    auto prev_K_ = [&]() -> double& { return rd_(R_SC); };
-    auto n_val_ = [&]() -> double& { return rd_(R_SC + 1); };
-    auto alpha_ = [&]() -> double& { return rd_(R_SC + 2); };
-    auto n_alpha_ = [&]() -> double& { return rd_(R_SC + 3); };
+#define prev_K_() MI_RD(R_SC)
+#define n_val_() MI_RD(R_SC + 1)
+#define alpha_() MI_RD(R_SC + 2)
+#define n_alpha_() MI_RD(R_SC + 3)
     int good_round = 0;
+    bool org_ok = false;         // the registers already hold the origin of the doubling about to start
+    double ca_keep = 0.0;        // MI_MEMO_WALK_CAP: alpha of the leaf a walk that was cut short goes on with
     // Draw boundaries without waiting: as nuts_reg.hpp / nuts_dyn.hpp (momenta generated ahead, prev_draw alternating between two vectors,
     // the edges are the draw's initial vectors until a doubling has written that side)
     int mv = V_MNTM, mvn = MV_MNTM2;
@@ -229,9 +241,27 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
     auto pvec = [](int b) -> int { return b ? MV_PREVB : V_PREV; };
     auto wvec = [](int b) -> int { return b ? MV_WPREVB : V_WPREV; };
 
+    // The uniforms of a draw are consumed in slot order (direction :233, one per merge nuts.ipp:213, top-level accept :261).  One Philox
+    // evaluation per WAVE serves four consecutive slots of every chain: lane class j4 of a chain computes slot ub0 + j4, consumers shuffle.
+    // (The walk of the leaves is a chain of merges -- with one evaluation per merge level it was most of a tick.)
+    uint32_t ub0 = 0x80000000u;  // first slot in the buffer; valid for slots [ub0, ub0 + 4) of the chain's CURRENT draw
+    double ubuf = 0.0;
+    auto uni = [&](bool need) __attribute__((always_inline)) -> double {      // the uniform of slot `uslot` (not advanced here)
+#ifdef MI_MEMO_NO_UBUF
+        (void)need;
+        return rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);
+#else
+        const bool stale = need && (uslot - ub0) >= 4u;
+        if (__ballot(stale) != 0ull) {                   // every chain of the wave refills from its own current slot
+            ub0 = uslot;
+            ubuf = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot + (uint32_t)j4);
+        }
+        return __shfl(ubuf, (lane & 15) + 16 * (int)((uslot - ub0) & 3u));
+#endif
+    };
     // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
-        const double zdir = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);
+        const double zdir = uni(p);
         if (p) {
             uslot++;
             vdir = (zdir <= 0.5) ? -1 : 1;
@@ -289,7 +319,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
             mom_ready = false;
             row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
             pb0 = pb; pos_init = true; neg_init = true;
-            uslot = 1;
+            uslot = 1; ub0 = 0x80000000u;                 // (a new draw: the buffered uniforms are the old draw's)
             jd = 0; n_val_() = 1.0; alpha_() = 0.0; n_alpha_() = 0.0; good_round = 0;
             state = NS_TREE;
         }
@@ -331,9 +361,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
         }
     };
 
+#ifdef MI_NUTS_REG_PROF   // phase clocks of block 0, wave 0 (tools/nuts_prof.py; a variant build, never the shipped library)
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_ticks = 0, n_active = 0, n_walk_it = 0, n_pair_it = 0;
+    unsigned long long tmark = clock64();
+#define MI_MPROF(k) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
+#else
+#define MI_MPROF(k)
+#endif
 #pragma unroll 1
     for (;;) {
         asm volatile("" : "+v"(lane_b), "+v"(lane_sc), "+v"(lrow));
+        MI_MPROF(7)
         retire(state != NS_DONE && nf_() != 0.0);   // a flagged chain is replayed from its initial state: nothing of it is kept
         // ------------------------------------------------------------ free slots take the next chains
         {
@@ -348,7 +387,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                     if (nid < C) {                       // a new chain in this slot: everything per-chain starts over
                         cl = nid;
                         state = NS_INIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
-                        mv = V_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false;
+                        mv = V_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false;
                     } else exhausted = true;
                 }
             }
@@ -391,7 +430,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
             else { end_draw(p, 0u); if (p) state = NS_NEED_DRAW; }              // while-loop of :227 never entered
         }
         const bool run = state == NS_TREE, init = state == NS_INIT, srch = state == NS_SEARCH;
+        MI_MPROF(0)
         if (__ballot(run || init || srch) == 0ull) continue;
+#ifdef MI_NUTS_REG_PROF
+        n_ticks++; n_active += (unsigned long long)__builtin_popcountll(__ballot(run)) / 4ull;
+#endif
 
         // INIT: first_draw and z_init (nuts.cpp:160-168) are staged in the workspace -- theta in V_PREV, the momentum in mv -- and enter the
         // registers through the origin load below; the tick is P theta with e = 0 (nuts_dyn.hpp: why rolled loops, and why here)
@@ -415,25 +458,33 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
             }
         }
         // ------------------------------------------------------------ B. the next point of every running chain's trajectory
+        // (a chain whose walk was cut short by MI_MEMO_WALK_CAP still has leaves on its existing points: it computes no point this tick -- e = 0
+        //  leaves its registers as they are, bit for bit -- and goes on walking)
+        const bool newpt = run && memo_npt(li) > npts;
         {   // the origin of a doubling (prev_draw, mntm_vec, P prev_draw: src/nuts.cpp:241-256); every later point continues from the registers
-            const bool need = (run && npts == 0u) || init;
+            const bool need = (newpt && npts == 0u && !org_ok) || init;      // (!org_ok: not requested at the end of the last tick already)
             if (__ballot(need) != 0ull) {
                 const int vt = pvec(pb), vp = mv, vw = init ? pvec(pb) : wvec(pb);      // INIT: first_draw (pb = 0), any finite row as P theta (e = 0)
                 if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
             }
         }
-        const uint32_t mpt = npts + 1u;                  // the point this tick computes (run lanes)
+        if (newpt) org_ok = false;
+        const uint32_t mpt = npts + 1u;                  // the point this tick computes (newpt lanes)
         // the tests this point closes: level l against point mpt - l (lds_pm), lowest level first
-        uint32_t pmask = run ? (uint32_t)lds_pm[jd * 48u + mpt] : 0u;
-        double dd[NS];           // theta of the other point of a test, then d = theta(mpt) - theta(mpt - l) (by direction)
-        double Lp[NS];           // p of the other point
+        uint32_t pmask = newpt ? (uint32_t)lds_pm[jd * 48u + mpt] : 0u;
+        // theta / p of the other point of a test; dd then holds d = theta(mpt) - theta(mpt - l) (by direction).  DEFINED on every lane before
+        // the (predicated) loads: left undefined, the values of lanes without a test count as live from the previous tick's loop -- 128 registers
+        // held through the walk, 400 bytes of scratch per lane
+        double dd[NS], Lp[NS];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) { dd[s_] = 0.0; Lp[s_] = 0.0; }
         [[maybe_unused]] const double* mic_d = DIAGM ? mcol(lds_mi) : nullptr;
         // SEARCH: the step of this leapfrog (nuts.ipp:62, 80-82).  INIT: e = 0, and the state is set after the (idle) updates
         if (srch) {
             if (!s_first) eps_() = eps_() * ((vdir == 1) ? 2.0 : 0.5);
             n_leap_() += 1ull; n_exec_() += 1ull;
         }
-        const double e_tick = run ? esg_() : (srch ? eps_() : 0.0);
+        const double e_tick = newpt ? esg_() : (srch ? eps_() : 0.0);
         // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154), grad = -w
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
@@ -444,7 +495,6 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // the first test's rows are requested here and used AFTER the mat-vec (8.6 us of matrix-pipe time in which the wave has nothing else
         // in flight): their latency costs nothing
-#ifndef MI_MEMO_NO_PREFETCH
         {
             const bool t1 = pmask != 0u;
             if (__ballot(t1) != 0ull) {
@@ -453,12 +503,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 if (t1) { ld_row(vq, 0, dd); ld_row(vq + 1, 0, Lp); }
             }
         }
-#endif
+        MI_MPROF(1)
         matvec_mfma<NT>(afrag, th, w);
 #pragma unroll
         for (int s = 0; s < NS; ++s) pm[s] = pm[s] - (e_tick * w[s]) / 2.0;
         double pU = 0.5 * dot4<NS>(th, w);               // nuts.ipp:134-138 / :50,65
         const double pK = kinetic_of(pm);                // :140 / :51,66
+        MI_MPROF(2)
         // ---- INIT: the chain's first state is on record; SEARCH: one step of nuts_find_initial_step_size
         if (__ballot(init) != 0ull) {
             if (init) {
@@ -479,15 +530,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
             if (srch) { vdir = 2 * (dHs > log_half ? 1 : 0) - 1; s_first = false; }      // :75,88
             start_sampling(srch && !(dHs > neg_log2));   // :78,90: the loop ends
         }
+        MI_MPROF(5)
         if (__ballot(run) == 0ull) continue;
-        // ---- the point's record and scalars (nuts.ipp:146-157)
+        // ---- the point's scalars (nuts.ipp:146-157): n', s' as bits in LDS; alpha and U go to the scalar table with the record, at the END of the tick
         const double dH = -(pU + pK) + H0_();
-        note_nonfinite(run && !is_finite(dH));           // pU (replaced by +inf above), pK or the draw's H0 non-finite
-        double ca = det_exp((dH < 0.0) ? dH : 0.0);      // :157
-        if (run) {
-            const int vr = MV_PT0 + 3 * ((int)mpt - 1);
-            st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
-            *scp(mpt) = double2{ca, pU};
+        note_nonfinite(newpt && !is_finite(dH));         // pU (replaced by +inf above), pK or the draw's H0 non-finite
+        const double ca_pt = det_exp((dH < 0.0) ? dH : 0.0);      // :157
+        if (newpt) {
             const unsigned long long bit = 1ull << mpt;
             const double lu_ = log_u_();
             const bool cn_b = lu_ <= -pU - pK;           // :146
@@ -496,26 +545,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
             okb_(11) = (okb_(11) & ~bit) | (cs_b ? bit : 0ull);
             n_exec_() += 1ull;
         }
-        // the tree's far edge (= the first leaf of its second half, point 1 + jd; the leaf itself at depth 0) is what a successful doubling leaves
-        // in draw_pos / draw_neg (src/nuts.cpp:241-256); a doubling that fails before that leaf ends the draw, so writing it early is harmless
-        const bool st_edge = run && mpt == 1u + jd;
-        if (st_edge) {
-            const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
-            st_row(et, 0, th); st_row(ep, 0, pm);
-            if (vdir > 0) pos_init = false; else neg_init = false;
-        }
-        // ---- the tests whose second point this is: [ d . p(n1) >= 0 ] * [ d . p(mpt) >= 0 ], d = theta(mpt) - theta(n1) by direction (:224-229)
+        // ---- the tests whose second point this is: [ d . p(n1) >= 0 ] * [ d . p(mpt) >= 0 ], d = theta(mpt) - theta(n1) by direction (:224-229).
+        //      LOADS ONLY between here and the end of the walk: memory operations of a wave complete in order, and a load behind the 3 KB of a
+        //      record store waits for all of it (measured: 10 k cycles per test that way)
         {
-#ifndef MI_MEMO_NO_PREFETCH
             bool first = true;
-#else
-            bool first = false;
-#endif
-#ifdef MI_MEMO_X_NOPAIR
-            pmask = 0;
-#endif
 #pragma unroll 1
             while (__ballot(pmask != 0u) != 0ull) {
+#ifdef MI_NUTS_REG_PROF
+                n_pair_it++;
+#endif
                 const bool t = pmask != 0u;
                 const int l = t ? __builtin_ctz(pmask) : 1;
                 const int n1 = (int)mpt - l;
@@ -525,7 +564,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 }
                 first = false;
                 // (two passes: d . p(n1) with theta, d, p(n1) as operands, then d . p(mpt) with d, p -- four vectors as VALU operands of one loop
-                //  are the whole architectural register file, and the allocator spills instead of streaming them from the AGPRs)
+                //  are the whole architectural register file)
                 double q1 = 0.0, q2 = 0.0;
 #pragma unroll
                 for (int s_ = 0; s_ < NS; ++s_) {
@@ -545,28 +584,46 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 }
             }
         }
-        if (run) npts = mpt;
+        // the tree's far edge (= the first leaf of its second half, point 1 + jd; the leaf itself at depth 0) is what a successful doubling leaves
+        // in draw_pos / draw_neg (src/nuts.cpp:241-256); a doubling that fails before that leaf ends the draw, so writing it early is harmless.
+        // (The one store before the walk: the test that ends this doubling may read it in this very tick.)
+        const bool st_edge = newpt && mpt == 1u + jd;
+        if (st_edge) {
+            const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+            st_row(et, 0, th); st_row(ep, 0, pm);
+            if (vdir > 0) pos_init = false; else neg_init = false;
+        }
+        if (newpt) npts = mpt;
+        MI_MPROF(3)
         // ------------------------------------------------------------ C. walk the leaves this point unblocks (nuts.ipp:146-158, 212-239)
-        bool wl = run;                                   // (the leaf the chain was waiting at sits on the new point)
+        bool wl = run;                                   // (the leaf a chain waits at sits on its newest point)
         bool at_fin = false, complete = false;
         uint32_t cn_i = 0, cna_i = 0, cref = 0;
+        double ca = newpt ? ca_pt : ca_keep;             // alpha of the leaf the walk starts at (a chain cut short last tick kept its own)
         double ca_nx = 0.0;
-#ifdef MI_MEMO_X_NOWALK
-        wl = false; at_fin = run; complete = run;
+        uint32_t n_walked = 0;                           // leaves walked this tick (= the reference's leapfrogs, nuts.ipp:132)
+#if MI_MEMO_WALK_CAP > 0
+        int walk_budget = MI_MEMO_WALK_CAP;
 #endif
 #pragma unroll 1
         while (__ballot(wl) != 0ull) {
+#ifdef MI_NUTS_REG_PROF
+            n_walk_it++;
+#endif
+#if MI_MEMO_WALK_CAP > 0
+            if (walk_budget-- == 0) break;
+#endif
             const uint32_t n = memo_npt(li);
-            // the next leaf's alpha, in case the chain gets that far (it is on record if its point exists)
+            // the next leaf's alpha, in case the chain gets that far: on record if its point exists -- this tick's own point is still in registers
             {
                 const uint32_t nn = memo_npt(li + 1u);
-                if (wl && nn <= npts) ca_nx = scp(nn)->x;
+                if (wl && nn <= npts) ca_nx = (newpt && nn == mpt) ? ca_pt : scp(nn)->x;
             }
             const unsigned long long nbit = 1ull << n;
             if (wl) {
                 cn_i = (okb_(0) & nbit) ? 1u : 0u;
                 cna_i = 1u; cref = n;
-                n_leap_() += 1ull;
+                n_walked++;
             }
             bool failed = wl && !(okb_(11) & nbit);
             bool walking = wl;
@@ -579,11 +636,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 if (__ballot(walking) == 0ull) break;
                 const bool mrg = walking && bit;
                 if (__ballot(mrg) == 0ull) continue;
-#ifdef MI_MEMO_X_NORNG
-                const double z = 0.25;
-#else
-                const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :213
-#endif
+                const double z = uni(mrg);                                   // :213
                 if (mrg) {
                     uslot++;
                     const uint32_t pk = (uint32_t)lp_((int)l);
@@ -613,14 +666,14 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 }
             }
         }
+        if (run && !at_fin) ca_keep = ca;                // (only read back by a chain whose walk was cut short: wl still set)
+        if (run) n_leap_() += (unsigned long long)n_walked;
+        MI_MPROF(4)
         // ------------------------------------------------------------ D. end of a doubling (src/nuts.cpp:260-289)
-#ifdef MI_MEMO_X_NOFIN
-        at_fin = false; if (run) { li = 0; npts = 0; }
-#endif
         if (__ballot(at_fin) != 0ull) {
             bool take = false;
             if (__ballot(complete) != 0ull) {
-                const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :261
+                const double z = uni(complete);                             // :261
                 if (complete) {
                     uslot++;
                     take = z < (double)cn_i / n_val_();                         // :263
@@ -628,11 +681,18 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 }
             }
             if (__ballot(take) != 0ull) {
-                if (take) {      // the proposal is a point of the trajectory: its record goes to prev_draw (both rows in ONE round trip)
-                    const int vq = MV_PT0 + 3 * ((int)cref - 1);
-                    ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
-                    prev_U_() = scp(cref)->y;
-                    st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
+                // the proposal is a point of the trajectory: (theta, P theta) of its record go to prev_draw in ONE round trip -- or straight from the
+                // registers when it is this tick's own point (whose record is not written yet, and never will be: the doubling is over)
+                const bool from_regs = take && newpt && cref == mpt;
+                if (from_regs) { st_row(pvec(1 - pb0), 0, th); st_row(wvec(1 - pb0), 0, w); prev_U_() = pU; }
+                const bool from_rec = take && !from_regs;
+                if (__ballot(from_rec) != 0ull) {
+                    if (from_rec) {
+                        const int vq = MV_PT0 + 3 * ((int)cref - 1);
+                        ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
+                        prev_U_() = scp(cref)->y;
+                        st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
+                    }
                 }
             }
             if (at_fin) { alpha_() = ca; n_alpha_() = (double)cna_i; n_val_() = n_val_() + (double)cn_i; }   // :246,255 ; :283
@@ -642,16 +702,17 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 const int ep_t = pos_init ? pvec(pb0) : V_TPOS_T, ep_p = pos_init ? mv : V_TPOS_P;
                 // [ (pos - neg) . p_neg >= 0 ] * [ (pos - neg) . p_pos >= 0 ] (:286-289).  The trajectory of a chain whose doubling is complete is
                 // dead (the next doubling starts from prev_draw), so its registers take the four operands in ONE round trip
-                double (&x4)[NS] = Lp;                   // (dead since the proposal copy)
                 double q1 = 0.0, q2 = 0.0;
                 if (complete) {
-                    ld_row(en_t, 0, th); ld_row(en_p, 0, pm); ld_row(ep_t, 0, w); ld_row(ep_p, 0, x4);
+                    ld_row(en_t, 0, th); ld_row(en_p, 0, pm); ld_row(ep_t, 0, w); ld_row(ep_p, 0, Lp);
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        const double dd_ = w[k] - th[k];
-                        q1 = dfma(dd_, pm[k], q1);
-                        q2 = dfma(dd_, x4[k], q2);
+                        w[k] = w[k] - th[k];
+                        q1 = dfma(w[k], pm[k], q1);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) q2 = dfma(w[k], Lp[k], q2);
                 }
                 q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
                 q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
@@ -668,8 +729,56 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
                 roll_state(roll);
             }
             begin_doubling(more || roll);
+            // the origin of the doubling that starts in the next tick (prev_draw, mntm_vec, P prev_draw), requested NOW: its round trip runs under
+            // the record stores below, the loop head and the phase instead of in front of the next kick
+            if (more || roll) {
+                ld_row(pvec(pb), 0, th); ld_row(mv, 0, pm); ld_row(wvec(pb), 0, w);
+                org_ok = true;
+            }
         }
+        // ------------------------------------------------------------ E. the record of this tick's point, for the chains whose doubling goes on
+        {
+            const bool rec = newpt && !at_fin;
+            if (__ballot(rec) != 0ull) {
+                if (rec) {
+                    const int vr = MV_PT0 + 3 * ((int)mpt - 1);
+                    st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
+                    *scp(mpt) = double2{ca_pt, pU};
+                }
+            }
+        }
+        MI_MPROF(6)
     }
+#ifdef MI_NUTS_REG_PROF
+    if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
+        prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_walk_it; prm.prof[11] = n_pair_it;
+    }
+#endif
+#undef MI_MPROF
+#undef la_
+#undef lp_
+#undef okb_
+#undef nf_
+#undef eps_
+#undef prev_U_
+#undef H0_
+#undef log_u_
+#undef esg_
+#undef next_K_
+#undef next_lu_
+#undef n_leap_
+#undef n_exec_
+#undef n_acc_
+#undef h_val_
+#undef eps_bar_
+#undef mu_val_
+#undef prev_K_
+#undef n_val_
+#undef alpha_
+#undef n_alpha_
+#undef MI_RD
+#undef MI_RU
 }
 
 }  // namespace mi

@@ -193,10 +193,11 @@ def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
     assert np.array_equal(g["eps"], o["eps"], equal_nan=True)
 
 
+@pytest.mark.parametrize("kern", ["reg", "memo"])
 @pytest.mark.parametrize("d,adapt", [(128, 6), (128, 0), (48, 4)])
-def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt):
-    """nuts_gauss_reg_kernel<., true>: the register-carried kernel with two mass tables; chains that leave the finite regime are replayed
-    by the general variant with the same tables (ref: src/nuts.cpp:139-154,168,202,204 with the diagonal matrices)."""
+def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt, kern):
+    """nuts_gauss_reg_kernel<., true> / nuts_gauss_memo_kernel<., true> (AUTO beyond d = 16): the plain-case kernels with two mass tables; chains that
+    leave the finite regime are replayed by the general variant with the same tables (ref: src/nuts.cpp:139-154,168,202,204 with the diagonal matrices)."""
     C = 40
     prec = synth.dense_gaussian_precision(d)
     M = np.diag(np.random.default_rng(8).uniform(0.4, 2.5, d))
@@ -206,8 +207,9 @@ def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt):
     init[33, d - 5] = np.nan
     st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=adapt, max_tree_depth=6, step_size=0.1,
                                    precond_mat=M)
-    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
-    assert mcmc_amd.last_kernel().startswith("nuts_gauss_reg_kernel<") and mcmc_amd.last_kernel().endswith("true>"), mcmc_amd.last_kernel()
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec,
+                               kernel_hint=mcmc_amd.KERNEL_NUTS_REG if kern == "reg" else mcmc_amd.KERNEL_AUTO)
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_%s_kernel<" % kern) and mcmc_amd.last_kernel().endswith("true>"), mcmc_amd.last_kernel()
     s = orc.make_settings(seed=6, n_burnin=6, n_keep=5, n_adapt=adapt, max_depth=6, step=0.1, W=4, precond=M)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
     assert len(_poisoned_chains(o_draws)) >= 2 and o["n_accept"].sum() > 0

@@ -69,8 +69,10 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
                                    n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
     g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
-    if hint in (mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_SPLIT):      # (these cases are few chains: AUTO picks the split shapes too)
+    if hint == mcmc_amd.KERNEL_NUTS_SPLIT:
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_split_kernel" if d > 64 else "nuts_gauss_reg_kernel")
+    if hint == mcmc_amd.KERNEL_AUTO:           # the memoised trajectory beyond d = 16 (max_tree_depth = 0 has no tree to memoise)
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel" if (d > 16 and max_depth >= 1) else "nuts_gauss_reg_kernel")
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
     assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs
@@ -78,7 +80,7 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     assert np.array_equal(g["eps"], o["eps"])                # same dual-averaging trajectory
     assert np.array_equal(g_draws, o_draws)
     assert np.linalg.norm(g_draws - o_draws) <= 1e-9 * np.linalg.norm(o_draws)
-    if hint == mcmc_amd.KERNEL_NUTS_MEMO and max_depth >= 1:
+    if (hint == mcmc_amd.KERNEL_NUTS_MEMO or (hint == mcmc_amd.KERNEL_AUTO and d > 16)) and max_depth >= 1:
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel")
         # the leapfrogs it really made: what the memoised oracle makes (one per distinct point of a doubling + the step-size search)
         n_exec = []

@@ -59,7 +59,9 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     after it (14) -- and continued with step_size + nuts_adapt_state: bit-identical to the uncut run on every nuts kernel."""
     burn, keep, n_adapt, C = 12, 6, 10, 21
     kw, tkw = dict(max_tree_depth=5), {}
-    hint = mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_NUTS_MEMO if route.startswith("memo") else mcmc_amd.KERNEL_AUTO     # (nuts_dyn.hpp / nuts_memo.hpp: chains handed to the lanes dynamically)
+    hint = (mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_NUTS_MEMO if route.startswith("memo")      # (nuts_dyn.hpp / nuts_memo.hpp: chains
+            else mcmc_amd.KERNEL_NUTS_REG if route.startswith("reg") else mcmc_amd.KERNEL_NUTS_SPLIT if route.startswith("split")  # handed to the lanes dynamically)
+            else mcmc_amd.KERNEL_AUTO)
     if route.startswith("reg") or route.startswith("general") or route.startswith("split") or route.startswith("dyn") or route.startswith("memo"):
         d = 100 if route.endswith("d100") else 32 if (route.startswith("reg") or route.startswith("dyn") or route.startswith("memo")) else 20     # (split_d100, few chains: nuts_gauss_split_kernel)
         if route.startswith("dyn") or route.startswith("memo"): C = 150

@@ -7,7 +7,7 @@ from mcmc_amd import synth
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 burn = keep = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device("cuda", 0)
-d = 128
+d = int(os.environ.get("MI_D", "128"))
 prec = torch.from_numpy(synth.dense_gaussian_precision(d)).to(dev)
 theta0 = torch.from_numpy(np.ascontiguousarray(synth.initial_states(C, d, seed=3).T)).to(dev)
 theta = torch.empty_like(theta0)
