@@ -175,6 +175,26 @@ def profiled_traffic(cfg_id, key, kernel_name):
     return None, why
 
 
+def profiled_pipe_budget(cfg_id, key, kernel_name):
+    """The combined-pipe budget of the dominant kernel -- (4 x VALU wave-instructions + MFMA busy cycles) / SIMD cycles -- from the newest
+    committed counter pass of this workload AND this kernel (tools/summarize_prof.py: derived.pipe_budget); None if there is none."""
+    import glob
+    import re
+    cands = []
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_c{cfg_id}_pmc.json")):
+        m = re.match(r"r(\d+)_c\d+_pmc\.json$", os.path.basename(p))
+        if m:
+            cands.append((int(m.group(1)), p))
+    for _, p in sorted(cands, reverse=True):
+        try:
+            j = json.load(open(p))
+            if j.get("workload_key") == list(key) and kernel_name.split("(")[0].strip() in j["derived"]["kernel"] and "pipe_budget" in j["derived"]:
+                return dict(j["derived"]["pipe_budget"], source=os.path.relpath(p, ROOT))
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def measured_traffic(cfg_id, kernel, chains_arg):
     """HBM bytes per launch of `kernel`, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE: they do not fit one pass,
     /opt/skills/guides/MI355X_MICROARCH.md) of one step of this workload in a child process.  Units and gfx950 corrections as the
@@ -506,6 +526,9 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
         if bfrac > 1.0:
             out["roofline"]["bytes_model_term"]["why_null"] = ("n/a: the state is register-resident, nothing streams per unit -- the model's "
                                                                "32 B / unit are not moved (see hbm_TBps for what the launch moved)")
+        pb = profiled_pipe_budget(cfg_id, key, kernel_name) if want_traffic else None
+        if pb is not None:           # what the kernel's instruction mix allows (fp64 VALU and MFMA share a pipe): frac / pipe_frac is the slack
+            out["roofline"]["pipe_budget"] = pb
         if traffic is not None:      # HBM side of the same launch
             out["roofline"]["hbm_TBps"] = traffic / (k_ms * 1e-3) / 1e12
             out["roofline"]["hbm_frac_of_8TBps"] = out["roofline"]["hbm_TBps"] / 8.0
@@ -586,6 +609,7 @@ def main():
                          "config that way, the others from the committed profiles/ of the same kernel; none: committed profiles only")
     ap.add_argument("--proxy-scaling", action="store_true", help="with --config N: also time chains/2, /4, /8 on this GPU (scaling_proxy)")
     ap.add_argument("--no-proxy", action="store_true", help="skip scaling_proxy in the default run")
+    ap.add_argument("--converged", action="store_true", help="with --config 3 | 5: also run that config's converged ESS leg (the default run always does)")
     ap.add_argument("--collate", action="store_true",
                     help="also time the RCCL all-gather of the kept draws (not part of `value`)")
     args = ap.parse_args()
@@ -680,7 +704,7 @@ def main():
         out["other_configs"] = others
         if not args.no_extra:
             out["extra"] = {"nuts_on_configs2_target": extra_nuts_on_logistic(ctx)}
-    elif ctx.rank == 0 and ctx.world == 1 and args.chains is None and head_id in CONVERGED and not args.no_ess:
+    elif ctx.rank == 0 and ctx.world == 1 and args.chains is None and head_id in CONVERGED and args.converged:
         out["converged"] = converged_leg(head_id, ctx)
     if (single and not args.no_proxy) or (args.proxy_scaling and ctx.world == 1):
         # ONE-GPU PROXY of the strong-scaling curve: the share of one GPU at N = 1, 2, 4, 8 -- total / N chains -- timed here

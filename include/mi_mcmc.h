@@ -83,10 +83,9 @@ typedef enum mi_kernel_hint {
                                             * default one with register-carried leaf state */
     MI_KERNEL_NUTS_REG = 10,               /* nuts, same case: register-carried leaf state, one wave per 16-chain tile and per SIMD (the default
                                             * for d <= 64) */
-    MI_KERNEL_NUTS_SPLIT = 11,             /* nuts, same case, 64 < d <= 128 only (ignored for d <= 64): every 16-chain tile split over two waves.  Tiles per
-                                            * workgroup by the chain count: 1 up to 16 chains per CU, 2 up to 32 per CU, 4 beyond.  AUTO takes it for FEW
-                                            * chains only (<= 32 per CU: the shorter tick per tile wins there); with more chains AUTO runs
-                                            * MI_KERNEL_NUTS_REG / _DYN / _MEMO, and this hint forces the (slower) four-tile shape */
+    MI_KERNEL_NUTS_SPLIT = 11,             /* RETIRED (round 5): the kernel that split every 16-chain tile over two waves (64 < d <= 128, few chains) is gone --
+                                            * the memoised kernel is faster at every chain count.  The value stays valid and is ignored (as any hint a request
+                                            * cannot honour): the default kernel runs */
     MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
                                             * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */

@@ -37,9 +37,6 @@ int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool di
 // persistent grid (prm.ws must hold nuts_memo_workspace_bytes)
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);
-// the plain case at d in (64, 128], every tile split over two waves, two tiles per SIMD (nuts_split.hpp); pfrag: 128 KB of device
-// scratch for the precision in fragment order (packed here, on the stream)
-int launch_nuts_gauss_split(const NutsParams& prm, int nt, int tiles_per_wg, double* pfrag, hipStream_t st);         // nuts_split_launch.hip
 int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
 int launch_nuts_gauss_dense_m(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_dense_launch.hip
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);

@@ -397,12 +397,6 @@ __global__ void fill_u64_kernel(uint64_t* out, uint64_t n, uint64_t v)
 
 // identity tables of the general kernel variants (no bounds, unit mass) in stream-ordered workspace memory: what a replay of the
 // plain case through a general variant reads (no host buffer has to outlive the call)
-// behind a nuts_gauss_split_kernel launch: its status word says a pair-wise LDS wait timed out (nuts_split.hpp) -> abort the queue
-__global__ void trap_if_sync_lost_kernel(const uint32_t* status)
-{
-    if (*status == 0xdeadu) __builtin_trap();
-}
-
 // nuts_gauss_memo_kernel: a flagged chain was replayed by the general variant, which executes every leapfrog it counts
 __global__ void copy_flagged_counts_kernel(const uint32_t* flag, const uint64_t* n_leap, uint64_t* n_exec, uint64_t C)
 {
@@ -2023,10 +2017,11 @@ bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
 
 // nuts_dyn.hpp instead of nuts_reg.hpp: on request, and by default when there are more chains than the chip has chain slots (then a slot
 // gets a second chain when its first one is done; with fewer chains the two kernels do the same thing)
+int nuts_hint(const mi_target* target);
 bool nuts_dynamic(const mi_target* target, uint64_t C)
 {
-    if (target->kernel_hint == MI_KERNEL_NUTS_DYN) return true;
-    if (target->kernel_hint != MI_KERNEL_AUTO) return false;
+    if (nuts_hint(target) == MI_KERNEL_NUTS_DYN) return true;
+    if (nuts_hint(target) != MI_KERNEL_AUTO) return false;
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
@@ -2035,10 +2030,12 @@ bool nuts_dynamic(const mi_target* target, uint64_t C)
 // nuts_memo.hpp instead of nuts_reg.hpp / nuts_dyn.hpp / nuts_split.hpp: on request, and by default for d > 16 at every chain count (measured, same
 // box, alternating, configs[3]'s settings: d = 128: 563 ms against 699 at 65 536 chains, 154 / 212 at 16 384, 139 / 156 at 8 192, 126 / 135 at 2 048;
 // d = 64: 209 / 208 and 48 / 54 at 4 096; d = 32: 71 / 72 and 26.5 / 27.6; d = 16: 37 / 33 -- there a leapfrog is too cheap for the walk to pay)
+// (MI_KERNEL_NUTS_SPLIT names a retired kernel: valid, ignored -- the automatic choice runs)
+int nuts_hint(const mi_target* target) { return target->kernel_hint == MI_KERNEL_NUTS_SPLIT ? (int)MI_KERNEL_AUTO : target->kernel_hint; }
 bool nuts_memoised(const mi_target* target, uint64_t)
 {
-    if (target->kernel_hint == MI_KERNEL_NUTS_MEMO) return true;
-    return target->kernel_hint == MI_KERNEL_AUTO && target->d > 16;
+    if (nuts_hint(target) == MI_KERNEL_NUTS_MEMO) return true;
+    return nuts_hint(target) == MI_KERNEL_AUTO && target->d > 16;
 }
 
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
@@ -2092,15 +2089,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     //  bytes in the asynchronous kernel's layout afterwards)
     if (memo) ws_own = std::max(ws_own, mi::nuts_memo_workspace_bytes(chains->n_chains, nt, gt.active));
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
-    const size_t flag_bytes = ((chains->n_chains + 2) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any", [C + 1] status (nuts_split.hpp)
-    const size_t pfrag_bytes = (size_t)128 * 128 * sizeof(double);           // the precision in fragment order (nuts_gauss_split_kernel)
-    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + pfrag_bytes + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
+    const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any"
+    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
     uint32_t* const nf_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ws_own_r);
     double* const id_tab = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ws_own_r + flag_bytes);
-    double* const pfrag = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ((ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 255) & ~(size_t)255));
-    prm.next_chain = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(pfrag) + pfrag_bytes);
+    prm.next_chain = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ((ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 255) & ~(size_t)255));
     prm.draws = sc.dev.draws;
     prm.n_accept = sc.dev.n_accept;
     prm.n_leap = sc.dev.n_leapfrogs;
@@ -2109,7 +2104,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
 #ifdef MI_PROFILING
     DevBuf prof_buf;
     if (getenv("MI_NUTS_PROF")) { HIP_TRY(prof_buf.alloc(96 * 8)); HIP_TRY(hipMemset(prof_buf.p, 0, 96 * 8)); prm.prof = prof_buf.as<unsigned long long>();
-        if (const char* e = getenv("MI_SPLIT_TILES")) { const unsigned long long nt_ = (unsigned long long)atoi(e); HIP_TRY(hipMemcpy(prm.prof + 95, &nt_, 8, hipMemcpyHostToDevice)); } }
+}
 #endif
     prm.seed = settings->rng_seed_value;
     prm.n_burnin = (uint32_t)settings->n_burnin_draws;
@@ -2176,28 +2171,18 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     else {
         // the plain case: nuts_gauss_reg_kernel; chains that reach the non-finite regime are flagged there and
         // replayed by the general variant, which reproduces the reference's dense products, with identity tables
-        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
-        // One wave per tile with register-carried leaf state (nuts_reg.hpp) is the throughput shape.  nuts_split.hpp spreads a tile over
-        // two waves: with FEW chains (no more tiles than the chip has SIMD pairs) that is the shorter tick per tile -- a run then lasts
-        // as long as its slowest tile, not as long as the chip needs for all of them -- and on request at any size.
-        int n_cu = 256;
-        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+        // Beyond d = 16 every doubling runs on a memoised trajectory (nuts_memo.hpp).  Otherwise one wave per tile with register-carried leaf
+        // state (nuts_reg.hpp), and with more chains than chain slots the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp:
+        // a wave does not end with its slowest chain).  (nuts_split.hpp -- every tile over two waves, rounds 4: the few-chains shape at
+        // 64 < d <= 128 -- is retired: the memoised kernel is faster at every chain count; its hint is ignored.)
         const uint64_t C_ = chains->n_chains;
-        const bool few = C_ <= (uint64_t)32 * (uint64_t)n_cu;
-        const bool split = !memo && nt > 4 && (target->kernel_hint == MI_KERNEL_NUTS_SPLIT || (target->kernel_hint == MI_KERNEL_AUTO && few));
-        const int tpw = !few ? 4 : (C_ > (uint64_t)16 * (uint64_t)n_cu ? 2 : 1);
-        // Many chains: the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp) -- a wave does not end with its slowest chain
         if (memo) { prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr; }
         rc = memo ? launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st))
-           : split ? launched("nuts", mi::launch_nuts_gauss_split(prm, nt, tpw, pfrag, st))
            : nuts_dynamic(target, C_) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st))
                                       : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
         if (rc) return rc;
-        if (split) {     // a lost pair-wise synchronisation must not return MI_OK with garbage: abort the queue, the next sync reports it
-            hipLaunchKernelGGL(trap_if_sync_lost_kernel, dim3(1), dim3(1), 0, st, nf_flag + chains->n_chains + 1);
-            HIP_TRY(hipGetLastError());
-        }
         const std::string reg_name = mi::host::last_kernel();
         int* bt_i = reinterpret_cast<int*>(id_tab);
         hipLaunchKernelGGL(fill_identity_tables_kernel, dim3(1), dim3(128), 0, st, bt_i, id_tab + 128, id_tab + 256, id_tab + 384, id_tab + 512, 128u);
@@ -2219,20 +2204,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
 #ifdef MI_PROFILING
-    if (prm.prof && mi::host::last_kernel().rfind("nuts_gauss_split", 0) == 0) {
-        unsigned long long h[96];
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));
-        const char* names[12] = {"phase A", "top loads", "kick loop", "gradient (exch+matvec)", "kick2 + relay", "stores", "unwind", "take/pending/copy", "fin block", "loop head", "(await total)", "(ticks)"};
-        for (int wv = 0; wv < 8; ++wv) {
-            unsigned long long tot = 0;
-            for (int k = 0; k < 10; ++k) tot += h[wv * 12 + k];
-            fprintf(stderr, "[split prof] wave %d: %llu ticks, %.1f k cycles per tick;", wv, h[wv * 12 + 11], (double)tot / (double)(h[wv * 12 + 11] ? h[wv * 12 + 11] : 1) / 1e3);
-            for (int k = 0; k < 11; ++k) fprintf(stderr, " %s %.1f%%", names[k], 100.0 * (double)h[wv * 12 + k] / (double)(tot ? tot : 1));
-            fprintf(stderr, "\n");
-        }
-    }
-    else if (prm.prof) {
+    if (prm.prof) {
         unsigned long long h[12];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));

@@ -68,7 +68,6 @@ struct NutsParams {
     double* adapt_state;    // [3][C] or nullptr (mi_chains.nuts_adapt_state): the dual-averaging state (h, epsilon_bar, mu; nuts.cpp:174-176,
                             // 294-302) -- written at the end of every call, read at the start of a continuation that begins inside the
                             // adaptation window (0 < draw0 <= n_adapt); n_adapt is the RUN's window, draw indices are global (draw0 + i)
-    const double* Pfrag;    // nuts_gauss_split_kernel: P in MFMA A-fragment order [t][s][lane] (pack_precision_fragments_kernel), device
     uint64_t* n_exec;       // [C] or nullptr (mi_chains.n_leapfrogs_executed): leapfrogs really computed -- nuts_gauss_memo_kernel writes it; every
                             // other kernel executes what it counts in n_leap, and the host copies that
 };

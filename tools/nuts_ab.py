@@ -1,5 +1,6 @@
-"""A/B timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events): split tiles, two per SIMD (nuts_split.hpp)
-vs one wave per tile with register-carried leaf state (nuts_reg.hpp), same box, alternating."""
+"""A/B timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events), same box, alternating: MI_AB=memo (memoised trajectory,
+nuts_memo.hpp, vs dynamic hand-out, nuts_dyn.hpp) | dyn (vs register-carried leaf state, nuts_reg.hpp) | memo_only | memo_reg; MI_D = dimension;
+argv: chains [draws per half]."""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch, mcmc_amd
@@ -20,8 +21,7 @@ for rep in range(2):
     AB = {"dyn": (("dyn", mcmc_amd.KERNEL_NUTS_DYN), ("reg", mcmc_amd.KERNEL_NUTS_REG)),
           "memo": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("dyn", mcmc_amd.KERNEL_NUTS_DYN)),
           "memo_only": (("memo", mcmc_amd.KERNEL_NUTS_MEMO),),
-          "memo_split": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG)),
-          "split": (("split", mcmc_amd.KERNEL_NUTS_SPLIT), ("reg", mcmc_amd.KERNEL_NUTS_REG))}[os.environ.get("MI_AB", "dyn")]
+          "memo_reg": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("reg", mcmc_amd.KERNEL_NUTS_REG))}[os.environ.get("MI_AB", "memo")]
     for name, hint in AB:
         t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
         ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, n_leapfrogs_executed=n_exec, mem=mcmc_amd.MEM_DEVICE)

@@ -19,7 +19,7 @@ bash tools/profile_bench.sh $TAG 2 --chains 8192 > gpurun_out/prof_${TAG}_c2s.lo
 mv gpurun_out/prof_${TAG}_c2 gpurun_out/prof_${TAG}_c2_8192
 cp gpurun_out/prof_${TAG}_c2_8192/pmc.json gpurun_out/profiles_$TAG/${TAG}_c2_8192chains_pmc.json
 cp gpurun_out/prof_${TAG}_c2_8192/kernel_stats.csv gpurun_out/profiles_$TAG/${TAG}_c2_8192chains_kernel_stats.csv
-# NUTS (configs[3]) at one GPU's share of 65 536 chains over 8 GPUs: the split-tile shapes (nuts_split.hpp)
+# NUTS (configs[3]) at one GPU's share of 65 536 chains over 8 GPUs
 mv gpurun_out/prof_${TAG}_c4 gpurun_out/prof_${TAG}_c4_full
 bash tools/profile_bench.sh $TAG 4 --chains 8192 > gpurun_out/prof_${TAG}_c4s.log 2>&1
 cp gpurun_out/prof_${TAG}_c4/pmc.json gpurun_out/profiles_$TAG/${TAG}_c4_8192chains_pmc.json

@@ -63,6 +63,15 @@ if out["kernel_stats"]:
     wa = per_launch("sq", "SQ_WAIT_INST_ANY")
     if wa is not None:
         d["wait_inst_any_per_launch"] = wa
+    # the combined-pipe budget: fp64 VALU and fp64 MFMA issue from the same pipe of a SIMD, so what a
+    # kernel's instruction mix allows is  [ 4 cycles x VALU wave-instructions + MFMA busy cycles ] / [ SIMDs x kernel cycles ]  (a wave64 VALU
+    # instruction occupies its SIMD for 4 cycles at least; every VALU instruction is priced at that minimum, so this is a LOWER bound of the
+    # pipe's occupancy)
+    if v is not None and busy is not None and gui:
+        simd_cycles = gui / 8.0 * 1024.0
+        d["pipe_budget"] = {"valu_issue_frac": 4.0 * v / simd_cycles, "mfma_busy_frac": busy / simd_cycles,
+                            "pipe_frac": (4.0 * v + busy) / simd_cycles,
+                            "what": "(4 x SQ_INSTS_VALU + SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per launch"}
     d["note"] = ("FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x2 only for 16-B-per-lane read streams (guide's gfx950 correction), else as "
                  "reported; counters summed over launches / launch count; one rocprofv3 run per counter group, --kernel-trace only")
     out["derived"] = d
