@@ -48,19 +48,24 @@ size_t memo_lds()
     // fragments | 52 per-chain rows of 64 eight-byte columns (nuts_memo.hpp: R_END) | the test table | the mass tables
     return ((size_t)NT * 4 * NT * 64 + 52 * 64) * sizeof(double) + 10 * 48 * sizeof(uint16_t) + (DIAGM ? 32 * NT : 0) * sizeof(double);
 }
+// waves per workgroup and workgroups of the persistent grid: 4 waves (64 chain slots) per workgroup when there are enough chains to fill the chip
+// that way; with fewer chains 2, then 1 -- every CU gets a workgroup, and a wave its SIMD, the LDS port and the L1 to itself
+struct MemoShape { uint32_t waves; uint64_t grid; };
 template <int NT, bool DIAGM>
-uint64_t memo_grid(uint64_t C)
+MemoShape memo_shape(uint64_t C)
 {
     const size_t lds = memo_lds<NT, DIAGM>();
     auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int dev = 0, n_cu = 256, per_cu = 1;
+    int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (n_cu <= 0) n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const uint64_t need = (C + 63) / 64, cap = (uint64_t)n_cu * (uint64_t)per_cu;
-    return cap_grid(need < cap ? need : cap);
+    const uint32_t waves = (C <= (uint64_t)16 * n_cu) ? 1u : (C <= (uint64_t)32 * n_cu) ? 2u : 4u;
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), (int)(64 * waves), lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint64_t need = (C + 16 * waves - 1) / (16 * waves), cap = (uint64_t)n_cu * (uint64_t)per_cu;
+    return MemoShape{waves, cap_grid(need < cap ? need : cap)};
 }
 template <int NT, bool DIAGM>
 int memo(NutsParams prm, hipStream_t st)
@@ -68,9 +73,9 @@ int memo(NutsParams prm, hipStream_t st)
     const size_t lds = memo_lds<NT, DIAGM>();
     auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
     note_kernel("nuts_gauss_memo_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
-    const uint64_t grid = memo_grid<NT, DIAGM>(prm.C);       // (sets the kernel's LDS attribute)
+    const MemoShape sh = memo_shape<NT, DIAGM>(prm.C);       // (sets the kernel's LDS attribute)
     MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, prm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)sh.grid), dim3(64 * sh.waves), lds, st, prm);
     return (int)hipGetLastError();
 }
 
@@ -118,10 +123,10 @@ int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool d
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)
 {
-    const uint64_t grid = diag_m ? MI_DISPATCH_NT(nt, (memo_grid<1, true>(C)), (memo_grid<2, true>(C)), (memo_grid<4, true>(C)), (memo_grid<8, true>(C)))
-                                 : MI_DISPATCH_NT(nt, (memo_grid<1, false>(C)), (memo_grid<2, false>(C)), (memo_grid<4, false>(C)), (memo_grid<8, false>(C)));
+    const MemoShape sh = diag_m ? MI_DISPATCH_NT(nt, (memo_shape<1, true>(C)), (memo_shape<2, true>(C)), (memo_shape<4, true>(C)), (memo_shape<8, true>(C)))
+                                : MI_DISPATCH_NT(nt, (memo_shape<1, false>(C)), (memo_shape<2, false>(C)), (memo_shape<4, false>(C)), (memo_shape<8, false>(C)));
     const int ns = 4 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8);
-    return (size_t)grid * 4 * memo_wave_bytes(ns);
+    return (size_t)sh.grid * sh.waves * memo_wave_bytes(ns);
 }
 
 int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)

@@ -122,8 +122,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
     const int cw = wave * 16 + (lane & 15);
     const uint32_t d = prm.d;
     const uint64_t C = prm.C;
-    const uint64_t n_slots = (uint64_t)gridDim.x * 64;   // chains [0, n_slots) start in their own slot; the counter hands out the rest
-    uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);     // this slot's chain (the four lanes of a chain agree); >= C: none
+    // 4, 2 or 1 waves per workgroup (the launcher: with few chains every CU gets a workgroup, and a wave the SIMD, the LDS port and the L1 to itself)
+    const uint32_t nw = blockDim.x >> 6;
+    const uint64_t n_slots = (uint64_t)gridDim.x * (16u * nw);   // chains [0, n_slots) start in their own slot; the counter hands out the rest
+    uint64_t cl = ((uint64_t)blockIdx.x * nw + wave) * 16 + (lane & 15);     // this slot's chain (the four lanes of a chain agree); >= C: none
     bool exhausted = false;
     const double* afrag = lds_P + lane;
 
@@ -141,7 +143,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
 #define nf_() MI_RD(R_NF)
     // workspace: [wave] blocks of memo_wave_bytes, wave-uniform base + one 32-bit byte offset per access (nuts_async.hpp)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * 4 + wave_u) * memo_wave_bytes(NS);
+    char* const ws_wave_u = reinterpret_cast<char*>(__builtin_assume_aligned(prm.ws, 256)) + ((size_t)blockIdx.x * nw + wave_u) * memo_wave_bytes(NS);
     // inside a vector: [chain][pair of slices][j4] in 16-byte granules (nuts_async.hpp: why)
     uint32_t lane_b = (uint32_t)(lane & 15) * (uint32_t)(NS * 32) + (uint32_t)j4 * 16u;     // redefined (opaquely) at the top of every tick
     uint32_t lane_sc = (uint32_t)MEMO_NVEC * (uint32_t)(NS * 512) + (uint32_t)lane * 16u;   // this lane's column of the scalar table
