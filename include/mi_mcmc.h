@@ -78,23 +78,21 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_HMC_SPLIT2 = 6,              /* two waves share a tile (row halves of the mat-vec, theta exchanged through LDS) */
     MI_KERNEL_HMC_SPLIT4 = 7,              /* four waves share a tile, one wave per SIMD (16 chains per workgroup) */
     MI_KERNEL_HMC_SPLIT4_TWO_WAVES = 8,    /* four waves share a tile, two waves per SIMD (32 chains per workgroup) */
-    MI_KERNEL_NUTS_TICK_LOCAL = 9,         /* nuts, unbounded Gaussian targets, identity precond_mat: the asynchronous kernel that reloads
-                                            * every leaf's start record (what the bounded / preconditioned variants run) instead of the
-                                            * default one with register-carried leaf state */
-    MI_KERNEL_NUTS_REG = 10,               /* nuts, same case: register-carried leaf state, one wave per 16-chain tile and per SIMD (the default
-                                            * for d <= 64) */
+    MI_KERNEL_NUTS_TICK_LOCAL = 9,         /* nuts, unbounded Gaussian targets, identity precond_mat: the asynchronous kernel that executes every leaf and
+                                            * reloads its start record (what the bounded / preconditioned variants run) instead of the default
+                                            * one on the memoised trajectory -- an independent implementation of the same bits, for A/B runs */
+    MI_KERNEL_NUTS_REG = 10,               /* RETIRED (round 5), valid and ignored: the register-carried kernel of rounds 2-4 (one wave per 16-chain tile) */
     MI_KERNEL_NUTS_SPLIT = 11,             /* RETIRED (round 5): the kernel that split every 16-chain tile over two waves (64 < d <= 128, few chains) is gone --
                                             * the memoised kernel is faster at every chain count.  The value stays valid and is ignored (as any hint a request
                                             * cannot honour): the default kernel runs */
     MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
                                             * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
-    MI_KERNEL_NUTS_DYN = 13,               /* nuts, same case as MI_KERNEL_NUTS_REG: its tick with the chains handed to the lanes dynamically (a persistent
-                                            * grid; a lane whose chain is done takes the next one) */
+    MI_KERNEL_NUTS_DYN = 13,               /* RETIRED (round 5), valid and ignored: round 4's register-carried tick with dynamic chain hand-out */
     MI_KERNEL_NUTS_MEMO = 14               /* nuts, same case: every doubling on a MEMOISED trajectory (nuts_memo.hpp) -- the 2^j leaves of a doubling visit only
                                             * 1 + j (j + 1) / 2 distinct states (the reference's crossed edge plumbing, nuts.ipp:195,207), each is computed
                                             * once, the tree is walked on scalars; same bits, ~40 % fewer leapfrogs executed on BASELINE configs[3]; chains
-                                            * handed out dynamically -- the default beyond 64 chains per CU */
+                                            * handed out dynamically -- THE kernel of the plain case (AUTO) */
 } mi_kernel_hint;
 
 typedef struct mi_target {

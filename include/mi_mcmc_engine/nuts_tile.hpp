@@ -1,5 +1,5 @@
 // nuts_tile.hpp -- mcmc::nuts for USER-DEFINED targets on the tiled (MFMA-layout) engine: the asynchronous per-chain tree state machine
-// of the built-in Gaussian kernel (mcmc_amd/csrc/nuts_reg.hpp: register-carried leaf state, eager U-turn tests, momenta generated
+// of rounds 2-4's built-in Gaussian kernel (nuts_reg.hpp, since replaced by nuts_memo.hpp; DESIGN.md 4.4: register-carried leaf state, eager U-turn tests, momenta generated
 // ahead; the iterative leaf-indexed tree is derived in mcmc_amd/csrc/nuts_dense.hpp) with the gradient behind the tile functor of
 // tile_samplers.hpp instead of the dense mat-vec.
 //
@@ -20,7 +20,7 @@
 namespace mi {
 
 namespace tile_nuts {
-// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp / nuts_reg.hpp)
+// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp)
 enum : int {
     V_PREV = 0, V_WPREV = 1, V_MNTM = 2, V_TPOS_T = 3, V_TPOS_P = 4, V_TNEG_T = 5, V_TNEG_P = 6,
     V_LEAF0 = 7,             // slot k: theta 7+3k, p 8+3k, grad 9+3k, k = 0..10 (even leaves only: slot 0's p / grad rows are free, see below)

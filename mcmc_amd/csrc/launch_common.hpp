@@ -6,8 +6,8 @@ namespace mi {
 // the kernel a call's time goes to, by the name rocprofv3 prints: read back through mi_mcmc_last_kernel() (thread-local;
 // defined in mi_mcmc.hip).  Set by the launchers, so bench.py labels a measurement with what actually ran.
 void note_kernel(const char* fmt, ...);
-// TEST HOOK (mi_mcmc_test_set_grid_cap, mi_mcmc_probes.h): an upper limit on the workgroups of the PERSISTENT grids (nuts_dyn.hpp,
-// nuts_memo.hpp, nuts_lds.hpp), 0 = none.  With a small cap a handful of chains exercises what only > 16 384 chains reach otherwise: the
+// TEST HOOK (mi_mcmc_test_set_grid_cap, mi_mcmc_probes.h): an upper limit on the workgroups of the PERSISTENT grids (nuts_memo.hpp,
+// nuts_lds.hpp), 0 = none.  With a small cap a handful of chains exercises what only > 16 384 chains reach otherwise: the
 // global counter, a slot taking its second and third chain, retire-on-leave.  Process-wide; results never depend on it.
 uint64_t test_grid_cap();
 inline uint64_t cap_grid(uint64_t n_wg) { const uint64_t c = test_grid_cap(); return (c != 0 && c < n_wg) ? c : n_wg; }

@@ -29,11 +29,8 @@ int launch_hmc_gauss_diagm(const HmcParams& prm, int nt, hipStream_t st);       
 int launch_mala_gauss(const MalaParams& prm, int nt, int variant, hipStream_t st);
 // lockstep: the first-generation kernel (plain variant only); batch: momentum-refresh batch of the asynchronous kernel
 int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m, bool lockstep, uint32_t batch, hipStream_t st);
-// the plain case (unbounded, identity precond_mat) with register-carried leaf state (nuts_reg.hpp): the default NUTS kernel
-int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m = false);
-// nuts_dyn.hpp: the same tick, chains handed to the lanes dynamically (prm.next_chain: one uint32_t of device memory)
-int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
-// nuts_memo.hpp: every doubling on a memoised trajectory, chains handed out dynamically; its workspace is sized by the chain SLOTS of the
+// the plain case (unbounded; identity or diagonal precond_mat): nuts_memo.hpp -- every doubling on a memoised trajectory, chains handed out dynamically
+// (prm.next_chain: one uint32_t of device memory); its workspace is sized by the chain SLOTS of the
 // persistent grid (prm.ws must hold nuts_memo_workspace_bytes)
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);

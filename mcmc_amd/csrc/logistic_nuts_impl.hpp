@@ -53,7 +53,7 @@ int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void
 template <bool DIAGM, bool BOUNDS>
 int dispatch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)
 {
-    if (target == LOGIT_TARGET_DENSE) {                 // 128 < d <= 512 (smaller d: nuts_reg.hpp keeps P resident in LDS)
+    if (target == LOGIT_TARGET_DENSE) {                 // 128 < d <= 512 (smaller d: nuts_memo.hpp keeps P resident in LDS)
         if (prm.d <= 192) return launch_nuts<3, LOGIT_TARGET_DENSE, DIAGM, BOUNDS>(prm, X_dev, y_dev, workspace, st);
         if (prm.d <= 256) return launch_nuts<4, LOGIT_TARGET_DENSE, DIAGM, BOUNDS>(prm, X_dev, y_dev, workspace, st);
         if (prm.d <= 384) return launch_nuts<6, LOGIT_TARGET_DENSE, DIAGM, BOUNDS>(prm, X_dev, y_dev, workspace, st);

@@ -2015,28 +2015,10 @@ bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
     return lds_general_ok(target, settings) && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
 }
 
-// nuts_dyn.hpp instead of nuts_reg.hpp: on request, and by default when there are more chains than the chip has chain slots (then a slot
-// gets a second chain when its first one is done; with fewer chains the two kernels do the same thing)
-int nuts_hint(const mi_target* target);
-bool nuts_dynamic(const mi_target* target, uint64_t C)
-{
-    if (nuts_hint(target) == MI_KERNEL_NUTS_DYN) return true;
-    if (nuts_hint(target) != MI_KERNEL_AUTO) return false;
-    int dev = 0, n_cu = 256;
-    (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    return C > (uint64_t)64 * (uint64_t)(n_cu > 0 ? n_cu : 256);
-}
-
-// nuts_memo.hpp instead of nuts_reg.hpp / nuts_dyn.hpp / nuts_split.hpp: on request, and by default for d > 16 at every chain count (measured, same
-// box, alternating, configs[3]'s settings: d = 128: 563 ms against 699 at 65 536 chains, 154 / 212 at 16 384, 139 / 156 at 8 192, 126 / 135 at 2 048;
-// d = 64: 209 / 208 and 48 / 54 at 4 096; d = 32: 71 / 72 and 26.5 / 27.6; d = 16: 37 / 33 -- there a leapfrog is too cheap for the walk to pay)
-// (MI_KERNEL_NUTS_SPLIT names a retired kernel: valid, ignored -- the automatic choice runs)
-int nuts_hint(const mi_target* target) { return target->kernel_hint == MI_KERNEL_NUTS_SPLIT ? (int)MI_KERNEL_AUTO : target->kernel_hint; }
-bool nuts_memoised(const mi_target* target, uint64_t)
-{
-    if (nuts_hint(target) == MI_KERNEL_NUTS_MEMO) return true;
-    return nuts_hint(target) == MI_KERNEL_AUTO && target->d > 16;
-}
+// The plain case (unbounded; identity or a diagonal precond_mat) runs on nuts_memo.hpp.  The register-carried kernels of rounds 2-4 (nuts_reg.hpp,
+// nuts_dyn.hpp, nuts_split.hpp) are retired: the memoised kernel is faster wherever a leapfrog costs anything (d = 128: 563 ms against 699 at
+// 65 536 chains, 135 / 156 at 8 192; d = 64: 209 / 208; d = 32: 71 / 72) and within 13 % at d = 16 (37 / 33 ms) -- one tick to maintain instead of
+// four.  Their hints stay valid and are ignored.  MI_KERNEL_NUTS_TICK_LOCAL keeps the independent tick-local kernel for A/B runs.
 
 int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_chains* chains, void* stream)
 {
@@ -2080,8 +2062,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     const bool lockstep = target->kernel_hint == MI_KERNEL_NUTS_LOCKSTEP && chains->draw0 == 0 && !chains->nuts_adapt_state;   // the first-generation kernel, same bits (it exports no adaptation state)
     const bool tick_local = target->kernel_hint == MI_KERNEL_NUTS_TICK_LOCAL;  // the asynchronous kernel without register-carried state
     // the plain case and a diagonal precond_mat alone can run on the memoised trajectory (nuts_memo.hpp)
-    const bool memo_case = (!gt.active || (!gt.dense && !settings->vals_bound)) && !lockstep && !tick_local && settings->max_tree_depth >= 1;
-    const bool memo = memo_case && nuts_memoised(target, chains->n_chains);
+    const bool memo = (!gt.active || (!gt.dense && !settings->vals_bound)) && !lockstep && !tick_local;
     WsLease ws;
     const size_t d_pad = (d <= 16) ? 16 : (d <= 32) ? 32 : (d <= 64) ? 64 : 128;
     size_t ws_own = (size_t)mi::NUTS_NVEC_ASYNC * d_pad * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double);
@@ -2135,16 +2116,14 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, true, false, nuts_batch, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
-    else if (gt.active && !settings->vals_bound && !lockstep && !tick_local) {
-        // a diagonal precond_mat alone: the register-carried kernel with two mass tables (nuts_reg.hpp, DIAGM); flagged chains are replayed
+    else if (gt.active && memo) {
+        // a diagonal precond_mat alone: the plain-case kernel with two mass tables (nuts_memo.hpp, DIAGM); flagged chains are replayed
         // by the general variant with the same tables
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
-        if (memo) { prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr; }
-        rc = memo ? launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st, true))
-           : nuts_dynamic(target, chains->n_chains) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st, true))
-                                                     : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st, true));
+        prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr;
+        rc = launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st, true));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         mi::NutsParams rp = prm;
@@ -2169,19 +2148,13 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     else if (lockstep || tick_local) rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));
     else {
-        // the plain case: nuts_gauss_reg_kernel; chains that reach the non-finite regime are flagged there and
+        // the plain case: nuts_gauss_memo_kernel; chains that reach the non-finite regime are flagged there and
         // replayed by the general variant, which reproduces the reference's dense products, with identity tables
         HIP_TRY(hipMemsetAsync(nf_flag, 0, (chains->n_chains + 1) * sizeof(uint32_t), st));
         prm.nf_flag = nf_flag;
-        // Beyond d = 16 every doubling runs on a memoised trajectory (nuts_memo.hpp).  Otherwise one wave per tile with register-carried leaf
-        // state (nuts_reg.hpp), and with more chains than chain slots the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp:
-        // a wave does not end with its slowest chain).  (nuts_split.hpp -- every tile over two waves, rounds 4: the few-chains shape at
-        // 64 < d <= 128 -- is retired: the memoised kernel is faster at every chain count; its hint is ignored.)
         const uint64_t C_ = chains->n_chains;
-        if (memo) { prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr; }
-        rc = memo ? launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st))
-           : nuts_dynamic(target, C_) ? launched("nuts", mi::launch_nuts_gauss_dyn(prm, nt, st))
-                                      : launched("nuts", mi::launch_nuts_gauss_reg(prm, nt, nuts_batch, st));
+        prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr;
+        rc = launched("nuts", mi::launch_nuts_gauss_memo(prm, nt, st));
         if (rc) return rc;
         const std::string reg_name = mi::host::last_kernel();
         int* bt_i = reinterpret_cast<int*>(id_tab);

@@ -13,7 +13,7 @@ int mi_probe_uniform(uint64_t seed, uint64_t chain, uint32_t draw, uint32_t slot
 int mi_probe_fp64_peak(int use_mfma, int iters, double* tflops_out);
 int mi_probe_mfma_cycles(int waves_per_simd, int use_lds, int iters, double* cycles_per_mfma, double* tflops_out);
 /* Defined in libmi_mcmc.so itself (a test hook, not a product entry point: it is declared here, not in mi_mcmc.h): limits the PERSISTENT grids of
- * the NUTS kernels with dynamic chain hand-out (nuts_dyn.hpp, nuts_memo.hpp, nuts_lds.hpp) to max_workgroups (0 = no limit), so that a test with a
+ * the NUTS kernels with dynamic chain hand-out (nuts_memo.hpp, nuts_lds.hpp) to max_workgroups (0 = no limit), so that a test with a
  * few hundred chains runs the global counter, slot re-use and retire-on-leave.  Process-wide.  Results do not depend on it. */
 void mi_mcmc_test_set_grid_cap(uint32_t max_workgroups);
 #ifdef __cplusplus

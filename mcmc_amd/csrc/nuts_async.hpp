@@ -93,7 +93,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
     const int j4 = lane >> 4;
     const int cw = wave * 16 + (lane & 15);
     const uint64_t cl = ((uint64_t)blockIdx.x * 4 + wave) * 16 + (lane & 15);
-    // replay of the chains nuts_gauss_reg_kernel flagged (non-finite regime): the others are not `live` -- they compute along from
+    // replay of the chains nuts_gauss_memo_kernel flagged (non-finite regime): the others are not `live` -- they compute along from
     // whatever theta holds and store nothing -- and a wave without a flagged chain leaves (no barrier follows)
     const bool live = cl < prm.C && (prm.replay_flag == nullptr || prm.replay_flag[cl] != 0u);
     if (prm.replay_flag != nullptr && __ballot(live) == 0ull) return;

@@ -60,11 +60,11 @@ struct NutsParams {
     const double* m_inv;    // diagonal of INV(precond_mat)
     const double* Minv;     // DENSE_M: INV(precond_mat), d*d row-major (device)
     const double* Lchol;    // DENSE_M: CHOL_LOWER(precond_mat), d*d row-major (device)
-    uint32_t* nf_flag;      // nuts_gauss_reg_kernel: [C + 1] or nullptr.  A chain that saw a non-finite energy is flagged (nf_flag[c] = 1,
+    uint32_t* nf_flag;      // nuts_gauss_memo_kernel: [C + 1] or nullptr.  A chain that saw a non-finite energy is flagged (nf_flag[c] = 1,
                             // nf_flag[C] = 1) and its outputs are left untouched: the general variant, which reproduces the reference's
                             // dense products in the non-finite regime, replays it
     const uint32_t* replay_flag;   // nuts_gauss_async_kernel as that replay: only the chains with a non-zero entry run (and write)
-    uint32_t* next_chain;   // nuts_gauss_dyn_kernel (nuts_dyn.hpp): chains handed out beyond the first gridDim.x * 64, zeroed by the launcher
+    uint32_t* next_chain;   // nuts_gauss_memo_kernel (nuts_memo.hpp): chains handed out beyond the first gridDim.x * 64, zeroed by the launcher
     double* adapt_state;    // [3][C] or nullptr (mi_chains.nuts_adapt_state): the dual-averaging state (h, epsilon_bar, mu; nuts.cpp:174-176,
                             // 294-302) -- written at the end of every call, read at the start of a continuation that begins inside the
                             // adaptation window (0 < draw0 <= n_adapt); n_adapt is the RUN's window, draw indices are global (draw0 + i)

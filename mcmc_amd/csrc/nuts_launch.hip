@@ -1,8 +1,6 @@
-// nuts_launch.hip -- translation unit of the NUTS MFMA kernels of the plain case (nuts_reg.hpp, nuts_async.hpp, lock-step predecessor
-// nuts_dense.hpp); the bounded / preconditioned variants compile in nuts_general_launch.hip and nuts_dense_launch.hip
+// nuts_launch.hip -- translation unit of the NUTS MFMA kernels of the plain case (nuts_memo.hpp; the tick-local nuts_async.hpp, lock-step
+// predecessor nuts_dense.hpp); the bounded / preconditioned variants compile in nuts_general_launch.hip and nuts_dense_launch.hip
 #include "nuts_async_launch.hpp"
-#include "nuts_reg.hpp"
-#include "nuts_dyn.hpp"
 #include "nuts_memo.hpp"
 #include "launchers.hpp"
 #include "launch_common.hpp"
@@ -10,38 +8,7 @@
 namespace mi {
 namespace {
 
-// the plain case with register-carried leaf state (nuts_reg.hpp): the default kernel
-template <int NT, bool DIAGM>
-int reg(const NutsParams& prm, uint32_t batch, hipStream_t st)
-{
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64 + 3 * 64 + (DIAGM ? 32 * NT : 0)) * sizeof(double);
-    auto kern = nuts_gauss_reg_kernel<NT, DIAGM>;
-    note_kernel("nuts_gauss_reg_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
-    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, batch);
-    return (int)hipGetLastError();
-}
-
-// the same tick with the chains handed to the lanes dynamically (nuts_dyn.hpp): a persistent grid, as many workgroups as the chip holds at once
-template <int NT, bool DIAGM>
-int dyn(NutsParams prm, uint32_t batch, hipStream_t st)
-{
-    const size_t lds = ((size_t)NT * 4 * NT * 64 + (size_t)NUTS_LVLS * 4 * 64 + 64 + 3 * 64 + (DIAGM ? 32 * NT : 0)) * sizeof(double);
-    auto kern = nuts_gauss_dyn_kernel<NT, DIAGM>;
-    note_kernel("nuts_gauss_dyn_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
-    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int dev = 0, n_cu = 256, per_cu = 1;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    const uint64_t need = (prm.C + 63) / 64, cap = (uint64_t)n_cu * (uint64_t)per_cu;
-    MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(kern, dim3((unsigned)cap_grid(need < cap ? need : cap)), dim3(256), lds, st, prm, batch);
-    return (int)hipGetLastError();
-}
-
-// every doubling on a memoised trajectory (nuts_memo.hpp): the same persistent grid
+// every doubling on a memoised trajectory (nuts_memo.hpp): a persistent grid, chains handed out dynamically
 template <int NT, bool DIAGM>
 size_t memo_lds()
 {
@@ -108,13 +75,6 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, boo
     return MI_DISPATCH_NT(nt, (async<1, false, false>(prm, batch, st)), (async<2, false, false>(prm, batch, st)), (async<4, false, false>(prm, batch, st)), (async<8, false, false>(prm, batch, st)));
 }
 
-int launch_nuts_gauss_reg(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st, bool diag_m)
-{
-    if (batch < 1) batch = 1;
-    if (diag_m) return MI_DISPATCH_NT(nt, (reg<1, true>(prm, batch, st)), (reg<2, true>(prm, batch, st)), (reg<4, true>(prm, batch, st)), (reg<8, true>(prm, batch, st)));
-    return MI_DISPATCH_NT(nt, (reg<1, false>(prm, batch, st)), (reg<2, false>(prm, batch, st)), (reg<4, false>(prm, batch, st)), (reg<8, false>(prm, batch, st)));
-}
-
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)
 {
     if (diag_m) return MI_DISPATCH_NT(nt, (memo<1, true>(prm, st)), (memo<2, true>(prm, st)), (memo<4, true>(prm, st)), (memo<8, true>(prm, st)));
@@ -127,12 +87,6 @@ size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)
                                 : MI_DISPATCH_NT(nt, (memo_shape<1, false>(C)), (memo_shape<2, false>(C)), (memo_shape<4, false>(C)), (memo_shape<8, false>(C)));
     const int ns = 4 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8);
     return (size_t)sh.grid * sh.waves * memo_wave_bytes(ns);
-}
-
-int launch_nuts_gauss_dyn(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)
-{
-    if (diag_m) return MI_DISPATCH_NT(nt, (dyn<1, true>(prm, 1u, st)), (dyn<2, true>(prm, 1u, st)), (dyn<4, true>(prm, 1u, st)), (dyn<8, true>(prm, 1u, st)));
-    return MI_DISPATCH_NT(nt, (dyn<1, false>(prm, 1u, st)), (dyn<2, false>(prm, 1u, st)), (dyn<4, false>(prm, 1u, st)), (dyn<8, false>(prm, 1u, st)));
 }
 
 }  // namespace mi

@@ -6,7 +6,7 @@
 // (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity or DIAGONAL precond_mat, with or without
 // settings.vals_bound (lds_box.hpp).
 //
-// The sampler is the asynchronous per-chain tree state machine of nuts_reg.hpp / include/mi_mcmc_engine/nuts_tile.hpp (iterative
+// The sampler is the asynchronous per-chain tree state machine of rounds 2-4's nuts_reg.hpp (retired) / include/mi_mcmc_engine/nuts_tile.hpp (iterative
 // leaf-indexed tree: nuts_dense.hpp; eager U-turn tests, momenta generated ahead, draw boundaries without waiting), with two changes
 // that the evaluation forces:
 //   * a chain's vectors are split over the FOUR waves of its tile (wave q: dims [q DQ, (q+1) DQ)), every per-chain scalar is replicated
@@ -48,7 +48,7 @@
 namespace mi {
 
 namespace lds_nuts {
-// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp / nuts_reg.hpp / nuts_tile.hpp)
+// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp / nuts_tile.hpp)
 enum : int {
     V_PREV = 0, V_WPREV = 1, V_MNTM = 2, V_TPOS_T = 3, V_TPOS_P = 4, V_TNEG_T = 5, V_TNEG_P = 6,
     V_LEAF0 = 7,             // slot k: theta 7+3k, p 8+3k, grad 9+3k, k = 0..10 (even leaves only: slot 1 is free, see below)

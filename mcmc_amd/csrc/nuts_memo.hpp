@@ -1,6 +1,7 @@
 // nuts_memo.hpp -- many-chain NUTS for the plain case (unbounded; identity or DIAGONAL precond_mat; d <= 128, max_tree_depth <= 10) with every
-// doubling evaluated on a MEMOISED TRAJECTORY: same draws, accepts, tree depths, leapfrog counts and step sizes as nuts_reg.hpp / nuts_dyn.hpp,
-// bit for bit, with ~40 % fewer leapfrogs executed on BASELINE configs[3].
+// doubling evaluated on a MEMOISED TRAJECTORY: same draws, accepts, tree depths, leapfrog counts and step sizes as the tick-local kernel of
+// nuts_async.hpp (and as rounds 2-4's register-carried kernels nuts_reg.hpp / nuts_dyn.hpp / nuts_split.hpp, which this one replaced), bit for bit,
+// with ~40 % fewer leapfrogs executed on BASELINE configs[3].
 //
 // Replaces what they replace: mcmc::internal::nuts_impl with nuts_find_initial_step_size and nuts_build_tree
 // (/root/reference/src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241).
@@ -16,8 +17,10 @@
 // burn-in grows depth-8..10 trees while the step size adapts; measured with oracle/mcmc_oracle.c: orc_nuts_memo, which is this algorithm on
 // the CPU and is checked against the recursion bit for bit in tests/test_oracle_memo.py).
 //
-// The tick.  Chains are handed to 16 slots per wave dynamically (nuts_dyn.hpp: persistent grid, global counter, INIT / SEARCH as tick
-// states).  Per tick every chain inside a tree
+// The tick.  Chains are handed to 16 slots per wave dynamically: the grid is persistent (as many workgroups as the chip holds), a slot whose chain
+// has finished its draws takes the next chain index from a global counter (one atomic per wave and tick with a free slot), and a new chain enters
+// the tick loop in two more states -- INIT (P theta at its initial values, nuts.cpp:181, with z_init as momentum so that the tick's kinetic energy is
+// K0) and SEARCH (one leapfrog of nuts_find_initial_step_size per tick); results cannot depend on the slot (counter-based RNG on the global chain id).  Per tick every chain inside a tree
 //   1. computes the NEXT POINT of its doubling's trajectory -- one leapfrog from the point in registers (the trajectory is sequential: no
 //      start-record loads except the origin at the start of a doubling), P theta on the matrix cores --, its energies and the leaf scalars
 //      (n', s' as bits, alpha and U in a per-chain scalar table), and stores the point's record (theta, p, P theta);
@@ -33,7 +36,7 @@
 //
 // Workspace per wave: 10 fixed vectors (prev_draw x 2 with P theta, momentum x 2, the four edge vectors) + 3 vectors per point (46 points at
 // max_tree_depth 10) in the record layout of nuts_async.hpp, then the scalar table [47][64 lanes][alpha, U].  Non-finite regime: detected,
-// flagged, retired and replayed by the general variant exactly as nuts_dyn.hpp does.
+// flagged (LDS), the chain leaves its slot at once, and the general variant (nuts_async.hpp) replays it from its initial state.
 
 #pragma once
 
@@ -42,11 +45,16 @@
                                  // 15 chains of its wave do not wait for a 32-leaf walk).  0 = no limit.  Measured on configs[3]: 0: 578 ms, 6: 569, 8: 563, 12: 568
 #endif
 
-#include "nuts_reg.hpp"
-#include "nuts_dyn.hpp"
+#include "nuts_async.hpp"
+
+#ifndef MI_NUTS_R_CHC
+#define MI_NUTS_R_CHC 16     // kept-row stores: slices per chunk
+#endif
 
 namespace mi {
 
+enum : int { NS_INIT = 3, NS_SEARCH = 4 };          // (next to NS_NEED_DRAW, NS_TREE, NS_DONE of nuts_async.hpp) a new chain in a slot: P theta at its initial
+                                                    // values, then one leapfrog of nuts_find_initial_step_size per tick (nuts.ipp:30-93)
 enum : int {
     MV_MNTM2 = 7, MV_PREVB = 8, MV_WPREVB = 9,
     MV_PT0 = 10,                 // point n (1 ..): theta at MV_PT0 + 3 (n - 1), p at + 1, P theta at + 2
@@ -232,8 +240,10 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
     int good_round = 0;
     bool org_ok = false;         // the registers already hold the origin of the doubling about to start
     double ca_keep = 0.0;        // MI_MEMO_WALK_CAP: alpha of the leaf a walk that was cut short goes on with
-    // Draw boundaries without waiting: as nuts_reg.hpp / nuts_dyn.hpp (momenta generated ahead, prev_draw alternating between two vectors,
-    // the edges are the draw's initial vectors until a doubling has written that side)
+    // Draw boundaries without waiting (round 2): what the next draw needs and that does not depend on the chain's state -- momentum
+    // (nuts.cpp:200-202), its kinetic energy, the slice uniform -- is generated AHEAD by a phase that serves every chain of the wave that lacks it;
+    // prev_draw alternates between two vectors (an accepted proposal goes to the one that did not hold prev_draw when the draw started, so the
+    // kept row can be written later from a vector that stays intact), and the edges are the draw's initial vectors until a doubling has written that side
     int mv = V_MNTM, mvn = MV_MNTM2;
     int pb = 0, pb0 = 0;
     bool mom_ready = false;
@@ -439,7 +449,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
 #endif
 
         // INIT: first_draw and z_init (nuts.cpp:160-168) are staged in the workspace -- theta in V_PREV, the momentum in mv -- and enter the
-        // registers through the origin load below; the tick is P theta with e = 0 (nuts_dyn.hpp: why rolled loops, and why here)
+        // registers through the origin load below; the tick is P theta with e = 0 (ROLLED loops, and HERE, where no test operands are live: unrolled they cost the d = 128 kernel 800 bytes of scratch)
         if (__ballot(init) != 0ull) {
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {

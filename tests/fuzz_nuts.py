@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the plain NUTS kernel (nuts_reg.hpp) against the recursive oracle: draw counts, burn-in / adaptation
+"""Randomised parity sweep of the plain NUTS kernels (nuts_memo.hpp, and the tick-local nuts_async.hpp) against the recursive oracle: draw counts, burn-in / adaptation
 windows, tree-depth caps (0 included), chain counts around the 16-chain wave, with and without kept draws.  Bit-exact or report.
 Usage (GPU box): python tests/fuzz_nuts.py [n_cases] [seed]   (test infrastructure: it drives the oracle)"""
 import os, sys
@@ -30,8 +30,8 @@ def sweep(n_cases=40, seed=1, verbose=True):
         st = mcmc_amd.default_settings(rng_seed_value=int(rng.integers(1, 10**6)), n_burnin_draws=burn, n_keep_draws=keep,
                                        n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
         chain0 = int(rng.integers(0, 5000))
-        # the launch shape: AUTO (few chains at d > 64: the split-tile kernel), or one of the plain-case kernels by name
-        hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN, mcmc_amd.KERNEL_NUTS_MEMO, mcmc_amd.KERNEL_NUTS_MEMO]))
+        # AUTO / MEMO: the memoised kernel; REG: a retired kernel's hint (ignored); TICK_LOCAL: the independent tick-local kernel
+        hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO]))
         g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0, kernel_hint=hint)
         o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0)
         bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)

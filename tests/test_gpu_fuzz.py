@@ -24,7 +24,7 @@ def test_random_normal_model_cases_are_bit_exact(seed):
 
 @pytest.mark.parametrize("seed", [5])
 def test_plain_nuts_kernel_random_windows_and_depth_caps(seed):
-    """Draw boundaries of nuts_reg.hpp (momenta ahead, epilogue on the spot, deferred rows): random burn-in / keep / adaptation
+    """Draw boundaries of the plain NUTS kernels (momenta ahead, epilogue on the spot, deferred rows): random burn-in / keep / adaptation
     windows, depth caps 0..10, chain counts around the wave size."""
     import fuzz_nuts
     assert fuzz_nuts.sweep(40, seed, verbose=False) == 0

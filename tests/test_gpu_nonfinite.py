@@ -170,12 +170,12 @@ def test_logistic_chain_driven_non_finite(algo, d, N):
     _same(g_draws, g, o_draws, o)
 
 
-@pytest.mark.parametrize("hint", ["reg", "dyn", "memo"])
+@pytest.mark.parametrize("hint", ["memo", "async"])
 @pytest.mark.parametrize("adapt", [0, 6])
 def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
-    """nuts_gauss_reg_kernel / nuts_gauss_dyn_kernel (the latter retires a flagged chain at once and hands its lane the next one): flagged chains are replayed by the general variant (identity tables), which forms the reference's dense
+    """nuts_gauss_memo_kernel (retires a flagged chain at once and hands its lane the next one): flagged chains are replayed by the general variant (identity tables), which forms the reference's dense
     `inv_precond_matrix * mntm` (nuts.cpp:139-154); healthy chains of the same wave keep what the plain kernel wrote."""
-    d, C = 128, (40 if hint == "reg" else 200)
+    d, C = 128, (40 if hint == "async" else 200)
     prec = synth.dense_gaussian_precision(d)
     init = synth.initial_states(C, d, seed=19)
     init[2] *= 1.0e300
@@ -183,7 +183,7 @@ def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
     init[33, 100] = np.nan
     st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=adapt, max_tree_depth=6, step_size=0.1)
     g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec,
-                               kernel_hint={"dyn": mcmc_amd.KERNEL_NUTS_DYN, "memo": mcmc_amd.KERNEL_NUTS_MEMO, "reg": mcmc_amd.KERNEL_NUTS_REG}[hint])
+                               kernel_hint={"memo": mcmc_amd.KERNEL_AUTO, "async": mcmc_amd.KERNEL_NUTS_TICK_LOCAL}[hint])
     assert mcmc_amd.last_kernel().startswith("nuts_gauss_%s_kernel<" % hint)
     s = orc.make_settings(seed=6, n_burnin=6, n_keep=5, n_adapt=adapt, max_depth=6, step=0.1, W=4)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
@@ -193,10 +193,10 @@ def test_plain_nuts_d128_chain_driven_non_finite(adapt, hint):
     assert np.array_equal(g["eps"], o["eps"], equal_nan=True)
 
 
-@pytest.mark.parametrize("kern", ["reg", "memo"])
-@pytest.mark.parametrize("d,adapt", [(128, 6), (128, 0), (48, 4)])
+@pytest.mark.parametrize("kern", ["memo"])
+@pytest.mark.parametrize("d,adapt", [(128, 6), (128, 0), (48, 4), (12, 3)])
 def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt, kern):
-    """nuts_gauss_reg_kernel<., true> / nuts_gauss_memo_kernel<., true> (AUTO beyond d = 16): the plain-case kernels with two mass tables; chains that
+    """nuts_gauss_memo_kernel<., true>: the plain-case kernel with two mass tables; chains that
     leave the finite regime are replayed by the general variant with the same tables (ref: src/nuts.cpp:139-154,168,202,204 with the diagonal matrices)."""
     C = 40
     prec = synth.dense_gaussian_precision(d)
@@ -208,7 +208,7 @@ def test_nuts_with_a_diagonal_precond_mat_alone_finite_and_non_finite(d, adapt, 
     st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=6, n_keep_draws=5, n_adapt_draws=adapt, max_tree_depth=6, step_size=0.1,
                                    precond_mat=M)
     g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec,
-                               kernel_hint=mcmc_amd.KERNEL_NUTS_REG if kern == "reg" else mcmc_amd.KERNEL_AUTO)
+                               kernel_hint=mcmc_amd.KERNEL_AUTO)
     assert mcmc_amd.last_kernel().startswith("nuts_gauss_%s_kernel<" % kern) and mcmc_amd.last_kernel().endswith("true>"), mcmc_amd.last_kernel()
     s = orc.make_settings(seed=6, n_burnin=6, n_keep=5, n_adapt=adapt, max_depth=6, step=0.1, W=4, precond=M)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)

@@ -48,11 +48,10 @@ CASES = [
 ]
 
 
-# KERNEL_NUTS_REG: one wave per tile with register-carried leaf state (nuts_reg.hpp), the default up to d = 16; KERNEL_NUTS_DYN: its tick with the
-# chains handed out dynamically; KERNEL_NUTS_SPLIT: a RETIRED kernel's hint -- valid, ignored, the default kernel runs;
-# the tick-local asynchronous kernel (what the bounded / preconditioned variants run) must give the same bits.  (The lock-step
-# first-generation kernel, 2.4 KB of scratch per lane, is no longer in the shipped library: `make prof` keeps it for A/B runs.)
-# ... and nuts_memo.hpp (KERNEL_NUTS_MEMO: every doubling on a memoised trajectory -- the default beyond 64 chains per CU) with fewer leapfrogs executed
+# AUTO / KERNEL_NUTS_MEMO: every doubling on a memoised trajectory (nuts_memo.hpp), THE kernel of the plain case.  KERNEL_NUTS_REG / _SPLIT / _DYN name
+# the register-carried kernels of rounds 2-4, retired in round 5: valid hints, ignored -- the default kernel runs.  KERNEL_NUTS_TICK_LOCAL: the
+# tick-local asynchronous kernel (what the bounded / preconditioned variants run; it executes every leaf) -- an independent implementation that must
+# give the same bits.  (The lock-step first-generation kernel is only in the A/B library: `make prof`.)
 KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN,
            mcmc_amd.KERNEL_NUTS_MEMO]
 
@@ -69,8 +68,8 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep,
                                    n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
     g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
-    if hint in (mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_SPLIT):           # the memoised trajectory beyond d = 16 (max_tree_depth = 0 has no tree to memoise)
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel" if (d > 16 and max_depth >= 1) else "nuts_gauss_reg_kernel")
+    memo = hint != mcmc_amd.KERNEL_NUTS_TICK_LOCAL
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel" if memo else "nuts_gauss_async_kernel")
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
     assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs
@@ -78,8 +77,7 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     assert np.array_equal(g["eps"], o["eps"])                # same dual-averaging trajectory
     assert np.array_equal(g_draws, o_draws)
     assert np.linalg.norm(g_draws - o_draws) <= 1e-9 * np.linalg.norm(o_draws)
-    if (hint == mcmc_amd.KERNEL_NUTS_MEMO or (hint in (mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_SPLIT) and d > 16)) and max_depth >= 1:
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel")
+    if memo:
         # the leapfrogs it really made: what the memoised oracle makes (one per distinct point of a doubling + the step-size search)
         n_exec = []
         for c in range(C):
@@ -196,16 +194,17 @@ def test_general_nuts_between_d64_and_d128(d, general, n_adapt):
     assert np.array_equal(g_draws, o_draws)
 
 
-def test_memoised_kernel_at_several_grid_sizes_gives_the_bits_of_the_register_carried_kernel():
-    """nuts_gauss_memo_kernel<8> on 700 / 5 000 / 20 000 chains (11 workgroups, 79, and -- beyond the chip's 16 384 chain slots -- a persistent grid
-    whose slots take a second chain): all equal to nuts_gauss_reg_kernel bit for bit, ragged last tiles included, with fewer leapfrogs executed."""
+def test_memoised_kernel_at_every_launch_shape_gives_the_bits_of_the_tick_local_kernel():
+    """nuts_gauss_memo_kernel<8> on 700 / 5 000 / 20 000 chains -- one, two and four waves per workgroup, the last beyond the chip's 16 384 chain
+    slots (a persistent grid whose slots take a second chain): all equal to nuts_gauss_async_kernel (which executes every leaf) bit for bit, ragged
+    last tiles included, with fewer leapfrogs executed."""
     d = 128
     prec = synth.dense_gaussian_precision(d, seed=6)
     st = mcmc_amd.default_settings(rng_seed_value=11, n_burnin_draws=4, n_keep_draws=3, n_adapt_draws=4, max_tree_depth=6)
     for C in (700, 5000, 20000):
         init = synth.initial_states(C, d, seed=C)
-        ref, r = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3, kernel_hint=mcmc_amd.KERNEL_NUTS_REG)
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_reg_kernel")
+        ref, r = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3, kernel_hint=mcmc_amd.KERNEL_NUTS_TICK_LOCAL)
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_async_kernel")
         got, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3)
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<8, false>")
         assert np.array_equal(got, ref)

@@ -51,7 +51,7 @@ def test_nuts_resumes_after_its_adaptation_window():
     assert e.value.code == mcmc_amd.MI_ERR_BAD_ARG
 
 
-@pytest.mark.parametrize("route", ["reg_d32", "reg_diag_mass_d32", "dyn_d32", "dyn_diag_mass_d100", "memo_d32", "memo_diag_mass_d100", "split_d100", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
+@pytest.mark.parametrize("route", ["memo_d32", "memo_diag_mass_d32", "memo_150chains_d32", "memo_150chains_diag_mass_d100", "memo_d12", "ignored_hint_d100", "tick_local_d32", "general_dense_precond_d20", "small_normal_model", "literal_d150", "literal_depth12"])
 @pytest.mark.parametrize("cut", [3, 9, 10, 14])
 def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     """checkpoint of (theta, eps, h, Philox counter).  n_adapt_draws = 10 of 12 burn-in + 6 kept draws; the run is cut after
@@ -59,12 +59,11 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     after it (14) -- and continued with step_size + nuts_adapt_state: bit-identical to the uncut run on every nuts kernel."""
     burn, keep, n_adapt, C = 12, 6, 10, 21
     kw, tkw = dict(max_tree_depth=5), {}
-    hint = (mcmc_amd.KERNEL_NUTS_DYN if route.startswith("dyn") else mcmc_amd.KERNEL_NUTS_MEMO if route.startswith("memo")      # (nuts_dyn.hpp / nuts_memo.hpp: chains
-            else mcmc_amd.KERNEL_NUTS_REG if route.startswith("reg") else mcmc_amd.KERNEL_NUTS_SPLIT if route.startswith("split")  # handed to the lanes dynamically)
-            else mcmc_amd.KERNEL_AUTO)
-    if route.startswith("reg") or route.startswith("general") or route.startswith("split") or route.startswith("dyn") or route.startswith("memo"):
-        d = 100 if route.endswith("d100") else 32 if (route.startswith("reg") or route.startswith("dyn") or route.startswith("memo")) else 20     # (split_d100, few chains: nuts_gauss_split_kernel)
-        if route.startswith("dyn") or route.startswith("memo"): C = 150
+    hint = (mcmc_amd.KERNEL_NUTS_SPLIT if route.startswith("ignored") else mcmc_amd.KERNEL_NUTS_TICK_LOCAL if route.startswith("tick_local")
+            else mcmc_amd.KERNEL_AUTO)         # (AUTO: nuts_memo.hpp; a retired kernel's hint is ignored; the tick-local kernel is the independent route)
+    if route.startswith("memo") or route.startswith("general") or route.startswith("ignored") or route.startswith("tick_local"):
+        d = 100 if route.endswith("d100") else 12 if route.endswith("d12") else 20 if route.startswith("general") else 32
+        if "150chains" in route: C = 150
         kind = mcmc_amd.TARGET_GAUSS_DENSE; tkw = dict(prec=synth.dense_gaussian_precision(d, seed=2))
         if "diag_mass" in route: kw["precond_mat"] = np.diag(np.linspace(0.5, 2.0, d))
         if "dense_precond" in route:                          # (the general tick-local kernel; bounds are left out on purpose: a checkpoint holds
@@ -84,10 +83,10 @@ def test_nuts_can_be_cut_anywhere_with_the_dual_averaging_state(route, cut):
     a_draws, a = mcmc_amd.sample("nuts", kind, init, S(0, cut), chain0=4, want_adapt_state=True, kernel_hint=hint, **tkw)
     b_draws, b = mcmc_amd.sample("nuts", kind, a["theta"].T.copy(), S(0, burn + keep - cut), chain0=4, draw0=cut, step_size_in=a["eps"],
                                  adapt_state_in=a["adapt_state"], kernel_hint=hint, **tkw)
-    if route.startswith("dyn"):
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_dyn_kernel<")
-    if route.startswith("split"):                       # (a retired kernel's hint: ignored, the default -- memoised -- kernel runs)
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<8, ")
+    if route.startswith("memo") or route.startswith("ignored"):
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<")
+    if route.startswith("tick_local"):
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_async_kernel<")
     assert np.array_equal(np.concatenate([a_draws, b_draws]), w_draws)
     assert np.array_equal(b["eps"], w["eps"])
     if cut <= n_adapt:                                  # (after the window the state is no longer read, hence not carried)

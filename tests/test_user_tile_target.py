@@ -125,7 +125,7 @@ def test_twisted_gaussian_tile_target_against_the_oracle_with_the_same_callback(
 @pytest.mark.parametrize("d,C_,max_depth", [(128, 150, 6), (100, 33, 10), (70, 16, 3)])
 def test_dense_gaussian_tile_target_under_nuts_reproduces_the_built_in_nuts_kernel(tile_lib, d, C_, max_depth):
     """mcmc::nuts on the tile route (nuts_tile.hpp): with the built-in dense Gaussian as the user target, p + (e grad) / 2 is
-    p - (e P theta) / 2 to the bit, so trees, step sizes and draws equal nuts_gauss_reg_kernel's."""
+    p - (e P theta) / 2 to the bit, so trees, step sizes and draws equal the built-in kernel's (nuts_gauss_memo_kernel, which executes fewer of the leapfrogs)."""
     import torch
     P = synth.dense_gaussian_precision(d, seed=d)
     Pd = torch.from_numpy(P).cuda()
@@ -133,7 +133,7 @@ def test_dense_gaussian_tile_target_under_nuts_reproduces_the_built_in_nuts_kern
     st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=4, n_keep_draws=5, n_adapt_draws=6, max_tree_depth=max_depth)
     t_draws, t = _run_tile(tile_lib, "gauss_tile_run", 2, GaussTile(Pd.data_ptr(), d), d, init, st)
     assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<")
-    b_draws, b = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=P, kernel_hint=mcmc_amd.KERNEL_NUTS_REG)
+    b_draws, b = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=P, kernel_hint=mcmc_amd.KERNEL_AUTO)
     assert np.array_equal(t["depth"], b["depth"]) and np.array_equal(t["n_leap"], b["n_leap"])
     assert np.array_equal(t["eps"], b["eps"]) and np.array_equal(t["n_accept"], b["n_accept"])
     assert np.array_equal(t_draws, b_draws)

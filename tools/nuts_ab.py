@@ -1,6 +1,6 @@
-"""A/B timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events), same box, alternating: MI_AB=memo (memoised trajectory,
-nuts_memo.hpp, vs dynamic hand-out, nuts_dyn.hpp) | dyn (vs register-carried leaf state, nuts_reg.hpp) | memo_only | memo_reg; MI_D = dimension;
-argv: chains [draws per half]."""
+"""Timing of the NUTS kernels on BASELINE configs[3] (device-resident, HIP events), same box, alternating: MI_AB=memo_only (nuts_memo.hpp) |
+memo (against the tick-local kernel, nuts_async.hpp: an independent implementation, same bits); MI_D = dimension; argv: chains [draws per half].
+(The A/B runs against the retired nuts_reg / nuts_dyn / nuts_split kernels are in profiles/r5_nuts_ab_*.log.)"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch, mcmc_amd
@@ -18,10 +18,8 @@ n_exec = torch.zeros(C, dtype=torch.int64, device=dev)
 st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn)
 ref = None
 for rep in range(2):
-    AB = {"dyn": (("dyn", mcmc_amd.KERNEL_NUTS_DYN), ("reg", mcmc_amd.KERNEL_NUTS_REG)),
-          "memo": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("dyn", mcmc_amd.KERNEL_NUTS_DYN)),
-          "memo_only": (("memo", mcmc_amd.KERNEL_NUTS_MEMO),),
-          "memo_reg": (("memo", mcmc_amd.KERNEL_NUTS_MEMO), ("reg", mcmc_amd.KERNEL_NUTS_REG))}[os.environ.get("MI_AB", "memo")]
+    AB = {"memo": (("memo", mcmc_amd.KERNEL_AUTO), ("tick_local", mcmc_amd.KERNEL_NUTS_TICK_LOCAL)),
+          "memo_only": (("memo", mcmc_amd.KERNEL_AUTO),)}[os.environ.get("MI_AB", "memo_only")]
     for name, hint in AB:
         t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
         ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, n_leapfrogs_executed=n_exec, mem=mcmc_amd.MEM_DEVICE)
