@@ -77,3 +77,9 @@ def test_bounded_lds_kernels_match_the_literal_kernel_on_longer_runs_and_in_the_
     assert mcmc_amd.last_kernel().startswith("literal_kernel<")
     _check(algo, a_draws, a, b_draws, b)
     assert np.array_equal(a["theta"], b["theta"], equal_nan=True)
+    # ... and against the ORACLE on the same run (the comparison above is the engine against itself)
+    _, _, spec = _problem(kind, d, n_rows, seed=d + 7)
+    s = orc.make_settings(seed=23, n_burnin=6, n_keep=6, n_leap=7, step=0.05, n_adapt=5, max_depth=7, W=4, hoist=1, blocks=4,
+                          block_size=_bs(kind, d), lower=lb, upper=ub)
+    o_draws, o = orc.run_many(ALGO[algo], spec, init, s, chain0=2)
+    _check(algo, a_draws, a, o_draws, o)

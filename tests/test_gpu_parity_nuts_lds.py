@@ -92,6 +92,22 @@ def test_lds_nuts_matches_the_literal_kernel_on_longer_runs(kind, d, n_rows, C):
     assert np.array_equal(a["theta"], b["theta"])
 
 
+@pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 512, 64, 48), ("logistic", 48, 200, 70), ("dense", 512, 0, 40), ("dense", 192, 0, 64)])
+def test_lds_nuts_matches_the_oracle_on_longer_runs(kind, d, n_rows, C):
+    """The same long runs against the ORACLE (the comparison with literal_kernel<2> above is the engine against itself):
+    deep trees (up to 2^8 leaves), 14 draws, the adaptation window inside the run, chains that finish at different times -- draws, accepts,
+    reference leapfrog counts, step sizes bit for bit.  (The oracle runs its chains on all host cores; about 10 s.)"""
+    tk, tkw, spec = _problem(kind, d, n_rows, seed=d + 5)
+    init = synth.initial_states(C, d, seed=d + 2) * (0.1 if kind == "logistic" else 0.5)
+    st = mcmc_amd.default_settings(rng_seed_value=11, n_burnin_draws=8, n_keep_draws=6, n_adapt_draws=6, max_tree_depth=8, step_size=0.05)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=9, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
+    s = orc.make_settings(seed=11, n_burnin=8, n_keep=6, n_adapt=6, max_depth=8, step=0.05, W=4, blocks=4, block_size=_bs(kind, d))
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=9)
+    assert g["depth"].max() >= 5 and o["n_leap"].max() > 200
+    _same(g_draws, g, o_draws, o, depth=False)
+
+
 @pytest.mark.parametrize("kind,d,n_rows", [("logistic", 100, 40), ("dense", 200, 0)])
 @pytest.mark.parametrize("cut", [3, 10, 14])
 def test_lds_nuts_can_be_cut_anywhere(kind, d, n_rows, cut):
