@@ -45,7 +45,7 @@ struct TileParams {
     double eps;             // step_size
     double s2, rs, cons_term, log_det;      // mala: eps^2, 1 / eps^2, -d log(2 pi) / 2, LOG_DET(eps^2 I) (host, the oracle's order)
     // nuts (nuts_tile.hpp)
-    double* ws;             // [n_tiles][64 vectors][NS][64 lanes] workspace, tile-local and contiguous
+    double* ws;             // nuts: memo::memo_wave_bytes(NS) per wave (16 chain slots): point records + scalar table (nuts_memo_core.hpp)
     double* step_out;       // [C] or nullptr: final step size (in: the adapted step sizes of a continuation, draw0 > 0)
     uint32_t* depth_trace;  // [n_total][C] or nullptr
     double* adapt_state;    // [3][C] or nullptr: dual-averaging state (h, epsilon_bar, mu), mi_chains.nuts_adapt_state
@@ -59,6 +59,12 @@ struct TileParams {
     const double* ub;
     const double* m_sqrt;   // diag of CHOL_LOWER(precond_mat) (ones = identity)
     const double* m_inv;    // diag of INV(precond_mat)
+    // nuts (nuts_memo_core.hpp): leapfrogs really computed [C] or nullptr; the fields of the built-in kernel's dynamic hand-out and replay, unused
+    // on this route (every chain has its own slot; the tile policy applies the reference's NaN rules itself): nullptr
+    uint64_t* n_exec;
+    uint32_t* next_chain;
+    uint32_t* nf_flag;
+    unsigned long long* prof;
 };
 
 // ---- settings.vals_bound and / or a diagonal precond_mat on the tile route, with the arithmetic of the general built-in kernels

@@ -35,6 +35,10 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m,
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);
 int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
+// settings.vals_bound (and / or a diagonal precond_mat next to it) on the memoised tick: the built-in Gaussian as a tile target with TileGen
+// (nuts_bounded_launch.hip); prm.ws must hold nuts_bounded_workspace_bytes, prm.btype / lb / ub / m_sqrt / m_inv the tables
+int launch_nuts_gauss_bounded(const NutsParams& prm, int nt, hipStream_t st);
+size_t nuts_bounded_workspace_bytes(uint64_t C, int nt);
 int launch_nuts_gauss_dense_m(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_dense_launch.hip
 int launch_rwmh_gauss(const RwmhParams& prm, int nt, bool general, bool dense_c, hipStream_t st);
 // one lane per chain, d = 2 normal model (rmhmc_small.hpp, small_samplers.hpp); algo: 0 hmc, 1 mala, 2 nuts, 3 rwmh, 4 rmhmc

@@ -1179,15 +1179,17 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         p.m_sqrt = gt.ms_dev.as<double>(); p.m_inv = gt.mi_dev.as<double>();
     }
     WsLease ws;
-    if (algo == 2) {                                       // nuts: 64 workspace vectors per chain (records, pending proposals, edges)
+    if (algo == 2) {                                       // nuts: point records + scalar table of every chain slot (nuts_memo_core.hpp), one workgroup per 64 chains
         if ((rc = nuts_continuation(settings, chains, &p.n_adapt))) return rc;
         p.max_depth = (uint32_t)settings->max_tree_depth;
         p.delta = settings->target_accept_rate; p.eps_bar0 = settings->step_size;
         p.gamma = settings->gamma_val; p.t0 = settings->t0_val; p.kappa = settings->kappa_val;
         p.step_out = sc.dev.step_size; p.depth_trace = sc.dev.nuts_depth; p.adapt_state = sc.dev.nuts_adapt_state;
-        rc = ws_get(st, (size_t)mi::tile_nuts::NUTS_NVEC * 16 * nt * ((chains->n_chains + 15) / 16 + 4) * 16 * sizeof(double), ws);
+        const int nt_pad = nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8;
+        rc = ws_get(st, mi::tile_nuts::ws_bytes(chains->n_chains, nt_pad), ws);
         if (rc) return rc;
         p.ws = ws.as<double>();
+        p.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = p.n_exec != nullptr;     // (each distinct state of a doubling is evaluated once)
     } else {
         rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
         if (rc) return rc;
@@ -2069,6 +2071,9 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     // (the memoised kernel's workspace is sized by the chain slots of its persistent grid; the replay of flagged chains re-uses the same
     //  bytes in the asynchronous kernel's layout afterwards)
     if (memo) ws_own = std::max(ws_own, mi::nuts_memo_workspace_bytes(chains->n_chains, nt, gt.active));
+    // bounds (with the identity or a diagonal precond_mat): the memoised tick with the tile route's policy (nuts_bounded_launch.hip)
+    const bool bounded_memo = gt.active && !gt.dense && settings->vals_bound && !lockstep && !tick_local;
+    if (bounded_memo) ws_own = std::max(ws_own, mi::nuts_bounded_workspace_bytes(chains->n_chains, nt));
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
     const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any"
     rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
@@ -2143,7 +2148,11 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         prm.btype = gt.bt.as<int>(); prm.lb = gt.lb.as<double>(); prm.ub = gt.ub.as<double>();
         prm.m_sqrt = gt.ms_dev.as<double>(); prm.m_inv = gt.mi_dev.as<double>();
         prm.vals_bound = settings->vals_bound ? 1 : 0;
-        rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, false, false, nuts_batch, st));
+        if (bounded_memo) {
+            prm.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = prm.n_exec != nullptr;
+            rc = launched("nuts", mi::launch_nuts_gauss_bounded(prm, nt, st));
+        }
+        else rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, true, false, false, nuts_batch, st));     // (MI_KERNEL_NUTS_TICK_LOCAL: the tick-local general kernel)
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the tables are ours
     }
     else if (lockstep || tick_local) rc = launched("nuts", mi::launch_nuts_gauss(prm, nt, false, false, lockstep, nuts_batch, st));

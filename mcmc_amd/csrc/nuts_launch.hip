@@ -35,7 +35,7 @@ MemoShape memo_shape(uint64_t C)
     return MemoShape{waves, cap_grid(need < cap ? need : cap)};
 }
 template <int NT, bool DIAGM>
-int memo(NutsParams prm, hipStream_t st)
+int run_memo(NutsParams prm, hipStream_t st)
 {
     const size_t lds = memo_lds<NT, DIAGM>();
     auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
@@ -77,8 +77,8 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool gen, bool dense_m, boo
 
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m)
 {
-    if (diag_m) return MI_DISPATCH_NT(nt, (memo<1, true>(prm, st)), (memo<2, true>(prm, st)), (memo<4, true>(prm, st)), (memo<8, true>(prm, st)));
-    return MI_DISPATCH_NT(nt, (memo<1, false>(prm, st)), (memo<2, false>(prm, st)), (memo<4, false>(prm, st)), (memo<8, false>(prm, st)));
+    if (diag_m) return MI_DISPATCH_NT(nt, (run_memo<1, true>(prm, st)), (run_memo<2, true>(prm, st)), (run_memo<4, true>(prm, st)), (run_memo<8, true>(prm, st)));
+    return MI_DISPATCH_NT(nt, (run_memo<1, false>(prm, st)), (run_memo<2, false>(prm, st)), (run_memo<4, false>(prm, st)), (run_memo<8, false>(prm, st)));
 }
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)

@@ -170,7 +170,8 @@ def test_dense_precond_nuts_bit_exact_vs_oracle(d, C, bounded):
 @pytest.mark.parametrize("general", ["bounds", "bounds_diag_precond", "dense_precond"])
 @pytest.mark.parametrize("n_adapt", [0, 3])
 def test_general_nuts_between_d64_and_d128(d, general, n_adapt):
-    """nuts_gauss_async_kernel<8, true, .> with dimensions that do not fill its eight row tiles (lanes without a dimension, partial
+    """The general kernels -- bounds: the memoised tick with the tile route's policy (nuts_bounded_launch.hip); a dense precond_mat:
+    nuts_gauss_async_kernel<8, true, true> -- with dimensions that do not fill the eight row tiles (lanes without a dimension, partial
     exec masks): a fuzz sweep of round 3 caught this shape returning the chain index as step size when three more loop-carried scalars
     had pushed the register allocation over an edge.  Pinned here: draws, leapfrog counts, adapted step sizes against the oracle."""
     C = 5
@@ -187,7 +188,7 @@ def test_general_nuts_between_d64_and_d128(d, general, n_adapt):
         A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + np.diag(np.linspace(0.5, 2.0, d)); kw.update(precond_mat=M); okw.update(precond=M)
     st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=3, n_keep_draws=4, step_size=0.05, n_adapt_draws=n_adapt, max_tree_depth=4, **kw)
     g_draws, g = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, want_adapt_state=True)
-    assert mcmc_amd.last_kernel().startswith("nuts_gauss_async_kernel<8, true")
+    assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<built-in Gaussian 8, true>" if "bounds" in general else "nuts_gauss_async_kernel<8, true, true>")
     s = orc.make_settings(seed=3, n_burnin=3, n_keep=4, step=0.05, n_adapt=n_adapt, max_depth=4, W=4, hoist=1, **okw)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
     assert np.array_equal(g["eps"], o["eps"]) and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
