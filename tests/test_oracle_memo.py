@@ -87,6 +87,29 @@ def test_the_points_of_a_doubling_follow_the_closed_form():
     assert max(n) == 56 and len(set(n)) == 56
 
 
+def test_the_device_formulas_of_the_memoised_tick():
+    """include/mi_mcmc_engine/nuts_memo_core.hpp computes n(i) with five popcounts (the bit positions k grouped by the bits of k) and decides which
+    (level, first point) pairs a doubling uses from the subset sums of consecutive integers; both restated here and checked against the definition."""
+    pc = lambda x: bin(x).count("1")
+    for i in range(1024):
+        n_dev = 1 + pc(i) + pc(i & 0x2AA) + 2 * pc(i & 0xCC) + 4 * pc(i & 0xF0) + 8 * pc(i & 0x300)
+        assert n_dev == 1 + sum(k + 1 for k in range(10) if (i >> k) & 1)
+
+    def used(l, n1, j):                                    # memo_pair_used
+        m = n1 - 1
+        return any(t * (l + 1) + t * (t - 1) // 2 <= m <= t * j - t * (t - 1) // 2 for t in range(0, j - l + 1))
+
+    npt = lambda i: 1 + sum(k + 1 for k in range(10) if (i >> k) & 1)
+    for j in range(10):
+        truth = {(l, npt(b)) for l in range(1, j + 1) for b in range(0, 1 << j, 1 << l)}      # first leaves of the level-l nodes
+        for l in range(1, j + 1):
+            for n1 in range(1, 48):
+                assert used(l, n1, j) == ((l, n1) in truth), (j, l, n1)
+        assert max(npt(i) for i in range(1 << j)) == 1 + j * (j + 1) // 2 <= 46
+        # the test of a level-l node at first point n1 closes when point n1 + l appears: it exists by then (n1 + l <= the doubling's points)
+        assert all(n1 + l <= 1 + j * (j + 1) // 2 for (l, n1) in truth)
+
+
 def test_many_chains_through_run_many():
     d, C = 16, 24
     prec = synth.dense_gaussian_precision(d, seed=2)
