@@ -198,27 +198,38 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     // The uniforms of a draw are consumed in slot order (direction :233, one per merge nuts.ipp:213, top-level accept :261).  One Philox
     // evaluation per WAVE serves four consecutive slots of every chain: lane class j4 of a chain computes slot ub0 + j4, consumers shuffle.
     // (The walk of the leaves is a chain of merges -- with one evaluation per merge level it was most of a tick.)
+    // They travel as the INTEGER they are made from: u = K 2^-53 with K = 2 k + 1 odd, k the 52 random bits (det_math.hpp: u01).  The three
+    // places that consume one compare it with a ratio a / b of small integers (u < n'' / (n' + n''), nuts.ipp:212-215; u < n' / n,
+    // src/nuts.cpp:263) or with 1 / 2 (:235): u < RN(a / b) is K b < a 2^53 decided in 64-bit integers, except within one grid step of the quotient
+    // (|K b - a 2^53| < b), where the rounding of the fp64 division decides and is asked.  Exactly the reference's decisions, without an fp64
+    // division per merge in the walk.
     uint32_t ub0 = 0x80000000u;  // first slot in the buffer; valid for slots [ub0, ub0 + 4) of the chain's CURRENT draw
-    double ubuf = 0.0;
-    auto uni = [&](bool need) __attribute__((always_inline)) -> double {      // the uniform of slot `uslot` (not advanced here)
-#ifdef MI_MEMO_NO_UBUF
-        (void)need;
-        return rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);
-#else
+    unsigned long long ubuf = 0ull;
+    auto uni = [&](bool need) __attribute__((always_inline)) -> unsigned long long {      // K of slot `uslot` (not advanced here)
         const bool stale = need && (uslot - ub0) >= 4u;
         if (__ballot(stale) != 0ull) {                   // every chain of the wave refills from its own current slot
             ub0 = uslot;
-            ubuf = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot + (uint32_t)j4);
+            const u32x4 wv = rng_block(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot + (uint32_t)j4, STREAM_UNIFORM);
+            ubuf = 2ull * ((((unsigned long long)wv.y << 32) | (unsigned long long)wv.x) >> 12) + 1ull;
         }
-        return __shfl(ubuf, (lane & 15) + 16 * (int)((uslot - ub0) & 3u));
-#endif
+        const int src = (lane & 15) + 16 * (int)((uslot - ub0) & 3u);
+        const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)ubuf, src), hi = (uint32_t)__shfl((int)(uint32_t)(ubuf >> 32), src);
+        return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+    };
+    // u < RN(a / b) for u = K 2^-53 and integers a, b < 2^11 (b = 0: a / b is NaN, the comparison false)
+    auto u_below = [&](unsigned long long K, uint32_t a, uint32_t b) __attribute__((always_inline)) -> bool {
+        const unsigned long long lhs = K * (unsigned long long)b, rhs = (unsigned long long)a << 53;
+        bool r = lhs < rhs;
+        const unsigned long long diff = r ? rhs - lhs : lhs - rhs;
+        if (diff < (unsigned long long)b) r = ((double)K * 0x1p-53) < ((double)a / (double)b);
+        return r;
     };
     // start doubling jd (direction draw, nuts.cpp:233-235) for lanes with `p`
     auto begin_doubling = [&](bool p) __attribute__((always_inline)) {
-        const double zdir = uni(p);
+        const unsigned long long zdir = uni(p);
         if (p) {
             uslot++;
-            vdir = (zdir <= 0.5) ? -1 : 1;
+            vdir = (zdir <= (1ull << 52)) ? -1 : 1;       // u <= 0.5
             esg_() = (double)vdir * eps_();
             H0_() = prev_U_() + prev_K_();
             li = 0; npts = 0;
@@ -581,13 +592,12 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 if (__ballot(walking) == 0ull) break;
                 const bool mrg = walking && bit;
                 if (__ballot(mrg) == 0ull) continue;
-                const double z = uni(mrg);                                   // :213
+                const unsigned long long z = uni(mrg);                       // :213
                 if (mrg) {
                     uslot++;
                     const uint32_t pk = (uint32_t)lp_((int)l);
                     const uint32_t p_n = pk & 0x7ffu, p_na = (pk >> 11) & 0x7ffu, p_ref = pk >> 22;
-                    const double prob = (double)cn_i / (double)(p_n + cn_i);     // :212
-                    if (!(z < prob)) cref = p_ref;                               // keep new_draw_p (:215-217; 0 / 0 = NaN keeps)
+                    if (!u_below(z, cn_i, p_n + cn_i)) cref = p_ref;             // :212, :215-217: keep new_draw_p unless u < n'' / (n' + n'') (0 / 0 = NaN keeps)
                     cn_i = p_n + cn_i;                                           // :220-222
                     ca = la_((int)l) + ca;
                     cna_i = p_na + cna_i;
@@ -618,10 +628,10 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (__ballot(at_fin) != 0ull) {
             bool take = false;
             if (__ballot(complete) != 0ull) {
-                const double z = uni(complete);                             // :261
+                const unsigned long long z = uni(complete);                 // :261
                 if (complete) {
                     uslot++;
-                    take = z < (double)cn_i / n_val_();                         // :263
+                    take = u_below(z, cn_i, (uint32_t)n_val_());                // :263 (n is a count: 1 + the n' of the doublings before)
                     if (take) { good_round = 1; pb = 1 - pb0; }                 // :264-277
                 }
             }
