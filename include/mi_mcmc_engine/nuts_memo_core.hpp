@@ -558,6 +558,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         double ca = newpt ? ca_pt : ca_keep;             // alpha of the leaf the walk starts at (a chain cut short last tick kept its own)
         double ca_nx = 0.0;
         uint32_t n_walked = 0;                           // leaves walked this tick (= the reference's leapfrogs, nuts.ipp:132)
+        uint32_t n = memo_npt(li);                       // the point of leaf li; carried: n(i + 1) = n(i) + (t + 1) - t (t + 1) / 2, t = the trailing ones of i
 #if MI_MEMO_WALK_CAP > 0
         int walk_budget = MI_MEMO_WALK_CAP;
 #endif
@@ -569,12 +570,10 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
 #if MI_MEMO_WALK_CAP > 0
             if (walk_budget-- == 0) break;
 #endif
-            const uint32_t n = memo_npt(li);
             // the next leaf's alpha, in case the chain gets that far: on record if its point exists -- this tick's own point is still in registers
-            {
-                const uint32_t nn = memo_npt(li + 1u);
-                if (wl && nn <= npts) ca_nx = (newpt && nn == mpt) ? ca_pt : scp(nn)->x;
-            }
+            const uint32_t t1 = (uint32_t)__builtin_ctz(~li);
+            const uint32_t nn = n + (t1 + 1u) - t1 * (t1 + 1u) / 2u;         // the point of leaf li + 1
+            if (wl && nn <= npts) ca_nx = (newpt && nn == mpt) ? ca_pt : scp(nn)->x;
             const unsigned long long nbit = 1ull << n;
             if (wl) {
                 cn_i = (okb_(0) & nbit) ? 1u : 0u;
@@ -613,9 +612,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 if (keep && !complete) {                 // a pending first half: scalars to LDS, the proposal by reference (its point)
                     la_((int)pend_level) = ca;
                     lp_((int)pend_level) = (unsigned long long)(cn_i | (cna_i << 11) | (cref << 22));
-                    li = li + 1u;
+                    li = li + 1u; n = nn;
                     ca = ca_nx;
-                    wl = memo_npt(li) <= npts;
+                    wl = nn <= npts;
                 } else {
                     at_fin = true; wl = false;
                 }
