@@ -153,6 +153,14 @@ def cpu_baseline(cfg_id, cfg):
     return out
 
 
+def same_kernel(label, profiled_name):
+    """Is the kernel rocprofv3 profiled (`void mi::name<args...>(params)`) the one the engine named (mi_mcmc_last_kernel: `name<args>`, possibly
+    without trailing defaulted template arguments)?  The label up to its closing bracket must be a prefix of the profiled instantiation."""
+    base = label.split("(")[0].strip()
+    base = base[:-1] if base.endswith(">") else base
+    return ("mi::" + base) in profiled_name or profiled_name.startswith(base)
+
+
 def profiled_traffic(cfg_id, key, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r<N>_c<cfg>_pmc.json, newest round first) --
     only from a profile of THIS workload (workload_key) and of THE KERNEL THAT JUST RAN (mi_mcmc_last_kernel): a figure measured on another
@@ -173,7 +181,7 @@ def profiled_traffic(cfg_id, key, kernel_name):
                 why = f"{rel}: another workload shape {j.get('workload_key')}"
                 continue
             prof_kernel = j["derived"]["kernel"]
-            if kernel_name.split("(")[0].strip() not in prof_kernel:
+            if not same_kernel(kernel_name, prof_kernel):
                 why = f"{rel} profiled {prof_kernel.split('(')[0].replace('void mi::', '')}, this run launched {kernel_name}: not quoted"
                 continue
             return j["derived"]["hbm_bytes_per_launch"], rel
@@ -195,7 +203,7 @@ def profiled_pipe_budget(cfg_id, key, kernel_name):
     for _, p in sorted(cands, reverse=True):
         try:
             j = json.load(open(p))
-            if j.get("workload_key") == list(key) and kernel_name.split("(")[0].strip() in j["derived"]["kernel"] and "pipe_budget" in j["derived"]:
+            if j.get("workload_key") == list(key) and same_kernel(kernel_name, j["derived"]["kernel"]) and "pipe_budget" in j["derived"]:
                 return dict(j["derived"]["pipe_budget"], source=os.path.relpath(p, ROOT))
         except (OSError, ValueError, KeyError):
             continue
