@@ -47,7 +47,9 @@ struct MalaParams {
     const double* ub;
     const double* m;        // [d] diagonal of precond_mat
     const double* m_sqrt;   // [d] diagonal of CHOL_LOWER(precond_mat)
-    // dense precond_mat (mala_gauss_dense_m_kernel): d*d row-major device matrices from the host
+    // dense precond_mat (mala_gauss_dense_m_kernel): d*d row-major device matrices from the host; sep_target: P is the diagonal matrix of
+    // an ISO / DIAG target, whose gradient the reference's target function takes ELEMENT-WISE (no 0 * inf from the other dimensions)
+    uint32_t sep_target;
     const double* Mfull;    // precond_mat
     const double* Lchol;    // CHOL_LOWER(precond_mat)
     const double* Sinv;     // INV(eps^2 precond_mat)
@@ -315,17 +317,40 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
     double th[NS], w[NS], mg[NS];      // current state, P theta, M grad (grad = -w)
     double tp[NS], wp[NS], mgp[NS];    // the same at the proposal
     double a[NS], b[NS];
+    // The padding dimensions (d is not a multiple of 16) have zero rows and columns in every staged matrix.  While the state is finite they stay
+    // 0; once a real dimension is +-inf a padded ROW of a product is 0 * inf = NaN, and the next dense product spreads it over every real
+    // dimension through the (zero) padded column -- the reference has no such dimensions (found by the round-5 fuzz: d = 31, a chain started at
+    // -inf, draws NaN where the oracle has +-inf).  So every product's padded entries are put back to 0.
+    auto clear_pad = [&](double (&x)[NS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) x[s] = ((uint32_t)(4 * s + j) < d) ? x[s] : 0.0;
+    };
+    // P x: the dense target's mat-vec; an ISO / DIAG target multiplies element-wise (oracle: orc_target_kernel; the user's target function of the
+    // reference does): the bits of the mat-vec over the expanded diagonal while everything is finite, and +-inf stays in its own dimension
+    auto p_times = [&](const double (&x)[NS], double (&out)[NS]) __attribute__((always_inline)) {
+        if (prm.sep_target) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const uint32_t dim = 4 * s + j;
+                out[s] = (dim < d) ? prm.P[(size_t)dim * (d + 1)] * x[s] : 0.0;
+            }
+        } else {
+            matvec_mfma<NT>(afrag, x, out);
+            clear_pad(out);
+        }
+    };
     auto m_times_grad = [&](const double (&ww)[NS], double (&out)[NS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = -ww[s];
         matvec_m2<NT>(afrag_m, a, out);                // precond_matrix * grad_obj (mala.cpp:123)
+        clear_pad(out);
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const uint32_t dim = 4 * s + j;
         th[s] = (dim < d) ? prm.theta[(size_t)(4 * s) * C + lane_off] : 0.0;
     }
-    matvec_mfma<NT>(afrag, th, w);
+    p_times(th, w);
     m_times_grad(w, mg);
     double prev_LP = -0.5 * dot4<NS>(th, w);            // mala.cpp:138
     uint64_t n_acc = 0;
@@ -342,20 +367,26 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_gauss_dense_m_kern
             __builtin_amdgcn_sched_barrier(0);
         }
         matvec_m2<NT>(afrag_l, a, b);                  // sqrt_precond_matrix * rand_vec (:159)
+        clear_pad(b);
 #pragma unroll
         for (int s = 0; s < NS; ++s) tp[s] = (th[s] + (s2 * mg[s]) / 2.0) + eps * b[s];   // :123, :159
-        matvec_mfma<NT>(afrag, tp, wp);
+        clear_pad(tp);                                 // (s2 = inf: inf * 0 in the padding)
+        p_times(tp, wp);
         double prop_LP = -0.5 * dot4<NS>(tp, wp);        // :162
         if (!is_finite(prop_LP)) prop_LP = -INF;         // :164-166
         m_times_grad(wp, mgp);
         // mala_prop_adjustment (mala.ipp:60-64): dmvnorm(prev | mu(prop), Sigma) - dmvnorm(prop | mu(prev), Sigma)
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = th[s] - (tp[s] + (s2 * mgp[s]) / 2.0);       // X - mu (dmvnorm.hpp:37)
+        clear_pad(a);
         matvec_m2<NT>(afrag_si, a, b);
+        clear_pad(b);
         const double quad_a = dot4<NS>(a, b);            // :39
 #pragma unroll
         for (int s = 0; s < NS; ++s) a[s] = tp[s] - (th[s] + (s2 * mg[s]) / 2.0);
+        clear_pad(a);
         matvec_m2<NT>(afrag_si, a, b);
+        clear_pad(b);
         const double quad_b = dot4<NS>(a, b);
         const double da = prm.cons_term - 0.5 * (prm.log_det + quad_a);   // :41
         const double db = prm.cons_term - 0.5 * (prm.log_det + quad_b);

@@ -1784,7 +1784,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     // (INV(eps^2 J(theta') M) per draw, mala.ipp:52-53) runs there entirely
     const bool mala_bounded = settings->vals_bound != 0;
     const bool literal_only = gt.active && gt.dense && mala_bounded;
-    const bool dense_unbounded = gt.active && gt.dense && !mala_bounded;   // real dense products: nothing to replay
+    const bool dense_unbounded = gt.active && gt.dense && !mala_bounded;   // real dense products (sep_target: element-wise where the reference is): nothing to replay
     WsLease lws;
     ReplayWs rp = replay_layout(0, chains->n_chains, (uint32_t)d, 0, mala_bounded);
     mi::lit::LitParams lp{};
@@ -1820,6 +1820,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         rc = upload_matrix(std::vector<double>(settings->precond_mat, settings->precond_mat + d * d), d, m_full); if (rc) return rc;
         rc = upload_matrix(Sinv, d, sinv_full); if (rc) return rc;
         prm.Mfull = m_full.as<double>(); prm.Lchol = gt.l_full.as<double>(); prm.Sinv = sinv_full.as<double>();
+        prm.sep_target = target->kind != MI_TARGET_GAUSS_DENSE;     // ISO / DIAG: the gradient is element-wise in the reference's target function
         rc = launched("mala", mi::launch_mala_gauss(prm, nt, 2, st));
         if (!rc) HIP_TRY(hipStreamSynchronize(st));     // the matrices are ours
     }

@@ -43,3 +43,11 @@ def test_per_chain_mass_sweep_is_bit_exact():
     non-finite starts (elementwise and literal kernels)"""
     import fuzz_parity
     assert fuzz_parity.sweep_mass(16, 3, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [5])
+def test_general_variants_with_chains_started_non_finite(seed):
+    """bounds / diagonal / dense precond_mat x dense / diag / iso targets x dimensions that do not fill their tiles x chains that start at
+    +-inf / NaN / 1e300 (tests/fuzz_nonfinite_general.py; round 5: caught mala_gauss_dense_m_kernel on ISO / DIAG targets)"""
+    import fuzz_nonfinite_general
+    assert fuzz_nonfinite_general.sweep(120, seed, verbose=False) == 0

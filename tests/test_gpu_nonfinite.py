@@ -149,6 +149,32 @@ def test_bounded_mala_with_a_dense_preconditioner_runs_on_the_literal_kernel(d, 
     _same(g_draws, g, o_draws, o)
 
 
+@pytest.mark.parametrize("kind,d", [("diag", 31), ("iso", 47), ("dense", 31), ("dense", 100)])
+def test_unbounded_mala_with_a_dense_preconditioner_and_chains_started_non_finite(kind, d):
+    """mala_gauss_dense_m_kernel has no replay -- its products ARE the reference's dense products --, so two things have to be literal: an ISO /
+    DIAG target's gradient is element-wise (the reference's target function: +-inf stays in its own dimension; the mat-vec over the expanded
+    diagonal made every other dimension NaN), and the padding dimensions of a d that does not fill its tiles stay 0 (0 * inf there fed NaN
+    back through the next product).  Found by the round-5 random sweep (fuzz_parity seed 4242: diag, d = 31, a chain started at -inf)."""
+    C = 20
+    prec, kg, ko = {"dense": (synth.dense_gaussian_precision(d, seed=3), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE),
+                    "diag": (synth.ill_conditioned_diag(d, 20.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG),
+                    "iso": (None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)}[kind]
+    rng = np.random.default_rng(d)
+    init = synth.initial_states(C, d, seed=4)
+    init[3, 6] = -np.inf; init[8, d - 1] = np.inf; init[11, 0] = np.nan; init[15, 2] = 1e300
+    A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + np.diag(rng.uniform(0.3, 3.0, d))
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=0, n_keep_draws=4, step_size=0.25, precond_mat=M)
+    g_draws, g = mcmc_amd.mala(kg, init, st, prec=prec)
+    assert mcmc_amd.last_kernel().startswith("mala_gauss_dense_m_kernel")
+    s = orc.make_settings(seed=5, n_burnin=0, n_keep=4, step=0.25, W=4, hoist=1, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, orc.TargetSpec(ko, d, prec=prec, W=4), init, s)
+    if kind != "dense":
+        assert np.isinf(o_draws[:, :, 3]).any() and np.isinf(o_draws[:, :, 8]).any(), "the case is meant to keep +-inf in single dimensions"
+    assert np.isnan(o_draws[:, :, 11]).all() and np.isfinite(o_draws[:, :, 15]).all()
+    assert np.isfinite(o_draws[:, :, 0]).all() and 0 < o["n_accept"].sum() < 4 * C, "... next to healthy chains that accept and reject"
+    _same(g_draws, g, o_draws, o)
+
+
 @pytest.mark.parametrize("algo", ["mala", "hmc"])
 @pytest.mark.parametrize("d,N", [(70, 33), (300, 40)])
 def test_logistic_chain_driven_non_finite(algo, d, N):
