@@ -104,10 +104,15 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
 #define MI_LOGIT_NUTS_W1 2
 #endif
 template <int NTQ, int ALGO> constexpr int logit_waves_per_simd() { return (ALGO == LOGIT_NUTS && NTQ == 1) ? MI_LOGIT_NUTS_W1 : 2; }
-template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false>
+// DENSEM (hmc, no bounds): a DENSE precond_mat (hmc.cpp:57-59: inv_precond_matrix = INV(M), sqrt_precond_matrix = CHOL_LOWER(M), both from the
+// host).  `sqrt_precond_matrix * rand_vec` (:158) and `inv_precond_matrix * new_mntm` (:160,171,184) are streamed through LDS block by block
+// like P of the dense Gaussian -- their transposed block images follow the target's in the same double buffer, every evaluation and product
+// prefetching block 0 of the matrix that comes next --, each element one fma chain over the columns in ascending order (the oracle's orc_gemv).
+template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false, bool DENSEM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO>())) void logit_lds_kernel(const LogitParams prm)
 {
     static_assert(!BOUNDS || (DIAGM && (ALGO == LOGIT_HMC || ALGO == LOGIT_NUTS)), "bounds: hmc and nuts, with the mass tables");
+    static_assert(!DENSEM || (ALGO == LOGIT_HMC && !DIAGM && !BOUNDS), "a dense precond_mat: hmc without bounds");
     using G = LogitGeo<NTQ>;
     constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
     extern __shared__ double smem[];
@@ -170,7 +175,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
     // before every ds_write otherwise); wait_loads() + a barrier is the explicit completion point.
     const uint32_t xs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)Xs;
     auto issue_block = [&](uint32_t b, int buf) __attribute__((always_inline)) {
-        const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + lane * 2;
+        const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + lane * 2;       // (the target's images: the first block of a launch, and the timing experiments)
         const uint32_t dst = xs_lds + (uint32_t)buf * (uint32_t)(G::XBUF_PAD * sizeof(double));
 #pragma unroll
         for (int c0 = 0; c0 < G::CHUNKS; c0 += 8) {
@@ -186,18 +191,23 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
     // queued pieces (measured ~320 cycles per piece when a wave issues its 9 pieces back to back), so inside the block
     // loop the pieces are issued one at a time, spread over the three phases
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto issue_piece = [&](uint32_t b, int buf, int i) __attribute__((always_inline)) {
+    auto issue_piece_of = [&](const double* img, uint32_t b, int buf, int i) __attribute__((always_inline)) {
         const int c = i * 8 + w;
         if (c < G::CHUNKS) {
             // wave-uniform source (SGPR pair) + the lane's 16 bytes as a 32-bit offset: with a 64-bit address per lane the compiler
             // kept one VGPR pair per piece as a loop invariant, spilled them, and reloaded three inside the block loop (a scratch
             // reload waits behind the pieces in flight: vmcnt is in order)
-            const double* src = prm.Xp + (size_t)b * G::XBUF_PAD + (size_t)c * 128;
+            const double* src = img + (size_t)b * G::XBUF_PAD + (size_t)c * 128;
             const uint32_t dst = xs_lds + (uint32_t)buf * (uint32_t)(G::XBUF_PAD * sizeof(double)) + (uint32_t)c * 1024u;
             uint32_t m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                          : "=&s"(m0_saved) : "v"(lane16), "s"(dst), "s"(src) : "memory");
         }
+    };
+    // DENSEM: the images of the matrix whose product FOLLOWS the running one (its block 0 is the wrap-around prefetch of the last block)
+    const double* next_img = prm.Xp;
+    auto img_of_next = [&](const double* img, bool last) __attribute__((always_inline)) -> const double* {
+        if constexpr (DENSEM) return last ? next_img : img; else return prm.Xp;
     };
     // schedule of the NP pieces a wave issues per block: NP_E behind every other eta MFMA group, one at the head of the
     // row-term phase, the rest behind every other gradient tile
@@ -249,6 +259,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
             const bool prefetch = !(ablate & 8u);
             const uint32_t nblk = (b + 1 < NB) ? b + 1 : 0u;
             const int nbuf = (int)((xbuf0 + b + 1) & 1u);
+            const double* const nimg = img_of_next(prm.Xp, b + 1 >= NB);
+            auto issue_piece = [&](uint32_t bb, int buf, int i) __attribute__((always_inline)) { issue_piece_of(nimg, bb, buf, i); };
             if (prefetch && (ablate & 4096u)) issue_block(nblk, nbuf);
             // eta tile of this wave's dims as TWO fma chains (slices [0, NSQ/2) and [NSQ/2, NSQ)), summed at the end: a
             // single chain of NSQ dependent MFMAs runs the matrix pipe at half rate (measured 155 cycles per MFMA).
@@ -400,8 +412,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
     // columns in ascending order (what gauss_dense_grad of hmc_dense.hpp and the oracle's orc_gemv do).  x travels between the four
     // waves of a tile through xexch (64 KiB per tile at d = 512: LDS is full of P), written once per evaluation; one barrier per
     // block (the double buffer), none for an eta phase or an exchange of partial sums.  lp = -1/2 x.w, gout = -w.
-    auto evaluate_dense = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
-        double4_t gacc[NTQ];
+    // gacc = A x for the matrix whose TRANSPOSED block images are img[0 .. nb) (P of the dense target; DENSEM: INV / CHOL_LOWER of precond_mat)
+    auto stream_product = [&](const double* img, uint32_t nb, const double (&x)[NSQ], double4_t (&gacc)[NTQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) gacc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
         const uint32_t xbuf0 = xbuf_parity();
@@ -422,11 +434,13 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
         for (int sp = 0; sp < 4; ++sp) r_cur[sp] = *xq_at((uint32_t)sp);
         constexpr bool prefetch = !(ablate & 8u);
 #pragma unroll 1
-        for (uint32_t b = 0; b < NB; ++b) {
+        for (uint32_t b = 0; b < nb; ++b) {
             const double* xb = Xs + ((xbuf0 + b) & 1u) * G::XBUF_PAD;
-            const uint32_t nblk = (b + 1 < NB) ? b + 1 : 0u;
+            const uint32_t nblk = (b + 1 < nb) ? b + 1 : 0u;
             const int nbuf = (int)((xbuf0 + b + 1) & 1u);
-            const uint32_t bn = (b + 1 < NB) ? b + 1 : b;
+            const uint32_t bn = (b + 1 < nb) ? b + 1 : b;
+            const double* const nimg = img_of_next(img, b + 1 >= nb);
+            auto issue_piece = [&](uint32_t bb, int buf, int i) __attribute__((always_inline)) { issue_piece_of(nimg, bb, buf, i); };
 #pragma unroll
             for (int sp = 0; sp < 4; ++sp) r_nxt[sp] = *xq_at(4u * bn + (uint32_t)sp);
             const double* xg = xb + grad_off;
@@ -476,7 +490,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
             for (int sp = 0; sp < 4; ++sp) r_cur[sp] = r_nxt[sp];
             blk_sync();                             // ... everybody's, and buffer b&1 is free for block b+2
         }
-        xbuf_next = (xbuf0 + NB) & 1u;
+        xbuf_next = (xbuf0 + nb) & 1u;
+    };
+    auto evaluate_dense = [&](const double (&x)[NSQ], double (&gout)[NSQ], double& lp) __attribute__((always_inline)) {
+        double4_t gacc[NTQ];
+        stream_product(prm.Xp, NB, x, gacc);
         double v[2];
         {
             double a = 0.0;
@@ -529,6 +547,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
         return;
     }
     double first_lp;
+    if constexpr (DENSEM) next_img = prm.Lp;             // the first draw's L z follows
     evaluate_at(bp, gp, first_lp);      // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
     if constexpr (BOUNDS) first_lp = first_lp + box.log_jacobian(bp, lj_rel, [&]() { __syncthreads(); });      // hmc.cpp:84-95
 #pragma unroll
@@ -740,13 +759,21 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
         const uint32_t n_leap = prm.n_leap;
         double pm[NSQ];
         double prev_U = -first_lp;                       // hmc.cpp:140
-        auto kinetic = [&]() __attribute__((always_inline)) -> double {   // p.p / 2, block order (:160,184)
+        const uint32_t NBM = (d + 15u) / 16u;            // DENSEM: blocks of the d x d matrices
+        auto kinetic = [&]() __attribute__((always_inline)) -> double {   // p.(Minv p) / 2, block order (:160,184)
             double v[2];
             double a = 0.0;
+            if constexpr (DENSEM) {
+                double4_t mp[NTQ];
+                stream_product(prm.Mip, NBM, pm, mp);      // inv_precond_matrix * mntm
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) a = dfma(pm[s], mp[s >> 2][s & 3], a);
+            } else {
 #pragma unroll
             for (int s = 0; s < NSQ; ++s) {
                 if constexpr (DIAGM) a = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], a);
                 else a = dfma(pm[s], pm[s], a);
+            }
             }
             a = a + __shfl_xor(a, 32);
             a = a + __shfl_xor(a, 16);
@@ -769,18 +796,44 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (DENSEM) {                       // p = CHOL_LOWER(M) z (:158); then Minv p for prev_K
+                double4_t lz[NTQ];
+                next_img = prm.Mip;
+                stream_product(prm.Lp, NBM, pm, lz);
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) pm[s] = lz[s >> 2][s & 3];
+            }
+            double prev_K;
+            if constexpr (DENSEM) {                       // (the product first: three vectors live across it, not five)
+                next_img = prm.Mip;                       // the first step's product (n_leap = 0: prop_K's) follows
+                prev_K = kinetic();
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) { bp[s] = *st(0, s); gp[s] = *st(1, s); }
+            } else {
 #pragma unroll
             for (int s = 0; s < NSQ; ++s) { bp[s] = *st(0, s); gp[s] = *st(1, s); }   // new_draw = prev_draw (:162)
-            const double prev_K = kinetic();
+            prev_K = kinetic();
+            }
             double lp = -prev_U;
 #pragma unroll 1
             for (uint32_t k = 0; k < n_leap; ++k) {      // :164-176
+                if constexpr (DENSEM) {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) pm[s] = pm[s] + (eps * gp[s]) / 2.0;     // first half-step (:126)
+                    double4_t mp[NTQ];
+                    next_img = prm.Xp;
+                    stream_product(prm.Mip, NBM, pm, mp);
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) bp[s] = bp[s] + eps * mp[s >> 2][s & 3];   // (:171) theta += eps (Minv p)
+                    next_img = prm.Mip;                   // behind the evaluation: the next step's product, or prop_K's
+                } else {
 #pragma unroll
                 for (int s = 0; s < NSQ; ++s) {
                     if constexpr (BOUNDS) pm[s] = pm[s] + (eps * box.jgrad(bp[s], gp[s], s)) / 2.0;     // (:122,126) with the inverse Jacobian
                     else pm[s] = pm[s] + (eps * gp[s]) / 2.0; // first half-step (:126)
                     if constexpr (DIAGM) bp[s] = bp[s] + eps * (mass_at(prm.m_inv, s) * pm[s]);   // (:171) theta += eps Minv p
                     else bp[s] = bp[s] + eps * pm[s];    // (:171)
+                }
                 }
                 evaluate_at(bp, gp, lp);
 #pragma unroll
@@ -789,7 +842,16 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
                     else pm[s] = pm[s] + (eps * gp[s]) / 2.0;     // second half-step (:175)
                 }
             }
+            if constexpr (DENSEM) {                       // the end point's gradient waits in the wave's third workspace vector
+                next_img = prm.Lp;                        // the next draw starts with L z
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) *st(2, s) = gp[s];
+            }
             const double prop_K = kinetic();
+            if constexpr (DENSEM) {
+#pragma unroll
+                for (int s = 0; s < NSQ; ++s) gp[s] = *st(2, s);
+            }
             // BOUNDS: box_log_kernel adds log_jacobian(theta) (:84-95) -- only the end point's value is used (n_leap = 0: prev_U, exactly)
             if constexpr (BOUNDS) { const double lj = box.log_jacobian(bp, lj_rel, [&]() { __syncthreads(); }); if (n_leap != 0u) lp = lp + lj; }
             double prop_U = -lp;                         // :178 (n_leap = 0: the value at the unchanged position)

@@ -436,8 +436,14 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         if (rcw) return rcw;
         prm.nf_flag = rp.flag;
     }
-    const int e = mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st, lds_target);
+    // hmc with a DENSE precond_mat (prm.Minv_rm / L_rm from the caller): the block images of INV(M) and CHOL_LOWER(M) live in a buffer of their own
+    const bool dense_m = prm.Minv_rm != nullptr;
+    DevBuf mws;
+    if (dense_m) HIP_TRY(mws.alloc(mi::logit_lds_dense_m_bytes(prm.d, prm.C, lds_target)));
+    const int e = dense_m ? mi::logit_lds_launch_hmc_dense_m(prm, X_dev, y_dev, base.p, mws.p, st, lds_target)
+                          : mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st, lds_target);
     if (e != 0) return fail(MI_ERR_HIP, "LDS-streamed kernel launch: %s", hipGetErrorString((hipError_t)e));
+    LitDev ldev;
     if (replay) {                                       // chains that reached the non-finite regime: replayed literally (literal.hpp)
         mi::lit::LitParams lp{};
         rcw = transpose_on_device(X_dev, rp.tbuf, prm.n_rows, prm.d, st);      // eta = X beta resp. P x read the matrix transposed (literal.hpp)
@@ -451,12 +457,20 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, dev_chains, rp, false);
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
-        if (lds_tables_active(lt)) lds_tables_replay(*lt, prm, lp);      // hmc: bounds and / or a diagonal precond_mat
+        if (dense_m) {                                   // the replay's own copies (transposed: literal_host.hpp)
+            mi::lit::LitPrep prep;
+            mi::lit::lit_prepare(0, prm.d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+            rcw = lit_upload(prep, prm.d, false, ldev, lp);
+            if (rcw) return rcw;
+        }
+        else if (lds_tables_active(lt)) lds_tables_replay(*lt, prm, lp);      // hmc: bounds and / or a diagonal precond_mat
         else if (prm.m_sqrt != nullptr) {                // a diagonal precond_mat (mala: m, m_sqrt, s_inv)
             lp.precond = 1; lp.m = prm.m; lp.m_sqrt = prm.m_sqrt; lp.m_inv = prm.m_inv; lp.sinv_diag = prm.s_inv;
         }
-        return launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
+        rcw = launched("LDS-streamed kernel (literal replay)", mi::launch_literal(algo == mi::LOGIT_MALA ? 1 : 0, lp, rp.n_wg, st));
+        if (rcw) return rcw;
     }
+    if (dense_m) HIP_TRY(hipStreamSynchronize(st));      // the images and the replay's matrices are ours
     return MI_OK;
 }
 
@@ -771,6 +785,25 @@ int lds_tables(const char* who, const mi_settings* settings, uint64_t d, LdsTabl
     }
     return MI_OK;
 }
+// hmc with a DENSE precond_mat on the LDS-streamed kernel (logistic_lds.hpp: DENSEM): INV(M) and CHOL_LOWER(M) from the host (hmc.cpp:57-59
+// through the oracle's Gauss-Jordan / column Cholesky, as everywhere), row-major on the device
+struct LdsDenseM { DevBuf minv, l; };
+int lds_dense_m(const mi_settings* settings, uint64_t d, LdsDenseM& t, mi::LogitParams& q)
+{
+    std::vector<double> Minv, L;
+    host_inverse(settings->precond_mat, d, Minv);
+    host_cholesky_lower(settings->precond_mat, d, L);
+    HIP_TRY(t.minv.alloc(d * d * 8)); HIP_TRY(t.l.alloc(d * d * 8));
+    HIP_TRY(hipMemcpy(t.minv.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.l.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
+    q.Minv_rm = t.minv.as<double>(); q.L_rm = t.l.as<double>();
+    return MI_OK;
+}
+// ... which the hmc front end routes there when this holds (bounds with a dense matrix stay on literal.hpp)
+bool lds_dense_m_ok(const mi_target* target, const mi_settings* settings)
+{
+    return target->kernel_hint != MI_KERNEL_LITERAL && settings->precond_mat && !settings->vals_bound && !precond_is_diagonal(settings, target->d);
+}
 // the same tables for the literal replay behind such a launch (precond 1: M, sqrt(M), 1 / M element by element; literal_host.hpp)
 void lds_tables_replay(const LdsTables& t, const mi::LogitParams& q, mi::lit::LitParams& lp)
 {
@@ -815,7 +848,9 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.eps = settings->step_size;
     q.draw0 = (uint32_t)chains->draw0;
     LdsTables lt;
-    if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
+    LdsDenseM ldm;
+    if (algo == mi::LOGIT_HMC && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q))) return rc; }      // a dense precond_mat, unbounded
+    else if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
     rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev, mi::LOGIT_TARGET_LOGISTIC, &lt);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
@@ -861,8 +896,10 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
         q.cons_term = -0.5 * (double)d * 1.83787706640934548356;
     }
     LdsTables lt;
+    LdsDenseM ldm;
     MalaDiagMass mdm;
-    if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
+    if (algo == mi::LOGIT_HMC && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q))) return rc; }      // a dense precond_mat, unbounded
+    else if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
     if (algo == mi::LOGIT_MALA && settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }
     rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE, &lt);
     if (rc) return rc;
@@ -1238,7 +1275,9 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
         // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation: two tables read from global memory)
         // ... and so do bounds (its BOUNDS instantiation, lds_box.hpp), with the identity or a diagonal matrix
-        const bool lds_general = (settings->vals_bound || settings->precond_mat) && lds_general_ok(target, settings) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+        // ... and, round 5, a DENSE precond_mat without bounds (DENSEM: INV(M) and CHOL_LOWER(M) streamed through LDS like X)
+        const bool lds_general = (settings->vals_bound || settings->precond_mat) && (lds_general_ok(target, settings) || lds_dense_m_ok(target, settings))
+                                 && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
         if ((settings->vals_bound || settings->precond_mat) && !lds_general)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("hmc", 0, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
         return d <= 512 ? run_logit_plain("hmc", mi::LOGIT_HMC, target, settings, chains, st) : run_literal("hmc", 0, target, settings, chains, st);
@@ -1263,8 +1302,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     }
     // beyond d = 128 the tiled kernels serve separable targets without bounds (identity or diagonal precond_mat: hmc_diag.hpp);
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
-    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && (!settings->precond_mat || !dense_m) && target->kernel_hint != MI_KERNEL_LITERAL)
-        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat, with or without bounds
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !(dense_m && settings->vals_bound) && target->kernel_hint != MI_KERNEL_LITERAL)
+        return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat, with or without bounds; a dense one without
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant

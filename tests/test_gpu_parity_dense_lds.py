@@ -133,3 +133,66 @@ def test_mala_with_a_diagonal_precond_mat_on_the_streamed_kernels(target, d):
     o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s)
     assert o["n_accept"].sum() > 0
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+# ---- hmc with a DENSE precond_mat on the LDS-streamed kernels (round 5; their DENSEM instantiation; ref: src/hmc.cpp:57-59 -- inv_precond_matrix =
+# INV(M), sqrt_precond_matrix = CHOL_LOWER(M) --, :158 L z, :160,184 p.(Minv p) / 2, :171 theta += eps (Minv p)): both matrices streamed through
+# LDS like P, every product the oracle's ascending fma chain; no bounds (with them: literal.hpp)
+def _dense_m(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    return A @ A.T + np.diag(rng.uniform(0.4, 2.5, d))
+
+
+@pytest.mark.parametrize("d", [129, 160, 192, 200, 256, 300, 384, 512])
+def test_dense_gaussian_hmc_with_a_dense_precond_mat(d):
+    C = 45                                              # one full workgroup of 32 chains + a ragged one
+    prec = synth.dense_gaussian_precision(d, seed=d % 89)
+    M = _dense_m(d, d)
+    init = synth.initial_states(C, d, seed=d + 1) * 0.5
+    init[5] *= 1e200; init[9, 3] = np.inf                 # two chains leave the finite regime: replayed literally with the same matrices
+    for L in (3, 0):                                    # (n_leap_steps = 0: the two kinetic products back to back)
+        st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=L, step_size=0.3, precond_mat=M)
+        g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=11)
+        kern = mcmc_amd.last_kernel()
+        assert kern.startswith("logit_lds_kernel<") and kern.endswith("1, false, false, true>"), kern
+        s = orc.make_settings(seed=3, n_burnin=2, n_keep=4, n_leap=L, step=0.3, W=4, hoist=1, precond=M, **_blk(d))
+        o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)), init, s, chain0=11)
+        assert L == 0 or 0 < o["n_accept"].sum() < 4 * C
+        assert np.array_equal(g["n_accept"], o["n_accept"]), L
+        assert np.array_equal(g_draws, o_draws, equal_nan=True), L
+        assert np.array_equal(g["n_leap"], o["n_leap"]), L
+
+
+@pytest.mark.parametrize("d,N", [(9, 20), (40, 33), (100, 64), (130, 64), (300, 50), (512, 100)])
+def test_logistic_hmc_with_a_dense_precond_mat(d, N):
+    C = 40
+    X, y = synth.logistic_problem(d, N, seed=5)
+    M = _dense_m(d, d + 7)
+    init = synth.initial_states(C, d, seed=8) * 0.3
+    init[5] *= 1e200; init[9, 3] = np.inf
+    bs = 16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128
+    st = mcmc_amd.default_settings(rng_seed_value=12, n_burnin_draws=2, n_keep_draws=4, n_leap_steps=3, step_size=0.1, precond_mat=M)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.endswith("0, false, false, true>"), kern
+    t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=bs, eta_chains=2)
+    s = orc.make_settings(seed=12, n_burnin=2, n_keep=4, n_leap=3, step=0.1, W=4, hoist=1, precond=M, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, t, init, s)
+    assert 0 < o["n_accept"].sum() <= 4 * C
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+def test_dense_precond_mat_with_bounds_stays_on_the_literal_kernel():
+    d, C = 160, 6
+    prec = synth.dense_gaussian_precision(d, seed=3)
+    M = _dense_m(d, 1)
+    lb = np.full(d, -np.inf); ub = np.full(d, np.inf); lb[::3] = -1.5; ub[::5] = 2.0
+    init = np.clip(synth.initial_states(C, d, seed=4) * 0.5, -1.0, 1.5)
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=1, n_keep_draws=3, n_leap_steps=3, step_size=0.04, precond_mat=M,
+                                   vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+    g_draws, g = mcmc_amd.hmc(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    assert mcmc_amd.last_kernel().startswith("literal_kernel<0>"), mcmc_amd.last_kernel()
+    s = orc.make_settings(seed=5, n_burnin=1, n_keep=3, n_leap=3, step=0.04, W=4, hoist=1, precond=M, lower=lb, upper=ub, **_blk(d))
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)), init, s)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
