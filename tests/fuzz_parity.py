@@ -55,7 +55,9 @@ def sweep(n_cases=60, seed=1, verbose=True):
                 init = np.clip(init, -1.0, 1.5)
             if rng.random() < 0.6 or not kw:
                 M = np.diag(rng.uniform(0.3, 3.0, d))
-                if (algo != "mala" or "vals_bound" not in kw) and d <= 64 and rng.random() < 0.4:   # dense precond / cov (d <= 64; mala: unbounded)
+                # dense precond / cov (d <= 64; mala: unbounded; hmc without bounds: any d -- beyond d = 128 and on the logistic target the
+                # LDS-streamed kernel streams INV(M) and CHOL_LOWER(M) too, logistic_lds.hpp DENSEM)
+                if (algo != "mala" or "vals_bound" not in kw) and (d <= 64 or (algo == "hmc" and "vals_bound" not in kw)) and rng.random() < 0.4:
                     A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
                 kw.update(precond_mat=M); okw.update(precond=M)
         tkw = {}
