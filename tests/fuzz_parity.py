@@ -91,6 +91,50 @@ def sweep(n_cases=60, seed=1, verbose=True):
     return fails
 
 
+def sweep_dense_m(n_cases=40, seed=1, verbose=True):
+    """hmc with a DENSE precond_mat on the LDS-streamed kernels (logistic_lds.hpp DENSEM, round 5): dense Gaussians with 128 < d <= 512 and the
+    logistic target with 8 < d <= 512 -- every instantiation, ragged workgroups, 0..5 leapfrog steps, step sizes up to the non-finite regime
+    and non-finite starts (flagged, replayed literally with the same matrices), continuation offsets.  Returns the number of mismatches."""
+    rng = np.random.default_rng(seed)
+    fails = 0
+    say = print if verbose else (lambda *a, **k: None)
+    for case in range(n_cases):
+        tgt = "dense" if case % 2 == 0 else "logit"
+        d = int(rng.choice([129, 144, 192, 193, 250, 256, 257, 384, 385, 512])) if tgt == "dense" else int(rng.choice([9, 16, 17, 64, 65, 128, 129, 256, 300, 512]))
+        C = int(rng.choice([1, 3, 16, 17, 33, 70]))
+        if d > 256: C = min(C, 17)                       # (the oracle inverts M once per chain)
+        rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))
+        burn, keep, L = int(rng.integers(0, 3)), int(rng.integers(1, 5)), int(rng.integers(0, 6))
+        eps = float(rng.choice([0.01, 0.05, 0.2, 0.5]))
+        A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + np.diag(rng.uniform(0.3, 3.0, d))
+        init = synth.initial_states(C, d, seed=rseed % 1013) * float(rng.choice([0.1, 0.5, 1.0]))
+        if rng.random() < 0.25:
+            eps = float(rng.choice([30.0, 1.0e5, 1.0e160]))
+            if rng.random() < 0.6: init[int(rng.integers(0, C)), int(rng.integers(0, d))] = float(rng.choice([np.inf, -np.inf, np.nan, 1e300]))
+        prec = X = y = None
+        if tgt == "dense":
+            prec, kg, ko = synth.dense_gaussian_precision(d, seed=rseed % 97), mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
+            blk = dict(blocks=4, block_size=48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128); tkw = dict(blk)
+        else:
+            N = int(rng.choice([1, 15, 16, 17, 40, 100])); X, y = synth.logistic_problem(d, N, seed=rseed % 89); kg, ko = mcmc_amd.TARGET_LOGISTIC, orc.TARGET_LOGISTIC
+            blk = dict(blocks=4, block_size=16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128); tkw = dict(blk, eta_chains=2)
+        st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps, precond_mat=M)
+        s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, precond=M, **blk)
+        desc = f"hmc {tgt} dense precond d={d} C={C} eps={eps} L={L} burn={burn} keep={keep}"
+        g_draws, g = mcmc_amd.sample("hmc", kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
+        kern = mcmc_amd.last_kernel()
+        o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw), init, s, chain0=chain0)
+        ok = (kern.startswith("logit_lds_kernel<") and kern.endswith("false, false, true>") and np.array_equal(g_draws, o_draws, equal_nan=True)
+              and np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g["n_leap"], o["n_leap"]))
+        if not ok:
+            fails += 1
+            bad = np.argwhere(~((g_draws == o_draws) | (np.isnan(g_draws) & np.isnan(o_draws))))
+            say("MISMATCH", desc, kern, "first bad index", bad[:1].tolist())
+        else:
+            say("ok      ", desc, "nan" if np.isnan(o_draws).any() else "")
+    return fails
+
+
 def sweep_small(n_cases=60, seed=1, verbose=True):
     """The one-lane-per-chain engine (hmc / mala / rwmh / rmhmc / nuts on the d = 2 normal model): random observations, bounds of every
     type, diagonal / dense preconditioners, degenerate sizes, step sizes that blow the chain up.  Returns the number of mismatches."""

@@ -51,3 +51,9 @@ def test_general_variants_with_chains_started_non_finite(seed):
     +-inf / NaN / 1e300 (tests/fuzz_nonfinite_general.py; round 5: caught mala_gauss_dense_m_kernel on ISO / DIAG targets)"""
     import fuzz_nonfinite_general
     assert fuzz_nonfinite_general.sweep(120, seed, verbose=False) == 0
+
+
+def test_hmc_with_a_dense_precond_mat_on_the_streamed_kernels_random_cases():
+    """logit_lds_kernel<.., DENSEM> (round 5): random sizes of both targets, 0..5 leapfrog steps, the non-finite regime"""
+    import fuzz_parity
+    assert fuzz_parity.sweep_dense_m(16, 3, verbose=False) == 0
