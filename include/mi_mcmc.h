@@ -85,8 +85,8 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_NUTS_SPLIT = 11,             /* RETIRED (round 5): the kernel that split every 16-chain tile over two waves (64 < d <= 128, few chains) is gone --
                                             * the memoised kernel is faster at every chain count.  The value stays valid and is ignored (as any hint a request
                                             * cannot honour): the default kernel runs */
-    MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat) on the logistic target (d <= 512) and on dense Gaussians
-                                            * with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
+    MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat; hmc and mala with a DENSE precond_mat) on the logistic target
+                                            * (d <= 512) and on dense Gaussians with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
     MI_KERNEL_NUTS_DYN = 13,               /* RETIRED (round 5), valid and ignored: round 4's register-carried tick with dynamic chain hand-out */
     MI_KERNEL_NUTS_MEMO = 14               /* nuts, same case: every doubling on a MEMOISED trajectory (nuts_memo.hpp) -- the 2^j leaves of a doubling visit only

@@ -41,12 +41,16 @@ struct LogitParams {
     double* adapt_state;    // [3][C] dual-averaging state (h, eps_bar, mu): out (and in, for a continuation inside the window), or nullptr
     uint32_t n_adapt, max_depth;
     double delta, eps_bar0, gamma, t0, kappa;
-    // hmc with a DENSE precond_mat (logit_lds_kernel<.., DENSEM>): INV(M) and CHOL_LOWER(M), d*d row-major on the device (in), and their
-    // transposed block images (set by the launcher)
+    // hmc / mala with a DENSE precond_mat (logit_lds_kernel<.., DENSEM>), d*d row-major on the device (in): hmc INV(M) and CHOL_LOWER(M); mala
+    // M, CHOL_LOWER(M) and INV(eps^2 M) -- and their transposed block images (set by the launcher)
     const double* Minv_rm;
     const double* L_rm;
+    const double* M_rm;
+    const double* Sinv_rm;
     const double* Mip;
     const double* Lp;
+    const double* Mp;
+    const double* Sip;
 };
 
 enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2, LOGIT_NUTS = 3 };   // RWMH: eps carries par_scale (identity cov_mat); NUTS: nuts_lds.hpp
@@ -58,10 +62,13 @@ enum { LOGIT_TARGET_LOGISTIC = 0, LOGIT_TARGET_DENSE = 1 };
 size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC, int algo = LOGIT_HMC);
 // nuts: workgroups of the persistent grid (32 chain slots each; the workspace is sized by chains = 32 * this)
 uint64_t logit_lds_nuts_workgroups(uint32_t d, uint64_t C, int target);
-// hmc with a dense precond_mat (prm.Minv_rm / L_rm set): bytes of the second workspace `mws` of logit_lds_launch_hmc_dense_m -- the block
-// images of the two matrices and, for the logistic target, the exchange vectors of the streamed products
-size_t logit_lds_dense_m_bytes(uint32_t d, uint64_t C, int target);
-int logit_lds_launch_hmc_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);
+// hmc / mala with a dense precond_mat (prm.L_rm and Minv_rm resp. M_rm / Sinv_rm set): bytes of the second workspace `mws` of
+// logit_lds_launch_dense_m -- the block images of the two resp. three matrices and, for the logistic target, the exchange vectors of the
+// streamed products
+size_t logit_lds_dense_m_bytes(uint32_t d, uint64_t C, int target, int algo);
+int logit_lds_launch_dense_m(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);
+int logit_lds_launch_hmc_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);     // logistic_hmc_dense_m.hip
+int logit_lds_launch_mala_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);    // logistic_mala_dense_m.hip
 // packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)
 int logit_lds_launch(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st,
                      int target = LOGIT_TARGET_LOGISTIC);

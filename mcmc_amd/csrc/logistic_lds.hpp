@@ -104,15 +104,17 @@ __global__ void pack_logit_lds_kernel(const double* __restrict__ X, const double
 #define MI_LOGIT_NUTS_W1 2
 #endif
 template <int NTQ, int ALGO> constexpr int logit_waves_per_simd() { return (ALGO == LOGIT_NUTS && NTQ == 1) ? MI_LOGIT_NUTS_W1 : 2; }
-// DENSEM (hmc, no bounds): a DENSE precond_mat (hmc.cpp:57-59: inv_precond_matrix = INV(M), sqrt_precond_matrix = CHOL_LOWER(M), both from the
+// DENSEM (hmc, mala; no bounds): a DENSE precond_mat (hmc.cpp:57-59: inv_precond_matrix = INV(M), sqrt_precond_matrix = CHOL_LOWER(M), both from the
 // host).  `sqrt_precond_matrix * rand_vec` (:158) and `inv_precond_matrix * new_mntm` (:160,171,184) are streamed through LDS block by block
 // like P of the dense Gaussian -- their transposed block images follow the target's in the same double buffer, every evaluation and product
 // prefetching block 0 of the matrix that comes next --, each element one fma chain over the columns in ascending order (the oracle's orc_gemv).
+// mala (mala.cpp:57-58,123,159; mala.ipp:58-64 with dmvnorm.hpp:37-41): `precond_matrix * grad`, `sqrt_precond_matrix * rand_vec` and the two
+// `INV(eps^2 M) * (X - mu)` of the proposal densities the same way; INV(eps^2 M) and its LOG_DET from the host once (Sigma is constant).
 template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false, bool DENSEM = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO>())) void logit_lds_kernel(const LogitParams prm)
 {
     static_assert(!BOUNDS || (DIAGM && (ALGO == LOGIT_HMC || ALGO == LOGIT_NUTS)), "bounds: hmc and nuts, with the mass tables");
-    static_assert(!DENSEM || (ALGO == LOGIT_HMC && !DIAGM && !BOUNDS), "a dense precond_mat: hmc without bounds");
+    static_assert(!DENSEM || ((ALGO == LOGIT_HMC || ALGO == LOGIT_MALA) && !DIAGM && !BOUNDS), "a dense precond_mat: hmc and mala without bounds");
     using G = LogitGeo<NTQ>;
     constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
     extern __shared__ double smem[];
@@ -547,7 +549,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
         return;
     }
     double first_lp;
-    if constexpr (DENSEM) next_img = prm.Lp;             // the first draw's L z follows
+    if constexpr (DENSEM) next_img = (ALGO == LOGIT_MALA) ? prm.Mp : prm.Lp;     // what follows the first evaluation: mala M grad, hmc the first draw's L z
     evaluate_at(bp, gp, first_lp);      // box_log_kernel(first_draw): mala.cpp:138 / hmc.cpp:140
     if constexpr (BOUNDS) first_lp = first_lp + box.log_jacobian(bp, lj_rel, [&]() { __syncthreads(); });      // hmc.cpp:84-95
 #pragma unroll
@@ -594,7 +596,80 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
         }
     };
 
-    if constexpr (ALGO == LOGIT_MALA) {
+    if constexpr (ALGO == LOGIT_MALA && DENSEM) {
+        // Workspace vectors of a wave: 0 the accepted beta, 2 M grad at it (what the mean needs of the gradient), 1 M grad at the proposal
+        // while the density products run.  Never more than three vectors in registers: the proposal, a product's vector and its result.
+        const uint32_t NBM = (d + 15u) / 16u;
+        const double s2 = prm.s2;
+        double prev_LP = first_lp, prop_LP;
+        double4_t acc[NTQ];
+        next_img = prm.Lp;                               // the first draw's L z follows
+        stream_product(prm.Mp, NBM, gp, acc);            // precond_matrix * grad at the initial values (mala.cpp:123)
+#pragma unroll
+        for (int s = 0; s < NSQ; ++s) *st(2, s) = acc[s >> 2][s & 3];
+        auto quad = [&]() __attribute__((always_inline)) -> double {      // (X - mu) . (INV(Sigma) (X - mu)), this wave's part (dmvnorm.hpp:39)
+            double a = 0.0;
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) a = dfma(gp[s], acc[s >> 2][s & 3], a);
+            a = a + __shfl_xor(a, 32);
+            a = a + __shfl_xor(a, 16);
+            return a;
+        };
+#pragma unroll 1
+        for (uint32_t draw = 0; draw < n_total; ++draw) {
+#pragma unroll
+            for (int m = 0; m < NSQ / 2; ++m) {          // rand_vec (:150)
+                double z0, z1;
+                const uint32_t slot = (uint32_t)(q * DQ / 2 + 4 * m + j4);
+                rng_normal_pair(prm.seed, chain, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1);
+                bp[2 * m] = (dim_of(2 * m) < d) ? z0 : 0.0;
+                bp[2 * m + 1] = (dim_of(2 * m + 1) < d) ? z1 : 0.0;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            next_img = prm.Xp;
+            stream_product(prm.Lp, NBM, bp, acc);        // sqrt_precond_matrix * rand_vec (:159)
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) bp[s] = (*st(0, s) + (s2 * *st(2, s)) / 2.0) + eps * acc[s >> 2][s & 3];     // :123, :159
+            next_img = prm.Mp;
+            evaluate(bp, gp, prop_LP);                   // :162
+            next_img = prm.Sip;
+            stream_product(prm.Mp, NBM, gp, acc);        // precond_matrix * grad at the proposal
+            // mala_prop_adjustment (mala.ipp:59-64): dmvnorm(prev | mean(prop), Sigma) - dmvnorm(prop | mean(prev), Sigma); the gradient's registers
+            // carry X - mu (dmvnorm.hpp:37)
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) {
+                const double mgp = acc[s >> 2][s & 3];
+                *st(1, s) = mgp;
+                gp[s] = *st(0, s) - (bp[s] + (s2 * mgp) / 2.0);
+            }
+            stream_product(prm.Sip, NBM, gp, acc);       // (the second density's product follows: next_img is Sip already)
+            double qv[2];
+            qv[0] = quad();
+#pragma unroll
+            for (int s = 0; s < NSQ; ++s) gp[s] = bp[s] - (*st(0, s) + (s2 * *st(2, s)) / 2.0);
+            next_img = prm.Lp;                           // the next draw starts with L z
+            stream_product(prm.Sip, NBM, gp, acc);
+            qv[1] = quad();
+            exchange(qv);
+            double pl = prop_LP;
+            if (!is_finite(pl)) pl = -INF;               // mala.cpp:164-166
+            const double da = prm.cons_term - 0.5 * (prm.log_det + qv[0]);       // dmvnorm.hpp:41
+            const double db = prm.cons_term - 0.5 * (prm.log_det + qv[1]);
+            if (!is_finite(da) || !is_finite(db)) n_acc |= NF_BIT;
+            const double x = pl - prev_LP + (da - db);
+            const double comp_val = (x < 0.01) ? x : 0.01;                       // mala.cpp:170
+            const double z = rng_uniform(prm.seed, chain, draw + prm.draw0, 0u);             // :171
+            const bool accept = z < det_exp(comp_val);                           // :173
+            if (accept) {
+                prev_LP = pl;
+                if (live) {
+#pragma unroll
+                    for (int s = 0; s < NSQ; ++s) { *st(0, s) = bp[s]; *st(2, s) = *st(1, s); }
+                }
+            }
+            keep_draw(draw, accept);
+        }
+    } else if constexpr (ALGO == LOGIT_MALA) {
         const double s2 = prm.s2, rs = prm.rs;
         double prev_LP = first_lp, prop_LP;
 #pragma unroll 1

@@ -436,11 +436,11 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         if (rcw) return rcw;
         prm.nf_flag = rp.flag;
     }
-    // hmc with a DENSE precond_mat (prm.Minv_rm / L_rm from the caller): the block images of INV(M) and CHOL_LOWER(M) live in a buffer of their own
-    const bool dense_m = prm.Minv_rm != nullptr;
+    // hmc / mala with a DENSE precond_mat (prm.L_rm and the sampler's other matrices from the caller): their block images live in a buffer of their own
+    const bool dense_m = prm.L_rm != nullptr;
     DevBuf mws;
-    if (dense_m) HIP_TRY(mws.alloc(mi::logit_lds_dense_m_bytes(prm.d, prm.C, lds_target)));
-    const int e = dense_m ? mi::logit_lds_launch_hmc_dense_m(prm, X_dev, y_dev, base.p, mws.p, st, lds_target)
+    if (dense_m) HIP_TRY(mws.alloc(mi::logit_lds_dense_m_bytes(prm.d, prm.C, lds_target, algo)));
+    const int e = dense_m ? mi::logit_lds_launch_dense_m(algo, prm, X_dev, y_dev, base.p, mws.p, st, lds_target)
                           : mi::logit_lds_launch(algo, prm, X_dev, y_dev, base.p, st, lds_target);
     if (e != 0) return fail(MI_ERR_HIP, "LDS-streamed kernel launch: %s", hipGetErrorString((hipError_t)e));
     LitDev ldev;
@@ -459,8 +459,8 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
         if (dense_m) {                                   // the replay's own copies (transposed: literal_host.hpp)
             mi::lit::LitPrep prep;
-            mi::lit::lit_prepare(0, prm.d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
-            rcw = lit_upload(prep, prm.d, false, ldev, lp);
+            mi::lit::lit_prepare(algo == mi::LOGIT_MALA ? 1 : 0, prm.d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+            rcw = lit_upload(prep, prm.d, false, ldev, lp);      // (mala: INV(Sigma), LOG_DET and the constant term with it)
             if (rcw) return rcw;
         }
         else if (lds_tables_active(lt)) lds_tables_replay(*lt, prm, lp);      // hmc: bounds and / or a diagonal precond_mat
@@ -787,19 +787,42 @@ int lds_tables(const char* who, const mi_settings* settings, uint64_t d, LdsTabl
 }
 // hmc with a DENSE precond_mat on the LDS-streamed kernel (logistic_lds.hpp: DENSEM): INV(M) and CHOL_LOWER(M) from the host (hmc.cpp:57-59
 // through the oracle's Gauss-Jordan / column Cholesky, as everywhere), row-major on the device
-struct LdsDenseM { DevBuf minv, l; };
-int lds_dense_m(const mi_settings* settings, uint64_t d, LdsDenseM& t, mi::LogitParams& q)
+// mala (mala.cpp:57-58; mala.ipp:58-64): M, CHOL_LOWER(M), and -- Sigma = eps^2 M is constant without bounds -- INV(Sigma) and LOG_DET(Sigma) =
+// sum_i 2 log CHOL_LOWER(Sigma)_ii, i ascending, as the d <= 128 kernel takes them (mala_gauss_dense_m_kernel)
+struct LdsDenseM { DevBuf minv, l, m, sinv; };
+int lds_dense_m(const mi_settings* settings, uint64_t d, LdsDenseM& t, mi::LogitParams& q, int algo)
 {
-    std::vector<double> Minv, L;
-    host_inverse(settings->precond_mat, d, Minv);
+    auto up = [&](DevBuf& b, const double* src) -> int {
+        HIP_TRY(b.alloc(d * d * 8));
+        HIP_TRY(hipMemcpy(b.p, src, d * d * 8, hipMemcpyHostToDevice));
+        return MI_OK;
+    };
+    int rc;
+    std::vector<double> L;
     host_cholesky_lower(settings->precond_mat, d, L);
-    HIP_TRY(t.minv.alloc(d * d * 8)); HIP_TRY(t.l.alloc(d * d * 8));
-    HIP_TRY(hipMemcpy(t.minv.p, Minv.data(), d * d * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t.l.p, L.data(), d * d * 8, hipMemcpyHostToDevice));
-    q.Minv_rm = t.minv.as<double>(); q.L_rm = t.l.as<double>();
+    if ((rc = up(t.l, L.data()))) return rc;
+    q.L_rm = t.l.as<double>();
+    if (algo == mi::LOGIT_MALA) {
+        const double s2 = settings->step_size * settings->step_size;
+        std::vector<double> Sigma(d * d), Sinv, Ls;
+        for (uint64_t i = 0; i < d * d; ++i) Sigma[i] = s2 * settings->precond_mat[i];
+        host_inverse(Sigma.data(), d, Sinv);
+        host_cholesky_lower(Sigma.data(), d, Ls);
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(Ls[i * d + i]);
+        q.log_det = ld;
+        if ((rc = up(t.m, settings->precond_mat))) return rc;
+        if ((rc = up(t.sinv, Sinv.data()))) return rc;
+        q.M_rm = t.m.as<double>(); q.Sinv_rm = t.sinv.as<double>();
+    } else {
+        std::vector<double> Minv;
+        host_inverse(settings->precond_mat, d, Minv);
+        if ((rc = up(t.minv, Minv.data()))) return rc;
+        q.Minv_rm = t.minv.as<double>();
+    }
     return MI_OK;
 }
-// ... which the hmc front end routes there when this holds (bounds with a dense matrix stay on literal.hpp)
+// ... which the hmc and mala front ends route there when this holds (bounds with a dense matrix stay on literal.hpp)
 bool lds_dense_m_ok(const mi_target* target, const mi_settings* settings)
 {
     return target->kernel_hint != MI_KERNEL_LITERAL && settings->precond_mat && !settings->vals_bound && !precond_is_diagonal(settings, target->d);
@@ -849,7 +872,7 @@ int run_logit_plain(const char* who, int algo, const mi_target* target, const mi
     q.draw0 = (uint32_t)chains->draw0;
     LdsTables lt;
     LdsDenseM ldm;
-    if (algo == mi::LOGIT_HMC && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q))) return rc; }      // a dense precond_mat, unbounded
+    if (algo == mi::LOGIT_HMC && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q, algo))) return rc; }      // a dense precond_mat, unbounded
     else if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
     rc = launch_logit(algo, q, X_dev, y_dev, st, settings, &sc.dev, mi::LOGIT_TARGET_LOGISTIC, &lt);
     if (rc) return rc;
@@ -898,9 +921,9 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
     LdsTables lt;
     LdsDenseM ldm;
     MalaDiagMass mdm;
-    if (algo == mi::LOGIT_HMC && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q))) return rc; }      // a dense precond_mat, unbounded
+    if ((algo == mi::LOGIT_HMC || algo == mi::LOGIT_MALA) && lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q, algo))) return rc; }      // a dense precond_mat, unbounded
     else if (algo == mi::LOGIT_HMC) { if ((rc = lds_tables(who, settings, d, lt, q))) return rc; }      // (the caller routed bounds / a DIAGONAL matrix here)
-    if (algo == mi::LOGIT_MALA && settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }
+    else if (algo == mi::LOGIT_MALA && settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }
     rc = launch_logit(algo, q, P_dev, nullptr, st, settings, &sc.dev, mi::LOGIT_TARGET_DENSE, &lt);
     if (rc) return rc;
     rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains,
@@ -1728,7 +1751,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("mala", 1, target, settings, chains, st);
     // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation)
-    const bool mala_diag_alone = !settings->vals_bound && precond_is_diagonal(settings, d) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+    // ... and, round 5, a DENSE one without bounds (DENSEM: M, CHOL_LOWER(M) and INV(eps^2 M) streamed through LDS like X)
+    const bool mala_diag_alone = !settings->vals_bound && (precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat) && !mala_diag_alone)
         return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("mala", 1, target, settings, chains, st) : run_literal("mala", 1, target, settings, chains, st);
     if (target->kind == MI_TARGET_LOGISTIC && d > 512) return run_literal("mala", 1, target, settings, chains, st);
@@ -1766,7 +1790,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         q.log_det = log_det_;
         q.draw0 = (uint32_t)chains->draw0;
         MalaDiagMass mdm;
-        if (settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }     // (diagonal, no bounds: routed above)
+        LdsDenseM ldm;
+        if (lds_dense_m_ok(target, settings)) { if ((rc = lds_dense_m(settings, d, ldm, q, mi::LOGIT_MALA))) return rc; }     // dense, no bounds
+        else if (settings->precond_mat) { if ((rc = mala_diag_mass_upload(settings, d, mdm, q))) return rc; }     // (diagonal, no bounds: routed above)
         rc = launch_logit(mi::LOGIT_MALA, q, X_dev, y_dev, st, settings, &sc.dev);
         if (rc) return rc;
         rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st);
@@ -1778,8 +1804,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     }
     if (target->kind != MI_TARGET_GAUSS_ISO && target->kind != MI_TARGET_GAUSS_DIAG && target->kind != MI_TARGET_GAUSS_DENSE)
         return fail(MI_ERR_UNSUPPORTED, "mala: target kind %d not implemented", target->kind);
-    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && (!settings->precond_mat || precond_is_diagonal(settings, d)))
-        return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat
+    if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound
+        && (!settings->precond_mat || precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)))
+        return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp); identity, diagonal or (round 5) dense precond_mat
     if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;

@@ -196,3 +196,31 @@ def test_dense_precond_mat_with_bounds_stays_on_the_literal_kernel():
     s = orc.make_settings(seed=5, n_burnin=1, n_keep=3, n_leap=3, step=0.04, W=4, hoist=1, precond=M, lower=lb, upper=ub, **_blk(d))
     o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **_blk(d)), init, s)
     assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+# ---- mala with a DENSE precond_mat on the same kernels (ref: src/mala.cpp:57-58,123,159; include/mcmc/mala.ipp:58-64; include/stats/dmvnorm.hpp:37-41):
+# M grad, L z and the two INV(eps^2 M) (X - mu) streamed through LDS; INV / LOG_DET of the constant Sigma from the host
+@pytest.mark.parametrize("target,d", [("dense", 129), ("dense", 192), ("dense", 256), ("dense", 300), ("dense", 512),
+                                      ("logit", 9), ("logit", 40), ("logit", 100), ("logit", 200), ("logit", 512)])
+def test_mala_with_a_dense_precond_mat_on_the_streamed_kernels(target, d):
+    C = 45
+    M = _dense_m(d, d + 3)
+    init = synth.initial_states(C, d, seed=d + 2) * 0.3
+    init[5] *= 1e200; init[9, 3] = np.inf                 # flagged, replayed literally with the same matrices
+    eps = 0.12 if target == "dense" else 0.25
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=2, n_keep_draws=5, step_size=eps, precond_mat=M)
+    if target == "dense":
+        prec = synth.dense_gaussian_precision(d, seed=d % 89)
+        g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=5)
+        blk = _blk(d); t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, **blk)
+    else:
+        X, y = synth.logistic_problem(d, 40, seed=5)
+        g_draws, g = mcmc_amd.mala(mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
+        blk = dict(blocks=4, block_size=16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128)
+        t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, eta_chains=2, **blk)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.split(",")[1].strip() == "0" and kern.endswith("false, false, true>"), kern
+    s = orc.make_settings(seed=7, n_burnin=2, n_keep=5, step=eps, W=4, hoist=1, precond=M, **blk)
+    o_draws, o = orc.run_many(orc.ALGO_MALA, t, init, s, chain0=5)
+    assert 0 < o["n_accept"].sum() < 5 * C
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
