@@ -92,7 +92,7 @@ def sweep(n_cases=60, seed=1, verbose=True):
 
 
 def sweep_dense_m(n_cases=40, seed=1, verbose=True):
-    """hmc with a DENSE precond_mat on the LDS-streamed kernels (logistic_lds.hpp DENSEM, round 5): dense Gaussians with 128 < d <= 512 and the
+    """hmc and mala with a DENSE precond_mat on the LDS-streamed kernels (logistic_lds.hpp DENSEM, round 5): dense Gaussians with 128 < d <= 512 and the
     logistic target with 8 < d <= 512 -- every instantiation, ragged workgroups, 0..5 leapfrog steps, step sizes up to the non-finite regime
     and non-finite starts (flagged, replayed literally with the same matrices), continuation offsets.  Returns the number of mismatches."""
     rng = np.random.default_rng(seed)
@@ -100,6 +100,7 @@ def sweep_dense_m(n_cases=40, seed=1, verbose=True):
     say = print if verbose else (lambda *a, **k: None)
     for case in range(n_cases):
         tgt = "dense" if case % 2 == 0 else "logit"
+        algo = "hmc" if (case // 2) % 2 == 0 else "mala"
         d = int(rng.choice([129, 144, 192, 193, 250, 256, 257, 384, 385, 512])) if tgt == "dense" else int(rng.choice([9, 16, 17, 64, 65, 128, 129, 256, 300, 512]))
         C = int(rng.choice([1, 3, 16, 17, 33, 70]))
         if d > 256: C = min(C, 17)                       # (the oracle inverts M once per chain)
@@ -120,10 +121,10 @@ def sweep_dense_m(n_cases=40, seed=1, verbose=True):
             blk = dict(blocks=4, block_size=16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128); tkw = dict(blk, eta_chains=2)
         st = mcmc_amd.default_settings(rng_seed_value=rseed, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps, precond_mat=M)
         s = orc.make_settings(seed=rseed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1, precond=M, **blk)
-        desc = f"hmc {tgt} dense precond d={d} C={C} eps={eps} L={L} burn={burn} keep={keep}"
-        g_draws, g = mcmc_amd.sample("hmc", kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
+        desc = f"{algo} {tgt} dense precond d={d} C={C} eps={eps} L={L} burn={burn} keep={keep}"
+        g_draws, g = mcmc_amd.sample(algo, kg, init, st, prec=prec, X=X, y=y, chain0=chain0)
         kern = mcmc_amd.last_kernel()
-        o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw), init, s, chain0=chain0)
+        o_draws, o = orc.run_many(orc.ALGO_HMC if algo == "hmc" else orc.ALGO_MALA, orc.TargetSpec(ko, d, prec=prec, X=X, y=y, W=4, **tkw), init, s, chain0=chain0)
         ok = (kern.startswith("logit_lds_kernel<") and kern.endswith("false, false, true>") and np.array_equal(g_draws, o_draws, equal_nan=True)
               and np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g["n_leap"], o["n_leap"]))
         if not ok:
