@@ -291,6 +291,46 @@ def extra_nuts_on_logistic(ctx):
                     "8 192 chain slots of the persistent grid dynamically, see DESIGN.md section 4.14"}
 
 
+def extra_hmc_dense_precond(ctx):
+    """Not a BASELINE config: mcmc::hmc with a DENSE precond_mat beyond d = 128 (ref: src/hmc.cpp:57-59,158-160,171,184), which ran on the
+    literal kernel until round 5.  A dense Gaussian with d = 256, 65 536 chains, 16 leapfrog steps x (10 + 10) draws on
+    logit_lds_kernel<.., DENSEM> (P, INV(M) and CHOL_LOWER(M) streamed through LDS); the shape of tools/dense_m_time.py.
+    Events on the launch stream around the whole call, so the host's factorisation of M is inside `ms` (it is not inside the kernel)."""
+    import torch
+    import mcmc_amd
+    from mcmc_amd import synth
+    d, C, L, burn, keep = 256, 65536, 16, 10, 10
+    rng = np.random.default_rng(d)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    M = A @ A.T + np.diag(rng.uniform(0.4, 2.5, d))
+    dev = ctx.dev
+    theta0 = torch.from_numpy(np.ascontiguousarray((synth.initial_states(C, d, seed=3) * 0.3).T)).to(dev)
+    theta = torch.empty_like(theta0)
+    draws = torch.empty((keep, d, C), dtype=torch.float64, device=dev)
+    target = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=torch.from_numpy(synth.dense_gaussian_precision(d)).to(dev), mem=mcmc_amd.MEM_DEVICE)
+    settings = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=0.03, precond_mat=M)
+    chains = mcmc_amd.make_chains(theta, C, draws=draws, mem=mcmc_amd.MEM_DEVICE)
+    stream = torch.cuda.current_stream().cuda_stream
+    ms = None
+    for _ in range(2):                          # the first run loads the code object
+        theta.copy_(theta0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        mcmc_amd.run("hmc", target, settings, chains, stream=stream)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+    n_draws = burn + keep
+    flop = float(C) * n_draws * (L * 2 * (2.0 * d * d) + 3 * (2.0 * d * d))       # per leapfrog P x and Minv p; per draw L z and two kinetic energies
+    tflops = flop / (ms * 1e-3) / 1e12
+    return {"workload": "mcmc::hmc on a dense Gaussian, d=256, DENSE precond_mat, 16 leapfrog steps, fp64", "chains": C, "draws": n_draws, "ms": ms,
+            "kernel": mcmc_amd.last_kernel(), "value": float(C) * d * L * n_draws / (ms * 1e-3), "unit": "chain*dim*leapfrog-steps/s",
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
+                         "flop_per_unit": (L * 4.0 * d * d + 6.0 * d * d) / (d * L)},
+            "note": "whole call incl. the host's INV / CHOL_LOWER of M and the literal replay launch; kernel alone 116.2 ms = 0.66 of peak in "
+                    "profiles/r5_dense_m_kernel_stats.csv"}
+
+
 # ESS/sec legs (VERDICT r4 next 4): BASELINE's frozen settings of configs[2] (step_size 0.02: accept 0.99996, the chains barely move) and
 # configs[4] (8 kept draws at M = I) give draws/sec but no ESS that is an estimate.  These legs run the SAME target and sampler, outside the
 # timed region, at settings under which the chains converge (R-hat < 1.1); the values are frozen in BASELINE.md section 9.
@@ -720,6 +760,10 @@ def main():
         out["other_configs"] = others
         if not args.no_extra:
             out["extra"] = {"nuts_on_configs2_target": extra_nuts_on_logistic(ctx)}
+            try:                                # (added after the round's last GPU minute: a failure here must not cost the line)
+                out["extra"]["hmc_dense_precond_d256"] = extra_hmc_dense_precond(ctx)
+            except Exception as e:              # noqa: BLE001
+                out["extra"]["hmc_dense_precond_d256"] = {"error": f"{type(e).__name__}: {e}"}
     elif ctx.rank == 0 and ctx.world == 1 and args.chains is None and head_id in CONVERGED and args.converged:
         out["converged"] = converged_leg(head_id, ctx)
     if (single and not args.no_proxy) or (args.proxy_scaling and ctx.world == 1):
