@@ -99,6 +99,29 @@ def test_literal_dense_gaussian_uses_the_blocked_dot_order_between_128_and_512(a
         assert np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"]), (algo, d, eps)
 
 
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("d", [129, 300])
+def test_literal_dense_gaussian_with_a_dense_precond_mat_between_128_and_512(algo, d):
+    """The replay behind round 5's DENSEM instantiations of the LDS-streamed kernel (hmc / mala with a dense precond_mat): INV /
+    CHOL_LOWER of M (mala: INV and LOG_DET of eps^2 M) from host_linalg.hpp -- the vectorised elimination, the memo (the second step size asks
+    for INV(M) again) -- and the blocked dot order, against the oracle."""
+    rng = np.random.default_rng([14, len(algo), d])
+    prec = synth.dense_gaussian_precision(d, seed=d % 97)
+    A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + np.diag(rng.uniform(0.3, 3.0, d))
+    D = np.ones(d); D[[0, 7, d // 2]] = 0.02              # D M D: still symmetric positive definite, and columns whose diagonal entry is not the
+    M = D[:, None] * M * D[None, :]                        # largest -- the elimination has to pivot
+    assert np.abs(M[1:, 0]).max() > M[0, 0]
+    bs = 48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128
+    for eps, scale in ((0.01, 0.3), (1e6, 1e3), (0.02, 0.3)):
+        init = synth.initial_states(2, d, seed=d) * scale
+        t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, blocks=4, block_size=bs)
+        s = orc.make_settings(seed=78, n_burnin=1, n_keep=3, n_leap=3, step=eps, W=4, hoist=1, precond=M, blocks=4, block_size=bs)
+        o_draws, o = orc.run_many({"hmc": orc.ALGO_HMC, "mala": orc.ALGO_MALA}[algo], t, init, s, chain0=5)
+        l_draws, l = lit_host.run(algo, "dense", init, 78, 1, 3, 3, eps, prec=prec, chain0=5, precond=M)
+        assert np.array_equal(l_draws, o_draws, equal_nan=True) and np.array_equal(l["n_accept"], o["n_accept"]), (algo, d, eps)
+        if scale <= 1.0: assert np.isfinite(o_draws).all() and o["n_accept"].sum() > 0, "the matrix is meant to be a usable preconditioner"
+
+
 # ---- the features round 3 added to the literal kernels, pinned on the CPU as well (host instantiation): per-chain diagonal masses, host
 # callbacks as the target (the host branch of the mailbox), the nuts dual-averaging state across a cut
 
