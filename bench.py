@@ -12,7 +12,10 @@ Multi-GPU (one rank per GPU: under torchrun, or `--gpus N` alone -- bench.py the
 torch.distributed.run and FAILS if fewer than N GPUs are visible): chains shard by global chain id (mcmc_amd.dist.shard_bounds) with no data-path
 collective.  north_star asks for STRONG scaling at 65 536 chains, so with WORLD_SIZE > 1 the total chain count stays
 fixed and every rank takes its shard ("scaling": "strong"); `--scaling weak` keeps the per-GPU count fixed instead.
-`--collate` additionally times the one exchange the path has (RCCL all-gather of the kept draws, HBM to HBM).
+With more than one rank the line ALWAYS carries the one exchange the path has -- the collation of draws_out, through the C ABI
+(mi_mcmc_allgather_draws_rank_major, then _begin / _wait in 4 chunks under the sampling): `value` (sampling only), `value_incl_collation`
+(sampling, then one blocking all-gather), `value_overlapped`, `collate_GBps`, and the RCCL rank count.  `--collate` does the same at one GPU
+(a one-rank communicator: the code path, not a transfer).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (named by the engine: mi_mcmc_last_kernel) against the resource that bounds it: algorithmic
@@ -161,17 +164,24 @@ def same_kernel(label, profiled_name):
     return ("mi::" + base) in profiled_name or profiled_name.startswith(base)
 
 
+def committed_pmc(cfg_id):
+    """(round, path) of the committed counter passes of a config: profiles/r<N>_c<cfg>_pmc.json (the full-size run) and
+    profiles/r<N>_c<cfg>_<C>chains_pmc.json (one GPU's share of an N-GPU split: what a rank of `--gpus N` launches)."""
+    import glob
+    import re
+    cands = []
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_c{cfg_id}_*pmc.json")):
+        m = re.match(r"r(\d+)_c\d+_(\d+chains_)?pmc\.json$", os.path.basename(p))
+        if m:
+            cands.append((int(m.group(1)), p))
+    return cands
+
+
 def profiled_traffic(cfg_id, key, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r<N>_c<cfg>_pmc.json, newest round first) --
     only from a profile of THIS workload (workload_key) and of THE KERNEL THAT JUST RAN (mi_mcmc_last_kernel): a figure measured on another
     kernel is not this kernel's traffic.  Returns (bytes, source) or (None, why)."""
-    import glob
-    import re
-    cands = []
-    for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_c{cfg_id}_pmc.json")):
-        m = re.match(r"r(\d+)_c\d+_pmc\.json$", os.path.basename(p))
-        if m:
-            cands.append((int(m.group(1)), p))
+    cands = committed_pmc(cfg_id)
     why = "no committed profile of this config"
     for _, p in sorted(cands, reverse=True):
         rel = os.path.relpath(p, ROOT)
@@ -193,13 +203,7 @@ def profiled_traffic(cfg_id, key, kernel_name):
 def profiled_pipe_budget(cfg_id, key, kernel_name):
     """The combined-pipe budget of the dominant kernel -- (4 x VALU wave-instructions + MFMA busy cycles) / SIMD cycles -- from the newest
     committed counter pass of this workload AND this kernel (tools/summarize_prof.py: derived.pipe_budget); None if there is none."""
-    import glob
-    import re
-    cands = []
-    for p in glob.glob(os.path.join(ROOT, "profiles", f"r*_c{cfg_id}_pmc.json")):
-        m = re.match(r"r(\d+)_c\d+_pmc\.json$", os.path.basename(p))
-        if m:
-            cands.append((int(m.group(1)), p))
+    cands = committed_pmc(cfg_id)
     for _, p in sorted(cands, reverse=True):
         try:
             j = json.load(open(p))
@@ -390,6 +394,80 @@ def converged_leg(cfg_id, ctx):
     return out
 
 
+def time_collation(args, ctx, cfg, algo, target, skw, theta, theta0, draws, chain0, C, total, n_keep, d, stream, barrier, eps_out):
+    """Times the collation of draws_out through the C ABI on every rank (barrier + synchronize on both sides, so the figure is the slowest
+    rank's): blocking (mi_mcmc_allgather_draws_rank_major) and overlapped with the sampling (4 chunks, _begin / _wait).  Returns the dict that
+    goes under `collation` (identical on every rank).  Under BENCH_TEST_SHARE_GPU (the ranks share ONE device, which RCCL refuses inside one
+    communicator) every rank collates its own shard over a ONE-rank communicator: the same C calls, no bytes between devices -- labelled."""
+    import torch
+    import mcmc_amd
+    from mcmc_amd import dist as mdist
+    world, rank, dev, share = ctx.world, ctx.rank, ctx.dev, ctx.share
+    solo = share or world == 1
+    comm = mdist.RcclComm(solo=solo)
+    n_total = C if solo else total                           # chains in the receive buffer
+    out = {"abi": "mi_mcmc_allgather_draws_rank_major; mi_mcmc_allgather_draws_begin / _wait (include/mi_mcmc.h)",
+           "rccl_ranks": comm.world, "layout": "rank-major [G][n_keep][d][C/G] (SURVEY 8(e)), one ncclAllGather, no staging buffer",
+           "bytes_received_per_rank": n_keep * d * n_total * 8, "bytes_sent_per_rank": n_keep * d * C * 8}
+    if solo and world > 1:
+        out["note"] = ("BENCH_TEST_SHARE_GPU: the ranks share one device, so each collates its OWN shard over a one-rank RCCL communicator "
+                       "(the C-ABI calls run, nothing crosses xGMI): NOT a multi-GPU collation time")
+    recv = torch.empty(n_keep * d * max(n_total, 1), dtype=torch.float64, device=dev)
+    loc = draws[:, :, :C] if C == draws.shape[2] else draws[:, :, :C].contiguous()
+    mdist.collate_rank_major(comm, loc, n_total, out=recv, stream=stream)      # warm-up: the communicator's first collective sets its rings up
+    reps = []
+    for _ in range(3):
+        barrier()
+        tc = time.perf_counter()
+        mdist.collate_rank_major(comm, loc, n_total, out=recv, stream=stream)
+        barrier()
+        reps.append((time.perf_counter() - tc) * 1e3)
+    out["blocking_ms"] = float(np.median(reps))
+    out["blocking_ms_reps"] = reps
+    out["GBps"] = out["bytes_received_per_rank"] / (out["blocking_ms"] * 1e-3) / 1e9
+    out["busbw_GBps"] = out["GBps"] * (comm.world - 1) / comm.world          # the all-gather convention: what crossed the links, per rank
+    # the rank's own shard sits where the layout says (equal shards: block `rank` of the receive buffer)
+    if C > 0 and (solo or total % world == 0):
+        r_ = 0 if solo else rank
+        blk = recv.view(-1)[r_ * n_keep * d * C:(r_ + 1) * n_keep * d * C].view(n_keep, d, C)
+        out["own_shard_in_place"] = bool(torch.equal(blk, loc))
+    # ... and OVERLAPPED with the sampling: the same run in four chunks chained through mi_chains.draw0 (bit-identical to one call:
+    # tests/test_gpu_resume.py); a nuts continuation starts after its adaptation window and takes the adapted step sizes back in
+    K = 4
+    ok = n_keep >= K and (algo in ("hmc", "mala") or (algo == "nuts" and cfg.get("n_adapt_draws", 0) <= cfg["n_burnin_draws"]))
+    if ok:
+        bounds = [(n_keep * i) // K for i in range(K + 1)]
+        slabs = [torch.empty((bounds[i + 1] - bounds[i], d, max(C, 1)), dtype=torch.float64, device=dev) for i in range(K)]
+        recv.zero_()
+        theta.copy_(theta0)
+        barrier()
+        tc = time.perf_counter()
+        handles = []
+        for i in range(K):
+            s_i = mcmc_amd.default_settings(**dict(skw, n_burnin_draws=cfg["n_burnin_draws"] if i == 0 else 0, n_keep_draws=bounds[i + 1] - bounds[i]))
+            ch_i = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=slabs[i], mem=mcmc_amd.MEM_DEVICE, step_size=eps_out if algo == "nuts" else None,
+                                        draw0=0 if i == 0 else cfg["n_burnin_draws"] + bounds[i])
+            if C > 0:
+                mcmc_amd.run(algo, target, s_i, ch_i, stream=stream)
+            handles.append(mdist.collate_begin(comm, slabs[i], n_total, bounds[i], n_keep, recv, producer_stream=stream))
+        for i, h in enumerate(handles):
+            mdist.collate_wait(h, consumer_stream=stream, block_host=(i == K - 1))
+        barrier()
+        out["overlapped_total_ms"] = (time.perf_counter() - tc) * 1e3
+        out["overlapped_chunks"] = K
+        if C > 0 and (solo or total % world == 0):
+            r_ = 0 if solo else rank
+            blk = recv.view(-1)[r_ * n_keep * d * C:(r_ + 1) * n_keep * d * C].view(n_keep, d, C)
+            out["overlapped_equals_blocking_run"] = bool(torch.equal(blk, loc))      # the chunked run reproduces the one-call run's rows
+        del slabs
+    else:
+        out["overlapped_total_ms"] = None
+        out["overlapped_why_not"] = "needs n_keep >= 4 and, for nuts, an adaptation window inside the burn-in"
+    del recv
+    comm.close()
+    return out
+
+
 def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, want_traffic=True):
     """Times `steps` steps of one BASELINE config on this rank's GPU (barrier + synchronize on both sides, max over ranks).
     Returns the result dict on rank 0 (None elsewhere)."""
@@ -475,49 +553,15 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, units_all = float(tmax[0].item()), float(t[1].item())
 
-    collate_ms, collate_overlapped_total_ms = None, None
-    if headline and args.collate and dist is not None and not share:
-        c_max = mdist.shard_bounds(total, world, 0)[1] if scaling == "strong" else C
-        send = torch.zeros((n_keep, d, c_max), dtype=torch.float64, device=dev)
-        send[:, :, :C] = draws[:, :, :C]
-        gathered = torch.empty((world * n_keep, d, c_max), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, send)     # warm-up (communicator set-up)
-        barrier()
-        tc = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, send)     # the path's one exchange: every rank ends with all kept draws, HBM to HBM
-        barrier()
-        collate_ms = (time.perf_counter() - tc) * 1e3
-        del gathered, send
-        # ... and OVERLAPPED with the sampling ("per kept-draw slab, overlapped with the next trajectory"): the same run in
-        # four chunks chained through mi_chains.draw0 (bit-identical to one call), chunk k's slab all-gathered asynchronously -- RCCL's
-        # own stream -- while chunk k + 1 samples.  One timed repetition, barrier on both sides; compare with ms_per_step + the blocking
-        # gather above.  (The C-ABI form of the same thing: mi_mcmc_allgather_draws_begin / _wait.)
-        if algo in ("hmc", "mala") and n_keep >= 4:
-            K = 4
-            bounds = [(n_keep * i) // K for i in range(K + 1)]
-            slabs = [torch.zeros((bounds[i + 1] - bounds[i], d, c_max), dtype=torch.float64, device=dev) for i in range(K)]
-            outs = [torch.empty((world * (bounds[i + 1] - bounds[i]), d, c_max), dtype=torch.float64, device=dev) for i in range(K)]
-            theta.copy_(theta0)
-            barrier()
-            tc = time.perf_counter()
-            works = []
-            for i in range(K):
-                s_i = mcmc_amd.default_settings(**dict(skw, n_burnin_draws=cfg["n_burnin_draws"] if i == 0 else 0, n_keep_draws=bounds[i + 1] - bounds[i]))
-                # (the slab of a chunk has the shard's own chain count as its row length; the padded send buffer is filled by a strided copy)
-                loc = torch.empty((bounds[i + 1] - bounds[i], d, max(C, 1)), dtype=torch.float64, device=dev)
-                ch_i = mcmc_amd.make_chains(theta, C, chain0=chain0, draws=loc, mem=mcmc_amd.MEM_DEVICE,
-                                            draw0=0 if i == 0 else cfg["n_burnin_draws"] + bounds[i])
-                if C > 0:
-                    mcmc_amd.run(algo, target, s_i, ch_i, stream=stream)
-                    slabs[i][:, :, :C] = loc[:, :, :C]
-                works.append(dist.all_gather_into_tensor(outs[i], slabs[i], async_op=True))
-            for w_ in works:
-                w_.wait()
-            barrier()
-            collate_overlapped_total_ms = (time.perf_counter() - tc) * 1e3
-            del slabs, outs
-        else:
-            collate_overlapped_total_ms = None
+    # The ONE exchange the path has (north_star: "a single RCCL all-gather over xGMI to collate draws_out"; what is collated is the rows of
+    # ref: src/hmc.cpp:196-204), ALWAYS timed when there is more than one rank ("report both with and without") and THROUGH THE
+    # C ABI -- the product's own collation (include/mi_mcmc.h), not torch's: mi_mcmc_allgather_draws_rank_major (blocking: sampling, then one
+    # gather) and mi_mcmc_allgather_draws_begin / _wait (the run cut into 4 chunks through mi_chains.draw0, chunk k's slab travelling on the
+    # library's communication stream while chunk k + 1 samples).  Outside `value`'s timed region; printed next to it.
+    collation = None
+    if headline and dist is not None and (world > 1 or args.collate):
+        collation = time_collation(args, ctx, cfg, algo, target, skw, theta, theta0, draws, chain0, C, total if scaling == "strong" else C * world,
+                                   n_keep, d, stream, barrier, eps_out)
 
     # ESS/sec (second half of BASELINE.json's metric): Geyer initial-positive-sequence ESS, min over dims, autocovariances pooled
     # over ALL chains of this rank by the device reducer (mi_mcmc_draw_stats, no D2H of the draws); outside the timed region, its own
@@ -630,13 +674,13 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
                                    "ms": t_ad * 1e3, "ess_per_sec": float(st_ad["ess"].min()) * C * world / t_ad,
                                    "accept_rate": float(n_accept[:C].double().mean().item()) / n_keep,
                                    "mass_over_precision_range": [float((mass / kw["prec"]).min()), float((mass / kw["prec"]).max())]}
-        if collate_ms is not None:
-            out["collate_allgather_ms"] = collate_ms
-            out["collate_bytes_per_rank"] = n_keep * d * C * 8
-            if collate_overlapped_total_ms is not None:
-                out["collate_overlapped"] = {"chunks": 4, "sampling_plus_gather_ms": collate_overlapped_total_ms,
-                                             "blocking_equivalent_ms": elapsed / steps * 1e3 + collate_ms,
-                                             "note": "one run in 4 chunks through mi_chains.draw0, each chunk's slab all-gathered asynchronously under the next chunk's sampling"}
+        if collation is not None:
+            step_s = elapsed / steps
+            units_step = units_all                          # units of ALL ranks in one step
+            out["value_incl_collation"] = units_step / (step_s + collation["blocking_ms"] * 1e-3)
+            out["value_overlapped"] = (units_step / (collation["overlapped_total_ms"] * 1e-3)) if collation.get("overlapped_total_ms") else None
+            out["collate_GBps"] = collation["GBps"]
+            out["collation"] = collation
     del draws, theta, theta0, n_accept, n_leap, n_exec, eps_out, kw_dev, target, chains
     mcmc_amd.release_workspace()
     torch.cuda.empty_cache()
@@ -666,7 +710,7 @@ def main():
     ap.add_argument("--no-proxy", action="store_true", help="skip scaling_proxy in the default run")
     ap.add_argument("--converged", action="store_true", help="with --config 3 | 5: also run that config's converged ESS leg (the default run always does)")
     ap.add_argument("--collate", action="store_true",
-                    help="also time the RCCL all-gather of the kept draws (not part of `value`)")
+                    help="one GPU: run the C-ABI collation over a one-rank RCCL communicator too (with N > 1 ranks it always runs)")
     args = ap.parse_args()
 
     import torch
@@ -790,7 +834,7 @@ def main():
         if ctx.rank == 0:
             out["scaling_proxy"] = proxy
     if ctx.rank == 0:
-        if not args.no_cpu_baseline and ctx.world == 1:
+        if not args.no_cpu_baseline:             # rank 0's host cores, at any N
             out["cpu_baseline"] = cpu_baseline(head_id, cfg)
             gv = out.get("executed", {}).get("reference_equivalent_value") or out["value"]
             out["gpu_over_cpu"] = {k: gv / out["cpu_baseline"][k]["value"] for k in ("mode_a", "mode_b") if k in out["cpu_baseline"]}

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_MCMC_VERSION 0x000500
+#define MI_MCMC_VERSION 0x000600
 
 typedef enum mi_status {
     MI_OK = 0,
@@ -290,6 +290,16 @@ typedef void (*mi_tensor_cb)(const double* vals_inp, double* tensor_out, double*
 int mi_mcmc_rmhmc_run_callback(const double* initial_vals, uint64_t d, mi_log_kernel_cb target_log_kernel, void* target_data,
                                mi_tensor_cb tensor_fn, void* tensor_data, const mi_settings* settings, double* draws_out,
                                uint64_t* n_accept_draws);
+
+/* ---- the BaseMatrixOps shim's INV and CHOL_LOWER as the engine computes them for a dense precond_mat (ref: src/hmc.cpp:58-59,
+ * src/mala.cpp:58, include/stats/dmvnorm.hpp:36-41 through include/mcmc/mala.ipp:63-64): Gauss-Jordan with partial pivoting (first largest
+ * magnitude) and column Cholesky, in the operation order the oracle states (oracle/mcmc_oracle.c: orc_inv, orc_chol_lower) -- bit-identical to
+ * it.  A, Ainv, L: HOST memory, d x d row-major; A's lower triangle is what CHOL_LOWER reads, L is zero above the diagonal.  d >= 64 runs on
+ * the device (one cooperative launch: d pivot / column steps of a parallel update, mcmc_amd/csrc/linalg_device.hip), smaller matrices on the
+ * calling thread; no input validation, as in the reference (a singular / non-SPD matrix gives inf / NaN entries, not an error).  Blocking.
+ * (ABI 0x000600.  Every sampler call with a dense precond_mat goes through these.) */
+int mi_mcmc_mat_inverse(const double* A, uint64_t d, double* Ainv);
+int mi_mcmc_mat_cholesky_lower(const double* A, uint64_t d, double* L);
 
 /* ---- multi-GPU: one process per GPU.  Chains are independent (the reference runs one per call), so the path shards with no
  * data-path collective: rank r of world_size runs the global chains [chain0, chain0 + n_local) in its own mi_mcmc_*_run call

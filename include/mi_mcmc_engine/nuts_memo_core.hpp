@@ -181,6 +181,8 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
 #define n_alpha_() MI_RD(R_SC + 3)
     int good_round = 0;
     bool org_ok = false;         // the registers already hold the origin of the doubling about to start
+    bool cp_pend = false;        // ... and that origin is an accepted proposal that came straight from its point record: prev_draw's copy of it
+                                 // (theta, P theta) is stored FROM THE REGISTERS at the top of the next tick -- no load-wait-store in the tick
     double ca_keep = 0.0;        // MI_MEMO_WALK_CAP: alpha of the leaf a walk that was cut short goes on with
     // Draw boundaries without waiting (round 2): what the next draw needs and that does not depend on the chain's state -- momentum
     // (nuts.cpp:200-202), its kinetic energy, the slice uniform -- is generated AHEAD by a phase that serves every chain of the wave that lacks it;
@@ -338,6 +340,12 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     for (;;) {
         asm volatile("" : "+v"(lane_b), "+v"(lane_sc), "+v"(lrow));
         MI_MPROF(7)
+        // prev_draw's copy of a proposal accepted in the last tick (requested from its record into the registers as the next doubling's origin):
+        // stored before anything of this tick can read prev_draw from memory (the phase's row stores, a later origin load)
+        if (__ballot(cp_pend) != 0ull) {
+            if (cp_pend) { st_row(pvec(pb), 0, th); st_row(wvec(pb), 0, w); }
+            cp_pend = false;
+        }
         if constexpr (POL::REPLAY) retire(state != NS_DONE && nf_() != 0.0);   // a flagged chain is replayed from its initial state: nothing of it is kept
         // ------------------------------------------------------------ free slots take the next chains
         {
@@ -352,7 +360,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                     if (nid < C) {                       // a new chain in this slot: everything per-chain starts over
                         cl = nid;
                         state = NS_INIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
-                        mv = MV_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false;
+                        mv = MV_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false; cp_pend = false;
                     } else exhausted = true;
                 }
             }
@@ -429,7 +437,21 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (newpt) org_ok = false;
         const uint32_t mpt = npts + 1u;                  // the point this tick computes (newpt lanes)
         // the tests this point closes: level l against point mpt - l (lds_pm), lowest level first
-        uint32_t pmask = newpt ? (uint32_t)lds_pm[jd * 48u + mpt] : 0u;
+        // ... and, as "level 0", the TOP-LEVEL test of src/nuts.cpp:286-289 when this point is the doubling's far edge (point 1 + jd): its operands
+        // are this point and the OTHER side's edge, which no tick of this doubling writes -- evaluated here, with the point in registers, it costs
+        // two row loads that mostly travel under the mat-vec instead of four behind the walk (result: bit 63 of okb_(0), read at the doubling's end)
+        const bool st_edge = newpt && mpt == 1u + jd;
+        uint32_t pmask = newpt ? ((uint32_t)lds_pm[jd * 48u + mpt] | (st_edge ? 1u : 0u)) : 0u;
+        // the (theta, p) vectors of the other point of a test: level l >= 1: the record of point mpt - l; level 0: the other edge (draw_neg / mntm_neg
+        // for a forward doubling, _pos for a backward one) -- the draw's initial vectors until a doubling has written that side
+        auto test_vecs = [&](int l, int& vt, int& vp) __attribute__((always_inline)) {
+            vt = MV_PT0 + 3 * ((int)mpt - l - 1); vp = vt + 1;
+            if (l == 0) {
+                const bool oinit = (vdir > 0) ? neg_init : pos_init;
+                vt = oinit ? pvec(pb0) : ((vdir > 0) ? MV_TNEG_T : MV_TPOS_T);
+                vp = oinit ? mv : ((vdir > 0) ? MV_TNEG_P : MV_TPOS_P);
+            }
+        };
         // theta / p of the other point of a test; dd then holds d = theta(mpt) - theta(mpt - l) (by direction).  DEFINED on every lane before
         // the (predicated) loads: left undefined, the values of lanes without a test count as live from the previous tick's loop -- 128 registers
         // held through the walk, 400 bytes of scratch per lane
@@ -455,8 +477,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             const bool t1 = pmask != 0u;
             if (__ballot(t1) != 0ull) {
                 const int l1 = t1 ? __builtin_ctz(pmask) : 1;
-                const int vq = MV_PT0 + 3 * ((int)mpt - l1 - 1);
-                if (t1) { ld_row(vq, 0, dd); ld_row(vq + 1, 0, Lp); }
+                int vq, vqp;
+                test_vecs(l1, vq, vqp);
+                if (t1) { ld_row(vq, 0, dd); ld_row(vqp, 0, Lp); }
             }
         }
         MI_MPROF(1)
@@ -515,8 +538,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 const int l = t ? __builtin_ctz(pmask) : 1;
                 const int n1 = (int)mpt - l;
                 if (!first) {
-                    const int vq = MV_PT0 + 3 * (n1 - 1);
-                    if (t) { ld_row(vq, 0, dd); ld_row(vq + 1, 0, Lp); }
+                    int vq, vqp;
+                    test_vecs(l, vq, vqp);
+                    if (t) { ld_row(vq, 0, dd); ld_row(vqp, 0, Lp); }
                 }
                 first = false;
                 // (two passes: d . p(n1) with theta, d, p(n1) as operands, then d . p(mpt) with d, p -- four vectors as VALU operands of one loop
@@ -533,7 +557,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
                 q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
                 if (t) {
-                    const unsigned long long bit = 1ull << n1;
+                    const unsigned long long bit = (l == 0) ? (1ull << 63) : (1ull << n1);      // (level 0: q1, q2 are the two products of :286-287, in either order)
                     const bool ok = (q1 >= 0.0) && (q2 >= 0.0);
                     okb_(l) = (okb_(l) & ~bit) | (ok ? bit : 0ull);
                     pmask &= pmask - 1u;
@@ -542,13 +566,8 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         }
         // the tree's far edge (= the first leaf of its second half, point 1 + jd; the leaf itself at depth 0) is what a successful doubling leaves
         // in draw_pos / draw_neg (src/nuts.cpp:241-256); a doubling that fails before that leaf ends the draw, so writing it early is harmless.
-        // (The one store before the walk: the test that ends this doubling may read it in this very tick.)
-        const bool st_edge = newpt && mpt == 1u + jd;
-        if (st_edge) {
-            const int et = (vdir > 0) ? MV_TPOS_T : MV_TNEG_T, ep = (vdir > 0) ? MV_TPOS_P : MV_TNEG_P;
-            st_row(et, 0, th); st_row(ep, 0, pm);
-            if (vdir > 0) pos_init = false; else neg_init = false;
-        }
+        // Nothing of this doubling reads it (its top-level test was taken above, from the registers): it is stored with the record, at the END of the tick
+        if (st_edge) { if (vdir > 0) pos_init = false; else neg_init = false; }
         if (newpt) npts = mpt;
         MI_MPROF(3)
         // ------------------------------------------------------------ C. walk the leaves this point unblocks (nuts.ipp:146-158, 212-239)
@@ -634,45 +653,29 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                     if (take) { good_round = 1; pb = 1 - pb0; }                 // :264-277
                 }
             }
-            if (__ballot(take) != 0ull) {
-                // the proposal is a point of the trajectory: (theta, P theta) of its record go to prev_draw in ONE round trip -- or straight from the
-                // registers when it is this tick's own point (whose record is not written yet, and never will be: the doubling is over)
-                const bool from_regs = take && newpt && cref == mpt;
-                if (from_regs) { st_row(pvec(1 - pb0), 0, th); st_row(wvec(1 - pb0), 0, w); prev_U_() = pU; }
-                const bool from_rec = take && !from_regs;
-                if (__ballot(from_rec) != 0ull) {
-                    if (from_rec) {
-                        const int vq = MV_PT0 + 3 * ((int)cref - 1);
-                        ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
-                        prev_U_() = scp(cref)->y;
-                        st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
-                    }
-                }
+            // the proposal is a point of the trajectory.  Its (theta, P theta) become prev_draw AND the origin of whatever this chain does next:
+            //   this tick's own point (whose record is not written, and never will be: the doubling is over): prev_draw stored from the registers,
+            //     which stay as they are;
+            //   an earlier point: its record is requested INTO THE REGISTERS below (as the next origin) and prev_draw's copy is stored from there at
+            //     the top of the next tick (cp_pend) -- no load-wait-store round trip in the tick
+            const bool from_regs = take && newpt && cref == mpt;
+            const bool from_rec = take && !from_regs;
+            if (from_regs) { st_row(pvec(1 - pb0), 0, th); st_row(wvec(1 - pb0), 0, w); prev_U_() = pU; }
+            if (__ballot(from_rec) != 0ull) {
+                if (from_rec) prev_U_() = scp(cref)->y;
             }
             if (at_fin) { alpha_() = ca; n_alpha_() = (double)cna_i; n_val_() = n_val_() + (double)cn_i; }   // :246,255 ; :283
-            bool s_ok = false;
-            if (__ballot(complete) != 0ull) {
-                const int en_t = neg_init ? pvec(pb0) : MV_TNEG_T, en_p = neg_init ? mv : MV_TNEG_P;
-                const int ep_t = pos_init ? pvec(pb0) : MV_TPOS_T, ep_p = pos_init ? mv : MV_TPOS_P;
-                // [ (pos - neg) . p_neg >= 0 ] * [ (pos - neg) . p_pos >= 0 ] (:286-289).  The trajectory of a chain whose doubling is complete is
-                // dead (the next doubling starts from prev_draw), so its registers take the four operands in ONE round trip
-                double q1 = 0.0, q2 = 0.0;
-                if (complete) {
-                    ld_row(en_t, 0, th); ld_row(en_p, 0, pm); ld_row(ep_t, 0, w); ld_row(ep_p, 0, Lp);
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        w[k] = w[k] - th[k];
-                        q1 = dfma(w[k], pm[k], q1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) q2 = dfma(w[k], Lp[k], q2);
-                }
-                q1 = q1 + __shfl_xor(q1, 32); q1 = q1 + __shfl_xor(q1, 16);
-                q2 = q2 + __shfl_xor(q2, 32); q2 = q2 + __shfl_xor(q2, 16);
-                s_ok = complete && (q1 >= 0.0) && (q2 >= 0.0);
-            }
+            // [ (pos - neg) . p_neg >= 0 ] * [ (pos - neg) . p_pos >= 0 ] (:286-289): taken when the far edge was the point in registers
+            const bool s_ok = complete && ((okb_(0) >> 63) & 1ull) != 0ull;
             const bool more = at_fin && s_ok && (jd + 1 < max_depth);
+            // a doubling that ends ON its far edge (depth 0 and 1: point 1 + jd is its last point) and is followed by another one of this draw:
+            // the edge is stored here, before the direction changes and the registers take the next origin
+            {
+                const bool edge_now = st_edge && more;
+                if (__ballot(edge_now) != 0ull) {
+                    if (edge_now) { st_row((vdir > 0) ? MV_TPOS_T : MV_TNEG_T, 0, th); st_row((vdir > 0) ? MV_TPOS_P : MV_TNEG_P, 0, pm); }
+                }
+            }
             if (at_fin) jd = jd + 1;                                     // :284
             const bool ended = at_fin && !more;
             bool roll = false;
@@ -685,9 +688,18 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             begin_doubling(more || roll);
             // the origin of the doubling that starts in the next tick (prev_draw, mntm_vec, P prev_draw), requested NOW: its round trip runs under
             // the record stores below, the loop head and the phase instead of in front of the next kick
-            if (more || roll) {
-                ld_row(pvec(pb), 0, th); ld_row(mv, 0, pm); ld_row(wvec(pb), 0, w);
-                org_ok = true;
+            const bool go = more || roll;
+            if (__ballot(go || from_rec) != 0ull) {
+                const int vq = MV_PT0 + 3 * ((int)cref - 1);
+                if (go) {
+                    if (from_rec) { ld_row(vq, 0, th); ld_row(vq + 2, 0, w); cp_pend = true; }
+                    else if (!from_regs) { ld_row(pvec(pb), 0, th); ld_row(wvec(pb), 0, w); }
+                    ld_row(mv, 0, pm);
+                    org_ok = true;
+                } else if (from_rec) {           // the chain waits for the phase (its row, its next momentum): prev_draw's copy now
+                    ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
+                    st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
+                }
             }
         }
         // ------------------------------------------------------------ E. the record of this tick's point, for the chains whose doubling goes on
@@ -698,6 +710,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                     const int vr = MV_PT0 + 3 * ((int)mpt - 1);
                     st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
                     *scp(mpt) = double2{ca_pt, pU};
+                    if (st_edge) {               // (a chain whose doubling ended in this tick stored it there, if the draw goes on)
+                        st_row((vdir > 0) ? MV_TPOS_T : MV_TNEG_T, 0, th); st_row((vdir > 0) ? MV_TPOS_P : MV_TNEG_P, 0, pm);
+                    }
                 }
             }
         }

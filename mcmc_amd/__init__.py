@@ -65,6 +65,7 @@ EXPORTS = [
     "mi_mcmc_hmc_run", "mi_mcmc_mala_run", "mi_mcmc_nuts_run", "mi_mcmc_rwmh_run", "mi_mcmc_rmhmc_run", "mi_mcmc_hmc_run_mass_adapted", "mi_mcmc_hmc_run_mass_adapted_per_chain", "mi_mcmc_hmc_run_callback", "mi_mcmc_mala_run_callback", "mi_mcmc_nuts_run_callback", "mi_mcmc_rwmh_run_callback", "mi_mcmc_rmhmc_run_callback",
     "mi_mcmc_draws_to_chain_major", "mi_mcmc_draws_to_chain_major_device", "mi_mcmc_shard_bounds", "mi_mcmc_allgather_draws", "mi_mcmc_allgather_draws_ragged", "mi_mcmc_merge_shards", "mi_mcmc_draw_stats",
     "mi_mcmc_allgather_draws_rank_major", "mi_mcmc_rank_major_index", "mi_mcmc_allgather_draws_begin", "mi_mcmc_allgather_draws_wait",
+    "mi_mcmc_mat_inverse", "mi_mcmc_mat_cholesky_lower",
 ]
 # test / measurement infrastructure: libmi_mcmc_probes.so (mcmc_amd/csrc/mi_mcmc_probes.h), not part of the shipped library
 PROBE_EXPORTS = ["mi_probe_mfma_f64", "mi_probe_math", "mi_probe_normals", "mi_probe_uniform", "mi_probe_fp64_peak", "mi_probe_mfma_cycles"]
@@ -413,6 +414,24 @@ def probe_mfma_cycles(waves_per_simd, use_lds, iters=20000):
     cyc, tf = C.c_double(0.0), C.c_double(0.0)
     _check(probes_lib().mi_probe_mfma_cycles(int(waves_per_simd), int(use_lds), int(iters), C.byref(cyc), C.byref(tf)))
     return cyc.value, tf.value
+
+
+def mat_inverse(A):
+    """INV of a d x d matrix as the engine computes it for a dense precond_mat (mi_mcmc_mat_inverse: the oracle's operation order; d >= 64 on the device)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    d = A.shape[0]
+    out = np.empty((d, d))
+    _check(lib().mi_mcmc_mat_inverse(C.c_void_p(A.ctypes.data), C.c_uint64(d), C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def mat_cholesky_lower(A):
+    """CHOL_LOWER likewise (mi_mcmc_mat_cholesky_lower)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    d = A.shape[0]
+    out = np.empty((d, d))
+    _check(lib().mi_mcmc_mat_cholesky_lower(C.c_void_p(A.ctypes.data), C.c_uint64(d), C.c_void_p(out.ctypes.data)))
+    return out
 
 
 def draw_stats(draws, n_keep=None, d=None, n_chains=None, mem=MEM_HOST, stream=None, want_acov=True):

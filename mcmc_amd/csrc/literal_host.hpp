@@ -33,8 +33,9 @@ inline void lit_transpose(const double* in, size_t rows, size_t cols, std::vecto
 }
 
 // algo: 0 hmc, 1 mala.  precond_mat: d*d row-major or nullptr.
-inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const double* lower, const double* upper,
-                        const double* precond_mat, LitPrep& o)
+// Returns 0, or the status of the (device) factorisation of a dense precond_mat (host_linalg.hpp).
+inline int lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const double* lower, const double* upper,
+                       const double* precond_mat, LitPrep& o)
 {
     o.bt.assign(d, 1); o.lb.assign(d, 0.0); o.ub.assign(d, 0.0);
     if (vals_bound)
@@ -57,8 +58,8 @@ inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const 
             }
         } else {
             std::vector<double> Minv, Lc;
-            host_inverse(precond_mat, d, Minv);
-            host_cholesky_lower(precond_mat, d, Lc);
+            if (int rc = host_inverse(precond_mat, d, Minv)) return rc;
+            if (int rc = host_cholesky_lower(precond_mat, d, Lc)) return rc;
             lit_transpose(precond_mat, d, d, o.Mfull);
             lit_transpose(Minv.data(), d, d, o.Minv);
             lit_transpose(Lc.data(), d, d, o.Lchol);
@@ -83,13 +84,14 @@ inline void lit_prepare(int algo, uint32_t d, double eps, int vals_bound, const 
             std::vector<double> Sigma((size_t)d * d), Ls;
             for (size_t i = 0; i < (size_t)d * d; ++i) Sigma[i] = s2 * precond_mat[i];
             std::vector<double> Sinv;
-            host_inverse(Sigma.data(), d, Sinv);
+            if (int rc = host_inverse(Sigma.data(), d, Sinv)) return rc;
             lit_transpose(Sinv.data(), d, d, o.Sinv);
-            host_cholesky_lower(Sigma.data(), d, Ls);
+            if (int rc = host_cholesky_lower(Sigma.data(), d, Ls)) return rc;
             for (uint32_t i = 0; i < d; ++i) ld = ld + 2.0 * det_log(Ls[(size_t)i * d + i]);
         }
         o.log_det = ld;
     }
+    return 0;
 }
 
 // the reduction orders of the throughput kernels: four strided fma chains per dot product; the logistic

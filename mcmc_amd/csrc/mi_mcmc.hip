@@ -48,7 +48,18 @@ namespace mi {
 namespace host {
 std::string& last_error() { thread_local std::string e; return e; }
 std::string& last_kernel() { thread_local std::string k; return k; }
+int device_inverse(const double* A, size_t d, double* Ainv);                 // linalg_device.hip
+int device_cholesky_lower(const double* A, size_t d, double* L);
 }  // namespace host
+namespace {
+// INV / CHOL_LOWER of a dense precond_mat with d >= 64 run on the device (host_linalg.hpp: same operations per element, same bits)
+const bool g_linalg_installed = [] {
+    LinalgAccel& a = linalg_accel();
+    a.inverse = host::device_inverse;
+    a.cholesky_lower = host::device_cholesky_lower;
+    return true;
+}();
+}  // namespace
 void note_kernel(const char* fmt, ...)
 {
     char buf[160];
@@ -459,7 +470,8 @@ int launch_logit(int algo, mi::LogitParams prm, const double* X_dev, const doubl
         lp.rs = prm.rs; lp.log_det = prm.log_det; lp.cons_term = prm.cons_term;
         if (dense_m) {                                   // the replay's own copies (transposed: literal_host.hpp)
             mi::lit::LitPrep prep;
-            mi::lit::lit_prepare(algo == mi::LOGIT_MALA ? 1 : 0, prm.d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+            rcw = mi::lit::lit_prepare(algo == mi::LOGIT_MALA ? 1 : 0, prm.d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+            if (rcw) return rcw;
             rcw = lit_upload(prep, prm.d, false, ldev, lp);      // (mala: INV(Sigma), LOG_DET and the constant term with it)
             if (rcw) return rcw;
         }
@@ -535,9 +547,9 @@ int general_tables(const char* who, const mi_settings* s, uint64_t d, GeneralTab
     if (g.dense) {
         if (d > 64 && !dense_beyond_64) return fail(MI_ERR_UNSUPPORTED, "%s: a dense precond_mat / cov_mat is implemented for d <= 64 (diagonal: d <= 128)", who);
         std::vector<double> Minv, L;
-        host_inverse(s->precond_mat, d, Minv);
-        host_cholesky_lower(s->precond_mat, d, L);
-        int rcu = upload_matrix(Minv, d, g.minv_full); if (rcu) return rcu;
+        int rcu = host_inverse(s->precond_mat, d, Minv); if (rcu) return rcu;
+        rcu = host_cholesky_lower(s->precond_mat, d, L); if (rcu) return rcu;
+        rcu = upload_matrix(Minv, d, g.minv_full); if (rcu) return rcu;
         rcu = upload_matrix(L, d, g.l_full); if (rcu) return rcu;
     }
     std::vector<int> bt(d, 1);
@@ -651,8 +663,9 @@ int run_literal(const char* who, int algo, const mi_target* target, const mi_set
     rp.work = ws.as<double>();
     lit_common(lp, settings, &sc.dev, rp, true);
     mi::lit::LitPrep prep;
-    mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
-                         settings->upper_bounds, algo == 4 ? nullptr : settings->precond_mat, prep);     // (rmhmc has no precond_mat)
+    rc = mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
+                              settings->upper_bounds, algo == 4 ? nullptr : settings->precond_mat, prep);     // (rmhmc has no precond_mat)
+    if (rc) return rc;
     lp.n_fp_steps = (uint32_t)settings->n_fp_steps;
     LitDev ldev;
     rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
@@ -733,7 +746,8 @@ struct MalaDiagMass { DevBuf m, ms, sinv; double log_det = 0.0; };
 int mala_diag_mass_upload(const mi_settings* settings, uint64_t d, MalaDiagMass& t, mi::LogitParams& q)
 {
     mi::lit::LitPrep prep;
-    mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+    const int rcp = mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+    if (rcp) return rcp;
     std::vector<double> m(512, 1.0), ms(512, 1.0), si(512, 1.0);
     for (uint64_t i = 0; i < d; ++i) { m[i] = prep.m[i]; ms[i] = prep.m_sqrt[i]; si[i] = prep.sinv_diag[i]; }
     HIP_TRY(t.m.alloc(512 * 8)); HIP_TRY(t.ms.alloc(512 * 8)); HIP_TRY(t.sinv.alloc(512 * 8));
@@ -799,15 +813,15 @@ int lds_dense_m(const mi_settings* settings, uint64_t d, LdsDenseM& t, mi::Logit
     };
     int rc;
     std::vector<double> L;
-    host_cholesky_lower(settings->precond_mat, d, L);
+    if ((rc = host_cholesky_lower(settings->precond_mat, d, L))) return rc;
     if ((rc = up(t.l, L.data()))) return rc;
     q.L_rm = t.l.as<double>();
     if (algo == mi::LOGIT_MALA) {
         const double s2 = settings->step_size * settings->step_size;
         std::vector<double> Sigma(d * d), Sinv, Ls;
         for (uint64_t i = 0; i < d * d; ++i) Sigma[i] = s2 * settings->precond_mat[i];
-        host_inverse(Sigma.data(), d, Sinv);
-        host_cholesky_lower(Sigma.data(), d, Ls);
+        if ((rc = host_inverse(Sigma.data(), d, Sinv))) return rc;
+        if ((rc = host_cholesky_lower(Sigma.data(), d, Ls))) return rc;
         double ld = 0.0;
         for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(Ls[i * d + i]);
         q.log_det = ld;
@@ -816,7 +830,7 @@ int lds_dense_m(const mi_settings* settings, uint64_t d, LdsDenseM& t, mi::Logit
         q.M_rm = t.m.as<double>(); q.Sinv_rm = t.sinv.as<double>();
     } else {
         std::vector<double> Minv;
-        host_inverse(settings->precond_mat, d, Minv);
+        if ((rc = host_inverse(settings->precond_mat, d, Minv))) return rc;
         if ((rc = up(t.minv, Minv.data()))) return rc;
         q.Minv_rm = t.minv.as<double>();
     }
@@ -1096,10 +1110,11 @@ int literal_run_callback(const char* who, int algo, const double* initial_vals, 
         lp.step_out = step.as<double>();
     }
     mi::lit::LitPrep prep;
-    mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds, settings->upper_bounds,
-                         algo == 4 ? nullptr : settings->precond_mat, prep);
+    int rc = mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds, settings->upper_bounds,
+                                  algo == 4 ? nullptr : settings->precond_mat, prep);
+    if (rc) return rc;
     LitDev ldev;
-    int rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
+    rc = lit_upload(prep, (uint32_t)d, settings->vals_bound != 0, ldev, lp);
     if (rc) return rc;
     hipStream_t st = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1273,8 +1288,31 @@ int mi_mcmc_run_user_target_v(int algo, uint64_t d, mi_small_launch_fn launch, c
     return mi_mcmc_run_user_target(algo, d, launch, target_pod, small_params_bytes, settings, chains, stream);
 }
 
+int mi_mcmc_mat_inverse(const double* A, uint64_t d, double* Ainv)
+{
+    if (!A || !Ainv) return fail(MI_ERR_BAD_ARG, "mat_inverse: NULL matrix");
+    if (d >= linalg_accel().min_d && mi_mcmc_device_count() < 1) return fail(MI_ERR_NO_DEVICE, "mat_inverse: no GPU visible (d >= 64 runs on the device)");
+    std::vector<double> out;
+    const int rc = host_inverse(A, (size_t)d, out);
+    if (rc) return rc;
+    std::memcpy(Ainv, out.data(), (size_t)d * d * sizeof(double));
+    return MI_OK;
+}
+
+int mi_mcmc_mat_cholesky_lower(const double* A, uint64_t d, double* L)
+{
+    if (!A || !L) return fail(MI_ERR_BAD_ARG, "mat_cholesky_lower: NULL matrix");
+    if (d >= linalg_accel().min_d && mi_mcmc_device_count() < 1) return fail(MI_ERR_NO_DEVICE, "mat_cholesky_lower: no GPU visible (d >= 64 runs on the device)");
+    std::vector<double> out;
+    const int rc = host_cholesky_lower(A, (size_t)d, out);
+    if (rc) return rc;
+    std::memcpy(L, out.data(), (size_t)d * d * sizeof(double));
+    return MI_OK;
+}
+
 int mi_mcmc_release_workspace(void* stream, int all_streams, uint64_t* bytes_freed)
 {
+    linalg_memo_clear();         // the calling thread's two memoised inverses of a precond_mat (host_linalg.hpp: 2 MiB each at d = 512)
     return ws_release(static_cast<hipStream_t>(stream), all_streams != 0, bytes_freed);
 }
 
@@ -1490,8 +1528,8 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         DevBuf minv_dev, l_dev;
         if (dense_m) {
             std::vector<double> Minv, L;
-            host_inverse(settings->precond_mat, d, Minv);
-            host_cholesky_lower(settings->precond_mat, d, L);
+            rc = host_inverse(settings->precond_mat, d, Minv); if (rc) return rc;
+            rc = host_cholesky_lower(settings->precond_mat, d, L); if (rc) return rc;
             rc = upload_matrix(Minv, d, minv_dev); if (rc) return rc;
             rc = upload_matrix(L, d, l_dev); if (rc) return rc;
             prm.Minv = minv_dev.as<double>(); prm.Lchol = l_dev.as<double>();
@@ -1864,8 +1902,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         if (rc) return rc;
         lit_common(lp, settings, &sc.dev, rp, literal_only);
         mi::lit::LitPrep prep;
-        mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
-                             settings->upper_bounds, settings->precond_mat, prep);
+        rc = mi::lit::lit_prepare(1, (uint32_t)d, settings->step_size, settings->vals_bound ? 1 : 0, settings->lower_bounds,
+                                  settings->upper_bounds, settings->precond_mat, prep);
+        if (rc) return rc;
         rc = lit_upload(prep, (uint32_t)d, mala_bounded, ldev, lp);
         if (rc) return rc;
         prm.nf_flag = rp.flag;
@@ -1877,8 +1916,8 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
         // dense precond_mat, unbounded: Sigma = eps^2 M is constant, so INV / CHOL_LOWER / LOG_DET come from the host once
         std::vector<double> Sigma(d * d), Sinv, Ls;
         for (uint64_t i = 0; i < d * d; ++i) Sigma[i] = prm.s2 * settings->precond_mat[i];
-        host_inverse(Sigma.data(), d, Sinv);
-        host_cholesky_lower(Sigma.data(), d, Ls);
+        rc = host_inverse(Sigma.data(), d, Sinv); if (rc) return rc;
+        rc = host_cholesky_lower(Sigma.data(), d, Ls); if (rc) return rc;
         double ld = 0.0;
         for (uint64_t i = 0; i < d; ++i) ld = ld + 2.0 * mi::det_log(Ls[i * d + i]);
         prm.log_det = ld;
@@ -1968,7 +2007,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
         prm.c_diag = c_dev.as<double>();
         if (gt.dense) {
             std::vector<double> L;
-            host_cholesky_lower(settings->precond_mat, d, L);
+            rc = host_cholesky_lower(settings->precond_mat, d, L); if (rc) return rc;
             for (auto& v : L) v = prm.par_scale * v;
             rc = upload_matrix(L, d, lc_dev); if (rc) return rc;
             prm.Lc = lc_dev.as<double>();

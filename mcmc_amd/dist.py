@@ -7,6 +7,7 @@ bit-identical to one big call.  The only exchange is the optional collation of d
 all-gather of the [n_keep][d][C_r] slabs -- RCCL over xGMI on GPUs, fed from and received into HBM
 (no host round trip); gloo in the CPU tests.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -214,3 +215,86 @@ def run_sharded(algo, kind, init_fn, n_chains_total, settings, runner=None, coll
     if engine:
         return all_draws.to(dev), all_acc.to(dev)
     return all_draws.numpy(), all_acc.numpy()
+
+
+# ---- the C-ABI collation (include/mi_mcmc.h: mi_mcmc_allgather_draws_rank_major, _begin / _wait) under a torch.distributed launch ----------------
+# The C entry points take the caller's ncclComm_t.  A torch process group does not hand its communicator out, so a rank builds one next to it:
+# rank 0 makes the ncclUniqueId, the process group (any backend) carries its 128 bytes to the others, every rank calls ncclCommInitRank --
+# in the librccl torch has already mapped (the engine's dlopen("librccl.so.1") resolves to the same image).
+
+class _NcclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+
+
+class RcclComm:
+    """An RCCL communicator of this rank's process group for the C ABI's collation calls.  `solo=True`: a ONE-rank communicator on the
+    current device (what a box with one GPU can build: two ranks of one communicator on one device are refused by RCCL)."""
+
+    def __init__(self, group=None, solo=False):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        self._rccl = C.CDLL("librccl.so.1")
+        self.comm = C.c_void_p(0)
+        if solo or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            self.world, self.rank = 1, 0
+            dev = (C.c_int * 1)(torch.cuda.current_device())
+            rc = self._rccl.ncclCommInitAll(C.byref(self.comm), 1, dev)
+        else:
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+            uid = _NcclUniqueId()
+            if self.rank == 0:
+                rc0 = self._rccl.ncclGetUniqueId(C.byref(uid))
+                if rc0 != 0:
+                    raise RuntimeError(f"ncclGetUniqueId failed ({rc0})")
+            box = [bytes(uid.internal) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            C.memmove(C.byref(uid), box[0], 128)
+            self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            rc = self._rccl.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+        if rc != 0 or not self.comm.value:
+            raise RuntimeError(f"RCCL communicator of {self.world} rank(s) could not be built (ncclResult {rc})")
+
+    def close(self):
+        if self.comm is not None and self.comm.value:
+            self._rccl.ncclCommDestroy(self.comm)
+        self.comm = None
+
+
+def collate_rank_major(comm, local_draws, n_chains_total, out=None, stream=None):
+    """mi_mcmc_allgather_draws_rank_major: this rank's slab [n_keep][d][n_local] (HBM) -> all_rank_major (HBM; SURVEY 8(e)'s receive layout
+    [G][n_keep][d][C / G] for equal shards, packed shard after shard otherwise).  Enqueued on `stream`; returns the flat receive tensor."""
+    import ctypes as C
+    import torch
+    import mcmc_amd
+    n_keep, d = int(local_draws.shape[0]), int(local_draws.shape[1])
+    if out is None:
+        out = torch.empty(n_keep * d * int(n_chains_total), dtype=torch.float64, device=local_draws.device)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    mcmc_amd._check(mcmc_amd.lib().mi_mcmc_allgather_draws_rank_major(
+        comm.comm, C.c_uint32(comm.world), C.c_uint32(comm.rank), C.c_void_p(local_draws.data_ptr()), C.c_uint64(n_keep), C.c_uint64(d),
+        C.c_uint64(int(n_chains_total)), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    return out
+
+
+def collate_begin(comm, slab, n_chains_total, row0, n_keep_total, out, producer_stream=None):
+    """mi_mcmc_allgather_draws_begin: the gather of kept rows [row0, row0 + slab.shape[0]) is ordered behind the producer stream's work so far
+    and runs on the library's communication stream; returns the handle for collate_wait.  The caller keeps `slab` alive and untouched."""
+    import ctypes as C
+    import torch
+    import mcmc_amd
+    producer_stream = torch.cuda.current_stream().cuda_stream if producer_stream is None else producer_stream
+    h = C.c_void_p(0)
+    mcmc_amd._check(mcmc_amd.lib().mi_mcmc_allgather_draws_begin(
+        comm.comm, C.c_uint32(comm.world), C.c_uint32(comm.rank), C.c_void_p(slab.data_ptr()), C.c_uint64(int(slab.shape[0])),
+        C.c_uint64(int(slab.shape[1])), C.c_uint64(int(n_chains_total)), C.c_uint64(int(row0)), C.c_uint64(int(n_keep_total)),
+        C.c_void_p(out.data_ptr()), C.c_void_p(producer_stream), C.byref(h)))
+    return h
+
+
+def collate_wait(handle, consumer_stream=None, block_host=False):
+    import ctypes as C
+    import torch
+    import mcmc_amd
+    consumer_stream = torch.cuda.current_stream().cuda_stream if consumer_stream is None else consumer_stream
+    mcmc_amd._check(mcmc_amd.lib().mi_mcmc_allgather_draws_wait(handle, C.c_void_p(consumer_stream), C.c_int(1 if block_host else 0)))

@@ -54,7 +54,7 @@ def test_struct_sizes_and_defaults_match_reference_settings():
     assert (s.n_adapt_draws, s.target_accept_rate, s.max_tree_depth) == (1000, 0.55, 10)
     assert (s.gamma_val, s.t0_val, s.kappa_val) == (0.05, 10.0, 0.75)
     assert s.vals_bound == 0 and not s.precond_mat
-    assert mcmc_amd.lib().mi_mcmc_version() == 0x000500
+    assert mcmc_amd.lib().mi_mcmc_version() == 0x000600
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

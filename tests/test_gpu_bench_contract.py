@@ -54,6 +54,22 @@ def test_two_rank_code_path():
     # north_star: strong scaling -- with WORLD_SIZE > 1 the total chain count is fixed and sharded (8193: ragged, nothing dropped)
     assert j["n_gpus"] == 2 and j["config"]["chains_total"] == 8193 and j["config"]["chains_per_gpu"] == 4097 and j["scaling"] == "strong"
     assert j["value"] > 0
+    _collation_on_the_line(j, shared_device=True)
+
+
+def _collation_on_the_line(j, shared_device):
+    """a line of more than one rank ALWAYS carries the collation of draws_out, through the C ABI: `value` (sampling only),
+    `value_incl_collation` (then one blocking all-gather), `value_overlapped` (4 chunks, _begin / _wait), `collate_GBps`, the RCCL rank count."""
+    assert 0 < j["value_incl_collation"] < j["value"]
+    assert j["value_overlapped"] > 0 and j["collate_GBps"] > 0
+    c = j["collation"]
+    assert "mi_mcmc_allgather_draws_rank_major" in c["abi"] and "mi_mcmc_allgather_draws_begin" in c["abi"]
+    assert c["blocking_ms"] > 0 and c["overlapped_total_ms"] > 0 and c["overlapped_chunks"] == 4
+    assert c["own_shard_in_place"] is True and c["overlapped_equals_blocking_run"] is True
+    if shared_device:          # two ranks on ONE device: RCCL refuses them in one communicator, each rank collates over its own
+        assert c["rccl_ranks"] == 1 and "NOT a multi-GPU collation" in c["note"]
+    else:
+        assert c["rccl_ranks"] == j["n_gpus"]
 
 
 def test_gpus_flag_alone_launches_the_ranks():
@@ -66,6 +82,9 @@ def test_gpus_flag_alone_launches_the_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
     assert j["n_gpus"] == 2 and j["ranks"]["world_size"] == 2 and j["config"]["chains_per_gpu"] == 4096 and j["scaling"] == "strong"
+    _collation_on_the_line(j, shared_device=True)
+    # rank 0's roofline quotes the committed counter pass of ONE GPU'S SHARE when there is one of this kernel (traffic is not null at N > 1)
+    assert "traffic" in j["roofline"]
 
 
 def test_gpus_flag_refuses_more_ranks_than_devices():
@@ -79,16 +98,14 @@ def test_gpus_flag_refuses_more_ranks_than_devices():
     assert "refusing" in out.stderr
 
 
-def test_collate_reports_the_blocking_and_the_overlapped_gather():
-    """--collate: the RCCL all-gather of the kept draws, blocking and overlapped with the sampling (four chunks through mi_chains.draw0);
-    on this box a 1-rank group."""
+def test_collate_flag_runs_the_c_abi_collation_on_one_rank():
+    """--collate at one GPU: the same C-ABI calls over a one-rank communicator (the code path, not a transfer)."""
     out = subprocess.run([sys.executable, "bench.py", "--collate", "--steps", "1", "--warmup", "0", "--chains", "4096", "--no-cpu-baseline",
                           "--traffic", "none", "--no-ess"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     j = _line(out.stdout)
-    assert j["collate_allgather_ms"] > 0 and j["collate_bytes_per_rank"] == 100 * 128 * 4096 * 8
-    ov = j["collate_overlapped"]
-    assert ov["chunks"] == 4 and ov["sampling_plus_gather_ms"] > 0 and ov["blocking_equivalent_ms"] > 0
+    assert j["collation"]["bytes_received_per_rank"] == 100 * 128 * 4096 * 8 and j["collation"]["rccl_ranks"] == 1
+    _collation_on_the_line(j, shared_device=False)
 
 
 @pytest.mark.parametrize("config,bound", [(3, "mfma"), (4, "mfma"), (5, "valu-fp64")])

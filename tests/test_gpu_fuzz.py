@@ -9,13 +9,16 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [7, 11])
+SLOW = pytest.mark.gpu_slow      # the second / larger slice of a sweep: -m gpu_slow (the first slice stays in the default suite)
+
+
+@pytest.mark.parametrize("seed", [7, pytest.param(11, marks=SLOW)])
 def test_random_cases_are_bit_exact(seed):
     import fuzz_parity
     assert fuzz_parity.sweep(60, seed, verbose=False) == 0
 
 
-@pytest.mark.parametrize("seed", [3, 5])
+@pytest.mark.parametrize("seed", [3, pytest.param(5, marks=SLOW)])
 def test_random_normal_model_cases_are_bit_exact(seed):
     """hmc / mala / rwmh / rmhmc / nuts on the one-lane-per-chain engine (d = 2 normal model)"""
     import fuzz_parity
@@ -38,19 +41,20 @@ def test_nuts_on_the_lds_streamed_evaluation_random_cases(seed):
     assert fuzz_nuts_lds.sweep(16, seed, verbose=False) == 0
 
 
-def test_per_chain_mass_sweep_is_bit_exact():
+@pytest.mark.parametrize("n", [6, pytest.param(16, marks=SLOW)])
+def test_per_chain_mass_sweep_is_bit_exact(n):
     """hmc with mi_chains.mass_diag: chain c against the oracle with precond_mat = diag(mass[:, c]), random targets / sizes / bounds /
     non-finite starts (elementwise and literal kernels)"""
     import fuzz_parity
-    assert fuzz_parity.sweep_mass(16, 3, verbose=False) == 0
+    assert fuzz_parity.sweep_mass(n, 3, verbose=False) == 0
 
 
-@pytest.mark.parametrize("seed", [5])
-def test_general_variants_with_chains_started_non_finite(seed):
+@pytest.mark.parametrize("n", [40, pytest.param(120, marks=SLOW)])
+def test_general_variants_with_chains_started_non_finite(n):
     """bounds / diagonal / dense precond_mat x dense / diag / iso targets x dimensions that do not fill their tiles x chains that start at
     +-inf / NaN / 1e300 (tests/fuzz_nonfinite_general.py; round 5: caught mala_gauss_dense_m_kernel on ISO / DIAG targets)"""
     import fuzz_nonfinite_general
-    assert fuzz_nonfinite_general.sweep(120, seed, verbose=False) == 0
+    assert fuzz_nonfinite_general.sweep(n, 5, verbose=False) == 0
 
 
 def test_hmc_with_a_dense_precond_mat_on_the_streamed_kernels_random_cases():

@@ -88,7 +88,8 @@ def _oracle_per_chain(kind, d, prec, init, mass, seed, burn, keep, L, eps, **okw
     return draws, nacc
 
 
-@pytest.mark.parametrize("case", ["diag_elementwise", "iso_elementwise_d1", "dense_mfma_d20", "dense_mfma_d100", "dense_bounded_literal", "diag_bounded_literal"])
+@pytest.mark.parametrize("case", ["diag_elementwise", "iso_elementwise_d1", "dense_mfma_d20", "dense_mfma_d100",
+                                  pytest.param("dense_mfma_d100_wide", marks=pytest.mark.gpu_slow), "dense_bounded_literal", "diag_bounded_literal"])
 def test_per_chain_masses_are_c_calls_of_hmc_with_their_own_precond_mat(case):
     rng = np.random.default_rng(7)
     burn, keep, L, eps, C = 3, 6, 5, 0.2, 70
@@ -98,7 +99,7 @@ def test_per_chain_masses_are_c_calls_of_hmc_with_their_own_precond_mat(case):
     elif case == "iso_elementwise_d1":
         d = 1; prec = None; kg, ko = mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO
     elif case.startswith("dense_mfma"):                      # round 4: per-chain tables on the MFMA kernel (hmc_gauss_mfma_kernel<., ., false, false, true, true>)
-        d = 20 if case.endswith("d20") else 100; C = 9 if d == 20 else 150
+        d = 20 if case.endswith("d20") else 100; C = 9 if d == 20 else (150 if case.endswith("wide") else 40)     # (the oracle runs chain by chain: 150 chains are 18 s)
         prec = synth.dense_gaussian_precision(d, seed=4); kg, ko = mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
     elif case == "dense_bounded_literal":
         d = 20; C = 9; prec = synth.dense_gaussian_precision(d, seed=4); kg, ko = mcmc_amd.TARGET_GAUSS_DENSE, orc.TARGET_DENSE
@@ -110,7 +111,7 @@ def test_per_chain_masses_are_c_calls_of_hmc_with_their_own_precond_mat(case):
         kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
     init = np.clip(synth.initial_states(C, d, seed=3) * 0.5, -1.0, 1.5)
     mass = np.ascontiguousarray(rng.uniform(0.2, 5.0, (d, C)))
-    if case in ("diag_elementwise", "dense_mfma_d100"): init[1, 0] = 1e200      # one chain of the throughput kernels leaves the finite regime: replayed literally
+    if case in ("diag_elementwise", "dense_mfma_d100", "dense_mfma_d100_wide"): init[1, 0] = 1e200      # one chain of the throughput kernels leaves the finite regime: replayed literally
     st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=eps, **kw)
     t = mcmc_amd.make_target(kg, d, prec=prec)
     theta = np.ascontiguousarray(init.T.copy()); draws = np.zeros((keep, d, C)); nacc = np.zeros(C, dtype=np.uint64)

@@ -52,8 +52,10 @@ CASES = [
 # the register-carried kernels of rounds 2-4, retired in round 5: valid hints, ignored -- the default kernel runs.  KERNEL_NUTS_TICK_LOCAL: the
 # tick-local asynchronous kernel (what the bounded / preconditioned variants run; it executes every leaf) -- an independent implementation that must
 # give the same bits.  (The lock-step first-generation kernel is only in the A/B library: `make prof`.)
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_DYN,
-           mcmc_amd.KERNEL_NUTS_MEMO]
+# (round 6: the full matrix runs on AUTO, KERNEL_NUTS_MEMO and KERNEL_NUTS_TICK_LOCAL; the three retired hints run the SAME kernel as AUTO and
+#  are checked for exactly that -- accepted, ignored -- on one case: test_retired_hints_run_the_default_kernel)
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO]
+RETIRED = [mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_DYN]
 
 
 @pytest.mark.parametrize("hint", KERNELS)
@@ -88,6 +90,19 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
         assert (g["n_exec"] <= g["n_leap"]).all()
     else:
         assert np.array_equal(g["n_exec"], g["n_leap"])     # every other kernel executes what it counts
+
+
+@pytest.mark.parametrize("hint", RETIRED)
+def test_retired_hints_run_the_default_kernel(hint):
+    d, C = 128, 70
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=21)
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=3, n_keep_draws=4, n_adapt_draws=4)
+    a, ga = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=mcmc_amd.KERNEL_AUTO)
+    name = mcmc_amd.last_kernel()
+    b, gb = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=hint)
+    assert mcmc_amd.last_kernel() == name and name.startswith("nuts_gauss_memo_kernel")
+    assert np.array_equal(a, b) and np.array_equal(ga["n_exec"], gb["n_exec"])
 
 
 def test_nuts_sharding_independence_and_statistics():

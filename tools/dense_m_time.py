@@ -26,7 +26,13 @@ def run(kind, d, Cn, L, nd, hint, N=1024, algo="hmc"):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     fl = float(Cn) * nd * (L * flop_leap + 3 * 2 * d * d)   # + L z and the two kinetic products per draw
     if algo == "mala": fl = float(Cn) * nd * ((flop_leap - 2 * d * d) + 4 * 2 * d * d)      # one evaluation + M grad, L z, two INV(Sigma) products
-    print(f"{algo} {kind} d={d} C={Cn} L={L} draws={nd}: {dt * 1e3:.1f} ms, kernel {mcmc_amd.last_kernel()}, {fl / dt / 1e12:.2f} TFLOP/s algorithmic", flush=True)
+    # ... and a call that finds nothing memoised: a NEW precond_mat (INV / CHOL_LOWER on the device, round 6: linalg_device.hip)
+    st2 = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=nd // 2, n_keep_draws=nd - nd // 2, n_leap_steps=L, step_size=0.03, precond_mat=M * 1.0009765625)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mcmc_amd.run(algo, tgt, st2, ch)
+    torch.cuda.synchronize(); dt_new = time.perf_counter() - t0
+    print(f"{algo} {kind} d={d} C={Cn} L={L} draws={nd}: {dt * 1e3:.1f} ms (new precond_mat: {dt_new * 1e3:.1f} ms), kernel {mcmc_amd.last_kernel()}, {fl / dt / 1e12:.2f} TFLOP/s algorithmic"
+          f" ({fl / dt_new / 1e12:.2f} with the factorisations)", flush=True)
     return dt
 
 for kind, d, Cn, L, nd in [("dense", 256, 8192, 16, 20), ("dense", 512, 8192, 16, 10), ("logit", 512, 8192, 8, 10), ("dense", 256, 65536, 16, 20)]:
