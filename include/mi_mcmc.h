@@ -161,8 +161,12 @@ typedef struct mi_chains {
                                * mcmc::hmc with precond_mat = diag(mass_diag[:, c]) in one launch).  settings.precond_mat must be
                                * NULL.  Separable Gaussian targets without bounds run on the elementwise kernels (any d), everything
                                * else on the literal kernels.  See mi_mcmc_hmc_run_mass_adapted_per_chain. */
-    uint64_t* n_leapfrogs_executed; /* out [C], may be NULL: the leapfrog steps the device really computed.  Equal to n_leapfrogs except for nuts on
-                               * MI_KERNEL_NUTS_MEMO, which computes every distinct state of a doubling once (same draws, fewer steps) */
+    uint64_t* n_leapfrogs_executed; /* out [C], may be NULL (needs n_leapfrogs next to it): the leapfrog steps the device really computed.
+                               * Equal to n_leapfrogs except for nuts on the MEMOISED tick -- the default of the plain and diagonal-mass
+                               * Gaussian case, of the built-in Gaussian with vals_bound and of nuts on tile targets -- which computes every
+                               * distinct state of a doubling once (same draws, fewer steps).  (MI_KERNEL_NUTS_MEMO is accepted and
+                               * equivalent to MI_KERNEL_AUTO: the memoised tick is what runs unless MI_KERNEL_NUTS_TICK_LOCAL or
+                               * MI_KERNEL_NUTS_LOCKSTEP asks for the kernel that executes every leaf.) */
 } mi_chains;
 
 void        mi_settings_default(mi_settings* s);

@@ -15,6 +15,10 @@
                                  // 15 chains of its wave do not wait for a 32-leaf walk).  0 = no limit.  Measured on configs[3]: 0: 578 ms, 6: 569, 8: 563, 12: 568
 #endif
 
+#ifndef MI_MEMO_RNG_ILP
+#define MI_MEMO_RNG_ILP 1        // Box-Muller pairs per iteration of the momentum loop.  Measured on configs[3] (NT = 8): 1: 518 ms; 2: 28 B of scratch; 4: 548 ms (no scratch, but the interleaved pairs push 15 more state registers through the AGPRs around the loop)
+#endif
+
 #include "hmc_dense.hpp"
 
 namespace mi {
@@ -329,7 +333,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     };
 
 #ifdef MI_NUTS_REG_PROF   // phase clocks of block 0, wave 0 (tools/nuts_prof.py; a variant build, never the shipped library)
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ticks = 0, n_active = 0, n_walk_it = 0, n_pair_it = 0;
     unsigned long long tmark = clock64();
 #define MI_MPROF(k) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn_ = clock64(); pc[k] += tn_ - tmark; tmark = tn_; }
@@ -345,6 +349,18 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (__ballot(cp_pend) != 0ull) {
             if (cp_pend) { st_row(pvec(pb), 0, th); st_row(wvec(pb), 0, w); }
             cp_pend = false;
+        }
+        // the kept row of the draw a chain left in the last tick (src/nuts.cpp:306-309: prev_draw after the draw) IS the origin of its next draw, which
+        // the registers hold: stored from there -- no row waits for a phase, so a chain whose next momentum is ready never waits at a draw boundary
+        if (__ballot(row_pend) != 0ull) {
+            if (row_pend) {
+                double* out = prm.draws + (size_t)(row_draw - prm.n_burnin) * d * C;
+                const size_t lane_off = (size_t)j4 * C + cl;
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if (dim_ok(k)) (out + (size_t)(4 * k) * C)[lane_off] = pol.leave(th[k], k);
+            }
+            row_pend = false;
         }
         if constexpr (POL::REPLAY) retire(state != NS_DONE && nf_() != 0.0);   // a flagged chain is replayed from its initial state: nothing of it is kept
         // ------------------------------------------------------------ free slots take the next chains
@@ -368,23 +384,31 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (__ballot(state != NS_DONE) == 0ull) break;
         // ------------------------------------------------------------ A. the phase: rows, momenta ahead, waiting chains start
         if (__ballot(state == NS_NEED_DRAW) != 0ull) {
-            store_row(row_pend, pvec(pb0), row_draw);
-            store_row(row2_pend, pvec(pb), draw - 1u);
-            row_pend = false; row2_pend = false;
+            store_row(row2_pend, pvec(pb), draw - 1u);       // (a chain that did not go straight on: its last draw's row, from prev_draw in memory)
+            row2_pend = false;
             retire(state == NS_NEED_DRAW && draw >= n_total);
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
             const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
+            // (MI_MEMO_RNG_ILP Box-Muller pairs per iteration: a pair is ~250 dependent operations -- Philox rounds, log, sqrt, sincos -- and a wave that is
+            //  alone on its SIMD waits out every result latency; independent pairs in one basic block interleave)
+            constexpr int RILP = (MI_MEMO_RNG_ILP < NS / 2) ? MI_MEMO_RNG_ILP : NS / 2;
 #pragma unroll 1
-            for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
-                double z0, z1;
-                rng_normal_pair(prm.seed, prm.chain0 + cl, nidx + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
-                double pa = (8u * b + j4 < d) ? z0 : 0.0;
-                double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                pa = pol.msqrt_times(pa, 8 * b + j4); pb_ = pol.msqrt_times(pb_, 8 * b + 4 + j4);       // :202: p = sqrt(M) z
-                kq = dfma(pa, pol.minv_times(pa, 8 * b + j4), kq);                                       // :204: K = p . (Minv p) / 2
-                kq = dfma(pb_, pol.minv_times(pb_, 8 * b + 4 + j4), kq);
-                if (gen) st_pair(mvn, 2 * b, pa, pb_);
+            for (int b0 = 0; b0 < NS / 2; b0 += RILP) {               // nuts.cpp:200-202, this chain's own draw index
+                double zz[2 * RILP];
+#pragma unroll
+                for (int q = 0; q < RILP; ++q)
+                    rng_normal_pair(prm.seed, prm.chain0 + cl, nidx + prm.draw0, (uint32_t)(4 * (b0 + q) + j4), STREAM_NORMAL, zz[2 * q], zz[2 * q + 1]);
+#pragma unroll
+                for (int q = 0; q < RILP; ++q) {
+                    const int b = b0 + q;
+                    double pa = (8u * b + j4 < d) ? zz[2 * q] : 0.0;
+                    double pb_ = (8u * b + 4 + j4 < d) ? zz[2 * q + 1] : 0.0;
+                    pa = pol.msqrt_times(pa, 8 * b + j4); pb_ = pol.msqrt_times(pb_, 8 * b + 4 + j4);       // :202: p = sqrt(M) z
+                    kq = dfma(pa, pol.minv_times(pa, 8 * b + j4), kq);                                       // :204: K = p . (Minv p) / 2
+                    kq = dfma(pb_, pol.minv_times(pb_, 8 * b + 4 + j4), kq);
+                    if (gen) st_pair(mvn, 2 * b, pa, pb_);
+                }
             }
             kq = kq + __shfl_xor(kq, 32);
             kq = kq + __shfl_xor(kq, 16);
@@ -440,8 +464,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         // ... and, as "level 0", the TOP-LEVEL test of src/nuts.cpp:286-289 when this point is the doubling's far edge (point 1 + jd): its operands
         // are this point and the OTHER side's edge, which no tick of this doubling writes -- evaluated here, with the point in registers, it costs
         // two row loads that mostly travel under the mat-vec instead of four behind the walk (result: bit 63 of okb_(0), read at the doubling's end)
-        const bool st_edge = newpt && mpt == 1u + jd;
-        uint32_t pmask = newpt ? ((uint32_t)lds_pm[jd * 48u + mpt] | (st_edge ? 1u : 0u)) : 0u;
+        uint32_t pmask = newpt ? ((uint32_t)lds_pm[jd * 48u + mpt] | ((mpt == 1u + jd) ? 1u : 0u)) : 0u;
         // the (theta, p) vectors of the other point of a test: level l >= 1: the record of point mpt - l; level 0: the other edge (draw_neg / mntm_neg
         // for a forward doubling, _pos for a backward one) -- the draw's initial vectors until a doubling has written that side
         auto test_vecs = [&](int l, int& vt, int& vp) __attribute__((always_inline)) {
@@ -524,6 +547,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             okb_(11) = (okb_(11) & ~bit) | (cs_b ? bit : 0ull);
             n_exec_() += 1ull;
         }
+        MI_MPROF(8)
         // ---- the tests whose second point this is: [ d . p(n1) >= 0 ] * [ d . p(mpt) >= 0 ], d = theta(mpt) - theta(n1) by direction (:224-229).
         //      LOADS ONLY between here and the end of the walk: memory operations of a wave complete in order, and a load behind the 3 KB of a
         //      record store waits for all of it (measured: 10 k cycles per test that way)
@@ -567,6 +591,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         // the tree's far edge (= the first leaf of its second half, point 1 + jd; the leaf itself at depth 0) is what a successful doubling leaves
         // in draw_pos / draw_neg (src/nuts.cpp:241-256); a doubling that fails before that leaf ends the draw, so writing it early is harmless.
         // Nothing of this doubling reads it (its top-level test was taken above, from the registers): it is stored with the record, at the END of the tick
+        const bool st_edge = newpt && mpt == 1u + jd;    // (re-derived here: one lane mask less to carry across the mat-vec)
         if (st_edge) { if (vdir > 0) pos_init = false; else neg_init = false; }
         if (newpt) npts = mpt;
         MI_MPROF(3)
@@ -690,18 +715,21 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             // the record stores below, the loop head and the phase instead of in front of the next kick
             const bool go = more || roll;
             if (__ballot(go || from_rec) != 0ull) {
-                const int vq = MV_PT0 + 3 * ((int)cref - 1);
+                // an accepted proposal that is an earlier point of the trajectory: its record comes INTO THE REGISTERS -- as the next origin when the
+                // chain goes on at once, and in any case as the source of prev_draw's copy at the top of the next tick (cp_pend: stored from there before
+                // the phase reads prev_draw for the chain's row or its exit) -- so the tick has no load-wait-store copy at all
+                if (from_rec) {
+                    const int vq = MV_PT0 + 3 * ((int)cref - 1);
+                    ld_row(vq, 0, th); ld_row(vq + 2, 0, w); cp_pend = true;
+                }
                 if (go) {
-                    if (from_rec) { ld_row(vq, 0, th); ld_row(vq + 2, 0, w); cp_pend = true; }
-                    else if (!from_regs) { ld_row(pvec(pb), 0, th); ld_row(wvec(pb), 0, w); }
+                    if (!take) { ld_row(pvec(pb), 0, th); ld_row(wvec(pb), 0, w); }     // (take from the registers: they stay as they are)
                     ld_row(mv, 0, pm);
                     org_ok = true;
-                } else if (from_rec) {           // the chain waits for the phase (its row, its next momentum): prev_draw's copy now
-                    ld_row(vq, 0, dd); ld_row(vq + 2, 0, Lp);
-                    st_row(pvec(1 - pb0), 0, dd); st_row(wvec(1 - pb0), 0, Lp);
                 }
             }
         }
+        MI_MPROF(9)
         // ------------------------------------------------------------ E. the record of this tick's point, for the chains whose doubling goes on
         {
             const bool rec = newpt && !at_fin;
@@ -720,8 +748,8 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     }
 #ifdef MI_NUTS_REG_PROF
     if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
-        prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_walk_it; prm.prof[11] = n_pair_it;
+        for (int k = 0; k < 12; ++k) prm.prof[k] = pc[k];
+        prm.prof[12] = n_ticks; prm.prof[13] = n_active; prm.prof[14] = n_walk_it; prm.prof[15] = n_pair_it;
     }
 #endif
 #undef MI_MPROF

@@ -29,6 +29,8 @@ enum : int { NUTS_MAX_DEPTH = memo::MEMO_MAX_DEPTH };
 constexpr size_t lds_doubles() { return memo::lds_bytes() / sizeof(double); }
 // workspace bytes of a launch of n_chains: one workgroup of four waves per 64 chains
 inline size_t ws_bytes(uint64_t n_chains, int nt) { return (size_t)((n_chains + 63) / 64) * 4 * memo::memo_wave_bytes(4 * nt); }
+// ... of a persistent grid of n_wg workgroups (TileParams::nuts_grid, ::next_chain): 4 waves x 16 chain slots each
+inline size_t ws_bytes_grid(uint64_t n_wg, int nt) { return (size_t)n_wg * 4 * memo::memo_wave_bytes(4 * nt); }
 
 // GEN: settings.vals_bound and / or a diagonal precond_mat (TileGen, tile_samplers.hpp): the tree lives in the transformed space (the
 // U-turn dots are plain), rows are reported through inv_transform

@@ -62,9 +62,12 @@ struct TileParams {
     // nuts (nuts_memo_core.hpp): leapfrogs really computed [C] or nullptr; the fields of the built-in kernel's dynamic hand-out and replay, unused
     // on this route (every chain has its own slot; the tile policy applies the reference's NaN rules itself): nullptr
     uint64_t* n_exec;
-    uint32_t* next_chain;
+    uint32_t* next_chain;   // nuts: the chain counter of the persistent grid (nuts_grid workgroups; chains beyond its 64 nuts_grid slots are handed out as slots
+                            // fall free), or nullptr: one workgroup per 64 chains, every chain in its own slot
     uint32_t* nf_flag;
     unsigned long long* prof;
+    uint32_t nuts_grid;     // nuts: workgroups to launch (the engine: min(tiles, CUs) -- the workspace, 148 vectors per chain SLOT at max_tree_depth 10, is sized
+                            // by the grid, not by the chains); 0 = (C + 63) / 64
 };
 
 // ---- settings.vals_bound and / or a diagonal precond_mat on the tile route, with the arithmetic of the general built-in kernels

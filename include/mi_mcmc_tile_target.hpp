@@ -84,7 +84,7 @@ int tile_target_launch(int algo, const void* tile_params, const void* target_pod
         auto kern = nuts_tile_kernel<T, true>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
+        hipLaunchKernelGGL(kern, dim3(prm.nuts_grid ? (unsigned)prm.nuts_grid : (unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
     } else if (algo == 0) {
         auto kern = hmc_tile_kernel<T, WPB>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -99,7 +99,7 @@ int tile_target_launch(int algo, const void* tile_params, const void* target_pod
         auto kern = nuts_tile_kernel<T, false>;          // one wave per SIMD: register-carried leaf state (nuts_tile.hpp)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
+        hipLaunchKernelGGL(kern, dim3(prm.nuts_grid ? (unsigned)prm.nuts_grid : (unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
     } else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }

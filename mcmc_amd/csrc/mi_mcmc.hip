@@ -69,8 +69,12 @@ void note_kernel(const char* fmt, ...)
     va_end(ap);
     host::last_kernel() = buf;
 }
-namespace { std::atomic<uint64_t> g_test_grid_cap{0}; }
-uint64_t test_grid_cap() { return g_test_grid_cap.load(std::memory_order_relaxed); }
+// The test hook's cap on the persistent grids is read ONCE per sampler call (snapshot_grid_cap, at the first thing every route does) into a
+// thread-local: the workspace of a call is sized and its kernel launched from the same value even if another thread moves the cap in between
+// (sized with one grid, launched with a larger one, the kernel would write point records out of bounds).
+namespace { std::atomic<uint64_t> g_test_grid_cap{0}; thread_local uint64_t t_grid_cap = 0; }
+uint64_t test_grid_cap() { return t_grid_cap; }
+namespace { void snapshot_grid_cap() { t_grid_cap = g_test_grid_cap.load(std::memory_order_relaxed); } }
 }  // namespace mi
 
 // test hook, declared in mi_mcmc_probes.h (not in the product header): see launch_common.hpp
@@ -288,6 +292,7 @@ int nuts_continuation(const mi_settings* s, const mi_chains* c, uint32_t* n_adap
 int check_common(const mi_target* t, const mi_settings* s, const mi_chains* c, bool mass_allowed = false)
 {
     if (!t || !s || !c) return fail(MI_ERR_BAD_ARG, "null target / settings / chains");
+    mi::snapshot_grid_cap();
     if (t->struct_size != sizeof(mi_target) || s->struct_size != sizeof(mi_settings) ||
         c->struct_size != sizeof(mi_chains))
         return fail(MI_ERR_BAD_ARG, "struct_size mismatch (header / library version skew)");
@@ -344,6 +349,10 @@ struct StagedChains {
 
 int stage_in(const mi_chains* c, uint64_t d, uint64_t n_keep, StagedChains& sc, hipStream_t st, uint64_t n_total = 0)
 {
+    // (every route passes here -- the tile- and user-target entry points do not go through check_common: stage_out copies n_leapfrogs into
+    //  n_leapfrogs_executed for every kernel that executes what it counts, so the latter without the former is a bad argument, not a late HIP error)
+    if (c->n_leapfrogs_executed && !c->n_leapfrogs) return fail(MI_ERR_BAD_ARG, "n_leapfrogs_executed needs n_leapfrogs next to it");
+    mi::snapshot_grid_cap();
     sc.dev = *c;
     if (c->mem == MI_MEM_DEVICE) return MI_OK;
     const size_t C = c->n_chains;
@@ -1261,9 +1270,15 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         p.gamma = settings->gamma_val; p.t0 = settings->t0_val; p.kappa = settings->kappa_val;
         p.step_out = sc.dev.step_size; p.depth_trace = sc.dev.nuts_depth; p.adapt_state = sc.dev.nuts_adapt_state;
         const int nt_pad = nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8;
-        rc = ws_get(st, mi::tile_nuts::ws_bytes(chains->n_chains, nt_pad), ws);
+        // a persistent grid (one workgroup per CU at most) with the chains handed out dynamically: the workspace is sized by the grid's chain slots
+        const uint64_t n_wg = mi::nuts_tile_grid(chains->n_chains);
+        const size_t vec_bytes = (mi::tile_nuts::ws_bytes_grid(n_wg, nt_pad) + 255) & ~(size_t)255;
+        rc = ws_get(st, vec_bytes + 256, ws);
         if (rc) return rc;
         p.ws = ws.as<double>();
+        p.nuts_grid = (uint32_t)n_wg;
+        p.next_chain = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + vec_bytes);
+        HIP_TRY(hipMemsetAsync(p.next_chain, 0, sizeof(uint32_t), st));
         p.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = p.n_exec != nullptr;     // (each distinct state of a doubling is evaluated once)
     } else {
         rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
@@ -1682,6 +1697,10 @@ int mi_mcmc_hmc_run_mass_adapted(const mi_target* target, const mi_settings* set
         const uint64_t total = (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps;
         if (chains->mem == MI_MEM_DEVICE) { rc = fill_n_leap(chains->n_leapfrogs, C, total, st); if (rc) return rc; }
         else for (uint64_t c = 0; c < C; ++c) chains->n_leapfrogs[c] = total;
+        if (chains->n_leapfrogs_executed) {              // hmc executes what it counts: the same total (the header's "equal to n_leapfrogs")
+            if (chains->mem == MI_MEM_DEVICE) { rc = fill_n_leap(chains->n_leapfrogs_executed, C, total, st); if (rc) return rc; }
+            else for (uint64_t c = 0; c < C; ++c) chains->n_leapfrogs_executed[c] = total;
+        }
     }
     if (mass_diag_out) std::memcpy(mass_diag_out, mass.data(), d * 8);
     return MI_OK;
@@ -2293,14 +2312,17 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (rc) return rc;
 #ifdef MI_PROFILING
     if (prm.prof) {
-        unsigned long long h[12];
+        unsigned long long h[16];
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, prm.prof, sizeof(h), hipMemcpyDeviceToHost));
-        const char* names[8] = {"refresh", "start-gather", "leapfrog", "energy+leaf-store", "merge-loop", "take+pending-store", "fin", "loop-head"};
+        // the marks of nuts_memo_core.hpp (MI_MPROF(k) closes phase k); the tick-local kernel (nuts_async.hpp) fills the first eight with its own phases
+        const char* names[12] = {"A phase: rows, momenta ahead", "B origin + kick + drift", "mat-vec + kick + energies", "tests (U-turn, memoised)", "C walk",
+                                 "init / search", "E record store", "loop head", "point scalars (n', s', alpha)", "D end of doubling", "-", "-"};
         unsigned long long tot = 0;
-        for (int k = 0; k < 8; ++k) tot += h[k];
-        for (int k = 0; k < 8; ++k) fprintf(stderr, "[nuts prof] %-20s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
-        fprintf(stderr, "[nuts prof] ticks %llu, active chain-ticks %llu (%.2f of 16 per tick), refresh phases %llu, fin blocks %llu\n", h[8], h[9], (double)h[9] / (h[8] ? h[8] : 1), h[10], h[11]);
+        for (int k = 0; k < 12; ++k) tot += h[k];
+        for (int k = 0; k < 12; ++k) if (h[k]) fprintf(stderr, "[nuts prof] %-32s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+        fprintf(stderr, "[nuts prof] ticks %llu (%.0f cycles each), active chain-ticks %llu (%.2f of 16 per tick), walk iterations %llu, test iterations %llu\n", h[12],
+                (double)tot / (h[12] ? h[12] : 1), h[13], (double)h[13] / (h[12] ? h[12] : 1), h[14], h[15]);
     }
 #endif
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));

@@ -765,7 +765,7 @@ const double* const mi_t = mi_tab();
     if (prm.prof && blockIdx.x == 0 && threadIdx.x == 0)
     {
         for (int k = 0; k < 8; ++k) prm.prof[k] = pc[k];
-        prm.prof[8] = n_ticks; prm.prof[9] = n_active; prm.prof[10] = n_refresh; prm.prof[11] = n_finblk;
+        prm.prof[12] = n_ticks; prm.prof[13] = n_active; prm.prof[14] = n_refresh; prm.prof[15] = n_finblk;
     }
 #endif
 

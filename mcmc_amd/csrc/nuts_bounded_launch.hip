@@ -37,13 +37,25 @@ int run(const TileParams& prm, const double* P, hipStream_t st)
     auto kern = tile_nuts::nuts_tile_kernel<BuiltinGaussTile<NT>, true>;
     note_kernel("nuts_tile_kernel<built-in Gaussian %d, true>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, BuiltinGaussTile<NT>{P, prm.d});
+    if (prm.next_chain) MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(kern, dim3(prm.nuts_grid ? (unsigned)prm.nuts_grid : (unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, BuiltinGaussTile<NT>{P, prm.d});
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-size_t nuts_bounded_workspace_bytes(uint64_t C, int nt) { return tile_nuts::ws_bytes(C, nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8); }
+// The persistent grid of the memoised tick on the tile policy: one workgroup (64 chain slots) per CU at most -- the workspace (148 vectors per chain SLOT:
+// 10.1 GB for 65 536 slots at d = 128) is sized by the grid, and chains beyond its slots are handed out as slots fall free (nuts_memo_core.hpp)
+uint64_t nuts_tile_grid(uint64_t C)
+{
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    const uint64_t need = (C + 63) / 64;
+    return cap_grid(need < (uint64_t)n_cu ? need : (uint64_t)n_cu);
+}
+size_t nuts_bounded_workspace_bytes(uint64_t C, int nt) { return tile_nuts::ws_bytes_grid(nuts_tile_grid(C), nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8); }
 
 int launch_nuts_gauss_bounded(const NutsParams& q, int nt, hipStream_t st)
 {
@@ -51,6 +63,7 @@ int launch_nuts_gauss_bounded(const NutsParams& q, int nt, hipStream_t st)
     p.d = q.d; p.C = q.C; p.chain0 = q.chain0;
     p.theta = q.theta; p.draws = q.draws; p.n_accept = q.n_accept; p.n_leap = q.n_leap; p.n_exec = q.n_exec;
     p.seed = q.seed; p.n_burnin = q.n_burnin; p.n_keep = q.n_keep; p.draw0 = q.draw0;
+    p.next_chain = q.next_chain; p.nuts_grid = (uint32_t)nuts_tile_grid(q.C);
     p.ws = q.ws; p.step_out = q.step_out; p.depth_trace = q.depth_trace; p.adapt_state = q.adapt_state;
     p.n_adapt = q.n_adapt; p.max_depth = q.max_depth;
     p.delta = q.delta; p.eps_bar0 = q.eps_bar0; p.gamma = q.gamma; p.t0 = q.t0; p.kappa = q.kappa;

@@ -64,6 +64,28 @@ def test_recycled_slots_with_a_diagonal_precond_mat(hint, grid_cap):
     assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"]) and np.array_equal(g_draws, o_draws)
 
 
+def test_recycled_slots_of_the_bounded_tick_on_the_tile_policy(grid_cap):
+    """round 6: nuts with vals_bound runs the memoised tick on the tile policy over a PERSISTENT grid too (nuts_bounded_launch.hip:
+    one workgroup per CU at most, the workspace sized by the grid) -- one workgroup here, every slot takes its second to fourth chain, one chain
+    starts non-finite (the tile policy applies the reference's NaN rules itself: no replay)."""
+    d, C = 100, 230
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = np.clip(synth.initial_states(C, d, seed=29) * 0.5, -1.0, 1.5)
+    init[140, 7] = np.inf         # a chain from the counter
+    lb = np.where(np.arange(d) % 3 == 0, -1.5, -np.inf); ub = np.where(np.arange(d) % 4 == 0, 2.0, np.inf)
+    st = mcmc_amd.default_settings(rng_seed_value=41, n_burnin_draws=5, n_keep_draws=5, n_adapt_draws=5, max_tree_depth=6,
+                                   vals_bound=1, lower_bounds=lb, upper_bounds=ub)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=11)
+    assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<built-in Gaussian")
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=41, n_burnin=5, n_keep=5, step=1.0, n_adapt=5, max_depth=6, W=4, lower=lb, upper=ub)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=11)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"], equal_nan=True) and np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert (g["n_exec"] <= g["n_leap"]).all()
+
+
 @pytest.mark.parametrize("hint", DYN_HINTS)
 def test_a_flagged_chain_leaves_a_recycled_slot_and_is_replayed(hint, grid_cap):
     d, C = 128, 200

@@ -15,7 +15,10 @@ theta = torch.empty_like(theta0)
 draws = torch.empty((keep, d, C), dtype=torch.float64, device=dev)
 n_leap = torch.zeros(C, dtype=torch.int64, device=dev)
 n_exec = torch.zeros(C, dtype=torch.int64, device=dev)
-st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn)
+skw = {}
+if os.environ.get("MI_DIAGM") == "1":           # a diagonal precond_mat: nuts_gauss_memo_kernel<NT, true>
+    skw["precond_mat"] = np.diag(np.linspace(0.5, 2.0, d))
+st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=burn, **skw)
 ref = None
 for rep in range(2):
     AB = {"memo": (("memo", mcmc_amd.KERNEL_AUTO), ("tick_local", mcmc_amd.KERNEL_NUTS_TICK_LOCAL)),

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch, mcmc_amd
 from mcmc_amd import synth
-C, d = 16384, 128
+C, d = int(os.environ.get("MI_C", "16384")), 128
 dev = torch.device("cuda", 0)
 prec = torch.from_numpy(synth.dense_gaussian_precision(d)).to(dev)
 theta = torch.from_numpy(np.ascontiguousarray(synth.initial_states(C, d, seed=3).T)).to(dev)
