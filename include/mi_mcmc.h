@@ -91,10 +91,13 @@ typedef enum mi_kernel_hint {
                                             * (d <= 512) and on dense Gaussians with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
     MI_KERNEL_NUTS_DYN = 13,               /* RETIRED (round 5), valid and ignored: round 4's register-carried tick with dynamic chain hand-out */
-    MI_KERNEL_NUTS_MEMO = 14               /* nuts, same case: every doubling on a MEMOISED trajectory (nuts_memo.hpp) -- the 2^j leaves of a doubling visit only
+    MI_KERNEL_NUTS_MEMO = 14,              /* nuts, same case: every doubling on a MEMOISED trajectory (nuts_memo.hpp) -- the 2^j leaves of a doubling visit only
                                             * 1 + j (j + 1) / 2 distinct states (the reference's crossed edge plumbing, nuts.ipp:195,207), each is computed
                                             * once, the tree is walked on scalars; same bits, ~40 % fewer leapfrogs executed on BASELINE configs[3]; chains
                                             * handed out dynamically -- THE kernel of the plain case (AUTO) */
+    MI_KERNEL_NUTS_MEMO_INTICK = 15        /* the same kernel generating every draw's momentum INSIDE the tick (rounds 2-5).  AUTO instead fills a table of
+                                            * all momenta of the run with a pre-pass kernel at full occupancy (16 NT + 2 doubles per chain and draw;
+                                            * nuts_memo.hpp: nuts_momenta_kernel) and falls back to this form when the table would not fit.  Same bits */
 } mi_kernel_hint;
 
 typedef struct mi_target {

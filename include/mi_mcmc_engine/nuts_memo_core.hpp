@@ -2,6 +2,10 @@
 // measured), as ONE device function shared by the built-in Gaussian kernel (nuts_memo.hpp: P theta on the matrix cores) and the user tile targets
 // (nuts_tile.hpp: the gradient behind a functor).  What differs between them is a POLICY:
 //     static constexpr bool REPLAY     -- the policy's arithmetic leaves the reference's in the non-finite regime: flag such chains for a replay
+//     static constexpr bool PRE_MOM    -- the momenta of every draw of every chain (src/nuts.cpp:200-204: p = sqrt(M) z, its kinetic energy, log of the slice
+//                                         uniform) come from a TABLE a pre-pass kernel filled at full occupancy (prm.mom, prm.msc: nuts_memo.hpp) instead of
+//                                         being generated inside the tick, where 128 Box-Muller normals per chain and draw are pure latency of a wave that is
+//                                         alone on its SIMD.  Same Philox counters, same operations, same bits.
 //     double enter(v, dim)             -- initial_vals into the sampler's space (nuts.cpp:160-162); leave(v, slice): the way back for rows / theta
 //     double msqrt_times(z, dim)       -- sqrt_precond_matrix * z (nuts.cpp:168, 202);   double minv_times(p, dim): inv_precond_matrix * p, element-wise
 //     void kick(th, pm, w, e, act)     -- p += (e [J^-1] grad) / 2 (nuts.cpp:108-135) on the lanes `act`;   drift(th, pm, e, act): theta += e (Minv p) (:139-154)
@@ -141,6 +145,25 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
         *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
     };
+    // PRE_MOM: the momentum of LOCAL draw k of this lane's chain -- prm.mom [draw][chain] blocks of NS * 32 bytes in the granule order of a workspace row
+    // ([pair of slices][j4], so that a lane reads what ld_row would) -- and its scalars prm.msc [draw][chain] = (kinetic energy, log of the slice uniform)
+    // (ONE load sequence from a per-lane address -- a workspace row or the table's row -- where a lane-varying choice between the two is made:
+    //  as two predicated sequences the choice cost the d = 128 kernel 68 bytes of scratch)
+    [[maybe_unused]] auto mom_lane_ptr = [&](uint32_t k) __attribute__((always_inline)) -> const char* {
+        if constexpr (POL::PRE_MOM) return reinterpret_cast<const char*>(prm.mom) + (((size_t)k * C + cl) * (size_t)(NS * 32) + (size_t)j4 * 16u);
+        else return nullptr;
+    };
+    [[maybe_unused]] auto ws_lane_ptr = [&](int v) __attribute__((always_inline)) -> const char* {
+        return ws_wave_u + ((uint32_t)v * (uint32_t)(NS * 512) + lane_b);
+    };
+    [[maybe_unused]] auto ld_ptr = [&](const char* lp, auto& dst) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(dst) / sizeof(double));
+#pragma unroll
+        for (int q = 0; q < N; q += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(lp + (size_t)(q >> 1) * 64u);
+            dst[q] = t.x; dst[q + 1] = t.y;
+        }
+    };
     auto dim_ok = [&](int s) -> bool { return (uint32_t)(4 * s + j4) < d; };
     constexpr int CHC = (NS < 16) ? NS : 16;          // kept-row stores: slices per chunk
     // the LAST POINT of the chain's trajectory (or the doubling's origin): position, momentum, P * position (MFMA B / D layout).  Loop-carried.
@@ -200,6 +223,14 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     bool pos_init = true, neg_init = true;
     auto pvec = [](int b) -> int { return b ? MV_PREVB : MV_PREV; };
     auto wvec = [](int b) -> int { return b ? MV_WPREVB : MV_WPREV; };
+    // the momentum vector of the running draw (mntm_vec, src/nuts.cpp:200-202) into dst: the table's row of this chain's draw (PRE_MOM), or workspace
+    // vector mv (generated inside the tick; INIT's z_init, `ws`, in either mode)
+    auto ld_draw_mom = [&](bool ws, auto& dst) __attribute__((always_inline)) {
+        if constexpr (POL::PRE_MOM) ld_ptr(ws ? ws_lane_ptr(mv) : mom_lane_ptr(draw), dst);
+        else ld_row(mv, 0, dst);
+    };
+    [[maybe_unused]] bool kl_pend = false;               // PRE_MOM: the scalars of the NEXT draw are on their way from the table (requested when this draw began)
+    [[maybe_unused]] double kl_x = 0.0, kl_y = 0.0;
 
     // The uniforms of a draw are consumed in slot order (direction :233, one per merge nuts.ipp:213, top-level accept :261).  One Philox
     // evaluation per WAVE serves four consecutive slots of every chain: lane class j4 of a chain computes slot ub0 + j4, consumers shuffle.
@@ -283,11 +314,17 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     // lanes with `p` (next momentum ready, no older row pending) enter their next draw (nuts.cpp:200-219)
     auto roll_state = [&](bool p) __attribute__((always_inline)) {
         if (p) {
-            const int t_ = mv; mv = mvn; mvn = t_;
+            if constexpr (!POL::PRE_MOM) { const int t_ = mv; mv = mvn; mvn = t_; }
             const double nk = next_K_();
             prev_K_() = nk;
             log_u_() = next_lu_() - prev_U_() - nk;       // :206
             mom_ready = false;
+            if constexpr (POL::PRE_MOM) {                 // the NEXT draw's scalars: requested now, in the LDS rows at the top of the next tick
+                if (draw + 1u < n_total) {
+                    const double2 v = reinterpret_cast<const double2*>(prm.msc)[(size_t)(draw + 1u) * C + cl];
+                    kl_x = v.x; kl_y = v.y; kl_pend = true;
+                }
+            }
             row_pend = row2_pend; row_draw = draw - 1u; row2_pend = false;
             pb0 = pb; pos_init = true; neg_init = true;
             uslot = 1; ub0 = 0x80000000u;                 // (a new draw: the buffered uniforms are the old draw's)
@@ -362,6 +399,12 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             }
             row_pend = false;
         }
+        if constexpr (POL::PRE_MOM) {
+            if (__ballot(kl_pend) != 0ull) {
+                if (kl_pend) { next_K_() = kl_x; next_lu_() = kl_y; mom_ready = true; }
+                kl_pend = false;
+            }
+        }
         if constexpr (POL::REPLAY) retire(state != NS_DONE && nf_() != 0.0);   // a flagged chain is replayed from its initial state: nothing of it is kept
         // ------------------------------------------------------------ free slots take the next chains
         {
@@ -376,7 +419,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                     if (nid < C) {                       // a new chain in this slot: everything per-chain starts over
                         cl = nid;
                         state = NS_INIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
-                        mv = MV_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false; cp_pend = false;
+                        mv = MV_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false; cp_pend = false; kl_pend = false;
                     } else exhausted = true;
                 }
             }
@@ -388,6 +431,14 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             row2_pend = false;
             retire(state == NS_NEED_DRAW && draw >= n_total);
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
+            if constexpr (POL::PRE_MOM) {
+                // (a chain's first draw, or one whose look-ahead found no draw to look at: the scalars straight from the table)
+                const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && !kl_pend && nidx < n_total;
+                if (gen) {
+                    const double2 v = reinterpret_cast<const double2*>(prm.msc)[(size_t)nidx * C + cl];
+                    next_K_() = v.x; next_lu_() = v.y; mom_ready = true;
+                }
+            } else {
             const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
             // (MI_MEMO_RNG_ILP Box-Muller pairs per iteration: a pair is ~250 dependent operations -- Philox rounds, log, sqrt, sincos -- and a wave that is
@@ -414,6 +465,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             kq = kq + __shfl_xor(kq, 16);
             const double lu = det_log(rng_uniform(prm.seed, prm.chain0 + cl, nidx + prm.draw0, 0u));
             if (gen) { next_K_() = kq / 2.0; next_lu_() = lu; mom_ready = true; }     // :204
+            }
             const bool p = state == NS_NEED_DRAW;             // (all of them have a momentum now and no row pending)
             roll_state(p);
             if (max_depth > 0) begin_doubling(p);
@@ -454,8 +506,8 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         {   // the origin of a doubling (prev_draw, mntm_vec, P prev_draw: src/nuts.cpp:241-256); every later point continues from the registers
             const bool need = (newpt && npts == 0u && !org_ok) || init;      // (!org_ok: not requested at the end of the last tick already)
             if (__ballot(need) != 0ull) {
-                const int vt = pvec(pb), vp = mv, vw = init ? pvec(pb) : wvec(pb);      // INIT: first_draw (pb = 0), any finite row as P theta (e = 0)
-                if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
+                const int vt = pvec(pb), vw = init ? pvec(pb) : wvec(pb);      // INIT: first_draw (pb = 0), any finite row as P theta (e = 0)
+                if (need) { ld_row(vt, 0, th); ld_draw_mom(init, pm); ld_row(vw, 0, w); }
             }
         }
         if (newpt) org_ok = false;
@@ -467,13 +519,18 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         uint32_t pmask = newpt ? ((uint32_t)lds_pm[jd * 48u + mpt] | ((mpt == 1u + jd) ? 1u : 0u)) : 0u;
         // the (theta, p) vectors of the other point of a test: level l >= 1: the record of point mpt - l; level 0: the other edge (draw_neg / mntm_neg
         // for a forward doubling, _pos for a backward one) -- the draw's initial vectors until a doubling has written that side
-        auto test_vecs = [&](int l, int& vt, int& vp) __attribute__((always_inline)) {
-            vt = MV_PT0 + 3 * ((int)mpt - l - 1); vp = vt + 1;
+        auto test_vecs = [&](int l, int& vt, int& vp, bool& pmom) __attribute__((always_inline)) {
+            vt = MV_PT0 + 3 * ((int)mpt - l - 1); vp = vt + 1; pmom = false;
             if (l == 0) {
                 const bool oinit = (vdir > 0) ? neg_init : pos_init;
                 vt = oinit ? pvec(pb0) : ((vdir > 0) ? MV_TNEG_T : MV_TPOS_T);
                 vp = oinit ? mv : ((vdir > 0) ? MV_TNEG_P : MV_TPOS_P);
+                pmom = oinit;                            // (PRE_MOM: the draw's momentum is a row of the table, not a workspace vector)
             }
+        };
+        auto ld_test_p = [&](int vp, bool pmom, auto& dst) __attribute__((always_inline)) {
+            if constexpr (POL::PRE_MOM) ld_ptr(pmom ? mom_lane_ptr(draw) : ws_lane_ptr(vp), dst);
+            else ld_row(vp, 0, dst);
         };
         // theta / p of the other point of a test; dd then holds d = theta(mpt) - theta(mpt - l) (by direction).  DEFINED on every lane before
         // the (predicated) loads: left undefined, the values of lanes without a test count as live from the previous tick's loop -- 128 registers
@@ -500,9 +557,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             const bool t1 = pmask != 0u;
             if (__ballot(t1) != 0ull) {
                 const int l1 = t1 ? __builtin_ctz(pmask) : 1;
-                int vq, vqp;
-                test_vecs(l1, vq, vqp);
-                if (t1) { ld_row(vq, 0, dd); ld_row(vqp, 0, Lp); }
+                int vq, vqp; bool pmom;
+                test_vecs(l1, vq, vqp, pmom);
+                if (t1) { ld_row(vq, 0, dd); ld_test_p(vqp, pmom, Lp); }
             }
         }
         MI_MPROF(1)
@@ -562,9 +619,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 const int l = t ? __builtin_ctz(pmask) : 1;
                 const int n1 = (int)mpt - l;
                 if (!first) {
-                    int vq, vqp;
-                    test_vecs(l, vq, vqp);
-                    if (t) { ld_row(vq, 0, dd); ld_row(vqp, 0, Lp); }
+                    int vq, vqp; bool pmom;
+                    test_vecs(l, vq, vqp, pmom);
+                    if (t) { ld_row(vq, 0, dd); ld_test_p(vqp, pmom, Lp); }
                 }
                 first = false;
                 // (two passes: d . p(n1) with theta, d, p(n1) as operands, then d . p(mpt) with d, p -- four vectors as VALU operands of one loop
@@ -724,7 +781,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 }
                 if (go) {
                     if (!take) { ld_row(pvec(pb), 0, th); ld_row(wvec(pb), 0, w); }     // (take from the registers: they stay as they are)
-                    ld_row(mv, 0, pm);
+                    ld_draw_mom(false, pm);
                     org_ok = true;
                 }
             }

@@ -38,6 +38,7 @@ template <class T, bool GEN>
 struct TileMemoPolicy {
     static constexpr int NT = T::NT, NS = 4 * NT;
     static constexpr bool REPLAY = false;
+    static constexpr bool PRE_MOM = false;       // momenta generated inside the tick (the table of nuts_memo.hpp belongs to the built-in kernel's launcher)
     const T& tgt;
     double* lds_t;               // the target's own LDS (its matrices in fragment order)
     const TileGen<T::NT>& tg;    // GEN: bounds / mass tables

@@ -21,7 +21,7 @@ TARGET_GAUSS_ISO, TARGET_GAUSS_DIAG, TARGET_GAUSS_DENSE, TARGET_LOGISTIC, TARGET
 MEM_HOST, MEM_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_ELEMENTWISE_1LANE, KERNEL_ELEMENTWISE_4LANE, KERNEL_NUTS_LOCKSTEP = 0, 1, 2, 3   # mi_kernel_hint
 KERNEL_HMC_TWO_WAVES_PER_SIMD, KERNEL_HMC_ONE_WAVE_PER_SIMD, KERNEL_HMC_SPLIT2, KERNEL_HMC_SPLIT4, KERNEL_HMC_SPLIT4_TWO_WAVES = 4, 5, 6, 7, 8
-KERNEL_NUTS_TICK_LOCAL, KERNEL_NUTS_REG, KERNEL_NUTS_SPLIT, KERNEL_LITERAL, KERNEL_NUTS_DYN, KERNEL_NUTS_MEMO = 9, 10, 11, 12, 13, 14
+KERNEL_NUTS_TICK_LOCAL, KERNEL_NUTS_REG, KERNEL_NUTS_SPLIT, KERNEL_LITERAL, KERNEL_NUTS_DYN, KERNEL_NUTS_MEMO, KERNEL_NUTS_MEMO_INTICK = 9, 10, 11, 12, 13, 14, 15
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)

@@ -34,6 +34,8 @@ int launch_nuts_gauss(const NutsParams& prm, int nt, bool general, bool dense_m,
 // persistent grid (prm.ws must hold nuts_memo_workspace_bytes)
 int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool diag_m = false);
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);
+// bytes of the table of momenta the memoised kernel reads when prm.mom is set (filled by its launcher's pre-pass: nuts_memo.hpp)
+size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt);
 uint64_t nuts_tile_grid(uint64_t C);                                // nuts_bounded_launch.hip: workgroups of the persistent grid of the tile-policy tick
 int launch_nuts_gauss_general(const NutsParams& prm, int nt, uint32_t batch, hipStream_t st);     // nuts_general_launch.hip
 // settings.vals_bound (and / or a diagonal precond_mat next to it) on the memoised tick: the built-in Gaussian as a tile target with TileGen

@@ -122,6 +122,20 @@ int ws_get(hipStream_t st, size_t bytes, WsLease& lease)
     return MI_OK;
 }
 
+// bytes the cache holds for (current device, st) right now
+size_t ws_cached_bytes(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(std::make_pair(dev, st));
+    return (it == g_ws.end() || !it->second) ? 0 : it->second->cap;
+}
+
+#ifndef MI_NUTS_MOMENTA_MAX_BYTES
+#define MI_NUTS_MOMENTA_MAX_BYTES ((size_t)24 << 30)     // the table of momenta of a nuts run (nuts_memo.hpp): 13.6 GB on BASELINE configs[3]
+#endif
+
 // frees the cached workspace of (current device, st); all_streams: every entry of the current device
 int ws_release(hipStream_t st, bool all_streams, uint64_t* freed)
 {
@@ -2201,9 +2215,25 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (bounded_memo) ws_own = std::max(ws_own, mi::nuts_bounded_workspace_bytes(chains->n_chains, nt));
     const size_t ws_own_r = (ws_own + 255) & ~(size_t)255;
     const size_t flag_bytes = ((chains->n_chains + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;   // [C] flags, [C] "any"
-    rc = ws_get(st, ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + 256, ws);   // + non-finite flags + identity tables of the replay + the chain counter of nuts_dyn.hpp
+    const size_t fixed_bytes = ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 256 + 256;     // + non-finite flags + identity tables of the replay + the chain counter
+    // The memoised kernel reads the momenta of the whole run from a table its launcher fills first (nuts_memo.hpp: nuts_momenta_kernel) when that table
+    // is affordable: at most MI_NUTS_MOMENTA_MAX_BYTES and a third of the device memory that is free right now; else -- and under
+    // MI_KERNEL_NUTS_MEMO_INTICK -- the momenta are generated inside the tick, as in rounds 2-5.  Same bits either way.
+    size_t mom_bytes = 0;
+    if (memo && (!gt.active || !settings->vals_bound) && target->kernel_hint != MI_KERNEL_NUTS_MEMO_INTICK) {
+        const size_t want = mi::nuts_memo_momenta_bytes(chains->n_chains, (uint32_t)n_total, nt);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        const size_t cached = ws_cached_bytes(st);       // (what this stream's workspace already holds counts as free: it is re-used)
+        if (want <= MI_NUTS_MOMENTA_MAX_BYTES && want <= (free_b + cached) / 3) mom_bytes = (want + 255) & ~(size_t)255;
+    }
+    rc = ws_get(st, fixed_bytes + mom_bytes, ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
+    if (mom_bytes) {
+        prm.mom = reinterpret_cast<double*>(static_cast<char*>(ws.p) + fixed_bytes);
+        prm.msc = prm.mom + (size_t)n_total * chains->n_chains * (size_t)(16 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8));
+    }
     uint32_t* const nf_flag = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ws_own_r);
     double* const id_tab = reinterpret_cast<double*>(static_cast<char*>(ws.p) + ws_own_r + flag_bytes);
     prm.next_chain = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + ((ws_own_r + flag_bytes + 5 * 128 * sizeof(double) + 255) & ~(size_t)255));

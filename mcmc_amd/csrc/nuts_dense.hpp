@@ -70,6 +70,10 @@ struct NutsParams {
                             // adaptation window (0 < draw0 <= n_adapt); n_adapt is the RUN's window, draw indices are global (draw0 + i)
     uint64_t* n_exec;       // [C] or nullptr (mi_chains.n_leapfrogs_executed): leapfrogs really computed -- nuts_gauss_memo_kernel writes it; every
                             // other kernel executes what it counts in n_leap, and the host copies that
+    // nuts_gauss_memo_kernel<., ., true> (nuts_memo.hpp): the momenta of every draw of every chain, filled by nuts_momenta_kernel before the launch.
+    // mom: [n_total][C] blocks of 16 NT doubles in the granule order of a workspace row; msc: [n_total][C] (kinetic energy, log of the slice uniform)
+    double* mom;
+    double* msc;
 };
 
 enum : int {

@@ -34,16 +34,27 @@ MemoShape memo_shape(uint64_t C)
     const uint64_t need = (C + 16 * waves - 1) / (16 * waves), cap = (uint64_t)n_cu * (uint64_t)per_cu;
     return MemoShape{waves, cap_grid(need < cap ? need : cap)};
 }
-template <int NT, bool DIAGM>
-int run_memo(NutsParams prm, hipStream_t st)
+template <int NT, bool DIAGM, bool PRE>
+int run_memo_k(const NutsParams& prm, hipStream_t st)
 {
     const size_t lds = memo_lds<NT, DIAGM>();
-    auto kern = nuts_gauss_memo_kernel<NT, DIAGM>;
-    note_kernel("nuts_gauss_memo_kernel<%d, %s>", NT, DIAGM ? "true" : "false");
-    const MemoShape sh = memo_shape<NT, DIAGM>(prm.C);       // (sets the kernel's LDS attribute)
+    auto kern = nuts_gauss_memo_kernel<NT, DIAGM, PRE>;
+    note_kernel("nuts_gauss_memo_kernel<%d, %s, %s>", NT, DIAGM ? "true" : "false", PRE ? "true" : "false");
+    const MemoShape sh = memo_shape<NT, DIAGM>(prm.C);       // (the occupancy of the in-tick instantiation: the same LDS, the same launch bounds)
+    MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
+    if constexpr (PRE) {                                 // every momentum of the run, at full occupancy, before the latency-bound tick starts
+        const uint64_t n_waves = ((prm.C + 15) / 16) * (uint64_t)(prm.n_burnin + prm.n_keep);
+        if (n_waves > 0) hipLaunchKernelGGL((nuts_momenta_kernel<NT, DIAGM>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, prm);
+        MI_LAUNCH_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)sh.grid), dim3(64 * sh.waves), lds, st, prm);
     return (int)hipGetLastError();
+}
+template <int NT, bool DIAGM>
+int run_memo(const NutsParams& prm, hipStream_t st)
+{
+    return prm.mom != nullptr ? run_memo_k<NT, DIAGM, true>(prm, st) : run_memo_k<NT, DIAGM, false>(prm, st);
 }
 
 #ifdef MI_WITH_LEGACY_KERNELS   // the lock-step first-generation kernel (nuts_dense.hpp: 2.4 KB of scratch per lane at d = 128) ships in the
@@ -79,6 +90,12 @@ int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool d
 {
     if (diag_m) return MI_DISPATCH_NT(nt, (run_memo<1, true>(prm, st)), (run_memo<2, true>(prm, st)), (run_memo<4, true>(prm, st)), (run_memo<8, true>(prm, st)));
     return MI_DISPATCH_NT(nt, (run_memo<1, false>(prm, st)), (run_memo<2, false>(prm, st)), (run_memo<4, false>(prm, st)), (run_memo<8, false>(prm, st)));
+}
+
+size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt)
+{
+    const int ns = 4 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8);
+    return memo_momenta_bytes(C, n_total, ns);
 }
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)

@@ -51,10 +51,11 @@ using memo::memo_wave_bytes;
 // (DIAGM) a DIAGONAL precond_mat without bounds (nuts.cpp:139-154 with hmc.cpp's leap_frog_fn: p = sqrt(m) z, theta += e (p / m),
 // K = p . (p / m) / 2; two tables in LDS, read where they are used).  The identity / diagonal products are applied element-wise, which is NOT the
 // reference's dense product once a component is non-finite: REPLAY -- flagged chains are replayed by the general variant (nuts_async.hpp).
-template <int NT, bool DIAGM>
+template <int NT, bool DIAGM, bool PRE = false>
 struct GaussMemoPolicy {
     static constexpr int NS = 4 * NT;
     static constexpr bool REPLAY = true;
+    static constexpr bool PRE_MOM = PRE;         // the momenta come from the table nuts_momenta_kernel filled (below)
     const double* afrag;         // this lane's column of P's fragments
     const double* lds_ms;        // DIAGM: [16 NT] sqrt(m), [16 NT] 1 / m
     const double* lds_mi;
@@ -107,7 +108,58 @@ struct GaussMemoPolicy {
 };
 
 // LDS: P's fragments | the tick's rows and test table (memo::lds_bytes()) | DIAGM: the two mass tables
-template <int NT, bool DIAGM = false>
+// The momenta of a run, ahead of it: mntm_vec = sqrt(M) z of every draw of every chain (src/nuts.cpp:200-202), its kinetic energy
+// (:204) and the log of the draw's slice uniform (:206) are pure functions of (seed, chain, draw) -- Philox counters -- so they need not be made inside
+// the tick, where a wave that is alone on its SIMD walks 16 Box-Muller pairs per lane one dependent operation at a time (5.6 % of the tick on
+// configs[3], and every chain of the wave waits).  One wave per (draw, 16-chain tile), the tick's own lane layout and the tick's own statements -- the
+// same operations in the same order, so the same bits -- at full occupancy; the tick then reads 16 NT doubles per chain and draw.
+// Table: (16 NT + 2) doubles per chain and draw (configs[3]: 13.6 GB); the launcher falls back to the in-tick generation when it would not fit.
+template <int NT, bool DIAGM>
+__global__ __launch_bounds__(256) void nuts_momenta_kernel(const NutsParams prm)
+{
+    constexpr int NS = 4 * NT;
+    const int lane = threadIdx.x & 63, j4 = lane >> 4;
+    const uint32_t d = prm.d;
+    const uint64_t n_tiles = (prm.C + 15) / 16;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_total = prm.n_burnin + prm.n_keep;
+    if (wid >= n_tiles * (uint64_t)n_total) return;
+    const uint32_t k = (uint32_t)(wid / n_tiles);                        // LOCAL draw index (the Philox counter takes k + draw0)
+    const uint64_t c = (wid % n_tiles) * 16 + (uint64_t)(lane & 15);
+    const bool live = c < prm.C;
+    const uint64_t cc = live ? c : prm.C - 1;
+    char* const base = reinterpret_cast<char*>(prm.mom) + (((size_t)k * prm.C + cc) * (size_t)(NS * 32) + (size_t)j4 * 16u);
+    double kq = 0.0;
+#pragma unroll 2
+    for (int b = 0; b < NS / 2; ++b) {                   // the statements of the tick's phase (nuts_memo_core.hpp), this chain's own draw index
+        double z0, z1;
+        rng_normal_pair(prm.seed, prm.chain0 + cc, k + prm.draw0, (uint32_t)(4 * b + j4), STREAM_NORMAL, z0, z1);
+        const uint32_t da = 8u * b + j4, db = 8u * b + 4u + j4;
+        double pa = (da < d) ? z0 : 0.0;
+        double pb_ = (db < d) ? z1 : 0.0;
+        if constexpr (DIAGM) {
+            const double msa = (da < d) ? prm.m_sqrt[da] : 1.0, msb = (db < d) ? prm.m_sqrt[db] : 1.0;
+            const double mia = (da < d) ? prm.m_inv[da] : 1.0, mib = (db < d) ? prm.m_inv[db] : 1.0;
+            pa = msa * pa; pb_ = msb * pb_;                                  // :202: p = sqrt(M) z
+            kq = dfma(pa, mia * pa, kq);                                     // :204: K = p . (Minv p) / 2
+            kq = dfma(pb_, mib * pb_, kq);
+        } else {
+            kq = dfma(pa, pa, kq);
+            kq = dfma(pb_, pb_, kq);
+        }
+        if (live) *reinterpret_cast<double2*>(base + (size_t)b * 64u) = double2{pa, pb_};
+    }
+    kq = kq + __shfl_xor(kq, 32);
+    kq = kq + __shfl_xor(kq, 16);
+    const double lu = det_log(rng_uniform(prm.seed, prm.chain0 + cc, k + prm.draw0, 0u));
+    if (live && j4 == 0) reinterpret_cast<double2*>(prm.msc)[(size_t)k * prm.C + c] = double2{kq / 2.0, lu};
+}
+__host__ __device__ constexpr size_t memo_momenta_bytes(uint64_t C, uint32_t n_total, int NS)
+{
+    return (size_t)n_total * C * ((size_t)NS * 32 + 16);
+}
+
+template <int NT, bool DIAGM = false, bool PRE = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(const NutsParams prm)
 {
     constexpr int NS = 4 * NT;
@@ -125,7 +177,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_memo_kernel(
         }
     }
     stage_precision<NT>(prm.P, prm.d, lds_P);            // ends with a barrier
-    GaussMemoPolicy<NT, DIAGM> pol{lds_P + (threadIdx.x & 63), lds_ms, lds_mi};
+    GaussMemoPolicy<NT, DIAGM, PRE> pol{lds_P + (threadIdx.x & 63), lds_ms, lds_mi};
     memo::nuts_memo_run<NT>(prm, pol, lds_rows, lds_pm);
 }
 

@@ -31,7 +31,7 @@ def sweep(n_cases=40, seed=1, verbose=True):
                                        n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
         chain0 = int(rng.integers(0, 5000))
         # AUTO / MEMO: the memoised kernel; REG: a retired kernel's hint (ignored); TICK_LOCAL: the independent tick-local kernel
-        hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO]))
+        hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO_INTICK]))
         g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0, kernel_hint=hint)
         o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0)
         bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)

@@ -52,9 +52,11 @@ CASES = [
 # the register-carried kernels of rounds 2-4, retired in round 5: valid hints, ignored -- the default kernel runs.  KERNEL_NUTS_TICK_LOCAL: the
 # tick-local asynchronous kernel (what the bounded / preconditioned variants run; it executes every leaf) -- an independent implementation that must
 # give the same bits.  (The lock-step first-generation kernel is only in the A/B library: `make prof`.)
-# (round 6: the full matrix runs on AUTO, KERNEL_NUTS_MEMO and KERNEL_NUTS_TICK_LOCAL; the three retired hints run the SAME kernel as AUTO and
+# (round 6: the full matrix runs on AUTO, KERNEL_NUTS_MEMO_INTICK and KERNEL_NUTS_TICK_LOCAL; the three retired hints run the SAME kernel as AUTO and
 #  are checked for exactly that -- accepted, ignored -- on one case: test_retired_hints_run_the_default_kernel)
-KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO]
+# KERNEL_NUTS_MEMO_INTICK (round 6): the memoised tick generating its momenta inside the tick, as until round 5 -- AUTO reads them from the table a
+# pre-pass kernel fills (nuts_memo.hpp: nuts_momenta_kernel) and falls back to this form when the table would not fit; same bits
+KERNELS = [mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO_INTICK]
 RETIRED = [mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_SPLIT, mcmc_amd.KERNEL_NUTS_DYN]
 
 
@@ -72,6 +74,8 @@ def test_nuts_bit_exact_vs_oracle(kind, d, C, burn, keep, adapt, max_depth, eps0
     g_draws, g = mcmc_amd.nuts(k_gpu, init, st, prec=prec, chain0=500, kernel_hint=hint)
     memo = hint != mcmc_amd.KERNEL_NUTS_TICK_LOCAL
     assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel" if memo else "nuts_gauss_async_kernel")
+    if memo:        # ... <NT, DIAGM, momenta from the pre-pass table>
+        assert mcmc_amd.last_kernel().endswith(", false>" if hint == mcmc_amd.KERNEL_NUTS_MEMO_INTICK else ", true>"), mcmc_amd.last_kernel()
     o_draws, o = _oracle(k_orc, d, init, st, prec=prec, chain0=500)
     assert np.array_equal(g["depth"], o["depth"])            # same trees
     assert np.array_equal(g["n_leap"], o["n_leap"])          # same executed leapfrogs
@@ -222,7 +226,7 @@ def test_memoised_kernel_at_every_launch_shape_gives_the_bits_of_the_tick_local_
         ref, r = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3, kernel_hint=mcmc_amd.KERNEL_NUTS_TICK_LOCAL)
         assert mcmc_amd.last_kernel().startswith("nuts_gauss_async_kernel")
         got, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=3)
-        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<8, false>")
+        assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<8, false, true>")     # (momenta from the pre-pass table)
         assert np.array_equal(got, ref)
         for k in ("n_accept", "n_leap", "eps", "depth"):
             assert np.array_equal(g[k], r[k]), k

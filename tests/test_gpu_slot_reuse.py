@@ -12,7 +12,7 @@ from mcmc_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-DYN_HINTS = ["KERNEL_NUTS_MEMO"]
+DYN_HINTS = ["KERNEL_NUTS_MEMO", "KERNEL_NUTS_MEMO_INTICK"]      # momenta from the pre-pass table (AUTO) / generated inside the tick
 
 
 @pytest.fixture
