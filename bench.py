@@ -200,6 +200,19 @@ def profiled_traffic(cfg_id, key, kernel_name):
     return None, why
 
 
+def profiled_kernel_ms(cfg_id, key, kernel_name):
+    """Average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats pass of this workload and this kernel
+    (profiles/r<N>_c<cfg>_pmc.json: derived.kernel_ms_avg, every launch of that run incl. its warm-up), or None."""
+    for _, p in sorted(committed_pmc(cfg_id), reverse=True):
+        try:
+            j = json.load(open(p))
+            if j.get("workload_key") == list(key) and same_kernel(kernel_name, j["derived"]["kernel"]):
+                return float(j["derived"]["kernel_ms_avg"]), os.path.relpath(p, ROOT)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def profiled_pipe_budget(cfg_id, key, kernel_name):
     """The combined-pipe budget of the dominant kernel -- (4 x VALU wave-instructions + MFMA busy cycles) / SIMD cycles -- from the newest
     committed counter pass of this workload AND this kernel (tools/summarize_prof.py: derived.pipe_budget); None if there is none."""
@@ -331,8 +344,8 @@ def extra_hmc_dense_precond(ctx):
             "kernel": mcmc_amd.last_kernel(), "value": float(C) * d * L * n_draws / (ms * 1e-3), "unit": "chain*dim*leapfrog-steps/s",
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
                          "flop_per_unit": (L * 4.0 * d * d + 6.0 * d * d) / (d * L)},
-            "note": "whole call incl. the host's INV / CHOL_LOWER of M and the literal replay launch; kernel alone 116.2 ms = 0.66 of peak in "
-                    "profiles/r5_dense_m_kernel_stats.csv"}
+            "note": "whole call incl. INV / CHOL_LOWER of M (round 6: on the device, mcmc_amd/csrc/linalg_device.hip; memoised after the first call) and the "
+                    "literal replay launch"}
 
 
 # ESS/sec legs: BASELINE's frozen settings of configs[2] (step_size 0.02: accept 0.99996, the chains barely move) and
@@ -625,6 +638,10 @@ def measure(cfg_id, steps, warmup, args, ctx, headline, chains_override=None, wa
         if bfrac > 1.0:
             out["roofline"]["bytes_model_term"]["why_null"] = ("n/a: the state is register-resident, nothing streams per unit -- the model's "
                                                                "32 B / unit are not moved (see hbm_TBps for what the launch moved)")
+        out["roofline"]["kernel_ms_source"] = "mean of the HIP-event durations of the timed steps on the launch stream (warm-up excluded)"
+        pk_ms, pk_src = profiled_kernel_ms(cfg_id, key, kernel_name) if want_traffic else (None, None)
+        if pk_ms:        # the same fraction from the committed rocprofv3 average (which includes that run's warm-up launch): the figure to quote next to profiles/
+            out["roofline"]["frac_rocprof"] = {"kernel_ms_avg": pk_ms, "frac": units_rank * fpu / (pk_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "source": pk_src}
         pb = profiled_pipe_budget(cfg_id, key, kernel_name) if want_traffic else None
         if pb is not None:           # what the kernel's instruction mix allows (fp64 VALU and MFMA share a pipe): frac / pipe_frac is the slack
             out["roofline"]["pipe_budget"] = pb

@@ -2220,7 +2220,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     // is affordable: at most MI_NUTS_MOMENTA_MAX_BYTES and a third of the device memory that is free right now; else -- and under
     // MI_KERNEL_NUTS_MEMO_INTICK -- the momenta are generated inside the tick, as in rounds 2-5.  Same bits either way.
     size_t mom_bytes = 0;
-    if (memo && (!gt.active || !settings->vals_bound) && target->kernel_hint != MI_KERNEL_NUTS_MEMO_INTICK) {
+    if (memo && !gt.active && target->kernel_hint != MI_KERNEL_NUTS_MEMO_INTICK) {          // (the plain case; with a diagonal precond_mat: in the tick, nuts_launch.hip)
         const size_t want = mi::nuts_memo_momenta_bytes(chains->n_chains, (uint32_t)n_total, nt);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;

@@ -54,7 +54,10 @@ int run_memo_k(const NutsParams& prm, hipStream_t st)
 template <int NT, bool DIAGM>
 int run_memo(const NutsParams& prm, hipStream_t st)
 {
-    return prm.mom != nullptr ? run_memo_k<NT, DIAGM, true>(prm, st) : run_memo_k<NT, DIAGM, false>(prm, st);
+    // (the table only without a mass matrix: with the two mass tables the d = 128 instantiation that reads it spills -- 80 B of scratch, 664 ms against
+    //  631 ms generating in the tick on a diagonal precond_mat, round 5: 652 -- so the host does not offer it there)
+    if constexpr (!DIAGM) { if (prm.mom != nullptr) return run_memo_k<NT, false, true>(prm, st); }
+    return run_memo_k<NT, DIAGM, false>(prm, st);
 }
 
 #ifdef MI_WITH_LEGACY_KERNELS   // the lock-step first-generation kernel (nuts_dense.hpp: 2.4 KB of scratch per lane at d = 128) ships in the
