@@ -18,8 +18,10 @@ def test_traffic_is_only_quoted_from_a_profile_of_the_kernel_that_ran():
     assert "nuts_gauss_dyn_kernel<8, false>" in json.load(open(os.path.join(ROOT, src)))["derived"]["kernel"]
     t2, why = bench.profiled_traffic(4, key, "nuts_gauss_no_such_kernel<8>")
     assert t2 is None and "not quoted" in why
-    tm, srcm = bench.profiled_traffic(4, key, "nuts_gauss_memo_kernel<8, false>")          # the kernel configs[3] runs on since round 5
-    assert tm is not None and tm < t and "nuts_gauss_memo_kernel<8, false>" in json.load(open(os.path.join(ROOT, srcm)))["derived"]["kernel"]
+    tm, srcm = bench.profiled_traffic(4, key, "nuts_gauss_memo_kernel<8, false, true>")    # what configs[3] runs on since round 6 (momenta from the pre-pass table)
+    assert tm is not None and tm < t and "nuts_gauss_memo_kernel<8, false, true>" in json.load(open(os.path.join(ROOT, srcm)))["derived"]["kernel"]
+    ti, whyi = bench.profiled_traffic(4, key, "nuts_gauss_memo_kernel<8, false, false>")   # the in-tick instantiation was never profiled under this name: no figure is made up
+    assert ti is None and "not quoted" in whyi
     t3, why3 = bench.profiled_traffic(4, (4, 1234, 128, 200), "nuts_gauss_dyn_kernel<8, false>")
     assert t3 is None and "another workload shape" in why3
 
