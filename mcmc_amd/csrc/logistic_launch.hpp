@@ -67,6 +67,10 @@ uint64_t logit_lds_nuts_workgroups(uint32_t d, uint64_t C, int target);
 // streamed products
 size_t logit_lds_dense_m_bytes(uint32_t d, uint64_t C, int target, int algo);
 int logit_lds_launch_dense_m(int algo, LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);
+// nuts with a dense precond_mat (prm.L_rm, prm.Minv_rm set; logistic_nuts_dense_m.hip): bytes of its `mws` and the launch (workspace: as for nuts)
+size_t logit_lds_nuts_dense_m_bytes(uint32_t d, uint64_t C, int target);
+uint64_t logit_lds_nuts_dense_m_workgroups(uint32_t d, uint64_t C, int target);        // workgroups of ITS persistent grid (the workspace is sized by 32 x this)
+int logit_lds_launch_nuts_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);
 int logit_lds_launch_hmc_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);     // logistic_hmc_dense_m.hip
 int logit_lds_launch_mala_dense_m(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, void* mws, hipStream_t st, int target);    // logistic_mala_dense_m.hip
 // packs X / y into `workspace` and runs the sampler on `st`; returns a hipError_t value (0 = launched)

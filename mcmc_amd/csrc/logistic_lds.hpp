@@ -114,7 +114,7 @@ template <int NTQ, int ALGO, int TARGET, bool DIAGM = false, bool BOUNDS = false
 __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO>())) void logit_lds_kernel(const LogitParams prm)
 {
     static_assert(!BOUNDS || (DIAGM && (ALGO == LOGIT_HMC || ALGO == LOGIT_NUTS)), "bounds: hmc and nuts, with the mass tables");
-    static_assert(!DENSEM || ((ALGO == LOGIT_HMC || ALGO == LOGIT_MALA) && !DIAGM && !BOUNDS), "a dense precond_mat: hmc and mala without bounds");
+    static_assert(!DENSEM || ((ALGO == LOGIT_HMC || ALGO == LOGIT_MALA || ALGO == LOGIT_NUTS) && !DIAGM && !BOUNDS), "a dense precond_mat: hmc, mala and nuts without bounds");
     using G = LogitGeo<NTQ>;
     constexpr int NSQ = G::NSQ, DQ = G::DQ, DP = G::DP, RSP = G::RSP;
     extern __shared__ double smem[];
@@ -545,7 +545,25 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
     if constexpr (ALGO == LOGIT_NUTS) {
         // NUTS (nuts.cpp:30-332): the per-chain tree state machine on this kernel's evaluation and exchange (nuts_lds.hpp); chains are
         // handed to the workgroup's 32 slots dynamically, their first evaluation is a state of that machine
-        nuts_lds_body<NTQ, DIAGM, BOUNDS>(prm, evaluate, part_all);
+        // DENSEM (round 6): the streamed products of INV(M) / CHOL_LOWER(M) as the tick's collectives (nuts_lds.hpp: dm)
+        struct DenseMOps {
+            decltype(stream_product)& sp; decltype(issue_piece_of)& ip; decltype(wait_loads)& wl; decltype(xbuf_parity)& xp;
+            const double*& nimg; uint32_t nbm;
+            __device__ __forceinline__ void product(const double* img, const double* next, const double (&x)[NSQ], double4_t (&acc)[NTQ]) const { nimg = next; sp(img, nbm, x, acc); }
+            __device__ __forceinline__ void next(const double* img) const { nimg = img; }
+            // block 0 of img into the buffer the next product starts from: the last product prefetched another matrix there (its DMA has landed and
+            // nobody reads that buffer: the product ended on a wait + barrier)
+            __device__ __forceinline__ void reload0(const double* img) const
+            {
+                const int buf = (int)xp();
+#pragma unroll
+                for (int i = 0; i < NP; ++i) ip(img, 0u, buf, i);
+                wl();
+                __syncthreads();
+            }
+        };
+        DenseMOps dm{stream_product, issue_piece_of, wait_loads, xbuf_parity, next_img, (d + 15u) / 16u};
+        nuts_lds_body<NTQ, DIAGM, BOUNDS, DENSEM>(prm, evaluate, part_all, dm);
         return;
     }
     double first_lp;

@@ -2103,14 +2103,18 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     q.max_depth = (uint32_t)settings->max_tree_depth;
     q.delta = settings->target_accept_rate; q.eps_bar0 = settings->step_size;
     q.gamma = settings->gamma_val; q.t0 = settings->t0_val; q.kappa = settings->kappa_val;
+    // a DENSE precond_mat without bounds (round 6): INV(M) and CHOL_LOWER(M) streamed through LDS like the target's matrix (nuts_lds.hpp: DENSEM)
+    const bool dense_m = lds_dense_m_ok(target, settings);
     LdsTables lt;
-    if ((rc = lds_tables("nuts", settings, d, lt, q))) return rc;      // (the caller routed bounds / a DIAGONAL matrix here)
+    LdsDenseM ldm;
+    if (dense_m) { if ((rc = lds_dense_m(settings, d, ldm, q, mi::LOGIT_HMC))) return rc; }
+    else if ((rc = lds_tables("nuts", settings, d, lt, q))) return rc;      // (the caller routed bounds / a DIAGONAL matrix here)
 
     // workspace: the kernel's own | non-finite flags | the matrix transposed and the work areas of the literal replay
     ReplayWs rp;
     rp.t_doubles = ((size_t)d * std::max<size_t>(d, n_rows) + 31) & ~(size_t)31;
     // (the kernel's workspace is sized by the chain SLOTS of its persistent grid, not by the chains)
-    const uint64_t n_slots = 32 * mi::logit_lds_nuts_workgroups(q.d, C, lds_target);
+    const uint64_t n_slots = 32 * (dense_m ? mi::logit_lds_nuts_dense_m_workgroups(q.d, C, lds_target) : mi::logit_lds_nuts_workgroups(q.d, C, lds_target));
     rp.own_bytes = (mi::logit_lds_workspace_bytes(q.d, q.NB, n_slots, lds_target, mi::LOGIT_NUTS) + 255) & ~(size_t)255;
     rp.stride = mi::lit::lit_work_doubles((uint32_t)d, dense ? 0u : (uint32_t)n_rows, false, q.max_depth, true, false);
     rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
@@ -2122,7 +2126,10 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     rc = replay_bind(rp, base.p, C, st);
     if (rc) return rc;
     q.nf_flag = rp.flag;
-    const int e = mi::logit_lds_launch(mi::LOGIT_NUTS, q, X_dev, y_dev, base.p, st, lds_target);
+    DevBuf mws;                                          // dense_m: the block images of the two matrices (+ the exchange vectors of their products)
+    if (dense_m) HIP_TRY(mws.alloc(mi::logit_lds_nuts_dense_m_bytes(q.d, C, lds_target)));
+    const int e = dense_m ? mi::logit_lds_launch_nuts_dense_m(q, X_dev, y_dev, base.p, mws.p, st, lds_target)
+                          : mi::logit_lds_launch(mi::LOGIT_NUTS, q, X_dev, y_dev, base.p, st, lds_target);
     if (e != 0) return fail(MI_ERR_HIP, "LDS-streamed nuts kernel launch: %s", hipGetErrorString((hipError_t)e));
     const std::string lds_name = mi::host::last_kernel();
     {
@@ -2139,21 +2146,31 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
         lp.n_adapt = q.n_adapt; lp.max_depth = q.max_depth;
         lp.delta = q.delta; lp.gamma = q.gamma; lp.t0 = q.t0; lp.kappa = q.kappa;
         lp.step_out = sc.dev.step_size; lp.depth_trace = sc.dev.nuts_depth; lp.adapt_state = sc.dev.nuts_adapt_state;
-        lds_tables_replay(lt, q, lp);
+        LitDev ldev;
+        if (dense_m) {                                   // the replay's own copies of M, INV(M), CHOL_LOWER(M) (transposed: literal_host.hpp)
+            mi::lit::LitPrep prep;
+            rc = mi::lit::lit_prepare(0, (uint32_t)d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+            if (rc) return rc;
+            rc = lit_upload(prep, (uint32_t)d, false, ldev, lp);
+            if (rc) return rc;
+        }
+        else lds_tables_replay(lt, q, lp);
         rc = launched("LDS-streamed nuts kernel (literal replay)", mi::launch_literal(2, lp, rp.n_wg, st));
+        if (!rc && dense_m) HIP_TRY(hipStreamSynchronize(st));     // (the replay's matrices are ours)
 
         if (rc) return rc;
         mi::host::last_kernel() = lds_name;
     }
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st, n_total);
     if (rc) return rc;
-    if (Xo.p || P_owned.p || lt.ms.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (Xo.p || P_owned.p || lt.ms.p || dense_m || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
-// the cases nuts_lds.hpp covers (everything else on these targets: literal.hpp)
+// the cases nuts_lds.hpp covers (everything else on these targets: literal.hpp): no bounds / bounds with the identity or a diagonal precond_mat, and --
+// round 6 -- a DENSE precond_mat without bounds
 bool lds_nuts_case(const mi_target* target, const mi_settings* settings)
 {
-    return lds_general_ok(target, settings) && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
+    return (lds_general_ok(target, settings) || lds_dense_m_ok(target, settings)) && settings->max_tree_depth >= 1 && settings->max_tree_depth <= 10;
 }
 
 // The plain case (unbounded; identity or a diagonal precond_mat) runs on nuts_memo.hpp.  The register-carried kernels of rounds 2-4 (nuts_reg.hpp,

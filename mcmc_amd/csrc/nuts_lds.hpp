@@ -56,7 +56,8 @@ enum : int {
     V_PPW0 = 52,
     V_TMPP = 40,             // the momentum across an evaluation (wide tiles)
     V_TMPT = 52,             // BOUNDS: theta across an evaluation (the registers hold x = inv_transform(theta) meanwhile)
-    NVEC = 64,
+    V_XT = 64, V_XW = 65, V_XP = 66,   // DENSEM: theta / gradient / momentum of the last leaf while a streamed product of the preconditioner has the registers
+    NVEC = 68,
     MAX_DEPTH = 10,
     LVLS = 12,
     SC_PER_CHAIN = 64        // doubles of per-chain scalars: [level][4] + the dual-averaging state at 48..50
@@ -73,9 +74,19 @@ __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 *
 // BOUNDS: settings.vals_bound (lds_box.hpp): the tree lives in the transformed space (the U-turn dots are plain), the target is evaluated at
 // x = inv_transform(theta), the kicks carry the inverse Jacobian, the potential the log-Jacobian, rows are reported through inv_transform.
 // Always together with DIAGM (tables of ones for the identity: 1.0 * p is p).
-template <int NTQ, bool DIAGM, bool BOUNDS, class Eval>
-__device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all)
+// DENSEM (round 6): a DENSE precond_mat without bounds (nuts.cpp:57-59: inv_precond_matrix = INV(M), sqrt_precond_matrix = CHOL_LOWER(M); :168,202
+// p = L z; leap_frog_fn :139-154 theta += e (Minv p); nuts.ipp:51,66,140 and nuts.cpp:204 K = p . (Minv p) / 2; the U-turn dots are plain).  `dm`:
+//     dm.product(img, next, x, acc) -- acc = A x for the matrix with block images img (prm.Lp / prm.Mip), streamed through LDS like the target's
+//                                      matrix by the whole workgroup; `next` = the images whose block 0 its last block prefetches
+//     dm.reload0(img)               -- block 0 of img into the buffer the next product starts from (the prefetch guessed another matrix)
+//     dm.next(img)                  -- what the NEXT evaluation of the target prefetches behind its last block
+// Per leaf: Minv p for the drift, the evaluation, Minv p for the kinetic energy -- three streamed products instead of one, each one fma chain per
+// element over the columns in ascending order (the oracle's orc_gemv).  Per draw: L z and Minv (L z).  A product needs the registers of two
+// vectors, so on the wide tiles the leaf's theta / gradient wait in the workspace meanwhile (V_XT, V_XW).
+template <int NTQ, bool DIAGM, bool BOUNDS, bool DENSEM = false, class Eval, class DM>
+__device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all, [[maybe_unused]] DM& dm)
 {
+    static_assert(!DENSEM || (!DIAGM && !BOUNDS), "a dense precond_mat: without bounds");
     using namespace lds_nuts;
     constexpr int NS = 4 * NTQ, DQ = 16 * NTQ;
     constexpr bool PM_MEM = NTQ >= 6;                    // the momentum leaves the registers for the evaluation
@@ -384,6 +395,29 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
             const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
+            if constexpr (DENSEM) {
+                // p = CHOL_LOWER(M) z (:202) and K = p . (INV(M) p) / 2 (:204): two streamed products; the last leaf waits in the workspace meanwhile
+                st_row(V_XT, 0, th); st_row(V_XP, 0, pm); st_row(V_XW, 0, w);
+                double zv[NS];
+#pragma unroll
+                for (int b = 0; b < NS / 2; ++b) {
+                    double z0, z1;
+                    rng_normal_pair(prm.seed, prm.chain0 + cl, nidx + prm.draw0, (uint32_t)(q * DQ / 2 + 4 * b + j4), STREAM_NORMAL, z0, z1);
+                    zv[2 * b] = (dim_of(2 * b) < d) ? z0 : 0.0;
+                    zv[2 * b + 1] = (dim_of(2 * b + 1) < d) ? z1 : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                double4_t acc[NTQ];
+                dm.reload0(prm.Lp);                          // (the last product prefetched INV(M) for a drift: this tick starts with a phase)
+                dm.product(prm.Lp, prm.Mip, zv, acc);
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) zv[s_] = acc[s_ >> 2][s_ & 3];
+                if (gen) st_row(mvn, 0, zv);
+                dm.product(prm.Mip, prm.Mip, zv, acc);       // (whatever follows -- INIT's product reloads its own block 0 -- starts from INV(M))
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) kq = dfma(zv[s_], acc[s_ >> 2][s_ & 3], kq);
+                ld_row(V_XT, 0, th); ld_row(V_XP, 0, pm); ld_row(V_XW, 0, w);
+            } else {
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {               // nuts.cpp:200-202, this chain's own draw index
                 double z0, z1;
@@ -399,6 +433,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                     kq = dfma(pb_, pb_, kq);
                 }
                 if (gen) st_pair(mvn, 2 * b, pa, pb_);
+            }
             }
             double v1[1] = {fold(kq)};
             (void)exchange(v1, 0u);
@@ -452,7 +487,15 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         // one leapfrog of size e (nuts.ipp:132 / :64, nuts.cpp:139-154), grad = w.  INIT: e = 0 and the state is set after the (idle) updates
         const double e_tick = run ? e_signed : (srch ? eps : 0.0);
         kick(e_tick);
-        drift(e_tick);
+        if constexpr (DENSEM) {                          // theta += e (INV(M) p) (nuts.cpp:148): the gradient is dead after the kick, the product takes its registers
+            constexpr bool PARK_T = NTQ >= 6;
+            if constexpr (PARK_T) st_row(V_XT, 0, th);
+            double4_t mp[NTQ];
+            dm.product(prm.Mip, prm.Xp, pm, mp);
+            if constexpr (PARK_T) ld_row(V_XT, 0, th);
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) th[s_] = th[s_] + e_tick * mp[s_ >> 2][s_ & 3];
+        } else drift(e_tick);
         if (any(init)) {                                 // first_draw and z_init (nuts.cpp:160-168): an evaluation, no leapfrog
             if (init) {
 #pragma unroll
@@ -474,15 +517,45 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             }
             if (init) ld_row(V_TMPP, 0, pm);
         }
+        if constexpr (DENSEM) {
+            // z_init is multiplied by CHOL_LOWER(M) too (nuts.cpp:168): a collective, so the workgroup votes on "a chain is in INIT"
+            if (wg_or(any(init) ? 1u : 0u) != 0u) {
+                st_row(V_XT, 0, th); st_row(V_XW, 0, w);
+                double zv[NS];
+                ld_row(V_TMPP, 0, zv);                       // (every lane of the wave stored its z_init slice above when some lane was in INIT; others: stale, unused)
+                double4_t acc[NTQ];
+                dm.reload0(prm.Lp);                          // (the drift's product prefetched the target's block 0: the evaluation comes after this one)
+                dm.product(prm.Lp, prm.Xp, zv, acc);
+                if (init) {
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; ++s_) pm[s_] = acc[s_ >> 2][s_ & 3];
+                }
+                ld_row(V_XT, 0, th); ld_row(V_XW, 0, w);
+            }
+        }
         MI_LPROF(3);
         if constexpr (PM_MEM) st_row(V_TMPP, 0, pm);
         if constexpr (BOUNDS) { st_row(V_TMPT, 0, th); box.x_inplace(th); }      // the target sees x = inv_transform(theta) (hmc.cpp:108)
+        if constexpr (DENSEM) dm.next(prm.Mip);          // the kinetic energy's product follows the evaluation
         evaluate(th, w, val);
         if constexpr (BOUNDS) ld_row(V_TMPT, 0, th);
         if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
         MI_LPROF(4);
         // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
         double q1 = 0.0, q2 = 0.0, pk = 0.0;
+        if constexpr (DENSEM) {
+            // K' = p' . (INV(M) p') / 2 (nuts.ipp:140): the second half-kick first, then the product of the new momentum (theta and the new gradient wait in
+            // the workspace on the wide tiles), then the dots of the pass below without its kick and kinetic terms
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) pm[s_] = pm[s_] + (e_tick * w[s_]) / 2.0;
+            constexpr bool PARK_TW = NTQ >= 4;
+            if constexpr (PARK_TW) { st_row(V_XT, 0, th); st_row(V_XW, 0, w); }
+            double4_t mp[NTQ];
+            dm.product(prm.Mip, prm.Mip, pm, mp);            // (the next tick's drift follows; a phase or an INIT in between reloads its own block 0)
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) pk = dfma(pm[s_], mp[s_ >> 2][s_ & 3], pk);
+            if constexpr (PARK_TW) { ld_row(V_XT, 0, th); ld_row(V_XW, 0, w); }
+        }
 #pragma unroll
         for (int c0 = 0; c0 < NS; c0 += CH) {
             double tb[CH], pbv[CH];
@@ -493,12 +566,12 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             for (int k = 0; k < CH; ++k) {
                 const int s = c0 + k;
                 if constexpr (BOUNDS) pm[s] = pm[s] + (e_tick * box.jgrad(th[s], w[s], s)) / 2.0;
-                else pm[s] = pm[s] + (e_tick * w[s]) / 2.0;
+                else if constexpr (!DENSEM) pm[s] = pm[s] + (e_tick * w[s]) / 2.0;
                 const double dd = (vdir > 0) ? (th[s] - tb[k]) : (tb[k] - th[s]);
                 q1 = dfma(dd, pbv[k], q1);
                 q2 = dfma(dd, pm[s], q2);
                 if constexpr (DIAGM) pk = dfma(pm[s], mass_at(prm.m_inv, s) * pm[s], pk);
-                else pk = dfma(pm[s], pm[s], pk);
+                else if constexpr (!DENSEM) pk = dfma(pm[s], pm[s], pk);
             }
         }
         MI_LPROF(5);

@@ -167,9 +167,57 @@ def test_lds_nuts_refusals_and_fallbacks_are_the_documented_ones():
     d, C = 160, 4
     prec = synth.dense_gaussian_precision(d, seed=1)
     init = synth.initial_states(C, d, seed=1) * 0.5
-    # a dense preconditioner / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal (bounds: tests/test_gpu_lds_bounds.py)
+    # a dense preconditioner WITH bounds / trees deeper than 10 / max_tree_depth = 0: the literal kernel, not a refusal (bounds alone:
+    # tests/test_gpu_lds_bounds.py; a dense preconditioner alone: the streamed kernel since round 6, below)
     A = np.random.default_rng(3).standard_normal((d, d)) / np.sqrt(d)
-    for kw in (dict(precond_mat=A @ A.T + np.eye(d)), dict(max_tree_depth=11), dict(max_tree_depth=0)):
+    lb = np.full(d, -np.inf); ub = np.full(d, np.inf); lb[0] = -50.0; ub[1] = 50.0
+    for kw in (dict(precond_mat=A @ A.T + np.eye(d), vals_bound=1, lower_bounds=lb, upper_bounds=ub), dict(max_tree_depth=11), dict(max_tree_depth=0)):
         st = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=1, n_keep_draws=1, n_adapt_draws=1, step_size=0.1, **{"max_tree_depth": 3, **kw})
         mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
         assert mcmc_amd.last_kernel().startswith("literal_kernel<")
+
+
+# ---- round 6: a DENSE precond_mat on the same kernels (nuts_lds.hpp: DENSEM; ref: src/nuts.cpp:57-59 inv_precond_matrix = INV(M), sqrt_precond_matrix =
+# CHOL_LOWER(M); :168,202 p = L z; :148 theta += e (Minv p); nuts.ipp:51,66,140 and nuts.cpp:204 K = p.(Minv p) / 2; the U-turn dots are plain): both
+# matrices streamed through LDS like the target's, three products per leaf; the literal kernel served this case until round 5
+def _dense_m(d, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    return A @ A.T + np.diag(rng.uniform(0.4, 2.5, d))
+
+
+DM_CASES = [("logistic", 20, 37, 37, 5), ("logistic", 100, 16, 5, 5), ("logistic", 200, 50, 37, 4), ("logistic", 512, 37, 5, 4),
+            ("dense", 160, 0, 37, 5), ("dense", 256, 0, 37, 5), ("dense", 300, 0, 5, 4), ("dense", 512, 0, 37, 3)]
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C,depth", DM_CASES)
+def test_lds_nuts_with_a_dense_precond_mat_matches_the_oracle(kind, d, n_rows, C, depth):
+    tk, tkw, spec = _problem(kind, d, n_rows, seed=d)
+    M = _dense_m(d, d + 11)
+    init = synth.initial_states(C, d, seed=d + 1) * (0.1 if kind == "logistic" else 0.5)
+    if C > 10:
+        init[5] *= 1e200; init[9, 3] = np.inf              # two chains leave the finite regime: flagged, replayed literally with the same matrices
+    eps = 0.05 if kind == "logistic" else 0.1
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=3, n_keep_draws=3, n_adapt_draws=4, max_tree_depth=depth, step_size=eps, precond_mat=M)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=3, **tkw)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and "nuts" in kern and kern.endswith("false, false, true>"), kern
+    s = orc.make_settings(seed=7, n_burnin=3, n_keep=3, n_adapt=4, max_depth=depth, step=eps, W=4, hoist=1, precond=M, blocks=4, block_size=_bs(kind, d))
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
+    assert o["n_leap"].max() > 2 ** (depth - 2), "the case is meant to grow trees of several levels"
+    _same(g_draws, g, o_draws, o, depth=False)
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 300, 40, 70), ("dense", 256, 0, 100)])
+def test_lds_nuts_with_a_dense_precond_mat_matches_the_literal_kernel_on_longer_runs(kind, d, n_rows, C):
+    """more chains than slots of two workgroups' tiles are not needed here (the grid cap test covers recycling): a longer run with the adaptation
+    window ending inside it, against literal_kernel<2> of the same library, and cut in two through mi_chains.draw0"""
+    tk, tkw, _ = _problem(kind, d, n_rows, seed=d + 2)
+    M = _dense_m(d, d + 13)
+    init = synth.initial_states(C, d, seed=d + 3) * (0.1 if kind == "logistic" else 0.5)
+    st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=6, n_keep_draws=6, n_adapt_draws=8, max_tree_depth=6, step_size=0.08, precond_mat=M)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, **tkw)
+    assert mcmc_amd.last_kernel().endswith("false, false, true>")
+    l_draws, l = mcmc_amd.sample("nuts", tk, init, st, kernel_hint=mcmc_amd.KERNEL_LITERAL, **tkw)
+    assert mcmc_amd.last_kernel().startswith("literal_kernel<2>")
+    _same(g_draws, g, l_draws, l, depth=True)
