@@ -6,6 +6,8 @@
 //                                         uniform) come from a TABLE a pre-pass kernel filled at full occupancy (prm.mom, prm.msc: nuts_memo.hpp) instead of
 //                                         being generated inside the tick, where 128 Box-Muller normals per chain and draw are pure latency of a wave that is
 //                                         alone on its SIMD.  Same Philox counters, same operations, same bits.
+//     static constexpr bool LANE_WALK  -- the merges of a leaf four levels per round, one accept decision per lane class (MI_MEMO_WALK_V2 below), or one level per
+//                                         iteration (the instantiations that have no registers left for the round's operands)
 //     double enter(v, dim)             -- initial_vals into the sampler's space (nuts.cpp:160-162); leave(v, slice): the way back for rows / theta
 //     double msqrt_times(z, dim)       -- sqrt_precond_matrix * z (nuts.cpp:168, 202);   double minv_times(p, dim): inv_precond_matrix * p, element-wise
 //     void kick(th, pm, w, e, act)     -- p += (e [J^-1] grad) / 2 (nuts.cpp:108-135) on the lanes `act`;   drift(th, pm, e, act): theta += e (Minv p) (:139-154)
@@ -21,6 +23,19 @@
 
 #ifndef MI_MEMO_RNG_ILP
 #define MI_MEMO_RNG_ILP 1        // Box-Muller pairs per iteration of the momentum loop.  Measured on configs[3] (NT = 8): 1: 518 ms; 2: 28 B of scratch; 4: 548 ms (no scratch, but the interleaved pairs push 15 more state registers through the AGPRs around the loop)
+#endif
+
+#ifndef MI_MEMO_WALK_V2
+#define MI_MEMO_WALK_V2 1        // the merges of a leaf (nuts.ipp:212-229) four levels per round: a leaf with t trailing ones in its index merges at the levels
+                                 // 1 .. t, and what those merges need -- the pending halves' n', n_alpha', alpha', proposal and the test bits -- is on record before the
+                                 // leaf is walked, so the counts are prefix sums and only the accept decisions differ by level: lane class j4 of a chain takes the
+                                 // decision of the level whose uniform it holds (no shuffles), a ballot collects them.  0: one level per iteration of a loop (round 5:
+                                 // ~110 instructions per level and ~4 levels per leaf for the slowest chain of a wave; the walk was 19 % of the tick)
+#endif
+#ifndef MI_MEMO_APF
+#define MI_MEMO_APF 0            // alpha of the leaves a walk can reach in this tick (nuts.ipp:157, on record in the scalar table) requested TOGETHER, ahead of the
+                                 // walk (1: behind the mat-vec; 2: in front of it), instead of one load per walk iteration: every iteration waited out a
+                                 // round trip to memory for 8 bytes (~2 k cycles of a 52 k tick x 4.8 iterations).  0: the per-iteration load.  Needs a walk cap
 #endif
 
 #include "hmc_dense.hpp"
@@ -544,6 +559,31 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             n_leap_() += 1ull; n_exec_() += 1ull;
         }
         const double e_tick = newpt ? esg_() : (srch ? eps_() : 0.0);
+#if MI_MEMO_APF > 0 && MI_MEMO_WALK_CAP > 0
+        // alpha of the next MI_MEMO_WALK_CAP leaves of a running chain whose points exist once this tick's point does (the walk below stops at the first
+        // one that does not): requested here in one go.  The leaf sequence li, li + 1, .. and their points are known before the point is computed; this
+        // tick's own point is taken from the registers in the walk
+        double apf[MI_MEMO_WALK_CAP];
+#pragma unroll
+        for (int k = 0; k < MI_MEMO_WALK_CAP; ++k) apf[k] = 0.0;
+        auto request_alphas = [&]() __attribute__((always_inline)) {
+            if (__ballot(run) == 0ull) return;
+            uint32_t i_ = li, n_ = memo_npt(li);
+            const uint32_t np_ = newpt ? mpt : npts;
+            bool ok_ = run;
+#pragma unroll
+            for (int k = 0; k < MI_MEMO_WALK_CAP; ++k) {
+                const uint32_t t_ = (uint32_t)__builtin_ctz(~i_);
+                const uint32_t nn_ = n_ + (t_ + 1u) - t_ * (t_ + 1u) / 2u;       // the point of leaf i_ + 1
+                ok_ = ok_ && nn_ <= np_;
+                if (ok_ && !(newpt && nn_ == mpt)) apf[k] = scp(nn_)->x;
+                i_ = i_ + 1u; n_ = nn_;
+            }
+        };
+#endif
+#if MI_MEMO_APF == 2 && MI_MEMO_WALK_CAP > 0
+        request_alphas();
+#endif
         // one leapfrog of signed size e (nuts.ipp:132, nuts.cpp:139-154): the policy's half-kick, drift, gradient evaluation, half-kick
         // (act: the lanes that really step.  INIT and cut-short lanes pass e = 0: a policy with REPLAY may let them through -- x + 0 y is x unless y is
         //  non-finite, and then the chain is flagged and replayed anyway -- a policy without must leave their registers alone)
@@ -604,6 +644,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             okb_(11) = (okb_(11) & ~bit) | (cs_b ? bit : 0ull);
             n_exec_() += 1ull;
         }
+#if MI_MEMO_APF == 1 && MI_MEMO_WALK_CAP > 0
+        request_alphas();
+#endif
         MI_MPROF(8)
         // ---- the tests whose second point this is: [ d . p(n1) >= 0 ] * [ d . p(mpt) >= 0 ], d = theta(mpt) - theta(n1) by direction (:224-229).
         //      LOADS ONLY between here and the end of the walk: memory operations of a wave complete in order, and a load behind the 3 KB of a
@@ -674,7 +717,13 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             // the next leaf's alpha, in case the chain gets that far: on record if its point exists -- this tick's own point is still in registers
             const uint32_t t1 = (uint32_t)__builtin_ctz(~li);
             const uint32_t nn = n + (t1 + 1u) - t1 * (t1 + 1u) / 2u;         // the point of leaf li + 1
+#if MI_MEMO_APF > 0 && MI_MEMO_WALK_CAP > 0
+            ca_nx = (newpt && nn == mpt) ? ca_pt : apf[0];                   // (requested ahead: this lane's k-th iteration is its k-th leaf of the tick)
+#pragma unroll
+            for (int k = 0; k + 1 < MI_MEMO_WALK_CAP; ++k) apf[k] = apf[k + 1];
+#else
             if (wl && nn <= npts) ca_nx = (newpt && nn == mpt) ? ca_pt : scp(nn)->x;
+#endif
             const unsigned long long nbit = 1ull << n;
             if (wl) {
                 cn_i = (okb_(0) & nbit) ? 1u : 0u;
@@ -682,8 +731,87 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 n_walked++;
             }
             bool failed = wl && !(okb_(11) & nbit);
-            bool walking = wl;
             uint32_t pend_level = jd + 1;
+            if constexpr (MI_MEMO_WALK_V2 != 0 && POL::LANE_WALK) {
+            // levels 1 .. t1 (the trailing ones of li; li < 2^jd, so t1 <= jd): every one of them merges (a failure on the way does not stop the merges of
+            // nuts.ipp:212-222 above it, and their alpha sums reach the dual averaging), in rounds of four
+            const bool failed0 = failed;
+            const uint32_t tm = wl ? t1 : 0u;
+            uint32_t lb = 0;                                                 // levels done
+#pragma unroll 1
+            while (__ballot(lb < tm) != 0ull) {
+                const bool act_r = lb < tm;
+                const uint32_t cnt = act_r ? (((tm - lb) < 4u) ? (tm - lb) : 4u) : 0u;
+                // the uniforms of slots [uslot, uslot + cnt) (:213, one per merge, in level order): lane class j4 holds slot ub0 + j4
+                {
+                    const bool stale = act_r && ((uslot - ub0) >= 4u || (uslot - ub0) + cnt > 4u);
+                    if (__ballot(stale) != 0ull) {               // every chain of the wave refills from its own current slot
+                        ub0 = uslot;
+                        const u32x4 wv = rng_block(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot + (uint32_t)j4, STREAM_UNIFORM);
+                        ubuf = 2ull * ((((unsigned long long)wv.y << 32) | (unsigned long long)wv.x) >> 12) + 1ull;
+                    }
+                }
+                const uint32_t off = uslot - ub0;                            // this lane decides merge kj = j4 - off of the round (if there is one)
+                const uint32_t kj = (uint32_t)j4 - off;
+                const bool valid_j = act_r && (uint32_t)j4 >= off && kj < cnt;
+                const uint32_t rb = lrow + lb * 512u;                        // rows of level lb + 1 + k at immediate offsets
+                double lav[4]; unsigned long long lpv[4], okv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lav[k] = *(lds_dptr)(uintptr_t)(rb + (uint32_t)(R_LA + 1 + k) * 512u);
+                    lpv[k] = *(lds_uptr)(uintptr_t)(rb + (uint32_t)(R_LP + 1 + k) * 512u);
+                    okv[k] = *(lds_uptr)(uintptr_t)(rb + (uint32_t)(R_OKB + 1 + k) * 512u);
+                }
+                uint32_t pn[4], pna[4], prf[4], pre[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t pk = (uint32_t)lpv[k];
+                    pn[k] = pk & 0x7ffu; pna[k] = (pk >> 11) & 0x7ffu; prf[k] = pk >> 22;
+                }
+                pre[0] = cn_i; pre[1] = pre[0] + pn[0]; pre[2] = pre[1] + pn[1]; pre[3] = pre[2] + pn[2];      // n'' of the merge: the counts below it
+                const uint32_t a_j = (kj == 0u) ? pre[0] : (kj == 1u) ? pre[1] : (kj == 2u) ? pre[2] : pre[3];
+                const uint32_t p_j = (kj == 0u) ? pn[0] : (kj == 1u) ? pn[1] : (kj == 2u) ? pn[2] : pn[3];
+                // :212, :215-217: keep new_draw_p unless u < n'' / (n' + n'') (0 / 0 = NaN keeps); the HIGHEST level that replaces it decides
+                const bool rej = valid_j && !u_below(ubuf, a_j, p_j + a_j);
+                const unsigned long long mine = (__ballot(rej) >> (lane & 15)) & 0x0001000100010001ull;
+                if (act_r && mine != 0ull) {
+                    const uint32_t ks = ((63u - (uint32_t)__builtin_clzll(mine)) >> 4) - off;
+                    cref = (ks == 0u) ? prf[0] : (ks == 1u) ? prf[1] : (ks == 2u) ? prf[2] : prf[3];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((uint32_t)k < cnt) {
+                        cn_i = cn_i + pn[k];                                 // :220-222
+                        cna_i = cna_i + pna[k];
+                        ca = lav[k] + ca;
+                        if (!failed0) {                                      // :226-229, evaluated when its second point appeared
+                            const uint32_t l = lb + 1u + (uint32_t)k;
+                            const uint32_t n1 = n - l * (l + 1u) / 2u;       // the node's first leaf: li with its l low (set) bits cleared
+                            if (!((okv[k] >> n1) & 1ull)) failed = true;
+                        }
+                    }
+                }
+                if (act_r) { uslot += cnt; lb += cnt; }
+            }
+            // a leaf that failed: the merges at the set bits of li above its first zero bit (a first half of a failed subtree returns at once, a second half
+            // merges).  The draw ends with this doubling, so of those merges only the sums that reach the dual averaging matter (alpha', n_alpha': src/nuts.cpp
+            // :246,255,294-302); the proposal, n' and the uniforms of a failed doubling are read by nobody
+            {
+                uint32_t hb = (wl && failed) ? ((li >> (t1 + 1u)) << (t1 + 1u)) : 0u;
+#pragma unroll 1
+                while (__ballot(hb != 0u) != 0ull) {
+                    if (hb != 0u) {
+                        const uint32_t l = (uint32_t)__builtin_ctz(hb) + 1u;
+                        const uint32_t ra = lrow + l * 512u;
+                        ca = *(lds_dptr)(uintptr_t)(ra + (uint32_t)R_LA * 512u) + ca;
+                        cna_i = cna_i + (((uint32_t)*(lds_uptr)(uintptr_t)(ra + (uint32_t)R_LP * 512u) >> 11) & 0x7ffu);
+                        hb &= hb - 1u;
+                    }
+                }
+            }
+            pend_level = t1 + 1u;
+            } else {
+            bool walking = wl;
 #pragma unroll 1
             for (uint32_t l = 1; l <= (uint32_t)MEMO_MAX_DEPTH; ++l) {
                 if (walking && l > jd) walking = false;                      // reached the root of its own tree
@@ -706,6 +834,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                         if (!((okb_((int)l) >> n1) & 1ull)) failed = true;
                     }
                 }
+            }
             }
             if (wl) {
                 const bool keep = !failed;

@@ -39,6 +39,10 @@ struct TileMemoPolicy {
     static constexpr int NT = T::NT, NS = 4 * NT;
     static constexpr bool REPLAY = false;
     static constexpr bool PRE_MOM = false;       // momenta generated inside the tick (the table of nuts_memo.hpp belongs to the built-in kernel's launcher)
+#ifndef MI_TILE_LANE_WALK
+#define MI_TILE_LANE_WALK 1
+#endif
+    static constexpr bool LANE_WALK = MI_TILE_LANE_WALK != 0;
     const T& tgt;
     double* lds_t;               // the target's own LDS (its matrices in fragment order)
     const TileGen<T::NT>& tg;    // GEN: bounds / mass tables
