@@ -35,7 +35,8 @@ struct LogitParams {
     double* nuts_ws;
     double* nuts_sc;
     uint32_t* nuts_next;    // chains handed out beyond the first gridDim.x * 32 (zeroed by the launcher)
-    uint64_t* n_leap_out;   // [C] leapfrog steps of every chain, or nullptr
+    uint64_t* n_leap_out;   // [C] leapfrog steps of every chain as the reference counts them (one per leaf), or nullptr
+    uint64_t* n_exec_out;   // [C] leapfrogs really made (one per distinct point of a doubling's trajectory + the step-size search), or nullptr
     double* step_out;       // [C] step sizes: out (and in, for a continuation: draw0 > 0), or nullptr
     uint32_t* depth_trace;  // [n_total][C] tree depth of every draw, or nullptr
     double* adapt_state;    // [3][C] dual-averaging state (h, eps_bar, mu): out (and in, for a continuation inside the window), or nullptr

@@ -2098,6 +2098,7 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     q.n_burnin = (uint32_t)settings->n_burnin_draws; q.n_keep = (uint32_t)settings->n_keep_draws;
     q.draw0 = (uint32_t)chains->draw0;
     q.n_leap_out = sc.dev.n_leapfrogs; q.step_out = sc.dev.step_size; q.depth_trace = sc.dev.nuts_depth;
+    q.n_exec_out = sc.dev.n_leapfrogs_executed; sc.exec_written = q.n_exec_out != nullptr;      // (every doubling on a memoised trajectory: nuts_lds.hpp)
     if ((rc = nuts_continuation(settings, chains, &q.n_adapt))) return rc;
     q.adapt_state = sc.dev.nuts_adapt_state;
     q.max_depth = (uint32_t)settings->max_tree_depth;
@@ -2156,6 +2157,10 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
         }
         else lds_tables_replay(lt, q, lp);
         rc = launched("LDS-streamed nuts kernel (literal replay)", mi::launch_literal(2, lp, rp.n_wg, st));
+        if (!rc && q.n_exec_out) {                       // a replayed chain executed every leapfrog it counts
+            hipLaunchKernelGGL(copy_flagged_counts_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, rp.flag, q.n_leap_out, q.n_exec_out, C);
+            HIP_TRY(hipGetLastError());
+        }
         if (!rc && dense_m) HIP_TRY(hipStreamSynchronize(st));     // (the replay's matrices are ours)
 
         if (rc) return rc;

@@ -6,19 +6,30 @@
 // (ref: src/nuts.cpp:30-332, include/mcmc/nuts.ipp:30-241; leap_frog_fn src/nuts.cpp:139-154), identity or DIAGONAL precond_mat, with or without
 // settings.vals_bound (lds_box.hpp).
 //
-// The sampler is the asynchronous per-chain tree state machine of rounds 2-4's nuts_reg.hpp (retired) / include/mi_mcmc_engine/nuts_tile.hpp (iterative
-// leaf-indexed tree: nuts_dense.hpp; eager U-turn tests, momenta generated ahead, draw boundaries without waiting), with two changes
-// that the evaluation forces:
+// The sampler evaluates every doubling on a MEMOISED TRAJECTORY (round 6; the derivation is nuts_memo.hpp's): the reference's second-half
+// calls cross their edge outputs (nuts.ipp:195,207) and every doubling restarts from (prev_draw, mntm_vec) (src/nuts.cpp:241-256), so leaf i of a doubling
+// is the state LF^{n(i)}(prev_draw, mntm_vec), n(i) = 1 + the sum over the set bits k of i of (k + 1): the 2^j leaves of a doubling visit only
+// 1 + j (j + 1) / 2 distinct points of ONE leapfrog trajectory, and the U-turn test of a level-l node whose first leaf sits at point n1 compares the points
+// n1 and n1 + l.  Per tick a running chain computes the NEXT POINT of its trajectory (one leapfrog = one evaluation of the target, which here is everything:
+// 4 N d flops), evaluates the tests whose second point this is, and then WALKS the leaves the point unblocks exactly as the recursion returns through them
+// (nuts.ipp:212-239: the same merges in the same order, one uniform per merge from the same Philox slot, the same early exit) on memoised scalars -- no
+// vector work.  Same draws, accepts, depths, leapfrog counts and step sizes as the leaf-per-tick machine of round 4 (and as the recursive oracle and
+// literal_kernel<2>), bit for bit; on bench.py's nuts-on-configs[2]'s-target leg 22 % of the leapfrogs the reference counts are distinct: 3 826 -> 1 012 ms.
+// What the evaluation forces:
 //   * a chain's vectors are split over the FOUR waves of its tile (wave q: dims [q DQ, (q+1) DQ)), every per-chain scalar is replicated
 //     in the four waves, and every dot product over dimensions is ((S0 + S1) + S2) + S3 of the waves' 4-strided partial dots through
 //     LDS -- the order the hmc / mala kernels of logistic_lds.hpp and the oracle's blocked reductions use (orc_dot_b);
-//   * the evaluation is a WORKGROUP collective (its block stream is shared by both tiles), so a tick -- one leapfrog for every running
-//     chain -- is taken by the 32 chains of a workgroup together and every decision that guards a collective is a workgroup vote.
-//     Chains stay asynchronous inside that: each is at its own leaf of its own tree of its own draw, so no lane waits for a longer tree.
-// Registers hold (theta, p, grad) of the chain's last leaf; the momentum crosses the evaluation through the workspace when the tile is
-// wide (NTQ >= 6: the evaluation's accumulators take its registers).  Records, pending proposals and the per-level scalars live in
-// global memory (LDS is full of matrix): vectors chain-major inside a wave's block so that a chain's row is contiguous whatever
-// record each chain of the wave addresses.
+//   * the evaluation is a WORKGROUP collective (its block stream is shared by both tiles), so a tick -- one point for every running
+//     chain -- is taken by the 32 chains of a workgroup together and every decision that guards a collective is a workgroup vote: the point's first
+//     test shares the pass over the registers and the exchange with the kinetic energy, every further test of the point (one point in six has a second
+//     one) and the whole tree's test (:286-289) are a pass and an exchange of their own, announced by flags that travel with the exchange before.
+//     The walk has no collective: the four waves of a tile walk the same leaves on their own copies of the scalars.
+//     Chains stay asynchronous inside that: each is at its own point of its own doubling of its own draw.
+// Registers hold (theta, p, grad) of the chain's last point; the momentum crosses the evaluation through the workspace when the tile is
+// wide (NTQ >= 6: the evaluation's accumulators take its registers).  Point records (3 vectors per point, 46 points), the fixed vectors and the per-chain
+// scalars -- pending first halves by level (the proposal BY REFERENCE: a point index), bit masks over points for n', s' and the tests, alpha and U of every
+// point -- live in global memory (LDS is full of matrix): vectors chain-major inside a wave's block so that a chain's row is contiguous whatever
+// record each chain of the wave addresses.  n_leap_out reports the REFERENCE's count (one per leaf walked), n_exec_out the leapfrogs really made.
 //
 // Chains are handed to lanes DYNAMICALLY.  A workgroup has 32 chain slots (2 tiles x 16 lanes); the grid is persistent (as many workgroups as
 // the chip holds at once, or fewer if the chains are few) and a slot whose chain has finished all its draws fetches the next chain index
@@ -48,25 +59,67 @@
 namespace mi {
 
 namespace lds_nuts {
-// workspace vectors of a chain (the numbering of nuts_dense.hpp / nuts_async.hpp / nuts_tile.hpp)
+// workspace vectors of a chain
 enum : int {
     V_PREV = 0, V_WPREV = 1, V_MNTM = 2, V_TPOS_T = 3, V_TPOS_P = 4, V_TNEG_T = 5, V_TNEG_P = 6,
-    V_LEAF0 = 7,             // slot k: theta 7+3k, p 8+3k, grad 9+3k, k = 0..10 (even leaves only: slot 1 is free, see below)
-    V_PP0 = 40,              // pending proposal of level l >= 1 at 40 + l, its gradient at 52 + l
-    V_PPW0 = 52,
-    V_TMPP = 40,             // the momentum across an evaluation (wide tiles)
-    V_TMPT = 52,             // BOUNDS: theta across an evaluation (the registers hold x = inv_transform(theta) meanwhile)
-    V_XT = 64, V_XW = 65, V_XP = 66,   // DENSEM: theta / gradient / momentum of the last leaf while a streamed product of the preconditioner has the registers
-    NVEC = 68,
+    V_MNTM2 = 7, V_PREVB = 8, V_WPREVB = 9,
+    V_TMPP = 10,             // the momentum across an evaluation (wide tiles); INIT: z_init
+    V_TMPT = 11,             // BOUNDS: theta across an evaluation (the registers hold x = inv_transform(theta) meanwhile)
+    V_XT = 12, V_XW = 13, V_XP = 14,   // DENSEM: theta / gradient / momentum of the last point while a streamed product of the preconditioner has the registers
+    V_PT0 = 15,              // point n (1 ..) of the doubling's trajectory: theta at V_PT0 + 3 (n - 1), p at + 1, the gradient at + 2
+    MAXPTS = 46,             // 1 + 9 * 10 / 2: the deepest doubling of max_tree_depth = 10 has depth 9
+    NVEC = V_PT0 + 3 * MAXPTS,
     MAX_DEPTH = 10,
-    LVLS = 12,
-    SC_PER_CHAIN = 64        // doubles of per-chain scalars: [level][4] + the dual-averaging state at 48..50
+    // doubles of per-chain scalars: [12 levels][4] pending first halves (n', alpha', n_alpha', proposal point; level 0: the draw's kinetic energy, n, alpha,
+    // n_alpha) | the dual-averaging state | 12 bit masks over points | alpha and U of every point
+    SC_DA = 48, SC_OKB = 52, SC_ALPHA = 64, SC_U = 112,
+    SC_PER_CHAIN = 160
 };
-enum : int { V_MNTM2 = V_LEAF0 + 3, V_PREVB = V_LEAF0 + 4, V_WPREVB = V_LEAF0 + 5 };
 enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2, NS_INIT = 3, NS_SEARCH = 4 };
 // doubles of workspace per workgroup (8 waves): vectors, then scalars
 __host__ __device__ constexpr size_t vec_doubles_per_wave(int NSQ) { return (size_t)NVEC * NSQ * 64; }
 __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 * SC_PER_CHAIN; }
+
+// The memoised trajectory (nuts_memo.hpp, DESIGN.md 4.4e: leaf i of a doubling is the state LF^{n(i)}(prev_draw, mntm_vec), n(i) = 1 + the sum over the set
+// bits k of i of (k + 1); the U-turn test of a level-l node whose first leaf sits at point n1 compares the points n1 and n1 + l).
+// point of leaf i
+__host__ __device__ constexpr uint32_t npt_of(uint32_t i)
+{
+    uint32_t n = 1;
+    for (uint32_t k = 0; k < 10; ++k) if ((i >> k) & 1u) n += k + 1;
+    return n;
+}
+// is there a level-l node in a doubling of depth j whose first leaf sits at point n1?  (n1 - 1 must be a sum of distinct integers of {l + 1 .. j})
+__host__ __device__ constexpr bool pair_used(int l, int n1, int j)
+{
+    const int m = n1 - 1;
+    for (int t = 0; t <= j - l; ++t) {
+        const int lo = t * (l + 1) + t * (t - 1) / 2, hi = t * j - t * (t - 1) / 2;
+        if (m >= lo && m <= hi) return true;
+    }
+    return false;
+}
+// bit l of [j][m]: point m of a depth-j doubling closes a level-l test (against point m - l)
+struct PmTable { uint16_t v[10][48]; };
+constexpr PmTable make_pm_table()
+{
+    PmTable t{};
+    for (int j = 0; j < 10; ++j)
+        for (int m = 0; m < 48; ++m) {
+            uint32_t bits = 0;
+            for (int l = 1; l <= j; ++l)
+                if (m - l >= 1 && pair_used(l, m - l, j)) bits |= 1u << l;
+            t.v[j][m] = (uint16_t)bits;
+        }
+    return t;
+}
+__device__ const PmTable pm_table = make_pm_table();
+// npt_of on the device: 1 + popc(i) + sum_b 2^b popc(i & M_b), M_b = the bit positions k with bit b of k set
+__device__ __forceinline__ uint32_t npt_of_dev(uint32_t i)
+{
+    return 1u + (uint32_t)__builtin_popcount(i) + (uint32_t)__builtin_popcount(i & 0x2AAu) + 2u * (uint32_t)__builtin_popcount(i & 0xCCu)
+         + 4u * (uint32_t)__builtin_popcount(i & 0xF0u) + 8u * (uint32_t)__builtin_popcount(i & 0x300u);
+}
 }  // namespace lds_nuts
 
 // DIAGM: a DIAGONAL precond_mat (nuts.cpp:57-59,168,202-204,139-154: p = sqrt(m) z, K = p.(p / m) / 2, theta += e (p / m); the U-turn dots
@@ -80,9 +133,9 @@ __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 *
 //                                      matrix by the whole workgroup; `next` = the images whose block 0 its last block prefetches
 //     dm.reload0(img)               -- block 0 of img into the buffer the next product starts from (the prefetch guessed another matrix)
 //     dm.next(img)                  -- what the NEXT evaluation of the target prefetches behind its last block
-// Per leaf: Minv p for the drift, the evaluation, Minv p for the kinetic energy -- three streamed products instead of one, each one fma chain per
+// Per point: Minv p for the drift, the evaluation, Minv p for the kinetic energy -- three streamed products instead of one, each one fma chain per
 // element over the columns in ascending order (the oracle's orc_gemv).  Per draw: L z and Minv (L z).  A product needs the registers of two
-// vectors, so on the wide tiles the leaf's theta / gradient wait in the workspace meanwhile (V_XT, V_XW).
+// vectors, so on the wide tiles the point's theta / gradient wait in the workspace meanwhile (V_XT, V_XW).
 template <int NTQ, bool DIAGM, bool BOUNDS, bool DENSEM = false, class Eval, class DM>
 __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& evaluate, double* const part_all, [[maybe_unused]] DM& dm)
 {
@@ -175,9 +228,14 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     // per-chain scalars: chain-major, one private copy per wave (the four waves of a tile compute the same values)
     double* const sc_chain = prm.nuts_sc + ((size_t)blockIdx.x * 8 + wv) * sc_doubles_per_wave() + (size_t)(lane & 15) * SC_PER_CHAIN;
     auto lvl = [&](int l, int f) -> double& { return sc_chain[l * 4 + f]; };
-    auto h_val_ = [&]() -> double& { return sc_chain[48]; };
-    auto eps_bar_ = [&]() -> double& { return sc_chain[49]; };
-    auto mu_val_ = [&]() -> double& { return sc_chain[50]; };
+    auto h_val_ = [&]() -> double& { return sc_chain[SC_DA]; };
+    auto eps_bar_ = [&]() -> double& { return sc_chain[SC_DA + 1]; };
+    auto mu_val_ = [&]() -> double& { return sc_chain[SC_DA + 2]; };
+    // bit masks over the points of the doubling in progress: row 0: n' of point n; rows 1..10: the U-turn test of the level-l node whose first leaf sits at
+    // point n1 passed; row 11: s' of point n.  alpha (nuts.ipp:157) and U of every point
+    auto okb = [&](int r) -> unsigned long long& { return reinterpret_cast<unsigned long long*>(sc_chain)[SC_OKB + r]; };
+    auto pt_alpha = [&](uint32_t n) -> double& { return sc_chain[SC_ALPHA + n]; };
+    auto pt_U = [&](uint32_t n) -> double& { return sc_chain[SC_U + n]; };
 
     auto dim_of = [&](int s) -> uint32_t {               // opaque on purpose (logistic_lds.hpp: why)
         uint32_t j = (uint32_t)j4;
@@ -220,13 +278,14 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     const uint32_t max_depth = prm.max_depth;            // 1 .. MAX_DEPTH (the host routes everything else to literal.hpp)
     const double log_half = det_log(0.5), neg_log2 = -det_log(2.0);
 
-    // ---------------------------------------------------------------- per-chain state (nuts_tile.hpp: the same machine, plus INIT / SEARCH)
+    // ---------------------------------------------------------------- per-chain state (replicated in the four waves of the tile)
     int state = (cl < C) ? NS_INIT : NS_DONE;
-    uint64_t n_leap = 0, n_acc = 0;
+    uint64_t n_leap = 0, n_exec = 0, n_acc = 0;          // leapfrogs as the reference counts them (one per leaf) / leapfrogs made (one per distinct point)
     double eps = 1.0, prev_U = 0.0;
     uint32_t draw = 0;           // this chain's draw index
     uint32_t jd = 0;             // depth of the doubling in progress
-    uint32_t li = 0;             // next leaf of that doubling
+    uint32_t li = 0;             // next leaf of that doubling to be walked
+    uint32_t npts = 0;           // points of its trajectory that exist (the registers hold point npts; 0: the origin has to be loaded)
     uint32_t uslot = 0;
     int vdir = 1;                // direction of the doubling; SEARCH: a of nuts.ipp:75
     bool s_first = true;         // SEARCH: the leapfrog of nuts.ipp:62-72 (before the loop)
@@ -236,7 +295,6 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     auto alpha_ = [&]() -> double& { return lvl(0, 2); };
     auto n_alpha_ = [&]() -> double& { return lvl(0, 3); };
     int good_round = 0;
-    uint32_t utpre = 0;          // bit l: the U-turn test of the open level-l node passed
     int mv = V_MNTM, mvn = V_MNTM2;          // momentum vector of the running draw / of the next one
     int pb = 0, pb0 = 0;                     // which of the two vectors holds prev_draw now / held it when the draw started
     bool mom_ready = false;
@@ -254,7 +312,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             vdir = (zdir <= 0.5) ? -1 : 1;
             e_signed = (double)vdir * eps;
             H0 = prev_U + prev_K_();
-            li = 0;
+            li = 0; npts = 0;
         }
     };
     auto end_draw = [&](bool p, uint32_t my_depth) __attribute__((always_inline)) {   // dual averaging nuts.cpp:294-302
@@ -329,6 +387,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             if (q == 0 && j4 == 0) {
                 if (prm.n_accept) prm.n_accept[cl] = n_acc;
                 if (prm.n_leap_out) prm.n_leap_out[cl] = n_leap;
+                if (prm.n_exec_out) prm.n_exec_out[cl] = n_exec;
                 if (prm.step_out) prm.step_out[cl] = eps;
                 if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
             }
@@ -350,7 +409,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     };
 
 #ifdef MI_NUTS_LDS_PROF
-    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), n_ticks_ = 0, n_phase_ = 0, n_top_ = 0, n_lane_ticks_ = 0;
+    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = clock64(), n_ticks_ = 0, n_phase_ = 0, n_top_ = 0, n_lane_ticks_ = 0, n_tests_ = 0, n_walk_ = 0;
 #endif
 #pragma unroll 1
     for (;;) {
@@ -378,7 +437,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 const double nid = part[FLAG_AT + 1 + (lane & 15)];
                 if (nid >= 0.0) {                        // a new chain in this slot: everything per-chain starts over
                     cl = (uint64_t)nid;
-                    state = NS_INIT; nf = false; n_leap = 0; n_acc = 0; draw = 0; eps = 1.0;
+                    state = NS_INIT; nf = false; n_leap = 0; n_exec = 0; n_acc = 0; draw = 0; eps = 1.0;
                     mv = V_MNTM; mvn = V_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false;
                 } else exhausted = true;
             }
@@ -396,7 +455,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
             if constexpr (DENSEM) {
-                // p = CHOL_LOWER(M) z (:202) and K = p . (INV(M) p) / 2 (:204): two streamed products; the last leaf waits in the workspace meanwhile
+                // p = CHOL_LOWER(M) z (:202) and K = p . (INV(M) p) / 2 (:204): two streamed products; the last point waits in the workspace meanwhile
                 st_row(V_XT, 0, th); st_row(V_XP, 0, pm); st_row(V_XW, 0, w);
                 double zv[NS];
 #pragma unroll
@@ -454,35 +513,28 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         n_lane_ticks_ += (unsigned long long)__builtin_popcountll(__ballot(run || init || srch) & 0xffffull);
 #endif
 
-        // ------------------------------------------------------------ B. one leaf for every running chain
-        auto slot_of = [&](uint32_t k) -> int { return (k == 0) ? 0 : (__builtin_ctz(k) + 1); };
-        const int slot_i = slot_of(li);
-        const int rec_t = V_LEAF0 + 3 * slot_i, rec_p = rec_t + 1, rec_w = rec_t + 2;    // this leaf's record (even leaves only)
-        const bool odd = (li & 1u) != 0u;
-        {   // start state: the registers hold the previous leaf (li odd, or ctz(li) == 1); otherwise a record
-            const int cz = (li == 0) ? 0 : __builtin_ctz(li);
-            const bool need = run && (li == 0 || cz >= 2);
+        // ------------------------------------------------------------ B. the next point of every running chain's trajectory.  The walk below takes every
+        // leaf its points allow, so a running chain always needs the point after the one in its registers (an evaluation is the workgroup's: a chain
+        // that sat one out would still pay for it)
+        {   // the origin of a doubling (prev_draw, mntm_vec, its gradient: src/nuts.cpp:241-256); every later point continues from the registers
+            const bool need = run && npts == 0u;
             if (any(need)) {
-                const int vt = (li == 0) ? pvec(pb) : V_LEAF0 + 3 * cz;                  // leaf li - 2^(cz-1) sits in slot cz
-                const int vp = (li == 0) ? mv : V_LEAF0 + 3 * cz + 1;
-                const int vw = (li == 0) ? wvec(pb) : V_LEAF0 + 3 * cz + 2;
-                if (need) { ld_row(vt, 0, th); ld_row(vp, 0, pm); ld_row(vw, 0, w); }
+                if (need) { ld_row(pvec(pb), 0, th); ld_row(mv, 0, pm); ld_row(wvec(pb), 0, w); }
             }
         }
-        // U-turn tests, evaluated when their second operand appears (nuts_tile.hpp: EAGER).  Leaf li > 0 is the first leaf b2 of the second
-        // half of exactly one node, level l = ctz(li) + 1 (if l <= jd), whose first leaf is b = li - 2^ctz(li) -- an even leaf, so its
-        // (theta, p) are a record (an odd li: the leaf this leapfrog starts from).  Both rows are fetched AFTER the evaluation.
-        const uint32_t cz_i = (li == 0) ? 0u : (uint32_t)__builtin_ctz(li);
-        const bool tst = run && li != 0u && (cz_i + 1u <= jd);
+        const uint32_t mpt = npts + 1u;                  // the point this tick computes (run lanes)
+        // the tests this point closes: level l against point mpt - l, lowest level first.  The first one shares the pass over the registers and the
+        // exchange with the kinetic energy; the others (one in six points has a second one) take a pass and an exchange each, voted by the workgroup
+        uint32_t pmask = run ? (uint32_t)pm_table.v[jd < 10u ? jd : 9u][mpt < 48u ? mpt : 0u] : 0u;
+        const bool tst = pmask != 0u;
         const bool any_tst = any(tst);
-        const uint32_t bleaf = li - (1u << cz_i);
-        const int sb = (!tst || bleaf == 0) ? 0 : (__builtin_ctz(bleaf) + 1);
-        const int eb_t = V_LEAF0 + 3 * sb, eb_p = eb_t + 1;
+        const uint32_t l_first = tst ? (uint32_t)__builtin_ctz(pmask) : 1u;
+        const int eb_t = V_PT0 + 3 * ((int)mpt - (int)l_first - 1), eb_p = eb_t + 1;     // (lanes without a test: never loaded)
         MI_LPROF(2);
         // SEARCH: the step of this leapfrog (nuts.ipp:62, 80-82)
         if (srch) {
             if (!s_first) eps = eps * ((vdir == 1) ? 2.0 : 0.5);
-            n_leap++;
+            n_leap++; n_exec++;
         }
         // one leapfrog of size e (nuts.ipp:132 / :64, nuts.cpp:139-154), grad = w.  INIT: e = 0 and the state is set after the (idle) updates
         const double e_tick = run ? e_signed : (srch ? eps : 0.0);
@@ -541,7 +593,8 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         if constexpr (BOUNDS) ld_row(V_TMPT, 0, th);
         if constexpr (PM_MEM) ld_row(V_TMPP, 0, pm);
         MI_LPROF(4);
-        // second half-kick, d = theta(b2) - theta(b) (by direction), q1 = d . p(b), q2 = d . p(b2), and the kinetic energy: one pass
+        // second half-kick, the kinetic energy and the point's first test -- d = theta(mpt) - theta(n1) (by direction), q1 = d . p(n1), q2 = d . p(mpt)
+        // (nuts.ipp:224-229) -- in one pass
         double q1 = 0.0, q2 = 0.0, pk = 0.0;
         if constexpr (DENSEM) {
             // K' = p' . (INV(M) p') / 2 (nuts.ipp:140): the second half-kick first, then the product of the new momentum (theta and the new gradient wait in
@@ -575,15 +628,55 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             }
         }
         MI_LPROF(5);
-        const bool last_leaf = run && (li == (1u << jd) - 1u);               // the doubling may complete in this tick
+        // a doubling can complete in this tick only on its last point, 1 + jd (jd + 1) / 2: the whole tree's test is a collective, voted here
+        const bool last_pt = run && (mpt == 1u + jd * (jd + 1u) / 2u);
         double v3[3] = {fold(q1), fold(q2), fold(pk)};
-        const bool wg_complete = exchange(v3, any(last_leaf) ? 1u : 0u) != 0u;
+        uint32_t fl = exchange(v3, (any(last_pt) ? 1u : 0u) | (any((pmask & (pmask - 1u)) != 0u) ? 2u : 0u));
+        const bool wg_complete = (fl & 1u) != 0u;
         MI_LPROF(6);
-        q1 = v3[0]; q2 = v3[1];
         const double pK = v3[2] / 2.0;                   // nuts.ipp:140 / :51,66
         double pU = -val;                                // nuts.ipp:134-138 / :50,65
         if constexpr (BOUNDS) pU = -(val + box.log_jacobian(th, lj_rel, [&]() { __syncthreads(); }));     // -box_log_kernel(theta), nuts.cpp:84-95
         const bool u_nf = !is_finite(pU);
+        if (tst) {                                       // the test of level l_first, first leaf at point mpt - l_first
+            const unsigned long long bit = 1ull << (mpt - l_first);
+            const bool ok = (v3[0] >= 0.0) && (v3[1] >= 0.0);
+            okb((int)l_first) = (okb((int)l_first) & ~bit) | (ok ? bit : 0ull);
+            pmask &= pmask - 1u;
+        }
+        // ... and the point's other tests (p(mpt) is final now): the rows of point mpt - l, two dots, an exchange
+        while ((fl & 2u) != 0u) {
+#ifdef MI_NUTS_LDS_PROF
+            n_tests_++;
+#endif
+            const bool t = pmask != 0u;
+            const uint32_t l = t ? (uint32_t)__builtin_ctz(pmask) : 1u;
+            const int vt = V_PT0 + 3 * ((int)mpt - (int)l - 1);
+            double r1 = 0.0, r2 = 0.0;
+            if (any(t)) {
+#pragma unroll
+                for (int c0 = 0; c0 < NS; c0 += CH) {
+                    double tb[CH], pbv[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) { tb[k] = 0.0; pbv[k] = 0.0; }
+                    if (t) { ld_row(vt, c0, tb); ld_row(vt + 1, c0, pbv); }
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const double dd = (vdir > 0) ? (th[c0 + k] - tb[k]) : (tb[k] - th[c0 + k]);
+                        r1 = dfma(dd, pbv[k], r1);
+                        r2 = dfma(dd, pm[c0 + k], r2);
+                    }
+                }
+            }
+            double v2[2] = {fold(r1), fold(r2)};
+            fl = exchange(v2, any((pmask & (pmask - 1u)) != 0u) ? 2u : 0u);
+            if (t) {
+                const unsigned long long bit = 1ull << (mpt - l);
+                const bool ok = (v2[0] >= 0.0) && (v2[1] >= 0.0);
+                okb((int)l) = (okb((int)l) & ~bit) | (ok ? bit : 0ull);
+                pmask &= pmask - 1u;
+            }
+        }
         // ---- INIT: the chain's first state is on record; SEARCH: one step of nuts_find_initial_step_size
         if (any(init)) {
             if (init) {
@@ -608,101 +701,114 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         }
         if (u_nf) { pU = INF; if (run) nf = true; }
         if (run && !is_finite(pK)) nf = true;
-        const bool ut_now = (q1 >= 0.0) && (q2 >= 0.0);  // the test of level ctz(li) + 1
-        if (tst && !odd) utpre = (utpre & ~(1u << (cz_i + 1u))) | ((ut_now ? 1u : 0u) << (cz_i + 1u));
-        if (any(run && !odd)) {
-            if (run && !odd) {                           // even leaves are the records later leaves and tests read
-                st_row(rec_t, 0, th); st_row(rec_p, 0, pm); st_row(rec_w, 0, w);
+        // ---- the point's scalars (nuts.ipp:146-157): n', s' as bits, alpha and U in the chain's table; its record (theta, p, gradient); the tree's far
+        //      edge -- point 1 + jd, the first leaf of the second half (the leaf itself at depth 0) -- is what a successful doubling leaves in draw_pos /
+        //      draw_neg (src/nuts.cpp:241-256); a doubling that fails before that ends the draw, so it is written in place
+        const double dH_pt = -(pU + pK) + H0;
+        const double ca_pt = det_exp((dH_pt < 0.0) ? dH_pt : 0.0);      // :157
+        if (any(run)) {
+            if (run) {
+                const unsigned long long bit = 1ull << mpt;
+                const bool cn_b = log_u <= -pU - pK;         // :146
+                const bool cs_b = log_u < 1000.0 - pU - pK;  // :147
+                okb(0) = (okb(0) & ~bit) | (cn_b ? bit : 0ull);
+                okb(11) = (okb(11) & ~bit) | (cs_b ? bit : 0ull);
+                pt_alpha(mpt) = ca_pt; pt_U(mpt) = pU;
+                n_exec++;
+                const int vr = V_PT0 + 3 * ((int)mpt - 1);
+                st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
+                npts = mpt;
             }
-        }
-        // the tree's far edge (= near edge of its second half, or the leaf itself at depth 0) is what a successful doubling
-        // leaves in draw_pos / draw_neg (src/nuts.cpp:241-256); a failed one ends the draw, so it is written in place
-        const bool st_edge = run && (li == ((jd == 0u) ? 0u : (1u << (jd - 1))));
-        if (any(st_edge)) {
-            if (st_edge) {
-                const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
-                st_row(et, 0, th); st_row(ep, 0, pm);
-                if (vdir > 0) pos_init = false; else neg_init = false;
+            const bool st_edge = run && (mpt == 1u + jd);
+            if (any(st_edge)) {
+                if (st_edge) {
+                    const int et = (vdir > 0) ? V_TPOS_T : V_TNEG_T, ep = (vdir > 0) ? V_TPOS_P : V_TNEG_P;
+                    st_row(et, 0, th); st_row(ep, 0, pm);
+                    if (vdir > 0) pos_init = false; else neg_init = false;
+                }
             }
         }
         MI_LPROF(7);
-        double cn = (log_u <= -pU - pK) ? 1.0 : 0.0;     // :146
-        const bool cs = log_u < 1000.0 - pU - pK;        // :147
-        const double dH = -(pU + pK) + H0;
-        double ca = det_exp((dH < 0.0) ? dH : 0.0);      // :157
-        double cna = 1.0;
-        double cU = pU;
-        bool cref_regs = true;                           // carried proposal: this leaf (registers) ...
-        int cref_t = rec_t, cref_w = rec_w;              // ... or a record (theta, grad)
-        if (run) n_leap++;
-        // ---- unwind (nuts.ipp:212-229), per-chain leaf index
-        bool failed = run && !cs;
-        bool walking = run;
-        uint32_t pend_level = jd + 1;
+        // ------------------------------------------------------------ C. walk the leaves this point unblocks (nuts.ipp:146-158, 212-239): leaf after leaf as
+        // the recursion returns through them -- the same merges in the same order, one uniform per merge from the same Philox slot, the same early exit --
+        // on the memoised scalars; no vector work, no collective (the four waves of a tile walk the same leaves on their own copies)
+        bool wl = run;                                   // (the leaf a chain waits at sits on its newest point)
+        bool at_fin = false, complete = false;
+        double cn = 0.0, cna = 0.0, ca = 0.0;
+        uint32_t cref = 0;
+        uint32_t n = npt_of_dev(li);
 #pragma unroll 1
-        for (uint32_t l = 1; l <= (uint32_t)MAX_DEPTH; ++l) {
-            if (walking && l > jd) walking = false;                      // reached the root of its own tree
-            const bool bit = ((li >> (l - 1)) & 1u) != 0u;
-            if (walking && !failed && !bit) { pend_level = l; walking = false; }   // first half: wait here
-            if (!any(walking)) break;
-            const bool mrg = walking && bit;
-            if (!any(mrg)) continue;
-            const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :213
-            if (mrg) {
-                uslot++;
-                const double p_n = lvl((int)l, 0), p_a = lvl((int)l, 1), p_na = lvl((int)l, 2), p_U = lvl((int)l, 3);
-                const double prob = cn / (p_n + cn);                     // :212
-                if (!(z < prob)) {                                       // keep new_draw_p (:215-217)
-                    const int ps = slot_of(li - 1);                      // level 1: the previous (even) leaf's record
-                    cref_regs = false;
-                    cref_t = (l == 1) ? V_LEAF0 + 3 * ps : V_PP0 + (int)l;
-                    cref_w = (l == 1) ? V_LEAF0 + 3 * ps + 2 : V_PPW0 + (int)l;
-                    cU = p_U;
-                }
-                cn = p_n + cn;                                           // :220-222
-                ca = p_a + ca;
-                cna = p_na + cna;
+        while (any(wl)) {
+#ifdef MI_NUTS_LDS_PROF
+            n_walk_++;
+#endif
+            const uint32_t t1 = (uint32_t)__builtin_ctz(~li);
+            const uint32_t nn = n + (t1 + 1u) - t1 * (t1 + 1u) / 2u;         // the point of leaf li + 1
+            bool failed = false;
+            if (wl) {
+                const unsigned long long nbit = 1ull << n;
+                cn = (okb(0) & nbit) ? 1.0 : 0.0;
+                ca = pt_alpha(n);
+                cna = 1.0; cref = n;
+                failed = !(okb(11) & nbit);
+                n_leap++;
             }
-            const bool need_ut = mrg && !failed;
-            const bool ok = (l == 1) ? ut_now : (((utpre >> l) & 1u) != 0u);      // :226-227
-            if (need_ut && !ok) failed = true;                                   // :229
+            bool walking = wl;
+            uint32_t pend_level = jd + 1;
+#pragma unroll 1
+            for (uint32_t l = 1; l <= (uint32_t)MAX_DEPTH; ++l) {
+                if (walking && l > jd) walking = false;                      // reached the root of its own tree
+                const bool bit = ((li >> (l - 1)) & 1u) != 0u;
+                if (walking && !failed && !bit) { pend_level = l; walking = false; }   // first half: wait here
+                if (!any(walking)) break;
+                const bool mrg = walking && bit;
+                if (!any(mrg)) continue;
+                const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :213
+                if (mrg) {
+                    uslot++;
+                    const double p_n = lvl((int)l, 0), p_a = lvl((int)l, 1), p_na = lvl((int)l, 2);
+                    const double prob = cn / (p_n + cn);                     // :212
+                    if (!(z < prob)) cref = (uint32_t)lvl((int)l, 3);        // keep new_draw_p (:215-217): a point of the trajectory, by reference
+                    cn = p_n + cn;                                           // :220-222
+                    ca = p_a + ca;
+                    cna = p_na + cna;
+                    if (!failed) {                                           // :226-229, evaluated when its second point appeared
+                        const uint32_t n1 = n - l * (l + 1u) / 2u;           // the node's first leaf: li with its l low (set) bits cleared
+                        if (!((okb((int)l) >> n1) & 1ull)) failed = true;
+                    }
+                }
+            }
+            if (wl) {
+                const bool keep = !failed;
+                complete = keep && (li == (1u << jd) - 1u);
+                if (keep && !complete) {                 // a pending first half: its scalars, the proposal by reference
+                    lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
+                    lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = (double)cref;
+                    li = li + 1u; n = nn;
+                    wl = nn <= npts;
+                } else {
+                    at_fin = true; wl = false;
+                }
+            }
         }
         MI_LPROF(8);
-        // ---- end of the doubling? top-level accept first (src/nuts.cpp:260-279)
-        const bool keep = run && !failed;
-        const bool complete = keep && (li == (1u << jd) - 1u);
-        const bool fin = run && (failed || complete);
+        // ------------------------------------------------------------ D. end of a doubling: top-level accept first (src/nuts.cpp:260-279).  The proposal is a
+        // point of the trajectory: its record (theta, gradient) becomes prev_draw
         bool take = false;
         if (any(complete)) {
             const double z = rng_uniform(prm.seed, prm.chain0 + cl, draw + prm.draw0, uslot);  // :261
             if (complete) {
                 uslot++;
                 take = z < cn / n_val_();                                   // :263
-                if (take) { prev_U = cU; good_round = 1; pb = 1 - pb0; }  // :264-277; the proposal goes to pvec(pb) below
+                if (take) { prev_U = pt_U(cref); good_round = 1; pb = 1 - pb0; }  // :264-277
             }
-        }
-        // ---- pending first half: proposal and its gradient by value, scalars to the level table
-        if (keep && !complete) {
-            lvl((int)pend_level, 0) = cn; lvl((int)pend_level, 1) = ca;
-            lvl((int)pend_level, 2) = cna; lvl((int)pend_level, 3) = cU;
-        }
-        {
-            // a pending first half at level 1 IS the (even) leaf's record just written (referenced, not copied); deeper levels
-            // and accepted proposals are written to their slot: from the registers when the carried proposal is this leaf,
-            // record -> slot otherwise
-            const bool do_store = keep && (complete ? take : (pend_level > 1u));
-            if (any(do_store)) {
-                const int pl = do_store ? (int)pend_level : 1;
-                const int dst_t = take ? pvec(1 - pb0) : V_PP0 + pl;
-                const int dst_w = take ? wvec(1 - pb0) : V_PPW0 + pl;
-                if (do_store && cref_regs) { st_row(dst_t, 0, th); st_row(dst_w, 0, w); }
-                const bool do_copy = do_store && !cref_regs;
-                if (any(do_copy)) { if (do_copy) { cp_row(cref_t, dst_t); cp_row(cref_w, dst_w); } }
+            if (any(take)) {
+                if (take) { const int vq = V_PT0 + 3 * ((int)cref - 1); cp_row(vq, pvec(1 - pb0)); cp_row(vq + 2, wvec(1 - pb0)); }
             }
         }
         MI_LPROF(9);
         // ---- the whole tree's U-turn test (:286-289): a dot product over dimensions, so every wave of the workgroup takes part
-        //      whenever some chain of the workgroup was at the last leaf of its doubling
+        //      whenever some chain of the workgroup was at the last point of its doubling
         bool s_ok = false;
 #ifdef MI_NUTS_LDS_PROF
         if (wg_complete) n_top_++;
@@ -731,11 +837,11 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             s_ok = complete && (v2[0] >= 0.0) && (v2[1] >= 0.0);
         }
         MI_LPROF(10);
-        if (any(fin)) {
-            if (fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
-            const bool more = fin && s_ok && (jd + 1 < max_depth);
-            if (fin) jd = jd + 1;                                        // :284
-            const bool ended = fin && !more;
+        if (any(at_fin)) {
+            if (at_fin) { alpha_() = ca; n_alpha_() = cna; n_val_() = n_val_() + cn; }   // :246,255 ; :283
+            const bool more = at_fin && s_ok && (jd + 1 < max_depth);
+            if (at_fin) jd = jd + 1;                                     // :284
+            const bool ended = at_fin && !more;
             bool roll = false;
             if (any(ended)) {
                 end_draw(ended, jd);
@@ -745,7 +851,6 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             }
             begin_doubling(more || roll);
         }
-        if (run && !fin) li = li + 1;
         MI_LPROF(11);
     }
 #ifdef MI_NUTS_LDS_PROF
@@ -759,9 +864,9 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     if (blockIdx.x == 0 && lane == 0) {
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += prof_[i];
-        printf("[nuts_lds prof] wave %d: %llu ticks (%.1f of 16 slots busy), %llu phases, %llu tree tests, %.1f k cycles per tick | vote %.1f%% phaseA %.1f%% top-loads %.1f%% kick+drift %.1f%% "
-               "eval %.1f%% kick2+dots %.1f%% exchange %.1f%% stores %.1f%% unwind %.1f%% take/pending %.1f%% tree-test %.1f%% fin %.1f%%\n",
-               wv, n_ticks_, (double)n_lane_ticks_ / (double)(n_ticks_ ? n_ticks_ : 1), n_phase_, n_top_, (double)tot / (double)(n_ticks_ ? n_ticks_ : 1) / 1e3,
+        printf("[nuts_lds prof] wave %d: %llu ticks (%.1f of 16 slots busy), %llu phases, %llu tree tests, %llu extra point tests, %llu walk iterations, %.1f k cycles per tick | vote %.1f%% phaseA %.1f%% origin %.1f%% kick+drift %.1f%% "
+               "eval %.1f%% kick2+dots %.1f%% exchange+tests %.1f%% point record %.1f%% walk %.1f%% accept %.1f%% tree-test %.1f%% fin %.1f%%\n",
+               wv, n_ticks_, (double)n_lane_ticks_ / (double)(n_ticks_ ? n_ticks_ : 1), n_phase_, n_top_, n_tests_, n_walk_, (double)tot / (double)(n_ticks_ ? n_ticks_ : 1) / 1e3,
                100.0 * prof_[0] / tot, 100.0 * prof_[1] / tot, 100.0 * prof_[2] / tot, 100.0 * prof_[3] / tot, 100.0 * prof_[4] / tot, 100.0 * prof_[5] / tot,
                100.0 * prof_[6] / tot, 100.0 * prof_[7] / tot, 100.0 * prof_[8] / tot, 100.0 * prof_[9] / tot, 100.0 * prof_[10] / tot, 100.0 * prof_[11] / tot);
     }

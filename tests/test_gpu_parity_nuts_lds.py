@@ -55,6 +55,14 @@ def test_lds_nuts_matches_the_oracle(kind, d, n_rows, C, depth):
     o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
     assert o["n_leap"].max() > 2 ** (depth - 1), "the case is meant to grow trees of several levels"
     _same(g_draws, g, o_draws, o, depth=False)
+    # the leapfrogs it really made (round 6: every doubling on a memoised trajectory): what the memoised oracle makes -- one per distinct point of a
+    # doubling + the step-size search -- fewer than the reference counts
+    n_exec = []
+    for c in range(C):
+        sc = orc.make_settings(seed=7, n_burnin=3, n_keep=3, n_adapt=4, max_depth=depth, step=eps, W=4, blocks=4, block_size=_bs(kind, d), chain_id=3 + c)
+        n_exec.append(orc.run_chain(orc.ALGO_NUTS_MEMO, spec, init[c], sc)[1]["n_exec"])
+    assert np.array_equal(g["n_exec"], np.array(n_exec, dtype=np.uint64))
+    assert (g["n_exec"] <= g["n_leap"]).all() and g["n_exec"].sum() < g["n_leap"].sum()
 
 
 @pytest.mark.parametrize("kind,d,n_rows,C", [("logistic", 100, 20, 37), ("logistic", 512, 24, 5), ("dense", 160, 0, 5), ("dense", 384, 0, 37)])
