@@ -87,7 +87,7 @@ typedef enum mi_kernel_hint {
     MI_KERNEL_NUTS_SPLIT = 11,             /* RETIRED (round 5): the kernel that split every 16-chain tile over two waves (64 < d <= 128, few chains) is gone --
                                             * the memoised kernel is faster at every chain count.  The value stays valid and is ignored (as any hint a request
                                             * cannot honour): the default kernel runs */
-    MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat; hmc and mala with a DENSE precond_mat) on the logistic target
+    MI_KERNEL_LITERAL = 12,                /* nuts (and hmc with bounds / a diagonal precond_mat; hmc, mala and nuts with a DENSE precond_mat) on the logistic target
                                             * (d <= 512) and on dense Gaussians with 128 < d <= 512: the literal kernel (one workgroup per chain) instead of the tiled kernel on the
                                             * LDS-streamed evaluation -- same bits, for A/B timing */
     MI_KERNEL_NUTS_DYN = 13,               /* RETIRED (round 5), valid and ignored: round 4's register-carried tick with dynamic chain hand-out */
@@ -165,8 +165,9 @@ typedef struct mi_chains {
                                * NULL.  Separable Gaussian targets without bounds run on the elementwise kernels (any d), everything
                                * else on the literal kernels.  See mi_mcmc_hmc_run_mass_adapted_per_chain. */
     uint64_t* n_leapfrogs_executed; /* out [C], may be NULL (needs n_leapfrogs next to it): the leapfrog steps the device really computed.
-                               * Equal to n_leapfrogs except for nuts on the MEMOISED tick -- the default of the plain and diagonal-mass
-                               * Gaussian case, of the built-in Gaussian with vals_bound and of nuts on tile targets -- which computes every
+                               * Equal to n_leapfrogs except for nuts on the MEMOISED ticks -- the default of the plain and diagonal-mass
+                               * Gaussian case, of the built-in Gaussian with vals_bound, of nuts on tile targets and (round 6) of nuts on the
+                               * LDS-streamed evaluation (logistic d <= 512, dense Gaussians 128 < d <= 512) -- which compute every
                                * distinct state of a doubling once (same draws, fewer steps).  (MI_KERNEL_NUTS_MEMO is accepted and
                                * equivalent to MI_KERNEL_AUTO: the memoised tick is what runs unless MI_KERNEL_NUTS_TICK_LOCAL or
                                * MI_KERNEL_NUTS_LOCKSTEP asks for the kernel that executes every leaf.) */
