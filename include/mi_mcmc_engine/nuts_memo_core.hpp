@@ -491,6 +491,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (__ballot(run || init || srch) == 0ull) continue;
 #ifdef MI_NUTS_REG_PROF
         n_ticks++; n_active += (unsigned long long)__builtin_popcountll(__ballot(run)) / 4ull;
+        pc[10] += (unsigned long long)__builtin_popcountll(__ballot(run && memo_npt(li) > npts)) / 4ull;     // (a count, not cycles: chains that compute a point in this tick)
 #endif
 
         // INIT: first_draw and z_init (nuts.cpp:160-168) are staged in the workspace -- theta in MV_PREV, the momentum in mv -- and enter the

@@ -2371,10 +2371,10 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         const char* names[12] = {"A phase: rows, momenta ahead", "B origin + kick + drift", "mat-vec + kick + energies", "tests (U-turn, memoised)", "C walk",
                                  "init / search", "E record store", "loop head", "point scalars (n', s', alpha)", "D end of doubling", "-", "-"};
         unsigned long long tot = 0;
-        for (int k = 0; k < 12; ++k) tot += h[k];
-        for (int k = 0; k < 12; ++k) if (h[k]) fprintf(stderr, "[nuts prof] %-32s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
-        fprintf(stderr, "[nuts prof] ticks %llu (%.0f cycles each), active chain-ticks %llu (%.2f of 16 per tick), walk iterations %llu, test iterations %llu\n", h[12],
-                (double)tot / (h[12] ? h[12] : 1), h[13], (double)h[13] / (h[12] ? h[12] : 1), h[14], h[15]);
+        for (int k = 0; k < 10; ++k) tot += h[k];            // (slot 10 of the memoised tick is a count: chain-ticks that compute a point)
+        for (int k = 0; k < 10; ++k) if (h[k]) fprintf(stderr, "[nuts prof] %-32s %12llu cycles %5.1f%%\n", names[k], h[k], 100.0 * h[k] / (tot ? tot : 1));
+        fprintf(stderr, "[nuts prof] ticks %llu (%.0f cycles each), active chain-ticks %llu (%.2f of 16 per tick), of them computing a point %llu (%.2f per tick), walk iterations %llu, test iterations %llu\n", h[12],
+                (double)tot / (h[12] ? h[12] : 1), h[13], (double)h[13] / (h[12] ? h[12] : 1), h[10], (double)h[10] / (h[12] ? h[12] : 1), h[14], h[15]);
     }
 #endif
     if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));

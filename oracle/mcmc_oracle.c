@@ -1093,23 +1093,49 @@ static int memo_pair_used(int l, int n1, int j)
     return 0;
 }
 
+/* ACROSS doublings (round 6, orc_nuts_memo_xd): consecutive doublings of a draw in the SAME direction start from the same (prev_draw, mntm_vec) with the
+ * same step as long as no proposal was accepted in between (src/nuts.cpp:241-256, :272), so they walk the same trajectory: a doubling of depth j re-uses the
+ * points 1 .. n the last doubling of its direction left (depth j' < j) and computes only the points behind them.  memo_dir is what survives a doubling:
+ * the points, their scalars and the test results of one direction.  A DEEPER tree tests pairs among points it did not compute itself (the pairs of a
+ * shallower tree are pairs of every deeper one: memo_pair_used's sums nest), so when a point is computed every test it closes in the DEEPEST doubling the run
+ * can make (depth max_tree_depth - 1) is evaluated, whatever the depth of the doubling that computes it. */
+typedef struct memo_dir {
+    int n_valid, je;                 /* points 1 .. n_valid exist (0: none); je: the depth whose tests are evaluated when a point appears */
+    double* pt_th; double* pt_p;     /* point n at [n * d] */
+    double pt_a[ORC_MEMO_MAXPTS];
+    uint64_t cnb, csb, okb[12], okc[12];
+} memo_dir;
+static void memo_dir_reset(memo_dir* m)
+{
+    m->n_valid = 0; m->cnb = 0; m->csb = 0;
+    memset(m->okb, 0, sizeof(m->okb)); memset(m->okc, 0, sizeof(m->okc));
+}
+
 static void nuts_doubling_memo(orc_ctx* c, int direction_val, double step_size, double log_rand_val, double prev_U, double prev_K,
                                const double* draw_vec, const double* mntm_vec, size_t tree_depth,
                                double* new_draw, double* edge_draw, double* edge_mntm,
                                size_t* n_val, size_t* s_val, double* alpha_val, size_t* n_alpha_val,
-                               uint32_t draw_ind, uint32_t* uslot, uint64_t* n_exec)
+                               uint32_t draw_ind, uint32_t* uslot, uint64_t* n_exec, memo_dir* xd)
 {
     const size_t d = c->d, nb = d * sizeof(double);
     const int jd = (int)tree_depth;
+    const int je = xd ? xd->je : jd;                            /* the depth whose tests are evaluated when a point appears */
     const double max_tuning_par = 1000;
-    double* pt_th = dvec((size_t)ORC_MEMO_MAXPTS * d);           /* point n at [n * d] (n = 1 ..) */
-    double* pt_p = dvec((size_t)ORC_MEMO_MAXPTS * d);
-    double pt_a[ORC_MEMO_MAXPTS];
-    uint64_t cnb = 0, csb = 0, okb[12] = {0}, okc[12] = {0};
-    double* cur_th = dvec(d); memcpy(cur_th, draw_vec, nb);
-    double* cur_p = dvec(d);  memcpy(cur_p, mntm_vec, nb);
+    memo_dir local;
+    memo_dir* const md = xd ? xd : &local;
+    if (!xd) { memo_dir_reset(md); md->pt_th = dvec((size_t)ORC_MEMO_MAXPTS * d); md->pt_p = dvec((size_t)ORC_MEMO_MAXPTS * d); }
+    double* const pt_th = md->pt_th;                            /* point n at [n * d] (n = 1 ..) */
+    double* const pt_p = md->pt_p;
+    double* const pt_a = md->pt_a;
+#define cnb (md->cnb)
+#define csb (md->csb)
+#define okb (md->okb)
+#define okc (md->okc)
+    int npts = md->n_valid;
+    double* cur_th = dvec(d); memcpy(cur_th, npts ? pt_th + (size_t)npts * d : draw_vec, nb);
+    double* cur_p = dvec(d);  memcpy(cur_p, npts ? pt_p + (size_t)npts * d : mntm_vec, nb);
     double* diff = dvec(d);
-    int npts = 0;
+    if (npts >= 1 + jd) { memcpy(edge_draw, pt_th + (size_t)(1 + jd) * d, nb); memcpy(edge_mntm, pt_p + (size_t)(1 + jd) * d, nb); }   /* the far edge is a point this doubling does not compute */
     const uint64_t leap_before = c->n_leap;
     uint64_t leaves = 0;
     /* pending first halves per level (ref: the frames of the recursion) */
@@ -1124,13 +1150,15 @@ static void nuts_doubling_memo(orc_ctx* c, int direction_val, double step_size, 
             if (!isfinite(prop_U)) prop_U = INFINITY;
             const double prop_K = kinetic(c, cur_p);                /* :140 */
             memcpy(pt_th + (size_t)m * d, cur_th, nb); memcpy(pt_p + (size_t)m * d, cur_p, nb);
+            cnb &= ~(1ull << m); csb &= ~(1ull << m);
             if (log_rand_val <= -prop_U - prop_K) cnb |= 1ull << m;                       /* :146 */
             if (log_rand_val < max_tuning_par - prop_U - prop_K) csb |= 1ull << m;        /* :147 */
             const double dd = -(prop_U + prop_K) + (prev_U + prev_K);
             pt_a[m] = orc_exp((dd < 0.0) ? dd : 0.0);               /* :157 */
-            for (int l = 1; l <= jd; ++l) {                         /* the tests whose second point this is (:224-229) */
+            for (int l = 1; l <= je; ++l) {                         /* the tests whose second point this is (:224-229) */
                 const int n1 = m - l;
-                if (n1 < 1 || !memo_pair_used(l, n1, jd)) continue;
+                if (n1 < 1 || !memo_pair_used(l, n1, je)) continue;
+                okb[l] &= ~(1ull << n1);
                 const double* ta = pt_th + (size_t)n1 * d; const double* pa = pt_p + (size_t)n1 * d;
                 for (size_t i = 0; i < d; ++i) diff[i] = (direction_val > 0) ? cur_th[i] - ta[i] : ta[i] - cur_th[i];   /* pos - neg */
                 const int c1 = orc_dot_b(diff, pa, d, c->W, c->nblk, c->bs) >= 0.0;
@@ -1168,7 +1196,13 @@ static void nuts_doubling_memo(orc_ctx* c, int direction_val, double step_size, 
     if (complete) memcpy(new_draw, pt_th + (size_t)cref * d, nb);
     *n_exec += c->n_leap - leap_before;
     c->n_leap = leap_before + leaves;                               /* the reference's count: one leapfrog per leaf */
-    free(pt_th); free(pt_p); free(cur_th); free(cur_p); free(diff);
+    md->n_valid = npts;
+#undef cnb
+#undef csb
+#undef okb
+#undef okc
+    if (!xd) { free(md->pt_th); free(md->pt_p); }
+    free(cur_th); free(cur_p); free(diff);
 }
 
 /* ref: src/nuts.cpp:30-332; memo != 0: every doubling through nuts_doubling_memo (same bits, fewer leap_frog calls) */
@@ -1184,6 +1218,13 @@ int orc_nuts_memo(const double* initial_vals, size_t d, orc_kernel_fn kernel, vo
 {
     if (s->max_tree_depth > 10) return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 0, n_exec_out);
     return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 1, n_exec_out);
+}
+/* ... and the trajectory memoised ACROSS the doublings of a draw as well (memo_dir above): what nuts_gauss_memo_kernel runs since round 6 */
+int orc_nuts_memo_xd(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+                     const orc_settings* s, double* draws_out, orc_stats* st, uint64_t* n_exec_out)
+{
+    if (s->max_tree_depth > 10) return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 0, n_exec_out);
+    return orc_nuts_impl(initial_vals, d, kernel, data, s, draws_out, st, 2, n_exec_out);
 }
 static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st, int memo, uint64_t* n_exec_out)
@@ -1228,9 +1269,16 @@ static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn ker
     double* diff = dvec(d);
     size_t n_accept = 0;
     (void)prop_U;
+    memo_dir xdir[2];                                                   /* memo == 2: what the doublings of a draw share, by direction (0: backward) */
+    for (int k = 0; k < 2; ++k) {
+        xdir[k].pt_th = (memo == 2) ? dvec((size_t)ORC_MEMO_MAXPTS * d) : NULL; xdir[k].pt_p = (memo == 2) ? dvec((size_t)ORC_MEMO_MAXPTS * d) : NULL;
+        xdir[k].je = (max_tree_depth >= 1) ? (int)max_tree_depth - 1 : 0;
+        memo_dir_reset(&xdir[k]);
+    }
 
     for (size_t draw_ind = 0; draw_ind < n_total; ++draw_ind) {         /* :199 */
         const uint64_t leap0 = c.n_leap;
+        memo_dir_reset(&xdir[0]); memo_dir_reset(&xdir[1]);             /* a new momentum: new trajectories */
         const double eps_used = step_size;
         uint32_t uslot = 0;
         orc_rng_normal_vec(c.seed, c.chain, (uint32_t)draw_ind, ORC_STREAM_NORMAL, d, rand_vec);  /* :200 */
@@ -1252,11 +1300,12 @@ static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn ker
             double z = orc_rng_uniform(c.seed, c.chain, (uint32_t)draw_ind, uslot++);   /* :233 */
             const int direction_val = (z <= 0.5) ? -1 : 1;              /* :235 */
             memcpy(start_draw, prev_draw, nb);   /* prev_draw is passed by const ref; it is not modified in the call */
+            memo_dir* const xd = (memo == 2) ? &xdir[direction_val > 0] : NULL;
             if (direction_val == -1) {
                 memcpy(dummy_draw, draw_pos, nb);                       /* :238-239 */
                 memcpy(dummy_mntm, mntm_pos, nb);
                 if (memo) nuts_doubling_memo(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec, tree_depth,
-                                             new_draw, draw_neg, mntm_neg, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec);
+                                             new_draw, draw_neg, mntm_neg, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec, xd);
                 else
                 nuts_build_tree(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec,
                                 tree_depth, new_draw, dummy_draw, draw_neg, dummy_mntm, mntm_neg,
@@ -1265,7 +1314,7 @@ static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn ker
                 memcpy(dummy_draw, draw_neg, nb);                       /* :248-249 */
                 memcpy(dummy_mntm, mntm_neg, nb);
                 if (memo) nuts_doubling_memo(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec, tree_depth,
-                                             new_draw, draw_pos, mntm_pos, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec);
+                                             new_draw, draw_pos, mntm_pos, &n_p_val, &s_p_val, &alpha_val, &n_alpha_val, (uint32_t)draw_ind, &uslot, &n_exec, xd);
                 else
                 nuts_build_tree(&c, direction_val, step_size, log_rand_val, prev_U, prev_K, start_draw, mntm_vec,
                                 tree_depth, new_draw, draw_pos, dummy_draw, mntm_pos, dummy_mntm,
@@ -1278,6 +1327,7 @@ static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn ker
                     if (!isfinite(prop_U)) prop_U = INFINITY;
                     memcpy(prev_draw, new_draw, nb);                    /* :272-273 */
                     prev_U = prop_U;
+                    memo_dir_reset(&xdir[0]); memo_dir_reset(&xdir[1]);   /* the next doubling starts from another state */
                     good_round = 1;                                     /* :277 */
                 }
             }
@@ -1314,6 +1364,7 @@ static int orc_nuts_impl(const double* initial_vals, size_t d, orc_kernel_fn ker
     free(first_draw); free(rand_vec); free(mntm_vec); free(prev_draw); free(new_draw);
     free(draw_pos); free(draw_neg); free(mntm_pos); free(mntm_neg);
     free(dummy_draw); free(dummy_mntm); free(start_draw); free(diff);
+    for (int k = 0; k < 2; ++k) { free(xdir[k].pt_th); free(xdir[k].pt_p); }
     ctx_free(&c);
     return 0;
 }

@@ -137,6 +137,9 @@ int orc_nuts(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* d
  * leapfrog count in st->n_leapfrogs, the leap_frog calls really made in *n_exec_out (may be NULL).  max_tree_depth > 10: the recursion. */
 int orc_nuts_memo(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
                   const orc_settings* s, double* draws_out, orc_stats* st, uint64_t* n_exec_out);
+/* ... and across the doublings of a draw (same direction, no accepted proposal in between): the plain-case kernel's count since round 6 */
+int orc_nuts_memo_xd(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
+                  const orc_settings* s, double* draws_out, orc_stats* st, uint64_t* n_exec_out);
 /* mcmc::rwmh (src/rwmh.cpp:30-175): step_size carries par_scale, precond_mat carries cov_mat */
 int orc_rwmh(const double* initial_vals, size_t d, orc_kernel_fn kernel, void* data,
              const orc_settings* s, double* draws_out, orc_stats* st);

@@ -9,6 +9,7 @@ _SO = os.environ.get("ORC_LIB", os.path.join(ROOT, "oracle", "liboracle.so"))   
 
 TARGET_ISO, TARGET_DIAG, TARGET_DENSE, TARGET_LOGISTIC, TARGET_NORMAL_MODEL = 1, 2, 3, 4, 5
 ALGO_HMC, ALGO_MALA, ALGO_NUTS, ALGO_RWMH, ALGO_RMHMC = 0, 1, 2, 3, 4
+ALGO_NUTS_MEMO_XD = 6                       # orc_nuts_memo_xd: ... and across the doublings of a draw (same direction, no accepted proposal in between): same bits again
 ALGO_NUTS_MEMO = 5                          # orc_nuts_memo: the same run, every doubling on a memoised trajectory (same bits)   # rwmh: step = par_scale, precond = cov_mat
 
 _dp = C.POINTER(C.c_double)
@@ -121,15 +122,16 @@ def run_chain(algo, target, init, settings, traces=False, kernel=None, data=None
                              C.byref(settings), _p(draws), C.byref(st))
     else:
         n_exec = C.c_uint64(0)
-        if algo == ALGO_NUTS_MEMO:
-            rc = lib().orc_nuts_memo(_p(init), C.c_size_t(d), kern, tdata, C.byref(settings), _p(draws), C.byref(st), C.byref(n_exec))
+        if algo in (ALGO_NUTS_MEMO, ALGO_NUTS_MEMO_XD):
+            fn = lib().orc_nuts_memo if algo == ALGO_NUTS_MEMO else lib().orc_nuts_memo_xd
+            rc = fn(_p(init), C.c_size_t(d), kern, tdata, C.byref(settings), _p(draws), C.byref(st), C.byref(n_exec))
         else:
             fn = [lib().orc_hmc, lib().orc_mala, lib().orc_nuts, lib().orc_rwmh][algo]
             rc = fn(_p(init), C.c_size_t(d), kern, tdata, C.byref(settings), _p(draws), C.byref(st))
     assert rc == 0
     info = dict(n_accept=st.n_accept_draws, n_leap=st.n_leapfrogs, eps=st.final_step_size,
                 accept=acc, depth=dep, leaps=lea, eps_trace=eps)
-    if algo == ALGO_NUTS_MEMO:
+    if algo in (ALGO_NUTS_MEMO, ALGO_NUTS_MEMO_XD):
         info["n_exec"] = int(n_exec.value)
     return draws[:n_keep], info
 

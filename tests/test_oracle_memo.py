@@ -16,7 +16,7 @@ def _both(kind, d, init, chain, **kw):
     elif kind == orc.TARGET_DIAG:
         prec = synth.ill_conditioned_diag(d, 50.0)
     out = []
-    for algo in (orc.ALGO_NUTS, orc.ALGO_NUTS_MEMO):
+    for algo in (orc.ALGO_NUTS, orc.ALGO_NUTS_MEMO, orc.ALGO_NUTS_MEMO_XD):
         t = orc.TargetSpec(kind, d, prec=prec, W=4)
         s = orc.make_settings(W=4, chain_id=chain, **kw)
         out.append(orc.run_chain(algo, t, init, s, traces=True))
@@ -38,19 +38,23 @@ CASES = [
 
 @pytest.mark.parametrize("kind,d,burn,keep,adapt,depth,step", CASES)
 def test_memoised_doubling_equals_the_recursion(kind, d, burn, keep, adapt, depth, step):
-    tot_ref = tot_exec = 0
+    """... and (round 6) memoised ACROSS the doublings of a draw as well (orc_nuts_memo_xd: a doubling re-uses the points the last doubling of its direction
+    left, while no proposal was accepted in between): the same bits again, fewer leap_frog calls still"""
+    tot_ref = tot_exec = tot_xd = 0
     for chain in range(6):
         init = synth.initial_states(1, d, seed=100 + chain)[0]
-        (a, ia), (b, ib) = _both(kind, d, init, chain, seed=77, n_burnin=burn, n_keep=keep, n_adapt=adapt, max_depth=depth, step=step)
-        assert np.array_equal(a, b)
-        for k in ("n_accept", "n_leap", "eps"):
-            assert ia[k] == ib[k], k
-        for k in ("accept", "depth", "leaps", "eps_trace"):
-            assert np.array_equal(ia[k], ib[k]), k
-        assert ib["n_exec"] <= ib["n_leap"]
-        tot_ref += ib["n_leap"]; tot_exec += ib["n_exec"]
+        (a, ia), (b, ib), (x, ix) = _both(kind, d, init, chain, seed=77, n_burnin=burn, n_keep=keep, n_adapt=adapt, max_depth=depth, step=step)
+        for o, io in ((b, ib), (x, ix)):
+            assert np.array_equal(a, o)
+            for k in ("n_accept", "n_leap", "eps"):
+                assert ia[k] == io[k], k
+            for k in ("accept", "depth", "leaps", "eps_trace"):
+                assert np.array_equal(ia[k], io[k]), k
+        assert ix["n_exec"] <= ib["n_exec"] <= ib["n_leap"]
+        tot_ref += ib["n_leap"]; tot_exec += ib["n_exec"]; tot_xd += ix["n_exec"]
     if depth >= 6 and kind != orc.TARGET_ISO:
         assert tot_exec < tot_ref                       # points are re-visited: fewer leap_frog calls than leaves
+        assert tot_xd < tot_exec                        # ... and doublings of one direction share their trajectory
 
 
 def test_memoised_doubling_in_the_non_finite_regime_and_with_bounds():
@@ -62,14 +66,15 @@ def test_memoised_doubling_in_the_non_finite_regime_and_with_bounds():
                              (4, 0.5, dict(lower=lb, upper=ub, precond=M))]:
         init = np.clip(synth.initial_states(1, d, seed=chain)[0] * 0.3, -1.0, 1.5) * scale
         res = []
-        for algo in (orc.ALGO_NUTS, orc.ALGO_NUTS_MEMO):
+        for algo in (orc.ALGO_NUTS, orc.ALGO_NUTS_MEMO, orc.ALGO_NUTS_MEMO_XD):
             t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
             s = orc.make_settings(seed=5, n_burnin=6, n_keep=8, n_adapt=6, max_depth=7, step=0.3, W=4, chain_id=chain, **kw)
             res.append(orc.run_chain(algo, t, init, s, traces=True))
-        (a, ia), (b, ib) = res
-        assert np.array_equal(a, b, equal_nan=True)
-        assert ia["n_leap"] == ib["n_leap"] and np.array_equal(ia["depth"], ib["depth"]) and np.array_equal(ia["accept"], ib["accept"])
-        assert (ia["eps"] == ib["eps"]) or (np.isnan(ia["eps"]) and np.isnan(ib["eps"]))
+        (a, ia) = res[0]
+        for b, ib in res[1:]:
+            assert np.array_equal(a, b, equal_nan=True)
+            assert ia["n_leap"] == ib["n_leap"] and np.array_equal(ia["depth"], ib["depth"]) and np.array_equal(ia["accept"], ib["accept"])
+            assert (ia["eps"] == ib["eps"]) or (np.isnan(ia["eps"]) and np.isnan(ib["eps"]))
 
 
 def test_the_points_of_a_doubling_follow_the_closed_form():
