@@ -68,6 +68,10 @@ struct TileParams {
     unsigned long long* prof;
     uint32_t nuts_grid;     // nuts: workgroups to launch (the engine: min(tiles, CUs) -- the workspace, 148 vectors per chain SLOT at max_tree_depth 10, is sized
                             // by the grid, not by the chains); 0 = (C + 63) / 64
+    // mala with a DIAGONAL precond_mat, no bounds (mala_tile_kernel<T, true>; round 6): the diagonal of precond_mat and of INV(eps^2 precond_mat), d values each on
+    // the device (m_sqrt above: of CHOL_LOWER(precond_mat)); log_det carries LOG_DET(eps^2 precond_mat).  nullptr: the identity
+    const double* m;
+    const double* s_inv;
 };
 
 // ---- settings.vals_bound and / or a diagonal precond_mat on the tile route, with the arithmetic of the general built-in kernels
@@ -194,6 +198,30 @@ __device__ __forceinline__ double diag_quadratic(const double (&x)[NS], double d
         double y[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) y[s] = dg * x[s];
+        dense_product_poison<NS>(x, y, j, d);
+        double q2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) q2 = dfma(x[s], y[s], q2);
+        q2 = q2 + __shfl_xor(q2, 32);
+        q2 = q2 + __shfl_xor(q2, 16);
+        q = q2;
+    }
+    return q;
+}
+
+// ... with a diagonal matrix diag(dg) (slice s of this lane: dg[s]) instead of dg * I
+template <int NS>
+__device__ __forceinline__ double diag_quadratic_v(const double (&x)[NS], const double (&dg)[NS], int j, uint32_t d)
+{
+    double q = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) q = dfma(x[s], dg[s] * x[s], q);
+    q = q + __shfl_xor(q, 32);
+    q = q + __shfl_xor(q, 16);
+    if (__ballot(!is_finite(q)) != 0ull) {
+        double y[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) y[s] = dg[s] * x[s];
         dense_product_poison<NS>(x, y, j, d);
         double q2 = 0.0;
 #pragma unroll
@@ -465,16 +493,26 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void hmc_tile_gen_kernel(con
     }
 }
 
-// mcmc::mala (ref: src/mala.cpp:149-186, include/mcmc/mala.ipp:59-64, include/stats/dmvnorm.hpp:28-54), identity preconditioner, no
+// mcmc::mala (ref: src/mala.cpp:149-186, include/mcmc/mala.ipp:59-64, include/stats/dmvnorm.hpp:28-54), no
 // bounds: one evaluation per draw (at the proposal), the current gradient cached -- the reference's three gradient calls are
-// deterministic repeats (mala_dense.hpp)
-template <class T>
+// deterministic repeats (mala_dense.hpp).  Identity preconditioner, or (GEN, round 6) a DIAGONAL precond_mat M (mala.cpp:57-58,123,159; mala.ipp:58-64):
+// mu(v) = v + (eps^2 (M g)) / 2, proposal = mu + eps (sqrt(M) z), Sigma = eps^2 M in both dmvnorm terms -- INV(Sigma) = diag(1 / (eps^2 m)) and
+// LOG_DET(Sigma) from the host, what the oracle's Gauss-Jordan / Cholesky give for a diagonal matrix --, every dense product of the reference
+// applied element-wise with its NaN rule (dense_product_poison), as on the identity route: no replay.  Tables: 3 x 16 NT doubles of LDS behind the target's.
+template <class T, bool GEN = false>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_tile_kernel(const TileParams prm, const T tgt)
 {
     constexpr int WPB = 4;                              // one wave per SIMD: four register-resident vectors per chain tile
     constexpr int NT = T::NT, NS = 4 * NT;
     extern __shared__ __attribute__((aligned(16))) double lds_t[];
     tgt.stage(lds_t);
+    [[maybe_unused]] double* const tab_m = lds_t + prm.lds_user_doubles;     // GEN: m | sqrt(m) | 1 / (eps^2 m), padded with ones
+    if constexpr (GEN) {
+        for (int k = threadIdx.x; k < 16 * NT; k += blockDim.x) {
+            const bool in = (uint32_t)k < prm.d;
+            tab_m[k] = in ? prm.m[k] : 1.0; tab_m[16 * NT + k] = in ? prm.m_sqrt[k] : 1.0; tab_m[32 * NT + k] = in ? prm.s_inv[k] : 1.0;
+        }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane >> 4;
@@ -498,29 +536,49 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void mala_tile_kernel(const 
     double prev_LP = val;                               // mala.cpp:138
     uint64_t n_acc = 0;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
-    // mala_mean_fn (:123): v + eps^2 (I grad) / 2, the identity as the dense product it is
-    auto mean_of = [&](const double (&v)[NS], const double (&gr)[NS], double (&out)[NS]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) out[s] = v[s] + (s2 * gr[s]) / 2.0;
-        dense_product_poison<NS>(gr, out, j, d);         // v_i + (eps^2 NaN) / 2 where (I grad)_i is poisoned
+    // this lane's column of a table (entry of slice s at [4 s]), re-derived opaquely where it is used: as loop invariants the entries would be kept in registers
+    [[maybe_unused]] auto tcol = [&](int t) __attribute__((always_inline)) -> const double* {
+        const double* p = tab_m + 16 * NT * t + j;
+        asm volatile("" : "+v"(p));
+        return p;
     };
-    // (x - mu)' INV(eps^2 I) (x - mu) (dmvnorm.hpp:37-39)
+    // mala_mean_fn (:123): v + eps^2 (M grad) / 2, M (the identity, or diagonal) as the dense product it is
+    auto mean_of = [&](const double (&v)[NS], const double (&gr)[NS], double (&out)[NS]) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            const double* mc = tcol(0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) out[s] = v[s] + (s2 * (mc[4 * s] * gr[s])) / 2.0;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) out[s] = v[s] + (s2 * gr[s]) / 2.0;
+        }
+        dense_product_poison<NS>(gr, out, j, d);         // v_i + (eps^2 NaN) / 2 where (M grad)_i is poisoned
+    };
+    // (x - mu)' INV(eps^2 M) (x - mu) (dmvnorm.hpp:37-39)
     auto quad = [&](const double (&xv)[NS], const double (&mu)[NS]) __attribute__((always_inline)) -> double {
         double xc[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) xc[s] = xv[s] - mu[s];
-        return diag_quadratic<NS>(xc, rs, j, d);
+        if constexpr (GEN) {
+            const double* sc = tcol(2);
+            double dg[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) dg[s] = sc[4 * s];
+            return diag_quadratic_v<NS>(xc, dg, j, d);
+        } else return diag_quadratic<NS>(xc, rs, j, d);
     };
 #pragma unroll 1
     for (uint32_t draw = 0; draw < n_total; ++draw) {
         double mean_prev[NS];
         mean_of(th, g, mean_prev);
 #pragma unroll
-        for (int b = 0; b < NS / 2; ++b) {               // proposal = mean + eps * (I z) (:150,159)
+        for (int b = 0; b < NS / 2; ++b) {               // proposal = mean + eps * (sqrt(M) z) (:150,159)
             double z0, z1;
             rng_normal_pair_at(prm.seed, chain, draw + prm.draw0, (uint32_t)(4 * b), (uint32_t)j, STREAM_NORMAL, z0, z1);
-            tp[2 * b] = mean_prev[2 * b] + eps * ((8u * b + j < d) ? z0 : 0.0);
-            tp[2 * b + 1] = mean_prev[2 * b + 1] + eps * ((8u * b + 4 + j < d) ? z1 : 0.0);
+            double za = (8u * b + j < d) ? z0 : 0.0, zb = (8u * b + 4 + j < d) ? z1 : 0.0;
+            if constexpr (GEN) { const double* lc = tcol(1); za = lc[8 * b] * za; zb = lc[8 * b + 4] * zb; }      // (z is finite: no NaN rule to apply)
+            tp[2 * b] = mean_prev[2 * b] + eps * za;
+            tp[2 * b + 1] = mean_prev[2 * b + 1] + eps * zb;
             __builtin_amdgcn_sched_barrier(0);
         }
         tgt.grad_tile(lds_t, tp, gp, valp, true);

@@ -28,7 +28,7 @@
 //
 // The macro defines  extern "C" int my_tile_run(int algo, const MyTile* target, uint64_t d, const mi_settings*, mi_chains*, void* stream)
 // with algo 0 = mcmc::hmc, 1 = mcmc::mala, 2 = mcmc::nuts (max_tree_depth <= 10); hmc and nuts also with settings.vals_bound and / or a
-// DIAGONAL precond_mat (anything else -- mala with either, a dense precond_mat -- returns MI_ERR_UNSUPPORTED with the reason),
+// DIAGONAL precond_mat, mala with a diagonal precond_mat (anything else -- mala with bounds, a dense precond_mat -- returns MI_ERR_UNSUPPORTED with the reason),
 // the settings / chains contract of include/mi_mcmc.h (host or device memory, global chain ids, draw0).  The target above IS the
 // built-in dense Gaussian: it reproduces hmc_gauss_mfma_kernel's draws bit for bit (tests/test_user_tile_target.py), and a
 // non-Gaussian target is checked the way every target is -- the oracle driven by a host function with the same operation order.
@@ -90,6 +90,11 @@ int tile_target_launch(int algo, const void* tile_params, const void* target_pod
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, grid, dim3(64 * WPB), lds_bytes, st, prm, tgt);
+    } else if (algo == 1 && prm.m != nullptr) {
+        auto kern = mala_tile_kernel<T, true>;           // a diagonal precond_mat
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((prm.C + 63) / 64)), dim3(256), lds_bytes, st, prm, tgt);
     } else if (algo == 1) {
         auto kern = mala_tile_kernel<T>;                 // always one wave per SIMD
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

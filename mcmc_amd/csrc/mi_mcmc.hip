@@ -1229,11 +1229,13 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         return fail(MI_ERR_UNSUPPORTED, "tile targets: nuts with max_tree_depth > %d is not implemented on this route", (int)mi::tile_nuts::NUTS_MAX_DEPTH);
     if (!(nt == 1 || nt == 2 || nt == 4 || nt == 8) || d == 0 || d > (uint64_t)16 * nt) return fail(MI_ERR_BAD_ARG, "tile targets: 1 <= d <= 16 NT, NT in {1, 2, 4, 8}");
     if (wpb != 4 && wpb != 8) return fail(MI_ERR_BAD_ARG, "tile targets: WPB is 4 or 8");
-    // vals_bound and / or a DIAGONAL precond_mat: hmc and nuts (TileGen, tile_samplers.hpp).  mala with either and a dense precond_mat stay
-    // with the one-lane targets (include/mi_mcmc_target.hpp), which take every combination: refused here with the reason
+    // vals_bound and / or a DIAGONAL precond_mat: hmc and nuts (TileGen, tile_samplers.hpp); mala with a diagonal precond_mat alone (round 6:
+    // mala_tile_kernel<T, true>).  mala with bounds and a dense precond_mat stay with the one-lane targets (include/mi_mcmc_target.hpp), which take
+    // every combination: refused here with the reason
     GeneralTables gt;
+    const bool mala_diag = algo == 1 && !settings->vals_bound && settings->precond_mat != nullptr;
     if (settings->vals_bound || settings->precond_mat) {
-        if (algo == 1) return fail(MI_ERR_UNSUPPORTED, "tile targets: mala with vals_bound / precond_mat is not implemented on this route (one-lane targets, include/mi_mcmc_target.hpp, take both)");
+        if (algo == 1 && settings->vals_bound) return fail(MI_ERR_UNSUPPORTED, "tile targets: mala with vals_bound is not implemented on this route (one-lane targets, include/mi_mcmc_target.hpp, take it)");
         const int rcg = general_tables("tile targets", settings, d, gt, false);
         if (rcg) return rcg;
     }
@@ -1250,7 +1252,8 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t lds_user = lds_bytes;
     if (algo == 2) lds_bytes += mi::tile_nuts::lds_doubles() * sizeof(double);     // the sampler's per-level tables behind the target's own LDS
-    if (gt.active) lds_bytes += (uint64_t)(16 * nt * 4 + 8 * nt) * sizeof(double);  // TileGen<NT>::lds_doubles(): bounds / mass tables
+    if (gt.active && !mala_diag) lds_bytes += (uint64_t)(16 * nt * 4 + 8 * nt) * sizeof(double);  // TileGen<NT>::lds_doubles(): bounds / mass tables
+    if (mala_diag) lds_bytes += (uint64_t)(3 * 16 * nt) * sizeof(double);           // mala_tile_kernel<T, true>: m | sqrt(m) | 1 / (eps^2 m)
     if (lds_bytes > (uint64_t)lds_max) return fail(MI_ERR_BAD_ARG, "tile targets: target + nuts tables ask for %llu bytes of LDS, a workgroup has %d", (unsigned long long)lds_bytes, lds_max);
     StagedChains sc;
     int rc = stage_in(chains, d, settings->n_keep_draws, sc, st, n_total);
@@ -1271,7 +1274,19 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         p.log_det = ld;
     }
     p.lds_user_doubles = (uint32_t)(lds_user / sizeof(double));
-    if (gt.active) {
+    DevBuf sinv_dev;
+    if (mala_diag) {
+        // Sigma = eps^2 M is constant: INV(Sigma) = diag(1 / (eps^2 m_i)) and LOG_DET(Sigma) = sum_i 2 log sqrt(eps^2 m_i), i ascending -- what the oracle's
+        // Gauss-Jordan / Cholesky give for a diagonal matrix (the built-in general mala kernel, mala_dense.hpp, forms the same values)
+        std::vector<double> sinv(d);
+        double ld = 0.0;
+        for (uint64_t i = 0; i < d; ++i) { const double sig = p.s2 * gt.m[i]; sinv[i] = 1.0 / sig; ld = ld + 2.0 * mi::det_log(__builtin_sqrt(sig)); }
+        p.log_det = ld;
+        HIP_TRY(sinv_dev.alloc(d * 8));
+        HIP_TRY(hipMemcpy(sinv_dev.p, sinv.data(), d * 8, hipMemcpyHostToDevice));
+        p.m = gt.m_dev.as<double>(); p.m_sqrt = gt.ms_dev.as<double>(); p.s_inv = sinv_dev.as<double>();
+    }
+    else if (gt.active) {
         p.vals_bound = settings->vals_bound ? 1 : 0;
         p.btype = gt.bt.as<int>(); p.lb = gt.lb.as<double>(); p.ub = gt.ub.as<double>();
         p.m_sqrt = gt.ms_dev.as<double>(); p.m_inv = gt.mi_dev.as<double>();
@@ -1299,7 +1314,7 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         if (rc) return rc;
         p.wsave = ws.as<double>();
     }
-    mi::note_kernel("%s_tile%s_kernel<user target, %d>", algo == 0 ? "hmc" : algo == 1 ? "mala" : "nuts", gt.active ? "_gen" : "", (algo == 0 && !gt.active) ? wpb : 4);
+    mi::note_kernel("%s_tile%s_kernel<user target, %d>", algo == 0 ? "hmc" : algo == 1 ? "mala" : "nuts", gt.active ? "_gen" : "", (algo == 0 && !gt.active) ? wpb : 4);     // (mala_tile_gen: mala_tile_kernel<T, true>)
     const int e = launch(algo, &p, target_pod, lds_bytes, stream);
     if (e != 0) return fail(MI_ERR_HIP, "tile target kernel launch: %s", hipGetErrorString((hipError_t)e));
     if (algo == 1) { rc = fill_n_leap(sc.dev.n_leapfrogs, chains->n_chains, 0, st); if (rc) return rc; }
