@@ -69,6 +69,8 @@ struct HmcParams {
     uint32_t m_per_chain;   // DIAGM: 0 = one mass for all chains (m_sqrt / m_inv are [d]); 1 = per-chain masses (mi_chains.mass_diag): [d][C]
     uint32_t* nf_flag;      // plain kernels: [C + 1] or nullptr.  A chain whose energies went non-finite is flagged (nf_flag[c] = 1,
                             // nf_flag[C] = 1) and its theta / n_accept / n_leap are left untouched: literal.hpp replays it
+    uint32_t sep_target;    // general variant: P is the expanded diagonal of an ISO / DIAG target, whose gradient the reference's target function takes
+                            // element-wise (target_times below)
 };
 
 template <int NS>
@@ -224,6 +226,25 @@ __device__ __forceinline__ void matvec_m2(const double* __restrict__ frag_lane, 
 {
     if constexpr (dense_m_from_global<NT>()) matvec_mfma_g<NT>(frag_lane, x, y);
     else matvec_mfma<NT>(frag_lane, x, y);
+}
+
+// P x of a built-in Gaussian in the kernels that follow a chain THROUGH the non-finite regime themselves (the general variants: nothing replays their
+// chains): a DENSE target's mat-vec -- and for an ISO / DIAG target, whose P here is the expanded diagonal, the element-wise product the reference's
+// target function forms (oracle: orc_target_kernel).  The bits of the mat-vec while everything is finite; a +-inf coordinate stays in its own dimension,
+// where 0 * inf of the expanded zeros would put NaN into every other one (found by the round-6 fuzz: hmc, DIAG target, dense precond_mat, d = 64, a chain
+// started at inf whose proposal is accepted -- draws NaN where the oracle has +-inf).  `sep` is wave-uniform.
+template <int NT>
+__device__ __forceinline__ void target_times(const double* __restrict__ afrag, const double* __restrict__ P, uint32_t d, bool sep,
+                                             const double (&x)[4 * NT], double (&w)[4 * NT])
+{
+    if (sep) {
+        const uint32_t j = (threadIdx.x & 63u) >> 4;
+#pragma unroll
+        for (int s = 0; s < 4 * NT; ++s) {
+            const uint32_t dim = 4u * (uint32_t)s + j;
+            w[s] = (dim < d) ? P[(size_t)dim * (d + 1u)] * x[s] : 0.0;
+        }
+    } else matvec_mfma<NT>(afrag, x, w);
 }
 
 // ---- box constraints (element-wise maps of /root/reference/include/misc/transform_vals.hpp:25-119,
@@ -418,7 +439,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(64 * WPB, WPB / 4) void hmc_gauss_mf
                 if (slice_bounded(s)) xs[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
                 else xs[s] = ((uint32_t)i < d) ? th[s] : 0.0;
             }
-            matvec_mfma<NT>(afrag, xs, w);
+            target_times<NT>(afrag, prm.P, d, prm.sep_target != 0u, xs, w);
         } else {
             matvec_mfma<NT>(afrag, th, w);
         }

@@ -1510,6 +1510,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     mi::HmcParams prm{};
     prm.P = P_dev;
     prm.d = (uint32_t)d;
+    prm.sep_target = target->kind != MI_TARGET_GAUSS_DENSE;     // ISO / DIAG: the general variants take the gradient element-wise, as the reference's target function does (hmc_dense.hpp: target_times)
     prm.C = chains->n_chains;
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;
@@ -2230,6 +2231,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
     mi::NutsParams prm{};
     prm.P = P_dev;
     prm.d = (uint32_t)d;
+    prm.sep_target = target->kind != MI_TARGET_GAUSS_DENSE;     // ISO / DIAG: the general variants (and the replay of flagged chains, which is one) take the gradient element-wise
     prm.C = chains->n_chains;
     prm.chain0 = chains->chain0;
     prm.theta = sc.dev.theta;

@@ -185,7 +185,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 1) void nuts_gauss_async_kernel
                 if ((bslices >> s) & 1u) xs_[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
                 else xs_[s] = ((uint32_t)i < d) ? th[s] : 0.0;      // (uniform branch: the transform code of an unbounded slice is never fetched)
             }
-            matvec_mfma<NT>(afrag, xs_, w);
+            target_times<NT>(afrag, prm.P, d, prm.sep_target != 0u, xs_, w);
         }
     };
     auto kick = [&](double e) __attribute__((always_inline)) {         // p += e [J] grad / 2, grad = -w (nuts.cpp:108-135)
@@ -589,7 +589,7 @@ const double* const mi_t = mi_tab();
                     if ((bslices >> s) & 1u) xl[s] = ((uint32_t)i < d) ? box_inv_transform(th[s], lds_bt[i], lds_lb[i], lds_ub[i]) : 0.0;
                     else xl[s] = ((uint32_t)i < d) ? th[s] : 0.0;
                 }
-                matvec_mfma<NT>(afrag, xl, w);
+                target_times<NT>(afrag, prm.P, d, prm.sep_target != 0u, xl, w);
             } else {
                 matvec_mfma<NT>(afrag, th, w);
             }

@@ -19,11 +19,12 @@ struct BuiltinGaussTile {
     static constexpr int NT = NT_;
     const double* P;        // device, d x d row-major
     uint32_t d;
+    uint32_t sep;           // an ISO / DIAG target (P: its expanded diagonal): the gradient element-wise, as the reference's target function takes it (target_times)
     __device__ void stage(double* lds) const { stage_precision<NT>(P, d, lds); }
     __device__ void grad_tile(const double* lds, const double (&th)[4 * NT], double (&g)[4 * NT], double& value, bool want_value) const
     {
         double w[4 * NT];
-        matvec_mfma<NT>(lds + (threadIdx.x & 63), th, w);
+        target_times<NT>(lds + (threadIdx.x & 63), P, d, sep != 0u, th, w);
 #pragma unroll
         for (int s = 0; s < 4 * NT; ++s) g[s] = -w[s];
         if (want_value) value = -0.5 * dot4<4 * NT>(th, w);
@@ -31,14 +32,14 @@ struct BuiltinGaussTile {
 };
 
 template <int NT>
-int run(const TileParams& prm, const double* P, hipStream_t st)
+int run(const TileParams& prm, const double* P, uint32_t sep, hipStream_t st)
 {
     const size_t lds = (size_t)NT * 4 * NT * 64 * sizeof(double) + memo::lds_bytes() + TileGen<NT>::lds_doubles() * sizeof(double);
     auto kern = tile_nuts::nuts_tile_kernel<BuiltinGaussTile<NT>, true>;
     note_kernel("nuts_tile_kernel<built-in Gaussian %d, true>", NT);
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (prm.next_chain) MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(kern, dim3(prm.nuts_grid ? (unsigned)prm.nuts_grid : (unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, BuiltinGaussTile<NT>{P, prm.d});
+    hipLaunchKernelGGL(kern, dim3(prm.nuts_grid ? (unsigned)prm.nuts_grid : (unsigned)((prm.C + 63) / 64)), dim3(256), lds, st, prm, BuiltinGaussTile<NT>{P, prm.d, sep});
     return (int)hipGetLastError();
 }
 
@@ -70,7 +71,7 @@ int launch_nuts_gauss_bounded(const NutsParams& q, int nt, hipStream_t st)
     p.vals_bound = q.vals_bound; p.btype = q.btype; p.lb = q.lb; p.ub = q.ub; p.m_sqrt = q.m_sqrt; p.m_inv = q.m_inv;
     const int ntp = nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8;
     p.lds_user_doubles = (uint32_t)(ntp * 4 * ntp * 64);
-    return MI_DISPATCH_NT(nt, (run<1>(p, q.P, st)), (run<2>(p, q.P, st)), (run<4>(p, q.P, st)), (run<8>(p, q.P, st)));
+    return MI_DISPATCH_NT(nt, (run<1>(p, q.P, q.sep_target, st)), (run<2>(p, q.P, q.sep_target, st)), (run<4>(p, q.P, q.sep_target, st)), (run<8>(p, q.P, q.sep_target, st)));
 }
 
 }  // namespace mi

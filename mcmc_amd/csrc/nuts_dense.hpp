@@ -73,7 +73,7 @@ struct NutsParams {
     // nuts_gauss_memo_kernel<., ., true> (nuts_memo.hpp): the momenta of every draw of every chain, filled by nuts_momenta_kernel before the launch.
     // mom: [n_total][C] blocks of 16 NT doubles in the granule order of a workspace row; msc: [n_total][C] (kinetic energy, log of the slice uniform)
     double* mom;
-    double* msc;
+    double* msc;    uint32_t sep_target;    // general variants: P is the expanded diagonal of an ISO / DIAG target: its gradient is taken element-wise (hmc_dense.hpp: target_times)
 };
 
 enum : int {

@@ -17,7 +17,7 @@ def sweep(n_cases=48, seed=1, verbose=True):
     fails = 0
     for case in range(n_cases):
         algo = ["hmc", "mala", "nuts", "rwmh"][case % 4]
-        d = int(rng.choice([5, 17, 31, 33, 47, 63, 65, 100, 127]))
+        d = int(rng.choice([5, 16, 17, 31, 32, 33, 47, 63, 64, 65, 100, 127, 128]))
         if algo == "mala" and d > 64: d = int(rng.choice([17, 31, 47, 63]))
         C = int(rng.choice([3, 16, 20]))
         rseed = int(rng.integers(1, 10**6)); chain0 = int(rng.integers(0, 1000))

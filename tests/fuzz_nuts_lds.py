@@ -39,7 +39,11 @@ def sweep(n_cases=30, seed=1, verbose=True):
                 if rng.random() < 0.3: init[c, 0] = np.inf
         kw = {}
         if rng.random() < 0.3: kw["precond_mat"] = np.diag(rng.uniform(0.3, 3.0, d))
-        if rng.random() < 0.3:                             # settings.vals_bound (lds_box.hpp)
+        dense_m = rng.random() < 0.25                      # round 6: a DENSE precond_mat without bounds (nuts_lds.hpp: DENSEM)
+        if dense_m:
+            A = rng.standard_normal((d, d)) / np.sqrt(d)
+            kw["precond_mat"] = A @ A.T + np.diag(rng.uniform(0.4, 2.5, d))
+        if not dense_m and rng.random() < 0.3:             # settings.vals_bound (lds_box.hpp)
             kind_b = np.where(rng.random(d) < rng.choice([0.05, 0.5]), rng.integers(2, 5, d), 1)
             kw.update(vals_bound=1, lower_bounds=np.where((kind_b == 2) | (kind_b == 4), -1.5, -np.inf), upper_bounds=np.where((kind_b == 3) | (kind_b == 4), 2.0, np.inf))
             if not wild: init = np.clip(init, -1.0, 1.5)
@@ -65,7 +69,7 @@ def sweep(n_cases=30, seed=1, verbose=True):
             ok = same(np.concatenate([p_draws, q_draws]), a_draws) and same(q["eps"], a["eps"]) and np.array_equal(p["n_leap"] + q["n_leap"], a["n_leap"])
         if verbose or not ok:
             print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, n_rows=(n_rows if kind == "logistic" else 0), C=C, burn=burn, keep=keep, adapt=adapt,
-                                                   max_depth=max_depth, eps0=eps0, chain0=chain0, wild=wild, diag="precond_mat" in kw, bounds="vals_bound" in kw, cut=cut,
+                                                   max_depth=max_depth, eps0=eps0, chain0=chain0, wild=wild, diag="precond_mat" in kw and not dense_m, dense_m=bool(dense_m), bounds="vals_bound" in kw, cut=cut,
                                                    seed=int(sd), kernel=kernel, leaps=int(a["n_leap"].sum())), flush=True)
         fails += 0 if ok else 1
     return fails

@@ -81,6 +81,11 @@ def sweep(n_cases=60, seed=1, verbose=True):
         if algo == "nuts": ok = ok and np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
         if not ok:
             fails += 1
+            if os.environ.get("MI_FUZZ_DUMP"):            # the case's inputs and both results, for a post-mortem off the box
+                np.savez(os.path.join(os.environ["MI_FUZZ_DUMP"], f"fuzz_mismatch_{seed}_{case}.npz"), algo=algo, tgt=tgt, d=d, C=C, eps=eps, L=L, burn=burn, keep=keep,
+                         rseed=rseed, chain0=chain0, init=init, prec=(prec if prec is not None else np.zeros(0)), M=kw.get("precond_mat", np.zeros(0)),
+                         lb=kw.get("lower_bounds", np.zeros(0)), ub=kw.get("upper_bounds", np.zeros(0)), g_draws=g_draws, o_draws=o_draws,
+                         g_acc=g["n_accept"], o_acc=o["n_accept"], kernel=mcmc_amd.last_kernel())
             bad = np.argwhere(~np.isclose(g_draws, o_draws, rtol=0, atol=0, equal_nan=True))
             fields = [k for k in ("n_accept", "n_leap", "eps") if k in o and not np.array_equal(g[k], o[k], equal_nan=True)]
             say("MISMATCH", desc, "first bad index", bad[:1].tolist(), "fields", fields,

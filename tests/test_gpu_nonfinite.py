@@ -258,3 +258,58 @@ def test_device_resident_run_replays_without_a_host_round_trip():
     s = orc.make_settings(seed=2, n_burnin=1, n_keep=3, n_leap=2, step=0.1, W=4)
     o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4), init, s)
     _same(draws.cpu().numpy(), dict(n_accept=info["n_accept"].cpu().numpy().astype(np.uint64)), o_draws, o)
+
+
+# ---- round 6: the gradient of an ISO / DIAG target in the kernels that follow a chain through the non-finite regime themselves (the general variants: bounds, a
+# diagonal or dense precond_mat -- nothing replays their chains).  The reference's target function multiplies element-wise (oracle: orc_target_kernel), so a +-inf
+# coordinate stays in its own dimension; the mat-vec over the expanded diagonal put 0 * inf = NaN into every other one (hmc_dense.hpp: target_times).
+def test_fuzz_case_hmc_diag_target_dense_precond_mat_chain_started_at_inf():
+    """the case tests/fuzz_parity.py 300 8812 found (tests/golden/fuzz_r6_hmc_diag_target_dense_m_d64.npz: its inputs and the oracle's draws): hmc, DIAG target,
+    d = 64, a dense precond_mat, eps = 1e160, one leapfrog; chain 3 starts at inf in one coordinate and ACCEPTS its proposal: +-inf in every dimension, not NaN"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_r6_hmc_diag_target_dense_m_d64.npz"))
+    init, prec, M = z["init"], z["prec"], z["M"]
+    d = init.shape[1]
+    st = mcmc_amd.default_settings(rng_seed_value=int(z["rseed"]), n_burnin_draws=int(z["burn"]), n_keep_draws=int(z["keep"]), n_leap_steps=int(z["L"]),
+                                   step_size=float(z["eps"]), precond_mat=M)
+    g_draws, g = mcmc_amd.sample("hmc", mcmc_amd.TARGET_GAUSS_DIAG, init, st, prec=prec, chain0=int(z["chain0"]))
+    assert mcmc_amd.last_kernel().startswith("hmc_gauss_mfma_kernel<4, 4, true, true")
+    s = orc.make_settings(seed=int(z["rseed"]), n_burnin=int(z["burn"]), n_keep=int(z["keep"]), n_leap=int(z["L"]), step=float(z["eps"]), W=4, hoist=1, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_HMC, orc.TargetSpec(orc.TARGET_DIAG, d, prec=prec, W=4), init, s, chain0=int(z["chain0"]))
+    assert np.array_equal(o_draws, z["o_draws"], equal_nan=True) and np.array_equal(o["n_accept"], z["o_acc"])       # (the fixture is the oracle's)
+    assert np.isinf(o_draws[0, :, 3]).sum() >= d - 1
+    assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
+
+
+@pytest.mark.parametrize("algo", ["hmc", "nuts"])
+@pytest.mark.parametrize("tgt", ["diag", "iso"])
+@pytest.mark.parametrize("gen", ["dense_m", "diag_m", "bounds"])
+@pytest.mark.parametrize("d", [64, 37])
+def test_separable_targets_on_the_general_variants_keep_an_infinite_coordinate_in_its_dimension(algo, tgt, gen, d):
+    C = 24
+    rng = np.random.default_rng(d * 7 + len(gen))
+    prec, kg, ko = (synth.ill_conditioned_diag(d, 20.0), mcmc_amd.TARGET_GAUSS_DIAG, orc.TARGET_DIAG) if tgt == "diag" else (None, mcmc_amd.TARGET_GAUSS_ISO, orc.TARGET_ISO)
+    kw, okw = {}, {}
+    if gen == "bounds":
+        kind = rng.integers(1, 5, d)
+        lb = np.where((kind == 2) | (kind == 4), -1.5, -np.inf); ub = np.where((kind == 3) | (kind == 4), 2.0, np.inf)
+        kw.update(vals_bound=1, lower_bounds=lb, upper_bounds=ub); okw.update(lower=lb, upper=ub)
+    else:
+        M = np.diag(rng.uniform(0.3, 3.0, d))
+        if gen == "dense_m": A = rng.standard_normal((d, d)) / np.sqrt(d); M = A @ A.T + M
+        kw.update(precond_mat=M); okw.update(precond=M)
+    init = synth.initial_states(C, d, seed=d) * 0.3
+    for c in range(0, C, 2):                                   # every other chain starts with one infinite coordinate (unbounded dimensions only)
+        free = np.arange(d) if gen != "bounds" else np.flatnonzero(~np.isfinite(lb) & ~np.isfinite(ub))
+        init[c, int(rng.choice(free))] = np.inf if c % 4 == 0 else -np.inf
+    n_bad = 0
+    for eps in (1.0e160, 0.5):
+        st = mcmc_amd.default_settings(rng_seed_value=d + 3, n_burnin_draws=0, n_keep_draws=2, n_leap_steps=1, step_size=eps, n_adapt_draws=0, max_tree_depth=2, **kw)
+        s = orc.make_settings(seed=d + 3, n_burnin=0, n_keep=2, n_leap=1, step=eps, n_adapt=0, max_depth=2, W=4, hoist=1, **okw)
+        g_draws, g = mcmc_amd.sample(algo, kg, init, st, prec=prec, chain0=5)
+        o_draws, o = orc.run_many(orc.ALGO_HMC if algo == "hmc" else orc.ALGO_NUTS, orc.TargetSpec(ko, d, prec=prec, W=4), init, s, chain0=5)
+        assert np.array_equal(g_draws, o_draws, equal_nan=True), mcmc_amd.last_kernel()
+        assert np.array_equal(g["n_accept"], o["n_accept"])
+        if algo == "nuts": assert np.array_equal(g["n_leap"], o["n_leap"])
+        n_bad += int((~np.isfinite(o_draws)).any(axis=(0, 1)).sum())
+    assert n_bad > 0
