@@ -32,6 +32,7 @@
 #include "hmc_diag.hpp"
 #include "logistic_launch.hpp"
 #include "launchers.hpp"
+#include "gemm_samplers.hpp"
 #include "small_samplers.hpp"
 #include "literal_host.hpp"
 #include "tile_samplers.hpp"
@@ -972,6 +973,80 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
     return MI_OK;
 }
 
+// hmc / mala / rwmh on a dense Gaussian BEYOND d = 512 (identity preconditioner / cov_mat, no bounds): the state of a 16-chain tile no longer fits a
+// workgroup, so it lives in HBM and the gradients of ALL chains at one leapfrog step are one fp64 matrix product W = P Theta with the half-kicks and the
+// drift in its epilogue (gemm_samplers.hip); chains that reach the non-finite regime are flagged and replayed by literal.hpp right behind it.
+// algo: the C ABI's numbers (0 hmc, 1 mala, 3 rwmh).
+bool dense_gemm_case(const mi_target* target, const mi_settings* settings, const mi_chains* chains, bool hmc)
+{
+    return target->kind == MI_TARGET_GAUSS_DENSE && target->d > 512 && !settings->vals_bound && !settings->precond_mat && !chains->mass_diag
+           && target->kernel_hint != MI_KERNEL_LITERAL && (!hmc || settings->n_leap_steps >= 1);
+}
+int run_dense_gemm(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+{
+    int rc;
+    const uint64_t d = target->d, C = chains->n_chains;
+    if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
+    if (d > 0x7fffffffULL) return fail(MI_ERR_BAD_ARG, "%s: d out of range", who);
+    if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
+    if (algo == 0 && settings->n_leap_steps > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "hmc: too many leapfrog steps");
+    DevBuf P_owned;
+    const double* P_dev = nullptr;
+    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+    if (rc) return rc;
+    StagedChains sc;
+    rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    mi::gemm::GemmRun g;
+    g.algo = algo; g.d = (uint32_t)d; g.C = C; g.chain0 = chains->chain0; g.P = P_dev;
+    g.theta = sc.dev.theta; g.draws = sc.dev.draws; g.n_accept = sc.dev.n_accept;
+    g.seed = settings->rng_seed_value;
+    g.n_burnin = (uint32_t)settings->n_burnin_draws; g.n_keep = (uint32_t)settings->n_keep_draws; g.n_leap = (uint32_t)settings->n_leap_steps;
+    g.draw0 = (uint32_t)chains->draw0; g.eps = settings->step_size;
+    if (algo == 1) {                                     // dmvnorm's constants for Sigma = eps^2 I, as the oracle states them (run_dense_lds)
+        const double s2 = settings->step_size * settings->step_size;
+        double log_det = 0.0;
+        const double lii = __builtin_sqrt(s2);
+        for (uint64_t i = 0; i < d; ++i) log_det = log_det + 2.0 * mi::det_log(lii);
+        g.s2 = s2; g.rs = 1.0 / s2; g.log_det = log_det;
+        g.cons_term = -0.5 * (double)d * 1.83787706640934548356;
+    }
+    // a draw is 5 + n_leap launches: replayed from a captured graph while a launch is short (few chains); at full size the queue runs ahead anyway
+    g.use_graph = (double)d * (double)d * (double)C < 3.0e10;
+    const bool replay = algo != 3;                       // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
+    WsLease base;
+    ReplayWs rp = replay_layout(mi::gemm::gemm_ws_bytes((uint32_t)d, C), C, (uint32_t)d, (uint32_t)d, false);
+    rc = ws_get(st, replay ? rp.total_bytes : rp.own_bytes, base);
+    if (rc) return rc;
+    if (replay) {
+        rc = replay_bind(rp, base.p, C, st);
+        if (rc) return rc;
+        g.nf_flag = rp.flag;
+    }
+    g.ws = base.p;
+    const char* kname = nullptr;
+    const int e = mi::gemm::gemm_run(g, st, &kname);
+    if (e != 0) return fail(MI_ERR_HIP, "%s: matrix-product sampler: %s", who, hipGetErrorString((hipError_t)e));
+    if (replay) {                                        // chains that reached the non-finite regime: replayed literally (literal.hpp)
+        mi::lit::LitParams lp{};
+        rc = transpose_on_device(P_dev, rp.tbuf, (uint32_t)d, (uint32_t)d, st);
+        if (rc) return rc;
+        lp.t.kind = mi::lit::LIT_DENSE; lp.t.d = (uint32_t)d; lp.t.prec = rp.tbuf;
+        mi::lit::lit_orders(lp.t);
+        lit_common(lp, settings, &sc.dev, rp, false);
+        lp.rs = g.rs; lp.log_det = g.log_det; lp.cons_term = g.cons_term;
+        rc = launched("matrix-product sampler (literal replay)", mi::launch_literal(algo, lp, rp.n_wg, st));
+        if (rc) return rc;
+    }
+    mi::note_kernel("%s", kname);
+    rc = fill_n_leap(sc.dev.n_leapfrogs, C, algo == 0 ? (settings->n_burnin_draws + settings->n_keep_draws) * settings->n_leap_steps : 0, st);
+    if (rc) return rc;
+    rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
+    if (rc) return rc;
+    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
 // The one-lane-per-chain engine (rmhmc_small.hpp, small_samplers.hpp): hmc, mala, rwmh with any precond_mat / cov_mat and any
 // bounds, nuts, rmhmc, for a target policy of dimension d <= SMALL_MAX_D.  Validates, stages the chains, packs the launch
 // parameters; `launch` instantiates the kernels for its target type (the built-in policies below, or a user's library through
@@ -1409,6 +1484,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !(dense_m && settings->vals_bound) && target->kernel_hint != MI_KERNEL_LITERAL)
         return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat, with or without bounds; a dense one without
+    if (dense_gemm_case(target, settings, chains, true)) return run_dense_gemm("hmc", 0, target, settings, chains, st);      // one matrix product per leapfrog step (gemm_samplers.hip)
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -1894,6 +1970,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound
         && (!settings->precond_mat || precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)))
         return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp); identity, diagonal or (round 5) dense precond_mat
+    if (dense_gemm_case(target, settings, chains, false)) return run_dense_gemm("mala", 1, target, settings, chains, st);    // one matrix product per draw (gemm_samplers.hip)
     if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
@@ -2022,6 +2099,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
         return run_dense_lds("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
+    if (dense_gemm_case(target, settings, chains, false)) return run_dense_gemm("rwmh", 3, target, settings, chains, st);
     if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
