@@ -36,6 +36,7 @@
 #include "det_math.hpp"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace mi {
 namespace gemm {
@@ -47,18 +48,23 @@ constexpr int LDS_STRIDE = 144;                      // doubles per staged row: 
 constexpr int STAGE = 2 * TK * LDS_STRIDE;           // doubles per stage: 16 rows of the A tile, 16 rows of the B tile
 constexpr size_t GEMM_LDS_BYTES = (size_t)2 * STAGE * sizeof(double);
 
+enum : int { TGT_DENSE = 0, TGT_LOGISTIC = 1 };
+
+// One product D = A B over K: A^T as [Kp][ldA] (k-major: a row holds the 128 output rows of a tile contiguously), B as [Kp][Cp]
 struct StepParams {
-    const double* Pt;        // [dK][dM]: Pt[k dM + i] = P[i][k], zero padded
-    const double* th_in;     // [dK][Cp]
-    double* th_out;          // MODE 0
-    double* pm;              // MODE 0 / 1
-    double* w_out;           // MODE 1 / 2
-    uint32_t dK, dM, n_ntiles;
+    const double* At;        // dense: P^T; logistic: X^T (MODE 3, eta = X Theta) or X itself (X^T r: K runs over the data rows)
+    const double* Bm;        // dense: the positions; logistic: the positions (MODE 3) or the row terms y - sigmoid(eta)
+    uint32_t Kp, ldA, M_store, n_ntiles;      // K extent (multiple of 16), padded output rows (multiple of 128), output rows that exist in memory
     uint64_t Cp;
     double eps;
+    const double* pos;       // MODE 0..2: the positions the gradient is taken at (the logistic gradient subtracts them; MODE 0 drifts them)
+    double* pos_out;         // MODE 0
+    double* pm;              // MODE 0 / 1
+    double* g_out;           // MODE 1 / 2: grad log K
+    double* term_out;        // MODE 3: eta = X Theta [rows padded to 16][Cp] (gemm_rowterm_kernel turns it into the row terms)
 };
 
-template <int MODE>
+template <int MODE, int TGT>
 __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const StepParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -66,20 +72,20 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane >> 4, c16 = lane & 15;
     // consecutive workgroup ids go round the 8 XCDs: XCD x takes chain tiles x, x + 8, ... and runs their row tiles back to back
-    const uint32_t MT = prm.dM / TM;
+    const uint32_t MT = prm.ldA / TM;
     const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
     const uint32_t nt = xcd + 8u * (q / MT), mt = q % MT;
     if (nt >= prm.n_ntiles) return;
     const size_t m0 = (size_t)mt * TM, n0 = (size_t)nt * TN;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)lds;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    // wave w moves rows w, w + 4, ... of the 32 staged rows (0..15: P^T rows k, columns m0..; 16..31: Theta rows k, chains n0..), 1 KiB each
+    // wave w moves rows w, w + 4, ... of the 32 staged rows (0..15: A^T rows k, columns m0..; 16..31: B rows k, chains n0..), 1 KiB each
     auto issue = [&](uint32_t kb, int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = wave + 4 * i;
             const int rr = r & 15;
-            const double* src = (i >= 4) ? prm.th_in + ((size_t)(kb * TK + rr) * prm.Cp + n0) : prm.Pt + ((size_t)(kb * TK + rr) * prm.dM + m0);
+            const double* src = (i >= 4) ? prm.Bm + ((size_t)(kb * TK + rr) * prm.Cp + n0) : prm.At + ((size_t)(kb * TK + rr) * prm.ldA + m0);
             const uint32_t dst = lds_base + (uint32_t)((stage * STAGE + r * LDS_STRIDE) * 8);
             uint32_t m0_saved;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
@@ -92,7 +98,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
     const int wm = wave >> 1, wn = wave & 1;             // the wave's 64 x 64 quarter of the tile
-    const uint32_t nkb = prm.dK / TK;
+    const uint32_t nkb = prm.Kp / TK;
     issue(0, 0);
 #pragma unroll 1
     for (uint32_t kb = 0; kb < nkb; ++kb) {
@@ -113,28 +119,34 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
                 for (int ni = 0; ni < 4; ++ni) acc[ti][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[ni], acc[ti][ni], 0, 0, 0);
         }
     }
-    // epilogue: acc[ti][ni][r] is W at dimension m0 + 64 wm + 16 ti + 4 r + j, chain n0 + 64 wn + 16 ni + c16
+    // epilogue: acc[ti][ni][r] is D at row m0 + 64 wm + 16 ti + 4 r + j, chain n0 + 64 wn + 16 ni + c16
     const double eps = prm.eps;
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t row = m0 + (size_t)(64 * wm + 16 * ti + 4 * r + j);
-            if (row < prm.dK) {
+            if (row < prm.M_store) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const size_t idx = row * prm.Cp + n0 + (size_t)(64 * wn + 16 * ni + c16);
-                    const double w = acc[ti][ni][r];
-                    if constexpr (MODE == 2) prm.w_out[idx] = w;
-                    else {
-                        const double g = -w;                                   // grad log K = -(P theta)
-                        double p = prm.pm[idx];
-                        p = p + (eps * g) / 2.0;                               // second half-step of this leapfrog step (hmc.cpp:175)
-                        if constexpr (MODE == 1) { prm.pm[idx] = p; prm.w_out[idx] = w; }
+                    const double v = acc[ti][ni][r];
+                    if constexpr (MODE == 3) {                                 // eta = X Theta as it is: gemm_rowterm_kernel makes the row terms of it, at full occupancy
+                        prm.term_out[idx] = v;
+                    } else {
+                        double g;
+                        if constexpr (TGT == TGT_DENSE) g = -v;                // grad log K = -(P theta)
+                        else g = v - prm.pos[idx];                             // X^T (y - sigmoid(eta)) - beta
+                        if constexpr (MODE == 2) prm.g_out[idx] = g;
                         else {
-                            p = p + (eps * g) / 2.0;                           // first half-step of the next one (:126): same position, same gradient
-                            prm.pm[idx] = p;
-                            prm.th_out[idx] = prm.th_in[idx] + eps * p;        // :171
+                            double p = prm.pm[idx];
+                            p = p + (eps * g) / 2.0;                           // second half-step of this leapfrog step (hmc.cpp:175)
+                            if constexpr (MODE == 1) { prm.pm[idx] = p; prm.g_out[idx] = g; }
+                            else {
+                                p = p + (eps * g) / 2.0;                       // first half-step of the next one (:126): same position, same gradient
+                                prm.pm[idx] = p;
+                                prm.pos_out[idx] = prm.pos[idx] + eps * p;     // :171
+                            }
                         }
                     }
                 }
@@ -142,25 +154,43 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
         }
 }
 
-// P (d x d row-major) -> Pt[k dM + i] = P[i][k], zeros outside
-__global__ void gemm_pack_kernel(const double* __restrict__ P, uint32_t d, uint32_t dK, uint32_t dM, double* __restrict__ Pt)
+// M (rows x cols row-major) -> out[k ld + i] = TRANSPOSE ? M[i][k] : M[k][i] for k < Kp, i < ld, zeros outside the matrix
+template <bool TRANSPOSE>
+__global__ void gemm_pack_kernel(const double* __restrict__ M, uint32_t rows, uint32_t cols, uint32_t Kp, uint32_t ld, double* __restrict__ out)
 {
-    const size_t n = (size_t)dK * dM;
+    const size_t n = (size_t)Kp * ld;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t k = (uint32_t)(e / dM), i = (uint32_t)(e % dM);
-        Pt[e] = (k < d && i < d) ? P[(size_t)i * d + k] : 0.0;
+        const uint32_t k = (uint32_t)(e / ld), i = (uint32_t)(e % ld);
+        if (TRANSPOSE) out[e] = (i < rows && k < cols) ? M[(size_t)i * cols + k] : 0.0;
+        else out[e] = (k < rows && i < cols) ? M[(size_t)k * cols + i] : 0.0;
+    }
+}
+
+// the row terms of the logistic target (the oracle's ORC_TARGET_LOGISTIC; softplus / sigmoid of det_math.hpp), in place over eta [nK][Cp]:
+// res = y - sigmoid(eta) (what X^T multiplies), term = y eta - log(1 + e^eta) (what the log-likelihood sums); zeros in the padding rows
+__global__ __launch_bounds__(256) void gemm_rowterm_kernel(const double* __restrict__ y, uint32_t n_rows, uint32_t nK, uint64_t Cp, double* __restrict__ res, double* __restrict__ term)
+{
+    const size_t n = (size_t)nK * Cp;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(e / Cp);
+        const bool valid = row < n_rows;
+        const double yv = valid ? y[row] : 0.0;
+        const double eta = valid ? term[e] : 0.0;
+        res[e] = valid ? (yv - sigmoid(eta)) : 0.0;
+        term[e] = valid ? (yv * eta - softplus(eta)) : 0.0;
     }
 }
 
 struct DrawParams {
-    int algo;
-    uint32_t d, dK;
+    int algo, tgt;
+    uint32_t d, dK, nK;      // nK: the data rows padded to 16 (logistic)
     uint64_t C, Cp, chain0;
     double* th;              // [dK][Cp] accepted position
-    double* wacc;            // P th at the accepted position
+    double* gacc;            // grad log K at the accepted position
     double* thw;             // the proposal (hmc: the leapfrog's end point)
-    double* wprop;           // P thw
+    double* gprop;           // grad log K there
     double* pm;              // hmc: momentum
+    const double* term;      // logistic: [nK][Cp] y eta - log(1 + e^eta) of the LAST evaluation
     double* prevE;           // [Cp] hmc: prev_U; mala / rwmh: prev_LP
     double* kprev;           // [Cp] hmc: prev_K of the running draw
     uint64_t* nacc;          // [Cp]
@@ -201,21 +231,43 @@ __global__ __launch_bounds__(256) void gemm_normals_kernel(const DrawParams prm)
     const size_t ia = (size_t)da * prm.Cp + c, ib = (size_t)db * prm.Cp + c;
     if (prm.algo == GEMM_HMC) { prm.pm[ia] = z0; prm.pm[ib] = z1; }
     else if (prm.algo == GEMM_MALA) {
-        prm.thw[ia] = (prm.th[ia] + (prm.s2 * -prm.wacc[ia]) / 2.0) + prm.eps * z0;
-        prm.thw[ib] = (prm.th[ib] + (prm.s2 * -prm.wacc[ib]) / 2.0) + prm.eps * z1;
+        prm.thw[ia] = (prm.th[ia] + (prm.s2 * prm.gacc[ia]) / 2.0) + prm.eps * z0;
+        prm.thw[ib] = (prm.th[ib] + (prm.s2 * prm.gacc[ib]) / 2.0) + prm.eps * z1;
     } else {
         prm.thw[ia] = prm.th[ia] + prm.eps * z0;
         prm.thw[ib] = prm.th[ib] + prm.eps * z1;
     }
 }
 
-// One thread per (chain, dimension class j = dim mod 4): the engine's dot products are four strided fma chains, combined (q0 + q2) + (q1 + q3); a wave
+// One thread per (chain, class j = index mod 4): the engine's dot products and row sums are four strided chains, combined (q0 + q2) + (q1 + q3); a wave
 // holds 16 chains x 4 classes (the MFMA B layout: its loads are the epilogue's 128-byte segments).
 __device__ __forceinline__ double class_sum(double q)
 {
     q = q + __shfl_xor(q, 32);
     q = q + __shfl_xor(q, 16);
     return q;
+}
+// log K at x, given what the evaluation left in memory.  dense: -1/2 x . (P x) with P x = -g; logistic: sum_r [y_r eta_r - log(1 + e^eta_r)] - 1/2 |x|^2
+// (the oracle's ORC_TARGET_LOGISTIC: orc_sum over the rows, orc_dot over the dimensions, both four-strided)
+template <int TGT>
+__device__ __forceinline__ double log_kernel_value(const DrawParams& prm, const double* x, const double* g, uint64_t c, int j)
+{
+    double q = 0.0;
+#pragma unroll 4
+    for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
+        const size_t e = (size_t)i * prm.Cp + c;
+        const double xv = x[e];
+        if constexpr (TGT == TGT_DENSE) q = dfma(xv, -g[e], q); else q = dfma(xv, xv, q);
+    }
+    q = class_sum(q);
+    if constexpr (TGT == TGT_DENSE) return -0.5 * q;
+    else {
+        double ll = 0.0;
+#pragma unroll 4
+        for (uint32_t r = (uint32_t)j; r < prm.nK; r += 4u) ll = ll + prm.term[(size_t)r * prm.Cp + c];
+        ll = class_sum(ll);
+        return ll - 0.5 * q;
+    }
 }
 
 // hmc: prev_K = p.p / 2 (hmc.cpp:160), the first half-step (:126) and the first drift (:171) of the draw; new_draw = prev_draw (:162)
@@ -229,8 +281,7 @@ __global__ __launch_bounds__(256) void gemm_pre_kernel(const DrawParams prm)
         const size_t e = (size_t)i * prm.Cp + c;
         double p = prm.pm[e];
         q = dfma(p, p, q);
-        const double g = -prm.wacc[e];
-        p = p + (prm.eps * g) / 2.0;
+        p = p + (prm.eps * prm.gacc[e]) / 2.0;
         prm.pm[e] = p;
         prm.thw[e] = prm.th[e] + prm.eps * p;
     }
@@ -238,49 +289,42 @@ __global__ __launch_bounds__(256) void gemm_pre_kernel(const DrawParams prm)
     if (j == 0) prm.kprev[c] = q / 2.0;
 }
 
-// the value at the initial state (hmc.cpp:140, mala.cpp:138, rwmh.cpp:113): log K = -1/2 theta . (P theta)
+// the value at the initial state (hmc.cpp:140, mala.cpp:138, rwmh.cpp:113)
+template <int TGT>
 __global__ __launch_bounds__(256) void gemm_first_kernel(const DrawParams prm)
 {
     const int lane = threadIdx.x & 63, j = lane >> 4;
     const uint64_t c = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
-    double q = 0.0;
-#pragma unroll 4
-    for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
-        const size_t e = (size_t)i * prm.Cp + c;
-        q = dfma(prm.th[e], prm.wacc[e], q);
-    }
-    q = class_sum(q);
-    const double first_lp = -0.5 * q;
+    const double first_lp = log_kernel_value<TGT>(prm, prm.th, prm.gacc, c, j);
     if (j == 0) { prm.prevE[c] = (prm.algo == GEMM_HMC) ? -first_lp : first_lp; prm.nacc[c] = 0ull; }
 }
 
 // the accept step (hmc.cpp:178-204; mala.cpp:162-184 with mala.ipp:59-64 and dmvnorm.hpp:37-41; rwmh.cpp:128-149), the accepted state and the kept row
-template <int ALGO>
+template <int ALGO, int TGT>
 __global__ __launch_bounds__(256) void gemm_post_kernel(const DrawParams prm)
 {
     const int lane = threadIdx.x & 63, j = lane >> 4;
     const uint64_t c = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane & 15);
     const bool live = c < prm.C;
     const uint32_t draw = *prm.draw_ctr;
-    double qv = 0.0, qk = 0.0, qa = 0.0, qb = 0.0;
+    const double lp = log_kernel_value<TGT>(prm, prm.thw, prm.gprop, c, j);
+    double qk = 0.0, qa = 0.0, qb = 0.0;
+    if constexpr (ALGO != GEMM_RWMH) {
 #pragma unroll 4
-    for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
-        const size_t e = (size_t)i * prm.Cp + c;
-        const double x = prm.thw[e], w = prm.wprop[e];
-        qv = dfma(x, w, qv);
-        if constexpr (ALGO == GEMM_HMC) { const double p = prm.pm[e]; qk = dfma(p, p, qk); }
-        if constexpr (ALGO == GEMM_MALA) {
-            const double be = prm.th[e], gr = -prm.wacc[e], gp = -w;
-            const double mean_prop = x + (prm.s2 * gp) / 2.0;
-            const double xa = be - mean_prop;                      // dmvnorm.hpp:37
-            qa = dfma(xa, prm.rs * xa, qa);
-            const double mean_prev = be + (prm.s2 * gr) / 2.0;
-            const double xb = x - mean_prev;
-            qb = dfma(xb, prm.rs * xb, qb);
+        for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
+            const size_t e = (size_t)i * prm.Cp + c;
+            if constexpr (ALGO == GEMM_HMC) { const double p = prm.pm[e]; qk = dfma(p, p, qk); }
+            else {
+                const double x = prm.thw[e], be = prm.th[e], gr = prm.gacc[e], gp = prm.gprop[e];
+                const double mean_prop = x + (prm.s2 * gp) / 2.0;
+                const double xa = be - mean_prop;                      // dmvnorm.hpp:37
+                qa = dfma(xa, prm.rs * xa, qa);
+                const double mean_prev = be + (prm.s2 * gr) / 2.0;
+                const double xb = x - mean_prev;
+                qb = dfma(xb, prm.rs * xb, qb);
+            }
         }
     }
-    qv = class_sum(qv);
-    const double lp = -0.5 * qv;
     const double prevE = prm.prevE[c];
     const double z = rng_uniform(prm.seed, prm.chain0 + (live ? c : 0), draw + prm.draw0, 0u);
     bool accept, flag = false;
@@ -326,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_post_kernel(const DrawParams prm)
     for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
         const size_t e = (size_t)i * prm.Cp + c;
         double v;
-        if (accept) { v = prm.thw[e]; prm.th[e] = v; prm.wacc[e] = prm.wprop[e]; }
+        if (accept) { v = prm.thw[e]; prm.th[e] = v; prm.gacc[e] = prm.gprop[e]; }
         else v = prm.th[e];
         if (out != nullptr && i < prm.d) out[(size_t)i * prm.C] = v;
     }
@@ -351,75 +395,102 @@ __global__ void gemm_store_kernel(const DrawParams prm)
 static inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
 struct Layout {
-    uint32_t dK, dM;
+    uint32_t dK, dM, nK, nM;
     uint64_t Cp;
-    size_t vec;            // doubles per state array
+    size_t vec, rvec;      // doubles per state array / per row-term array
+    size_t mat;            // doubles of the packed matrices
     size_t n_doubles;
 };
-static Layout layout_of(uint32_t d, uint64_t C)
+static Layout layout_of(uint32_t d, uint32_t n_rows, uint64_t C)
 {
     Layout l;
     l.dK = round_up(d, TK); l.dM = round_up(d, TM);
+    l.nK = n_rows ? round_up(n_rows, TK) : 0; l.nM = n_rows ? round_up(n_rows, TM) : 0;
     l.Cp = (C + TN - 1) / TN * TN;
     l.vec = (size_t)l.dK * l.Cp;
-    // Pt | th, wacc, thw0, thw1, wprop, pm | prevE, kprev, nacc | draw counter
-    l.n_doubles = (size_t)l.dK * l.dM + 6 * l.vec + 3 * l.Cp + 32;
+    l.rvec = (size_t)l.nK * l.Cp;
+    // dense: P^T [dK][dM]; logistic: X^T [dK][nM] and X [nK][dM]
+    l.mat = n_rows ? (size_t)l.dK * l.nM + (size_t)l.nK * l.dM : (size_t)l.dK * l.dM;
+    // matrices | th, gacc, thw0, thw1, gprop, pm | res, term | prevE, kprev, nacc | draw counter
+    l.n_doubles = l.mat + 6 * l.vec + 2 * l.rvec + 3 * l.Cp + 32;
     return l;
 }
-size_t gemm_ws_bytes(uint32_t d, uint64_t C) { return layout_of(d, C).n_doubles * sizeof(double); }
+size_t gemm_ws_bytes(uint32_t d, uint32_t n_rows, uint64_t C) { return layout_of(d, n_rows, C).n_doubles * sizeof(double); }
 
 #define GEMM_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-template <int MODE>
+template <int MODE, int TGT>
 static int step_attr()      // (73 728 bytes of dynamic LDS: above the 64 KiB default)
 {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_step_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_step_kernel<MODE, TGT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
 }
-template <int MODE>
+template <int MODE, int TGT>
 static int launch_step(const StepParams& sp, hipStream_t st)
 {
-    const uint32_t MT = sp.dM / TM;
+    const uint32_t MT = sp.ldA / TM;
     const uint32_t grid = 8u * MT * ((sp.n_ntiles + 7u) / 8u);
-    hipLaunchKernelGGL(gemm_step_kernel<MODE>, dim3(grid), dim3(256), GEMM_LDS_BYTES, st, sp);
+    hipLaunchKernelGGL((gemm_step_kernel<MODE, TGT>), dim3(grid), dim3(256), GEMM_LDS_BYTES, st, sp);
     return (int)hipGetLastError();
 }
 
-int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name)
+template <int TGT>
+static int gemm_run_t(const GemmRun& r, hipStream_t st, const char** kernel_name)
 {
-    const Layout l = layout_of(r.d, r.C);
+    constexpr bool LOGIT = TGT == TGT_LOGISTIC;
+    const Layout l = layout_of(r.d, LOGIT ? r.n_rows : 0u, r.C);
     double* base = static_cast<double*>(r.ws);
-    double* Pt = base;
-    double* th = Pt + (size_t)l.dK * l.dM;
-    double* wacc = th + l.vec;
-    double* thw[2] = {wacc + l.vec, wacc + 2 * l.vec};
-    double* wprop = wacc + 3 * l.vec;
-    double* pm = wacc + 4 * l.vec;
-    double* prevE = pm + l.vec;
+    double* A1 = base;                                        // dense: P^T; logistic: X^T [dK][nM]
+    double* A2 = LOGIT ? A1 + (size_t)l.dK * l.nM : nullptr;  // logistic: X [nK][dM]
+    double* th = base + l.mat;
+    double* gacc = th + l.vec;
+    double* thw[2] = {gacc + l.vec, gacc + 2 * l.vec};
+    double* gprop = gacc + 3 * l.vec;
+    double* pm = gacc + 4 * l.vec;
+    double* res = pm + l.vec;
+    double* term = res + l.rvec;
+    double* prevE = term + l.rvec;
     double* kprev = prevE + l.Cp;
     uint64_t* nacc = reinterpret_cast<uint64_t*>(kprev + l.Cp);
     uint32_t* draw_ctr = reinterpret_cast<uint32_t*>(kprev + 2 * l.Cp);
 
     DrawParams dp{};
-    dp.algo = r.algo; dp.d = r.d; dp.dK = l.dK; dp.C = r.C; dp.Cp = l.Cp; dp.chain0 = r.chain0;
-    dp.th = th; dp.wacc = wacc; dp.thw = thw[0]; dp.wprop = wprop; dp.pm = pm; dp.prevE = prevE; dp.kprev = kprev; dp.nacc = nacc; dp.draw_ctr = draw_ctr;
+    dp.algo = r.algo; dp.tgt = TGT; dp.d = r.d; dp.dK = l.dK; dp.nK = l.nK; dp.C = r.C; dp.Cp = l.Cp; dp.chain0 = r.chain0;
+    dp.th = th; dp.gacc = gacc; dp.thw = thw[0]; dp.gprop = gprop; dp.pm = pm; dp.term = term; dp.prevE = prevE; dp.kprev = kprev; dp.nacc = nacc; dp.draw_ctr = draw_ctr;
     dp.theta_in = r.theta; dp.theta_out = r.theta; dp.draws = r.draws; dp.n_accept = r.n_accept; dp.nf_flag = r.nf_flag;
     dp.seed = r.seed; dp.n_burnin = r.n_burnin; dp.draw0 = r.draw0;
     dp.eps = r.eps; dp.s2 = r.s2; dp.rs = r.rs; dp.log_det = r.log_det; dp.cons_term = r.cons_term;
 
-    StepParams sp{};
-    sp.Pt = Pt; sp.dK = l.dK; sp.dM = l.dM; sp.n_ntiles = (uint32_t)(l.Cp / TN); sp.Cp = l.Cp; sp.eps = r.eps; sp.pm = pm;
-
-    static const int attr_rc = [] { int e = step_attr<0>(); if (!e) e = step_attr<1>(); if (!e) e = step_attr<2>(); return e; }();
+    static const int attr_rc = [] { int e = step_attr<0, TGT>(); if (!e) e = step_attr<1, TGT>(); if (!e) e = step_attr<2, TGT>(); if constexpr (LOGIT) { if (!e) e = step_attr<3, TGT>(); } return e; }();
     if (attr_rc) return attr_rc;
+    const uint32_t n_ntiles = (uint32_t)(l.Cp / TN);
+    // grad log K (and, logistic, the row terms) at `pos`; mode 0: a leapfrog step that is not the last (pos_out: the next position), 1: the last, 2: the gradient alone
+    auto evaluate = [&](const double* pos, int mode, double* pos_out, double* g_out, hipStream_t s) -> int {
+        StepParams sp{};
+        sp.n_ntiles = n_ntiles; sp.Cp = l.Cp; sp.eps = r.eps; sp.pm = pm; sp.pos = pos; sp.pos_out = pos_out; sp.g_out = g_out;
+        if constexpr (LOGIT) {
+            StepParams se = sp;                               // eta = X Theta and the row terms
+            se.At = A1; se.Bm = pos; se.Kp = l.dK; se.ldA = l.nM; se.M_store = l.nK; se.term_out = term;
+            if (int e = launch_step<3, TGT>(se, s)) return e;
+            hipLaunchKernelGGL(gemm_rowterm_kernel, dim3((unsigned)std::min<size_t>((l.rvec + 255) / 256, 1u << 20)), dim3(256), 0, s, r.y, r.n_rows, l.nK, l.Cp, res, term);
+            sp.At = A2; sp.Bm = res; sp.Kp = l.nK; sp.ldA = l.dM; sp.M_store = l.dK;       // X^T (y - sigmoid(eta)), rows ascending
+        } else {
+            sp.At = A1; sp.Bm = pos; sp.Kp = l.dK; sp.ldA = l.dM; sp.M_store = l.dK;
+        }
+        return mode == 0 ? launch_step<0, TGT>(sp, s) : mode == 1 ? launch_step<1, TGT>(sp, s) : launch_step<2, TGT>(sp, s);
+    };
+
     const unsigned ew_grid = (unsigned)std::min<size_t>((l.vec + 255) / 256, 65535);
     const unsigned cls_grid = (unsigned)(l.Cp / 64);                 // 4 waves x 16 chains per workgroup
-    hipLaunchKernelGGL(gemm_pack_kernel, dim3(std::min<unsigned>((unsigned)(((size_t)l.dK * l.dM + 255) / 256), 65535u)), dim3(256), 0, st, r.P, r.d, l.dK, l.dM, Pt);
-    hipLaunchKernelGGL(gemm_load_kernel, dim3(ew_grid), dim3(256), 0, st, dp);
-    {   // the evaluation at the initial values
-        StepParams s0 = sp; s0.th_in = th; s0.w_out = wacc;
-        if (int e = launch_step<2>(s0, st)) return e;
+    auto pack_grid = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)); };
+    if constexpr (LOGIT) {
+        hipLaunchKernelGGL(gemm_pack_kernel<true>, pack_grid((size_t)l.dK * l.nM), dim3(256), 0, st, r.X, r.n_rows, r.d, l.dK, l.nM, A1);
+        hipLaunchKernelGGL(gemm_pack_kernel<false>, pack_grid((size_t)l.nK * l.dM), dim3(256), 0, st, r.X, r.n_rows, r.d, l.nK, l.dM, A2);
+    } else {
+        hipLaunchKernelGGL(gemm_pack_kernel<true>, pack_grid((size_t)l.dK * l.dM), dim3(256), 0, st, r.P, r.d, r.d, l.dK, l.dM, A1);
     }
-    hipLaunchKernelGGL(gemm_first_kernel, dim3(cls_grid), dim3(256), 0, st, dp);
+    hipLaunchKernelGGL(gemm_load_kernel, dim3(ew_grid), dim3(256), 0, st, dp);
+    if (int e = evaluate(th, 2, nullptr, gacc, st)) return e;          // the evaluation at the initial values
+    hipLaunchKernelGGL(gemm_first_kernel<TGT>, dim3(cls_grid), dim3(256), 0, st, dp);
     GEMM_TRY(hipGetLastError());
 
     const uint32_t n_total = r.n_burnin + r.n_keep;
@@ -430,19 +501,14 @@ int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name)
         DrawParams pp = dp;
         if (r.algo == GEMM_HMC) {
             hipLaunchKernelGGL(gemm_pre_kernel, dim3(cls_grid), dim3(256), 0, s, dp);
-            for (uint32_t k = 0; k < L; ++k) {
-                StepParams sk = sp;
-                sk.th_in = thw[k & 1u]; sk.th_out = thw[(k + 1u) & 1u]; sk.w_out = wprop;
-                const int e = (k + 1 < L) ? launch_step<0>(sk, s) : launch_step<1>(sk, s);
-                if (e) return e;
-            }
+            for (uint32_t k = 0; k < L; ++k)
+                if (int e = evaluate(thw[k & 1u], (k + 1 < L) ? 0 : 1, thw[(k + 1u) & 1u], gprop, s)) return e;
             pp.thw = thw[(L - 1u) & 1u];
-            hipLaunchKernelGGL(gemm_post_kernel<GEMM_HMC>, dim3(cls_grid), dim3(256), 0, s, pp);
+            hipLaunchKernelGGL((gemm_post_kernel<GEMM_HMC, TGT>), dim3(cls_grid), dim3(256), 0, s, pp);
         } else {
-            StepParams sk = sp; sk.th_in = thw[0]; sk.w_out = wprop;
-            if (int e = launch_step<2>(sk, s)) return e;
-            if (r.algo == GEMM_MALA) hipLaunchKernelGGL(gemm_post_kernel<GEMM_MALA>, dim3(cls_grid), dim3(256), 0, s, pp);
-            else hipLaunchKernelGGL(gemm_post_kernel<GEMM_RWMH>, dim3(cls_grid), dim3(256), 0, s, pp);
+            if (int e = evaluate(thw[0], 2, nullptr, gprop, s)) return e;
+            if (r.algo == GEMM_MALA) hipLaunchKernelGGL((gemm_post_kernel<GEMM_MALA, TGT>), dim3(cls_grid), dim3(256), 0, s, pp);
+            else hipLaunchKernelGGL((gemm_post_kernel<GEMM_RWMH, TGT>), dim3(cls_grid), dim3(256), 0, s, pp);
         }
         hipLaunchKernelGGL(gemm_advance_kernel, dim3(1), dim3(1), 0, s, draw_ctr);
         return (int)hipGetLastError();
@@ -478,9 +544,18 @@ int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name)
 
     hipLaunchKernelGGL(gemm_store_kernel, dim3((unsigned)std::min<size_t>(((size_t)r.d * r.C + 255) / 256, 65535)), dim3(256), 0, st, dp);
     GEMM_TRY(hipGetLastError());
-    if (kernel_name) *kernel_name = r.algo == GEMM_HMC ? (L > 1 ? "gemm_step_kernel<0> (hmc)" : "gemm_step_kernel<1> (hmc)")
-                                    : r.algo == GEMM_MALA ? "gemm_step_kernel<2> (mala)" : "gemm_step_kernel<2> (rwmh)";
+    if (kernel_name) {
+        static thread_local char name[96];
+        snprintf(name, sizeof(name), "gemm_step_kernel<%d, %d> (%s%s)", r.algo == GEMM_HMC ? (L > 1 ? 0 : 1) : 2, TGT,
+                 r.algo == GEMM_HMC ? "hmc" : r.algo == GEMM_MALA ? "mala" : "rwmh", graphed ? ", graph" : "");
+        *kernel_name = name;
+    }
     return 0;
+}
+
+int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name)
+{
+    return r.X != nullptr ? gemm_run_t<TGT_LOGISTIC>(r, st, kernel_name) : gemm_run_t<TGT_DENSE>(r, st, kernel_name);
 }
 
 }  // namespace gemm

@@ -16,7 +16,10 @@ struct GemmRun {
     int algo = GEMM_HMC;
     uint32_t d = 0;
     uint64_t C = 0, chain0 = 0;
-    const double* P = nullptr;        // d x d row-major precision, device
+    const double* P = nullptr;        // dense Gaussian: d x d row-major precision, device
+    const double* X = nullptr;        // logistic regression (when set): n_rows x d row-major design matrix and the labels, device
+    const double* y = nullptr;
+    uint32_t n_rows = 0;
     double* theta = nullptr;          // [d][C] in: initial values, out: final state (left alone for flagged chains)
     double* draws = nullptr;          // [n_keep][d][C] or nullptr
     uint64_t* n_accept = nullptr;     // [C] or nullptr (left alone for flagged chains)
@@ -25,11 +28,11 @@ struct GemmRun {
     uint32_t n_burnin = 0, n_keep = 0, n_leap = 0, draw0 = 0;
     double eps = 0.0;                 // step_size (hmc, mala) / par_scale (rwmh)
     double s2 = 0.0, rs = 0.0, log_det = 0.0, cons_term = 0.0;     // mala: dmvnorm's constants for Sigma = eps^2 I (mi_mcmc.hip: as the oracle states them)
-    void* ws = nullptr;               // gemm_ws_bytes(d, C) bytes of device memory
+    void* ws = nullptr;               // gemm_ws_bytes(d, n_rows, C) bytes of device memory
     bool use_graph = true;            // replay the launches of one draw from a captured hipGraph (the draw index lives in device memory)
 };
 
-size_t gemm_ws_bytes(uint32_t d, uint64_t C);
+size_t gemm_ws_bytes(uint32_t d, uint32_t n_rows, uint64_t C);      // n_rows = 0: the dense Gaussian
 // enqueues the whole run on `st`; returns a hipError_t as int (0 = enqueued).  *kernel_name: what ran, for mi_mcmc_last_kernel()
 int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name);
 

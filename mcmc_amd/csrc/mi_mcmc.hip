@@ -973,32 +973,44 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
     return MI_OK;
 }
 
-// hmc / mala / rwmh on a dense Gaussian BEYOND d = 512 (identity preconditioner / cov_mat, no bounds): the state of a 16-chain tile no longer fits a
-// workgroup, so it lives in HBM and the gradients of ALL chains at one leapfrog step are one fp64 matrix product W = P Theta with the half-kicks and the
-// drift in its epilogue (gemm_samplers.hip); chains that reach the non-finite regime are flagged and replayed by literal.hpp right behind it.
-// algo: the C ABI's numbers (0 hmc, 1 mala, 3 rwmh).
-bool dense_gemm_case(const mi_target* target, const mi_settings* settings, const mi_chains* chains, bool hmc)
+// hmc / mala / rwmh on a dense Gaussian or the logistic-regression target BEYOND d = 512 (identity preconditioner / cov_mat, no bounds): the state of a
+// 16-chain tile no longer fits a workgroup, so it lives in HBM and the gradients of ALL chains at one leapfrog step are fp64 matrix products on the matrix
+// cores -- W = P Theta, resp. eta = X Theta and X^T (y - sigmoid(eta)) -- with the half-kicks and the drift in the epilogue (gemm_samplers.hip); chains that
+// reach the non-finite regime are flagged and replayed by literal.hpp right behind it.  algo: the C ABI's numbers (0 hmc, 1 mala, 3 rwmh).
+bool gemm_case(const mi_target* target, const mi_settings* settings, const mi_chains* chains, bool hmc)
 {
-    return target->kind == MI_TARGET_GAUSS_DENSE && target->d > 512 && !settings->vals_bound && !settings->precond_mat && !chains->mass_diag
-           && target->kernel_hint != MI_KERNEL_LITERAL && (!hmc || settings->n_leap_steps >= 1);
+    return (target->kind == MI_TARGET_GAUSS_DENSE || target->kind == MI_TARGET_LOGISTIC) && target->d > 512 && !settings->vals_bound && !settings->precond_mat
+           && !chains->mass_diag && target->kernel_hint != MI_KERNEL_LITERAL && (!hmc || settings->n_leap_steps >= 1);
 }
-int run_dense_gemm(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
+int run_gemm(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
 {
     int rc;
     const uint64_t d = target->d, C = chains->n_chains;
-    if (!target->prec) return fail(MI_ERR_BAD_ARG, "GAUSS_DENSE needs prec (d*d)");
-    if (d > 0x7fffffffULL) return fail(MI_ERR_BAD_ARG, "%s: d out of range", who);
+    const bool logit = target->kind == MI_TARGET_LOGISTIC;
+    const uint64_t n = logit ? target->n_rows : 0;
+    if (d > 0x7fffffffULL || n > 0x7fffffffULL) return fail(MI_ERR_BAD_ARG, "%s: d / n_rows out of range", who);
     if (settings->n_burnin_draws + settings->n_keep_draws > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "too many draws");
     if (algo == 0 && settings->n_leap_steps > 0xffffffffULL) return fail(MI_ERR_BAD_ARG, "hmc: too many leapfrog steps");
-    DevBuf P_owned;
-    const double* P_dev = nullptr;
-    rc = dense_precision_on_device(target, P_owned, &P_dev, st);
-    if (rc) return rc;
+    DevBuf P_owned, Xo, yo;
+    const double *P_dev = nullptr, *X_dev = nullptr, *y_dev = nullptr;
+    if (logit) {
+        if (!target->X || !target->y || n == 0) return fail(MI_ERR_BAD_ARG, "LOGISTIC needs X, y, n_rows");
+        X_dev = target->X; y_dev = target->y;
+        if (target->mem == MI_MEM_HOST) {
+            HIP_TRY(Xo.alloc(n * d * sizeof(double))); HIP_TRY(yo.alloc(n * sizeof(double)));
+            HIP_TRY(hipMemcpy(Xo.p, target->X, n * d * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(yo.p, target->y, n * sizeof(double), hipMemcpyHostToDevice));
+            X_dev = Xo.as<double>(); y_dev = yo.as<double>();
+        }
+    } else {
+        rc = dense_precision_on_device(target, P_owned, &P_dev, st);
+        if (rc) return rc;
+    }
     StagedChains sc;
     rc = stage_in(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
     mi::gemm::GemmRun g;
-    g.algo = algo; g.d = (uint32_t)d; g.C = C; g.chain0 = chains->chain0; g.P = P_dev;
+    g.algo = algo; g.d = (uint32_t)d; g.C = C; g.chain0 = chains->chain0; g.P = P_dev; g.X = X_dev; g.y = y_dev; g.n_rows = (uint32_t)n;
     g.theta = sc.dev.theta; g.draws = sc.dev.draws; g.n_accept = sc.dev.n_accept;
     g.seed = settings->rng_seed_value;
     g.n_burnin = (uint32_t)settings->n_burnin_draws; g.n_keep = (uint32_t)settings->n_keep_draws; g.n_leap = (uint32_t)settings->n_leap_steps;
@@ -1011,11 +1023,11 @@ int run_dense_gemm(const char* who, int algo, const mi_target* target, const mi_
         g.s2 = s2; g.rs = 1.0 / s2; g.log_det = log_det;
         g.cons_term = -0.5 * (double)d * 1.83787706640934548356;
     }
-    // a draw is 5 + n_leap launches: replayed from a captured graph while a launch is short (few chains); at full size the queue runs ahead anyway
-    g.use_graph = (double)d * (double)d * (double)C < 3.0e10;
+    // a draw is a handful of launches + one or two per gradient: replayed from a captured graph while a launch is short (few chains); at full size the queue runs ahead anyway
+    g.use_graph = (double)d * (double)(logit ? 2 * n : d) * (double)C < 3.0e10;
     const bool replay = algo != 3;                       // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
     WsLease base;
-    ReplayWs rp = replay_layout(mi::gemm::gemm_ws_bytes((uint32_t)d, C), C, (uint32_t)d, (uint32_t)d, false);
+    ReplayWs rp = replay_layout(mi::gemm::gemm_ws_bytes((uint32_t)d, (uint32_t)n, C), C, (uint32_t)d, (uint32_t)(logit ? n : d), false);
     rc = ws_get(st, replay ? rp.total_bytes : rp.own_bytes, base);
     if (rc) return rc;
     if (replay) {
@@ -1029,9 +1041,10 @@ int run_dense_gemm(const char* who, int algo, const mi_target* target, const mi_
     if (e != 0) return fail(MI_ERR_HIP, "%s: matrix-product sampler: %s", who, hipGetErrorString((hipError_t)e));
     if (replay) {                                        // chains that reached the non-finite regime: replayed literally (literal.hpp)
         mi::lit::LitParams lp{};
-        rc = transpose_on_device(P_dev, rp.tbuf, (uint32_t)d, (uint32_t)d, st);
+        rc = transpose_on_device(logit ? X_dev : P_dev, rp.tbuf, (uint32_t)(logit ? n : d), (uint32_t)d, st);     // (literal.hpp reads the matrix transposed)
         if (rc) return rc;
-        lp.t.kind = mi::lit::LIT_DENSE; lp.t.d = (uint32_t)d; lp.t.prec = rp.tbuf;
+        if (logit) { lp.t.kind = mi::lit::LIT_LOGISTIC; lp.t.d = (uint32_t)d; lp.t.n_rows = (uint32_t)n; lp.t.X = X_dev; lp.t.y = y_dev; lp.t.Xt = rp.tbuf; }
+        else { lp.t.kind = mi::lit::LIT_DENSE; lp.t.d = (uint32_t)d; lp.t.prec = rp.tbuf; }
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, &sc.dev, rp, false);
         lp.rs = g.rs; lp.log_det = g.log_det; lp.cons_term = g.cons_term;
@@ -1043,7 +1056,7 @@ int run_dense_gemm(const char* who, int algo, const mi_target* target, const mi_
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (P_owned.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    if (P_owned.p || Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
     return MI_OK;
 }
 
@@ -1452,6 +1465,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
         }
     }
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("hmc", 0, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, true)) return run_gemm("hmc", 0, target, settings, chains, st);   // d > 512, plain: two matrix products per leapfrog step
     if (target->kind == MI_TARGET_LOGISTIC) {      // plain: the LDS-staged MFMA kernel (d <= 512); bounds / precond_mat: one chain per lane (d <= 8); else literal.hpp
         // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation: two tables read from global memory)
         // ... and so do bounds (its BOUNDS instantiation, lds_box.hpp), with the identity or a diagonal matrix
@@ -1484,7 +1498,7 @@ int mi_mcmc_hmc_run(const mi_target* target, const mi_settings* settings, mi_cha
     // everything else there -- dense gradients, bounds, a dense precond_mat -- runs on the literal kernel (literal.hpp)
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !(dense_m && settings->vals_bound) && target->kernel_hint != MI_KERNEL_LITERAL)
         return run_dense_lds("hmc", mi::LOGIT_HMC, target, settings, chains, st);      // P streamed through LDS (logistic_lds.hpp); identity or diagonal precond_mat, with or without bounds; a dense one without
-    if (dense_gemm_case(target, settings, chains, true)) return run_dense_gemm("hmc", 0, target, settings, chains, st);      // one matrix product per leapfrog step (gemm_samplers.hip)
+    if (gemm_case(target, settings, chains, true)) return run_gemm("hmc", 0, target, settings, chains, st);      // one matrix product per leapfrog step (gemm_samplers.hip)
     if (d > 128 && (target->kind == MI_TARGET_GAUSS_DENSE || settings->vals_bound || dense_m))
         return run_literal("hmc", 0, target, settings, chains, st);
     const bool bounded = settings->vals_bound != 0 || settings->precond_mat != nullptr;   // the general kernel variant
@@ -1918,6 +1932,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     const bool mala_diag_alone = !settings->vals_bound && (precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat) && !mala_diag_alone)
         return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("mala", 1, target, settings, chains, st) : run_literal("mala", 1, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false)) return run_gemm("mala", 1, target, settings, chains, st);    // d > 512, plain
     if (target->kind == MI_TARGET_LOGISTIC && d > 512) return run_literal("mala", 1, target, settings, chains, st);
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
@@ -1970,7 +1985,7 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound
         && (!settings->precond_mat || precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)))
         return run_dense_lds("mala", mi::LOGIT_MALA, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp); identity, diagonal or (round 5) dense precond_mat
-    if (dense_gemm_case(target, settings, chains, false)) return run_dense_gemm("mala", 1, target, settings, chains, st);    // one matrix product per draw (gemm_samplers.hip)
+    if (gemm_case(target, settings, chains, false)) return run_gemm("mala", 1, target, settings, chains, st);    // one matrix product per draw (gemm_samplers.hip)
     if (d > 128) return run_literal("mala", 1, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;
@@ -2090,6 +2105,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
+    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false)) return run_gemm("rwmh", 3, target, settings, chains, st);    // d > 512, plain
     if (target->kind == MI_TARGET_LOGISTIC) {
         if (settings->vals_bound || settings->precond_mat)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("rwmh", 3, target, settings, chains, st) : run_literal("rwmh", 3, target, settings, chains, st);
@@ -2099,7 +2115,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
         return run_dense_lds("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
-    if (dense_gemm_case(target, settings, chains, false)) return run_dense_gemm("rwmh", 3, target, settings, chains, st);
+    if (gemm_case(target, settings, chains, false)) return run_gemm("rwmh", 3, target, settings, chains, st);
     if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;

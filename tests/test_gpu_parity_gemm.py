@@ -101,3 +101,59 @@ def test_matrix_product_hmc_recovers_the_covariance():
     v = g_draws[0].var(axis=1)
     assert np.all(np.abs(v / np.diag(cov) - 1.0) < 0.15)
     assert g["n_accept"].mean() > 0.5
+
+
+# ---- the logistic-regression target beyond d = 512: eta = X Theta and X^T (y - sigmoid(eta)) as two matrix products per gradient, the row terms in between
+# element-wise (gemm_rowterm_kernel); the oracle's plain orders (one eta chain per row, rows ascending in the gradient, four-strided sums)
+def _logit_oracle(algo, d, X, y, init, seed, burn, keep, L, eps, chain0=0):
+    s = orc.make_settings(seed=seed, n_burnin=burn, n_keep=keep, n_leap=L, step=eps, W=4, hoist=1)
+    return orc.run_many(ALGO[algo], orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4), init, s, chain0=chain0)
+
+
+LEPS = {"hmc": 0.02, "mala": 0.03, "rwmh": 0.01}
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala", "rwmh"])
+@pytest.mark.parametrize("d,N,C,L", [(513, 40, 45, 3), (640, 300, 130, 1), (1030, 129, 20, 2)])
+def test_logistic_beyond_d512_equals_the_oracle(algo, d, N, C, L):
+    X, y = synth.logistic_problem(d, N, seed=5)
+    init = synth.initial_states(C, d, seed=8) * 0.1
+    st = _settings(algo, 12, 2, 4, L, LEPS[algo])
+    g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=5)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("gemm_step_kernel<") and ", 1>" in kern, kern
+    o_draws, o = _logit_oracle(algo, d, X, y, init, 12, 2, 4, L, LEPS[algo], chain0=5)
+    assert 0 < o["n_accept"].sum()
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws)
+    assert np.array_equal(g["theta"], o_draws[-1])
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+def test_logistic_beyond_d512_in_the_non_finite_regime(algo):
+    d, N, C = 600, 64, 40
+    X, y = synth.logistic_problem(d, N, seed=3)
+    init = synth.initial_states(C, d, seed=d) * 0.1
+    init[3] *= 1e200; init[7, 5] = np.inf; init[20, d - 1] = np.nan; init[33] *= 1e160
+    for eps in (LEPS[algo], 1e6):
+        st = _settings(algo, 5, 2, 3, 3, eps)
+        g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+        assert mcmc_amd.last_kernel().startswith("gemm_step_kernel<")
+        o_draws, o = _logit_oracle(algo, d, X, y, init, 5, 2, 3, 3, eps)
+        assert np.array_equal(g["n_accept"], o["n_accept"]), eps
+        assert np.array_equal(g_draws, o_draws, equal_nan=True), eps
+        assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True), eps
+
+
+@pytest.mark.parametrize("algo", ["hmc", "mala", "rwmh"])
+def test_logistic_beyond_d512_equals_the_literal_kernel_on_more_chains(algo):
+    d, N, C = 700, 200, 300
+    X, y = synth.logistic_problem(d, N, seed=9)
+    init = synth.initial_states(C, d, seed=9) * 0.1
+    st = _settings(algo, 21, 4, 8, 4, LEPS[algo])
+    g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=1000)
+    assert mcmc_amd.last_kernel().startswith("gemm_step_kernel<")
+    l_draws, l = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y, chain0=1000, kernel_hint=mcmc_amd.KERNEL_LITERAL)
+    assert mcmc_amd.last_kernel().startswith("literal_kernel<")
+    assert 0 < l["n_accept"].sum() <= 8 * C
+    assert np.array_equal(g["n_accept"], l["n_accept"]) and np.array_equal(g_draws, l_draws) and np.array_equal(g["theta"], l["theta"])
