@@ -43,6 +43,10 @@ namespace gemm {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+#ifndef MI_GEMM_ABLATE
+#define MI_GEMM_ABLATE 0          // timing experiments only (results meaningless): 1 no epilogue memory traffic, 2 no tile loads, 4 no barriers
+#endif
+
 constexpr int TM = 128, TN = 128, TK = 16;
 constexpr int LDS_STRIDE = 144;                      // doubles per staged row: 128 + 16 (k rows j and j + 1 of a fragment read sit 32 banks apart)
 constexpr int STAGE = 2 * TK * LDS_STRIDE;           // doubles per stage: 16 rows of the A tile, 16 rows of the B tile
@@ -104,8 +108,8 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
     for (uint32_t kb = 0; kb < nkb; ++kb) {
         const int stage = (int)(kb & 1u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of step kb landed ...
-        __syncthreads();                                      // ... everybody's, and nobody still reads the other stage
-        if (kb + 1 < nkb) issue(kb + 1, stage ^ 1);
+        if (!(MI_GEMM_ABLATE & 4)) __syncthreads();           // ... everybody's, and nobody still reads the other stage
+        if (kb + 1 < nkb && !(MI_GEMM_ABLATE & 2)) issue(kb + 1, stage ^ 1);
         const double* As = lds + stage * STAGE + j * LDS_STRIDE + wm * 64 + c16;
         const double* Bs = lds + stage * STAGE + (TK + j) * LDS_STRIDE + wn * 64 + c16;
 #pragma unroll
@@ -119,39 +123,58 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
                 for (int ni = 0; ni < 4; ++ni) acc[ti][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[ni], acc[ti][ni], 0, 0, 0);
         }
     }
-    // epilogue: acc[ti][ni][r] is D at row m0 + 64 wm + 16 ti + 4 r + j, chain n0 + 64 wn + 16 ni + c16
+    // epilogue: acc[ti][ni][r] is D at row m0 + 64 wm + 16 ti + 4 r + j, chain n0 + 64 wn + 16 ni + c16.  One batch per 16-row block ti: its 32 loads
+    // (momentum and position of 16 elements per lane) are issued together, then the arithmetic, then the stores -- element by element the epilogue was a
+    // chain of 64 dependent round trips to memory (66 us per tile with the matrix pipe idle: 0.70 instead of 0.89 of the peak for the whole call)
     const double eps = prm.eps;
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
+    for (int ti = 0; ti < 4; ++ti) {
+        const size_t row0 = m0 + (size_t)(64 * wm + 16 * ti);
+        if (row0 >= prm.M_store || (MI_GEMM_ABLATE & 1)) continue;          // (M_store is a multiple of 16: the block exists or it does not)
+        const size_t base = (row0 + (size_t)j) * prm.Cp + n0 + (size_t)(64 * wn + c16);
+        auto at = [&](int r, int ni) -> size_t { return base + (size_t)(4 * r) * prm.Cp + (size_t)(16 * ni); };
+        if constexpr (MODE == 3) {                                         // eta = X Theta as it is: gemm_rowterm_kernel makes the row terms of it, at full occupancy
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t row = m0 + (size_t)(64 * wm + 16 * ti + 4 * r + j);
-            if (row < prm.M_store) {
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) prm.term_out[at(r, ni)] = acc[ti][ni][r];
+        } else {
+            [[maybe_unused]] double pv[4][4], xv[4][4];
+            if constexpr (MODE != 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) pv[r][ni] = prm.pm[at(r, ni)];
+            }
+            if constexpr (MODE == 0 || TGT == TGT_LOGISTIC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) xv[r][ni] = prm.pos[at(r, ni)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const size_t idx = row * prm.Cp + n0 + (size_t)(64 * wn + 16 * ni + c16);
+                    const size_t idx = at(r, ni);
                     const double v = acc[ti][ni][r];
-                    if constexpr (MODE == 3) {                                 // eta = X Theta as it is: gemm_rowterm_kernel makes the row terms of it, at full occupancy
-                        prm.term_out[idx] = v;
-                    } else {
-                        double g;
-                        if constexpr (TGT == TGT_DENSE) g = -v;                // grad log K = -(P theta)
-                        else g = v - prm.pos[idx];                             // X^T (y - sigmoid(eta)) - beta
-                        if constexpr (MODE == 2) prm.g_out[idx] = g;
+                    double g;
+                    if constexpr (TGT == TGT_DENSE) g = -v;                // grad log K = -(P theta)
+                    else g = v - xv[r][ni];                                // X^T (y - sigmoid(eta)) - beta
+                    if constexpr (MODE == 2) prm.g_out[idx] = g;
+                    else {
+                        double p = pv[r][ni];
+                        p = p + (eps * g) / 2.0;                           // second half-step of this leapfrog step (hmc.cpp:175)
+                        if constexpr (MODE == 1) { prm.pm[idx] = p; prm.g_out[idx] = g; }
                         else {
-                            double p = prm.pm[idx];
-                            p = p + (eps * g) / 2.0;                           // second half-step of this leapfrog step (hmc.cpp:175)
-                            if constexpr (MODE == 1) { prm.pm[idx] = p; prm.g_out[idx] = g; }
-                            else {
-                                p = p + (eps * g) / 2.0;                       // first half-step of the next one (:126): same position, same gradient
-                                prm.pm[idx] = p;
-                                prm.pos_out[idx] = prm.pos[idx] + eps * p;     // :171
-                            }
+                            p = p + (eps * g) / 2.0;                       // first half-step of the next one (:126): same position, same gradient
+                            prm.pm[idx] = p;
+                            prm.pos_out[idx] = xv[r][ni] + eps * p;        // :171
                         }
                     }
                 }
-            }
         }
+    }
 }
 
 // M (rows x cols row-major) -> out[k ld + i] = TRANSPOSE ? M[i][k] : M[k][i] for k < Kp, i < ld, zeros outside the matrix

@@ -11,7 +11,7 @@ root, cfg, cmd = sys.argv[1], int(sys.argv[2]), (sys.argv[3] if len(sys.argv) > 
 out = {"command": cmd}
 
 # kernels whose global reads are 16-byte-per-lane streams (the guide's calibrated case)
-WIDE_READ_KERNELS = ("nuts_gauss_",)      # per-lane rows moved 16 bytes per instruction
+WIDE_READ_KERNELS = ("nuts_gauss_", "gemm_step_kernel")      # per-lane rows moved 16 bytes per instruction (gemm_step_kernel: its tiles; the epilogue reads 8 bytes per lane)
 
 
 def rows(path):
