@@ -353,6 +353,41 @@ def extra_hmc_dense_precond(ctx):
                     "literal replay launch"}
 
 
+def extra_hmc_dense_d1024(ctx):
+    """Not a BASELINE config: mcmc::hmc on a dense Gaussian BEYOND d = 512 (ref: src/hmc.cpp:40 -- n_vals is unrestricted; VERDICT r5 missing 5), which ran on
+    the literal kernel (~1 % of the matrix peak) until round 6.  d = 1024, 65 536 chains, 16 leapfrog steps x (2 + 2) draws on gemm_step_kernel
+    (mcmc_amd/csrc/gemm_samplers.hip, DESIGN.md section 4.18: the state in HBM, one fp64 matrix product W = P Theta per leapfrog step for all chains, kicks and
+    drift in its epilogue).  Events on the launch stream around the whole call: the pack of P, the first evaluation, the normals and the accept step are inside `ms`."""
+    import torch
+    import mcmc_amd
+    from mcmc_amd import synth
+    d, C, L, burn, keep = 1024, 65536, 16, 2, 2
+    dev = ctx.dev
+    theta0 = torch.from_numpy(np.ascontiguousarray(synth.initial_states(C, d, seed=3).T)).to(dev)
+    theta = torch.empty_like(theta0)
+    draws = torch.empty((keep, d, C), dtype=torch.float64, device=dev)
+    target = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=torch.from_numpy(synth.dense_gaussian_precision(d)).to(dev), mem=mcmc_amd.MEM_DEVICE)
+    settings = mcmc_amd.default_settings(rng_seed_value=1, n_burnin_draws=burn, n_keep_draws=keep, n_leap_steps=L, step_size=0.02)
+    chains = mcmc_amd.make_chains(theta, C, draws=draws, mem=mcmc_amd.MEM_DEVICE)
+    stream = torch.cuda.current_stream().cuda_stream
+    ms = None
+    for _ in range(2):                          # the first run loads the code object
+        theta.copy_(theta0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        mcmc_amd.run("hmc", target, settings, chains, stream=stream)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1)
+    n_draws = burn + keep
+    flop = float(C) * (n_draws * L + 1) * 2.0 * d * d
+    tflops = flop / (ms * 1e-3) / 1e12
+    return {"workload": "mcmc::hmc on a dense Gaussian, d=1024, identity precond_mat, 16 leapfrog steps, fp64", "chains": C, "draws": n_draws, "ms": ms,
+            "kernel": mcmc_amd.last_kernel(), "value": float(C) * d * L * n_draws / (ms * 1e-3), "unit": "chain*dim*leapfrog-steps/s",
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS, "flop_per_unit": 2.0 * d},
+            "note": "whole call; the kernel's own rocprofv3 average and counters: profiles/r6_gemm_kernel_stats.csv, profiles/r6_gemm_pmc.json"}
+
+
 # ESS/sec legs (VERDICT r4 next 4): BASELINE's frozen settings of configs[2] (step_size 0.02: accept 0.99996, the chains barely move) and
 # configs[4] (8 kept draws at M = I) give draws/sec but no ESS that is an estimate.  These legs run the SAME target and sampler, outside the
 # timed region, at settings under which the chains converge (R-hat < 1.1); the values are frozen in BASELINE.md section 9.
@@ -830,6 +865,10 @@ def main():
                 out["extra"]["hmc_dense_precond_d256"] = extra_hmc_dense_precond(ctx)
             except Exception as e:              # noqa: BLE001
                 out["extra"]["hmc_dense_precond_d256"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                out["extra"]["hmc_dense_d1024"] = extra_hmc_dense_d1024(ctx)
+            except Exception as e:              # noqa: BLE001
+                out["extra"]["hmc_dense_d1024"] = {"error": f"{type(e).__name__}: {e}"}
     elif ctx.rank == 0 and ctx.world == 1 and args.chains is None and head_id in CONVERGED and args.converged:
         out["converged"] = converged_leg(head_id, ctx)
     if (single and not args.no_proxy) or (args.proxy_scaling and ctx.world == 1):

@@ -55,7 +55,9 @@ typedef enum mi_target_kind {
     MI_TARGET_LOGISTIC = 4,     /* log K = sum_r [y_r eta_r - log(1+e^eta_r)] - 1/2 |beta|^2, eta = X beta.  d <= 512 on the LDS-staged MFMA
                                  * kernels: hmc / mala / rwmh / nuts; hmc and nuts also with vals_bound; a diagonal precond_mat (hmc, mala, nuts)
                                  * or, unbounded, a dense one (hmc, mala).  d <= 8: one chain per lane, every setting.  Everything else
-                                 * (d > 512, the remaining combinations, rwmh with a cov_mat or bounds beyond d = 8): the literal kernels -- same bits */
+                                 * (the remaining combinations, rwmh with a cov_mat or bounds beyond d = 8): the literal kernels -- same bits.  d > 512, hmc / mala / rwmh without
+                                 * bounds / precond_mat (round 6): the state in HBM, two fp64 matrix products per gradient for all chains (gemm_samplers.hip);
+                                 * the same for MI_TARGET_GAUSS_DENSE beyond d = 512 (one product per gradient) */
     MI_TARGET_NORMAL_MODEL = 5  /* d = 2, vals = (mu, sigma), observations x_1..x_n in y[0..n_rows): the model of the reference's
                                  * example programs (/root/reference/examples/eigen/rmhmc_normal.cpp:44-106),
                                  * log K = -n (log(2 pi)/2 + log sigma) - sum_r (x_r - mu)^2 / (2 sigma^2); its metric tensor for

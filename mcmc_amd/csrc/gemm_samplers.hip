@@ -199,8 +199,13 @@ __global__ __launch_bounds__(256) void gemm_rowterm_kernel(const double* __restr
         const bool valid = row < n_rows;
         const double yv = valid ? y[row] : 0.0;
         const double eta = valid ? term[e] : 0.0;
-        res[e] = valid ? (yv - sigmoid(eta)) : 0.0;
-        term[e] = valid ? (yv * eta - softplus(eta)) : 0.0;
+        // softplus / sigmoid (det_math.hpp) share e = exp(-|eta|): each of them evaluates it once, on the same argument -- the same bits (logistic_lds.hpp does the same)
+        const double ex = det_exp(eta > 0.0 ? -eta : eta);
+        const double l1p = det_log(1.0 + ex);
+        const double sp = (eta > 0.0) ? (eta + l1p) : l1p;
+        const double sg = (eta >= 0.0) ? (1.0 / (1.0 + ex)) : (ex / (1.0 + ex));
+        res[e] = valid ? (yv - sg) : 0.0;
+        term[e] = valid ? (yv * eta - sp) : 0.0;
     }
 }
 

@@ -61,3 +61,11 @@ def test_hmc_with_a_dense_precond_mat_on_the_streamed_kernels_random_cases():
     """logit_lds_kernel<.., DENSEM> (round 5): random sizes of both targets, 0..5 leapfrog steps, the non-finite regime"""
     import fuzz_parity
     assert fuzz_parity.sweep_dense_m(16, 3, verbose=False) == 0
+
+
+@pytest.mark.parametrize("n", [12, pytest.param(60, marks=SLOW)])
+def test_matrix_product_samplers_random_cases(n):
+    """gemm_samplers.hip (hmc / mala / rwmh beyond d = 512, dense Gaussians and the logistic target) against the literal kernels of the same library:
+    ragged d / N / chain tiles, step sizes from tiny to absurd, non-finite starts, chain0 / draw0 offsets, runs cut in two (tests/fuzz_gemm.py)"""
+    import fuzz_gemm
+    assert fuzz_gemm.sweep(n, 9, verbose=False) == 0
