@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 
 namespace mi {
 namespace gemm {
@@ -65,6 +66,7 @@ struct StepParams {
     double* pos_out;         // MODE 0
     double* pm;              // MODE 0 / 1
     double* g_out;           // MODE 1 / 2: grad log K
+    const double* m_inv;     // MODE 0: diagonal of INV(precond_mat) per dimension (ones: the identity -- 1.0 * p is p, bit for bit)
     double* term_out;        // MODE 3: eta = X Theta [rows padded to 16][Cp] (gemm_rowterm_kernel turns it into the row terms)
 };
 
@@ -139,7 +141,11 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) prm.term_out[at(r, ni)] = acc[ti][ni][r];
         } else {
-            [[maybe_unused]] double pv[4][4], xv[4][4];
+            [[maybe_unused]] double pv[4][4], xv[4][4], mi[4];
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mi[r] = prm.m_inv[row0 + (size_t)(4 * r + j)];
+            }
             if constexpr (MODE != 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -169,7 +175,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(256, 2) void gemm_step_kernel(const 
                         else {
                             p = p + (eps * g) / 2.0;                       // first half-step of the next one (:126): same position, same gradient
                             prm.pm[idx] = p;
-                            prm.pos_out[idx] = xv[r][ni] + eps * p;        // :171
+                            prm.pos_out[idx] = xv[r][ni] + eps * (mi[r] * p);   // :171: theta += eps (inv_precond_matrix p), the matrix diagonal
                         }
                     }
                 }
@@ -219,6 +225,10 @@ struct DrawParams {
     double* gprop;           // grad log K there
     double* pm;              // hmc: momentum
     const double* term;      // logistic: [nK][Cp] y eta - log(1 + e^eta) of the LAST evaluation
+    const double* m;         // [dK] the diagonal of precond_mat, its CHOL_LOWER (sqrt) and INV (reciprocal), and of INV(eps^2 M) (mala); ones / 1 / eps^2 for the
+    const double* m_sqrt;    //      identity (1.0 * x is x bit for bit, so the identity runs the same statements)
+    const double* m_inv;
+    const double* s_inv;
     double* prevE;           // [Cp] hmc: prev_U; mala / rwmh: prev_LP
     double* kprev;           // [Cp] hmc: prev_K of the running draw
     uint64_t* nacc;          // [Cp]
@@ -257,10 +267,10 @@ __global__ __launch_bounds__(256) void gemm_normals_kernel(const DrawParams prm)
     if (c < prm.C && da < prm.d) rng_normal_pair(prm.seed, prm.chain0 + c, draw + prm.draw0, slot, STREAM_NORMAL, z0, z1);
     if (db >= prm.d) z1 = 0.0;
     const size_t ia = (size_t)da * prm.Cp + c, ib = (size_t)db * prm.Cp + c;
-    if (prm.algo == GEMM_HMC) { prm.pm[ia] = z0; prm.pm[ib] = z1; }
-    else if (prm.algo == GEMM_MALA) {
-        prm.thw[ia] = (prm.th[ia] + (prm.s2 * prm.gacc[ia]) / 2.0) + prm.eps * z0;
-        prm.thw[ib] = (prm.th[ib] + (prm.s2 * prm.gacc[ib]) / 2.0) + prm.eps * z1;
+    if (prm.algo == GEMM_HMC) { prm.pm[ia] = prm.m_sqrt[da] * z0; prm.pm[ib] = prm.m_sqrt[db] * z1; }      // p = sqrt_precond_matrix z (:158), the matrix diagonal
+    else if (prm.algo == GEMM_MALA) {                    // mean = x + eps^2 (M grad) / 2 (mala.cpp:123), proposal = mean + eps (sqrt(M) z) (:159)
+        prm.thw[ia] = (prm.th[ia] + (prm.s2 * (prm.m[da] * prm.gacc[ia])) / 2.0) + prm.eps * (prm.m_sqrt[da] * z0);
+        prm.thw[ib] = (prm.th[ib] + (prm.s2 * (prm.m[db] * prm.gacc[ib])) / 2.0) + prm.eps * (prm.m_sqrt[db] * z1);
     } else {
         prm.thw[ia] = prm.th[ia] + prm.eps * z0;
         prm.thw[ib] = prm.th[ib] + prm.eps * z1;
@@ -308,10 +318,11 @@ __global__ __launch_bounds__(256) void gemm_pre_kernel(const DrawParams prm)
     for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
         const size_t e = (size_t)i * prm.Cp + c;
         double p = prm.pm[e];
-        q = dfma(p, p, q);
+        const double mi = prm.m_inv[i];
+        q = dfma(p, mi * p, q);                              // K = p . (Minv p) / 2 (:160)
         p = p + (prm.eps * prm.gacc[e]) / 2.0;
         prm.pm[e] = p;
-        prm.thw[e] = prm.th[e] + prm.eps * p;
+        prm.thw[e] = prm.th[e] + prm.eps * (mi * p);         // :171
     }
     q = class_sum(q);
     if (j == 0) prm.kprev[c] = q / 2.0;
@@ -341,15 +352,16 @@ __global__ __launch_bounds__(256) void gemm_post_kernel(const DrawParams prm)
 #pragma unroll 4
         for (uint32_t i = (uint32_t)j; i < prm.dK; i += 4u) {
             const size_t e = (size_t)i * prm.Cp + c;
-            if constexpr (ALGO == GEMM_HMC) { const double p = prm.pm[e]; qk = dfma(p, p, qk); }
-            else {
+            if constexpr (ALGO == GEMM_HMC) { const double p = prm.pm[e]; qk = dfma(p, prm.m_inv[i] * p, qk); }      // :184
+            else {                                                     // Sigma = eps^2 M: INV(Sigma)_ii from the host (s_inv), the means with M grad
                 const double x = prm.thw[e], be = prm.th[e], gr = prm.gacc[e], gp = prm.gprop[e];
-                const double mean_prop = x + (prm.s2 * gp) / 2.0;
+                const double mm = prm.m[i], si = prm.s_inv[i];
+                const double mean_prop = x + (prm.s2 * (mm * gp)) / 2.0;
                 const double xa = be - mean_prop;                      // dmvnorm.hpp:37
-                qa = dfma(xa, prm.rs * xa, qa);
-                const double mean_prev = be + (prm.s2 * gr) / 2.0;
+                qa = dfma(xa, si * xa, qa);
+                const double mean_prev = be + (prm.s2 * (mm * gr)) / 2.0;
                 const double xb = x - mean_prev;
-                qb = dfma(xb, prm.rs * xb, qb);
+                qb = dfma(xb, si * xb, qb);
             }
         }
     }
@@ -443,6 +455,7 @@ static Layout layout_of(uint32_t d, uint32_t n_rows, uint64_t C)
     l.n_doubles = l.mat + 6 * l.vec + 2 * l.rvec + 3 * l.Cp + 32;
     return l;
 }
+uint32_t gemm_padded_d(uint32_t d) { return round_up(d, TK); }
 size_t gemm_ws_bytes(uint32_t d, uint32_t n_rows, uint64_t C) { return layout_of(d, n_rows, C).n_doubles * sizeof(double); }
 
 #define GEMM_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -487,6 +500,7 @@ static int gemm_run_t(const GemmRun& r, hipStream_t st, const char** kernel_name
     dp.theta_in = r.theta; dp.theta_out = r.theta; dp.draws = r.draws; dp.n_accept = r.n_accept; dp.nf_flag = r.nf_flag;
     dp.seed = r.seed; dp.n_burnin = r.n_burnin; dp.draw0 = r.draw0;
     dp.eps = r.eps; dp.s2 = r.s2; dp.rs = r.rs; dp.log_det = r.log_det; dp.cons_term = r.cons_term;
+    dp.m = r.mass_tables; dp.m_sqrt = r.mass_tables + l.dK; dp.m_inv = r.mass_tables + 2 * (size_t)l.dK; dp.s_inv = r.mass_tables + 3 * (size_t)l.dK;
 
     static const int attr_rc = [] { int e = step_attr<0, TGT>(); if (!e) e = step_attr<1, TGT>(); if (!e) e = step_attr<2, TGT>(); if constexpr (LOGIT) { if (!e) e = step_attr<3, TGT>(); } return e; }();
     if (attr_rc) return attr_rc;
@@ -494,7 +508,7 @@ static int gemm_run_t(const GemmRun& r, hipStream_t st, const char** kernel_name
     // grad log K (and, logistic, the row terms) at `pos`; mode 0: a leapfrog step that is not the last (pos_out: the next position), 1: the last, 2: the gradient alone
     auto evaluate = [&](const double* pos, int mode, double* pos_out, double* g_out, hipStream_t s) -> int {
         StepParams sp{};
-        sp.n_ntiles = n_ntiles; sp.Cp = l.Cp; sp.eps = r.eps; sp.pm = pm; sp.pos = pos; sp.pos_out = pos_out; sp.g_out = g_out;
+        sp.n_ntiles = n_ntiles; sp.Cp = l.Cp; sp.eps = r.eps; sp.pm = pm; sp.pos = pos; sp.pos_out = pos_out; sp.g_out = g_out; sp.m_inv = dp.m_inv;
         if constexpr (LOGIT) {
             StepParams se = sp;                               // eta = X Theta and the row terms
             se.At = A1; se.Bm = pos; se.Kp = l.dK; se.ldA = l.nM; se.M_store = l.nK; se.term_out = term;
@@ -576,6 +590,7 @@ static int gemm_run_t(const GemmRun& r, hipStream_t st, const char** kernel_name
         static thread_local char name[96];
         snprintf(name, sizeof(name), "gemm_step_kernel<%d, %d> (%s%s)", r.algo == GEMM_HMC ? (L > 1 ? 0 : 1) : 2, TGT,
                  r.algo == GEMM_HMC ? "hmc" : r.algo == GEMM_MALA ? "mala" : "rwmh", graphed ? ", graph" : "");
+        if (r.diag_mass) { const size_t n = strlen(name); snprintf(name + n - 1, sizeof(name) - n + 1, ", diagonal precond_mat)"); }
         *kernel_name = name;
     }
     return 0;

@@ -28,10 +28,14 @@ struct GemmRun {
     uint32_t n_burnin = 0, n_keep = 0, n_leap = 0, draw0 = 0;
     double eps = 0.0;                 // step_size (hmc, mala) / par_scale (rwmh)
     double s2 = 0.0, rs = 0.0, log_det = 0.0, cons_term = 0.0;     // mala: dmvnorm's constants for Sigma = eps^2 I (mi_mcmc.hip: as the oracle states them)
+    const double* mass_tables = nullptr;   // device, 4 tables of gemm_padded_d(d) doubles: diag(M), its sqrt, its reciprocal, diag(INV(eps^2 M)) (mala) -- ones / 1 / eps^2
+                                           // for the identity, ones in the padding
+    bool diag_mass = false;                // (for the kernel's name only: the tables decide)
     void* ws = nullptr;               // gemm_ws_bytes(d, n_rows, C) bytes of device memory
     bool use_graph = true;            // replay the launches of one draw from a captured hipGraph (the draw index lives in device memory)
 };
 
+uint32_t gemm_padded_d(uint32_t d);
 size_t gemm_ws_bytes(uint32_t d, uint32_t n_rows, uint64_t C);      // n_rows = 0: the dense Gaussian
 // enqueues the whole run on `st`; returns a hipError_t as int (0 = enqueued).  *kernel_name: what ran, for mi_mcmc_last_kernel()
 int gemm_run(const GemmRun& r, hipStream_t st, const char** kernel_name);

@@ -977,9 +977,10 @@ int run_dense_lds(const char* who, int algo, const mi_target* target, const mi_s
 // 16-chain tile no longer fits a workgroup, so it lives in HBM and the gradients of ALL chains at one leapfrog step are fp64 matrix products on the matrix
 // cores -- W = P Theta, resp. eta = X Theta and X^T (y - sigmoid(eta)) -- with the half-kicks and the drift in the epilogue (gemm_samplers.hip); chains that
 // reach the non-finite regime are flagged and replayed by literal.hpp right behind it.  algo: the C ABI's numbers (0 hmc, 1 mala, 3 rwmh).
-bool gemm_case(const mi_target* target, const mi_settings* settings, const mi_chains* chains, bool hmc)
+bool gemm_case(const mi_target* target, const mi_settings* settings, const mi_chains* chains, bool hmc, bool algo_has_mass = true)
 {
-    return (target->kind == MI_TARGET_GAUSS_DENSE || target->kind == MI_TARGET_LOGISTIC) && target->d > 512 && !settings->vals_bound && !settings->precond_mat
+    return (target->kind == MI_TARGET_GAUSS_DENSE || target->kind == MI_TARGET_LOGISTIC) && target->d > 512 && !settings->vals_bound
+           && (!settings->precond_mat || (algo_has_mass && precond_is_diagonal(settings, target->d)))       // identity, or (hmc, mala) a DIAGONAL precond_mat
            && !chains->mass_diag && target->kernel_hint != MI_KERNEL_LITERAL && (!hmc || settings->n_leap_steps >= 1);
 }
 int run_gemm(const char* who, int algo, const mi_target* target, const mi_settings* settings, mi_chains* chains, hipStream_t st)
@@ -1015,14 +1016,23 @@ int run_gemm(const char* who, int algo, const mi_target* target, const mi_settin
     g.seed = settings->rng_seed_value;
     g.n_burnin = (uint32_t)settings->n_burnin_draws; g.n_keep = (uint32_t)settings->n_keep_draws; g.n_leap = (uint32_t)settings->n_leap_steps;
     g.draw0 = (uint32_t)chains->draw0; g.eps = settings->step_size;
-    if (algo == 1) {                                     // dmvnorm's constants for Sigma = eps^2 I, as the oracle states them (run_dense_lds)
-        const double s2 = settings->step_size * settings->step_size;
-        double log_det = 0.0;
-        const double lii = __builtin_sqrt(s2);
-        for (uint64_t i = 0; i < d; ++i) log_det = log_det + 2.0 * mi::det_log(lii);
-        g.s2 = s2; g.rs = 1.0 / s2; g.log_det = log_det;
-        g.cons_term = -0.5 * (double)d * 1.83787706640934548356;
+    // identity or a DIAGONAL precond_mat (hmc.cpp:57-59, mala.cpp:57-58 with mala.ipp:58-64): diag(M), CHOL_LOWER (sqrt), INV (reciprocal) and, mala, INV(eps^2 M) with
+    // LOG_DET(eps^2 M) -- all from lit_prepare, in the oracle's operation order; the identity as tables of ones (1.0 * x is x bit for bit)
+    mi::lit::LitPrep prep;
+    rc = mi::lit::lit_prepare(algo == 1 ? 1 : 0, (uint32_t)d, settings->step_size, 0, nullptr, nullptr, settings->precond_mat, prep);
+    if (rc) return rc;
+    const uint32_t dK = mi::gemm::gemm_padded_d((uint32_t)d);
+    std::vector<double> tabs(4 * (size_t)dK, 1.0);
+    if (algo == 1) {                                     // dmvnorm's constants for Sigma = eps^2 M, as the oracle states them
+        g.s2 = settings->step_size * settings->step_size; g.rs = prep.rs; g.log_det = prep.log_det; g.cons_term = prep.cons_term;
+        for (uint64_t i = 0; i < d; ++i) tabs[3 * (size_t)dK + i] = prep.precond == 1 ? prep.sinv_diag[i] : prep.rs;
     }
+    if (prep.precond == 1)
+        for (uint64_t i = 0; i < d; ++i) { tabs[i] = prep.m[i]; tabs[dK + i] = prep.m_sqrt[i]; tabs[2 * (size_t)dK + i] = prep.m_inv[i]; }
+    DevBuf tabs_dev;
+    HIP_TRY(tabs_dev.alloc(tabs.size() * 8));
+    HIP_TRY(hipMemcpy(tabs_dev.p, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
+    g.mass_tables = tabs_dev.as<double>(); g.diag_mass = prep.precond == 1;
     // a draw is a handful of launches + one or two per gradient: replayed from a captured graph while a launch is short (few chains); at full size the queue runs ahead anyway
     g.use_graph = (double)d * (double)(logit ? 2 * n : d) * (double)C < 3.0e10;
     const bool replay = algo != 3;                       // rwmh forms no product with a vector that can be non-finite (rwmh.cpp:126)
@@ -1048,6 +1058,7 @@ int run_gemm(const char* who, int algo, const mi_target* target, const mi_settin
         mi::lit::lit_orders(lp.t);
         lit_common(lp, settings, &sc.dev, rp, false);
         lp.rs = g.rs; lp.log_det = g.log_det; lp.cons_term = g.cons_term;
+        if (prep.precond == 1) { lp.precond = 1; lp.m = g.mass_tables; lp.m_sqrt = g.mass_tables + dK; lp.m_inv = g.mass_tables + 2 * (size_t)dK; lp.sinv_diag = g.mass_tables + 3 * (size_t)dK; }
         rc = launched("matrix-product sampler (literal replay)", mi::launch_literal(algo, lp, rp.n_wg, st));
         if (rc) return rc;
     }
@@ -1056,7 +1067,7 @@ int run_gemm(const char* who, int algo, const mi_target* target, const mi_settin
     if (rc) return rc;
     rc = stage_out(chains, d, settings->n_keep_draws, sc, st);
     if (rc) return rc;
-    if (P_owned.p || Xo.p || chains->mem == MI_MEM_HOST) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));                  // (the mass tables are ours)
     return MI_OK;
 }
 
@@ -1930,9 +1941,9 @@ int mi_mcmc_mala_run(const mi_target* target, const mi_settings* settings, mi_ch
     // a DIAGONAL precond_mat alone rides the LDS-staged kernel too (its DIAGM instantiation)
     // ... and, round 5, a DENSE one without bounds (DENSEM: M, CHOL_LOWER(M) and INV(eps^2 M) streamed through LDS like X)
     const bool mala_diag_alone = !settings->vals_bound && (precond_is_diagonal(settings, d) || lds_dense_m_ok(target, settings)) && d > (uint64_t)mi::SMALL_MAX_D && d <= 512;
+    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false)) return run_gemm("mala", 1, target, settings, chains, st);    // d > 512, identity or a diagonal precond_mat, no bounds
     if (target->kind == MI_TARGET_LOGISTIC && (settings->vals_bound || settings->precond_mat) && !mala_diag_alone)
         return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("mala", 1, target, settings, chains, st) : run_literal("mala", 1, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false)) return run_gemm("mala", 1, target, settings, chains, st);    // d > 512, plain
     if (target->kind == MI_TARGET_LOGISTIC && d > 512) return run_literal("mala", 1, target, settings, chains, st);
     // Sigma = eps^2 * I (mala.ipp:41,63): INV by Gauss-Jordan gives diag(1/s2); CHOL gives diag(sqrt(s2));
     // LOG_DET = sum_i 2 log L_ii accumulated sequentially, exactly as the oracle states it.
@@ -2105,7 +2116,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t d = target->d;
     if (target->kind == MI_TARGET_NORMAL_MODEL) return run_small_normal_model("rwmh", 3, target, settings, chains, st);
-    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false)) return run_gemm("rwmh", 3, target, settings, chains, st);    // d > 512, plain
+    if (target->kind == MI_TARGET_LOGISTIC && gemm_case(target, settings, chains, false, false)) return run_gemm("rwmh", 3, target, settings, chains, st);    // d > 512, plain
     if (target->kind == MI_TARGET_LOGISTIC) {
         if (settings->vals_bound || settings->precond_mat)
             return d <= (uint64_t)mi::SMALL_MAX_D ? run_small_logistic("rwmh", 3, target, settings, chains, st) : run_literal("rwmh", 3, target, settings, chains, st);
@@ -2115,7 +2126,7 @@ int mi_mcmc_rwmh_run(const mi_target* target, const mi_settings* settings, mi_ch
         return fail(MI_ERR_UNSUPPORTED, "rwmh: target kind %d not implemented", target->kind);
     if (d > 128 && d <= 512 && target->kind == MI_TARGET_GAUSS_DENSE && !settings->vals_bound && !settings->precond_mat)
         return run_dense_lds("rwmh", mi::LOGIT_RWMH, target, settings, chains, st);     // P streamed through LDS (logistic_lds.hpp)
-    if (gemm_case(target, settings, chains, false)) return run_gemm("rwmh", 3, target, settings, chains, st);
+    if (gemm_case(target, settings, chains, false, false)) return run_gemm("rwmh", 3, target, settings, chains, st);
     if (d > 128) return run_literal("rwmh", 3, target, settings, chains, st);      // no other tiled kernel beyond d = 128: literal.hpp
 
     DevBuf P_owned;

@@ -1,7 +1,7 @@
 """Randomised sweep of the matrix-product samplers (mcmc_amd/csrc/gemm_samplers.hip: hmc / mala / rwmh beyond d = 512, dense Gaussians and the logistic
 target) against the literal kernels of the same library (MI_KERNEL_LITERAL: one workgroup per chain, the reference's operations as written, themselves
 pinned against the oracle by tests/test_gpu_literal_paths.py and the CPU suite) -- both run on the GPU: ragged d and N (not multiples of 16 / 128),
-ragged chain tiles, 0 .. many draws, one .. several leapfrog steps, step sizes from tiny to absurd, chains that start in the non-finite regime,
+ragged chain tiles, a diagonal precond_mat, 0 .. many draws, one .. several leapfrog steps, step sizes from tiny to absurd, chains that start in the non-finite regime,
 chain0 / draw0 offsets, runs cut in two.  Bit-exact or report.
 Usage (GPU box): python tests/fuzz_gemm.py [n_cases] [seed]"""
 import os, sys
@@ -39,7 +39,9 @@ def sweep(n_cases=30, seed=1, verbose=True):
                 if rng.random() < 0.3: init[c, int(rng.integers(0, d))] = float(rng.choice([np.inf, -np.inf, np.nan]))
         sd = int(rng.integers(1, 10**6))
         chain0, draw0 = int(rng.integers(0, 5000)), int(rng.choice([0, 0, 3]))
-        S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=sd, n_burnin_draws=b, n_keep_draws=k, n_leap_steps=L, step_size=eps)
+        kw = {}
+        if algo != "rwmh" and rng.random() < 0.35: kw["precond_mat"] = np.diag(rng.uniform(0.3, 3.0, d))      # a DIAGONAL precond_mat (hmc, mala)
+        S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=sd, n_burnin_draws=b, n_keep_draws=k, n_leap_steps=L, step_size=eps, **kw)
         a_draws, a = mcmc_amd.sample(algo, tk, init, S(burn, keep), chain0=chain0, draw0=draw0, **tkw)
         kernel = mcmc_amd.last_kernel()
         b_draws, b = mcmc_amd.sample(algo, tk, init, S(burn, keep), chain0=chain0, draw0=draw0, kernel_hint=mcmc_amd.KERNEL_LITERAL, **tkw)
@@ -54,7 +56,7 @@ def sweep(n_cases=30, seed=1, verbose=True):
             q_draws, q = mcmc_amd.sample(algo, tk, p["theta"].T.copy(), S(0, keep - cut), chain0=chain0, draw0=cut, **tkw)
             ok = same(np.concatenate([p_draws, q_draws]), a_draws) and np.array_equal(p["n_accept"] + q["n_accept"], a["n_accept"])
         if verbose or not ok:
-            print(("ok  " if ok else "FAIL"), dict(algo=algo, kind=kind, d=d, n_rows=n_rows, C=C, burn=burn, keep=keep, L=L, eps=eps, chain0=chain0, draw0=draw0, wild=wild, cut=cut,
+            print(("ok  " if ok else "FAIL"), dict(algo=algo, kind=kind, d=d, n_rows=n_rows, C=C, burn=burn, keep=keep, L=L, eps=eps, chain0=chain0, draw0=draw0, wild=wild, diag=bool(kw), cut=cut,
                                                    seed=sd, kernel=kernel, acc=int(a["n_accept"].sum())), flush=True)
         fails += 0 if ok else 1
     return fails

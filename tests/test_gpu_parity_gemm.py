@@ -157,3 +157,40 @@ def test_logistic_beyond_d512_equals_the_literal_kernel_on_more_chains(algo):
     assert mcmc_amd.last_kernel().startswith("literal_kernel<")
     assert 0 < l["n_accept"].sum() <= 8 * C
     assert np.array_equal(g["n_accept"], l["n_accept"]) and np.array_equal(g_draws, l_draws) and np.array_equal(g["theta"], l["theta"])
+
+
+# ---- a DIAGONAL precond_mat beyond d = 512 (ref: src/hmc.cpp:57-59,158-160,171,184: p = sqrt(m) z, theta += eps (p / m), K = p.(p / m) / 2; src/mala.cpp:57-58,123,159 with
+# include/mcmc/mala.ipp:58-64: mean = x + eps^2 (m grad) / 2, noise eps sqrt(m) z, INV(eps^2 M) diagonal): element-wise in the same kernels (tables of ones for the identity)
+@pytest.mark.parametrize("algo", ["hmc", "mala"])
+@pytest.mark.parametrize("target,d", [("dense", 600), ("dense", 1024), ("logit", 513), ("logit", 700)])
+def test_matrix_product_samplers_with_a_diagonal_precond_mat(algo, target, d):
+    C = 40
+    M = np.diag(np.random.default_rng(d + 1).uniform(0.4, 2.5, d))
+    eps = 0.02 if algo == "hmc" else 0.03
+    init = synth.initial_states(C, d, seed=d + 2) * (0.5 if target == "dense" else 0.1)
+    init[5] *= 1e200; init[9, 3] = np.inf                 # two chains leave the finite regime: replayed literally with the same tables
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=2, n_keep_draws=5, n_leap_steps=3, step_size=eps, precond_mat=M)
+    s = orc.make_settings(seed=7, n_burnin=2, n_keep=5, n_leap=3, step=eps, W=4, hoist=1, precond=M)
+    if target == "dense":
+        prec = synth.dense_gaussian_precision(d, seed=d % 89)
+        g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+        t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    else:
+        X, y = synth.logistic_problem(d, 70, seed=5)
+        g_draws, g = mcmc_amd.sample(algo, mcmc_amd.TARGET_LOGISTIC, init, st, X=X, y=y)
+        t = orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("gemm_step_kernel<") and "diagonal precond_mat" in kern, kern
+    o_draws, o = orc.run_many(ALGO[algo], t, init, s)
+    assert o["n_accept"].sum() > 0
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g_draws, o_draws, equal_nan=True)
+
+
+def test_rwmh_with_a_cov_mat_beyond_d512_stays_on_the_literal_kernel():
+    d, C = 520, 6
+    prec = synth.dense_gaussian_precision(d, seed=3)
+    M = np.diag(np.random.default_rng(1).uniform(0.5, 2.0, d))
+    init = synth.initial_states(C, d, seed=2) * 0.5
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=1, n_keep_draws=3, step_size=0.01, precond_mat=M)
+    mcmc_amd.sample("rwmh", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    assert mcmc_amd.last_kernel().startswith("literal_kernel<3>"), mcmc_amd.last_kernel()
