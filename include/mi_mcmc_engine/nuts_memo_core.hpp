@@ -6,6 +6,10 @@
 //                                         uniform) come from a TABLE a pre-pass kernel filled at full occupancy (prm.mom, prm.msc: nuts_memo.hpp) instead of
 //                                         being generated inside the tick, where 128 Box-Muller normals per chain and draw are pure latency of a wave that is
 //                                         alone on its SIMD.  Same Philox counters, same operations, same bits.
+//     static constexpr bool SPLIT      -- the launcher may cut every chain's run into prm.n_pieces PIECES of prm.piece_len draws that are handed out as separate work items
+//                                         (the built-in kernel's persistent grid: a slot's last chain otherwise ends up to one whole chain after the mean load).  A piece that is
+//                                         not the first continues its chain exactly as a continuation CALL does (mi_chains.draw0: step size, dual-averaging state, theta come back
+//                                         from memory, the gradient is re-evaluated, no step-size search) -- the hand-over is the one tests/test_gpu_resume.py pins
 //     static constexpr bool LANE_WALK  -- the merges of a leaf four levels per round, one accept decision per lane class (MI_MEMO_WALK_V2 below), or one level per
 //                                         iteration (the instantiations that have no registers left for the round's operands)
 //     double enter(v, dim)             -- initial_vals into the sampler's space (nuts.cpp:160-162); leave(v, slice): the way back for rows / theta
@@ -44,8 +48,15 @@ namespace mi {
 namespace memo {
 
 enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2,
-             NS_INIT = 3, NS_SEARCH = 4 };          // a new chain in a slot: the gradient at its initial values, then one leapfrog of
+             NS_INIT = 3, NS_SEARCH = 4,            // a new chain in a slot: the gradient at its initial values, then one leapfrog of
                                                     // nuts_find_initial_step_size per tick (nuts.ipp:30-93)
+             NS_WAIT = 5 };                         // SPLIT: the slot holds the ticket of a later piece whose chain has not been published yet
+// SPLIT: entries of the piece queues
+enum : uint32_t { PQ_EMPTY = 0xffffffffu, PQ_GONE = 0xfffffffeu };       // not published yet / the chain was flagged before it got here (nothing to continue)
+// loads and stores of what one slot hands to another THROUGH MEMORY inside a launch: agent scope (write-through / L2-coherent reads), so that a slot on
+// another XCD sees them without a release fence's write-back of its whole L2
+template <class T> __device__ __forceinline__ T coh_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void coh_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // workspace vectors of a chain slot
 enum : int {
     MV_PREV = 0, MV_WPREV = 1, MV_MNTM = 2, MV_TPOS_T = 3, MV_TPOS_P = 4, MV_TNEG_T = 5, MV_TNEG_P = 6,
@@ -119,6 +130,12 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
     const uint64_t n_slots = (uint64_t)gridDim.x * (16u * nw);   // chains [0, n_slots) start in their own slot; the counter hands out the rest
     uint64_t cl = ((uint64_t)blockIdx.x * nw + wave) * 16 + (lane & 15);     // this slot's chain (the four lanes of a chain agree); >= C: none
     bool exhausted = prm.next_chain == nullptr;          // no counter: every chain has its own slot (the tile route), nothing is handed out
+    // SPLIT: work items are (piece, chain) pairs -- item v < C is piece 0 of chain v; item v >= C is the ticket for entry v - C of the piece queues
+    // prm.piece_q [n_pieces - 1][C], where the chains are published in the order in which their previous piece ended
+    uint32_t n_pieces = 1u, piece_len = 0xffffffffu;
+    if constexpr (POL::SPLIT) { if (prm.n_pieces > 1u && prm.next_chain != nullptr) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; } }
+    const uint64_t n_items = C * (uint64_t)n_pieces;
+    bool piece_done = false;     // this chain's piece ended with the draw it just finished: it leaves the slot like a finished chain and is published for its next piece
 
     // (a 32-bit LDS byte address, re-materialised as address-space-3 pointers: through a generic char* the accesses become FLAT instructions,
     //  which queue in order with the wave's global memory operations)
@@ -308,6 +325,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             row2_pend = kept && prm.draws != nullptr;
             draw++;
         }
+        if constexpr (POL::SPLIT) { if (n_pieces > 1u && p && draw < n_total && draw % piece_len == 0u) piece_done = true; }
     };
     // kept row `idx` of lanes with `p` from workspace vector `vec`
     auto store_row = [&](bool p, int vec, uint32_t idx) __attribute__((always_inline)) {
@@ -347,28 +365,65 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             state = NS_TREE;
         }
     };
-    // a chain leaves its slot: final state, counters, step size and dual-averaging state (nuts.cpp:311-330) -- or, flagged, only its flag
+    // a chain leaves its slot: final state, counters, step size and dual-averaging state (nuts.cpp:311-330) -- or, flagged, only its flag.
+    // SPLIT with pieces: the same record is what the chain's NEXT piece starts from in another slot, so it is written with agent-scope stores, and the
+    // chain is published in the next piece's queue once they have completed (vmcnt(0) in front of the publishing store)
     auto retire = [&](bool p) __attribute__((always_inline)) {
         if (__ballot(p) == 0ull) return;
         const bool flagged = p && nf_() != 0.0 && prm.nf_flag != nullptr;
         if (flagged && j4 == 0) { prm.nf_flag[cl] = 1u; prm.nf_flag[C] = 1u; }
+        bool pieces = false;
+        if constexpr (POL::SPLIT) pieces = n_pieces > 1u;
         if (p && !flagged) {
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {           // (a rolled loop: see INIT)
                 const double2 t = *reinterpret_cast<const double2*>(wsp(pvec(pb), 2 * b));
                 double* dst = prm.theta + ((size_t)(8u * b + j4) * C + cl);
+                if constexpr (POL::SPLIT) {
+                    if (pieces) {
+                        if (8u * b + j4 < d) coh_st(dst, pol.leave(t.x, 2 * b));
+                        if (8u * b + 4 + j4 < d) coh_st(dst + (size_t)4 * C, pol.leave(t.y, 2 * b + 1));
+                        continue;
+                    }
+                }
                 if (8u * b + j4 < d) dst[0] = pol.leave(t.x, 2 * b);
                 if (8u * b + 4 + j4 < d) dst[(size_t)4 * C] = pol.leave(t.y, 2 * b + 1);
             }
             if (j4 == 0) {
+                if constexpr (POL::SPLIT) {
+                    if (pieces) {        // (the launcher provides every one of these arrays when it cuts the runs into pieces)
+                        coh_st(prm.n_accept + cl, (uint64_t)n_acc_()); coh_st(prm.n_leap + cl, (uint64_t)n_leap_()); coh_st(prm.n_exec + cl, (uint64_t)n_exec_());
+                        coh_st(prm.step_out + cl, eps_());
+                        coh_st(prm.adapt_state + cl, h_val_()); coh_st(prm.adapt_state + C + cl, eps_bar_()); coh_st(prm.adapt_state + 2 * C + cl, mu_val_());
+                    }
+                }
+                if (!pieces) {
                 if (prm.n_accept) prm.n_accept[cl] = n_acc_();
                 if (prm.n_leap) prm.n_leap[cl] = n_leap_();
                 if (prm.n_exec) prm.n_exec[cl] = n_exec_();
                 if (prm.step_out) prm.step_out[cl] = eps_();
                 if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
+                }
             }
         }
-        if (p) state = NS_DONE;
+        if constexpr (POL::SPLIT) {
+            if (pieces) {
+                // not flagged: the chain finished a piece (draw is a multiple of piece_len) and is published for piece draw / piece_len -- at the end of the run
+                // for none.  Flagged (at any point of piece p): it never continues, so PQ_GONE goes into EVERY later queue -- each queue still receives its C
+                // entries and no ticket waits for ever
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (p && j4 == 0) {
+                    const uint32_t p_cur = draw / piece_len - (piece_done ? 1u : 0u);
+                    const uint32_t first = flagged ? p_cur + 1u : draw / piece_len;
+                    const uint32_t last = flagged ? n_pieces - 1u : ((draw < n_total) ? first : 0u);
+                    for (uint32_t q = (first < 1u ? 1u : first); q <= last && q < n_pieces; ++q) {
+                        const uint32_t t = atomicAdd(prm.piece_tail + q, 1u);
+                        coh_st(prm.piece_q + ((size_t)(q - 1u) * C + t), flagged ? (uint32_t)PQ_GONE : (uint32_t)cl);
+                    }
+                }
+            }
+        }
+        if (p) { state = NS_DONE; piece_done = false; }
     };
     // SEARCH ends (or is skipped by a continuation): the dual-averaging state of nuts.cpp:174-176, then the chain waits for its first phase
     auto start_sampling = [&](bool p) __attribute__((always_inline)) {
@@ -376,9 +431,10 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (p) {
             mu_val_() = det_log(10 * eps_());                // nuts.cpp:174
             h_val_() = 0.0;
-            eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps_();
-            if (prm.draw0 > 0 && prm.draw0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
-                h_val_() = prm.adapt_state[cl]; eps_bar_() = prm.adapt_state[C + cl]; mu_val_() = prm.adapt_state[2 * C + cl];
+            const uint32_t g0 = prm.draw0 + draw;        // the global index of the chain's next draw (SPLIT: a later piece starts at draw > 0 like a continuation call)
+            eps_bar_() = (g0 == 0u) ? prm.eps_bar0 : eps_();
+            if (g0 > 0u && g0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+                h_val_() = coh_ld(prm.adapt_state + cl); eps_bar_() = coh_ld(prm.adapt_state + C + cl); mu_val_() = coh_ld(prm.adapt_state + 2 * C + cl);
             }
             state = NS_NEED_DRAW;
         }
@@ -431,11 +487,30 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 const uint64_t nid = n_slots + base + (uint32_t)__builtin_popcount(m & ((1u << (lane & 15)) - 1u));
                 if (want) {
-                    if (nid < C) {                       // a new chain in this slot: everything per-chain starts over
-                        cl = nid;
-                        state = NS_INIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
+                    if (nid < n_items) {                 // a new chain in this slot: everything per-chain starts over
+                        cl = nid;                        // (nid >= C: the ticket of a later piece -- the chain comes out of the piece queue below)
+                        state = (nid < C) ? NS_INIT : NS_WAIT; n_leap_() = 0ull; n_exec_() = 0ull; n_acc_() = 0ull; draw = 0; eps_() = 1.0; nf_() = 0.0;
                         mv = MV_MNTM; mvn = MV_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; org_ok = false; cp_pend = false; kl_pend = false;
+                        piece_done = false;
                     } else exhausted = true;
+                }
+            }
+        }
+        if constexpr (POL::SPLIT) {
+            // tickets of later pieces: one look at the queue entry per tick (never a spin: the chain it waits for may run in this very wave).  The chain goes on
+            // where its last piece stopped: counters and draw index here, theta / step size / dual-averaging state in INIT, as a continuation call would
+            if (__ballot(state == NS_WAIT) != 0ull) {
+                uint32_t e = PQ_EMPTY;
+                if (state == NS_WAIT) e = coh_ld(prm.piece_q + (size_t)(cl - C));
+                if (__ballot(state != NS_WAIT && state != NS_DONE) == 0ull && __ballot(state == NS_WAIT && e != PQ_EMPTY) == 0ull) __builtin_amdgcn_s_sleep(32);   // (only tickets left in this wave, none served: look again in ~2 k cycles)
+                if (state == NS_WAIT && e != PQ_EMPTY) {
+                    if (e == PQ_GONE) state = NS_DONE;   // flagged before it got here: the slot takes the next item
+                    else {
+                        draw = (uint32_t)(cl / C) * piece_len;
+                        cl = e;
+                        n_acc_() = coh_ld(prm.n_accept + cl); n_leap_() = coh_ld(prm.n_leap + cl); n_exec_() = coh_ld(prm.n_exec + cl);
+                        state = NS_INIT;
+                    }
                 }
             }
         }
@@ -444,7 +519,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
         if (__ballot(state == NS_NEED_DRAW) != 0ull) {
             store_row(row2_pend, pvec(pb), draw - 1u);       // (a chain that did not go straight on: its last draw's row, from prev_draw in memory)
             row2_pend = false;
-            retire(state == NS_NEED_DRAW && draw >= n_total);
+            retire(state == NS_NEED_DRAW && (draw >= n_total || piece_done));
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
             if constexpr (POL::PRE_MOM) {
                 // (a chain's first draw, or one whose look-ahead found no draw to look at: the scalars straight from the table)
@@ -502,16 +577,25 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 const bool in0 = 8u * b + j4 < d, in1 = 8u * b + 4 + j4 < d;
                 const double* src = prm.theta + ((size_t)(in0 ? 8u * b + j4 : 0u) * C + cl);
                 double t0 = 0.0, t1 = 0.0;
-                if (init) { t0 = src[0]; t1 = src[in1 ? (size_t)4 * C : 0]; }
+                if (init) {
+                    if constexpr (POL::SPLIT) { t0 = coh_ld(src); t1 = coh_ld(src + (in1 ? (size_t)4 * C : 0)); }     // (a later piece: what another slot stored in this launch)
+                    else { t0 = src[0]; t1 = src[in1 ? (size_t)4 * C : 0]; }
+                }
                 if (init) st_pair(MV_PREV, 2 * b, in0 ? pol.enter(t0, 8 * b + j4) : 0.0, in1 ? pol.enter(t1, 8 * b + 4 + j4) : 0.0);   // nuts.cpp:160-162
             }
+            // z_init (nuts.cpp:166-168) feeds K0 of nuts_find_initial_step_size only: a continuation -- a call with draw0 > 0 or (SPLIT) a later piece -- goes
+            // straight to its first draw, so its 16 NT Box-Muller normals (a third of a tick of the whole wave) are not made; zeros keep the idle update finite
+            const bool any_fresh = __ballot(init && prm.draw0 == 0 && draw == 0u) != 0ull;
 #pragma unroll 1
             for (int b = 0; b < NS / 2; ++b) {
-                double z0, z1;
-                rng_normal_pair(prm.seed, prm.chain0 + cl, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
-                double pa = (8u * b + j4 < d) ? z0 : 0.0;
-                double pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
-                pa = pol.msqrt_times(pa, 8 * b + j4); pb_ = pol.msqrt_times(pb_, 8 * b + 4 + j4);       // nuts.cpp:168
+                double pa = 0.0, pb_ = 0.0;
+                if (any_fresh) {
+                    double z0, z1;
+                    rng_normal_pair(prm.seed, prm.chain0 + cl, 0u, (uint32_t)(4 * b + j4), STREAM_INIT, z0, z1);
+                    pa = (8u * b + j4 < d) ? z0 : 0.0;
+                    pb_ = (8u * b + 4 + j4 < d) ? z1 : 0.0;
+                    pa = pol.msqrt_times(pa, 8 * b + j4); pb_ = pol.msqrt_times(pb_, 8 * b + 4 + j4);       // nuts.cpp:168
+                }
                 if (init) st_pair(mv, 2 * b, pa, pb_);
             }
         }
@@ -619,9 +703,10 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 H0_() = (is_finite(pU) ? pU : INF) + pK; // U0 + K0 (nuts.ipp:50-52)
                 s_first = true;
             }
-            if (init && prm.draw0 != 0) eps_() = prm.step_out ? prm.step_out[cl] : 1.0;  // a continuation: the step size comes back in
-            start_sampling(init && prm.draw0 != 0);
-            if (init && prm.draw0 == 0) state = NS_SEARCH;
+            const bool cont = prm.draw0 != 0 || draw != 0u;      // a continuation call, or (SPLIT) a later piece of a run: the same thing
+            if (init && cont) eps_() = prm.step_out ? coh_ld(prm.step_out + cl) : 1.0;  // the step size comes back in
+            start_sampling(init && cont);
+            if (init && !cont) state = NS_SEARCH;
         }
         if (!is_finite(pU)) pU = INF;
         if (__ballot(srch) != 0ull) {
@@ -893,7 +978,7 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             bool roll = false;
             if (__ballot(ended) != 0ull) {
                 end_draw(ended, jd);
-                roll = ended && draw < n_total && mom_ready && !row_pend;
+                roll = ended && draw < n_total && mom_ready && !row_pend && !piece_done;
                 if (ended && !roll) state = NS_NEED_DRAW;                // the phase: its row, its next momentum, or the end of its run
                 roll_state(roll);
             }

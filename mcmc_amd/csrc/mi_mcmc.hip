@@ -2371,9 +2371,11 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         const size_t cached = ws_cached_bytes(st);       // (what this stream's workspace already holds counts as free: it is re-used)
         if (want <= MI_NUTS_MOMENTA_MAX_BYTES && want <= (free_b + cached) / 3) mom_bytes = (want + 255) & ~(size_t)255;
     }
-    rc = ws_get(st, fixed_bytes + mom_bytes, ws);
+    const size_t split_bytes = memo ? ((mi::nuts_split_workspace_bytes(chains->n_chains) + 255) & ~(size_t)255) : 0;      // (nuts_launch.hip: runs cut into pieces)
+    rc = ws_get(st, fixed_bytes + mom_bytes + split_bytes, ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();
+    if (split_bytes) prm.split_ws = static_cast<char*>(ws.p) + fixed_bytes + mom_bytes;
     if (mom_bytes) {
         prm.mom = reinterpret_cast<double*>(static_cast<char*>(ws.p) + fixed_bytes);
         prm.msc = prm.mom + (size_t)n_total * chains->n_chains * (size_t)(16 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8));

@@ -73,7 +73,15 @@ struct NutsParams {
     // nuts_gauss_memo_kernel<., ., true> (nuts_memo.hpp): the momenta of every draw of every chain, filled by nuts_momenta_kernel before the launch.
     // mom: [n_total][C] blocks of 16 NT doubles in the granule order of a workspace row; msc: [n_total][C] (kinetic energy, log of the slice uniform)
     double* mom;
-    double* msc;    uint32_t sep_target;    // general variants: P is the expanded diagonal of an ISO / DIAG target: its gradient is taken element-wise (hmc_dense.hpp: target_times)
+    double* msc;
+    // nuts_gauss_memo_kernel, GaussMemoPolicy::SPLIT (nuts_memo_core.hpp): n_pieces > 1 cuts every chain's run into pieces of piece_len draws handed out as
+    // separate work items; piece_q [n_pieces - 1][C] (0xffffffff = not published) and piece_tail [n_pieces] are zeroed / filled by the launcher, which then
+    // also makes sure n_accept, n_leap, n_exec, step_out and adapt_state exist (the hand-over goes through them)
+    uint32_t n_pieces, piece_len;
+    uint32_t* piece_q;
+    uint32_t* piece_tail;
+    void* split_ws;         // nuts_split_workspace_bytes(C) bytes for the two arrays above and stand-ins for the outputs the caller did not ask for, or nullptr (no pieces)
+    uint32_t sep_target;    // general variants: P is the expanded diagonal of an ISO / DIAG target: its gradient is taken element-wise (hmc_dense.hpp: target_times)
 };
 
 enum : int {

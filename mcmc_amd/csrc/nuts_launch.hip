@@ -34,15 +34,45 @@ MemoShape memo_shape(uint64_t C)
     const uint64_t need = (C + 16 * waves - 1) / (16 * waves), cap = (uint64_t)n_cu * (uint64_t)per_cu;
     return MemoShape{waves, cap_grid(need < cap ? need : cap)};
 }
+#ifndef MI_MEMO_PIECES
+#define MI_MEMO_PIECES 4
+#endif
+constexpr uint32_t MEMO_PIECES = MI_MEMO_PIECES;
 template <int NT, bool DIAGM, bool PRE>
-int run_memo_k(const NutsParams& prm, hipStream_t st)
+int run_memo_k(const NutsParams& prm_in, hipStream_t st)
 {
+    NutsParams prm = prm_in;
     const size_t lds = memo_lds<NT, DIAGM>();
     auto kern = nuts_gauss_memo_kernel<NT, DIAGM, PRE>;
     note_kernel("nuts_gauss_memo_kernel<%d, %s, %s>", NT, DIAGM ? "true" : "false", PRE ? "true" : "false");
-    const MemoShape sh = memo_shape<NT, DIAGM>(prm.C);       // (the occupancy of the in-tick instantiation: the same LDS, the same launch bounds)
+    const MemoShape sh = memo_shape<NT, DIAGM>(prm_in.C);       // (the occupancy of the in-tick instantiation: the same LDS, the same launch bounds)
     MI_LAUNCH_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MI_LAUNCH_TRY(hipMemsetAsync(prm.next_chain, 0, sizeof(uint32_t), st));
+    // More chains than chain slots: a slot runs several chains one after the other, and the run ends when the slot with the most work does -- up to one
+    // whole chain after the mean load (configs[3]: 4 chains per slot, ~13 % of the run).  Cut into MEMO_PIECES pieces, the work items are a quarter as long:
+    // a piece that is not the first is its chain's continuation in whatever slot is free (nuts_memo_core.hpp, SPLIT; same draws: a continuation call's hand-over)
+    prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
+    {
+        const uint64_t n_slots = sh.grid * (uint64_t)sh.waves * 16u;
+        const uint32_t n_total = prm.n_burnin + prm.n_keep;
+        if (prm.split_ws != nullptr && prm.C > n_slots && n_total >= 4u * MEMO_PIECES && prm.C < (1ull << 28)) {
+            prm.piece_len = (n_total + MEMO_PIECES - 1u) / MEMO_PIECES;
+            prm.n_pieces = (n_total + prm.piece_len - 1u) / prm.piece_len;
+            char* b = static_cast<char*>(prm.split_ws);
+            prm.piece_tail = reinterpret_cast<uint32_t*>(b);
+            prm.piece_q = reinterpret_cast<uint32_t*>(b + 256);
+            const size_t q_bytes = ((size_t)(MEMO_PIECES - 1u) * prm.C * sizeof(uint32_t) + 255) & ~(size_t)255;
+            MI_LAUNCH_TRY(hipMemsetAsync(prm.piece_tail, 0, 256, st));
+            MI_LAUNCH_TRY(hipMemsetAsync(prm.piece_q, 0xff, q_bytes, st));
+            uint64_t* u = reinterpret_cast<uint64_t*>(b + 256 + q_bytes);       // stand-ins for what the hand-over goes through
+            if (!prm.n_accept) prm.n_accept = u;
+            if (!prm.n_leap) prm.n_leap = u + prm.C;
+            if (!prm.n_exec) prm.n_exec = u + 2 * prm.C;
+            double* dd = reinterpret_cast<double*>(u + 3 * prm.C);
+            if (!prm.step_out) prm.step_out = dd;
+            if (!prm.adapt_state) prm.adapt_state = dd + prm.C;
+        }
+    }
     if constexpr (PRE) {                                 // every momentum of the run, at full occupancy, before the latency-bound tick starts
         const uint64_t n_waves = ((prm.C + 15) / 16) * (uint64_t)(prm.n_burnin + prm.n_keep);
         if (n_waves > 0) hipLaunchKernelGGL((nuts_momenta_kernel<NT, DIAGM>), dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, prm);
@@ -99,6 +129,11 @@ size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt)
 {
     const int ns = 4 * (nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8);
     return memo_momenta_bytes(C, n_total, ns);
+}
+
+size_t nuts_split_workspace_bytes(uint64_t C)
+{
+    return 256 + (((size_t)(MEMO_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255) + (size_t)7 * C * 8 + 256;
 }
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)

@@ -56,6 +56,7 @@ struct GaussMemoPolicy {
     static constexpr int NS = 4 * NT;
     static constexpr bool REPLAY = true;
     static constexpr bool PRE_MOM = PRE;         // the momenta come from the table nuts_momenta_kernel filled (below)
+    static constexpr bool SPLIT = true;          // the launcher may cut the runs into pieces (NutsParams::n_pieces; nuts_launch.hip decides)
     // the lane-parallel walk everywhere but at d = 128 with the two mass tables: that instantiation has no register left for a round's operands
     // (100 B of scratch and 718 ms against 638 ms with the level loop on configs[3] with a diagonal precond_mat, same bits)
     static constexpr bool LANE_WALK = !(DIAGM && NT == 8);

@@ -143,3 +143,84 @@ def test_lds_nuts_on_recycled_slots_matches_the_oracle(kind, d, n_rows, C, grid_
     o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
     assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
     assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+
+
+# ---- round 6: runs cut into PIECES (nuts_launch.hip: MI_MEMO_PIECES work items per chain when there are more chains than chain slots and 16+ draws; a piece that is
+# not the first continues its chain in whatever slot is free, exactly as a continuation call does -- nuts_memo_core.hpp, SPLIT).  Same draws, counts and step
+# sizes as the oracle's uninterrupted chains: piece boundaries inside the adaptation window, at its end and in the kept draws; draw counts that are no multiple of
+# the piece length; chains that go non-finite in their first and in a later piece (PQ_GONE in every later queue); a run that is itself a continuation.
+@pytest.mark.parametrize("hint", DYN_HINTS)
+@pytest.mark.parametrize("d,C,cap,burn,keep,adapt,depth", [
+    (128, 200, 1, 10, 9, 10, 7),     # 19 draws: pieces of 5, 5, 5, 4; the window ends at a piece boundary
+    (64, 333, 2, 0, 17, 0, 6),       # two workgroups: pieces migrate between them; no adaptation
+    (16, 150, 1, 20, 20, 33, 5),     # pieces of 10; the window ends inside the last piece but one
+    (128, 700, 2, 9, 8, 7, 5),       # 5-6 chains per slot
+])
+def test_runs_cut_into_pieces_match_the_oracle(hint, d, C, cap, burn, keep, adapt, depth, grid_cap):
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=23)
+    st = mcmc_amd.default_settings(rng_seed_value=77, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=adapt, max_tree_depth=depth,
+                                   step_size=1.0 if adapt else 0.05)
+    grid_cap(cap)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=500, kernel_hint=getattr(mcmc_amd, hint))
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel")
+    o_draws, o = _oracle(d, init, st, prec, 500)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"])
+    assert np.array_equal(g_draws, o_draws)
+    assert (g["n_exec"] <= g["n_leap"]).all() and (g["n_exec"] > 0).all()
+
+
+@pytest.mark.parametrize("hint", DYN_HINTS)
+def test_chains_flagged_in_any_piece_are_replayed(hint, grid_cap):
+    d, C = 128, 260
+    prec = synth.dense_gaussian_precision(d)
+    init = synth.initial_states(C, d, seed=19)
+    init[2] *= 1.0e300            # flagged at its first evaluation (piece 0, its own slot)
+    init[90, 3] = np.inf          # a chain from the counter
+    init[150, 100] = np.nan
+    init[201] *= 1.0e150          # overflows its energies
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=10, n_keep_draws=10, n_adapt_draws=10, max_tree_depth=6, step_size=0.1)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=getattr(mcmc_amd, hint))
+    o_draws, o = _oracle(d, init, st, prec, 0)
+    assert np.isnan(o_draws[:, :, [2, 90, 150]]).any()
+    assert np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    assert np.array_equal(g["n_accept"], o["n_accept"])
+
+
+def test_a_continuation_call_is_cut_into_pieces_too(grid_cap):
+    d, C, n_adapt = 64, 200, 14
+    prec = synth.dense_gaussian_precision(d, seed=2)
+    init = synth.initial_states(C, d, seed=8) * 0.5
+    S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=99, n_burnin_draws=b, n_keep_draws=k, n_adapt_draws=n_adapt, max_tree_depth=6)
+    grid_cap(1)
+    kw = dict(prec=prec)
+    whole, w = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, S(0, 30), want_adapt_state=True, **kw)
+    a_draws, a = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, S(0, 6), want_adapt_state=True, **kw)          # (6 draws: in one piece)
+    b_draws, b = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, a["theta"].T, S(0, 24), draw0=6, step_size_in=a["eps"],
+                                 adapt_state_in=a["adapt_state"], want_adapt_state=True, **kw)                                 # (24 draws from draw 6 on: pieces of 6)
+    assert np.array_equal(np.concatenate([a_draws, b_draws], axis=0), whole)
+    assert np.array_equal(a["n_leap"] + b["n_leap"], w["n_leap"]) and np.array_equal(b["eps"], w["eps"]) and np.array_equal(b["adapt_state"], w["adapt_state"])
+    o_draws, o = _oracle(d, init, S(0, 30), prec, 0)
+    assert np.array_equal(whole, o_draws) and np.array_equal(w["eps"], o["eps"])
+
+
+def test_pieces_without_the_optional_outputs(grid_cap):
+    """the hand-over goes through step sizes, counters and the dual-averaging state: the launcher provides stand-ins for the ones the caller did not ask for"""
+    import torch
+    d, C = 64, 200
+    prec = synth.dense_gaussian_precision(d, seed=4)
+    init = synth.initial_states(C, d, seed=3) * 0.5
+    st = mcmc_amd.default_settings(rng_seed_value=5, n_burnin_draws=10, n_keep_draws=10, n_adapt_draws=10, max_tree_depth=6)
+    grid_cap(1)
+    full_draws, full = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec)
+    dev = torch.device("cuda", 0)
+    theta = torch.from_numpy(np.ascontiguousarray(init.T)).to(dev)
+    draws = torch.empty((10, d, C), dtype=torch.float64, device=dev)
+    tgt = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=torch.from_numpy(prec).to(dev), mem=mcmc_amd.MEM_DEVICE)
+    ch = mcmc_amd.make_chains(theta, C, draws=draws, mem=mcmc_amd.MEM_DEVICE)          # theta and draws only
+    mcmc_amd.run("nuts", tgt, st, ch)
+    torch.cuda.synchronize()
+    assert np.array_equal(draws.cpu().numpy(), full_draws) and np.array_equal(theta.cpu().numpy(), full["theta"])
