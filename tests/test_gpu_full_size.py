@@ -60,3 +60,41 @@ def test_config5_hmc_d1024_diag_one_gpu_shard():
     # started in stationarity: the scaled second moment stays 1
     m2 = (draws[-1] ** 2 * prec[:, None]).mean()
     assert abs(m2 - 1) < 0.02
+
+
+def test_config3_shape_cut_into_pieces_equals_the_tick_local_kernel():
+    """65 536 chains on the chip's 16 384 chain slots: the runs are cut into four pieces that migrate between slots -- and XCDs -- through memory inside one launch
+    (nuts_memo_core.hpp, SPLIT).  Device-resident, 8 + 8 draws, four chains started non-finite; every output equals the tick-local kernel's (whole chains in fixed
+    slots, an independent implementation), and five chains are re-run by the oracle."""
+    import torch
+    d, C, half = 128, 65536, 8
+    dev = torch.device("cuda", 0)
+    prec_h = synth.dense_gaussian_precision(d)
+    prec = torch.from_numpy(prec_h).to(dev)
+    init = synth.initial_states(C, d, seed=3)
+    init[5] *= 1e300; init[20000, 7] = np.inf; init[40000, 100] = np.nan; init[65535] *= 1e160
+    theta0 = torch.from_numpy(np.ascontiguousarray(init.T)).to(dev)
+    st = mcmc_amd.default_settings(rng_seed_value=2024, n_burnin_draws=half, n_keep_draws=half, n_adapt_draws=half)
+
+    def run(hint):
+        theta = theta0.clone()
+        draws = torch.empty((half, d, C), dtype=torch.float64, device=dev)
+        n_leap = torch.zeros(C, dtype=torch.int64, device=dev); eps = torch.zeros(C, dtype=torch.float64, device=dev)
+        t = mcmc_amd.make_target(mcmc_amd.TARGET_GAUSS_DENSE, d, prec=prec, mem=mcmc_amd.MEM_DEVICE, kernel_hint=hint)
+        ch = mcmc_amd.make_chains(theta, C, draws=draws, n_leapfrogs=n_leap, step_size=eps, mem=mcmc_amd.MEM_DEVICE)
+        mcmc_amd.run("nuts", t, st, ch, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return draws, theta, n_leap, eps
+
+    ref = run(mcmc_amd.KERNEL_NUTS_TICK_LOCAL)
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_async_kernel<")
+    got = run(mcmc_amd.KERNEL_AUTO)
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel<")
+    same = lambda a, b: bool(torch.equal(torch.nan_to_num(a, nan=123.0, posinf=1e308, neginf=-1e308), torch.nan_to_num(b, nan=123.0, posinf=1e308, neginf=-1e308)))
+    assert same(got[0], ref[0]) and same(got[1], ref[1]) and bool(torch.equal(got[2], ref[2])) and same(got[3], ref[3])
+    draws = got[0].cpu().numpy()
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec_h, W=4)
+    for c in [0, 16383, 16384, 40001, 65534]:
+        s = orc.make_settings(seed=2024, n_burnin=half, n_keep=half, n_adapt=half, step=1.0, W=4, chain_id=c)
+        o, info = orc.run_chain(orc.ALGO_NUTS, t, init[c], s, traces=True)
+        assert np.array_equal(draws[:, :, c], o) and int(got[2][c].item()) == info["n_leap"] and float(got[3][c].item()) == info["eps"]
