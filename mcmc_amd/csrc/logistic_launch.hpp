@@ -52,6 +52,14 @@ struct LogitParams {
     const double* Lp;
     const double* Mp;
     const double* Sip;
+    // nuts without bounds / a dense precond_mat (nuts_lds.hpp, "runs cut into pieces"): n_pieces > 1 cuts every chain's run into pieces of piece_len draws handed
+    // out as separate work items; piece_q [n_pieces - 1][C] (0xffffffff = not published) and piece_tail [n_pieces] are set up by the launcher inside split_ws
+    // (logit_lds_nuts_split_bytes(C, d) bytes from the caller, or nullptr: no pieces), which then also makes sure n_accept, n_leap_out, n_exec_out, step_out and
+    // adapt_state exist (the hand-over goes through them) and keeps a copy of the initial values for the replay of chains flagged after their first piece
+    uint32_t n_pieces, piece_len;
+    uint32_t* piece_q;
+    uint32_t* piece_tail;
+    void* split_ws;
 };
 
 enum { LOGIT_MALA = 0, LOGIT_HMC = 1, LOGIT_RWMH = 2, LOGIT_NUTS = 3 };   // RWMH: eps carries par_scale (identity cov_mat); NUTS: nuts_lds.hpp
@@ -63,6 +71,8 @@ enum { LOGIT_TARGET_LOGISTIC = 0, LOGIT_TARGET_DENSE = 1 };
 size_t logit_lds_workspace_bytes(uint32_t d, uint32_t NB, uint64_t C, int target = LOGIT_TARGET_LOGISTIC, int algo = LOGIT_HMC);
 // nuts: workgroups of the persistent grid (32 chain slots each; the workspace is sized by chains = 32 * this)
 uint64_t logit_lds_nuts_workgroups(uint32_t d, uint64_t C, int target);
+// nuts: bytes behind LogitParams::split_ws
+size_t logit_lds_nuts_split_bytes(uint64_t C, uint32_t d);
 // hmc / mala with a dense precond_mat (prm.L_rm and Minv_rm resp. M_rm / Sinv_rm set): bytes of the second workspace `mws` of
 // logit_lds_launch_dense_m -- the block images of the two resp. three matrices and, for the logistic target, the exchange vectors of the
 // streamed products

@@ -2242,12 +2242,16 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
     rp.total_bytes = rp.own_bytes + flag_bytes + (rp.t_doubles + (size_t)rp.n_wg * rp.stride) * sizeof(double);
+    // more chains than chain slots, no bounds, no dense precond_mat: the launcher cuts the runs into pieces (logistic_nuts_impl.hpp) and needs room for the queues
+    const size_t rp_bytes = (rp.total_bytes + 255) & ~(size_t)255;
+    const size_t split_bytes = (!dense_m && !settings->vals_bound && C > n_slots) ? mi::logit_lds_nuts_split_bytes(C, q.d) : 0;
     WsLease base;
-    rc = ws_get(st, rp.total_bytes, base);
+    rc = ws_get(st, rp_bytes + split_bytes, base);
     if (rc) return rc;
     rc = replay_bind(rp, base.p, C, st);
     if (rc) return rc;
     q.nf_flag = rp.flag;
+    if (split_bytes) q.split_ws = static_cast<char*>(base.p) + rp_bytes;
     DevBuf mws;                                          // dense_m: the block images of the two matrices (+ the exchange vectors of their products)
     if (dense_m) HIP_TRY(mws.alloc(mi::logit_lds_nuts_dense_m_bytes(q.d, C, lds_target)));
     const int e = dense_m ? mi::logit_lds_launch_nuts_dense_m(q, X_dev, y_dev, base.p, mws.p, st, lds_target)
@@ -2371,7 +2375,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         const size_t cached = ws_cached_bytes(st);       // (what this stream's workspace already holds counts as free: it is re-used)
         if (want <= MI_NUTS_MOMENTA_MAX_BYTES && want <= (free_b + cached) / 3) mom_bytes = (want + 255) & ~(size_t)255;
     }
-    const size_t split_bytes = memo ? ((mi::nuts_split_workspace_bytes(chains->n_chains) + 255) & ~(size_t)255) : 0;      // (nuts_launch.hip: runs cut into pieces)
+    const size_t split_bytes = memo ? ((mi::nuts_split_workspace_bytes(chains->n_chains, (uint32_t)d) + 255) & ~(size_t)255) : 0;      // (nuts_launch.hip: runs cut into pieces)
     rc = ws_get(st, fixed_bytes + mom_bytes + split_bytes, ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();

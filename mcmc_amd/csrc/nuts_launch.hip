@@ -38,6 +38,14 @@ MemoShape memo_shape(uint64_t C)
 #define MI_MEMO_PIECES 4
 #endif
 constexpr uint32_t MEMO_PIECES = MI_MEMO_PIECES;
+// Runs cut into pieces: a piece that ends stores its chain's theta over prm.theta, but a chain that is FLAGGED in a later piece (non-finite regime) is replayed
+// from its INITIAL values -- the launcher keeps a copy of prm.theta, and the flagged chains' columns come back from it before the replay reads them
+__global__ void restore_flagged_theta_kernel(const uint32_t* __restrict__ flag, const double* __restrict__ backup, double* __restrict__ theta, uint64_t C)
+{
+    if (flag[C] == 0u) return;                           // (the "any chain flagged" word)
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < C && flag[c] != 0u) theta[(size_t)blockIdx.y * C + c] = backup[(size_t)blockIdx.y * C + c];
+}
 template <int NT, bool DIAGM, bool PRE>
 int run_memo_k(const NutsParams& prm_in, hipStream_t st)
 {
@@ -52,6 +60,7 @@ int run_memo_k(const NutsParams& prm_in, hipStream_t st)
     // whole chain after the mean load (configs[3]: 4 chains per slot, ~13 % of the run).  Cut into MEMO_PIECES pieces, the work items are a quarter as long:
     // a piece that is not the first is its chain's continuation in whatever slot is free (nuts_memo_core.hpp, SPLIT; same draws: a continuation call's hand-over)
     prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
+    double* theta_backup = nullptr;
     {
         const uint64_t n_slots = sh.grid * (uint64_t)sh.waves * 16u;
         const uint32_t n_total = prm.n_burnin + prm.n_keep;
@@ -71,6 +80,10 @@ int run_memo_k(const NutsParams& prm_in, hipStream_t st)
             double* dd = reinterpret_cast<double*>(u + 3 * prm.C);
             if (!prm.step_out) prm.step_out = dd;
             if (!prm.adapt_state) prm.adapt_state = dd + prm.C;
+            if (prm.nf_flag != nullptr) {                // (the initial values of chains that may be flagged after their first piece: see restore_flagged_theta_kernel)
+                theta_backup = dd + 4 * prm.C + 32;
+                MI_LAUNCH_TRY(hipMemcpyAsync(theta_backup, prm.theta, (size_t)prm.d * prm.C * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
         }
     }
     if constexpr (PRE) {                                 // every momentum of the run, at full occupancy, before the latency-bound tick starts
@@ -79,6 +92,9 @@ int run_memo_k(const NutsParams& prm_in, hipStream_t st)
         MI_LAUNCH_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)sh.grid), dim3(64 * sh.waves), lds, st, prm);
+    MI_LAUNCH_TRY(hipGetLastError());
+    if (theta_backup != nullptr)
+        hipLaunchKernelGGL(restore_flagged_theta_kernel, dim3((unsigned)((prm.C + 255) / 256), prm.d), dim3(256), 0, st, prm.nf_flag, theta_backup, prm.theta, prm.C);
     return (int)hipGetLastError();
 }
 template <int NT, bool DIAGM>
@@ -131,9 +147,10 @@ size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt)
     return memo_momenta_bytes(C, n_total, ns);
 }
 
-size_t nuts_split_workspace_bytes(uint64_t C)
+size_t nuts_split_workspace_bytes(uint64_t C, uint32_t d)
 {
-    return 256 + (((size_t)(MEMO_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255) + (size_t)7 * C * 8 + 256;
+    // tails | queues | stand-ins for 3 counters, the step size and the dual-averaging state (7 C words) | the copy of the initial values
+    return 256 + (((size_t)(MEMO_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255) + (size_t)7 * C * 8 + 256 + (size_t)d * C * 8 + 256;
 }
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)

@@ -75,7 +75,13 @@ enum : int {
     SC_DA = 48, SC_OKB = 52, SC_ALPHA = 64, SC_U = 112,
     SC_PER_CHAIN = 160
 };
-enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2, NS_INIT = 3, NS_SEARCH = 4 };
+enum : int { NS_NEED_DRAW = 0, NS_TREE = 1, NS_DONE = 2, NS_INIT = 3, NS_SEARCH = 4,
+             NS_WAIT = 5 };      // pieces (below): the slot holds the ticket of a later piece whose chain has not been published yet
+// runs cut into pieces (nuts_lds_body): entries of the piece queues -- not published yet / the chain was flagged before it got here -- and the loads and stores of
+// what one slot hands to another THROUGH MEMORY inside a launch: agent scope, so that a slot on another XCD sees them without a fence's write-back of its whole L2
+enum : uint32_t { PQ_EMPTY = 0xffffffffu, PQ_GONE = 0xfffffffeu };
+template <class T> __device__ __forceinline__ T coh_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void coh_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // doubles of workspace per workgroup (8 waves): vectors, then scalars
 __host__ __device__ constexpr size_t vec_doubles_per_wave(int NSQ) { return (size_t)NVEC * NSQ * 64; }
 __host__ __device__ constexpr size_t sc_doubles_per_wave() { return (size_t)16 * SC_PER_CHAIN; }
@@ -160,6 +166,16 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     // this slot's chain (replicated in the four waves of the tile); cl >= C: none
     uint64_t cl = ((uint64_t)blockIdx.x * 2 + g) * 16 + (lane & 15);
     bool exhausted = false;                              // the counter has run past the last chain: this slot asks no more
+    // Runs cut into PIECES (the launcher: prm.n_pieces > 1 when there are more chains than chain slots; nuts_memo_core.hpp has the reasoning and the protocol):
+    // item v < C is piece 0 of chain v, item v >= C the ticket for entry v - C of the piece queues prm.piece_q [n_pieces - 1][C], where chains are published in
+    // the order in which their previous piece ended; a later piece continues its chain exactly as a continuation call does.  What crosses between slots inside
+    // the launch is written / read at agent scope (lds_nuts::coh_st / coh_ld).  Never with bounds (a checkpoint holds theta in the constrained space) or a dense precond_mat.
+    uint32_t n_pieces = 1u, piece_len = 0xffffffffu;
+    if constexpr (!BOUNDS && !DENSEM) { if (prm.n_pieces > 1u) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; } }
+    const bool pieces = n_pieces > 1u;
+    const uint64_t n_items = C * (uint64_t)n_pieces;
+    bool piece_done = false;     // this chain's piece ended with the draw it just finished
+    bool pub_pend = false;       // ... and it left its slot: wave 0 of the tile publishes it at the next vote, behind the barrier that orders the four waves' stores
 
     // ---- workgroup collectives.  ((S0 + S1) + S2) + S3 of per-wave partial sums (each already butterflied inside the wave), K <= 3 values
     // at a time, and the OR of a flag word over the workgroup's waves (the four waves of a tile hold the same flags: wave 0 of each tile
@@ -334,6 +350,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             row2_pend = kept && prm.draws != nullptr;
             draw++;
         }
+        if (pieces && p && draw < n_total && draw % piece_len == 0u) piece_done = true;
     };
     auto store_row = [&](bool p, int vec, uint32_t idx) __attribute__((always_inline)) {   // kept row `idx` (nuts.cpp:306-309)
         if (!any(p)) return;
@@ -380,18 +397,25 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 for (int k = 0; k < CH; ++k) {
                     const uint32_t dim = dim_of(c0 + k);
                     if constexpr (BOUNDS) tmp[k] = box.leave(tmp[k], c0 + k);
-                    if (dim < d) prm.theta[(size_t)dim * C + cl] = tmp[k];
+                    if (dim < d) { if (pieces) lds_nuts::coh_st(prm.theta + ((size_t)dim * C + cl), tmp[k]); else prm.theta[(size_t)dim * C + cl] = tmp[k]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q == 0 && j4 == 0) {
+                if (pieces) {            // (the launcher provides every one of these arrays when it cuts the runs into pieces)
+                    lds_nuts::coh_st(prm.n_accept + cl, (uint64_t)n_acc); lds_nuts::coh_st(prm.n_leap_out + cl, (uint64_t)n_leap); lds_nuts::coh_st(prm.n_exec_out + cl, (uint64_t)n_exec);
+                    lds_nuts::coh_st(prm.step_out + cl, eps);
+                    lds_nuts::coh_st(prm.adapt_state + cl, h_val_()); lds_nuts::coh_st(prm.adapt_state + C + cl, eps_bar_()); lds_nuts::coh_st(prm.adapt_state + 2 * C + cl, mu_val_());
+                } else {
                 if (prm.n_accept) prm.n_accept[cl] = n_acc;
                 if (prm.n_leap_out) prm.n_leap_out[cl] = n_leap;
                 if (prm.n_exec_out) prm.n_exec_out[cl] = n_exec;
                 if (prm.step_out) prm.step_out[cl] = eps;
                 if (prm.adapt_state) { prm.adapt_state[cl] = h_val_(); prm.adapt_state[C + cl] = eps_bar_(); prm.adapt_state[2 * C + cl] = mu_val_(); }
+                }
             }
         }
+        if (pieces) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (p) pub_pend = true; }     // (published at the next vote: piece_done, nf, draw and cl stay as they are until then)
         if (p) state = NS_DONE;
     };
     // SEARCH ends (or is skipped by a continuation): the dual-averaging state of nuts.cpp:174-176, then the chain waits for its first phase
@@ -400,9 +424,10 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
         if (p) {
             mu_val_() = det_log(10 * eps);                   // nuts.cpp:174
             h_val_() = 0.0;
-            eps_bar_() = (prm.draw0 == 0) ? prm.eps_bar0 : eps;
-            if (prm.draw0 > 0 && prm.draw0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
-                h_val_() = prm.adapt_state[cl]; eps_bar_() = prm.adapt_state[C + cl]; mu_val_() = prm.adapt_state[2 * C + cl];
+            const uint32_t g0 = prm.draw0 + draw;        // the global index of the chain's next draw (a later piece starts at draw > 0 like a continuation call)
+            eps_bar_() = (g0 == 0u) ? prm.eps_bar0 : eps;
+            if (g0 > 0u && g0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+                h_val_() = lds_nuts::coh_ld(prm.adapt_state + cl); eps_bar_() = lds_nuts::coh_ld(prm.adapt_state + C + cl); mu_val_() = lds_nuts::coh_ld(prm.adapt_state + 2 * C + cl);
             }
             state = NS_NEED_DRAW;
         }
@@ -420,6 +445,27 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             const bool want = state == NS_DONE && !exhausted;
             __syncthreads();
             if (q == 0) {
+                if (pieces) {
+                    // chains that left their slot since the last vote (all four waves' stores are complete: each waited, and the barrier above ordered them).  Not
+                    // flagged: the chain finished a piece and is published for piece draw / piece_len (none at the end of the run); flagged (in piece p): it never
+                    // continues -- PQ_GONE in EVERY later queue, so that each queue still receives its C entries
+                    if (any(pub_pend)) {
+                        if (pub_pend && lane < 16) {
+                            const bool flagged = nf;
+                            const uint32_t p_cur = draw / piece_len - (piece_done ? 1u : 0u);
+                            const uint32_t first = flagged ? p_cur + 1u : draw / piece_len;
+                            const uint32_t last = flagged ? n_pieces - 1u : ((draw < n_total) ? first : 0u);
+                            for (uint32_t qq = (first < 1u ? 1u : first); qq <= last && qq < n_pieces; ++qq) {
+                                const uint32_t t = atomicAdd(prm.piece_tail + qq, 1u);
+                                lds_nuts::coh_st(prm.piece_q + ((size_t)(qq - 1u) * C + t), flagged ? (uint32_t)lds_nuts::PQ_GONE : (uint32_t)cl);
+                            }
+                        }
+                    }
+                    // tickets: one look at the queue entry per vote (never a spin)
+                    uint32_t e = lds_nuts::PQ_EMPTY;
+                    if (any(state == NS_WAIT)) { if (state == NS_WAIT && lane < 16) e = lds_nuts::coh_ld(prm.piece_q + (size_t)(cl - C)); }
+                    if (lane < 16) part[FLAG_AT + 17 + lane] = (double)e;
+                }
                 const uint32_t m = (uint32_t)(__ballot(want) & 0xffffull);          // the tile's 16 slots (lanes 0..15; the j4 copies agree)
                 uint32_t base = 0;
                 if (m != 0u) {
@@ -427,18 +473,33 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 }
                 const uint64_t nid = n_slots + base + (uint32_t)__builtin_popcount(m & ((1u << (lane & 15)) - 1u));
-                const bool got = want && nid < C;
+                const bool got = want && nid < n_items;
                 if (lane < 16) part[FLAG_AT + 1 + lane] = got ? (double)nid : -1.0;
+                // (a tile that holds nothing but unserved tickets runs empty ticks meanwhile: an early `continue` with an s_sleep here costs every instantiation
+                //  hundreds of bytes of scratch, and such a tile is rare -- tickets are drawn in the order in which chains are published)
                 const uint32_t fl = ((any(state != NS_DONE) || any(got)) ? 1u : 0u) | (any(state == NS_NEED_DRAW) ? 2u : 0u);
                 if (lane == 0) part[FLAG_AT] = (double)fl;
             }
             __syncthreads();
+            pub_pend = false;
+            if (pieces && state == NS_WAIT) {            // (the ticket's entry, as wave 0 of the tile saw it)
+                const uint32_t e = (uint32_t)part[FLAG_AT + 17 + (lane & 15)];
+                if (e != lds_nuts::PQ_EMPTY) {
+                    if (e == lds_nuts::PQ_GONE) state = NS_DONE;     // flagged before it got here: the slot takes the next item at the next vote
+                    else {                               // the chain goes on where its last piece stopped: counters and draw index here, theta / step size / dual averaging in INIT
+                        draw = (uint32_t)(cl / C) * piece_len;
+                        cl = e;
+                        n_acc = lds_nuts::coh_ld(prm.n_accept + cl); n_leap = lds_nuts::coh_ld(prm.n_leap_out + cl); n_exec = lds_nuts::coh_ld(prm.n_exec_out + cl);
+                        state = NS_INIT;
+                    }
+                }
+            }
             if (want) {
                 const double nid = part[FLAG_AT + 1 + (lane & 15)];
                 if (nid >= 0.0) {                        // a new chain in this slot: everything per-chain starts over
-                    cl = (uint64_t)nid;
-                    state = NS_INIT; nf = false; n_leap = 0; n_exec = 0; n_acc = 0; draw = 0; eps = 1.0;
-                    mv = V_MNTM; mvn = V_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false;
+                    cl = (uint64_t)nid;                  // (nid >= C: the ticket of a later piece)
+                    state = (cl < C) ? NS_INIT : NS_WAIT; nf = false; n_leap = 0; n_exec = 0; n_acc = 0; draw = 0; eps = 1.0;
+                    mv = V_MNTM; mvn = V_MNTM2; pb = 0; pb0 = 0; mom_ready = false; row_pend = false; row2_pend = false; piece_done = false;
                 } else exhausted = true;
             }
         }
@@ -450,7 +511,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             store_row(row_pend, pvec(pb0), row_draw);
             store_row(row2_pend, pvec(pb), draw - 1u);
             row_pend = false; row2_pend = false;
-            retire(state == NS_NEED_DRAW && draw >= n_total);
+            retire(state == NS_NEED_DRAW && (draw >= n_total || piece_done));
             const uint32_t nidx = draw + ((state == NS_TREE) ? 1u : 0u);     // the draw the momentum is for
             const bool gen = (state == NS_TREE || state == NS_NEED_DRAW) && !mom_ready && nidx < n_total;
             double kq = 0.0;
@@ -553,7 +614,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t dim = dim_of(s);
-                    const double v = prm.theta[(size_t)(dim < d ? dim : 0u) * C + cl];
+                    const double v = pieces ? lds_nuts::coh_ld(prm.theta + ((size_t)(dim < d ? dim : 0u) * C + cl)) : prm.theta[(size_t)(dim < d ? dim : 0u) * C + cl];
                     if constexpr (BOUNDS) th[s] = (dim < d) ? box.enter(v, s) : 0.0;      // nuts.cpp:160-162
                     else th[s] = (dim < d) ? v : 0.0;
                 }
@@ -686,9 +747,10 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 H0 = (u_nf ? INF : pU) + pK;             // U0 + K0 (nuts.ipp:50-52)
                 s_first = true;
             }
-            if (init && prm.draw0 != 0) eps = prm.step_out ? prm.step_out[cl] : 1.0;     // a continuation: the step size comes back in
-            start_sampling(init && prm.draw0 != 0);
-            if (init && prm.draw0 == 0) state = NS_SEARCH;
+            const bool cont = prm.draw0 != 0 || draw != 0u;      // a continuation call, or a later piece of a run: the same thing
+            if (init && cont) eps = prm.step_out ? lds_nuts::coh_ld(prm.step_out + cl) : 1.0;     // the step size comes back in
+            start_sampling(init && cont);
+            if (init && !cont) state = NS_SEARCH;
         }
         if (any(srch)) {
             if (srch) {
@@ -845,7 +907,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             bool roll = false;
             if (any(ended)) {
                 end_draw(ended, jd);
-                roll = ended && draw < n_total && mom_ready && !row_pend;
+                roll = ended && draw < n_total && mom_ready && !row_pend && !piece_done;
                 if (ended && !roll) state = NS_NEED_DRAW;                // the phase: its row, its next momentum, or the end of its run
                 roll_state(roll);
             }

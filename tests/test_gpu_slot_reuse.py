@@ -190,6 +190,27 @@ def test_chains_flagged_in_any_piece_are_replayed(hint, grid_cap):
     assert np.array_equal(g["n_accept"], o["n_accept"])
 
 
+@pytest.mark.parametrize("hint", DYN_HINTS)
+def test_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values(hint, grid_cap):
+    """a flat target and a tiny gamma_val: dual averaging drives the step size past 1e150 -- the kinetic energy overflows -- after draw 3, 6 or 12 of 20, i.e. in
+    piece 0, 1 or 2 of the run.  The replay starts from the chain's INITIAL values, which the earlier pieces have overwritten in mi_chains.theta: the launcher
+    keeps a copy (nuts_launch.hip: restore_flagged_theta_kernel)"""
+    d, C = 16, 150
+    prec = synth.dense_gaussian_precision(d) * 1.0e-100
+    init = synth.initial_states(C, d, seed=19)
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=0, n_keep_draws=20, n_adapt_draws=20, max_tree_depth=5, step_size=0.1, gamma_val=2.3e-4)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, kernel_hint=getattr(mcmc_amd, hint))
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel")
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=6, n_burnin=0, n_keep=20, step=0.1, n_adapt=20, max_depth=5, W=4, gamma=2.3e-4)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=0)
+    assert np.isinf(o["eps"]).sum() > C // 2             # (the regime was reached -- by most chains after draw 12)
+    assert np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    assert np.array_equal(g["n_accept"], o["n_accept"]) and np.array_equal(g["theta"], o_draws[-1], equal_nan=True)
+
+
 def test_a_continuation_call_is_cut_into_pieces_too(grid_cap):
     d, C, n_adapt = 64, 200, 14
     prec = synth.dense_gaussian_precision(d, seed=2)
@@ -224,3 +245,75 @@ def test_pieces_without_the_optional_outputs(grid_cap):
     mcmc_amd.run("nuts", tgt, st, ch)
     torch.cuda.synchronize()
     assert np.array_equal(draws.cpu().numpy(), full_draws) and np.array_equal(theta.cpu().numpy(), full["theta"])
+
+
+# ---- the same cut on nuts_lds.hpp (logistic_nuts_impl.hpp: MI_LDS_NUTS_PIECES work items per chain when there are more chains than chain slots and 8+ draws; never
+# with bounds or a dense precond_mat).  The four waves of a chain tile store their quarters of theta, the tile's wave 0 publishes the chain at the next vote.
+def _lds_problem(kind, d, n_rows, seed):
+    bs = ((16 if d <= 64 else 32 if d <= 128 else 64 if d <= 256 else 128) if kind == "logistic" else (48 if d <= 192 else 64 if d <= 256 else 96 if d <= 384 else 128))
+    if kind == "logistic":
+        X, y = synth.logistic_problem(d, n_rows, seed=seed)
+        return mcmc_amd.TARGET_LOGISTIC, dict(X=X, y=y), orc.TargetSpec(orc.TARGET_LOGISTIC, d, X=X, y=y, W=4, blocks=4, block_size=bs, eta_chains=2), bs
+    prec = synth.dense_gaussian_precision(d, seed=seed)
+    return mcmc_amd.TARGET_GAUSS_DENSE, dict(prec=prec), orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4, blocks=4, block_size=bs), bs
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C,cap,burn,keep,adapt,depth,diag", [
+    ("logistic", 100, 16, 150, 1, 10, 9, 10, 5, False),    # 19 draws: pieces of 5, 5, 5, 4; the window ends at a piece boundary; 4-5 chains per slot
+    ("dense", 160, 0, 100, 1, 0, 17, 0, 5, False),         # no adaptation
+    ("logistic", 72, 24, 200, 2, 20, 20, 33, 4, True),     # two workgroups exchange pieces; pieces of 10, the window ends inside the last piece but one; diagonal M
+    ("logistic", 300, 20, 70, 1, 9, 8, 7, 4, False),       # the wide tiles (the momentum leaves the registers for the evaluation)
+    ("dense", 512, 0, 70, 1, 6, 10, 16, 4, True),
+    ("logistic", 100, 16, 150, 1, 4, 4, 4, 5, False),      # the shortest run that is cut: 8 draws, pieces of 2
+])
+def test_lds_nuts_runs_cut_into_pieces_match_the_oracle(kind, d, n_rows, C, cap, burn, keep, adapt, depth, diag, grid_cap):
+    tk, tkw, spec, bs = _lds_problem(kind, d, n_rows, seed=d + 5)
+    init = synth.initial_states(C, d, seed=d + 1) * (0.1 if kind == "logistic" else 0.5)
+    init[40] = 1e200                                  # flagged at its first evaluation (piece 0): PQ_GONE in every later queue
+    M = np.diag(np.random.default_rng(d).uniform(0.4, 2.5, d)) if diag else None
+    kw = dict(precond_mat=M) if diag else {}
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=adapt, max_tree_depth=depth,
+                                   step_size=1.0 if adapt else 0.05, **kw)
+    grid_cap(cap)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=3, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
+    s = orc.make_settings(seed=7, n_burnin=burn, n_keep=keep, n_adapt=adapt, max_depth=depth, step=1.0 if adapt else 0.05, W=4, blocks=4, block_size=bs, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True)
+    assert (g["n_exec"] <= g["n_leap"]).all()
+
+
+def test_lds_nuts_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values(grid_cap):
+    """as test_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values, on the dense Gaussian of nuts_lds.hpp"""
+    d, C = 160, 100
+    tk, tkw, spec, bs = _lds_problem("dense", d, 0, seed=3)
+    tkw = dict(prec=tkw["prec"] * 1.0e-100)
+    spec = orc.TargetSpec(orc.TARGET_DENSE, d, prec=tkw["prec"], W=4, blocks=4, block_size=bs)
+    init = synth.initial_states(C, d, seed=19)
+    st = mcmc_amd.default_settings(rng_seed_value=6, n_burnin_draws=0, n_keep_draws=20, n_adapt_draws=20, max_tree_depth=5, step_size=0.1, gamma_val=2.3e-4)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<")
+    s = orc.make_settings(seed=6, n_burnin=0, n_keep=20, step=0.1, n_adapt=20, max_depth=5, W=4, gamma=2.3e-4, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=0)
+    assert np.isinf(o["eps"]).sum() > C // 2
+    assert np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["eps"], o["eps"], equal_nan=True) and np.array_equal(g["n_accept"], o["n_accept"])
+
+
+def test_lds_nuts_a_continuation_call_is_cut_into_pieces_too(grid_cap):
+    d, C, n_adapt = 100, 120, 14
+    tk, tkw, spec, bs = _lds_problem("logistic", d, 30, seed=8)
+    init = synth.initial_states(C, d, seed=8) * 0.1
+    S = lambda b, k: mcmc_amd.default_settings(rng_seed_value=99, n_burnin_draws=b, n_keep_draws=k, n_adapt_draws=n_adapt, max_tree_depth=4)
+    grid_cap(1)
+    whole, w = mcmc_amd.sample("nuts", tk, init, S(0, 30), want_adapt_state=True, **tkw)
+    a_draws, a = mcmc_amd.sample("nuts", tk, init, S(0, 6), want_adapt_state=True, **tkw)                  # (6 draws: in one piece)
+    b_draws, b = mcmc_amd.sample("nuts", tk, a["theta"].T, S(0, 24), draw0=6, step_size_in=a["eps"], adapt_state_in=a["adapt_state"], want_adapt_state=True, **tkw)
+    assert np.array_equal(np.concatenate([a_draws, b_draws], axis=0), whole)
+    assert np.array_equal(a["n_leap"] + b["n_leap"], w["n_leap"]) and np.array_equal(b["eps"], w["eps"]) and np.array_equal(b["adapt_state"], w["adapt_state"])
+    s = orc.make_settings(seed=99, n_burnin=0, n_keep=30, n_adapt=n_adapt, max_depth=4, step=1.0, W=4, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=0)
+    assert np.array_equal(whole, o_draws) and np.array_equal(w["eps"], o["eps"])

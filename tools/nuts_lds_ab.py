@@ -28,7 +28,7 @@ print(f"{best * 1e3:.1f} ms  {float(nleap.double().sum()):.4e} leapfrogs  checks
 '''
 libs = [a for a in sys.argv[1:] if a.endswith(".so")]
 only = [a for a in sys.argv[1:] if not a.endswith(".so")]
-SHAPES = [("dense", 256, 0, 4096, 20), ("dense", 512, 0, 4096, 10), ("dense", 256, 0, 65536, 20), ("logistic", 512, 1024, 16384, 10), ("dense", 512, 0, 32768, 10),
+SHAPES = [("logistic", 512, 1024, 32768, 8), ("dense", 256, 0, 4096, 20), ("dense", 512, 0, 4096, 10), ("dense", 256, 0, 65536, 20), ("logistic", 512, 1024, 16384, 10), ("dense", 512, 0, 32768, 10),
           ("logistic", 64, 1024, 16384, 20), ("logistic", 32, 256, 16384, 20), ("logistic", 20, 100, 65536, 20)]
 for shp in SHAPES:
     if only and f"{shp[0]}{shp[1]}x{shp[3]}" not in only: continue
