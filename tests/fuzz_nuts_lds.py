@@ -3,7 +3,9 @@
 tests/test_gpu_literal_paths.py and the CPU suite) -- both run on the GPU, so the cases can be long: logistic / dense targets of every
 instantiation, ragged workgroups, draw counts and adaptation windows incl. none, depth caps 1..10, step sizes from tiny to absurd, a
 diagonal precond_mat, chains that start in the non-finite regime, runs cut in two.  Bit-exact or report.
-Usage (GPU box): python tests/fuzz_nuts_lds.py [n_cases] [seed]"""
+Usage (GPU box): python tests/fuzz_nuts_lds.py [n_cases] [seed] [grid_cap]
+grid_cap > 0: the persistent grid is capped at that many workgroups (32 chain slots each), chain counts go up to 300 and draw counts to 28 -- more chains than slots, so
+chains are handed out by the counter and the runs are cut into PIECES that migrate between slots (logistic_nuts_impl.hpp)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -12,8 +14,9 @@ import mcmc_amd
 from mcmc_amd import synth
 
 
-def sweep(n_cases=30, seed=1, verbose=True):
+def sweep(n_cases=30, seed=1, verbose=True, cap=0):
     rng = np.random.default_rng(seed)
+    mcmc_amd.test_set_grid_cap(cap)
     fails = 0
     for case in range(n_cases):
         kind = str(rng.choice(["logistic", "dense"]))
@@ -25,8 +28,8 @@ def sweep(n_cases=30, seed=1, verbose=True):
         else:
             d = int(rng.choice([129, 160, 192, 193, 256, 257, 384, 385, 512]))
             tk, tkw, scale = mcmc_amd.TARGET_GAUSS_DENSE, dict(prec=synth.dense_gaussian_precision(d, seed=int(rng.integers(1, 99)))), 0.5
-        C = int(rng.choice([1, 5, 16, 17, 32, 33, 70, 130]))
-        burn, keep = int(rng.integers(0, 10)), int(rng.integers(0, 10))
+        C = int(rng.choice([1, 5, 16, 17, 32, 33, 70, 130])) if cap == 0 else int(rng.choice([33, 70, 130, 200, 300]))
+        burn, keep = (int(rng.integers(0, 10)), int(rng.integers(0, 10))) if cap == 0 else (int(rng.integers(0, 15)), int(rng.integers(0, 15)))
         if burn + keep == 0: keep = 1
         adapt = int(rng.integers(0, burn + keep + 3))
         max_depth = int(rng.choice([1, 2, 3, 5, 7, 10]))
@@ -78,6 +81,6 @@ def sweep(n_cases=30, seed=1, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     s = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    f = sweep(n, s)
+    f = sweep(n, s, cap=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     print("mismatching cases:", f)
     sys.exit(1 if f else 0)
