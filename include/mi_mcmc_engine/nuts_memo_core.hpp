@@ -433,7 +433,11 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             h_val_() = 0.0;
             const uint32_t g0 = prm.draw0 + draw;        // the global index of the chain's next draw (SPLIT: a later piece starts at draw > 0 like a continuation call)
             eps_bar_() = (g0 == 0u) ? prm.eps_bar0 : eps_();
-            if (g0 > 0u && g0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+            // a continuation inside the adaptation window -- or (SPLIT) ANY later piece of a run: behind the window the triple is dead weight for the draws, but it is
+            // what the call exports at its end (mi_chains.nuts_adapt_state), and that must not depend on the cut
+            bool later_piece = false;
+            if constexpr (POL::SPLIT) later_piece = draw != 0u;
+            if (((g0 > 0u && g0 <= n_adapt) || later_piece) && prm.adapt_state != nullptr) {
                 h_val_() = coh_ld(prm.adapt_state + cl); eps_bar_() = coh_ld(prm.adapt_state + C + cl); mu_val_() = coh_ld(prm.adapt_state + 2 * C + cl);
             }
             state = NS_NEED_DRAW;

@@ -426,7 +426,9 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
             h_val_() = 0.0;
             const uint32_t g0 = prm.draw0 + draw;        // the global index of the chain's next draw (a later piece starts at draw > 0 like a continuation call)
             eps_bar_() = (g0 == 0u) ? prm.eps_bar0 : eps;
-            if (g0 > 0u && g0 <= n_adapt && prm.adapt_state != nullptr) {      // a continuation inside the adaptation window
+            // a continuation inside the adaptation window -- or ANY later piece of a run: behind the window the triple is dead weight for the draws, but it is what
+            // the call exports at its end (mi_chains.nuts_adapt_state), and that must not depend on the cut
+            if (((g0 > 0u && g0 <= n_adapt) || (pieces && draw != 0u)) && prm.adapt_state != nullptr) {
                 h_val_() = lds_nuts::coh_ld(prm.adapt_state + cl); eps_bar_() = lds_nuts::coh_ld(prm.adapt_state + C + cl); mu_val_() = lds_nuts::coh_ld(prm.adapt_state + 2 * C + cl);
             }
             state = NS_NEED_DRAW;

@@ -59,10 +59,10 @@ def sweep(n_cases=30, seed=1, verbose=True, cap=0):
         b_draws, b = mcmc_amd.sample("nuts", tk, init, S(burn, keep), chain0=chain0, want_adapt_state=True, kernel_hint=mcmc_amd.KERNEL_LITERAL, **tkw)
         bits = lambda v: np.ascontiguousarray(v, dtype=np.float64).view(np.uint64)
         same = lambda u, v: np.array_equal(bits(u), bits(v)) or np.array_equal(u, v, equal_nan=True)     # (NaN payloads may differ)
-        ok = (kernel.startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().startswith("literal_kernel<")
-              and same(a_draws, b_draws) and np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["n_leap"], b["n_leap"])
-              and np.array_equal(a["n_accept"], b["n_accept"]) and same(a["eps"], b["eps"]) and same(a["theta"], b["theta"])
-              and same(a["adapt_state"], b["adapt_state"]))
+        diff = [k for k, v in dict(kernel=kernel.startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().startswith("literal_kernel<"), draws=same(a_draws, b_draws),
+                                   depth=np.array_equal(a["depth"], b["depth"]), n_leap=np.array_equal(a["n_leap"], b["n_leap"]), n_accept=np.array_equal(a["n_accept"], b["n_accept"]),
+                                   eps=same(a["eps"], b["eps"]), theta=same(a["theta"], b["theta"]), adapt_state=same(a["adapt_state"], b["adapt_state"])).items() if not v]
+        ok = not diff
         cut = None
         if ok and not wild and burn == 0 and keep >= 2 and "vals_bound" not in kw:   # (a checkpoint holds theta in the natural space: transform(inv_transform(.)) is not the identity in floating point)   # the same run cut in two on the tiled kernel (all draws kept: rows compare one to one)
             cut = int(rng.integers(1, keep))
@@ -73,7 +73,7 @@ def sweep(n_cases=30, seed=1, verbose=True, cap=0):
         if verbose or not ok:
             print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, n_rows=(n_rows if kind == "logistic" else 0), C=C, burn=burn, keep=keep, adapt=adapt,
                                                    max_depth=max_depth, eps0=eps0, chain0=chain0, wild=wild, diag="precond_mat" in kw and not dense_m, dense_m=bool(dense_m), bounds="vals_bound" in kw, cut=cut,
-                                                   seed=int(sd), kernel=kernel, leaps=int(a["n_leap"].sum())), flush=True)
+                                                   seed=int(sd), kernel=kernel, leaps=int(a["n_leap"].sum()), differ=diff), flush=True)
         fails += 0 if ok else 1
     return fails
 

@@ -317,3 +317,26 @@ def test_lds_nuts_a_continuation_call_is_cut_into_pieces_too(grid_cap):
     s = orc.make_settings(seed=99, n_burnin=0, n_keep=30, n_adapt=n_adapt, max_depth=4, step=1.0, W=4, blocks=4, block_size=bs)
     o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=0)
     assert np.array_equal(whole, o_draws) and np.array_equal(w["eps"], o["eps"])
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C", [("memo", 64, 0, 150), ("logistic", 100, 16, 100), ("dense", 160, 0, 100)])
+@pytest.mark.parametrize("adapt", [0, 7, 30])
+def test_what_a_call_exports_does_not_depend_on_the_cut(kind, d, n_rows, C, adapt, grid_cap):
+    """mi_chains.nuts_adapt_state (h, eps_bar, mu) is dead weight for the draws behind the adaptation window, but a piece that starts there must still carry it: the
+    run cut into pieces (grid cap 1) exports what the uncut run (no cap: fewer chains than chain slots) exports -- found by tests/fuzz_nuts_lds.py with a grid cap"""
+    if kind == "memo":
+        tk, tkw = mcmc_amd.TARGET_GAUSS_DENSE, dict(prec=synth.dense_gaussian_precision(d, seed=6))
+    else:
+        tk, tkw, _, _ = _lds_problem(kind, d, n_rows, seed=d)
+    init = synth.initial_states(C, d, seed=5) * (0.1 if kind == "logistic" else 0.5)
+    st = mcmc_amd.default_settings(rng_seed_value=31, n_burnin_draws=8, n_keep_draws=9, n_adapt_draws=adapt, max_tree_depth=5, step_size=0.3)
+    grid_cap(0)
+    u_draws, u = mcmc_amd.sample("nuts", tk, init, st, want_adapt_state=True, **tkw)
+    name = mcmc_amd.last_kernel()
+    assert name.startswith("nuts_gauss_memo_kernel" if kind == "memo" else "logit_lds_kernel<")
+    grid_cap(1)
+    c_draws, c = mcmc_amd.sample("nuts", tk, init, st, want_adapt_state=True, **tkw)
+    assert mcmc_amd.last_kernel() == name
+    assert np.array_equal(c_draws, u_draws)
+    for k in ("adapt_state", "eps", "theta", "n_leap", "n_accept", "depth"):
+        assert np.array_equal(c[k], u[k]), k
