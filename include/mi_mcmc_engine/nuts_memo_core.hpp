@@ -380,9 +380,10 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 const double2 t = *reinterpret_cast<const double2*>(wsp(pvec(pb), 2 * b));
                 double* dst = prm.theta + ((size_t)(8u * b + j4) * C + cl);
                 if constexpr (POL::SPLIT) {
-                    if (pieces) {
-                        if (8u * b + j4 < d) coh_st(dst, pol.leave(t.x, 2 * b));
-                        if (8u * b + 4 + j4 < d) coh_st(dst + (size_t)4 * C, pol.leave(t.y, 2 * b + 1));
+                    if (pieces) {                        // (a piece's end inside the run: the chain's own -- transformed -- values, which the next piece takes as they are;
+                                                         //  through leave() and enter() a bounded dimension would be rounded twice)
+                        if (8u * b + j4 < d) coh_st(dst, piece_done ? t.x : pol.leave(t.x, 2 * b));
+                        if (8u * b + 4 + j4 < d) coh_st(dst + (size_t)4 * C, piece_done ? t.y : pol.leave(t.y, 2 * b + 1));
                         continue;
                     }
                 }
@@ -585,7 +586,9 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                     if constexpr (POL::SPLIT) { t0 = coh_ld(src); t1 = coh_ld(src + (in1 ? (size_t)4 * C : 0)); }     // (a later piece: what another slot stored in this launch)
                     else { t0 = src[0]; t1 = src[in1 ? (size_t)4 * C : 0]; }
                 }
-                if (init) st_pair(MV_PREV, 2 * b, in0 ? pol.enter(t0, 8 * b + j4) : 0.0, in1 ? pol.enter(t1, 8 * b + 4 + j4) : 0.0);   // nuts.cpp:160-162
+                bool raw = false;                        // (SPLIT, a later piece: the values are the chain's own already)
+                if constexpr (POL::SPLIT) raw = draw != 0u;
+                if (init) st_pair(MV_PREV, 2 * b, in0 ? (raw ? t0 : pol.enter(t0, 8 * b + j4)) : 0.0, in1 ? (raw ? t1 : pol.enter(t1, 8 * b + 4 + j4)) : 0.0);   // nuts.cpp:160-162
             }
             // z_init (nuts.cpp:166-168) feeds K0 of nuts_find_initial_step_size only: a continuation -- a call with draw0 > 0 or (SPLIT) a later piece -- goes
             // straight to its first draw, so its 16 NT Box-Muller normals (a third of a tick of the whole wave) are not made; zeros keep the idle update finite

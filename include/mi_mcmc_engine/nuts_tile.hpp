@@ -38,7 +38,7 @@ template <class T, bool GEN>
 struct TileMemoPolicy {
     static constexpr int NT = T::NT, NS = 4 * NT;
     static constexpr bool REPLAY = false;
-    static constexpr bool SPLIT = false;         // whole chains per slot (the persistent grid of this route hands out chains, not pieces)
+    static constexpr bool SPLIT = true;          // the engine may cut the runs into pieces (TileParams::n_pieces); with bounds the hand-over carries theta in the transformed space
     static constexpr bool PRE_MOM = false;       // momenta generated inside the tick (the table of nuts_memo.hpp belongs to the built-in kernel's launcher)
 #ifndef MI_TILE_LANE_WALK
 #define MI_TILE_LANE_WALK 1

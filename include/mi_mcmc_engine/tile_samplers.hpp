@@ -72,6 +72,12 @@ struct TileParams {
     // the device (m_sqrt above: of CHOL_LOWER(precond_mat)); log_det carries LOG_DET(eps^2 precond_mat).  nullptr: the identity
     const double* m;
     const double* s_inv;
+    // nuts on a persistent grid (next_chain set) with more chains than chain slots: the runs cut into n_pieces pieces of piece_len draws that migrate between slots
+    // (nuts_memo_core.hpp, SPLIT); piece_q [n_pieces - 1][C] and piece_tail [n_pieces] set up by the engine (launch_common.hpp: memo_setup_pieces), which then
+    // also provides n_accept, n_leap, n_exec, step_out and adapt_state (the hand-over goes through them).  n_pieces <= 1: whole chains per slot
+    uint32_t n_pieces, piece_len;
+    uint32_t* piece_q;
+    uint32_t* piece_tail;
 };
 
 // ---- settings.vals_bound and / or a diagonal precond_mat on the tile route, with the arithmetic of the general built-in kernels

@@ -36,6 +36,8 @@ int launch_nuts_gauss_memo(const NutsParams& prm, int nt, hipStream_t st, bool d
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m);
 // bytes behind NutsParams::split_ws: the piece queues of a run cut into pieces and stand-ins for outputs the caller did not ask for (nuts_launch.hip)
 size_t nuts_split_workspace_bytes(uint64_t C, uint32_t d);
+struct TileParams;
+int nuts_tile_setup_pieces(TileParams& p, void* split_ws, hipStream_t st);          // nuts_bounded_launch.hip: the same cut on the tile route's persistent grid
 // bytes of the table of momenta the memoised kernel reads when prm.mom is set (filled by its launcher's pre-pass: nuts_memo.hpp)
 size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt);
 uint64_t nuts_tile_grid(uint64_t C);                                // nuts_bounded_launch.hip: workgroups of the persistent grid of the tile-policy tick

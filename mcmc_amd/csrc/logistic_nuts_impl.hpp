@@ -54,11 +54,11 @@ int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void
     hipError_t e = hipMemsetAsync(prm.nuts_next, 0, 64, st);
     if (e != hipSuccess) return (int)e;
     // More chains than chain slots: the runs are cut into pieces, as nuts_launch.hip cuts those of nuts_gauss_memo_kernel (the reasoning is there; the protocol
-    // in nuts_lds.hpp).  Not with bounds (a hand-over holds theta in the constrained space: leaving and re-entering the box rounds twice).  Pieces of two draws
+    // in nuts_lds.hpp).  With bounds the hand-over carries theta in the transformed space (nuts_lds.hpp).  Pieces of two draws
     // and more: a hand-over costs one evaluation, a draw here tens of them
     prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
     double* theta_backup = nullptr;
-    if constexpr (!BOUNDS && NTQ > 1) {                  // (NTQ = 1, d <= 64: measured 2 % SLOWER cut -- 65 536 chains of d = 20: 56.1 -> 57.1 ms; the wider tiles gain 4-9 %)
+    if constexpr (NTQ > 1) {                  // (NTQ = 1, d <= 64: measured 2 % SLOWER cut -- 65 536 chains of d = 20: 56.1 -> 57.1 ms; the wider tiles gain 4-9 %)
         const uint32_t n_total = prm.n_burnin + prm.n_keep;
         if (prm.split_ws != nullptr && prm.nf_flag != nullptr && prm.C > (uint64_t)n_wg * 32u && n_total >= 2u * LDS_NUTS_PIECES && prm.C < (1ull << 28)) {
             prm.piece_len = (n_total + LDS_NUTS_PIECES - 1u) / LDS_NUTS_PIECES;

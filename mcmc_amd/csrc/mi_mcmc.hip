@@ -1401,13 +1401,15 @@ int mi_mcmc_run_tile_target(int algo, uint64_t d, int nt, int wpb, uint64_t lds_
         // a persistent grid (one workgroup per CU at most) with the chains handed out dynamically: the workspace is sized by the grid's chain slots
         const uint64_t n_wg = mi::nuts_tile_grid(chains->n_chains);
         const size_t vec_bytes = (mi::tile_nuts::ws_bytes_grid(n_wg, nt_pad) + 255) & ~(size_t)255;
-        rc = ws_get(st, vec_bytes + 256, ws);
+        const size_t split_bytes = chains->n_chains > n_wg * 64 ? mi::nuts_split_workspace_bytes(chains->n_chains, 0) : 0;     // (more chains than chain slots: the runs cut into pieces)
+        rc = ws_get(st, vec_bytes + 256 + split_bytes, ws);
         if (rc) return rc;
         p.ws = ws.as<double>();
         p.nuts_grid = (uint32_t)n_wg;
         p.next_chain = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + vec_bytes);
         HIP_TRY(hipMemsetAsync(p.next_chain, 0, sizeof(uint32_t), st));
         p.n_exec = sc.dev.n_leapfrogs_executed; sc.exec_written = p.n_exec != nullptr;     // (each distinct state of a doubling is evaluated once)
+        if (split_bytes) { const int e = mi::nuts_tile_setup_pieces(p, static_cast<char*>(ws.p) + vec_bytes + 256, st); if (e != 0) return fail(MI_ERR_HIP, "tile target nuts: %s", hipGetErrorString((hipError_t)e)); }
     } else {
         rc = ws_get(st, (size_t)3 * 16 * nt * ((chains->n_chains + 15) / 16 + 8) * 16 * sizeof(double), ws);
         if (rc) return rc;
@@ -2242,9 +2244,9 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
     rp.total_bytes = rp.own_bytes + flag_bytes + (rp.t_doubles + (size_t)rp.n_wg * rp.stride) * sizeof(double);
-    // more chains than chain slots, no bounds, no dense precond_mat: the launcher cuts the runs into pieces (logistic_nuts_impl.hpp) and needs room for the queues
+    // more chains than chain slots, no dense precond_mat: the launcher cuts the runs into pieces (logistic_nuts_impl.hpp) and needs room for the queues
     const size_t rp_bytes = (rp.total_bytes + 255) & ~(size_t)255;
-    const size_t split_bytes = (!dense_m && !settings->vals_bound && C > n_slots) ? mi::logit_lds_nuts_split_bytes(C, q.d) : 0;
+    const size_t split_bytes = (!dense_m && C > n_slots) ? mi::logit_lds_nuts_split_bytes(C, q.d) : 0;
     WsLease base;
     rc = ws_get(st, rp_bytes + split_bytes, base);
     if (rc) return rc;
@@ -2375,7 +2377,7 @@ int mi_mcmc_nuts_run(const mi_target* target, const mi_settings* settings, mi_ch
         const size_t cached = ws_cached_bytes(st);       // (what this stream's workspace already holds counts as free: it is re-used)
         if (want <= MI_NUTS_MOMENTA_MAX_BYTES && want <= (free_b + cached) / 3) mom_bytes = (want + 255) & ~(size_t)255;
     }
-    const size_t split_bytes = memo ? ((mi::nuts_split_workspace_bytes(chains->n_chains, (uint32_t)d) + 255) & ~(size_t)255) : 0;      // (nuts_launch.hip: runs cut into pieces)
+    const size_t split_bytes = (memo || bounded_memo) ? ((mi::nuts_split_workspace_bytes(chains->n_chains, (uint32_t)d) + 255) & ~(size_t)255) : 0;      // (nuts_launch.hip: runs cut into pieces)
     rc = ws_get(st, fixed_bytes + mom_bytes + split_bytes, ws);
     if (rc) return rc;     // every workspace vector is stored by the kernel before it is loaded: no memset needed
     prm.ws = ws.as<double>();

@@ -56,6 +56,12 @@ uint64_t nuts_tile_grid(uint64_t C)
     const uint64_t need = (C + 63) / 64;
     return cap_grid(need < (uint64_t)n_cu ? need : (uint64_t)n_cu);
 }
+// the tile route (mi_mcmc_run_tile_target): the same cut for a user target's nuts_tile_kernel on its persistent grid
+int nuts_tile_setup_pieces(TileParams& p, void* split_ws, hipStream_t st)
+{
+    double* unused = nullptr;
+    return memo_setup_pieces(p, split_ws, (uint64_t)p.nuts_grid * 64u, st, &unused);
+}
 size_t nuts_bounded_workspace_bytes(uint64_t C, int nt) { return tile_nuts::ws_bytes_grid(nuts_tile_grid(C), nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8); }
 
 int launch_nuts_gauss_bounded(const NutsParams& q, int nt, hipStream_t st)
@@ -71,6 +77,10 @@ int launch_nuts_gauss_bounded(const NutsParams& q, int nt, hipStream_t st)
     p.vals_bound = q.vals_bound; p.btype = q.btype; p.lb = q.lb; p.ub = q.ub; p.m_sqrt = q.m_sqrt; p.m_inv = q.m_inv;
     const int ntp = nt <= 1 ? 1 : nt == 2 ? 2 : nt <= 4 ? 4 : 8;
     p.lds_user_doubles = (uint32_t)(ntp * 4 * ntp * 64);
+    // more chains than the grid's chain slots: the runs cut into pieces, as nuts_launch.hip cuts the plain kernel's (no copy of the initial values: on this
+    // policy a chain is never flagged)
+    double* unused = nullptr;
+    MI_LAUNCH_TRY((hipError_t)memo_setup_pieces(p, q.split_ws, (uint64_t)p.nuts_grid * 64u, st, &unused));
     return MI_DISPATCH_NT(nt, (run<1>(p, q.P, q.sep_target, st)), (run<2>(p, q.P, q.sep_target, st)), (run<4>(p, q.P, q.sep_target, st)), (run<8>(p, q.P, q.sep_target, st)));
 }
 

@@ -34,10 +34,6 @@ MemoShape memo_shape(uint64_t C)
     const uint64_t need = (C + 16 * waves - 1) / (16 * waves), cap = (uint64_t)n_cu * (uint64_t)per_cu;
     return MemoShape{waves, cap_grid(need < cap ? need : cap)};
 }
-#ifndef MI_MEMO_PIECES
-#define MI_MEMO_PIECES 4
-#endif
-constexpr uint32_t MEMO_PIECES = MI_MEMO_PIECES;
 // Runs cut into pieces: a piece that ends stores its chain's theta over prm.theta, but a chain that is FLAGGED in a later piece (non-finite regime) is replayed
 // from its INITIAL values -- the launcher keeps a copy of prm.theta, and the flagged chains' columns come back from it before the replay reads them
 __global__ void restore_flagged_theta_kernel(const uint32_t* __restrict__ flag, const double* __restrict__ backup, double* __restrict__ theta, uint64_t C)
@@ -59,32 +55,12 @@ int run_memo_k(const NutsParams& prm_in, hipStream_t st)
     // More chains than chain slots: a slot runs several chains one after the other, and the run ends when the slot with the most work does -- up to one
     // whole chain after the mean load (configs[3]: 4 chains per slot, ~13 % of the run).  Cut into MEMO_PIECES pieces, the work items are a quarter as long:
     // a piece that is not the first is its chain's continuation in whatever slot is free (nuts_memo_core.hpp, SPLIT; same draws: a continuation call's hand-over)
-    prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
     double* theta_backup = nullptr;
-    {
-        const uint64_t n_slots = sh.grid * (uint64_t)sh.waves * 16u;
-        const uint32_t n_total = prm.n_burnin + prm.n_keep;
-        if (prm.split_ws != nullptr && prm.C > n_slots && n_total >= 4u * MEMO_PIECES && prm.C < (1ull << 28)) {
-            prm.piece_len = (n_total + MEMO_PIECES - 1u) / MEMO_PIECES;
-            prm.n_pieces = (n_total + prm.piece_len - 1u) / prm.piece_len;
-            char* b = static_cast<char*>(prm.split_ws);
-            prm.piece_tail = reinterpret_cast<uint32_t*>(b);
-            prm.piece_q = reinterpret_cast<uint32_t*>(b + 256);
-            const size_t q_bytes = ((size_t)(MEMO_PIECES - 1u) * prm.C * sizeof(uint32_t) + 255) & ~(size_t)255;
-            MI_LAUNCH_TRY(hipMemsetAsync(prm.piece_tail, 0, 256, st));
-            MI_LAUNCH_TRY(hipMemsetAsync(prm.piece_q, 0xff, q_bytes, st));
-            uint64_t* u = reinterpret_cast<uint64_t*>(b + 256 + q_bytes);       // stand-ins for what the hand-over goes through
-            if (!prm.n_accept) prm.n_accept = u;
-            if (!prm.n_leap) prm.n_leap = u + prm.C;
-            if (!prm.n_exec) prm.n_exec = u + 2 * prm.C;
-            double* dd = reinterpret_cast<double*>(u + 3 * prm.C);
-            if (!prm.step_out) prm.step_out = dd;
-            if (!prm.adapt_state) prm.adapt_state = dd + prm.C;
-            if (prm.nf_flag != nullptr) {                // (the initial values of chains that may be flagged after their first piece: see restore_flagged_theta_kernel)
-                theta_backup = dd + 4 * prm.C + 32;
-                MI_LAUNCH_TRY(hipMemcpyAsync(theta_backup, prm.theta, (size_t)prm.d * prm.C * sizeof(double), hipMemcpyDeviceToDevice, st));
-            }
-        }
+    MI_LAUNCH_TRY((hipError_t)memo_setup_pieces(prm, prm.split_ws, sh.grid * (uint64_t)sh.waves * 16u, st, &theta_backup));
+    if (theta_backup != nullptr) {
+        if (prm.nf_flag != nullptr)                      // (the initial values of chains that may be flagged after their first piece: see restore_flagged_theta_kernel)
+            MI_LAUNCH_TRY(hipMemcpyAsync(theta_backup, prm.theta, (size_t)prm.d * prm.C * sizeof(double), hipMemcpyDeviceToDevice, st));
+        else theta_backup = nullptr;
     }
     if constexpr (PRE) {                                 // every momentum of the run, at full occupancy, before the latency-bound tick starts
         const uint64_t n_waves = ((prm.C + 15) / 16) * (uint64_t)(prm.n_burnin + prm.n_keep);
@@ -147,11 +123,7 @@ size_t nuts_memo_momenta_bytes(uint64_t C, uint32_t n_total, int nt)
     return memo_momenta_bytes(C, n_total, ns);
 }
 
-size_t nuts_split_workspace_bytes(uint64_t C, uint32_t d)
-{
-    // tails | queues | stand-ins for 3 counters, the step size and the dual-averaging state (7 C words) | the copy of the initial values
-    return 256 + (((size_t)(MEMO_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255) + (size_t)7 * C * 8 + 256 + (size_t)d * C * 8 + 256;
-}
+size_t nuts_split_workspace_bytes(uint64_t C, uint32_t d) { return memo_split_bytes(C, d); }
 
 size_t nuts_memo_workspace_bytes(uint64_t C, int nt, bool diag_m)
 {

@@ -169,9 +169,10 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     // Runs cut into PIECES (the launcher: prm.n_pieces > 1 when there are more chains than chain slots; nuts_memo_core.hpp has the reasoning and the protocol):
     // item v < C is piece 0 of chain v, item v >= C the ticket for entry v - C of the piece queues prm.piece_q [n_pieces - 1][C], where chains are published in
     // the order in which their previous piece ended; a later piece continues its chain exactly as a continuation call does.  What crosses between slots inside
-    // the launch is written / read at agent scope (lds_nuts::coh_st / coh_ld).  Never with bounds (a checkpoint holds theta in the constrained space) or a dense precond_mat.
+    // the launch is written / read at agent scope (lds_nuts::coh_st / coh_ld).  With bounds the hand-over carries theta in the TRANSFORMED space, as the chain holds it
+    // (through inv_transform and transform it would be rounded twice): prm.theta holds constrained values again when a chain's last piece has ended.  Never with a dense precond_mat.
     uint32_t n_pieces = 1u, piece_len = 0xffffffffu;
-    if constexpr (!BOUNDS && !DENSEM) { if (prm.n_pieces > 1u) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; } }
+    if constexpr (!DENSEM) { if (prm.n_pieces > 1u) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; } }
     const bool pieces = n_pieces > 1u;
     const uint64_t n_items = C * (uint64_t)n_pieces;
     bool piece_done = false;     // this chain's piece ended with the draw it just finished
@@ -396,7 +397,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
                     const uint32_t dim = dim_of(c0 + k);
-                    if constexpr (BOUNDS) tmp[k] = box.leave(tmp[k], c0 + k);
+                    if constexpr (BOUNDS) { const double lv = box.leave(tmp[k], c0 + k); tmp[k] = (pieces && piece_done) ? tmp[k] : lv; }     // (a piece's end inside the run: the transformed value)
                     if (dim < d) { if (pieces) lds_nuts::coh_st(prm.theta + ((size_t)dim * C + cl), tmp[k]); else prm.theta[(size_t)dim * C + cl] = tmp[k]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -617,7 +618,7 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 for (int s = 0; s < NS; ++s) {
                     const uint32_t dim = dim_of(s);
                     const double v = pieces ? lds_nuts::coh_ld(prm.theta + ((size_t)(dim < d ? dim : 0u) * C + cl)) : prm.theta[(size_t)(dim < d ? dim : 0u) * C + cl];
-                    if constexpr (BOUNDS) th[s] = (dim < d) ? box.enter(v, s) : 0.0;      // nuts.cpp:160-162
+                    if constexpr (BOUNDS) th[s] = (dim < d) ? ((pieces && draw != 0u) ? v : box.enter(v, s)) : 0.0;      // nuts.cpp:160-162 (a later piece: already transformed)
                     else th[s] = (dim < d) ? v : 0.0;
                 }
             }

@@ -86,6 +86,35 @@ def test_recycled_slots_of_the_bounded_tick_on_the_tile_policy(grid_cap):
     assert (g["n_exec"] <= g["n_leap"]).all()
 
 
+@pytest.mark.parametrize("mass", [False, True])
+def test_the_bounded_tick_on_the_tile_policy_is_cut_into_pieces_too(mass, grid_cap):
+    """more chains than chain slots and 16+ draws: the runs of nuts with vals_bound are cut into pieces as the plain kernel's are (nuts_bounded_launch.hip:
+    memo_setup_pieces); the hand-over carries theta in the TRANSFORMED space.  Against the oracle, and the cut run exports what the uncut run exports."""
+    d, C = 100, 230
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = np.clip(synth.initial_states(C, d, seed=29) * 0.5, -1.0, 1.5)
+    init[140, 7] = np.inf
+    lb = np.where(np.arange(d) % 3 == 0, -1.5, -np.inf); ub = np.where(np.arange(d) % 4 == 0, 2.0, np.inf)
+    M = np.diag(np.random.default_rng(3).uniform(0.4, 2.5, d)) if mass else None
+    kw = dict(precond_mat=M) if mass else {}
+    st = mcmc_amd.default_settings(rng_seed_value=41, n_burnin_draws=10, n_keep_draws=9, n_adapt_draws=12, max_tree_depth=5,
+                                   vals_bound=1, lower_bounds=lb, upper_bounds=ub, **kw)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=11, want_adapt_state=True)
+    assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<built-in Gaussian")
+    t = orc.TargetSpec(orc.TARGET_DENSE, d, prec=prec, W=4)
+    s = orc.make_settings(seed=41, n_burnin=10, n_keep=9, step=1.0, n_adapt=12, max_depth=5, W=4, lower=lb, upper=ub, precond=M)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, t, init, s, chain0=11)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"], equal_nan=True) and np.array_equal(g_draws, o_draws, equal_nan=True)
+    assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True)
+    grid_cap(0)
+    u_draws, u = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=11, want_adapt_state=True)
+    assert np.array_equal(u_draws, g_draws, equal_nan=True)
+    for k in ("adapt_state", "eps", "theta", "n_leap", "n_exec", "n_accept", "depth"):
+        assert np.array_equal(u[k], g[k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("hint", DYN_HINTS)
 def test_a_flagged_chain_leaves_a_recycled_slot_and_is_replayed(hint, grid_cap):
     d, C = 128, 200
@@ -283,6 +312,35 @@ def test_lds_nuts_runs_cut_into_pieces_match_the_oracle(kind, d, n_rows, C, cap,
     assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
     assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True)
     assert (g["n_exec"] <= g["n_leap"]).all()
+
+
+@pytest.mark.parametrize("kind,d,n_rows,C,burn,keep,adapt,mass", [("logistic", 100, 16, 150, 10, 9, 10, False), ("dense", 192, 0, 100, 3, 6, 12, True), ("logistic", 300, 20, 70, 9, 8, 7, True)])
+def test_lds_nuts_with_bounds_is_cut_into_pieces_too(kind, d, n_rows, C, burn, keep, adapt, mass, grid_cap):
+    """settings.vals_bound: the hand-over carries theta in the TRANSFORMED space, as the chain holds it (through inv_transform and transform it would be rounded twice);
+    mi_chains.theta holds constrained values again at the end; a chain flagged in piece 0"""
+    tk, tkw, spec, bs = _lds_problem(kind, d, n_rows, seed=d + 2)
+    rng = np.random.default_rng(d)
+    bk = np.where(rng.random(d) < 0.4, rng.integers(2, 5, d), 1); bk[0] = 4; bk[d - 1] = 2
+    lb = np.where((bk == 2) | (bk == 4), -1.5, -np.inf); ub = np.where((bk == 3) | (bk == 4), 2.0, np.inf)
+    init = np.clip(synth.initial_states(C, d, seed=d + 4) * (0.1 if kind == "logistic" else 0.5), -1.0, 1.5)
+    init[40, 1:d - 1] *= 1e200
+    kw, okw = dict(vals_bound=1, lower_bounds=lb, upper_bounds=ub), dict(lower=lb, upper=ub)
+    if mass:
+        M = np.diag(rng.uniform(0.4, 2.5, d)); kw["precond_mat"] = M; okw["precond"] = M
+    st = mcmc_amd.default_settings(rng_seed_value=17, n_burnin_draws=burn, n_keep_draws=keep, step_size=0.05, n_adapt_draws=adapt, max_tree_depth=4, **kw)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=6, want_adapt_state=True, **tkw)
+    assert mcmc_amd.last_kernel().startswith("logit_lds_kernel<") and mcmc_amd.last_kernel().endswith("true, true>")
+    s = orc.make_settings(seed=17, n_burnin=burn, n_keep=keep, step=0.05, n_adapt=adapt, max_depth=4, W=4, hoist=1, blocks=4, block_size=bs, **okw)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=6)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    assert np.array_equal(g["theta"], o_draws[-1], equal_nan=True)
+    grid_cap(0)                                          # ... and what the call exports is what the uncut run exports
+    u_draws, u = mcmc_amd.sample("nuts", tk, init, st, chain0=6, want_adapt_state=True, **tkw)
+    assert np.array_equal(u_draws, g_draws, equal_nan=True)
+    for k in ("adapt_state", "eps", "theta", "n_leap", "n_accept", "depth"):
+        assert np.array_equal(u[k], g[k], equal_nan=True), k
 
 
 def test_lds_nuts_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values(grid_cap):

@@ -141,6 +141,28 @@ def test_dense_gaussian_tile_target_under_nuts_reproduces_the_built_in_nuts_kern
 
 
 @pytest.mark.gpu
+def test_tile_target_nuts_runs_are_cut_into_pieces_on_a_small_grid(tile_lib):
+    """more chains than the chain slots of the persistent grid (capped at one workgroup here: 64 slots) and 16+ draws: the engine cuts the runs of a user target's
+    nuts_tile_kernel into pieces that migrate between slots (mi_mcmc_run_tile_target: nuts_tile_setup_pieces); same results as the built-in kernel's uncut run"""
+    import torch
+    d, C_ = 128, 200
+    P = synth.dense_gaussian_precision(d, seed=d)
+    Pd = torch.from_numpy(P).cuda()
+    init = synth.initial_states(C_, d, seed=5)
+    st = mcmc_amd.default_settings(rng_seed_value=9, n_burnin_draws=8, n_keep_draws=9, n_adapt_draws=11, max_tree_depth=6)
+    b_draws, b = mcmc_amd.nuts(mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=P, kernel_hint=mcmc_amd.KERNEL_AUTO)
+    mcmc_amd.test_set_grid_cap(1)
+    try:
+        t_draws, t = _run_tile(tile_lib, "gauss_tile_run", 2, GaussTile(Pd.data_ptr(), d), d, init, st)
+    finally:
+        mcmc_amd.test_set_grid_cap(0)
+    assert mcmc_amd.last_kernel().startswith("nuts_tile_kernel<")
+    assert np.array_equal(t["depth"], b["depth"]) and np.array_equal(t["n_leap"], b["n_leap"])
+    assert np.array_equal(t["eps"], b["eps"]) and np.array_equal(t["n_accept"], b["n_accept"])
+    assert np.array_equal(t_draws, b_draws)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("d,C_,adapt", [(64, 40, 6), (37, 17, 0), (2, 70, 4)])
 def test_twisted_gaussian_tile_target_under_nuts_against_the_oracle_with_the_same_callback(tile_lib, d, C_, adapt):
     """a non-Gaussian d = 64 tile target under mcmc::nuts, bit for bit against the oracle driven by the same
