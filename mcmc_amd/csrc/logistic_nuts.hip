@@ -19,7 +19,7 @@ uint64_t logit_lds_nuts_workgroups(uint32_t d, uint64_t C, int target)
 size_t logit_lds_nuts_split_bytes(uint64_t C, uint32_t d)
 {
     // tails | queues | stand-ins for 3 counters, the step size and the dual-averaging state (7 C words) | the copy of the initial values
-    return 256 + lds_nuts_queue_bytes(C) + (size_t)7 * C * 8 + 256 + (size_t)d * C * 8 + 256;
+    return lds_nuts_split_bytes(C, d);
 }
 
 int logit_lds_launch_nuts(LogitParams prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st, int target)

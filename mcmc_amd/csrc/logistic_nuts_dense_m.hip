@@ -5,6 +5,7 @@
 #define MI_RNG_NOINLINE 1
 #include "logistic_lds.hpp"
 #include "launch_common.hpp"
+#include "lds_nuts_pieces.hpp"
 
 namespace mi {
 namespace {
@@ -52,6 +53,8 @@ int launch_nuts_dense_m(LogitParams& prm, const double* X_dev, const double* y_d
     prm.Xp = xp;
     hipError_t e = hipMemsetAsync(prm.nuts_next, 0, 64, st);
     if (e != hipSuccess) return (int)e;
+    double* theta_backup = nullptr;                      // more chains than chain slots: the runs are cut into pieces (lds_nuts_pieces.hpp)
+    if (int ep = lds_nuts_setup_pieces<NTQ>(prm, n_wg, st, &theta_backup)) return ep;
     hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, TARGET == LOGIT_TARGET_DENSE>), dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
     auto pack = [&](const double* rm, double* dst) {
         hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, true>), dim3(nbm), dim3(256), 0, st, rm, nullptr, prm.d, prm.d, dst);
@@ -63,7 +66,7 @@ int launch_nuts_dense_m(LogitParams& prm, const double* X_dev, const double* y_d
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);
-    return (int)hipGetLastError();
+    return lds_nuts_restore_flagged(prm, theta_backup, st);
 }
 
 }  // namespace

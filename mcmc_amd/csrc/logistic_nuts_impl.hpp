@@ -3,6 +3,7 @@
 #pragma once
 #include "logistic_lds.hpp"
 #include "launch_common.hpp"
+#include "lds_nuts_pieces.hpp"
 
 namespace mi {
 namespace {
@@ -24,19 +25,6 @@ uint64_t grid_of(uint64_t C)
     return cap_grid(need < cap ? need : cap);
 }
 
-#ifndef MI_LDS_NUTS_PIECES
-#define MI_LDS_NUTS_PIECES 4
-#endif
-constexpr uint32_t LDS_NUTS_PIECES = MI_LDS_NUTS_PIECES;
-inline size_t lds_nuts_queue_bytes(uint64_t C) { return ((size_t)(LDS_NUTS_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255; }
-// a chain that is flagged in a later piece is replayed from its INITIAL values, which its earlier pieces have overwritten in prm.theta: the launcher's copy comes back
-__global__ void lds_nuts_restore_flagged_theta_kernel(const uint32_t* __restrict__ flag, const double* __restrict__ backup, double* __restrict__ theta, uint64_t C)
-{
-    if (flag[C] == 0u) return;                           // (the "any chain flagged" word)
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c < C && flag[c] != 0u) theta[(size_t)blockIdx.y * C + c] = backup[(size_t)blockIdx.y * C + c];
-}
-
 template <int NTQ, int TARGET, bool DIAGM = false, bool BOUNDS = false>
 int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void* workspace, hipStream_t st)
 {
@@ -53,33 +41,8 @@ int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void
     prm.Xp = xp;
     hipError_t e = hipMemsetAsync(prm.nuts_next, 0, 64, st);
     if (e != hipSuccess) return (int)e;
-    // More chains than chain slots: the runs are cut into pieces, as nuts_launch.hip cuts those of nuts_gauss_memo_kernel (the reasoning is there; the protocol
-    // in nuts_lds.hpp).  With bounds the hand-over carries theta in the transformed space (nuts_lds.hpp).  Pieces of two draws
-    // and more: a hand-over costs one evaluation, a draw here tens of them
-    prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
-    double* theta_backup = nullptr;
-    if constexpr (NTQ > 1) {                  // (NTQ = 1, d <= 64: measured 2 % SLOWER cut -- 65 536 chains of d = 20: 56.1 -> 57.1 ms; the wider tiles gain 4-9 %)
-        const uint32_t n_total = prm.n_burnin + prm.n_keep;
-        if (prm.split_ws != nullptr && prm.nf_flag != nullptr && prm.C > (uint64_t)n_wg * 32u && n_total >= 2u * LDS_NUTS_PIECES && prm.C < (1ull << 28)) {
-            prm.piece_len = (n_total + LDS_NUTS_PIECES - 1u) / LDS_NUTS_PIECES;
-            prm.n_pieces = (n_total + prm.piece_len - 1u) / prm.piece_len;
-            char* b = static_cast<char*>(prm.split_ws);
-            prm.piece_tail = reinterpret_cast<uint32_t*>(b);
-            prm.piece_q = reinterpret_cast<uint32_t*>(b + 256);
-            const size_t q_bytes = lds_nuts_queue_bytes(prm.C);
-            if ((e = hipMemsetAsync(prm.piece_tail, 0, 256, st)) != hipSuccess) return (int)e;
-            if ((e = hipMemsetAsync(prm.piece_q, 0xff, q_bytes, st)) != hipSuccess) return (int)e;
-            uint64_t* u = reinterpret_cast<uint64_t*>(b + 256 + q_bytes);       // stand-ins for what the hand-over goes through
-            if (!prm.n_accept) prm.n_accept = u;
-            if (!prm.n_leap_out) prm.n_leap_out = u + prm.C;
-            if (!prm.n_exec_out) prm.n_exec_out = u + 2 * prm.C;
-            double* dd = reinterpret_cast<double*>(u + 3 * prm.C);
-            if (!prm.step_out) prm.step_out = dd;
-            if (!prm.adapt_state) prm.adapt_state = dd + prm.C;
-            theta_backup = dd + 4 * prm.C + 32;
-            if ((e = hipMemcpyAsync(theta_backup, prm.theta, (size_t)prm.d * prm.C * sizeof(double), hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
-        }
-    }
+    double* theta_backup = nullptr;                      // more chains than chain slots: the runs are cut into pieces (lds_nuts_pieces.hpp)
+    if (int ep = lds_nuts_setup_pieces<NTQ>(prm, n_wg, st, &theta_backup)) return ep;
     hipLaunchKernelGGL((pack_logit_lds_kernel<NTQ, TARGET == LOGIT_TARGET_DENSE>), dim3(prm.NB), dim3(256), 0, st, X_dev, y_dev, prm.d, prm.n_rows, xp);
     auto kern = logit_lds_kernel<NTQ, LOGIT_NUTS, TARGET, DIAGM, BOUNDS>;
     if (BOUNDS) note_kernel("logit_lds_kernel<%d, nuts, %d, true, true>", NTQ, TARGET);
@@ -88,9 +51,7 @@ int launch_nuts(LogitParams& prm, const double* X_dev, const double* y_dev, void
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), G::LDS_BYTES, st, prm);
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    if (theta_backup != nullptr)
-        hipLaunchKernelGGL(lds_nuts_restore_flagged_theta_kernel, dim3((unsigned)((prm.C + 255) / 256), prm.d), dim3(256), 0, st, prm.nf_flag, theta_backup, prm.theta, prm.C);
-    return (int)hipGetLastError();
+    return lds_nuts_restore_flagged(prm, theta_backup, st);
 }
 
 template <bool DIAGM, bool BOUNDS>

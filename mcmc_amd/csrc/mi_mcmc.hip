@@ -2244,9 +2244,9 @@ int run_lds_nuts(const mi_target* target, const mi_settings* settings, mi_chains
     rp.n_wg = (unsigned)std::min<uint64_t>(C, 512u);
     const size_t flag_bytes = ((C + 1) * sizeof(uint32_t) + 255) & ~(size_t)255;
     rp.total_bytes = rp.own_bytes + flag_bytes + (rp.t_doubles + (size_t)rp.n_wg * rp.stride) * sizeof(double);
-    // more chains than chain slots, no dense precond_mat: the launcher cuts the runs into pieces (logistic_nuts_impl.hpp) and needs room for the queues
+    // more chains than chain slots: the launcher cuts the runs into pieces (lds_nuts_pieces.hpp) and needs room for the queues
     const size_t rp_bytes = (rp.total_bytes + 255) & ~(size_t)255;
-    const size_t split_bytes = (!dense_m && C > n_slots) ? mi::logit_lds_nuts_split_bytes(C, q.d) : 0;
+    const size_t split_bytes = (C > n_slots) ? mi::logit_lds_nuts_split_bytes(C, q.d) : 0;
     WsLease base;
     rc = ws_get(st, rp_bytes + split_bytes, base);
     if (rc) return rc;

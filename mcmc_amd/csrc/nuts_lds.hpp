@@ -170,9 +170,9 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
     // item v < C is piece 0 of chain v, item v >= C the ticket for entry v - C of the piece queues prm.piece_q [n_pieces - 1][C], where chains are published in
     // the order in which their previous piece ended; a later piece continues its chain exactly as a continuation call does.  What crosses between slots inside
     // the launch is written / read at agent scope (lds_nuts::coh_st / coh_ld).  With bounds the hand-over carries theta in the TRANSFORMED space, as the chain holds it
-    // (through inv_transform and transform it would be rounded twice): prm.theta holds constrained values again when a chain's last piece has ended.  Never with a dense precond_mat.
+    // (through inv_transform and transform it would be rounded twice): prm.theta holds constrained values again when a chain's last piece has ended.
     uint32_t n_pieces = 1u, piece_len = 0xffffffffu;
-    if constexpr (!DENSEM) { if (prm.n_pieces > 1u) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; } }
+    if (prm.n_pieces > 1u) { n_pieces = prm.n_pieces; piece_len = prm.piece_len; }
     const bool pieces = n_pieces > 1u;
     const uint64_t n_items = C * (uint64_t)n_pieces;
     bool piece_done = false;     // this chain's piece ended with the draw it just finished

@@ -343,6 +343,32 @@ def test_lds_nuts_with_bounds_is_cut_into_pieces_too(kind, d, n_rows, C, burn, k
         assert np.array_equal(u[k], g[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("kind,d,n_rows,C,burn,keep,adapt", [("logistic", 100, 16, 100, 6, 6, 8), ("dense", 160, 0, 100, 10, 9, 10), ("dense", 512, 0, 70, 3, 6, 12)])
+def test_lds_nuts_with_a_dense_precond_mat_is_cut_into_pieces_too(kind, d, n_rows, C, burn, keep, adapt, grid_cap):
+    """logit_lds_kernel<., nuts, ., false, false, true> (logistic_nuts_dense_m.hip): the same cut; two chains leave the finite regime at once (PQ_GONE in every later queue, replayed with the same matrices)"""
+    tk, tkw, spec, bs = _lds_problem(kind, d, n_rows, seed=d)
+    rng = np.random.default_rng(d + 11)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    M = A @ A.T + np.diag(rng.uniform(0.4, 2.5, d))
+    init = synth.initial_states(C, d, seed=d + 1) * (0.1 if kind == "logistic" else 0.5)
+    init[5] *= 1e200; init[49, 3] = np.inf
+    eps = 0.05 if kind == "logistic" else 0.1
+    st = mcmc_amd.default_settings(rng_seed_value=7, n_burnin_draws=burn, n_keep_draws=keep, n_adapt_draws=adapt, max_tree_depth=4, step_size=eps, precond_mat=M)
+    grid_cap(1)
+    g_draws, g = mcmc_amd.sample("nuts", tk, init, st, chain0=3, want_adapt_state=True, **tkw)
+    kern = mcmc_amd.last_kernel()
+    assert kern.startswith("logit_lds_kernel<") and kern.endswith("false, false, true>"), kern
+    s = orc.make_settings(seed=7, n_burnin=burn, n_keep=keep, n_adapt=adapt, max_depth=4, step=eps, W=4, hoist=1, precond=M, blocks=4, block_size=bs)
+    o_draws, o = orc.run_many(orc.ALGO_NUTS, spec, init, s, chain0=3)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
+    grid_cap(0)                                          # ... and what the call exports is what the uncut run exports
+    u_draws, u = mcmc_amd.sample("nuts", tk, init, st, chain0=3, want_adapt_state=True, **tkw)
+    assert np.array_equal(u_draws, g_draws, equal_nan=True)
+    for k in ("adapt_state", "eps", "theta", "n_leap", "n_accept", "depth"):
+        assert np.array_equal(u[k], g[k], equal_nan=True), k
+
+
 def test_lds_nuts_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values(grid_cap):
     """as test_a_chain_flagged_in_a_later_piece_is_replayed_from_its_initial_values, on the dense Gaussian of nuts_lds.hpp"""
     d, C = 160, 100
