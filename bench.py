@@ -309,7 +309,7 @@ def extra_nuts_on_logistic(ctx):
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS,
                          "flop_per_unit": 4 * n_rows},
             "note": "whole run incl. every chain's first evaluation and step-size search and the literal replay launch; chains are handed to the "
-                    "8 192 chain slots of the persistent grid dynamically, see DESIGN.md section 4.14; value = executed leapfrogs (one per distinct point of a "
+                    "8 192 chain slots of the persistent grid dynamically, their runs cut into pieces, see DESIGN.md section 4.14; value = executed leapfrogs (one per distinct point of a "
                     "doubling's trajectory), reference_equivalent_value = the leapfrogs mcmc::nuts executes for these draws / the same seconds"}
 
 
