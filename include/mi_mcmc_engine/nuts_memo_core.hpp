@@ -174,6 +174,18 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
 #pragma unroll
         for (int k = 0; k < N; k += 2) *reinterpret_cast<double2*>(wsp(v, s0 + k)) = double2{src[k], src[k + 1]};
     };
+#ifndef MI_MEMO_NT
+#define MI_MEMO_NT 1             // 1: the gradient row of a point's record -- read again only if the point becomes an origin -- is stored NON-TEMPORAL, so that the L2 keeps more of
+                                 // the theta / p rows the next ticks' U-turn tests read (65 536 chains: an XCD's 2 048 chains store 4 MB of theta / p per tick, the size of its L2).
+                                 // Measured on configs[3], same box, alternating (profiles/r6_nuts_nt_ab.log): 0 (plain stores) 478.7 / 477.1 / 476.6 / 485.1 ms against 1: 474.7 /
+                                 // 472.5 / 472.4 / 480.1 (-1.0 %); 2 (all three rows non-temporal): +0.3 %; 3 (1 + the loads of the higher-level tests non-temporal): +3 %; 8 192 chains: no change
+#endif
+    [[maybe_unused]] auto st_row_nt = [&](int v, int s0, const auto& src) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(src) / sizeof(double));
+        typedef double d2v_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < N; k += 2) { d2v_ t = {src[k], src[k + 1]}; __builtin_nontemporal_store(t, reinterpret_cast<d2v_*>(wsp(v, s0 + k))); }
+    };
     auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
         *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
     };
@@ -193,6 +205,15 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
 #pragma unroll
         for (int q = 0; q < N; q += 2) {
             const double2 t = *reinterpret_cast<const double2*>(lp + (size_t)(q >> 1) * 64u);
+            dst[q] = t.x; dst[q + 1] = t.y;
+        }
+    };
+    [[maybe_unused]] auto ld_ptr_nt = [&](const char* lp, auto& dst) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(dst) / sizeof(double));
+        typedef double d2v_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < N; q += 2) {
+            const d2v_ t = __builtin_nontemporal_load(reinterpret_cast<const d2v_*>(lp + (size_t)(q >> 1) * 64u));
             dst[q] = t.x; dst[q + 1] = t.y;
         }
     };
@@ -757,7 +778,11 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
                 if (!first) {
                     int vq, vqp; bool pmom;
                     test_vecs(l, vq, vqp, pmom);
+#if MI_MEMO_NT == 3
+                    if (t) { ld_ptr_nt(ws_lane_ptr(vq), dd); if constexpr (POL::PRE_MOM) ld_ptr_nt(pmom ? mom_lane_ptr(draw) : ws_lane_ptr(vqp), Lp); else ld_ptr_nt(ws_lane_ptr(vqp), Lp); }
+#else
                     if (t) { ld_row(vq, 0, dd); ld_test_p(vqp, pmom, Lp); }
+#endif
                 }
                 first = false;
                 // (two passes: d . p(n1) with theta, d, p(n1) as operands, then d . p(mpt) with d, p -- four vectors as VALU operands of one loop
@@ -1015,7 +1040,13 @@ __device__ __forceinline__ void nuts_memo_run(const PRM& prm, POL& pol, char* co
             if (__ballot(rec) != 0ull) {
                 if (rec) {
                     const int vr = MV_PT0 + 3 * ((int)mpt - 1);
+#if MI_MEMO_NT == 1 || MI_MEMO_NT == 3
+                    st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row_nt(vr + 2, 0, w);
+#elif MI_MEMO_NT == 2
+                    st_row_nt(vr, 0, th); st_row_nt(vr + 1, 0, pm); st_row_nt(vr + 2, 0, w);
+#else
                     st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
+#endif
                     *scp(mpt) = double2{ca_pt, pU};
                     if (st_edge) {               // (a chain whose doubling ended in this tick stored it there, if the draw goes on)
                         st_row((vdir > 0) ? MV_TPOS_T : MV_TNEG_T, 0, th); st_row((vdir > 0) ? MV_TPOS_P : MV_TNEG_P, 0, pm);

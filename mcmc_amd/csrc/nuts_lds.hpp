@@ -235,6 +235,16 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
 #pragma unroll
         for (int k = 0; k < N; k += 2) *reinterpret_cast<double2*>(wsp(v, s0 + k)) = double2{src[k], src[k + 1]};
     };
+#ifndef MI_LDS_NUTS_NT
+#define MI_LDS_NUTS_NT 0         // (timing experiment, as MI_MEMO_NT of nuts_memo_core.hpp) the gradient row (1) / every row (2) of a point's record stored non-temporal: measured, nothing
+                                 // on this kernel (profiles/r6_nuts_lds_nt_ab.log: the streamed evaluation is two thirds of its tick)
+#endif
+    [[maybe_unused]] auto st_row_nt = [&](int v, int s0, const auto& src) __attribute__((always_inline)) {
+        constexpr int N = (int)(sizeof(src) / sizeof(double));
+        typedef double d2v_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < N; k += 2) { d2v_ t = {src[k], src[k + 1]}; __builtin_nontemporal_store(t, reinterpret_cast<d2v_*>(wsp(v, s0 + k))); }
+    };
     auto st_pair = [&](int v, int s0, double a, double b) __attribute__((always_inline)) {
         *reinterpret_cast<double2*>(wsp(v, s0)) = double2{a, b};
     };
@@ -781,7 +791,13 @@ __device__ __forceinline__ void nuts_lds_body(const LogitParams& prm, Eval& eval
                 pt_alpha(mpt) = ca_pt; pt_U(mpt) = pU;
                 n_exec++;
                 const int vr = V_PT0 + 3 * ((int)mpt - 1);
+#if MI_LDS_NUTS_NT == 1
+                st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row_nt(vr + 2, 0, w);
+#elif MI_LDS_NUTS_NT == 2
+                st_row_nt(vr, 0, th); st_row_nt(vr + 1, 0, pm); st_row_nt(vr + 2, 0, w);
+#else
                 st_row(vr, 0, th); st_row(vr + 1, 0, pm); st_row(vr + 2, 0, w);
+#endif
                 npts = mpt;
             }
             const bool st_edge = run && (mpt == 1u + jd);
