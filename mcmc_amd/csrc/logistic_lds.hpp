@@ -582,6 +582,17 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
 
     constexpr int SB0 = (MI_LOGIT_BATCH == 0) ? 2 : ((NSQ < MI_LOGIT_BATCH) ? NSQ : MI_LOGIT_BATCH);
     constexpr int SB = (NSQ % SB0 == 0) ? SB0 : 4;      // slices per batch of workspace loads (NTQ = 3: NSQ = 12)
+#ifndef MI_LOGIT_NT_DRAWS
+#define MI_LOGIT_NT_DRAWS 0      // (timing experiment) 1: kept rows -- never read again by the kernel -- stored non-temporal, so that they do not push the streamed matrix out of the L2:
+                                 // measured on configs[2], nothing (profiles/r6_mala_nt_ab.log: 2 146 against 2 146 ms)
+#endif
+    auto put_row = [&](double* p_, double v_) __attribute__((always_inline)) {
+#if MI_LOGIT_NT_DRAWS
+        __builtin_nontemporal_store(v_, p_);
+#else
+        *p_ = v_;
+#endif
+    };
     auto keep_draw = [&](uint32_t draw, bool accept) __attribute__((always_inline)) {
         if (draw >= prm.n_burnin) {
             n_acc += accept ? 1u : 0u;
@@ -598,7 +609,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
                             const uint32_t dim = dim_of(s0 + i);
                             double v = accept ? bp[s0 + i] : old[i];
                             if constexpr (BOUNDS) v = box.leave(v, s0 + i);      // rows are reported in the constrained space (hmc.cpp:211-218)
-                            if (live && dim < d) out[(size_t)dim * C] = v;
+                            if (live && dim < d) put_row(out + (size_t)dim * C, v);
                         }
                     }
                 } else {
@@ -607,7 +618,7 @@ __global__ MI_NO_DS_MERGE __launch_bounds__(512, (logit_waves_per_simd<NTQ, ALGO
                         const uint32_t dim = dim_of(s);
                         double v = bp[s];
                         if constexpr (BOUNDS) v = box.leave(v, s);
-                        if (live && dim < d) out[(size_t)dim * C] = v;
+                        if (live && dim < d) put_row(out + (size_t)dim * C, v);
                     }
                 }
             }
