@@ -32,19 +32,20 @@ def sweep(n_cases=40, seed=1, verbose=True, cap=0):
         init = synth.initial_states(C, d, seed=int(rng.integers(1, 1000)))
         if cap and rng.random() < 0.3:
             for c in rng.choice(C, size=3, replace=False): init[c] *= float(rng.choice([1e150, 1e300, np.inf]))
+        M = np.diag(rng.uniform(0.3, 3.0, d)) if rng.random() < 0.3 else None        # a diagonal precond_mat: nuts_gauss_memo_kernel<., true, .>
         st = mcmc_amd.default_settings(rng_seed_value=int(rng.integers(1, 10**6)), n_burnin_draws=burn, n_keep_draws=keep,
-                                       n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0)
+                                       n_adapt_draws=adapt, max_tree_depth=max_depth, step_size=eps0, **(dict(precond_mat=M) if M is not None else {}))
         chain0 = int(rng.integers(0, 5000))
         # AUTO / MEMO: the memoised kernel; REG: a retired kernel's hint (ignored); TICK_LOCAL: the independent tick-local kernel
         hint = int(rng.choice([mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_AUTO, mcmc_amd.KERNEL_NUTS_REG, mcmc_amd.KERNEL_NUTS_TICK_LOCAL, mcmc_amd.KERNEL_NUTS_MEMO_INTICK]))
         g_draws, g = mcmc_amd.nuts(kg, init, st, prec=prec, chain0=chain0, kernel_hint=hint)
-        o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0)
+        o_draws, o = _oracle(ko, d, init, st, prec=prec, chain0=chain0, **(dict(precond=M) if M is not None else {}))
         bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
         same = lambda a, b: np.array_equal(bits(a), bits(b)) or np.array_equal(a, b, equal_nan=True)     # (NaN payloads may differ)
         ok = (same(g_draws, o_draws) and np.array_equal(g["depth"], o["depth"]) and np.array_equal(g["n_leap"], o["n_leap"])
               and np.array_equal(g["n_accept"], o["n_accept"]) and same(g["eps"], o["eps"]))
         if verbose or not ok:
-            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, C=C, burn=burn, keep=keep, adapt=adapt, max_depth=max_depth, eps0=eps0, chain0=chain0, hint=hint, kernel=mcmc_amd.last_kernel()), flush=True)
+            print(("ok  " if ok else "FAIL"), dict(kind=kind, d=d, C=C, burn=burn, keep=keep, adapt=adapt, max_depth=max_depth, eps0=eps0, chain0=chain0, hint=hint, diag_m=M is not None, kernel=mcmc_amd.last_kernel()), flush=True)
         fails += 0 if ok else 1
     return fails
 

@@ -9,7 +9,7 @@ from mcmc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(kind_orc, d, init, st, prec=None, chain0=0):
+def _oracle(kind_orc, d, init, st, prec=None, chain0=0, precond=None):
     C = init.shape[0]
     n_tot = int(st.n_burnin_draws + st.n_keep_draws)
     draws = np.zeros((int(st.n_keep_draws), d, C))
@@ -21,7 +21,7 @@ def _oracle(kind_orc, d, init, st, prec=None, chain0=0):
                               n_keep=int(st.n_keep_draws), step=float(st.step_size),
                               n_adapt=int(st.n_adapt_draws), delta=float(st.target_accept_rate),
                               max_depth=int(st.max_tree_depth), gamma=float(st.gamma_val),
-                              t0=float(st.t0_val), kappa=float(st.kappa_val), W=4, chain_id=chain0 + c)
+                              t0=float(st.t0_val), kappa=float(st.kappa_val), W=4, chain_id=chain0 + c, precond=precond)
         dr, info = orc.run_chain(orc.ALGO_NUTS, t, init[c], s, traces=True)
         draws[:, :, c] = dr
         out["n_accept"][c] = info["n_accept"]

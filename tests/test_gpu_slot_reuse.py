@@ -86,6 +86,28 @@ def test_recycled_slots_of_the_bounded_tick_on_the_tile_policy(grid_cap):
     assert (g["n_exec"] <= g["n_leap"]).all()
 
 
+@pytest.mark.parametrize("d,C,cap", [(128, 200, 1), (48, 330, 2)])
+def test_runs_with_a_diagonal_precond_mat_are_cut_into_pieces_too(d, C, cap, grid_cap):
+    """nuts_gauss_memo_kernel<., true, false> (momenta generated in the tick; d = 128: the level-loop walk): 19 draws in pieces of 5, a chain started non-finite (flagged,
+    replayed by the general variant with the same tables); against the oracle and against the uncut run"""
+    prec = synth.dense_gaussian_precision(d, seed=6)
+    init = synth.initial_states(C, d, seed=5)
+    init[77] *= 1e200
+    M = np.diag(np.linspace(0.5, 2.0, d))
+    st = mcmc_amd.default_settings(rng_seed_value=3, n_burnin_draws=10, n_keep_draws=9, n_adapt_draws=12, max_tree_depth=6, precond_mat=M)
+    grid_cap(cap)
+    g_draws, g = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=7, want_adapt_state=True)
+    assert mcmc_amd.last_kernel().startswith("nuts_gauss_memo_kernel") and ", true," in mcmc_amd.last_kernel()
+    o_draws, o = _oracle(d, init, st, prec, 7, precond=M)
+    assert np.array_equal(g["n_leap"], o["n_leap"]) and np.array_equal(g["n_accept"], o["n_accept"])
+    assert np.array_equal(g["eps"], o["eps"], equal_nan=True) and np.array_equal(g_draws, o_draws, equal_nan=True)
+    grid_cap(0)
+    u_draws, u = mcmc_amd.sample("nuts", mcmc_amd.TARGET_GAUSS_DENSE, init, st, prec=prec, chain0=7, want_adapt_state=True)
+    assert np.array_equal(u_draws, g_draws, equal_nan=True)
+    for k in ("adapt_state", "eps", "theta", "n_leap", "n_exec", "n_accept", "depth"):
+        assert np.array_equal(u[k], g[k], equal_nan=True), k
+
+
 @pytest.mark.parametrize("mass", [False, True])
 def test_the_bounded_tick_on_the_tile_policy_is_cut_into_pieces_too(mass, grid_cap):
     """more chains than chain slots and 16+ draws: the runs of nuts with vals_bound are cut into pieces as the plain kernel's are (nuts_bounded_launch.hip:
