@@ -25,7 +25,7 @@ namespace mi {
 constexpr uint32_t MEMO_PIECES = MI_MEMO_PIECES;
 inline size_t memo_queue_bytes(uint64_t C) { return ((size_t)(MEMO_PIECES - 1u) * C * sizeof(uint32_t) + 255) & ~(size_t)255; }
 inline size_t memo_split_bytes(uint64_t C, uint32_t d) { return 256 + memo_queue_bytes(C) + (size_t)7 * C * 8 + 256 + (size_t)d * C * 8 + 256; }
-// PRM: NutsParams or TileParams.  Cuts when there are more chains than chain slots and 16+ draws; then also makes sure n_accept, n_leap, n_exec, step_out and
+// PRM: NutsParams or TileParams.  Cuts when there are more chains than chain slots and the pieces hold two draws or more (a hand-over costs one tick, a draw tens of them); then also makes sure n_accept, n_leap, n_exec, step_out and
 // adapt_state exist (the hand-over goes through them).  *backup: where the launcher may keep a copy of prm.theta (chains flagged after their first piece are
 // replayed from their INITIAL values), or nullptr when the runs are not cut
 template <class PRM>
@@ -34,7 +34,7 @@ int memo_setup_pieces(PRM& prm, void* split_ws, uint64_t n_slots, hipStream_t st
     prm.n_pieces = 1; prm.piece_len = 0; prm.piece_q = nullptr; prm.piece_tail = nullptr;
     *backup = nullptr;
     const uint32_t n_total = prm.n_burnin + prm.n_keep;
-    if (split_ws == nullptr || prm.next_chain == nullptr || prm.C <= n_slots || n_total < 4u * MEMO_PIECES || prm.C >= (1ull << 28)) return 0;
+    if (split_ws == nullptr || prm.next_chain == nullptr || prm.C <= n_slots || n_total < 2u * MEMO_PIECES || prm.C >= (1ull << 28)) return 0;
     prm.piece_len = (n_total + MEMO_PIECES - 1u) / MEMO_PIECES;
     prm.n_pieces = (n_total + prm.piece_len - 1u) / prm.piece_len;
     char* b = static_cast<char*>(split_ws);

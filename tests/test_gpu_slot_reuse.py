@@ -110,7 +110,7 @@ def test_runs_with_a_diagonal_precond_mat_are_cut_into_pieces_too(d, C, cap, gri
 
 @pytest.mark.parametrize("mass", [False, True])
 def test_the_bounded_tick_on_the_tile_policy_is_cut_into_pieces_too(mass, grid_cap):
-    """more chains than chain slots and 16+ draws: the runs of nuts with vals_bound are cut into pieces as the plain kernel's are (nuts_bounded_launch.hip:
+    """more chains than chain slots and 8+ draws: the runs of nuts with vals_bound are cut into pieces as the plain kernel's are (nuts_bounded_launch.hip:
     memo_setup_pieces); the hand-over carries theta in the TRANSFORMED space.  Against the oracle, and the cut run exports what the uncut run exports."""
     d, C = 100, 230
     prec = synth.dense_gaussian_precision(d, seed=6)
@@ -196,7 +196,7 @@ def test_lds_nuts_on_recycled_slots_matches_the_oracle(kind, d, n_rows, C, grid_
     assert np.array_equal(g_draws, o_draws, equal_nan=True) and np.array_equal(g["eps"], o["eps"], equal_nan=True)
 
 
-# ---- round 6: runs cut into PIECES (nuts_launch.hip: MI_MEMO_PIECES work items per chain when there are more chains than chain slots and 16+ draws; a piece that is
+# ---- round 6: runs cut into PIECES (nuts_launch.hip: MI_MEMO_PIECES work items per chain when there are more chains than chain slots and 8+ draws; a piece that is
 # not the first continues its chain in whatever slot is free, exactly as a continuation call does -- nuts_memo_core.hpp, SPLIT).  Same draws, counts and step
 # sizes as the oracle's uninterrupted chains: piece boundaries inside the adaptation window, at its end and in the kept draws; draw counts that are no multiple of
 # the piece length; chains that go non-finite in their first and in a later piece (PQ_GONE in every later queue); a run that is itself a continuation.

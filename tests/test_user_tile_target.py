@@ -142,7 +142,7 @@ def test_dense_gaussian_tile_target_under_nuts_reproduces_the_built_in_nuts_kern
 
 @pytest.mark.gpu
 def test_tile_target_nuts_runs_are_cut_into_pieces_on_a_small_grid(tile_lib):
-    """more chains than the chain slots of the persistent grid (capped at one workgroup here: 64 slots) and 16+ draws: the engine cuts the runs of a user target's
+    """more chains than the chain slots of the persistent grid (capped at one workgroup here: 64 slots) and 8+ draws: the engine cuts the runs of a user target's
     nuts_tile_kernel into pieces that migrate between slots (mi_mcmc_run_tile_target: nuts_tile_setup_pieces); same results as the built-in kernel's uncut run"""
     import torch
     d, C_ = 128, 200
